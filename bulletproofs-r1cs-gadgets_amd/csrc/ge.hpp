@@ -1,0 +1,194 @@
+// ristretto255 group arithmetic on the Edwards form of Curve25519 (a = -1)
+// for gfx950.  Extended coordinates (X:Y:Z:T); precomputed operands in
+// "Niels" forms so that a fixed-base table addition costs 7 field
+// multiplications (affine Niels) and a variable-base addition 8.
+//
+// Replaces curve25519-dalek's EdwardsPoint / RistrettoPoint /
+// CompressedRistretto on the hot path.
+// Encoding / decoding / map-to-group follow RFC 9496 §4.3.
+#pragma once
+#include "fe.hpp"
+
+struct ge {          // extended
+    fe X, Y, Z, T;
+};
+struct ge_niels {    // affine Niels: (y+x, y-x, 2dxy), Z = 1
+    fe yplusx, yminusx, xy2d;
+};
+struct ge_cached {   // projective Niels: (Y+X, Y-X, Z, 2dT)
+    fe YplusX, YminusX, Z, T2d;
+};
+
+HD inline ge ge_identity() {
+    ge r;
+    r.X = fe_zero(); r.Y = fe_one(); r.Z = fe_one(); r.T = fe_zero();
+    return r;
+}
+HD inline ge_niels ge_niels_identity() {
+    ge_niels r;
+    r.yplusx = fe_one(); r.yminusx = fe_one(); r.xy2d = fe_zero();
+    return r;
+}
+HD inline ge ge_neg(const ge& p) {
+    ge r;
+    r.X = fe_neg(p.X); r.Y = p.Y; r.Z = p.Z; r.T = fe_neg(p.T);
+    return r;
+}
+HD inline ge_cached ge_to_cached(const ge& p) {
+    ge_cached r;
+    r.YplusX = fe_add(p.Y, p.X);
+    r.YminusX = fe_sub(p.Y, p.X);
+    r.Z = p.Z;
+    r.T2d = fe_mul(p.T, fe_const(FE_2D_L));
+    return r;
+}
+
+// p + q  (q cached): 8M
+HD inline ge ge_add(const ge& p, const ge_cached& q) {
+    fe PP = fe_mul(fe_add(p.Y, p.X), q.YplusX);
+    fe MM = fe_mul(fe_sub(p.Y, p.X), q.YminusX);
+    fe TT2d = fe_mul(p.T, q.T2d);
+    fe ZZ = fe_mul(p.Z, q.Z);
+    fe ZZ2 = fe_add(ZZ, ZZ);
+    fe cX = fe_sub(PP, MM), cY = fe_add(PP, MM), cZ = fe_add(ZZ2, TT2d), cT = fe_sub(ZZ2, TT2d);
+    ge r;
+    r.X = fe_mul(cX, cT); r.Y = fe_mul(cY, cZ); r.Z = fe_mul(cZ, cT); r.T = fe_mul(cX, cY);
+    return r;
+}
+// p - q
+HD inline ge ge_sub(const ge& p, const ge_cached& q) {
+    fe PM = fe_mul(fe_add(p.Y, p.X), q.YminusX);
+    fe MP = fe_mul(fe_sub(p.Y, p.X), q.YplusX);
+    fe TT2d = fe_mul(p.T, q.T2d);
+    fe ZZ = fe_mul(p.Z, q.Z);
+    fe ZZ2 = fe_add(ZZ, ZZ);
+    fe cX = fe_sub(PM, MP), cY = fe_add(PM, MP), cZ = fe_sub(ZZ2, TT2d), cT = fe_add(ZZ2, TT2d);
+    ge r;
+    r.X = fe_mul(cX, cT); r.Y = fe_mul(cY, cZ); r.Z = fe_mul(cZ, cT); r.T = fe_mul(cX, cY);
+    return r;
+}
+// p + q (q affine Niels): 7M.  `negate` selects p - q without branching.
+HD inline ge ge_madd(const ge& p, const ge_niels& q, int negate) {
+    fe a = fe_select(q.yplusx, q.yminusx, negate);
+    fe b = fe_select(q.yminusx, q.yplusx, negate);
+    fe PP = fe_mul(fe_add(p.Y, p.X), a);
+    fe MM = fe_mul(fe_sub(p.Y, p.X), b);
+    fe Txy2d = fe_mul(p.T, q.xy2d);
+    fe ZZ2 = fe_add(p.Z, p.Z);
+    fe cX = fe_sub(PP, MM), cY = fe_add(PP, MM);
+    fe zp = fe_add(ZZ2, Txy2d), zm = fe_sub(ZZ2, Txy2d);
+    fe cZ = fe_select(zp, zm, negate), cT = fe_select(zm, zp, negate);
+    ge r;
+    r.X = fe_mul(cX, cT); r.Y = fe_mul(cY, cZ); r.Z = fe_mul(cZ, cT); r.T = fe_mul(cX, cY);
+    return r;
+}
+// 2p: 4S + 4M
+HD inline ge ge_dbl(const ge& p) {
+    fe XX = fe_sq(p.X), YY = fe_sq(p.Y), ZZ = fe_sq(p.Z);
+    fe ZZ2 = fe_add(ZZ, ZZ);
+    fe XpY2 = fe_sq(fe_add(p.X, p.Y));
+    fe YYpXX = fe_add(YY, XX), YYmXX = fe_sub(YY, XX);
+    fe cX = fe_sub(XpY2, YYpXX), cY = YYpXX, cZ = YYmXX, cT = fe_sub(ZZ2, YYmXX);
+    ge r;
+    r.X = fe_mul(cX, cT); r.Y = fe_mul(cY, cZ); r.Z = fe_mul(cZ, cT); r.T = fe_mul(cX, cY);
+    return r;
+}
+HD inline ge ge_add_ge(const ge& p, const ge& q) { return ge_add(p, ge_to_cached(q)); }
+
+// extended -> affine Niels (one inversion)
+HD inline ge_niels ge_to_niels(const ge& p) {
+    fe zi = fe_invert(p.Z);
+    fe x = fe_mul(p.X, zi), y = fe_mul(p.Y, zi);
+    ge_niels r;
+    r.yplusx = fe_add(y, x);
+    r.yminusx = fe_sub(y, x);
+    r.xy2d = fe_mul(fe_mul(x, y), fe_const(FE_2D_L));
+    return r;
+}
+
+// RFC 9496 §4.3.2 Encode  (== RistrettoPoint::compress)
+HD inline void ge_compress(const ge& p, uint8_t out[32]) {
+    fe u1 = fe_mul(fe_add(p.Z, p.Y), fe_sub(p.Z, p.Y));
+    fe u2 = fe_mul(p.X, p.Y);
+    fe invsqrt;
+    fe_sqrt_ratio_m1(fe_one(), fe_mul(u1, fe_sq(u2)), invsqrt);
+    fe den1 = fe_mul(invsqrt, u1), den2 = fe_mul(invsqrt, u2);
+    fe z_inv = fe_mul(fe_mul(den1, den2), p.T);
+    fe i = fe_const(FE_SQRT_M1_L);
+    fe ix0 = fe_mul(p.X, i), iy0 = fe_mul(p.Y, i);
+    fe ench = fe_mul(den1, fe_const(FE_INVSQRT_A_MINUS_D_L));
+    int rotate = fe_is_negative(fe_mul(p.T, z_inv));
+    fe x = fe_select(p.X, iy0, rotate);
+    fe y = fe_select(p.Y, ix0, rotate);
+    fe den_inv = fe_select(den2, ench, rotate);
+    y = fe_select(y, fe_neg(y), fe_is_negative(fe_mul(x, z_inv)));
+    fe s = fe_abs(fe_mul(den_inv, fe_sub(p.Z, y)));
+    fe_tobytes(s, out);
+}
+
+// RFC 9496 §4.3.1 Decode (== CompressedRistretto::decompress); returns 0 on failure
+HD inline int ge_decompress(const uint8_t in[32], ge& out) {
+    fe s = fe_frombytes(in);
+    uint8_t chk[32];
+    fe_tobytes(s, chk);
+    int canonical = 1;
+    for (int k = 0; k < 32; k++) canonical &= (chk[k] == in[k]);
+    if (!canonical || (in[0] & 1)) return 0;
+    fe ss = fe_sq(s);
+    fe u1 = fe_sub(fe_one(), ss), u2 = fe_add(fe_one(), ss);
+    fe u2s = fe_sq(u2);
+    fe v = fe_sub(fe_neg(fe_mul(fe_const(FE_D_L), fe_sq(u1))), u2s);
+    fe invsqrt;
+    int was_square = fe_sqrt_ratio_m1(fe_one(), fe_mul(v, u2s), invsqrt);
+    fe den_x = fe_mul(invsqrt, u2);
+    fe den_y = fe_mul(fe_mul(invsqrt, den_x), v);
+    fe x = fe_abs(fe_mul(fe_add(s, s), den_x));
+    fe y = fe_mul(u1, den_y);
+    fe t = fe_mul(x, y);
+    if (!was_square || fe_is_negative(t) || fe_is_zero(y)) return 0;
+    out.X = x; out.Y = y; out.Z = fe_one(); out.T = t;
+    return 1;
+}
+
+// RFC 9496 §4.3.4 MAP (Elligator)
+HD inline ge ge_elligator(const fe& r0) {
+    fe i = fe_const(FE_SQRT_M1_L), d = fe_const(FE_D_L), one = fe_one();
+    fe r = fe_mul(i, fe_sq(r0));
+    fe u = fe_mul(fe_add(r, one), fe_const(FE_ONE_MINUS_D_SQ_L));
+    fe c = fe_neg(one);
+    fe v = fe_mul(fe_sub(c, fe_mul(r, d)), fe_add(r, d));
+    fe s;
+    int was_square = fe_sqrt_ratio_m1(u, v, s);
+    fe s_prime = fe_neg(fe_abs(fe_mul(s, r0)));
+    s = fe_select(s_prime, s, was_square);
+    c = fe_select(r, c, was_square);
+    fe N = fe_sub(fe_mul(fe_mul(c, fe_sub(r, one)), fe_const(FE_D_MINUS_ONE_SQ_L)), v);
+    fe ss = fe_sq(s);
+    fe w0 = fe_mul(fe_add(s, s), v);
+    fe w1 = fe_mul(N, fe_const(FE_SQRT_AD_MINUS_ONE_L));
+    fe w2 = fe_sub(one, ss), w3 = fe_add(one, ss);
+    ge p;
+    p.X = fe_mul(w0, w3); p.Y = fe_mul(w2, w1); p.Z = fe_mul(w1, w3); p.T = fe_mul(w0, w2);
+    return p;
+}
+
+// RistrettoPoint::from_uniform_bytes (64 bytes)
+HD inline ge ge_from_uniform_bytes(const uint8_t b[64]) {
+    uint8_t t[32];
+    for (int k = 0; k < 32; k++) t[k] = b[k];
+    t[31] &= 0x7f;
+    ge p1 = ge_elligator(fe_frombytes(t));
+    for (int k = 0; k < 32; k++) t[k] = b[32 + k];
+    t[31] &= 0x7f;
+    ge p2 = ge_elligator(fe_frombytes(t));
+    return ge_add_ge(p1, p2);
+}
+
+HD_CONST uint32_t GE_BX_L[8] = {0x8f25d51au, 0xc9562d60u, 0x9525a7b2u, 0x692cc760u, 0xfdd6dc5cu, 0xc0a4e231u, 0xcd6e53feu, 0x216936d3u};
+HD_CONST uint32_t GE_BY_L[8] = {0x66666658u, 0x66666666u, 0x66666666u, 0x66666666u, 0x66666666u, 0x66666666u, 0x66666666u, 0x66666666u};
+HD_CONST uint32_t GE_BT_L[8] = {0xa5b7dda3u, 0x6dde8ab3u, 0x775152f5u, 0x20f09f80u, 0x64abe37du, 0x66ea4e8eu, 0xd78b7665u, 0x67875f0fu};
+HD inline ge ge_basepoint() {
+    ge r;
+    r.X = fe_const(GE_BX_L); r.Y = fe_const(GE_BY_L); r.Z = fe_one(); r.T = fe_const(GE_BT_L);
+    return r;
+}

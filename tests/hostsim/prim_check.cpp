@@ -1,0 +1,74 @@
+// Test-only: compiles the DEVICE arithmetic headers for the host CPU
+// (BPR1CS_HOSTSIM) so `-m "not gpu"` tests can compare them with the oracle.
+// Not part of the product; the shipped library has no CPU path.
+#include "fe.hpp"
+#include "sc.hpp"
+#include "ge.hpp"
+#include "merlin.hpp"
+#include <string.h>
+extern "C" {
+void hs_fe_mul(const uint8_t* a, const uint8_t* b, uint8_t* o) { fe_tobytes(fe_mul(fe_frombytes(a), fe_frombytes(b)), o); }
+void hs_fe_add(const uint8_t* a, const uint8_t* b, uint8_t* o) { fe_tobytes(fe_add(fe_frombytes(a), fe_frombytes(b)), o); }
+void hs_fe_sub(const uint8_t* a, const uint8_t* b, uint8_t* o) { fe_tobytes(fe_sub(fe_frombytes(a), fe_frombytes(b)), o); }
+void hs_fe_inv(const uint8_t* a, uint8_t* o) { fe_tobytes(fe_invert(fe_frombytes(a)), o); }
+void hs_sc_mul(const uint8_t* a, const uint8_t* b, uint8_t* o) {
+    sc x = sc_mont_from_bytes_mod_order(a), y = sc_mont_from_bytes_mod_order(b);
+    sc_mont_tobytes(sc_mul(x, y), o);
+}
+void hs_sc_add(const uint8_t* a, const uint8_t* b, uint8_t* o) {
+    sc_mont_tobytes(sc_add(sc_mont_from_bytes_mod_order(a), sc_mont_from_bytes_mod_order(b)), o);
+}
+void hs_sc_sub(const uint8_t* a, const uint8_t* b, uint8_t* o) {
+    sc_mont_tobytes(sc_sub(sc_mont_from_bytes_mod_order(a), sc_mont_from_bytes_mod_order(b)), o);
+}
+void hs_sc_inv(const uint8_t* a, uint8_t* o) { sc_mont_tobytes(sc_invert(sc_mont_from_bytes_mod_order(a)), o); }
+void hs_sc_wide(const uint8_t* a, uint8_t* o) { sc_mont_tobytes(sc_mont_from_wide(a), o); }
+void hs_uniform(const uint8_t* a, uint8_t* o) { ge_compress(ge_from_uniform_bytes(a), o); }
+int hs_decompress_recompress(const uint8_t* a, uint8_t* o) {
+    ge p;
+    if (!ge_decompress(a, p)) return 0;
+    ge_compress(p, o);
+    return 1;
+}
+// k*B by double-and-add
+void hs_basemul(const uint8_t* k, uint8_t* o) {
+    ge acc = ge_identity(), base = ge_basepoint();
+    for (int i = 0; i < 256; i++) {
+        if ((k[i >> 3] >> (i & 7)) & 1) acc = ge_add_ge(acc, base);
+        base = ge_dbl(base);
+    }
+    ge_compress(acc, o);
+}
+// P+Q, P-Q, P+niels(Q), P-niels(Q) on compressed inputs
+int hs_addsub(const uint8_t* a, const uint8_t* b, uint8_t* o4) {
+    ge p, q;
+    if (!ge_decompress(a, p) || !ge_decompress(b, q)) return 0;
+    ge_cached c = ge_to_cached(q);
+    ge_niels n = ge_to_niels(q);
+    ge_compress(ge_add(p, c), o4);
+    ge_compress(ge_sub(p, c), o4 + 32);
+    ge_compress(ge_madd(p, n, 0), o4 + 64);
+    ge_compress(ge_madd(p, n, 1), o4 + 96);
+    return 1;
+}
+void hs_merlin_kat(uint8_t* out32) {
+    strobe s;
+    merlin_new(s, (const uint8_t*)"test protocol", 13);
+    merlin_append(s, "some label", 10, (const uint8_t*)"some data", 9);
+    merlin_challenge_bytes(s, "challenge", 9, out32, 32);
+}
+// label, then k appends of 32-byte msgs under "V", rng rekey/finalize, n draws
+void hs_merlin_script(const uint8_t* label, uint32_t ll, const uint8_t* msgs, uint32_t k, const uint8_t* seed,
+                      uint32_t ndraw, uint8_t* draws /*ndraw*32*/, uint8_t* chal /*32*/) {
+    strobe s;
+    merlin_new(s, label, ll);
+    for (uint32_t i = 0; i < k; i++) merlin_append(s, "V", 1, msgs + 32 * i, 32);
+    merlin_append_u64(s, "m", 1, k);
+    strobe rng = s;
+    for (uint32_t i = 0; i < k; i++) merlin_rng_rekey(rng, "v_blinding", 10, msgs + 32 * i, 32);
+    merlin_rng_finalize(rng, seed);
+    for (uint32_t i = 0; i < ndraw; i++) sc_mont_tobytes(merlin_rng_scalar(rng), draws + 32 * i);
+    sc c = merlin_challenge_scalar(s, "y", 1);
+    sc_mont_tobytes(c, chal);
+}
+}
