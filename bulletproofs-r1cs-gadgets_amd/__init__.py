@@ -1,0 +1,197 @@
+"""bulletproofs-r1cs-gadgets_amd — MI355X-native Bulletproofs R1CS prover hot path.
+
+Thin ctypes binding over the C ABI of include/bpr1cs.h (libbpr1cs_hip.so, built
+in-tree by `__graft_entry__.build()` / `csrc/build.sh`).  The library is HIP
+only: importing works without a GPU, every compute call fails loudly without
+one.  Nothing here imports or calls the test oracle.
+
+Import with importlib (the directory name carries hyphens):
+    bp = importlib.import_module("bulletproofs-r1cs-gadgets_amd")
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libbpr1cs_hip.so")
+GADGETS_LIB_PATH = os.path.join(_HERE, "csrc", "libbpr1cs_gadgets.so")
+POSEIDON_PARAMS_PATH = os.path.join(_HERE, "data", "poseidon_params_ristretto.bin")
+
+VAR_COMMITTED, VAR_MUL_LEFT, VAR_MUL_RIGHT, VAR_MUL_OUT, VAR_ONE = 0, 1, 2, 3, 4
+W_LC, W_INV_LEFT, W_BIT, W_NOTBIT = 0, 1, 2, 3
+
+ERRORS = {0: "OK", -1: "InvalidGeneratorsLength", -2: "FormatError", -3: "VerificationError",
+          -4: "MissingAssignment", -5: "GadgetError", -16: "NoDevice", -17: "InvalidArgument"}
+
+
+class R1CSError(RuntimeError):
+    def __init__(self, code):
+        super().__init__("bpr1cs: %s (%d)" % (ERRORS.get(code, "?"), code))
+        self.code = code
+
+
+class _WOp(ctypes.Structure):
+    _fields_ = [("lkind", ctypes.c_uint32), ("larg", ctypes.c_uint32), ("rkind", ctypes.c_uint32), ("rarg", ctypes.c_uint32)]
+
+
+class _CircuitDesc(ctypes.Structure):
+    _fields_ = [("n", ctypes.c_uint32), ("q", ctypes.c_uint32), ("m", ctypes.c_uint32),
+                ("row_off", ctypes.POINTER(ctypes.c_uint32)), ("term_var", ctypes.POINTER(ctypes.c_uint32)),
+                ("term_coeff", ctypes.c_char_p),
+                ("wops", ctypes.POINTER(_WOp)), ("n_lc", ctypes.c_uint32),
+                ("lc_off", ctypes.POINTER(ctypes.c_uint32)), ("lc_var", ctypes.POINTER(ctypes.c_uint32)),
+                ("lc_coeff", ctypes.c_char_p)]
+
+
+_lib = None
+
+
+def load_library(path=None):
+    """Load libbpr1cs_hip.so (or an ABI-compatible test build when `path` is given)."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise ImportError("bpr1cs: %s is missing — run __graft_entry__.build() (hipcc, gfx950). "
+                          "There is no CPU fallback." % p)
+    lib = ctypes.CDLL(p)
+    vp, u32, sz, cp = ctypes.c_void_p, ctypes.c_uint32, ctypes.c_size_t, ctypes.c_char_p
+    lib.bpr1cs_device_count.restype = ctypes.c_int
+    lib.bpr1cs_set_device.argtypes = [ctypes.c_int]
+    lib.bpr1cs_gens_create.argtypes = [u32, ctypes.POINTER(vp)]
+    lib.bpr1cs_gens_destroy.argtypes = [vp]
+    lib.bpr1cs_gens_capacity.argtypes = [vp]
+    lib.bpr1cs_gens_capacity.restype = u32
+    lib.bpr1cs_gens_point.argtypes = [vp, ctypes.c_int, u32, cp]
+    lib.bpr1cs_circuit_create.argtypes = [ctypes.POINTER(_CircuitDesc), ctypes.POINTER(vp)]
+    lib.bpr1cs_circuit_destroy.argtypes = [vp]
+    lib.bpr1cs_proof_len.argtypes = [vp]
+    lib.bpr1cs_proof_len.restype = sz
+    lib.bpr1cs_prove_batch.argtypes = [vp, vp, cp, sz, cp, cp, cp, cp, sz, cp, cp]
+    lib.bpr1cs_msm_fixed.argtypes = [vp, ctypes.POINTER(u32), sz, cp, sz, cp]
+    lib.bpr1cs_set_unfold_rounds.argtypes = [ctypes.c_int]
+    lib.bpr1cs_last_timings.argtypes = [ctypes.POINTER(ctypes.c_float), ctypes.c_int]
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def _chk(rc):
+    if rc != 0:
+        raise R1CSError(rc)
+
+
+def _u32arr(xs):
+    return (ctypes.c_uint32 * max(1, len(xs)))(*xs)
+
+
+class Gens:
+    """PedersenGens::default() + BulletproofGens::new(capacity, 1)."""
+
+    def __init__(self, capacity, lib=None):
+        self.lib = lib or load_library()
+        h = ctypes.c_void_p()
+        _chk(self.lib.bpr1cs_gens_create(capacity, ctypes.byref(h)))
+        self.h, self.capacity = h, capacity
+
+    def point(self, which, i=0):
+        out = ctypes.create_string_buffer(32)
+        _chk(self.lib.bpr1cs_gens_point(self.h, which, i, out))
+        return out.raw
+
+    def msm_fixed(self, bases, scalars, batch):
+        """scalars: bytes batch*terms*32 (proof-major) -> batch compressed points."""
+        out = ctypes.create_string_buffer(32 * batch)
+        _chk(self.lib.bpr1cs_msm_fixed(self.h, _u32arr(bases), len(bases), scalars, batch, out))
+        return [out.raw[32 * i:32 * i + 32] for i in range(batch)]
+
+    def close(self):
+        if self.h:
+            self.lib.bpr1cs_gens_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Circuit:
+    """Flattened constraint system (+ optional device witness program).
+
+    constraints: list of rows, each a list of ((kind, index), coeff_int_or_bytes)
+    wops: optional list of (lkind, larg, rkind, rarg); lcs: list of term lists for W_LC operands.
+    """
+
+    def __init__(self, n, m, constraints, wops=None, lcs=None, lib=None, raw=None):
+        self.lib = lib or load_library()
+        self.n, self.m = n, m
+        if raw is not None:
+            row_off, tvar, tcoef, q = raw
+        else:
+            row_off, tvar, tcoef = [0], [], bytearray()
+            for row in constraints:
+                for (kind, idx), c in row:
+                    tvar.append((kind << 28) | idx)
+                    tcoef += c if isinstance(c, (bytes, bytearray)) else int(c).to_bytes(32, "little")
+                row_off.append(len(tvar))
+            q = len(constraints)
+        self.q = q
+        d = _CircuitDesc()
+        d.n, d.q, d.m = n, q, m
+        self._keep = [_u32arr(row_off), _u32arr(tvar), bytes(tcoef) or b"\0"]
+        d.row_off, d.term_var, d.term_coeff = self._keep[0], self._keep[1], self._keep[2]
+        if wops is not None:
+            arr = (_WOp * max(1, len(wops)))(*[_WOp(*w) for w in wops])
+            lc_off, lc_var, lc_coeff = [0], [], bytearray()
+            for terms in (lcs or []):
+                for (kind, idx), c in terms:
+                    lc_var.append((kind << 28) | idx)
+                    lc_coeff += c if isinstance(c, (bytes, bytearray)) else int(c).to_bytes(32, "little")
+                lc_off.append(len(lc_var))
+            self._keep += [arr, _u32arr(lc_off), _u32arr(lc_var), bytes(lc_coeff) or b"\0"]
+            d.wops, d.n_lc = arr, len(lcs or [])
+            d.lc_off, d.lc_var, d.lc_coeff = self._keep[4], self._keep[5], self._keep[6]
+        h = ctypes.c_void_p()
+        _chk(self.lib.bpr1cs_circuit_create(ctypes.byref(d), ctypes.byref(h)))
+        self.h = h
+        self.proof_len = self.lib.bpr1cs_proof_len(h)
+
+    def close(self):
+        if self.h:
+            self.lib.bpr1cs_circuit_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def prove_batch(gens, circuit, label, values, v_blindings, rng_seeds, batch, wires=None):
+    """-> (list of proof bytes, list of per-proof commitment lists).
+
+    values / v_blindings: bytes batch*m*32 proof-major; rng_seeds: bytes batch*32;
+    wires: None (device witness program) or bytes batch*3*n*32 (a_L|a_R|a_O per proof).
+    """
+    lib = gens.lib
+    m, plen = circuit.m, circuit.proof_len
+    assert len(values) == batch * m * 32 and len(v_blindings) == batch * m * 32 and len(rng_seeds) == batch * 32
+    if wires is not None:
+        assert len(wires) == batch * 3 * circuit.n * 32
+    proofs = ctypes.create_string_buffer(batch * plen)
+    comms = ctypes.create_string_buffer(max(1, batch * m * 32))
+    _chk(lib.bpr1cs_prove_batch(gens.h, circuit.h, label, len(label), values or b"\0", v_blindings or b"\0", rng_seeds,
+                                wires, batch, proofs, comms))
+    P = [proofs.raw[i * plen:(i + 1) * plen] for i in range(batch)]
+    C = [[comms.raw[(i * m + j) * 32:(i * m + j + 1) * 32] for j in range(m)] for i in range(batch)]
+    return P, C
+
+
+def last_timings(lib=None):
+    lib = lib or load_library()
+    buf = (ctypes.c_float * 6)()
+    k = lib.bpr1cs_last_timings(buf, 6)
+    return list(buf)[:k]

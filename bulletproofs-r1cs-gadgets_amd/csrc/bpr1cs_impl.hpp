@@ -1,0 +1,455 @@
+// Host orchestration of the batched prover + the C ABI of include/bpr1cs.h.
+// One HIP stream per call; all per-batch state lives in HBM for the whole
+// prove (inputs are uploaded once, only proofs/commitments come back).
+#pragma once
+#include <vector>
+#include <algorithm>
+#include <string>
+#include "../../include/bpr1cs.h"
+#include "dev.hpp"
+#include "kernels.hpp"
+
+// ------------------------------------------------------------ host-side hashes
+static void host_sponge(uint32_t rate, uint8_t suffix, const uint8_t* in, size_t inlen, uint8_t* out, size_t outlen) {
+    uint64_t st[25];
+    memset(st, 0, sizeof st);
+    std::vector<uint8_t> buf(in, in + inlen);
+    buf.push_back(suffix);
+    while (buf.size() % rate) buf.push_back(0);
+    buf.back() |= 0x80;
+    for (size_t off = 0; off < buf.size(); off += rate) {
+        for (uint32_t i = 0; i < rate; i++) st[i >> 3] ^= (uint64_t)buf[off + i] << (8 * (i & 7));
+        keccak_f1600(st);
+    }
+    size_t done = 0;
+    while (done < outlen) {
+        size_t take = std::min<size_t>(rate, outlen - done);
+        for (size_t i = 0; i < take; i++) out[done + i] = (uint8_t)(st[i >> 3] >> (8 * (i & 7)));
+        done += take;
+        if (done < outlen) keccak_f1600(st);
+    }
+}
+
+static int g_unfold_rounds = 4;
+static float g_timings[8];
+
+struct bpr1cs_gens {
+    uint32_t cap = 0;
+    DevBuf<ge> pts;          // [2 + 2cap] : B, B~, G.., H..
+    DevBuf<ge_niels> tab;    // [(2+2cap) * 4096]
+    std::vector<uint8_t> comp;  // compressed, host copy
+    dev_stream_t stream{};
+};
+
+struct bpr1cs_circuit {
+    uint32_t n = 0, q = 0, m = 0, N = 1, lgN = 0;
+    DevBuf<uint32_t> slot_off, ent_row;
+    DevBuf<sc> ent_coeff;
+    bool has_program = false;
+    DevBuf<WOp> wops;
+    DevBuf<uint32_t> lc_off, lc_var;
+    DevBuf<sc> lc_coeff;
+};
+
+static bool have_device() {
+#if defined(BPR1CS_HOSTSIM)
+    return true;
+#else
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return false;
+    return n > 0;
+#endif
+}
+
+template <class T>
+static void upload(DevBuf<T>& d, const std::vector<T>& h, dev_stream_t s) {
+    d.alloc(h.size());
+    if (!h.empty()) dev_h2d(d.p, h.data(), h.size() * sizeof(T), s);
+}
+
+// canonical 32-byte scalars on the host -> Montgomery sc (host uses the same HD code)
+static sc host_mont(const uint8_t* b) { return sc_mont_from_bytes_mod_order(b); }
+
+extern "C" {
+
+int bpr1cs_device_count(void) {
+#if defined(BPR1CS_HOSTSIM)
+    return 1;
+#else
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+#endif
+}
+int bpr1cs_set_device(int ordinal) {
+#if !defined(BPR1CS_HOSTSIM)
+    if (hipSetDevice(ordinal) != hipSuccess) return BPR1CS_ERR_NO_DEVICE;
+#endif
+    (void)ordinal;
+    return BPR1CS_OK;
+}
+void bpr1cs_set_unfold_rounds(int r) { g_unfold_rounds = r < 0 ? 0 : r; }
+int bpr1cs_last_timings(float* out, int cap) {
+    int k = cap < 6 ? cap : 6;
+    for (int i = 0; i < k; i++) out[i] = g_timings[i];
+    return k;
+}
+
+int bpr1cs_gens_create(uint32_t cap, bpr1cs_gens** out) {
+    if (!out || cap == 0) return BPR1CS_ERR_INVALID_ARGUMENT;
+    if (!have_device()) return BPR1CS_ERR_NO_DEVICE;
+    bpr1cs_gens* g = new bpr1cs_gens();
+    g->cap = cap;
+#if !defined(BPR1CS_HOSTSIM)
+    HIPCHK(hipStreamCreate(&g->stream));
+#endif
+    uint32_t nb = 2 + 2 * cap;
+    // uniform bytes: B~ <- SHA3-512(compress(B)); G/H <- SHAKE256("GeneratorsChain"||'G'|'H'||LE32(0))  
+    std::vector<uint8_t> uni((size_t)(1 + 2 * cap) * 64);
+    uint8_t bcomp[32];
+    ge_compress(ge_basepoint(), bcomp);
+    host_sponge(72, 0x06, bcomp, 32, uni.data(), 64);
+    for (int side = 0; side < 2; side++) {
+        uint8_t lab[20] = {'G', 'e', 'n', 'e', 'r', 'a', 't', 'o', 'r', 's', 'C', 'h', 'a', 'i', 'n', (uint8_t)(side ? 'H' : 'G'), 0, 0, 0, 0};
+        host_sponge(136, 0x1f, lab, 20, uni.data() + 64 + (size_t)side * cap * 64, (size_t)cap * 64);
+    }
+    DevBuf<uint8_t> d_uni(uni.size()), d_comp((size_t)nb * 32);
+    dev_h2d(d_uni.p, uni.data(), uni.size(), g->stream);
+    g->pts.alloc(nb);
+    ge bp = ge_basepoint();
+    dev_h2d(g->pts.p, &bp, sizeof(ge), g->stream);
+    launch(1 + 2 * cap, K_gen_points{d_uni.p, g->pts.p + 1, d_comp.p + 32}, g->stream);
+    g->comp.resize((size_t)nb * 32);
+    dev_d2h(g->comp.data(), d_comp.p, (size_t)nb * 32, g->stream);
+    memcpy(g->comp.data(), bcomp, 32);
+    g->tab.alloc((size_t)nb * TAB_PER_BASE);
+    launch((uint64_t)nb * TAB_WINDOWS, K_build_table{g->pts.p, g->tab.p}, g->stream);
+    dev_sync(g->stream);
+    *out = g;
+    return BPR1CS_OK;
+}
+void bpr1cs_gens_destroy(bpr1cs_gens* g) {
+    if (!g) return;
+#if !defined(BPR1CS_HOSTSIM)
+    hipStreamDestroy(g->stream);
+#endif
+    delete g;
+}
+uint32_t bpr1cs_gens_capacity(const bpr1cs_gens* g) { return g ? g->cap : 0; }
+int bpr1cs_gens_point(const bpr1cs_gens* g, int which, uint32_t i, uint8_t out[32]) {
+    if (!g || !out) return BPR1CS_ERR_INVALID_ARGUMENT;
+    size_t idx;
+    if (which == 0) idx = 0;
+    else if (which == 1) idx = 1;
+    else if (which == 2 && i < g->cap) idx = 2 + i;
+    else if (which == 3 && i < g->cap) idx = 2 + g->cap + i;
+    else return BPR1CS_ERR_INVALID_ARGUMENT;
+    memcpy(out, g->comp.data() + idx * 32, 32);
+    return BPR1CS_OK;
+}
+
+int bpr1cs_circuit_create(const bpr1cs_circuit_desc* d, bpr1cs_circuit** out) {
+    if (!d || !out) return BPR1CS_ERR_INVALID_ARGUMENT;
+    if (!have_device()) return BPR1CS_ERR_NO_DEVICE;
+    bpr1cs_circuit* c = new bpr1cs_circuit();
+    c->n = d->n; c->q = d->q; c->m = d->m;
+    c->N = 1; c->lgN = 0;
+    while (c->N < d->n) { c->N <<= 1; c->lgN++; }
+    dev_stream_t s{};
+    // CSR by row -> CSC by wire slot (LEFT i -> i, RIGHT -> n+i, OUT -> 2n+i, COMMITTED -> 3n+i); One terms dropped (prover)
+    uint32_t nslots = 3 * d->n + d->m;
+    std::vector<uint32_t> cnt(nslots + 1, 0);
+    uint32_t nnz = d->q ? d->row_off[d->q] : 0;
+    auto slot_of = [&](uint32_t var, uint32_t& slot) -> int {
+        uint32_t kind = var >> 28, idx = var & 0x0fffffffu;
+        if (kind == VK_ONE) return 0;
+        if (kind == VK_COMMITTED) { if (idx >= d->m) return -1; slot = 3 * d->n + idx; return 1; }
+        if (kind > VK_OUT || idx >= d->n) return -1;
+        slot = (kind - 1) * d->n + idx;
+        return 1;
+    };
+    for (uint32_t t = 0; t < nnz; t++) {
+        uint32_t slot;
+        int r = slot_of(d->term_var[t], slot);
+        if (r < 0) { delete c; return BPR1CS_ERR_INVALID_ARGUMENT; }
+        if (r) cnt[slot + 1]++;
+    }
+    for (uint32_t i = 0; i < nslots; i++) cnt[i + 1] += cnt[i];
+    std::vector<uint32_t> fill(cnt.begin(), cnt.end() - 1), ent_row(cnt[nslots]);
+    std::vector<sc> ent_coeff(cnt[nslots]);
+    for (uint32_t j = 0; j < d->q; j++)
+        for (uint32_t t = d->row_off[j]; t < d->row_off[j + 1]; t++) {
+            uint32_t slot;
+            if (slot_of(d->term_var[t], slot) == 1) {
+                uint32_t p = fill[slot]++;
+                ent_row[p] = j;
+                ent_coeff[p] = host_mont(d->term_coeff + 32 * (size_t)t);
+            }
+        }
+    upload(c->slot_off, cnt, s);
+    upload(c->ent_row, ent_row, s);
+    upload(c->ent_coeff, ent_coeff, s);
+    if (d->wops) {
+        c->has_program = true;
+        std::vector<WOp> ops(d->n);
+        for (uint32_t i = 0; i < d->n; i++) ops[i] = WOp{d->wops[i].lkind, d->wops[i].larg, d->wops[i].rkind, d->wops[i].rarg};
+        uint32_t nt = d->n_lc ? d->lc_off[d->n_lc] : 0;
+        std::vector<uint32_t> lo(d->lc_off, d->lc_off + d->n_lc + 1), lv(d->lc_var, d->lc_var + nt);
+        std::vector<sc> lcf(nt);
+        for (uint32_t t = 0; t < nt; t++) lcf[t] = host_mont(d->lc_coeff + 32 * (size_t)t);
+        upload(c->wops, ops, s);
+        upload(c->lc_off, lo, s);
+        upload(c->lc_var, lv, s);
+        upload(c->lc_coeff, lcf, s);
+    }
+    *out = c;
+    return BPR1CS_OK;
+}
+void bpr1cs_circuit_destroy(bpr1cs_circuit* c) { delete c; }
+size_t bpr1cs_proof_len(const bpr1cs_circuit* c) { return c ? 1 + 32 * (size_t)(13 + 2 * c->lgN) : 0; }
+
+}  // extern "C"
+
+// ---------------------------------------------------------------- timing
+struct PhaseTimer {
+#if defined(BPR1CS_HOSTSIM)
+    void mark(dev_stream_t) {}
+    void finish(float*) {}
+#else
+    std::vector<hipEvent_t> ev;
+    void mark(dev_stream_t s) {
+        hipEvent_t e;
+        HIPCHK(hipEventCreate(&e));
+        HIPCHK(hipEventRecord(e, s));
+        ev.push_back(e);
+    }
+    void finish(float* out) {  // out[0] total, out[1..] consecutive phases
+        if (ev.size() < 2) return;
+        HIPCHK(hipEventSynchronize(ev.back()));
+        HIPCHK(hipEventElapsedTime(&out[0], ev.front(), ev.back()));
+        for (size_t i = 1; i < ev.size() && i < 6; i++) HIPCHK(hipEventElapsedTime(&out[i], ev[i - 1], ev[i]));
+        for (auto e : ev) hipEventDestroy(e);
+        ev.clear();
+    }
+#endif
+};
+
+static uint32_t pick_chunks(uint64_t items, uint32_t B, uint32_t target_threads, uint32_t& chunk) {
+    uint32_t want = (target_threads + B - 1) / B;
+    if (want < 1) want = 1;
+    if ((uint64_t)want > items) want = (uint32_t)(items ? items : 1);
+    chunk = (uint32_t)((items + want - 1) / want);
+    if (chunk == 0) chunk = 1;
+    return (uint32_t)((items + chunk - 1) / chunk);
+}
+
+// proof-major host array [B][cnt][32] -> element-major device array [cnt][B]
+static void upload_transposed(DevBuf<sc>& d, const uint8_t* h, size_t B, size_t cnt, dev_stream_t s) {
+    std::vector<sc> t(cnt * B);
+    for (size_t b = 0; b < B; b++)
+        for (size_t j = 0; j < cnt; j++) t[j * B + b] = sc_load_raw(h + (b * cnt + j) * 32);
+    d.alloc(cnt * B);
+    if (cnt * B) dev_h2d(d.p, t.data(), t.size() * sizeof(sc), s);
+}
+
+struct MsmPlan {
+    uint32_t nchunks, chunk;
+};
+
+static void run_msm(const bpr1cs_gens* g, MsmSeg s0, MsmSeg s1, uint32_t B, DevBuf<ge>& partial, MsmPlan& plan, dev_stream_t st) {
+    uint32_t total = s0.count + s1.count;
+    plan.nchunks = pick_chunks(total, B, 1u << 17, plan.chunk);
+    if (partial.n < (size_t)plan.nchunks * B) partial.alloc((size_t)plan.nchunks * B);
+    K_msm_fixed k{g->tab.p, {s0, s1}, partial.p, B, plan.chunk};
+    launch((uint64_t)plan.nchunks * B, k, st);
+}
+
+extern "C" int bpr1cs_prove_batch(const bpr1cs_gens* g, const bpr1cs_circuit* c, const uint8_t* label, size_t label_len,
+                                  const uint8_t* values, const uint8_t* v_blindings, const uint8_t* rng_seeds,
+                                  const uint8_t* wires, size_t batch, uint8_t* proofs_out, uint8_t* commitments_out) {
+    if (!g || !c || !label || !rng_seeds || !proofs_out || batch == 0) return BPR1CS_ERR_INVALID_ARGUMENT;
+    if (c->m && (!values || !v_blindings)) return BPR1CS_ERR_INVALID_ARGUMENT;
+    if (!have_device()) return BPR1CS_ERR_NO_DEVICE;
+    if (g->cap < c->N) return BPR1CS_ERR_INVALID_GENERATORS_LENGTH;
+    if (!wires && !c->has_program) return BPR1CS_ERR_MISSING_ASSIGNMENT;
+    if (batch > (1u << 20)) return BPR1CS_ERR_INVALID_ARGUMENT;
+    const uint32_t B = (uint32_t)batch, n = c->n, m = c->m, N = c->N, lgN = c->lgN;
+    const uint32_t baseG = 2, baseH = 2 + g->cap;
+    dev_stream_t st = g->stream;
+    PhaseTimer pt;
+    pt.mark(st);
+
+    // ---- inputs
+    DevBuf<sc> v_raw, vbl_raw, v_m((size_t)m * B), vbl_m((size_t)m * B);
+    upload_transposed(v_raw, values, B, m, st);
+    upload_transposed(vbl_raw, v_blindings, B, m, st);
+    DevBuf<uint8_t> d_seeds((size_t)B * 32), d_label(label_len ? label_len : 1);
+    dev_h2d(d_seeds.p, rng_seeds, (size_t)B * 32, st);
+    if (label_len) dev_h2d(d_label.p, label, label_len, st);
+    launch((uint64_t)m * B, K_load_inputs{v_raw.p, vbl_raw.p, v_m.p, vbl_m.p}, st);
+
+    // ---- P1: V commitments, transcript, RNG stream
+    DevBuf<uint8_t> Vcomp((size_t)B * m * 32 + 1);
+    launch((uint64_t)m * B, K_commit_v{g->tab.p, v_raw.p, vbl_raw.p, Vcomp.p, B, m}, st);
+    DevBuf<strobe> tr(B);
+    DevBuf<sc> blind((size_t)8 * B), W((size_t)5 * n * B + 1);
+    sc* sL = W.p + (size_t)3 * n * B;
+    sc* sR = W.p + (size_t)4 * n * B;
+    launch(B, K_transcript_init{d_label.p, (uint32_t)label_len, Vcomp.p, vbl_raw.p, d_seeds.p, tr.p, blind.p, sL, sR, B, m, n}, st);
+    pt.mark(st);
+
+    // ---- P7/P8: witness (device program) or host-synthesised wires
+    if (wires) {
+        DevBuf<sc> raw;
+        upload_transposed(raw, wires, B, (size_t)3 * n, st);
+        launch((uint64_t)3 * n * B, K_load_wires{raw.p, W.p}, st);
+        dev_sync(st);
+    } else {
+        launch(B, K_witness{c->wops.p, c->lc_off.p, c->lc_var.p, c->lc_coeff.p, v_raw.p, v_m.p, W.p, B, n}, st);
+    }
+    pt.mark(st);
+
+    // ---- P2: A_I1, A_O1, S1
+    DevBuf<ge> partial;
+    DevBuf<uint8_t> AOS((size_t)3 * B * 32);
+    MsmPlan plan;
+    {
+        sc* aL = W.p; sc* aR = W.p + (size_t)n * B; sc* aO = W.p + (size_t)2 * n * B;
+        MsmSeg none{nullptr, 0, 1, 1, 0, 0, 0};
+        auto seg = [&](const sc* p, uint32_t base0) { return MsmSeg{p, n, n ? n : 1, n ? n : 1, 0, base0, 1}; };
+        run_msm(g, seg(aL, baseG), seg(aR, baseH), B, partial, plan, st);
+        launch(B, K_msm_finish{g->tab.p, partial.p, blind.p + 0 * (size_t)B, nullptr, AOS.p + 0 * (size_t)B * 32, B, plan.nchunks, 1}, st);
+        run_msm(g, seg(aO, baseG), none, B, partial, plan, st);
+        launch(B, K_msm_finish{g->tab.p, partial.p, blind.p + 1 * (size_t)B, nullptr, AOS.p + 1 * (size_t)B * 32, B, plan.nchunks, 1}, st);
+        run_msm(g, seg(sL, baseG), seg(sR, baseH), B, partial, plan, st);
+        launch(B, K_msm_finish{g->tab.p, partial.p, blind.p + 2 * (size_t)B, nullptr, AOS.p + 2 * (size_t)B * 32, B, plan.nchunks, 1}, st);
+    }
+    pt.mark(st);
+
+    // ---- P3/P4: challenges, flatten, t(x), T commitments, l(x), r(x)
+    DevBuf<sc> chal((size_t)CH_COUNT * B);
+    launch(B, K_transcript_A{tr.p, AOS.p, chal.p, B}, st);
+    uint32_t maxe = std::max<uint32_t>(N, c->q + 1);
+    uint32_t H = (maxe >> 8) + 1;
+    DevBuf<sc> plo((size_t)3 * 256 * B), phi((size_t)3 * H * B);
+    launch((uint64_t)3 * B, K_pow_tables{chal.p, plo.p, phi.p, B, H}, st);
+    DevBuf<sc> wvec((size_t)(3 * n + m) * B + 1);
+    launch((uint64_t)(3 * n + m) * B, K_flatten{c->slot_off.p, c->ent_row.p, c->ent_coeff.p, plo.p, phi.p, wvec.p, B, H, 3 * n}, st);
+    uint32_t tchunk, TC = pick_chunks(n, B, 1u << 16, tchunk);
+    DevBuf<sc> tpart((size_t)6 * TC * B), tco((size_t)6 * B);
+    launch((uint64_t)TC * B, K_tcoef_partial{W.p, wvec.p, plo.p, phi.p, tpart.p, B, H, n, tchunk, TC}, st);
+    launch((uint64_t)6 * B, K_sum_partials{tpart.p, tco.p, B, TC}, st);
+    DevBuf<uint8_t> Tc((size_t)5 * B * 32);
+    launch((uint64_t)5 * B, K_commit_T{g->tab.p, tco.p, blind.p, Tc.p, B}, st);
+    DevBuf<sc> txs((size_t)3 * B);
+    launch(B, K_transcript_T{tr.p, Tc.p, tco.p, blind.p, wvec.p + (size_t)3 * n * B, vbl_m.p, chal.p, txs.p, B, m, (uint64_t)N}, st);
+    DevBuf<sc> a((size_t)N * B), bb((size_t)N * B), cG((size_t)N * B), cH((size_t)N * B);
+    launch((uint64_t)N * B, K_lr_eval{W.p, wvec.p, plo.p, phi.p, chal.p, a.p, bb.p, cG.p, cH.p, B, H, n}, st);
+    pt.mark(st);
+
+    // ---- P5: inner-product argument
+    DevBuf<uint8_t> LR((size_t)(lgN ? lgN : 1) * 2 * B * 32);
+    DevBuf<sc> uk((size_t)(lgN ? lgN : 1) * 2 * B), cross((size_t)2 * B);
+    uint32_t r = (uint32_t)g_unfold_rounds < lgN ? (uint32_t)g_unfold_rounds : lgN;
+    DevBuf<sc> sG, sH, cpart;
+    DevBuf<ge> GH, vtmp, vpart;
+    uint32_t M = N >> r;  // size of the materialised folded generator vectors
+    if (r > 0) { sG.alloc((size_t)N * B); sH.alloc((size_t)N * B); }
+    const uint32_t VC = 16;
+    for (uint32_t k = 0; k < lgN; k++) {
+        uint32_t Nk = N >> k, mk = Nk >> 1;
+        uint32_t cchunk, CC = pick_chunks(mk, B, 1u << 16, cchunk);
+        if (cpart.n < (size_t)2 * CC * B) cpart.alloc((size_t)2 * CC * B);
+        launch((uint64_t)CC * B, K_ipa_cross{a.p, bb.p, cpart.p, B, mk, cchunk, CC}, st);
+        launch((uint64_t)2 * B, K_sum_partials{cpart.p, cross.p, B, CC}, st);
+        uint8_t* Lout = LR.p + ((size_t)k * 2 + 0) * B * 32;
+        uint8_t* Rout = LR.p + ((size_t)k * 2 + 1) * B * 32;
+        const sc* wch = chal.p + (size_t)CH_W * B;
+        if (k < r) {
+            launch((uint64_t)N * B, K_ipa_scalars{a.p, bb.p, cG.p, cH.p, sG.p, sH.p, B, Nk}, st);
+            uint32_t half = N / 2;
+            // L: G-terms with pos >= m, H-terms with pos < m ; R: the complement
+            MsmSeg gL{sG.p, half, mk, Nk, mk, baseG, 0}, hL{sH.p, half, mk, Nk, 0, baseH, 0};
+            MsmSeg gR{sG.p, half, mk, Nk, 0, baseG, 0}, hR{sH.p, half, mk, Nk, mk, baseH, 0};
+            run_msm(g, gL, hL, B, partial, plan, st);
+            launch(B, K_msm_finish{g->tab.p, partial.p, cross.p, wch, Lout, B, plan.nchunks, 0}, st);
+            run_msm(g, gR, hR, B, partial, plan, st);
+            launch(B, K_msm_finish{g->tab.p, partial.p, cross.p + B, wch, Rout, B, plan.nchunks, 0}, st);
+        } else {
+            if (k == r) {
+                GH.alloc((size_t)2 * M * B);
+                launch((uint64_t)2 * M * B, K_ipa_fold_from_tables{g->tab.p, cG.p, cH.p, GH.p, B, M, N, baseG, baseH}, st);
+                vtmp.alloc((size_t)4 * (M / 2 ? M / 2 : 1) * B);
+                vpart.alloc((size_t)2 * VC * B);
+            }
+            launch((uint64_t)4 * mk * B, K_ipa_vb_mul{a.p, bb.p, GH.p, vtmp.p, B, mk, M}, st);
+            launch((uint64_t)2 * VC * B, K_ipa_vb_reduce{vtmp.p, vpart.p, B, mk, VC}, st);
+            launch(B, K_msm_finish{g->tab.p, vpart.p, cross.p, wch, Lout, B, VC, 0}, st);
+            launch(B, K_msm_finish{g->tab.p, vpart.p + (size_t)VC * B, cross.p + B, wch, Rout, B, VC, 0}, st);
+        }
+        sc* ukk = uk.p + (size_t)k * 2 * B;
+        launch(B, K_transcript_LR{tr.p, Lout, ukk, B}, st);
+        launch((uint64_t)mk * B, K_ipa_fold_ab{a.p, bb.p, ukk, B, mk}, st);
+        if (k < r) launch((uint64_t)N * B, K_ipa_update_c{cG.p, cH.p, ukk, B, Nk}, st);
+        else if (mk > 0 && k + 1 < lgN) launch((uint64_t)2 * mk * B, K_ipa_vb_fold{GH.p, ukk, B, mk, M}, st);
+    }
+    size_t plen = bpr1cs_proof_len(c);
+    DevBuf<uint8_t> d_out((size_t)B * plen);
+    launch(B, K_assemble{AOS.p, Tc.p, txs.p, LR.p, a.p, bb.p, d_out.p, B, lgN, (uint32_t)plen}, st);
+    pt.mark(st);
+    dev_d2h(proofs_out, d_out.p, (size_t)B * plen, st);
+    if (commitments_out && m) dev_d2h(commitments_out, Vcomp.p, (size_t)B * m * 32, st);
+    pt.finish(g_timings);
+    return BPR1CS_OK;
+}
+
+extern "C" int bpr1cs_msm_fixed(const bpr1cs_gens* g, const uint32_t* bases, size_t terms, const uint8_t* scalars, size_t batch,
+                                uint8_t* out) {
+    if (!g || !bases || !scalars || !out || batch == 0) return BPR1CS_ERR_INVALID_ARGUMENT;
+    if (!have_device()) return BPR1CS_ERR_NO_DEVICE;
+    uint32_t nb = 2 + 2 * g->cap;
+    for (size_t t = 0; t < terms; t++)
+        if (bases[t] >= nb) return BPR1CS_ERR_INVALID_ARGUMENT;
+    // general base lists are served as runs of consecutive bases (the common case: one or two runs)
+    const uint32_t B = (uint32_t)batch;
+    dev_stream_t st = g->stream;
+    DevBuf<sc> sc_dev;
+    upload_transposed(sc_dev, scalars, B, terms, st);
+    DevBuf<ge> acc_partial, partial;
+    std::vector<std::pair<size_t, size_t>> runs;  // [start, len)
+    for (size_t t = 0; t < terms;) {
+        size_t e = t + 1;
+        while (e < terms && bases[e] == bases[e - 1] + 1) e++;
+        runs.push_back({t, e - t});
+        t = e;
+    }
+    // accumulate the runs pairwise into chunk partials, then finish once
+    size_t total_chunks = 0;
+    std::vector<ge> dummy;
+    DevBuf<ge> all;
+    std::vector<MsmPlan> plans;
+    // first pass: size
+    for (size_t i = 0; i < runs.size(); i += 2) {
+        uint32_t cnt = (uint32_t)runs[i].second + (i + 1 < runs.size() ? (uint32_t)runs[i + 1].second : 0);
+        uint32_t ch;
+        total_chunks += pick_chunks(cnt, B, 1u << 17, ch);
+    }
+    all.alloc((total_chunks ? total_chunks : 1) * (size_t)B);
+    size_t off = 0;
+    for (size_t i = 0; i < runs.size(); i += 2) {
+        auto mk = [&](size_t ri) {
+            uint32_t len = (uint32_t)runs[ri].second;
+            return MsmSeg{sc_dev.p + runs[ri].first * (size_t)B, len, len, len, 0, bases[runs[ri].first], 0};
+        };
+        MsmSeg s0 = mk(i), s1{nullptr, 0, 1, 1, 0, 0, 0};
+        if (i + 1 < runs.size()) s1 = mk(i + 1);
+        uint32_t ch, nc = pick_chunks(s0.count + s1.count, B, 1u << 17, ch);
+        K_msm_fixed k{g->tab.p, {s0, s1}, all.p + off * B, B, ch};
+        launch((uint64_t)nc * B, k, st);
+        off += nc;
+    }
+    DevBuf<uint8_t> d_out((size_t)B * 32);
+    launch(B, K_msm_finish{g->tab.p, all.p, nullptr, nullptr, d_out.p, B, (uint32_t)total_chunks, 0}, st);
+    dev_d2h(out, d_out.p, (size_t)B * 32, st);
+    return BPR1CS_OK;
+}

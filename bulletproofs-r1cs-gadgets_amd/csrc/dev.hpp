@@ -1,0 +1,92 @@
+// Device memory + launch plumbing.
+//
+// Product build (hipcc, gfx950): hipMalloc / hipMemcpyAsync / kernel launches on
+// one HIP stream per prover context.  Every kernel in kernels.hpp is a functor
+// with `operator()(uint32_t gid)`; `launch(n, f)` runs it over a 1-D grid.
+//
+// Test build (g++ -DBPR1CS_HOSTSIM, tests/hostsim only): the same functors are
+// executed by a plain loop so the pipeline logic can be compared with the oracle
+// in a container that has no GPU.  Never linked into the shipped library.
+#pragma once
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdio.h>
+#include "hd.hpp"
+
+#if defined(BPR1CS_HOSTSIM)
+typedef int dev_stream_t;
+inline void* dev_alloc(size_t n) { return calloc(n ? n : 1, 1); }
+inline void dev_free(void* p) { free(p); }
+inline void dev_h2d(void* d, const void* h, size_t n, dev_stream_t) { memcpy(d, h, n); }
+inline void dev_d2h(void* h, const void* d, size_t n, dev_stream_t) { memcpy(h, d, n); }
+inline void dev_zero(void* d, size_t n, dev_stream_t) { memset(d, 0, n); }
+inline void dev_sync(dev_stream_t) {}
+template <class F>
+inline void launch(uint64_t n, const F& f, dev_stream_t) {
+    for (uint64_t g = 0; g < n; g++) f((uint32_t)g);
+}
+#else
+#include <hip/hip_runtime.h>
+typedef hipStream_t dev_stream_t;
+#define HIPCHK(x)                                                                                  \
+    do {                                                                                           \
+        hipError_t e_ = (x);                                                                       \
+        if (e_ != hipSuccess) {                                                                    \
+            fprintf(stderr, "bpr1cs: HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); \
+            abort();                                                                               \
+        }                                                                                          \
+    } while (0)
+inline void* dev_alloc(size_t n) {
+    void* p = nullptr;
+    HIPCHK(hipMalloc(&p, n ? n : 1));
+    return p;
+}
+inline void dev_free(void* p) {
+    if (p) HIPCHK(hipFree(p));
+}
+inline void dev_h2d(void* d, const void* h, size_t n, dev_stream_t s) {
+    HIPCHK(hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, s));
+    HIPCHK(hipStreamSynchronize(s));
+}
+inline void dev_d2h(void* h, const void* d, size_t n, dev_stream_t s) {
+    HIPCHK(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+}
+inline void dev_zero(void* d, size_t n, dev_stream_t s) { HIPCHK(hipMemsetAsync(d, 0, n, s)); }
+inline void dev_sync(dev_stream_t s) { HIPCHK(hipStreamSynchronize(s)); }
+
+template <class F>
+__global__ void __launch_bounds__(256) k_functor(F f, uint32_t n) {
+    uint32_t g = blockIdx.x * 256u + threadIdx.x;
+    if (g < n) f(g);
+}
+template <class F>
+inline void launch(uint64_t n, const F& f, dev_stream_t s) {
+    if (n == 0) return;
+    if (n > 0xffffffffull) {
+        fprintf(stderr, "bpr1cs: grid too large\n");
+        abort();
+    }
+    uint32_t blocks = (uint32_t)((n + 255) / 256);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_functor<F>), dim3(blocks), dim3(256), 0, s, f, (uint32_t)n);
+    HIPCHK(hipGetLastError());
+}
+#endif
+
+template <class T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    DevBuf() {}
+    explicit DevBuf(size_t count) { alloc(count); }
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    ~DevBuf() { dev_free(p); }
+    void alloc(size_t count) {
+        dev_free(p);
+        n = count;
+        p = (T*)dev_alloc(count * sizeof(T));
+    }
+    size_t bytes() const { return n * sizeof(T); }
+};

@@ -1,0 +1,643 @@
+// Kernel bodies of the batched Bulletproofs R1CS prover.
+//
+// Data layout in HBM: every per-proof vector is stored element-major /
+// proof-minor, X[i*B + b], 32-byte scalars in Montgomery form -> the 64 lanes of
+// a wavefront are 64 consecutive proofs touching one contiguous 2 KiB run.
+// Fixed-base tables: for each base P (B, B~, G_i, H_i) and each of the 32 byte
+// windows k, the 128 affine-Niels multiples j*2^(8k)*P, j=1..128 (96 B each):
+//     tab[(base*32 + k)*128 + (j-1)]
+// Signed radix-256 digits turn s*P into <= 32 mixed additions, no doublings.
+//
+// Each functor is one kernel; `gid` enumerates (index, proof) pairs with the
+// proof index fastest.
+#pragma once
+#include "fe.hpp"
+#include "sc.hpp"
+#include "ge.hpp"
+#include "merlin.hpp"
+
+#define TAB_WINDOWS 32
+#define TAB_ENTRIES 128
+#define TAB_PER_BASE (TAB_WINDOWS * TAB_ENTRIES)
+
+// variable encoding shared with the host front-end (kind<<28 | index)
+#define VK_COMMITTED 0u
+#define VK_LEFT 1u
+#define VK_RIGHT 2u
+#define VK_OUT 3u
+#define VK_ONE 4u
+
+// witness-program operand kinds
+#define WK_LC 0u        // evaluate linear combination #arg
+#define WK_INV_LEFT 1u  // (right wire only) inverse of this multiplier's left wire
+#define WK_BIT 2u       // bit (arg & 0xff) of committed value (arg >> 8)
+#define WK_NOTBIT 3u    // 1 - that bit
+
+// ------------------------------------------------------------ fixed-base core
+// acc += s * Base, s canonical (< l).  Signed byte digits.
+HD inline ge table_mul_acc(ge acc, const ge_niels* tbase, const sc& s) {
+    int carry = 0;
+    for (int k = 0; k < TAB_WINDOWS; k++) {
+        int d = (int)((s.v[k >> 2] >> (8 * (k & 3))) & 0xffu) + carry;
+        carry = d > 127;
+        d -= carry << 8;
+        if (d != 0) {
+            int neg = d < 0;
+            int mag = neg ? -d : d;
+            acc = ge_madd(acc, tbase[k * TAB_ENTRIES + mag - 1], neg);
+        }
+    }
+    return acc;
+}
+
+// s*P for an arbitrary point (double-and-add, MSB first); s canonical
+HD inline ge ge_scalarmul(const ge& P, const sc& s) {
+    ge_cached c = ge_to_cached(P);
+    ge acc = ge_identity();
+    int started = 0;
+    for (int i = 252; i >= 0; i--) {
+        if (started) acc = ge_dbl(acc);
+        if ((s.v[i >> 5] >> (i & 31)) & 1u) {
+            acc = ge_add(acc, c);
+            started = 1;
+        }
+    }
+    return acc;
+}
+
+// ------------------------------------------------------------------- setup
+struct K_gen_points {  // uniform[cnt][64] -> pts[cnt]
+    const uint8_t* uniform;
+    ge* pts;
+    uint8_t* comp;
+    HD void operator()(uint32_t g) const {
+        ge p = ge_from_uniform_bytes(uniform + 64 * (size_t)g);
+        pts[g] = p;
+        ge_compress(p, comp + 32 * (size_t)g);
+    }
+};
+
+struct K_build_table {  // gid = base*32 + k
+    const ge* pts;
+    ge_niels* tab;
+    HD void operator()(uint32_t g) const {
+        uint32_t base = g / TAB_WINDOWS, k = g % TAB_WINDOWS;
+        ge P = pts[base];
+        for (uint32_t t = 0; t < 8 * k; t++) P = ge_dbl(P);
+        ge_cached c = ge_to_cached(P);
+        ge acc = P;
+        ge_niels* out = tab + (size_t)g * TAB_ENTRIES;
+        out[0] = ge_to_niels(acc);
+        for (int j = 1; j < TAB_ENTRIES; j++) {
+            acc = ge_add(acc, c);
+            out[j] = ge_to_niels(acc);
+        }
+    }
+};
+
+// ------------------------------------------------------- inputs / V commitments
+struct K_load_inputs {  // canonical v, vbl [m][B] -> Montgomery copies
+    const sc* v_raw;
+    const sc* vbl_raw;
+    sc* v_m;
+    sc* vbl_m;
+    HD void operator()(uint32_t g) const {
+        v_m[g] = sc_to_mont(v_raw[g]);
+        vbl_m[g] = sc_to_mont(vbl_raw[g]);
+    }
+};
+
+struct K_commit_v {  // gid = j*B + b : V = v*B + vbl*B~   (Prover::commit, P1)
+    const ge_niels* tab;
+    const sc* v_raw;
+    const sc* vbl_raw;
+    uint8_t* out;  // [B][m][32]
+    uint32_t B, m;
+    HD void operator()(uint32_t g) const {
+        uint32_t j = g / B, b = g % B;
+        ge acc = table_mul_acc(ge_identity(), tab, v_raw[g]);
+        acc = table_mul_acc(acc, tab + TAB_PER_BASE, vbl_raw[g]);
+        ge_compress(acc, out + ((size_t)b * m + j) * 32);
+    }
+};
+
+// --------------------------------------------------------------- transcript
+// Transcript::new(label); Prover::new; V appends; "m"; TranscriptRng; all draws.
+struct K_transcript_init {
+    const uint8_t* label;
+    uint32_t label_len;
+    const uint8_t* Vcomp;   // [B][m][32]
+    const sc* vbl_raw;      // [m][B]
+    const uint8_t* seeds;   // [B][32]
+    strobe* tr;             // [B]
+    sc* blind;              // [8][B]: i_bl o_bl s_bl t1 t3 t4 t5 t6
+    sc* sL;                 // [n][B]
+    sc* sR;                 // [n][B]
+    uint32_t B, m, n;
+    HD void operator()(uint32_t b) const {
+        strobe s;
+        merlin_new(s, label, label_len);
+        merlin_append(s, "dom-sep", 7, (const uint8_t*)"r1cs v1", 7);
+        for (uint32_t j = 0; j < m; j++) merlin_append(s, "V", 1, Vcomp + ((size_t)b * m + j) * 32, 32);
+        merlin_append_u64(s, "m", 1, m);
+        tr[b] = s;
+        strobe r = s;
+        for (uint32_t j = 0; j < m; j++) {
+            uint8_t w[32];
+            sc_store_raw(vbl_raw[(size_t)j * B + b], w);
+            merlin_rng_rekey(r, "v_blinding", 10, w, 32);
+        }
+        merlin_rng_finalize(r, seeds + 32 * (size_t)b);
+        for (int k = 0; k < 3; k++) blind[(size_t)k * B + b] = merlin_rng_scalar(r);
+        for (uint32_t i = 0; i < n; i++) sL[(size_t)i * B + b] = merlin_rng_scalar(r);
+        for (uint32_t i = 0; i < n; i++) sR[(size_t)i * B + b] = merlin_rng_scalar(r);
+        for (int k = 3; k < 8; k++) blind[(size_t)k * B + b] = merlin_rng_scalar(r);
+    }
+};
+
+// append A_I1 A_O1 S1, 1-phase dom-sep, identity x3 -> y, z ; y^-1
+struct K_transcript_A {
+    strobe* tr;
+    const uint8_t* AOS;  // [3][B][32]
+    sc* chal;            // [CH_*][B]
+    uint32_t B;
+    HD void operator()(uint32_t b) const {
+        strobe s = tr[b];
+        merlin_append(s, "A_I1", 4, AOS + ((size_t)0 * B + b) * 32, 32);
+        merlin_append(s, "A_O1", 4, AOS + ((size_t)1 * B + b) * 32, 32);
+        merlin_append(s, "S1", 2, AOS + ((size_t)2 * B + b) * 32, 32);
+        merlin_append(s, "dom-sep", 7, (const uint8_t*)"r1cs-1phase", 11);
+        uint8_t id[32];
+        for (int i = 0; i < 32; i++) id[i] = 0;
+        merlin_append(s, "A_I2", 4, id, 32);
+        merlin_append(s, "A_O2", 4, id, 32);
+        merlin_append(s, "S2", 2, id, 32);
+        sc y = merlin_challenge_scalar(s, "y", 1);
+        sc z = merlin_challenge_scalar(s, "z", 1);
+        tr[b] = s;
+        chal[0 * (size_t)B + b] = y;
+        chal[1 * (size_t)B + b] = z;
+        chal[2 * (size_t)B + b] = sc_invert(y);
+    }
+};
+#define CH_Y 0
+#define CH_Z 1
+#define CH_YINV 2
+#define CH_U 3
+#define CH_X 4
+#define CH_W 5
+#define CH_COUNT 6
+
+// two-level power tables: lo[t] = x^t (t<256), hi[h] = x^(256h) (h<H)
+struct K_pow_tables {  // gid = which*B + b ; which: 0=y 1=yinv 2=z
+    const sc* chal;
+    sc* lo;  // [3][256][B]
+    sc* hi;  // [3][H][B]
+    uint32_t B, H;
+    HD void operator()(uint32_t g) const {
+        uint32_t which = g / B, b = g % B;
+        const uint32_t src[3] = {CH_Y, CH_YINV, CH_Z};
+        sc x = chal[(size_t)src[which] * B + b];
+        sc* l = lo + (size_t)which * 256 * B;
+        sc* h = hi + (size_t)which * H * B;
+        sc p = sc_one_mont();
+        for (uint32_t t = 0; t < 256; t++) {
+            l[(size_t)t * B + b] = p;
+            p = sc_mul(p, x);
+        }
+        sc x256 = p, q = sc_one_mont();
+        for (uint32_t t = 0; t < H; t++) {
+            h[(size_t)t * B + b] = q;
+            q = sc_mul(q, x256);
+        }
+    }
+};
+HD inline sc pow_lookup(const sc* lo, const sc* hi, uint32_t which, uint32_t H, uint32_t B, uint32_t e, uint32_t b) {
+    const sc* l = lo + (size_t)which * 256 * B;
+    const sc* h = hi + (size_t)which * H * B;
+    return sc_mul(l[(size_t)(e & 255u) * B + b], h[(size_t)(e >> 8) * B + b]);
+}
+
+// --------------------------------------------------------------- witness VM
+// One multiplier per op: left/right operands by recipe, out = left*right.
+struct WOp {
+    uint32_t lkind, larg, rkind, rarg;
+};
+struct K_witness {  // thread per proof (sequential program)
+    const WOp* ops;
+    const uint32_t* lc_off;
+    const uint32_t* lc_var;
+    const sc* lc_coeff;  // Montgomery
+    const sc* v_raw;     // [m][B]
+    const sc* v_m;       // [m][B]
+    sc* W;               // [3][n][B] a_L a_R a_O
+    uint32_t B, n;
+    HD sc value(uint32_t var, uint32_t b) const {
+        uint32_t kind = var >> 28, idx = var & 0x0fffffffu;
+        if (kind == VK_COMMITTED) return v_m[(size_t)idx * B + b];
+        if (kind == VK_ONE) return sc_one_mont();
+        return W[((size_t)(kind - 1) * n + idx) * B + b];
+    }
+    HD sc operand(uint32_t kind, uint32_t arg, uint32_t b) const {
+        if (kind == WK_LC) {
+            sc acc = sc_zero();
+            for (uint32_t t = lc_off[arg]; t < lc_off[arg + 1]; t++) acc = sc_add(acc, sc_mul(lc_coeff[t], value(lc_var[t], b)));
+            return acc;
+        }
+        sc raw = v_raw[(size_t)(arg >> 8) * B + b];
+        uint32_t k = arg & 0xffu;
+        uint32_t bit = (raw.v[k >> 5] >> (k & 31)) & 1u;
+        if (kind == WK_NOTBIT) bit ^= 1u;
+        return bit ? sc_one_mont() : sc_zero();
+    }
+    HD void operator()(uint32_t b) const {
+        for (uint32_t i = 0; i < n; i++) {
+            WOp op = ops[i];
+            sc l = operand(op.lkind, op.larg, b);
+            W[((size_t)0 * n + i) * B + b] = l;
+            sc r = (op.rkind == WK_INV_LEFT) ? sc_invert(l) : operand(op.rkind, op.rarg, b);
+            W[((size_t)1 * n + i) * B + b] = r;
+            W[((size_t)2 * n + i) * B + b] = sc_mul(l, r);
+        }
+    }
+};
+struct K_load_wires {  // host-synthesised a_L a_R a_O (canonical) -> Montgomery
+    const sc* raw;
+    sc* W;
+    HD void operator()(uint32_t g) const { W[g] = sc_to_mont(raw[g]); }
+};
+
+// ---------------------------------------------------------- fixed-base MSM
+// Segment: ordinal o in [0,count) -> element index i = (o / run)*period + off + (o % run);
+// scalar = scal[i*B + b], base = base0 + i.
+struct MsmSeg {
+    const sc* scal;
+    uint32_t count, run, period, off, base0, mont;
+};
+struct K_msm_fixed {  // gid = c*B + b -> partial[c*B + b]
+    const ge_niels* tab;
+    MsmSeg seg[2];
+    ge* partial;
+    uint32_t B, chunk;  // ordinals per chunk over the concatenated segments
+    HD void operator()(uint32_t g) const {
+        uint32_t c = g / B, b = g % B;
+        uint32_t total = seg[0].count + seg[1].count;
+        uint32_t lo = c * chunk, hi = lo + chunk < total ? lo + chunk : total;
+        ge acc = ge_identity();
+        for (uint32_t o = lo; o < hi; o++) {
+            const MsmSeg& s = o < seg[0].count ? seg[0] : seg[1];
+            uint32_t oo = o < seg[0].count ? o : o - seg[0].count;
+            uint32_t i = (oo / s.run) * s.period + s.off + (oo % s.run);
+            sc x = s.scal[(size_t)i * B + b];
+            if (s.mont) x = sc_from_mont(x);
+            acc = table_mul_acc(acc, tab + (size_t)(s.base0 + i) * TAB_PER_BASE, x);
+        }
+        partial[g] = acc;
+    }
+};
+// sum of partials + extra*Base(extra_base) -> compressed (and optional extended copy)
+struct K_msm_finish {  // gid = b
+    const ge_niels* tab;
+    const ge* partial;    // [nchunks][B]
+    const sc* extra;      // [B] Montgomery, may be null
+    const sc* extra2;     // optional second factor (extra*extra2), Montgomery
+    uint8_t* out;         // [B][32]
+    uint32_t B, nchunks, extra_base;
+    HD void operator()(uint32_t b) const {
+        ge acc = ge_identity();
+        for (uint32_t c = 0; c < nchunks; c++) acc = ge_add_ge(acc, partial[(size_t)c * B + b]);
+        if (extra) {
+            sc e = extra[b];
+            e = extra2 ? sc_from_mont(sc_mul(e, extra2[b])) : sc_from_mont(e);
+            acc = table_mul_acc(acc, tab + (size_t)extra_base * TAB_PER_BASE, e);
+        }
+        ge_compress(acc, out + 32 * (size_t)b);
+    }
+};
+
+// ------------------------------------------------------ constraints / polys
+// wvec[s][b] = sum over entries (j, c) of slot s : z^(j+1) * c   (slots 3n.. are wV, negated)
+struct K_flatten {  // gid = s*B + b
+    const uint32_t* slot_off;
+    const uint32_t* ent_row;
+    const sc* ent_coeff;  // Montgomery
+    const sc* plo;
+    const sc* phi;
+    sc* wvec;  // [3n+m][B]
+    uint32_t B, H, n3;
+    HD void operator()(uint32_t g) const {
+        uint32_t s = g / B, b = g % B;
+        sc acc = sc_zero();
+        for (uint32_t t = slot_off[s]; t < slot_off[s + 1]; t++)
+            acc = sc_add(acc, sc_mul(pow_lookup(plo, phi, 2, H, B, ent_row[t] + 1, b), ent_coeff[t]));
+        wvec[g] = s >= n3 ? sc_neg(acc) : acc;
+    }
+};
+
+struct K_tcoef_partial {  // gid = c*B + b -> part[k][c][b], k<6
+    const sc* W;     // [5][n][B] a_L a_R a_O s_L s_R
+    const sc* wvec;  // wL wR wO
+    const sc* plo;
+    const sc* phi;
+    sc* part;  // [6][C][B]
+    uint32_t B, H, n, chunk, C;
+    HD void operator()(uint32_t g) const {
+        uint32_t c = g / B, b = g % B;
+        uint32_t lo = c * chunk, hi = lo + chunk < n ? lo + chunk : n;
+        sc t1 = sc_zero(), t2 = t1, t3 = t1, t4 = t1, t5 = t1, t6 = t1;
+        for (uint32_t i = lo; i < hi; i++) {
+            size_t ib = (size_t)i * B + b, nb = (size_t)n * B;
+            sc yi = pow_lookup(plo, phi, 0, H, B, i, b), yinv = pow_lookup(plo, phi, 1, H, B, i, b);
+            sc aL = W[ib], aR = W[nb + ib], aO = W[2 * nb + ib], sL = W[3 * nb + ib], sR = W[4 * nb + ib];
+            sc wL = wvec[ib], wR = wvec[nb + ib], wO = wvec[2 * nb + ib];
+            sc l1 = sc_add(aL, sc_mul(yinv, wR)), l2 = aO, l3 = sL;
+            sc r0 = sc_sub(wO, yi), r1 = sc_add(sc_mul(yi, aR), wL), r3 = sc_mul(yi, sR);
+            t1 = sc_add(t1, sc_mul(l1, r0));
+            t2 = sc_add(t2, sc_add(sc_mul(l1, r1), sc_mul(l2, r0)));
+            t3 = sc_add(t3, sc_add(sc_mul(l2, r1), sc_mul(l3, r0)));
+            t4 = sc_add(t4, sc_add(sc_mul(l1, r3), sc_mul(l3, r1)));
+            t5 = sc_add(t5, sc_mul(l2, r3));
+            t6 = sc_add(t6, sc_mul(l3, r3));
+        }
+        size_t cb = (size_t)C * B;
+        part[0 * cb + g] = t1; part[1 * cb + g] = t2; part[2 * cb + g] = t3;
+        part[3 * cb + g] = t4; part[4 * cb + g] = t5; part[5 * cb + g] = t6;
+    }
+};
+struct K_sum_partials {  // gid = k*B + b : out[k][b] = sum_c part[k][c][b]
+    const sc* part;
+    sc* out;
+    uint32_t B, C;
+    HD void operator()(uint32_t g) const {
+        uint32_t k = g / B, b = g % B;
+        sc acc = sc_zero();
+        for (uint32_t c = 0; c < C; c++) acc = sc_add(acc, part[((size_t)k * C + c) * B + b]);
+        out[g] = acc;
+    }
+};
+
+struct K_commit_T {  // gid = k*B + b, k<5 : T = t*B + tau*B~  (t1,t3,t4,t5,t6)
+    const ge_niels* tab;
+    const sc* tco;    // [6][B]
+    const sc* blind;  // [8][B]
+    uint8_t* out;     // [5][B][32]
+    uint32_t B;
+    HD void operator()(uint32_t g) const {
+        uint32_t k = g / B, b = g % B;
+        const uint32_t ti[5] = {0, 2, 3, 4, 5};
+        ge acc = table_mul_acc(ge_identity(), tab, sc_from_mont(tco[(size_t)ti[k] * B + b]));
+        acc = table_mul_acc(acc, tab + TAB_PER_BASE, sc_from_mont(blind[(size_t)(3 + k) * B + b]));
+        ge_compress(acc, out + 32 * (size_t)g);
+    }
+};
+
+// append T_*, u, x ; t_x, t_x_blinding, e_blinding ; w ; ipp dom-sep + n
+struct K_transcript_T {
+    strobe* tr;
+    const uint8_t* Tc;   // [5][B][32]
+    const sc* tco;       // [6][B]
+    const sc* blind;     // [8][B]
+    const sc* wV;        // [m][B]
+    const sc* vbl_m;     // [m][B]
+    sc* chal;
+    sc* txs;             // [3][B] t_x, t_x_blinding, e_blinding (Montgomery)
+    uint32_t B, m;
+    uint64_t padded_n;
+    HD void operator()(uint32_t b) const {
+        strobe s = tr[b];
+        merlin_append(s, "T_1", 3, Tc + ((size_t)0 * B + b) * 32, 32);
+        merlin_append(s, "T_3", 3, Tc + ((size_t)1 * B + b) * 32, 32);
+        merlin_append(s, "T_4", 3, Tc + ((size_t)2 * B + b) * 32, 32);
+        merlin_append(s, "T_5", 3, Tc + ((size_t)3 * B + b) * 32, 32);
+        merlin_append(s, "T_6", 3, Tc + ((size_t)4 * B + b) * 32, 32);
+        sc u = merlin_challenge_scalar(s, "u", 1);
+        sc x = merlin_challenge_scalar(s, "x", 1);
+        sc t2b = sc_zero();
+        for (uint32_t j = 0; j < m; j++) t2b = sc_add(t2b, sc_mul(wV[(size_t)j * B + b], vbl_m[(size_t)j * B + b]));
+        sc t[6], tb[6];
+        for (int k = 0; k < 6; k++) t[k] = tco[(size_t)k * B + b];
+        tb[0] = blind[(size_t)3 * B + b]; tb[1] = t2b;
+        for (int k = 2; k < 6; k++) tb[k] = blind[(size_t)(2 + k) * B + b];
+        sc tx = t[5], txb = tb[5];
+        for (int k = 4; k >= 0; k--) {
+            tx = sc_add(t[k], sc_mul(x, tx));
+            txb = sc_add(tb[k], sc_mul(x, txb));
+        }
+        tx = sc_mul(x, tx);
+        txb = sc_mul(x, txb);
+        sc ib = blind[(size_t)0 * B + b], ob = blind[(size_t)1 * B + b], sb = blind[(size_t)2 * B + b];
+        sc eb = sc_mul(x, sc_add(ib, sc_mul(x, sc_add(ob, sc_mul(x, sb)))));
+        merlin_append_scalar(s, "t_x", 3, tx);
+        merlin_append_scalar(s, "t_x_blinding", 12, txb);
+        merlin_append_scalar(s, "e_blinding", 10, eb);
+        sc w = merlin_challenge_scalar(s, "w", 1);
+        merlin_append(s, "dom-sep", 7, (const uint8_t*)"ipp v1", 6);
+        merlin_append_u64(s, "n", 1, padded_n);
+        tr[b] = s;
+        chal[(size_t)CH_U * B + b] = u;
+        chal[(size_t)CH_X * B + b] = x;
+        chal[(size_t)CH_W * B + b] = w;
+        txs[(size_t)0 * B + b] = tx; txs[(size_t)1 * B + b] = txb; txs[(size_t)2 * B + b] = eb;
+    }
+};
+
+// l(x), r(x) padded to N ; IPA factor vectors cG = G_factors, cH = H_factors
+struct K_lr_eval {  // gid = i*B + b, i < N
+    const sc* W;
+    const sc* wvec;
+    const sc* plo;
+    const sc* phi;
+    const sc* chal;
+    sc* a;   // [N][B]
+    sc* bb;  // [N][B]
+    sc* cG;  // [N][B]
+    sc* cH;  // [N][B]
+    uint32_t B, H, n;
+    HD void operator()(uint32_t g) const {
+        uint32_t i = g / B, b = g % B;
+        sc yi = pow_lookup(plo, phi, 0, H, B, i, b), yinv = pow_lookup(plo, phi, 1, H, B, i, b);
+        sc x = chal[(size_t)CH_X * B + b];
+        if (i < n) {
+            size_t ib = (size_t)i * B + b, nb = (size_t)n * B;
+            sc aL = W[ib], aR = W[nb + ib], aO = W[2 * nb + ib], sL = W[3 * nb + ib], sR = W[4 * nb + ib];
+            sc wL = wvec[ib], wR = wvec[nb + ib], wO = wvec[2 * nb + ib];
+            sc l1 = sc_add(aL, sc_mul(yinv, wR));
+            sc r0 = sc_sub(wO, yi), r1 = sc_add(sc_mul(yi, aR), wL), r3 = sc_mul(yi, sR);
+            a[g] = sc_mul(x, sc_add(l1, sc_mul(x, sc_add(aO, sc_mul(x, sL)))));
+            bb[g] = sc_add(r0, sc_mul(x, sc_add(r1, sc_mul(x, sc_mul(x, r3)))));
+            cG[g] = sc_one_mont();
+            cH[g] = yinv;
+        } else {
+            a[g] = sc_zero();
+            bb[g] = sc_neg(yi);
+            sc u = chal[(size_t)CH_U * B + b];
+            cG[g] = u;
+            cH[g] = sc_mul(yinv, u);
+        }
+    }
+};
+
+// --------------------------------------------------------------------- IPA
+struct K_ipa_cross {  // gid = c*B + b -> part[0][c][b] = <a_lo,b_hi>, part[1][c][b] = <a_hi,b_lo>
+    const sc* a;
+    const sc* bb;
+    sc* part;  // [2][C][B]
+    uint32_t B, m, chunk, C;
+    HD void operator()(uint32_t g) const {
+        uint32_t c = g / B, b = g % B;
+        uint32_t lo = c * chunk, hi = lo + chunk < m ? lo + chunk : m;
+        sc cl = sc_zero(), cr = sc_zero();
+        for (uint32_t j = lo; j < hi; j++) {
+            size_t jl = (size_t)j * B + b, jh = (size_t)(j + m) * B + b;
+            cl = sc_add(cl, sc_mul(a[jl], bb[jh]));
+            cr = sc_add(cr, sc_mul(a[jh], bb[jl]));
+        }
+        part[(size_t)0 * C * B + g] = cl;
+        part[(size_t)1 * C * B + g] = cr;
+    }
+};
+// scalars of the un-folded generators for round k (canonical form, ready for the table MSM)
+struct K_ipa_scalars {  // gid = i*B + b, i<N
+    const sc* a;
+    const sc* bb;
+    const sc* cG;
+    const sc* cH;
+    sc* sG;
+    sc* sH;
+    uint32_t B, Nk;
+    HD void operator()(uint32_t g) const {
+        uint32_t i = g / B, b = g % B, m = Nk >> 1;
+        uint32_t pos = i & (Nk - 1);
+        uint32_t partner = pos >= m ? pos - m : pos + m;
+        size_t pb = (size_t)partner * B + b;
+        sG[g] = sc_from_mont(sc_mul(a[pb], cG[g]));
+        sH[g] = sc_from_mont(sc_mul(bb[pb], cH[g]));
+    }
+};
+struct K_transcript_LR {  // append L,R -> u_k, u_k^-1
+    strobe* tr;
+    const uint8_t* LR;  // [2][B][32] for this round
+    sc* uk;             // [2][B] for this round: u, u^-1
+    uint32_t B;
+    HD void operator()(uint32_t b) const {
+        strobe s = tr[b];
+        merlin_append(s, "L", 1, LR + ((size_t)0 * B + b) * 32, 32);
+        merlin_append(s, "R", 1, LR + ((size_t)1 * B + b) * 32, 32);
+        sc u = merlin_challenge_scalar(s, "u", 1);
+        tr[b] = s;
+        uk[b] = u;
+        uk[(size_t)B + b] = sc_invert(u);
+    }
+};
+struct K_ipa_fold_ab {  // gid = j*B + b, j<m
+    sc* a;
+    sc* bb;
+    const sc* uk;
+    uint32_t B, m;
+    HD void operator()(uint32_t g) const {
+        uint32_t b = g % B;
+        size_t hi = g + (size_t)m * B;
+        sc u = uk[b], ui = uk[(size_t)B + b];
+        a[g] = sc_add(sc_mul(a[g], u), sc_mul(ui, a[hi]));
+        bb[g] = sc_add(sc_mul(bb[g], ui), sc_mul(u, bb[hi]));
+    }
+};
+struct K_ipa_update_c {  // gid = i*B + b, i<N : fold factors of the original generators
+    sc* cG;
+    sc* cH;
+    const sc* uk;
+    uint32_t B, Nk;
+    HD void operator()(uint32_t g) const {
+        uint32_t i = g / B, b = g % B, m = Nk >> 1;
+        int hi = (i & (Nk - 1)) >= m;
+        sc u = uk[b], ui = uk[(size_t)B + b];
+        cG[g] = sc_mul(cG[g], hi ? u : ui);
+        cH[g] = sc_mul(cH[g], hi ? ui : u);
+    }
+};
+// materialise the folded generators of round r straight from the tables
+struct K_ipa_fold_from_tables {  // gid = (side*M + j)*B + b
+    const ge_niels* tab;
+    const sc* cG;
+    const sc* cH;
+    ge* GH;  // [2][M][B]
+    uint32_t B, M, N, baseG, baseH;
+    HD void operator()(uint32_t g) const {
+        uint32_t b = g % B, sj = g / B, side = sj / M, j = sj % M;
+        const sc* c = side ? cH : cG;
+        uint32_t base0 = side ? baseH : baseG;
+        ge acc = ge_identity();
+        for (uint32_t i = j; i < N; i += M)
+            acc = table_mul_acc(acc, tab + (size_t)(base0 + i) * TAB_PER_BASE, sc_from_mont(c[(size_t)i * B + b]));
+        GH[g] = acc;
+    }
+};
+struct K_ipa_vb_mul {  // gid = (w*m + j)*B + b, w<4
+    const sc* a;
+    const sc* bb;
+    const ge* GH;  // [2][M][B] (current size 2m used)
+    ge* tmp;       // [4][m][B]
+    uint32_t B, m, M;
+    HD void operator()(uint32_t g) const {
+        uint32_t b = g % B, wj = g / B, w = wj / m, j = wj % m;
+        const ge* G = GH;
+        const ge* Hh = GH + (size_t)M * B;
+        sc s;
+        ge P;
+        if (w == 0) { s = a[(size_t)j * B + b]; P = G[(size_t)(m + j) * B + b]; }
+        else if (w == 1) { s = bb[(size_t)(m + j) * B + b]; P = Hh[(size_t)j * B + b]; }
+        else if (w == 2) { s = a[(size_t)(m + j) * B + b]; P = G[(size_t)j * B + b]; }
+        else { s = bb[(size_t)j * B + b]; P = Hh[(size_t)(m + j) * B + b]; }
+        tmp[g] = ge_scalarmul(P, sc_from_mont(s));
+    }
+};
+struct K_ipa_vb_reduce {  // gid = (out*VC + c)*B + b ; out: 0=L (w 0,1) 1=R (w 2,3)
+    const ge* tmp;
+    ge* partial;  // [2][VC][B]
+    uint32_t B, m, VC;
+    HD void operator()(uint32_t g) const {
+        uint32_t b = g % B, oc = g / B, out = oc / VC, c = oc % VC;
+        uint32_t total = 2 * m, per = (total + VC - 1) / VC;
+        uint32_t lo = c * per, hi = lo + per < total ? lo + per : total;
+        ge acc = ge_identity();
+        for (uint32_t o = lo; o < hi; o++) acc = ge_add_ge(acc, tmp[((size_t)(2 * out) * m + o) * B + b]);
+        partial[g] = acc;
+    }
+};
+struct K_ipa_vb_fold {  // gid = (side*m + j)*B + b
+    ge* GH;
+    const sc* uk;
+    uint32_t B, m, M;
+    HD void operator()(uint32_t g) const {
+        uint32_t b = g % B, sj = g / B, side = sj / m, j = sj % m;
+        ge* P = GH + (size_t)side * M * B;
+        sc u = sc_from_mont(uk[b]), ui = sc_from_mont(uk[(size_t)B + b]);
+        ge lo = P[(size_t)j * B + b], hi = P[(size_t)(j + m) * B + b];
+        ge r = side ? ge_add_ge(ge_scalarmul(lo, u), ge_scalarmul(hi, ui))
+                    : ge_add_ge(ge_scalarmul(lo, ui), ge_scalarmul(hi, u));
+        P[(size_t)j * B + b] = r;
+    }
+};
+
+// ---------------------------------------------------------------- proof out
+struct K_assemble {  // gid = b
+    const uint8_t* AOS;  // [3][B][32]
+    const uint8_t* Tc;   // [5][B][32]
+    const sc* txs;       // [3][B]
+    const uint8_t* LR;   // [lgN][2][B][32]
+    const sc* a;
+    const sc* bb;
+    uint8_t* out;        // [B][len]
+    uint32_t B, lgN, len;
+    HD void operator()(uint32_t b) const {
+        uint8_t* o = out + (size_t)b * len;
+        *o++ = 0;
+        for (int k = 0; k < 3; k++) { for (int t = 0; t < 32; t++) o[t] = AOS[((size_t)k * B + b) * 32 + t]; o += 32; }
+        for (int k = 0; k < 5; k++) { for (int t = 0; t < 32; t++) o[t] = Tc[((size_t)k * B + b) * 32 + t]; o += 32; }
+        for (int k = 0; k < 3; k++) { sc_mont_tobytes(txs[(size_t)k * B + b], o); o += 32; }
+        for (uint32_t k = 0; k < lgN; k++)
+            for (int lr = 0; lr < 2; lr++) { for (int t = 0; t < 32; t++) o[t] = LR[(((size_t)k * 2 + lr) * B + b) * 32 + t]; o += 32; }
+        sc_mont_tobytes(a[b], o); o += 32;
+        sc_mont_tobytes(bb[b], o);
+    }
+};

@@ -1,0 +1,126 @@
+/* bpr1cs.h — C ABI of the MI355X-native Bulletproofs R1CS prover hot path.
+ *
+ * Drop-in boundary for lovesh/bulletproofs-r1cs-gadgets.  The reference has no
+ * FFI: its gadgets are generic over the Rust trait `bulletproofs::r1cs::
+ * ConstraintSystem` and the hot path sits behind `Prover::commit` /
+ * `Prover::prove` (reference src/gadget_vsmt_4.rs:393,434).  A
+ * patched `bulletproofs` crate (or this repo's C++ front-end, which mirrors the
+ * trait) forwards to the entry points below — see INTEGRATION.md for the Rust
+ * `extern "C"` binding.
+ *
+ * Conventions: all scalars and points are 32-byte little-endian canonical
+ * encodings (Scalar::to_bytes / CompressedRistretto); all buffers are
+ * caller-owned host memory unless a name ends in `_dev`; return 0 = OK,
+ * negative = bpr1cs_error (mirrors R1CSError).  No exceptions cross the ABI.
+ * Handles may be used from one thread at a time; distinct handles are
+ * independent.  There is NO CPU fallback: every compute entry point fails with
+ * BPR1CS_ERR_NO_DEVICE when no gfx950 device is visible.
+ */
+#ifndef BPR1CS_H
+#define BPR1CS_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    BPR1CS_OK = 0,
+    BPR1CS_ERR_INVALID_GENERATORS_LENGTH = -1, /* R1CSError::InvalidGeneratorsLength */
+    BPR1CS_ERR_FORMAT = -2,                    /* R1CSError::FormatError            */
+    BPR1CS_ERR_VERIFICATION = -3,              /* R1CSError::VerificationError      */
+    BPR1CS_ERR_MISSING_ASSIGNMENT = -4,        /* R1CSError::MissingAssignment      */
+    BPR1CS_ERR_GADGET = -5,                    /* R1CSError::GadgetError            */
+    BPR1CS_ERR_NO_DEVICE = -16,
+    BPR1CS_ERR_INVALID_ARGUMENT = -17
+} bpr1cs_error;
+
+typedef struct bpr1cs_gens bpr1cs_gens;       /* PedersenGens::default() + BulletproofGens::new(cap, 1) */
+typedef struct bpr1cs_circuit bpr1cs_circuit; /* the constraint system a Prover holds when prove() is called */
+
+/* Variable encoding used in constraint terms: (kind << 28) | index. */
+#define BPR1CS_VAR_COMMITTED 0u /* Variable::Committed(i)        */
+#define BPR1CS_VAR_MUL_LEFT 1u  /* Variable::MultiplierLeft(i)   */
+#define BPR1CS_VAR_MUL_RIGHT 2u /* Variable::MultiplierRight(i)  */
+#define BPR1CS_VAR_MUL_OUT 3u   /* Variable::MultiplierOutput(i) */
+#define BPR1CS_VAR_ONE 4u       /* Variable::One()               */
+
+/* Witness-program operand kinds (device-side constraint synthesis). */
+#define BPR1CS_W_LC 0u       /* value of linear combination #arg (cs.multiply / evaluate_lc)   */
+#define BPR1CS_W_INV_LEFT 1u /* right wire = inverse of this multiplier's left wire (Inverse S-box, gadget_poseidon.rs:160-166) */
+#define BPR1CS_W_BIT 2u      /* bit (arg & 0xff) of committed value (arg >> 8)  (gadget_vsmt_4.rs:226-238, r1cs_utils.rs:28-31) */
+#define BPR1CS_W_NOTBIT 3u   /* 1 - that bit */
+
+typedef struct {
+    uint32_t lkind, larg, rkind, rarg;
+} bpr1cs_wop;
+
+typedef struct {
+    uint32_t n; /* multipliers (len a_L)          */
+    uint32_t q; /* constraints                    */
+    uint32_t m; /* committed variables V          */
+    /* constraints, CSR by row: terms of constraint j are [row_off[j], row_off[j+1]) */
+    const uint32_t* row_off;   /* q+1 */
+    const uint32_t* term_var;  /* nnz : (kind<<28)|index */
+    const uint8_t* term_coeff; /* nnz * 32 */
+    /* optional witness program (NULL -> caller must pass wires to prove_batch) */
+    const bpr1cs_wop* wops;   /* n */
+    uint32_t n_lc;            /* number of linear combinations referenced by wops */
+    const uint32_t* lc_off;   /* n_lc+1 */
+    const uint32_t* lc_var;   /* terms */
+    const uint8_t* lc_coeff;  /* terms * 32 */
+} bpr1cs_circuit_desc;
+
+/* number of visible gfx950 devices (0 when none) */
+int bpr1cs_device_count(void);
+/* select the HIP device used by handles created afterwards on this thread */
+int bpr1cs_set_device(int ordinal);
+
+/* PedersenGens::default() + BulletproofGens::new(gens_capacity, 1)
+ * (reference src/gadget_vsmt_4.rs:386-387); builds the fixed-base tables in HBM. */
+int bpr1cs_gens_create(uint32_t gens_capacity, bpr1cs_gens** out);
+void bpr1cs_gens_destroy(bpr1cs_gens* g);
+uint32_t bpr1cs_gens_capacity(const bpr1cs_gens* g);
+/* which: 0 = B, 1 = B_blinding, 2 = G[i], 3 = H[i]; compressed encoding */
+int bpr1cs_gens_point(const bpr1cs_gens* g, int which, uint32_t i, uint8_t out[32]);
+
+int bpr1cs_circuit_create(const bpr1cs_circuit_desc* desc, bpr1cs_circuit** out);
+void bpr1cs_circuit_destroy(bpr1cs_circuit* c);
+/* proof length in bytes: 1 + 32*(13 + 2*lg(next_pow2(n))) */
+size_t bpr1cs_proof_len(const bpr1cs_circuit* c);
+
+/* Batched Prover::commit x m  +  gadget synthesis  +  Prover::prove
+ * (reference src/gadget_vsmt_4.rs:390-434), one independent transcript per proof.
+ *   label              Transcript::new(label)
+ *   values             batch * m * 32   committed values, proof-major
+ *   v_blindings        batch * m * 32
+ *   rng_seeds          batch * 32       the 32 bytes upstream draws from thread_rng()
+ *                                       in TranscriptRng::finalize (made explicit)
+ *   wires              NULL (run the circuit's witness program on the device) or
+ *                      batch * 3 * n * 32 : a_L | a_R | a_O per proof
+ *   proofs_out         batch * bpr1cs_proof_len
+ *   commitments_out    batch * m * 32 (may be NULL)
+ */
+int bpr1cs_prove_batch(const bpr1cs_gens* g, const bpr1cs_circuit* c, const uint8_t* label, size_t label_len,
+                       const uint8_t* values, const uint8_t* v_blindings, const uint8_t* rng_seeds,
+                       const uint8_t* wires, size_t batch, uint8_t* proofs_out, uint8_t* commitments_out);
+
+/* Low-level, for parity tests and a Rust shim: out = sum_t scalars[t] * Base(bases[t])
+ * for `batch` independent scalar vectors over the SAME fixed bases; base index:
+ * 0 = B, 1 = B_blinding, 2+i = G[i], 2+capacity+i = H[i].
+ * (replaces RistrettoPoint::multiscalar_mul over the generators). */
+int bpr1cs_msm_fixed(const bpr1cs_gens* g, const uint32_t* bases, size_t terms, const uint8_t* scalars /* batch*terms*32 */,
+                     size_t batch, uint8_t* out /* batch*32 */);
+
+/* tuning knob: IPA rounds computed from the un-folded generator tables before the
+ * folded generators are materialised (default 4; clamped to lg N) */
+void bpr1cs_set_unfold_rounds(int r);
+
+/* last prove_batch phase timings in milliseconds (HIP events), for bench.py:
+ * [0]=total [1]=commitV+transcript/rng [2]=witness [3]=commit MSMs [4]=polys [5]=IPA; returns count */
+int bpr1cs_last_timings(float* out, int cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
