@@ -1,0 +1,116 @@
+// Instruction- and primitive-level throughput microbenchmark for gfx950.
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -I../bulletproofs-r1cs-gadgets_amd/csrc ubench.hip -o ubench
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdint.h>
+#include "fe.hpp"
+#include "sc.hpp"
+#include "ge.hpp"
+#define CHK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s line %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
+#define ITER 4096
+
+template <int OP>
+__global__ void __launch_bounds__(256) k_inst(uint32_t* out, uint32_t seed) {
+    uint32_t t = threadIdx.x + blockIdx.x * 256;
+    uint64_t a0 = t * 3 + seed, a1 = t * 5 + 1, a2 = t * 7 + 2, a3 = t * 11 + 3, a4 = t + 9, a5 = t + 17, a6 = t ^ 0x55, a7 = t ^ 0x99;
+    uint32_t x = t | 1, y = (t * 2654435761u) | 1;
+    double d0 = t, d1 = t + 1, d2 = t + 2, d3 = t + 3, d4 = t + 4, d5 = t + 5, d6 = t + 6, d7 = t + 7, dx = 1.0000001, dy = 0.5;
+    for (int i = 0; i < ITER; i++) {
+        if (OP == 0) {  // v_mad_u64_u32, 8 independent chains
+#define M(a) asm volatile("v_mad_u64_u32 %0, s[2:3], %1, %2, %0" : "+v"(a) : "v"(x), "v"(y) : "s2", "s3");
+            M(a0) M(a1) M(a2) M(a3) M(a4) M(a5) M(a6) M(a7)
+#undef M
+        } else if (OP == 1) {  // v_mul_lo_u32
+#define M(a) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(*(uint32_t*)&a) : "v"(y));
+            M(a0) M(a1) M(a2) M(a3) M(a4) M(a5) M(a6) M(a7)
+#undef M
+        } else if (OP == 2) {  // v_mul_hi_u32
+#define M(a) asm volatile("v_mul_hi_u32 %0, %0, %1" : "+v"(*(uint32_t*)&a) : "v"(y));
+            M(a0) M(a1) M(a2) M(a3) M(a4) M(a5) M(a6) M(a7)
+#undef M
+        } else if (OP == 3) {  // v_lshl_add_u64
+#define M(a) asm volatile("v_lshl_add_u64 %0, %0, 0, %1" : "+v"(a) : "v"(a7));
+            M(a0) M(a1) M(a2) M(a3) M(a4) M(a5) M(a6) M(a0)
+#undef M
+        } else if (OP == 4) {  // v_add_u32
+#define M(a) asm volatile("v_add_u32 %0, %0, %1" : "+v"(*(uint32_t*)&a) : "v"(y));
+            M(a0) M(a1) M(a2) M(a3) M(a4) M(a5) M(a6) M(a7)
+#undef M
+        } else if (OP == 5) {  // v_fma_f64
+#define M(a) asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(a) : "v"(dx), "v"(dy));
+            M(d0) M(d1) M(d2) M(d3) M(d4) M(d5) M(d6) M(d7)
+#undef M
+        } else if (OP == 6) {  // v_mad_u32_u24
+#define M(a) asm volatile("v_mad_u32_u24 %0, %0, %1, %2" : "+v"(*(uint32_t*)&a) : "v"(x), "v"(y));
+            M(a0) M(a1) M(a2) M(a3) M(a4) M(a5) M(a6) M(a7)
+#undef M
+        } else if (OP == 7) {  // v_mul_hi_u32_u24
+#define M(a) asm volatile("v_mul_hi_u32_u24 %0, %0, %1" : "+v"(*(uint32_t*)&a) : "v"(y));
+            M(a0) M(a1) M(a2) M(a3) M(a4) M(a5) M(a6) M(a7)
+#undef M
+        } else if (OP == 8) {  // v_addc_co_u32 chain (carry adds)
+#define M(a) asm volatile("v_add_co_u32 %0, vcc, %0, %1\n v_addc_co_u32 %0, vcc, %0, %1, vcc" : "+v"(*(uint32_t*)&a) : "v"(y) : "vcc");
+            M(a0) M(a1) M(a2) M(a3) M(a4) M(a5) M(a6) M(a7)
+#undef M
+        } else if (OP == 9) {  // v_fma_f32
+#define M(a) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(*(float*)&a) : "v"(*(float*)&x), "v"(*(float*)&y));
+            M(a0) M(a1) M(a2) M(a3) M(a4) M(a5) M(a6) M(a7)
+#undef M
+        }
+    }
+    out[t] = (uint32_t)(a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7) ^ (uint32_t)(d0 + d1 + d2 + d3 + d4 + d5 + d6 + d7);
+}
+
+template <int OP>
+__global__ void __launch_bounds__(256) k_prim(uint32_t* out, const uint32_t* in, int iters) {
+    uint32_t t = threadIdx.x + blockIdx.x * 256;
+    fe a, b;
+    for (int i = 0; i < 8; i++) { a.v[i] = in[i] + t; b.v[i] = in[8 + i] ^ t; }
+    if (OP == 0) { for (int i = 0; i < iters; i++) a = fe_mul(a, b); }
+    if (OP == 1) { for (int i = 0; i < iters; i++) a = fe_add(a, b); }
+    if (OP == 2) { for (int i = 0; i < iters; i++) a = fe_sub(a, b); }
+    if (OP == 3) {
+        sc x, y;
+        for (int i = 0; i < 8; i++) { x.v[i] = a.v[i]; y.v[i] = b.v[i]; }
+        x.v[7] &= 0x0fffffff; y.v[7] &= 0x0fffffff;
+        for (int i = 0; i < iters; i++) x = sc_mul(x, y);
+        for (int i = 0; i < 8; i++) a.v[i] = x.v[i];
+    }
+    if (OP == 4 || OP == 5 || OP == 6) {
+        ge p = ge_basepoint();
+        p.X = fe_add(p.X, a);
+        ge_niels n; n.yplusx = a; n.yminusx = b; n.xy2d = fe_add(a, b);
+        ge_cached c = ge_to_cached(p);
+        for (int i = 0; i < iters; i++) {
+            if (OP == 4) p = ge_madd(p, n, i & 1);
+            if (OP == 5) p = ge_dbl(p);
+            if (OP == 6) p = ge_add(p, c);
+        }
+        a = fe_add(fe_add(p.X, p.Y), fe_add(p.Z, p.T));
+    }
+    for (int i = 0; i < 8; i++) out[t * 8 + i] = a.v[i];
+}
+
+int main() {
+    const int blocks = 256 * 8, threads = 256;
+    uint32_t* out; uint32_t* in;
+    CHK(hipMalloc(&out, (size_t)blocks * threads * 8 * 4));
+    CHK(hipMalloc(&in, 64));
+    uint32_t h[16]; for (int i = 0; i < 16; i++) h[i] = 0x9e3779b9u * (i + 1);
+    CHK(hipMemcpy(in, h, 64, hipMemcpyHostToDevice));
+    hipEvent_t e0, e1; CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
+    const char* names[] = {"v_mad_u64_u32", "v_mul_lo_u32", "v_mul_hi_u32", "v_lshl_add_u64", "v_add_u32", "v_fma_f64", "v_mad_u32_u24", "v_mul_hi_u32_u24", "add_co+addc pair", "v_fma_f32"};
+    float ms;
+#define RUN_INST(OP) { hipLaunchKernelGGL(k_inst<OP>, dim3(blocks), dim3(threads), 0, 0, out, 1u); CHK(hipDeviceSynchronize()); \
+    CHK(hipEventRecord(e0)); hipLaunchKernelGGL(k_inst<OP>, dim3(blocks), dim3(threads), 0, 0, out, 2u); CHK(hipEventRecord(e1)); CHK(hipEventSynchronize(e1)); \
+    CHK(hipEventElapsedTime(&ms, e0, e1)); double n = (double)blocks * threads * ITER * 8; \
+    printf("%-18s %8.3f ms  %8.2f Tlane-op/s  (%.2f cyc/wave-inst/SIMD @2.4GHz)\n", names[OP], ms, n / ms / 1e9, 1024.0 * 2.4e9 * 64 / (n / (ms * 1e-3))); }
+    RUN_INST(0) RUN_INST(1) RUN_INST(2) RUN_INST(3) RUN_INST(4) RUN_INST(5) RUN_INST(6) RUN_INST(7) RUN_INST(8) RUN_INST(9)
+    const char* pn[] = {"fe_mul", "fe_add", "fe_sub", "sc_mul", "ge_madd", "ge_dbl", "ge_add"};
+#define RUN_PRIM(OP, IT) { hipLaunchKernelGGL(k_prim<OP>, dim3(blocks), dim3(threads), 0, 0, out, in, 8); CHK(hipDeviceSynchronize()); \
+    CHK(hipEventRecord(e0)); hipLaunchKernelGGL(k_prim<OP>, dim3(blocks), dim3(threads), 0, 0, out, in, IT); CHK(hipEventRecord(e1)); CHK(hipEventSynchronize(e1)); \
+    CHK(hipEventElapsedTime(&ms, e0, e1)); double n = (double)blocks * threads * IT; \
+    printf("%-18s %8.3f ms  %8.2f Gop/s  (%.0f cyc/wave-op/SIMD @2.4GHz)\n", pn[OP], ms, n / ms / 1e6, 1024.0 * 2.4e9 * 64 / (n / (ms * 1e-3))); }
+    RUN_PRIM(0, 2048) RUN_PRIM(1, 2048) RUN_PRIM(2, 2048) RUN_PRIM(3, 2048) RUN_PRIM(4, 256) RUN_PRIM(5, 256) RUN_PRIM(6, 256)
+    return 0;
+}
