@@ -12,6 +12,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <stdio.h>
+#include <typeinfo>
 #include "hd.hpp"
 
 #if defined(BPR1CS_HOSTSIM)
@@ -71,6 +72,11 @@ inline void launch(uint64_t n, const F& f, dev_stream_t s) {
     uint32_t blocks = (uint32_t)((n + 255) / 256);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_functor<F>), dim3(blocks), dim3(256), 0, s, f, (uint32_t)n);
     HIPCHK(hipGetLastError());
+    static const bool dbg = getenv("BPR1CS_DEBUG_SYNC") != nullptr;
+    if (dbg) {
+        fprintf(stderr, "bpr1cs: launched %s n=%llu\n", typeid(F).name(), (unsigned long long)n);
+        HIPCHK(hipStreamSynchronize(s));
+    }
 }
 #endif
 

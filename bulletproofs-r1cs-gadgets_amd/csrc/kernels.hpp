@@ -580,14 +580,12 @@ struct K_ipa_vb_mul {  // gid = (w*m + j)*B + b, w<4
     uint32_t B, m, M;
     HD void operator()(uint32_t g) const {
         uint32_t b = g % B, wj = g / B, w = wj / m, j = wj % m;
-        const ge* G = GH;
-        const ge* Hh = GH + (size_t)M * B;
-        sc s;
-        ge P;
-        if (w == 0) { s = a[(size_t)j * B + b]; P = G[(size_t)(m + j) * B + b]; }
-        else if (w == 1) { s = bb[(size_t)(m + j) * B + b]; P = Hh[(size_t)j * B + b]; }
-        else if (w == 2) { s = a[(size_t)(m + j) * B + b]; P = G[(size_t)j * B + b]; }
-        else { s = bb[(size_t)j * B + b]; P = Hh[(size_t)(m + j) * B + b]; }
+        // branch-free operand selection (w: 0 = a_lo*G_hi, 1 = b_hi*H_lo, 2 = a_hi*G_lo, 3 = b_lo*H_hi)
+        const sc* sv = (w & 1u) ? bb : a;
+        const ge* pv = (w & 1u) ? GH + (size_t)M * B : GH;
+        uint32_t s_hi = (w == 1u) | (w == 2u), p_hi = (w == 0u) | (w == 3u);
+        sc s = sv[(size_t)(j + s_hi * m) * B + b];
+        ge P = pv[(size_t)(j + p_hi * m) * B + b];
         tmp[g] = ge_scalarmul(P, sc_from_mont(s));
     }
 };
@@ -613,8 +611,13 @@ struct K_ipa_vb_fold {  // gid = (side*m + j)*B + b
         ge* P = GH + (size_t)side * M * B;
         sc u = sc_from_mont(uk[b]), ui = sc_from_mont(uk[(size_t)B + b]);
         ge lo = P[(size_t)j * B + b], hi = P[(size_t)(j + m) * B + b];
-        ge r = side ? ge_add_ge(ge_scalarmul(lo, u), ge_scalarmul(hi, ui))
-                    : ge_add_ge(ge_scalarmul(lo, ui), ge_scalarmul(hi, u));
+        // G' = u^-1*G_lo + u*G_hi ; H' = u*H_lo + u^-1*H_hi
+        sc slo, shi;
+        for (int t = 0; t < 8; t++) {
+            slo.v[t] = side ? u.v[t] : ui.v[t];
+            shi.v[t] = side ? ui.v[t] : u.v[t];
+        }
+        ge r = ge_add_ge(ge_scalarmul(lo, slo), ge_scalarmul(hi, shi));
         P[(size_t)j * B + b] = r;
     }
 };

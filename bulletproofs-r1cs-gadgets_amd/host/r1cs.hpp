@@ -1,0 +1,401 @@
+// Host front-end mirroring the reference's boundary types:
+//   bulletproofs::r1cs::{ConstraintSystem, Prover, Verifier, LinearCombination, Variable,
+//   R1CSError}, bulletproofs::{PedersenGens, BulletproofGens}, merlin::Transcript,
+//   curve25519_dalek::scalar::Scalar
+// with the same method names and argument meaning, so that the gadget code in
+// gadgets.hpp reads like the reference's Rust.  Three ConstraintSystem
+// implementations:
+//   Prover          – concrete assignments, host synthesis; prove() runs on the GPU (batch of 1)
+//   Verifier        – no assignments; collects constraints (verification on device is row N1)
+//   CircuitCompiler – no assignments; records the constraint system AND a witness program so
+//                     the whole batch (synthesis included) runs on the GPU (bpr1cs_prove_batch)
+// This layer does linear-combination bookkeeping only; every group operation and
+// the prover itself are behind the C ABI (include/bpr1cs.h).
+#pragma once
+#include <stdint.h>
+#include <array>
+#include <optional>
+#include <string>
+#include <tuple>
+#include <unordered_map>
+#include <utility>
+#include <vector>
+#include "../../include/bpr1cs.h"
+#include "../csrc/sc.hpp"
+
+namespace bpr1cs {
+
+// R1CSError (constructed at reference src/gadget_poseidon.rs:136; `?` at gadget_bound_check.rs:84)
+struct R1CSError {
+    int code;
+    std::string description;
+    static R1CSError InvalidGeneratorsLength() { return {BPR1CS_ERR_INVALID_GENERATORS_LENGTH, "InvalidGeneratorsLength"}; }
+    static R1CSError FormatError() { return {BPR1CS_ERR_FORMAT, "FormatError"}; }
+    static R1CSError VerificationError() { return {BPR1CS_ERR_VERIFICATION, "VerificationError"}; }
+    static R1CSError MissingAssignment() { return {BPR1CS_ERR_MISSING_ASSIGNMENT, "MissingAssignment"}; }
+    static R1CSError GadgetError(const std::string& d) { return {BPR1CS_ERR_GADGET, d}; }
+    static R1CSError Backend(int code) { return {code, "backend"}; }
+};
+
+// curve25519_dalek::scalar::Scalar; Montgomery form inside.
+struct Scalar {
+    sc m;
+    Scalar() : m(sc_zero()) {}
+    Scalar(uint64_t x) : m(sc_mont_from_u64(x)) {}  // From<u8/u32/u64>
+    static Scalar zero() { return Scalar(); }
+    static Scalar one() { return Scalar(1); }
+    static Scalar from_bytes_mod_order(const uint8_t b[32]) { Scalar s; s.m = sc_mont_from_bytes_mod_order(b); return s; }
+    static Scalar from_bytes_mod_order_wide(const uint8_t b[64]) { Scalar s; s.m = sc_mont_from_wide(b); return s; }
+    std::array<uint8_t, 32> to_bytes() const { std::array<uint8_t, 32> o; sc_mont_tobytes(m, o.data()); return o; }
+    uint8_t operator[](size_t i) const { return to_bytes()[i]; }  // `l[i]` at gadget_vsmt_4.rs:227
+    Scalar invert() const { Scalar r; r.m = sc_invert(m); return r; }  // 0 -> 0
+    Scalar operator+(const Scalar& o) const { Scalar r; r.m = sc_add(m, o.m); return r; }
+    Scalar operator-(const Scalar& o) const { Scalar r; r.m = sc_sub(m, o.m); return r; }
+    Scalar operator*(const Scalar& o) const { Scalar r; r.m = sc_mul(m, o.m); return r; }
+    Scalar operator-() const { Scalar r; r.m = sc_neg(m); return r; }
+    Scalar& operator+=(const Scalar& o) { m = sc_add(m, o.m); return *this; }
+    bool operator==(const Scalar& o) const { for (int i = 0; i < 8; i++) if (m.v[i] != o.m.v[i]) return false; return true; }
+    bool is_zero() const { return sc_is_zero(m); }
+};
+
+using CompressedRistretto = std::array<uint8_t, 32>;
+
+enum class VarKind : uint32_t { Committed = 0, MultiplierLeft = 1, MultiplierRight = 2, MultiplierOutput = 3, One = 4 };
+
+struct LinearCombination;
+struct Variable {
+    VarKind kind;
+    uint32_t index;
+    static Variable Committed(uint32_t i) { return {VarKind::Committed, i}; }
+    static Variable MultiplierLeft(uint32_t i) { return {VarKind::MultiplierLeft, i}; }
+    static Variable MultiplierRight(uint32_t i) { return {VarKind::MultiplierRight, i}; }
+    static Variable MultiplierOutput(uint32_t i) { return {VarKind::MultiplierOutput, i}; }
+    static Variable One() { return {VarKind::One, 0}; }
+    uint32_t encode() const { return ((uint32_t)kind << 28) | index; }
+    bool operator==(const Variable& o) const { return kind == o.kind && index == o.index; }
+};
+
+struct LinearCombination {
+    std::vector<std::pair<Variable, Scalar>> terms;
+    LinearCombination() {}
+    LinearCombination(const Variable& v) { terms.push_back({v, Scalar::one()}); }             // From<Variable>
+    LinearCombination(const Scalar& s) { terms.push_back({Variable::One(), s}); }             // From<Scalar>
+    LinearCombination(uint64_t s) { terms.push_back({Variable::One(), Scalar(s)}); }          // From<u64>
+    LinearCombination(std::vector<std::pair<Variable, Scalar>> t) : terms(std::move(t)) {}    // FromIterator
+    const std::vector<std::pair<Variable, Scalar>>& get_terms() const { return terms; }       // fork API
+    LinearCombination operator+(const LinearCombination& o) const {
+        LinearCombination r(terms);
+        r.terms.insert(r.terms.end(), o.terms.begin(), o.terms.end());
+        return r;
+    }
+    LinearCombination operator-(const LinearCombination& o) const {
+        LinearCombination r(terms);
+        for (auto& t : o.terms) r.terms.push_back({t.first, -t.second});
+        return r;
+    }
+    LinearCombination operator-() const {
+        LinearCombination r;
+        for (auto& t : terms) r.terms.push_back({t.first, -t.second});
+        return r;
+    }
+    LinearCombination operator*(const Scalar& s) const {
+        LinearCombination r;
+        r.terms.reserve(terms.size());
+        for (auto& t : terms) r.terms.push_back({t.first, t.second * s});
+        return r;
+    }
+    // fork-added `simplify` (reference README.md:22); deterministic first-seen order (trap T5)
+    LinearCombination simplify() const {
+        std::unordered_map<uint32_t, size_t> pos;
+        LinearCombination r;
+        for (auto& t : terms) {
+            auto it = pos.find(t.first.encode());
+            if (it == pos.end()) {
+                pos[t.first.encode()] = r.terms.size();
+                r.terms.push_back(t);
+            } else {
+                r.terms[it->second].second += t.second;
+            }
+        }
+        return r;
+    }
+};
+inline LinearCombination operator+(const Variable& a, const LinearCombination& b) { return LinearCombination(a) + b; }
+inline LinearCombination operator-(const Variable& a, const LinearCombination& b) { return LinearCombination(a) - b; }
+inline LinearCombination operator+(const Variable& a, const Variable& b) { return LinearCombination(a) + LinearCombination(b); }
+inline LinearCombination operator-(const Variable& a, const Variable& b) { return LinearCombination(a) - LinearCombination(b); }
+inline LinearCombination operator-(const Variable& a, uint64_t b) { return LinearCombination(a) - LinearCombination(b); }
+
+// src/r1cs_utils.rs:7-17
+struct AllocatedQuantity {
+    Variable variable;
+    std::optional<uint64_t> assignment;
+};
+struct AllocatedScalar {
+    Variable variable;
+    std::optional<Scalar> assignment;
+};
+
+// How a wire can be recomputed on the device from earlier wires / committed values.
+// Extension over the reference API (default = none): gadgets that pass hints can be
+// compiled into a device witness program; without hints the Prover path still works.
+struct WitnessHint {
+    enum Kind { None, LC, InverseOfLeft, Bit, NotBit } kind = None;
+    LinearCombination lc;       // LC
+    uint32_t committed = 0;     // Bit / NotBit: index of the committed value
+    uint32_t bit = 0;
+    static WitnessHint of_lc(const LinearCombination& l) { WitnessHint h; h.kind = LC; h.lc = l; return h; }
+    static WitnessHint inverse_of_left() { WitnessHint h; h.kind = InverseOfLeft; return h; }
+    static WitnessHint bit_of(const Variable& v, uint32_t k, bool negate) {
+        WitnessHint h;
+        h.kind = negate ? NotBit : Bit;
+        h.committed = v.index;
+        h.bit = k;
+        if (v.kind != VarKind::Committed) h.kind = None;
+        return h;
+    }
+};
+
+struct MulVars {
+    Variable left, right, out;
+};
+
+// trait bulletproofs::r1cs::ConstraintSystem (+ fork methods)
+class ConstraintSystem {
+public:
+    virtual ~ConstraintSystem() {}
+    virtual MulVars multiply(LinearCombination left, LinearCombination right) = 0;
+    virtual MulVars allocate_multiplier(const std::optional<std::pair<Scalar, Scalar>>& assignment,
+                                        const WitnessHint& left = WitnessHint(), const WitnessHint& right = WitnessHint()) = 0;
+    // -> (var, Some(output) on the second call of a pair)   (trap T8)
+    virtual std::pair<Variable, std::optional<Variable>> allocate_single(const std::optional<Scalar>& assignment,
+                                                                           const WitnessHint& hint = WitnessHint()) = 0;
+    virtual std::optional<Scalar> evaluate_lc(const LinearCombination& lc) const = 0;
+    virtual void constrain(LinearCombination lc) = 0;
+    virtual size_t num_constraints() const = 0;
+    virtual size_t num_multipliers() const = 0;
+};
+
+// merlin::Transcript as seen by the reference: created with a label, handed to Prover/Verifier.
+// The Fiat-Shamir state itself lives on the device.
+struct Transcript {
+    std::string label;
+    explicit Transcript(const std::string& l) : label(l) {}
+    Transcript(const char* l, size_t n) : label(l, n) {}
+};
+
+class BulletproofGens {
+public:
+    bpr1cs_gens* h = nullptr;
+    size_t gens_capacity = 0;
+    BulletproofGens(size_t gens_capacity_, size_t party_capacity) : gens_capacity(gens_capacity_) {
+        if (party_capacity != 1) throw R1CSError::GadgetError("party_capacity must be 1");
+        int rc = bpr1cs_gens_create((uint32_t)gens_capacity_, &h);
+        if (rc) throw R1CSError::Backend(rc);
+    }
+    ~BulletproofGens() { bpr1cs_gens_destroy(h); }
+    BulletproofGens(const BulletproofGens&) = delete;
+};
+
+class PedersenGens {
+public:
+    // PedersenGens::default(); `bp` supplies the device tables of B and B_blinding
+    explicit PedersenGens(const BulletproofGens& bp) : gens(bp.h) {
+        bpr1cs_gens_point(gens, 0, 0, B.data());
+        bpr1cs_gens_point(gens, 1, 0, B_blinding.data());
+    }
+    CompressedRistretto commit(const Scalar& v, const Scalar& blinding) const {  // .compress()ed
+        uint32_t bases[2] = {0, 1};
+        uint8_t s[64];
+        auto a = v.to_bytes(), b = blinding.to_bytes();
+        memcpy(s, a.data(), 32);
+        memcpy(s + 32, b.data(), 32);
+        CompressedRistretto out;
+        int rc = bpr1cs_msm_fixed(gens, bases, 2, s, 1, out.data());
+        if (rc) throw R1CSError::Backend(rc);
+        return out;
+    }
+    bpr1cs_gens* gens;
+    CompressedRistretto B, B_blinding;
+};
+
+struct R1CSProof {
+    std::vector<uint8_t> bytes;
+    const std::vector<uint8_t>& to_bytes() const { return bytes; }
+};
+
+// shared bookkeeping of the three constraint systems
+class CSBase : public ConstraintSystem {
+public:
+    std::vector<LinearCombination> constraints;
+    size_t num_vars = 0;
+    std::optional<size_t> pending_multiplier;
+    void constrain(LinearCombination lc) override { constraints.push_back(std::move(lc)); }
+    size_t num_constraints() const override { return constraints.size(); }
+    size_t num_multipliers() const override { return num_vars; }
+    // flattened CSR of the constraint list (One terms kept; the device prover drops them)
+    void export_csr(std::vector<uint32_t>& row_off, std::vector<uint32_t>& tvar, std::vector<uint8_t>& tcoeff) const {
+        row_off.assign(1, 0);
+        tvar.clear();
+        tcoeff.clear();
+        for (auto& lc : constraints) {
+            for (auto& t : lc.terms) {
+                tvar.push_back(t.first.encode());
+                auto b = t.second.to_bytes();
+                tcoeff.insert(tcoeff.end(), b.begin(), b.end());
+            }
+            row_off.push_back((uint32_t)tvar.size());
+        }
+    }
+};
+
+class Prover : public CSBase {
+public:
+    Prover(const PedersenGens& pc, Transcript& t) : pc_gens(pc), transcript(t) {}
+    std::pair<CompressedRistretto, Variable> commit(const Scalar& v, const Scalar& v_blinding) {
+        uint32_t i = (uint32_t)v_.size();
+        v_.push_back(v);
+        v_blinding_.push_back(v_blinding);
+        return {pc_gens.commit(v, v_blinding), Variable::Committed(i)};
+    }
+    Scalar eval(const LinearCombination& lc) const {
+        Scalar acc;
+        for (auto& t : lc.terms) {
+            Scalar val;
+            switch (t.first.kind) {
+                case VarKind::Committed: val = v_[t.first.index]; break;
+                case VarKind::MultiplierLeft: val = a_L[t.first.index]; break;
+                case VarKind::MultiplierRight: val = a_R[t.first.index]; break;
+                case VarKind::MultiplierOutput: val = a_O[t.first.index]; break;
+                default: val = Scalar::one();
+            }
+            acc += t.second * val;
+        }
+        return acc;
+    }
+    std::optional<Scalar> evaluate_lc(const LinearCombination& lc) const override { return eval(lc); }
+    MulVars multiply(LinearCombination left, LinearCombination right) override {
+        Scalar l = eval(left), r = eval(right);
+        uint32_t i = (uint32_t)a_L.size();
+        a_L.push_back(l); a_R.push_back(r); a_O.push_back(l * r);
+        num_vars = a_L.size();
+        MulVars mv{Variable::MultiplierLeft(i), Variable::MultiplierRight(i), Variable::MultiplierOutput(i)};
+        left.terms.push_back({mv.left, -Scalar::one()});
+        right.terms.push_back({mv.right, -Scalar::one()});
+        constrain(std::move(left));
+        constrain(std::move(right));
+        return mv;
+    }
+    MulVars allocate_multiplier(const std::optional<std::pair<Scalar, Scalar>>& a, const WitnessHint&, const WitnessHint&) override {
+        if (!a) throw R1CSError::MissingAssignment();
+        uint32_t i = (uint32_t)a_L.size();
+        a_L.push_back(a->first); a_R.push_back(a->second); a_O.push_back(a->first * a->second);
+        num_vars = a_L.size();
+        return {Variable::MultiplierLeft(i), Variable::MultiplierRight(i), Variable::MultiplierOutput(i)};
+    }
+    std::pair<Variable, std::optional<Variable>> allocate_single(const std::optional<Scalar>& a, const WitnessHint&) override {
+        if (!a) throw R1CSError::MissingAssignment();
+        if (!pending_multiplier) {
+            uint32_t i = (uint32_t)a_L.size();
+            pending_multiplier = i;
+            a_L.push_back(*a); a_R.push_back(Scalar()); a_O.push_back(Scalar());
+            num_vars = a_L.size();
+            return {Variable::MultiplierLeft(i), std::nullopt};
+        }
+        uint32_t i = (uint32_t)*pending_multiplier;
+        pending_multiplier.reset();
+        a_R[i] = *a;
+        a_O[i] = a_L[i] * a_R[i];
+        return {Variable::MultiplierRight(i), Variable::MultiplierOutput(i)};
+    }
+    // The 32 bytes upstream takes from thread_rng() in TranscriptRng::finalize; explicit here
+    // (SURVEY §8c); defaults to OS randomness.
+    void set_rng_seed(const std::array<uint8_t, 32>& s) { rng_seed = s; }
+    R1CSProof prove(const BulletproofGens& bp_gens);
+
+    const PedersenGens& pc_gens;
+    Transcript& transcript;
+    std::vector<Scalar> a_L, a_R, a_O, v_, v_blinding_;
+    std::optional<std::array<uint8_t, 32>> rng_seed;
+};
+
+class Verifier : public CSBase {
+public:
+    explicit Verifier(Transcript& t) : transcript(t) {}
+    Variable commit(const CompressedRistretto& V) {
+        uint32_t i = (uint32_t)V_.size();
+        V_.push_back(V);
+        return Variable::Committed(i);
+    }
+    std::optional<Scalar> evaluate_lc(const LinearCombination&) const override { return std::nullopt; }
+    MulVars alloc() {
+        uint32_t i = (uint32_t)num_vars++;
+        return {Variable::MultiplierLeft(i), Variable::MultiplierRight(i), Variable::MultiplierOutput(i)};
+    }
+    MulVars multiply(LinearCombination left, LinearCombination right) override {
+        MulVars mv = alloc();
+        left.terms.push_back({mv.left, -Scalar::one()});
+        right.terms.push_back({mv.right, -Scalar::one()});
+        constrain(std::move(left));
+        constrain(std::move(right));
+        return mv;
+    }
+    MulVars allocate_multiplier(const std::optional<std::pair<Scalar, Scalar>>&, const WitnessHint&, const WitnessHint&) override { return alloc(); }
+    std::pair<Variable, std::optional<Variable>> allocate_single(const std::optional<Scalar>&, const WitnessHint&) override {
+        if (!pending_multiplier) {
+            uint32_t i = (uint32_t)num_vars++;
+            pending_multiplier = i;
+            return {Variable::MultiplierLeft(i), std::nullopt};
+        }
+        uint32_t i = (uint32_t)*pending_multiplier;
+        pending_multiplier.reset();
+        return {Variable::MultiplierRight(i), Variable::MultiplierOutput(i)};
+    }
+    Transcript& transcript;
+    std::vector<CompressedRistretto> V_;
+};
+
+// Records the constraint system + witness program of a gadget run once, shape only.
+class CircuitCompiler : public Verifier {
+public:
+    explicit CircuitCompiler(Transcript& t) : Verifier(t) {}
+    // Prover-side API so that gadget harnesses written for `Prover` compile unchanged
+    Variable commit_placeholder() { return commit(CompressedRistretto{}); }
+
+    struct Op { WitnessHint l, r; bool have_l = false, have_r = false; };
+    std::vector<Op> ops;
+    bool complete = true;  // false when some wire had no hint
+
+    MulVars multiply(LinearCombination left, LinearCombination right) override {
+        Op op;
+        op.l = WitnessHint::of_lc(left); op.r = WitnessHint::of_lc(right);
+        op.have_l = op.have_r = true;
+        ops.push_back(op);
+        return Verifier::multiply(std::move(left), std::move(right));
+    }
+    MulVars allocate_multiplier(const std::optional<std::pair<Scalar, Scalar>>& a, const WitnessHint& l, const WitnessHint& r) override {
+        Op op;
+        op.l = l; op.r = r;
+        op.have_l = l.kind != WitnessHint::None;
+        op.have_r = r.kind != WitnessHint::None;
+        if (!op.have_l || !op.have_r) complete = false;
+        ops.push_back(op);
+        return Verifier::allocate_multiplier(a, l, r);
+    }
+    std::pair<Variable, std::optional<Variable>> allocate_single(const std::optional<Scalar>& a, const WitnessHint& h) override {
+        if (h.kind == WitnessHint::None) complete = false;
+        if (!pending_multiplier) {
+            Op op;
+            op.l = h; op.have_l = h.kind != WitnessHint::None;
+            ops.push_back(op);
+        } else {
+            Op& op = ops[*pending_multiplier];
+            op.r = h; op.have_r = h.kind != WitnessHint::None;
+        }
+        return Verifier::allocate_single(a, h);
+    }
+    // -> device circuit handle (caller owns)
+    bpr1cs_circuit* finish(uint32_t* n_out = nullptr, uint32_t* q_out = nullptr, uint32_t* m_out = nullptr);
+};
+
+}  // namespace bpr1cs
