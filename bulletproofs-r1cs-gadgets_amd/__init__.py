@@ -195,3 +195,128 @@ def last_timings(lib=None):
     buf = (ctypes.c_float * 6)()
     k = lib.bpr1cs_last_timings(buf, 6)
     return list(buf)[:k]
+
+
+# ---------------------------------------------------------------- host front-end (libbpr1cs_gadgets.so)
+_glib = None
+
+
+def poseidon_blob():
+    with open(POSEIDON_PARAMS_PATH, "rb") as f:
+        return f.read()
+
+
+def load_gadgets_library(path=None):
+    """C++ mirror of the reference's gadget layer (include/bpr1cs_gadgets.h)."""
+    global _glib
+    if _glib is not None and path is None:
+        return _glib
+    p = path or GADGETS_LIB_PATH
+    if not os.path.exists(p):
+        raise ImportError("bpr1cs: %s is missing — run __graft_entry__.build()" % p)
+    if path is None:
+        load_library()  # resolve libbpr1cs_hip.so first
+    g = ctypes.CDLL(p, mode=ctypes.RTLD_GLOBAL)
+    vp, u32, sz, cp, ip = ctypes.c_void_p, ctypes.c_uint32, ctypes.c_size_t, ctypes.c_char_p, ctypes.POINTER(ctypes.c_uint32)
+    g.bpr1cs_gadget_compile.argtypes = [cp, ip, sz, cp, sz, cp, sz, ctypes.POINTER(vp), ip, ip, ip, ctypes.POINTER(ctypes.c_int)]
+    g.bpr1cs_gadget_prove_single.argtypes = [cp, ip, sz, cp, sz, cp, sz, u32, cp, sz, cp, cp, sz, cp, cp, sz, ctypes.POINTER(sz), cp]
+    g.bpr1cs_poseidon_hash.argtypes = [ctypes.c_int, ctypes.c_int, u32, cp, sz, cp, cp]
+    g.bpr1cs_mimc.argtypes = [cp, cp, cp, sz, cp]
+    for nm in ("vsmt4", "vsmt2"):
+        getattr(g, "bpr1cs_%s_new" % nm).argtypes = [u32, u32, cp, sz, ctypes.POINTER(vp)]
+        getattr(g, "bpr1cs_%s_free" % nm).argtypes = [vp]
+        getattr(g, "bpr1cs_%s_root" % nm).argtypes = [vp, cp]
+        getattr(g, "bpr1cs_%s_update" % nm).argtypes = [vp, cp, cp]
+        getattr(g, "bpr1cs_%s_get" % nm).argtypes = [vp, cp, cp, cp]
+    if path is None:
+        _glib = g
+    return g
+
+
+def _sc(x):
+    return x if isinstance(x, (bytes, bytearray)) else int(x).to_bytes(32, "little")
+
+
+class CompiledGadget:
+    """A reference gadget compiled (shape only) into a device circuit + witness program."""
+
+    def __init__(self, name, iparams=(), sparams=(), lib=None, glib=None):
+        self.lib = lib or load_library()
+        self.glib = glib or load_gadgets_library()
+        blob = poseidon_blob()
+        sp = b"".join(_sc(s) for s in sparams)
+        h = ctypes.c_void_p()
+        n, q, m, hw = ctypes.c_uint32(), ctypes.c_uint32(), ctypes.c_uint32(), ctypes.c_int()
+        _chk(self.glib.bpr1cs_gadget_compile(name.encode(), _u32arr(list(iparams)), len(iparams), sp or b"\0", len(sparams), blob, len(blob),
+                                             ctypes.byref(h), ctypes.byref(n), ctypes.byref(q), ctypes.byref(m), ctypes.byref(hw)))
+        self.h, self.n, self.q, self.m, self.has_witness_program = h, n.value, q.value, m.value, bool(hw.value)
+        self.proof_len = self.lib.bpr1cs_proof_len(h)
+
+    def close(self):
+        if self.h:
+            self.lib.bpr1cs_circuit_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def prove_single(name, iparams, sparams, gens_capacity, label, values, blindings, rng_seed, glib=None):
+    """The reference's single-proof harness over the C++ `Prover` (host synthesis, device prove)."""
+    g = glib or load_gadgets_library()
+    blob = poseidon_blob()
+    sp = b"".join(_sc(s) for s in sparams)
+    m = len(values)
+    proof = ctypes.create_string_buffer(1 + 32 * (13 + 2 * 32))
+    plen = ctypes.c_size_t()
+    comms = ctypes.create_string_buffer(32 * max(1, m))
+    _chk(g.bpr1cs_gadget_prove_single(name.encode(), _u32arr(list(iparams)), len(iparams), sp or b"\0", len(sparams), blob, len(blob),
+                                      gens_capacity, label, len(label), b"".join(_sc(v) for v in values), b"".join(_sc(v) for v in blindings),
+                                      m, rng_seed, proof, len(proof), ctypes.byref(plen), comms))
+    return proof.raw[:plen.value], [comms.raw[32 * i:32 * i + 32] for i in range(m)]
+
+
+def poseidon_hash(arity, inverse, partial_rounds, inputs, glib=None):
+    g = glib or load_gadgets_library()
+    blob = poseidon_blob()
+    out = ctypes.create_string_buffer(192 if arity == 6 else 32)
+    _chk(g.bpr1cs_poseidon_hash(arity, 1 if inverse else 0, partial_rounds, blob, len(blob), b"".join(_sc(x) for x in inputs), out))
+    return out.raw
+
+
+class SparseMerkleTree:
+    """VanillaSparseMerkleTree_4 (arity 4) / VanillaSparseMerkleTree (arity 2) of the reference."""
+
+    def __init__(self, arity, levels, partial_rounds=140, glib=None):
+        self.g = glib or load_gadgets_library()
+        self.nm = "vsmt4" if arity == 4 else "vsmt2"
+        self.arity, self.levels = arity, levels
+        blob = poseidon_blob()
+        h = ctypes.c_void_p()
+        _chk(getattr(self.g, "bpr1cs_%s_new" % self.nm)(levels, partial_rounds, blob, len(blob), ctypes.byref(h)))
+        self.h = h
+
+    def root(self):
+        out = ctypes.create_string_buffer(32)
+        getattr(self.g, "bpr1cs_%s_root" % self.nm)(self.h, out)
+        return out.raw
+
+    def update(self, idx, val):
+        getattr(self.g, "bpr1cs_%s_update" % self.nm)(self.h, _sc(idx), _sc(val))
+
+    def get(self, idx):
+        """-> (leaf bytes, [node bytes...]) with the Merkle path root level first."""
+        per = 3 if self.arity == 4 else 1
+        leaf = ctypes.create_string_buffer(32)
+        proof = ctypes.create_string_buffer(32 * per * self.levels)
+        _chk(getattr(self.g, "bpr1cs_%s_get" % self.nm)(self.h, _sc(idx), leaf, proof))
+        return leaf.raw, [proof.raw[32 * i:32 * i + 32] for i in range(per * self.levels)]
+
+    def __del__(self):
+        try:
+            getattr(self.g, "bpr1cs_%s_free" % self.nm)(self.h)
+        except Exception:
+            pass

@@ -3,7 +3,7 @@
 // the very same headers with g++ and BPR1CS_HOSTSIM defined, so that the device
 // arithmetic can be checked against the oracle in a container without a GPU.
 #pragma once
-#if defined(BPR1CS_HOSTSIM)
+#if defined(BPR1CS_HOSTSIM) || defined(BPR1CS_HOST_ONLY)
 #define HD
 #define HD_CONST static constexpr
 #define DEV_ONLY

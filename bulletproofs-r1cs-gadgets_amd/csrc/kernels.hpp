@@ -87,10 +87,27 @@ struct K_build_table {  // gid = base*32 + k
         ge_cached c = ge_to_cached(P);
         ge acc = P;
         ge_niels* out = tab + (size_t)g * TAB_ENTRIES;
-        out[0] = ge_to_niels(acc);
-        for (int j = 1; j < TAB_ENTRIES; j++) {
-            acc = ge_add(acc, c);
-            out[j] = ge_to_niels(acc);
+        // affine normalisation with Montgomery's trick, 16 entries per field inversion
+        const int CH = 16;
+        for (int j0 = 0; j0 < TAB_ENTRIES; j0 += CH) {
+            ge q[CH];
+            fe pre[CH];
+            for (int t = 0; t < CH; t++) {
+                if (j0 + t > 0) acc = ge_add(acc, c);
+                q[t] = acc;
+                pre[t] = t ? fe_mul(pre[t - 1], acc.Z) : acc.Z;
+            }
+            fe inv = fe_invert(pre[CH - 1]);
+            for (int t = CH - 1; t >= 0; t--) {
+                fe zi = t ? fe_mul(inv, pre[t - 1]) : inv;
+                inv = fe_mul(inv, q[t].Z);
+                fe x = fe_mul(q[t].X, zi), y = fe_mul(q[t].Y, zi);
+                ge_niels e;
+                e.yplusx = fe_add(y, x);
+                e.yminusx = fe_sub(y, x);
+                e.xy2d = fe_mul(fe_mul(x, y), fe_const(FE_2D_L));
+                out[j0 + t] = e;
+            }
         }
     }
 };

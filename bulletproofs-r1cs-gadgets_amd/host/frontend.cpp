@@ -1,0 +1,400 @@
+// libbpr1cs_gadgets.so — host front-end: Prover::prove, CircuitCompiler::finish and the
+// C ABI of include/bpr1cs_gadgets.h (the reference's proving harnesses restated over
+// the C++ mirror of its gadget API).  Links against libbpr1cs_hip.so; contains no
+// group arithmetic and no prover of its own.
+#include <functional>
+#include <random>
+#include <memory>
+#include "gadgets.hpp"
+#include "../../include/bpr1cs_gadgets.h"
+
+namespace bpr1cs {
+
+R1CSProof Prover::prove(const BulletproofGens& bp_gens) {
+    // Prover::prove (reference src/gadget_vsmt_4.rs:434): constraints + host-synthesised wires
+    // go to the device prover as a batch of one.
+    size_t n = a_L.size(), m = v_.size();
+    size_t padded = 1;
+    while (padded < n) padded <<= 1;
+    if (bp_gens.gens_capacity < padded) throw R1CSError::InvalidGeneratorsLength();
+    std::vector<uint32_t> row_off, tvar;
+    std::vector<uint8_t> tcoeff;
+    export_csr(row_off, tvar, tcoeff);
+    bpr1cs_circuit_desc d{};
+    d.n = (uint32_t)n; d.q = (uint32_t)constraints.size(); d.m = (uint32_t)m;
+    d.row_off = row_off.data(); d.term_var = tvar.data(); d.term_coeff = tcoeff.data();
+    bpr1cs_circuit* c = nullptr;
+    int rc = bpr1cs_circuit_create(&d, &c);
+    if (rc) throw R1CSError::Backend(rc);
+    std::vector<uint8_t> vals(32 * m + 1), bls(32 * m + 1), wires(32 * 3 * n + 1);
+    for (size_t i = 0; i < m; i++) {
+        auto a = v_[i].to_bytes(), b = v_blinding_[i].to_bytes();
+        memcpy(&vals[32 * i], a.data(), 32);
+        memcpy(&bls[32 * i], b.data(), 32);
+    }
+    for (size_t i = 0; i < n; i++) {
+        auto l = a_L[i].to_bytes(), r = a_R[i].to_bytes(), o = a_O[i].to_bytes();
+        memcpy(&wires[32 * i], l.data(), 32);
+        memcpy(&wires[32 * (n + i)], r.data(), 32);
+        memcpy(&wires[32 * (2 * n + i)], o.data(), 32);
+    }
+    std::array<uint8_t, 32> seed;
+    if (rng_seed) seed = *rng_seed;
+    else {
+        std::random_device rd;  // stands in for rand::thread_rng()
+        for (auto& x : seed) x = (uint8_t)rd();
+    }
+    R1CSProof proof;
+    proof.bytes.resize(bpr1cs_proof_len(c));
+    rc = bpr1cs_prove_batch(bp_gens.h, c, (const uint8_t*)transcript.label.data(), transcript.label.size(), vals.data(), bls.data(),
+                            seed.data(), wires.data(), 1, proof.bytes.data(), nullptr);
+    bpr1cs_circuit_destroy(c);
+    if (rc) throw R1CSError::Backend(rc);
+    return proof;
+}
+
+bpr1cs_circuit* CircuitCompiler::finish(uint32_t* n_out, uint32_t* q_out, uint32_t* m_out) {
+    std::vector<uint32_t> row_off, tvar;
+    std::vector<uint8_t> tcoeff;
+    export_csr(row_off, tvar, tcoeff);
+    bpr1cs_circuit_desc d{};
+    d.n = (uint32_t)num_vars; d.q = (uint32_t)constraints.size(); d.m = (uint32_t)V_.size();
+    d.row_off = row_off.data(); d.term_var = tvar.data(); d.term_coeff = tcoeff.data();
+    // witness program
+    std::vector<bpr1cs_wop> wops;
+    std::vector<uint32_t> lc_off{0}, lc_var;
+    std::vector<uint8_t> lc_coeff;
+    if (complete && ops.size() == num_vars) {
+        auto add_lc = [&](const LinearCombination& lc0) {
+            LinearCombination lc = lc0.simplify();
+            for (auto& t : lc.terms) {
+                if (t.second.is_zero()) continue;
+                lc_var.push_back(t.first.encode());
+                auto b = t.second.to_bytes();
+                lc_coeff.insert(lc_coeff.end(), b.begin(), b.end());
+            }
+            lc_off.push_back((uint32_t)lc_var.size());
+            return (uint32_t)(lc_off.size() - 2);
+        };
+        auto enc = [&](const WitnessHint& h, uint32_t& kind, uint32_t& arg) {
+            switch (h.kind) {
+                case WitnessHint::LC: kind = BPR1CS_W_LC; arg = add_lc(h.lc); break;
+                case WitnessHint::InverseOfLeft: kind = BPR1CS_W_INV_LEFT; arg = 0; break;
+                case WitnessHint::Bit: kind = BPR1CS_W_BIT; arg = (h.committed << 8) | h.bit; break;
+                case WitnessHint::NotBit: kind = BPR1CS_W_NOTBIT; arg = (h.committed << 8) | h.bit; break;
+                default: kind = BPR1CS_W_LC; arg = add_lc(LinearCombination());
+            }
+        };
+        for (auto& op : ops) {
+            bpr1cs_wop w{};
+            enc(op.l, w.lkind, w.larg);
+            enc(op.r, w.rkind, w.rarg);
+            wops.push_back(w);
+        }
+        d.wops = wops.data();
+        d.n_lc = (uint32_t)(lc_off.size() - 1);
+        d.lc_off = lc_off.data(); d.lc_var = lc_var.data(); d.lc_coeff = lc_coeff.data();
+    }
+    bpr1cs_circuit* c = nullptr;
+    int rc = bpr1cs_circuit_create(&d, &c);
+    if (rc) throw R1CSError::Backend(rc);
+    if (n_out) *n_out = d.n;
+    if (q_out) *q_out = d.q;
+    if (m_out) *m_out = d.m;
+    return c;
+}
+
+// ------------------------------------------------------------------------------------------------
+// The reference's proving harnesses, written once against an abstract "committer" so that the same
+// code drives the Prover (real values), the Verifier (commitments) and the CircuitCompiler (shape).
+struct Harness {
+    ConstraintSystem& cs;
+    // commit the k-th high-level value; returns its Variable (and knows the assignment if any)
+    std::function<Variable(size_t k)> commit;
+    std::function<std::optional<Scalar>(size_t k)> value;    // assignment of the k-th committed value
+    std::function<std::optional<uint64_t>(size_t k)> value64;
+};
+
+struct GadgetSpec {
+    std::string name;
+    std::vector<uint32_t> ip;
+    std::vector<Scalar> sp;
+    const uint8_t* blob = nullptr;
+    size_t blob_len = 0;
+};
+
+static uint64_t u64_of(const std::vector<uint32_t>& ip, size_t i) { return (uint64_t)ip.at(i) | ((uint64_t)ip.at(i + 1) << 32); }
+
+// number of high-level committed values and the gadget run
+static size_t run_gadget(const GadgetSpec& g, Harness& h) {
+    auto AS = [&](size_t k) { return AllocatedScalar{h.commit(k), h.value(k)}; };
+    auto AQ = [&](size_t k) { return AllocatedQuantity{h.commit(k), h.value64(k)}; };
+    if (g.name == "factors") {  // src/factors.rs:48-103
+        auto p = AS(0), q = AS(1);
+        factors(h.cs, p, q, g.sp.at(0));
+        return 2;
+    }
+    if (g.name == "bound_check") {  // src/gadget_bound_check.rs:49-87 ; ip = [bits, min(lo,hi), max(lo,hi)]
+        auto v = AQ(0), a = AQ(1), b = AQ(2);
+        bound_check_gadget(h.cs, v, a, b, u64_of(g.ip, 3), u64_of(g.ip, 1), g.ip.at(0));
+        return 3;
+    }
+    if (g.name == "set_membership") {  // src/gadget_set_membership.rs:93-134 ; ip = [k, items(lo,hi)...]
+        size_t k = g.ip.at(0);
+        std::vector<uint64_t> items;
+        for (size_t i = 0; i < k; i++) items.push_back(u64_of(g.ip, 1 + 2 * i));
+        std::vector<AllocatedQuantity> bit_vars;
+        for (size_t i = 0; i < k; i++) {
+            auto q = AQ(i);
+            bit_gadget(h.cs, q);
+            bit_vars.push_back(q);
+        }
+        vector_sum_gadget(h.cs, bit_vars, 1);
+        auto val = AQ(k);
+        vector_product_gadget(h.cs, items, bit_vars, val);
+        return k + 1;
+    }
+    if (g.name == "mimc") {  // src/gadget_mimc.rs:92-175 ; sp = constants[rounds] ++ [image]
+        size_t rounds = g.ip.at(0);
+        std::vector<Scalar> consts(g.sp.begin(), g.sp.begin() + rounds);
+        auto l = AS(0), r = AS(1);
+        mimc_gadget(h.cs, l, r, rounds, consts, g.sp.at(rounds));
+        return 2;
+    }
+    // Poseidon family: ip = [sbox(0 cube / 1 inverse) or depth..., partial_rounds]
+    auto statics_from = [&](size_t first, size_t num) {
+        std::vector<AllocatedScalar> st;
+        for (size_t i = 0; i < num; i++) st.push_back(AS(first + i));
+        return st;
+    };
+    if (g.name == "poseidon_hash_2" || g.name == "poseidon_hash_4" || g.name == "poseidon_perm") {
+        PoseidonParams params(6, 4, 4, g.ip.at(1), g.blob, g.blob_len);
+        SboxType sbox = g.ip.at(0) ? SboxType::Inverse : SboxType::Cube;
+        if (g.name == "poseidon_hash_2") {  // src/gadget_poseidon.rs:692-790
+            auto xl = AS(0), xr = AS(1);
+            auto st = statics_from(2, 4);
+            Poseidon_hash_2_gadget(h.cs, xl, xr, st, params, sbox, g.sp.at(0));
+            return 6;
+        }
+        if (g.name == "poseidon_hash_4") {  // :792-875
+            std::vector<AllocatedScalar> in;
+            for (size_t i = 0; i < 4; i++) in.push_back(AS(i));
+            auto st = statics_from(4, 2);
+            Poseidon_hash_4_gadget(h.cs, in, st, params, sbox, g.sp.at(0));
+            return 6;
+        }
+        std::vector<AllocatedScalar> in;  // :624-690
+        for (size_t i = 0; i < 6; i++) in.push_back(AS(i));
+        std::vector<Scalar> out(g.sp.begin(), g.sp.begin() + 6);
+        Poseidon_permutation_gadget(h.cs, in, params, sbox, out);
+        return 6;
+    }
+    if (g.name == "vsmt_4") {  // src/gadget_vsmt_4.rs:363-440 ; ip = [levels, partial_rounds], sp = [root]
+        size_t levels = g.ip.at(0);
+        PoseidonParams params(6, 4, 4, g.ip.at(1), g.blob, g.blob_len);
+        auto leaf = AS(0), idx = AS(1);
+        std::vector<AllocatedScalar> nodes;
+        for (size_t i = 0; i < 3 * levels; i++) nodes.push_back(AS(2 + i));
+        auto st = statics_from(2 + 3 * levels, 2);
+        vanilla_merkle_merkle_tree_4_verif_gadget(h.cs, levels, g.sp.at(0), leaf, idx, nodes, st, params, levels / 4);
+        return 4 + 3 * levels;
+    }
+    if (g.name == "vsmt_2") {  // src/gadget_vsmt_2.rs:262-352 ; ip = [depth, partial_rounds], sp = [root]
+        size_t depth = g.ip.at(0);
+        PoseidonParams params(6, 4, 4, g.ip.at(1), g.blob, g.blob_len);
+        auto leaf = AS(0);
+        std::vector<AllocatedScalar> bits, nodes;
+        for (size_t i = 0; i < depth; i++) bits.push_back(AS(1 + i));
+        for (size_t i = 0; i < depth; i++) nodes.push_back(AS(1 + depth + i));
+        auto st = statics_from(1 + 2 * depth, 4);
+        vanilla_merkle_merkle_tree_verif_gadget(h.cs, depth, g.sp.at(0), leaf, bits, nodes, st, params);
+        return 5 + 2 * depth;
+    }
+    throw R1CSError::GadgetError("unknown gadget " + g.name);
+}
+
+static GadgetSpec make_spec(const char* gadget, const uint32_t* ip, size_t ni, const uint8_t* sp, size_t ns, const uint8_t* blob, size_t bl) {
+    GadgetSpec g;
+    g.name = gadget;
+    g.ip.assign(ip, ip + ni);
+    for (size_t i = 0; i < ns; i++) g.sp.push_back(Scalar::from_bytes_mod_order(sp + 32 * i));
+    g.blob = blob; g.blob_len = bl;
+    return g;
+}
+
+static uint64_t low64(const Scalar& s) {
+    auto b = s.to_bytes();
+    uint64_t x = 0;
+    for (int i = 7; i >= 0; i--) x = (x << 8) | b[i];
+    return x;
+}
+
+}  // namespace bpr1cs
+
+using namespace bpr1cs;
+
+struct bpr1cs_vsmt4 {
+    std::unique_ptr<PoseidonParams> params;
+    std::unique_ptr<VanillaSparseMerkleTree_4> tree;
+};
+struct bpr1cs_vsmt2 {
+    std::unique_ptr<PoseidonParams> params;
+    std::unique_ptr<VanillaSparseMerkleTree> tree;
+};
+
+extern "C" {
+
+int bpr1cs_gadget_compile(const char* gadget, const uint32_t* iparams, size_t n_iparams, const uint8_t* sparams, size_t n_sparams,
+                          const uint8_t* poseidon_blob, size_t blob_len, bpr1cs_circuit** out, uint32_t* n, uint32_t* q, uint32_t* m,
+                          int* has_witness_program) {
+    try {
+        GadgetSpec g = make_spec(gadget, iparams, n_iparams, sparams, n_sparams, poseidon_blob, blob_len);
+        Transcript t("");
+        CircuitCompiler cc(t);
+        Harness h{cc, [&](size_t) { return cc.commit_placeholder(); }, [](size_t) { return std::optional<Scalar>(); },
+                  [](size_t) { return std::optional<uint64_t>(); }};
+        run_gadget(g, h);
+        *out = cc.finish(n, q, m);
+        if (has_witness_program) *has_witness_program = cc.complete ? 1 : 0;
+        return BPR1CS_OK;
+    } catch (const R1CSError& e) {
+        return e.code;
+    } catch (const std::exception&) {
+        return BPR1CS_ERR_INVALID_ARGUMENT;
+    }
+}
+
+int bpr1cs_gadget_prove_single(const char* gadget, const uint32_t* iparams, size_t n_iparams, const uint8_t* sparams, size_t n_sparams,
+                               const uint8_t* poseidon_blob, size_t blob_len, uint32_t gens_capacity, const uint8_t* label, size_t label_len,
+                               const uint8_t* values, const uint8_t* v_blindings, size_t m, const uint8_t rng_seed[32],
+                               uint8_t* proof_out, size_t proof_cap, size_t* proof_len, uint8_t* commitments_out) {
+    try {
+        GadgetSpec g = make_spec(gadget, iparams, n_iparams, sparams, n_sparams, poseidon_blob, blob_len);
+        BulletproofGens bp_gens(gens_capacity, 1);
+        PedersenGens pc_gens(bp_gens);
+        Transcript t((const char*)label, label_len);
+        Prover prover(pc_gens, t);
+        std::vector<Scalar> vals, bls;
+        for (size_t i = 0; i < m; i++) {
+            vals.push_back(Scalar::from_bytes_mod_order(values + 32 * i));
+            bls.push_back(Scalar::from_bytes_mod_order(v_blindings + 32 * i));
+        }
+        std::vector<CompressedRistretto> comms;
+        Harness h{prover,
+                  [&](size_t k) {
+                      if (k >= m) throw R1CSError::MissingAssignment();
+                      auto cv = prover.commit(vals[k], bls[k]);
+                      comms.push_back(cv.first);
+                      return cv.second;
+                  },
+                  [&](size_t k) { return std::optional<Scalar>(vals.at(k)); },
+                  [&](size_t k) { return std::optional<uint64_t>(low64(vals.at(k))); }};
+        run_gadget(g, h);
+        std::array<uint8_t, 32> seed;
+        memcpy(seed.data(), rng_seed, 32);
+        prover.set_rng_seed(seed);
+        R1CSProof proof = prover.prove(bp_gens);
+        if (proof.bytes.size() > proof_cap) return BPR1CS_ERR_INVALID_ARGUMENT;
+        memcpy(proof_out, proof.bytes.data(), proof.bytes.size());
+        *proof_len = proof.bytes.size();
+        if (commitments_out)
+            for (size_t i = 0; i < comms.size(); i++) memcpy(commitments_out + 32 * i, comms[i].data(), 32);
+        return BPR1CS_OK;
+    } catch (const R1CSError& e) {
+        return e.code;
+    } catch (const std::exception&) {
+        return BPR1CS_ERR_INVALID_ARGUMENT;
+    }
+}
+
+// ---- native hashes / trees (witness generation; reference L1) ------------------------------------
+int bpr1cs_poseidon_hash(int arity, int sbox_inverse, uint32_t partial_rounds, const uint8_t* blob, size_t blob_len, const uint8_t* inputs,
+                         uint8_t out[32]) {
+    try {
+        PoseidonParams p(6, 4, 4, partial_rounds, blob, blob_len);
+        SboxType s = sbox_inverse ? SboxType::Inverse : SboxType::Cube;
+        Scalar r;
+        if (arity == 2) r = Poseidon_hash_2(Scalar::from_bytes_mod_order(inputs), Scalar::from_bytes_mod_order(inputs + 32), p, s);
+        else if (arity == 4) {
+            std::array<Scalar, 4> in;
+            for (int i = 0; i < 4; i++) in[i] = Scalar::from_bytes_mod_order(inputs + 32 * i);
+            r = Poseidon_hash_4(in, p, s);
+        } else if (arity == 6) {  // raw permutation: 6 in, 6 out (out must hold 192 bytes)
+            std::vector<Scalar> in;
+            for (int i = 0; i < 6; i++) in.push_back(Scalar::from_bytes_mod_order(inputs + 32 * i));
+            auto o = Poseidon_permutation(in, p, s);
+            for (int i = 0; i < 6; i++) memcpy(out + 32 * i, o[i].to_bytes().data(), 32);
+            return BPR1CS_OK;
+        } else return BPR1CS_ERR_INVALID_ARGUMENT;
+        memcpy(out, r.to_bytes().data(), 32);
+        return BPR1CS_OK;
+    } catch (const R1CSError& e) {
+        return e.code;
+    }
+}
+int bpr1cs_mimc(const uint8_t* xl, const uint8_t* xr, const uint8_t* constants, size_t rounds, uint8_t out[32]) {
+    std::vector<Scalar> c;
+    for (size_t i = 0; i < rounds; i++) c.push_back(Scalar::from_bytes_mod_order(constants + 32 * i));
+    memcpy(out, mimc(Scalar::from_bytes_mod_order(xl), Scalar::from_bytes_mod_order(xr), c).to_bytes().data(), 32);
+    return BPR1CS_OK;
+}
+
+int bpr1cs_vsmt4_new(uint32_t levels, uint32_t partial_rounds, const uint8_t* blob, size_t blob_len, bpr1cs_vsmt4** out) {
+    try {
+        auto t = new bpr1cs_vsmt4();
+        t->params.reset(new PoseidonParams(6, 4, 4, partial_rounds, blob, blob_len));
+        t->tree.reset(new VanillaSparseMerkleTree_4(*t->params, levels));
+        *out = t;
+        return BPR1CS_OK;
+    } catch (const R1CSError& e) {
+        return e.code;
+    }
+}
+void bpr1cs_vsmt4_free(bpr1cs_vsmt4* t) { delete t; }
+void bpr1cs_vsmt4_root(const bpr1cs_vsmt4* t, uint8_t out[32]) { memcpy(out, t->tree->root.to_bytes().data(), 32); }
+void bpr1cs_vsmt4_update(bpr1cs_vsmt4* t, const uint8_t idx[32], const uint8_t val[32]) {
+    t->tree->update(Scalar::from_bytes_mod_order(idx), Scalar::from_bytes_mod_order(val));
+}
+// leaf_out[32], proof_out[levels*3*32] root level first (the order the reference test commits them)
+int bpr1cs_vsmt4_get(const bpr1cs_vsmt4* t, const uint8_t idx[32], uint8_t* leaf_out, uint8_t* proof_out) {
+    try {
+        std::vector<ProofNode> proof;
+        Scalar leaf = t->tree->get(Scalar::from_bytes_mod_order(idx), &proof);
+        memcpy(leaf_out, leaf.to_bytes().data(), 32);
+        size_t k = 0;
+        for (auto& pn : proof)
+            for (auto& s : pn) memcpy(proof_out + 32 * (k++), s.to_bytes().data(), 32);
+        return t->tree->verify_proof(Scalar::from_bytes_mod_order(idx), leaf, proof) ? BPR1CS_OK : BPR1CS_ERR_VERIFICATION;
+    } catch (const std::exception&) {
+        return BPR1CS_ERR_INVALID_ARGUMENT;
+    }
+}
+int bpr1cs_vsmt2_new(uint32_t depth, uint32_t partial_rounds, const uint8_t* blob, size_t blob_len, bpr1cs_vsmt2** out) {
+    try {
+        auto t = new bpr1cs_vsmt2();
+        t->params.reset(new PoseidonParams(6, 4, 4, partial_rounds, blob, blob_len));
+        t->tree.reset(new VanillaSparseMerkleTree(*t->params, depth));
+        *out = t;
+        return BPR1CS_OK;
+    } catch (const R1CSError& e) {
+        return e.code;
+    }
+}
+void bpr1cs_vsmt2_free(bpr1cs_vsmt2* t) { delete t; }
+void bpr1cs_vsmt2_root(const bpr1cs_vsmt2* t, uint8_t out[32]) { memcpy(out, t->tree->root.to_bytes().data(), 32); }
+void bpr1cs_vsmt2_update(bpr1cs_vsmt2* t, const uint8_t idx[32], const uint8_t val[32]) {
+    t->tree->update(Scalar::from_bytes_mod_order(idx), Scalar::from_bytes_mod_order(val));
+}
+// proof_out[depth*32] in tree.get order (root level first)
+int bpr1cs_vsmt2_get(const bpr1cs_vsmt2* t, const uint8_t idx[32], uint8_t* leaf_out, uint8_t* proof_out) {
+    try {
+        std::vector<Scalar> proof;
+        Scalar leaf = t->tree->get(Scalar::from_bytes_mod_order(idx), &proof);
+        memcpy(leaf_out, leaf.to_bytes().data(), 32);
+        for (size_t k = 0; k < proof.size(); k++) memcpy(proof_out + 32 * k, proof[k].to_bytes().data(), 32);
+        return t->tree->verify_proof(Scalar::from_bytes_mod_order(idx), leaf, proof) ? BPR1CS_OK : BPR1CS_ERR_VERIFICATION;
+    } catch (const std::exception&) {
+        return BPR1CS_ERR_INVALID_ARGUMENT;
+    }
+}
+}

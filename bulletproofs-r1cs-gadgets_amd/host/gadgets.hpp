@@ -1,0 +1,551 @@
+// The reference's in-scope gadgets, generic over `ConstraintSystem` exactly as the
+// Rust is generic over `CS: ConstraintSystem` (SURVEY §2 components 1-10).  Function
+// names, argument order and constraint order follow the reference line by line;
+// the only additions are the optional WitnessHint arguments that let the
+// CircuitCompiler move constraint synthesis onto the GPU.
+#pragma once
+#include <map>
+#include "r1cs.hpp"
+
+namespace bpr1cs {
+
+// ---- src/scalar_utils.rs ---------------------------------------------------
+// get_bits (scalar_utils.rs:144-153): LSB first
+inline std::vector<uint8_t> get_bits(const Scalar& s, size_t process_bits) {
+    auto b = s.to_bytes();
+    std::vector<uint8_t> bits(process_bits);
+    for (size_t i = 0; i < process_bits; i++) bits[i] = (b[i >> 3] >> (i & 7)) & 1;
+    return bits;
+}
+// get_base_4_repr (scalar_utils.rs:170-186): most-significant digit first
+inline std::vector<uint8_t> get_base_4_repr(const Scalar& s, size_t limit_bytes) {
+    auto bits = get_bits(s, limit_bytes * 8);
+    std::vector<uint8_t> rev(bits.rbegin(), bits.rend()), out(limit_bytes * 4);
+    for (size_t i = 0; i + 1 < rev.size(); i += 2) out[i / 2] = 2 * rev[i] + rev[i + 1];
+    return out;
+}
+
+// ---- src/r1cs_utils.rs ------------------------------------------------------
+// constrain_lc_with_scalar (r1cs_utils.rs:51-53)
+inline void constrain_lc_with_scalar(ConstraintSystem& cs, const LinearCombination& lc, const Scalar& scalar) {
+    cs.constrain(lc - LinearCombination(scalar));
+}
+// positive_no_gadget (r1cs_utils.rs:20-48)
+inline void positive_no_gadget(ConstraintSystem& cs, const AllocatedQuantity& v, size_t bit_size) {
+    std::vector<std::pair<Variable, Scalar>> constraint_v{{v.variable, -Scalar::one()}};
+    Scalar exp_2 = Scalar::one();
+    for (size_t i = 0; i < bit_size; i++) {
+        std::optional<std::pair<Scalar, Scalar>> asg;
+        if (v.assignment) {
+            uint64_t bit = (*v.assignment >> i) & 1;
+            asg = std::make_pair(Scalar(1 - bit), Scalar(bit));
+        }
+        MulVars mv = cs.allocate_multiplier(asg, WitnessHint::bit_of(v.variable, (uint32_t)i, true),
+                                            WitnessHint::bit_of(v.variable, (uint32_t)i, false));
+        cs.constrain(LinearCombination(mv.out));
+        cs.constrain(mv.left + (mv.right - 1u));
+        constraint_v.push_back({mv.right, exp_2});
+        exp_2 = exp_2 + exp_2;
+    }
+    cs.constrain(LinearCombination(constraint_v));
+}
+
+// ---- src/factors.rs:12-21 -----------------------------------------------------
+inline void factors(ConstraintSystem& cs, const AllocatedScalar& p, const AllocatedScalar& q, const Scalar& r) {
+    MulVars mv = cs.multiply(LinearCombination(p.variable), LinearCombination(q.variable));
+    constrain_lc_with_scalar(cs, LinearCombination(mv.out), r);
+}
+
+// ---- src/gadget_zero_nonzero.rs:46-66 ------------------------------------------
+inline void is_nonzero_gadget(ConstraintSystem& cs, const AllocatedScalar& x, const AllocatedScalar& x_inv) {
+    LinearCombination x_lc(x.variable);
+    LinearCombination y_lc(Scalar::one());
+    LinearCombination one_minus_y_lc = LinearCombination(Variable::One()) - y_lc;
+    MulVars m1 = cs.multiply(x_lc, one_minus_y_lc);
+    cs.constrain(LinearCombination(m1.out));
+    LinearCombination inv_lc(std::vector<std::pair<Variable, Scalar>>{{x_inv.variable, Scalar::one()}});
+    MulVars m2 = cs.multiply(x_lc, inv_lc);
+    cs.constrain(m2.out - y_lc);
+}
+
+// ---- src/gadget_bound_check.rs:18-45 ---------------------------------------------
+inline void bound_check_gadget(ConstraintSystem& cs, const AllocatedQuantity& v, const AllocatedQuantity& a,
+                               const AllocatedQuantity& b, uint64_t max, uint64_t min, size_t bit_size) {
+    cs.constrain(v.variable - LinearCombination(min) - LinearCombination(a.variable));
+    cs.constrain(LinearCombination(max) - LinearCombination(v.variable) - LinearCombination(b.variable));
+    constrain_lc_with_scalar(cs, a.variable + b.variable, Scalar(max - min));
+    positive_no_gadget(cs, a, bit_size);
+    positive_no_gadget(cs, b, bit_size);
+}
+
+// ---- src/gadget_poseidon.rs --------------------------------------------------------
+constexpr uint64_t PADDING_CONST = 101;  // gadget_poseidon.rs:425
+constexpr uint64_t ZERO_CONST = 0;       // :426
+
+// PoseidonParams (gadget_poseidon.rs:27-94); constants = the reference's effective
+// values after its own hex parsing (trap T1), shipped as data/poseidon_params_ristretto.bin
+struct PoseidonParams {
+    size_t width, full_rounds_beginning, full_rounds_end, partial_rounds;
+    std::vector<Scalar> round_keys;
+    std::vector<std::vector<Scalar>> MDS_matrix;
+    // `blob` = 36 MDS entries + 960 round constants, 32 bytes each
+    PoseidonParams(size_t width_, size_t fb, size_t fe, size_t pr, const uint8_t* blob, size_t blob_len)
+        : width(width_), full_rounds_beginning(fb), full_rounds_end(fe), partial_rounds(pr) {
+        size_t total = fb + pr + fe, cap = total * width;
+        size_t avail = blob_len / 32 >= 36 ? blob_len / 32 - 36 : 0;
+        if (avail < cap) throw R1CSError::GadgetError("Not enough round constants");                      // :59-61
+        if (width != 6) throw R1CSError::GadgetError("Incorrect width, only width 6 is supported now");   // :75-82
+        for (size_t i = 0; i < cap; i++) round_keys.push_back(Scalar::from_bytes_mod_order(blob + 32 * (36 + i)));
+        MDS_matrix.assign(width, std::vector<Scalar>(width));
+        for (size_t i = 0; i < width; i++)
+            for (size_t j = 0; j < width; j++) MDS_matrix[i][j] = Scalar::from_bytes_mod_order(blob + 32 * (6 * i + j));
+    }
+    size_t get_total_rounds() const { return full_rounds_beginning + partial_rounds + full_rounds_end; }
+};
+
+enum class SboxType { Cube, Inverse };  // gadget_poseidon.rs:114-117
+
+inline Scalar apply_sbox(SboxType t, const Scalar& e) {  // :120-125
+    return t == SboxType::Cube ? (e * e) * e : e.invert();
+}
+
+// synthesize_sbox (gadget_poseidon.rs:127-185); trap T2 replicated (inp_plus_const never tied to var_l)
+inline Variable synthesize_sbox(ConstraintSystem& cs, SboxType t, const LinearCombination& input_var, const Scalar& round_key) {
+    LinearCombination inp_plus_const = input_var + LinearCombination(round_key);
+    if (t == SboxType::Cube) {
+        MulVars m1 = cs.multiply(inp_plus_const, inp_plus_const);
+        MulVars m2 = cs.multiply(LinearCombination(m1.out), LinearCombination(m1.left));
+        return m2.out;
+    }
+    std::optional<Scalar> val_l = cs.evaluate_lc(inp_plus_const);
+    std::optional<Scalar> val_r;
+    if (val_l) val_r = val_l->invert();
+    auto l = cs.allocate_single(val_l, WitnessHint::of_lc(inp_plus_const));
+    auto r = cs.allocate_single(val_r, WitnessHint::inverse_of_left());
+    is_nonzero_gadget(cs, AllocatedScalar{l.first, val_l}, AllocatedScalar{r.first, val_r});
+    constrain_lc_with_scalar(cs, LinearCombination(*r.second), Scalar::one());
+    return r.first;
+}
+
+// Poseidon_permutation (gadget_poseidon.rs:189-280)
+inline std::vector<Scalar> Poseidon_permutation(const std::vector<Scalar>& input, const PoseidonParams& params, SboxType sbox) {
+    size_t w = params.width;
+    std::vector<Scalar> st = input, tmp(w);
+    size_t off = 0;
+    auto linear = [&]() {
+        for (size_t i = 0; i < w; i++) tmp[i] = Scalar();
+        for (size_t j = 0; j < w; j++)
+            for (size_t i = 0; i < w; i++) tmp[i] += st[j] * params.MDS_matrix[i][j];
+        st = tmp;
+    };
+    for (size_t r = 0; r < params.full_rounds_beginning; r++) {
+        for (size_t i = 0; i < w; i++) st[i] = apply_sbox(sbox, st[i] + params.round_keys[off++]);
+        linear();
+    }
+    for (size_t r = 0; r < params.partial_rounds; r++) {
+        for (size_t i = 0; i < w; i++) st[i] += params.round_keys[off++];
+        st[w - 1] = apply_sbox(sbox, st[w - 1]);
+        linear();
+    }
+    for (size_t r = 0; r < params.full_rounds_end; r++) {
+        for (size_t i = 0; i < w; i++) st[i] = apply_sbox(sbox, st[i] + params.round_keys[off++]);
+        linear();
+    }
+    return st;
+}
+
+// Poseidon_permutation_constraints (gadget_poseidon.rs:282-399)
+inline std::vector<LinearCombination> Poseidon_permutation_constraints(ConstraintSystem& cs, std::vector<LinearCombination> input,
+                                                                       const PoseidonParams& params, SboxType sbox_type) {
+    size_t width = params.width;
+    auto apply_linear_layer = [&](const std::vector<LinearCombination>& sbox_outs) {
+        std::vector<LinearCombination> next(width);
+        for (size_t j = 0; j < width; j++)
+            for (size_t i = 0; i < width; i++) next[i] = next[i] + sbox_outs[j] * params.MDS_matrix[i][j];
+        return next;
+    };
+    std::vector<LinearCombination> input_vars = std::move(input);
+    size_t off = 0;
+    for (size_t k = 0; k < params.full_rounds_beginning; k++) {
+        std::vector<LinearCombination> outs(width);
+        for (size_t i = 0; i < width; i++) outs[i] = LinearCombination(synthesize_sbox(cs, sbox_type, input_vars[i], params.round_keys[off++]));
+        input_vars = apply_linear_layer(outs);
+    }
+    for (size_t k = 0; k < params.partial_rounds; k++) {
+        std::vector<LinearCombination> outs(width);
+        for (size_t i = 0; i < width; i++) {
+            const Scalar& rk = params.round_keys[off++];
+            if (i == width - 1) outs[i] = LinearCombination(synthesize_sbox(cs, sbox_type, input_vars[i], rk));
+            else outs[i] = input_vars[i] + LinearCombination(rk);
+        }
+        input_vars = apply_linear_layer(outs);
+        for (auto& lc : input_vars) lc = lc.simplify();
+    }
+    for (size_t k = 0; k < params.full_rounds_end; k++) {
+        std::vector<LinearCombination> outs(width);
+        for (size_t i = 0; i < width; i++) outs[i] = LinearCombination(synthesize_sbox(cs, sbox_type, input_vars[i], params.round_keys[off++]));
+        input_vars = apply_linear_layer(outs);
+    }
+    return input_vars;
+}
+
+// Poseidon_permutation_gadget (gadget_poseidon.rs:402-420)
+inline void Poseidon_permutation_gadget(ConstraintSystem& cs, const std::vector<AllocatedScalar>& input, const PoseidonParams& params,
+                                        SboxType sbox_type, const std::vector<Scalar>& output) {
+    std::vector<LinearCombination> in;
+    for (auto& e : input) in.push_back(LinearCombination(e.variable));
+    auto out = Poseidon_permutation_constraints(cs, in, params, sbox_type);
+    for (size_t i = 0; i < params.width; i++) constrain_lc_with_scalar(cs, out[i], output[i]);
+}
+
+// Poseidon_hash_2 (gadget_poseidon.rs:428-443)
+inline Scalar Poseidon_hash_2(const Scalar& xl, const Scalar& xr, const PoseidonParams& params, SboxType sbox) {
+    return Poseidon_permutation({Scalar(ZERO_CONST), xl, xr, Scalar(PADDING_CONST), Scalar(ZERO_CONST), Scalar(ZERO_CONST)}, params, sbox)[1];
+}
+// Poseidon_hash_2_constraints (:445-468)
+inline LinearCombination Poseidon_hash_2_constraints(ConstraintSystem& cs, const LinearCombination& xl, const LinearCombination& xr,
+                                                     const std::vector<LinearCombination>& statics, const PoseidonParams& params, SboxType sbox_type) {
+    if (statics.size() != params.width - 2) throw R1CSError::GadgetError("statics");
+    std::vector<LinearCombination> inputs{statics[0], xl, xr};
+    for (size_t i = 1; i < statics.size(); i++) inputs.push_back(statics[i]);
+    return Poseidon_permutation_constraints(cs, inputs, params, sbox_type)[1];
+}
+// Poseidon_hash_2_gadget (:470-486)
+inline void Poseidon_hash_2_gadget(ConstraintSystem& cs, const AllocatedScalar& xl, const AllocatedScalar& xr,
+                                   const std::vector<AllocatedScalar>& statics, const PoseidonParams& params, SboxType sbox_type, const Scalar& output) {
+    std::vector<LinearCombination> st;
+    for (auto& s : statics) st.push_back(LinearCombination(s.variable));
+    auto hash = Poseidon_hash_2_constraints(cs, LinearCombination(xl.variable), LinearCombination(xr.variable), st, params, sbox_type);
+    constrain_lc_with_scalar(cs, hash, output);
+}
+// Poseidon_hash_4 (:488-503)
+inline Scalar Poseidon_hash_4(const std::array<Scalar, 4>& in, const PoseidonParams& params, SboxType sbox) {
+    return Poseidon_permutation({Scalar(ZERO_CONST), in[0], in[1], in[2], in[3], Scalar(PADDING_CONST)}, params, sbox)[1];
+}
+// Poseidon_hash_4_constraints (:505-530)
+inline LinearCombination Poseidon_hash_4_constraints(ConstraintSystem& cs, const std::array<LinearCombination, 4>& input,
+                                                     const std::vector<LinearCombination>& statics, const PoseidonParams& params, SboxType sbox_type) {
+    if (statics.size() != params.width - 4) throw R1CSError::GadgetError("statics");
+    std::vector<LinearCombination> inputs{statics[0], input[0], input[1], input[2], input[3]};
+    for (size_t i = 1; i < statics.size(); i++) inputs.push_back(statics[i]);
+    return Poseidon_permutation_constraints(cs, inputs, params, sbox_type)[1];
+}
+// Poseidon_hash_4_gadget (:532-551)
+inline void Poseidon_hash_4_gadget(ConstraintSystem& cs, const std::vector<AllocatedScalar>& input, const std::vector<AllocatedScalar>& statics,
+                                   const PoseidonParams& params, SboxType sbox_type, const Scalar& output) {
+    std::vector<LinearCombination> st;
+    for (auto& s : statics) st.push_back(LinearCombination(s.variable));
+    std::array<LinearCombination, 4> arr;
+    for (size_t i = 0; i < input.size() && i < 4; i++) arr[i] = LinearCombination(input[i].variable);
+    auto hash = Poseidon_hash_4_constraints(cs, arr, st, params, sbox_type);
+    constrain_lc_with_scalar(cs, hash, output);
+}
+// allocate_statics_for_prover (:554-578) — commitments with blinding 0 (trap T6)
+inline std::vector<AllocatedScalar> allocate_statics_for_prover(Prover& prover, size_t num_statics) {
+    std::vector<AllocatedScalar> statics;
+    auto push = [&](uint64_t val) {
+        auto cv = prover.commit(Scalar(val), Scalar::zero());
+        statics.push_back({cv.second, Scalar(val)});
+    };
+    push(ZERO_CONST);
+    push(PADDING_CONST);
+    for (size_t i = 2; i < num_statics; i++) push(ZERO_CONST);
+    return statics;
+}
+// allocate_statics_for_verifier (:581-608)
+inline std::vector<AllocatedScalar> allocate_statics_for_verifier(Verifier& verifier, size_t num_statics, const PedersenGens& pc_gens) {
+    auto pad_comm = pc_gens.commit(Scalar(PADDING_CONST), Scalar::zero());
+    auto zero_comm = pc_gens.commit(Scalar(ZERO_CONST), Scalar::zero());
+    std::vector<AllocatedScalar> statics;
+    statics.push_back({verifier.commit(zero_comm), std::nullopt});
+    statics.push_back({verifier.commit(pad_comm), std::nullopt});
+    for (size_t i = 2; i < num_statics; i++) statics.push_back({verifier.commit(zero_comm), std::nullopt});
+    return statics;
+}
+
+// ---- src/gadget_mimc.rs ----------------------------------------------------------------
+constexpr size_t MIMC_ROUNDS = 322;  // gadget_mimc.rs:15
+// mimc (:19-39)
+inline Scalar mimc(Scalar xl, Scalar xr, const std::vector<Scalar>& constants) {
+    for (auto& c : constants) {
+        Scalar tmp1 = xl + c;
+        Scalar tmp2 = (tmp1 * tmp1) * tmp1 + xr;
+        xr = xl;
+        xl = tmp2;
+    }
+    return xl;
+}
+// mimc_hash_2 (:55-79)
+inline LinearCombination mimc_hash_2(ConstraintSystem& cs, LinearCombination left, LinearCombination right, size_t mimc_rounds,
+                                     const std::vector<Scalar>& mimc_constants) {
+    LinearCombination left_v = std::move(left), right_v = std::move(right);
+    for (size_t j = 0; j < mimc_rounds; j++) {
+        LinearCombination const_lc(std::vector<std::pair<Variable, Scalar>>{{Variable::One(), mimc_constants[j]}});
+        LinearCombination left_plus_const = left_v + const_lc;
+        MulVars m1 = cs.multiply(left_plus_const, left_plus_const);
+        MulVars m2 = cs.multiply(LinearCombination(m1.out), LinearCombination(m1.left));
+        LinearCombination tmp = LinearCombination(m2.out) + right_v;
+        right_v = left_v;
+        left_v = tmp;
+    }
+    return left_v;
+}
+// mimc_gadget (:41-52)
+inline void mimc_gadget(ConstraintSystem& cs, const AllocatedScalar& left, const AllocatedScalar& right, size_t mimc_rounds,
+                        const std::vector<Scalar>& mimc_constants, const Scalar& image) {
+    auto res = mimc_hash_2(cs, LinearCombination(left.variable), LinearCombination(right.variable), mimc_rounds, mimc_constants);
+    constrain_lc_with_scalar(cs, res, image);
+}
+
+// ---- src/gadget_set_membership.rs ------------------------------------------------------------
+// bit_gadget (:16-38)
+inline void bit_gadget(ConstraintSystem& cs, const AllocatedQuantity& v) {
+    std::optional<std::pair<Scalar, Scalar>> asg;
+    if (v.assignment) asg = std::make_pair(Scalar(1 - *v.assignment), Scalar(*v.assignment));
+    MulVars mv = cs.allocate_multiplier(asg, WitnessHint::bit_of(v.variable, 0, true), WitnessHint::bit_of(v.variable, 0, false));
+    LinearCombination neg_v(std::vector<std::pair<Variable, Scalar>>{{v.variable, -Scalar::one()}});
+    cs.constrain(mv.right + neg_v);
+    cs.constrain(LinearCombination(mv.out));
+    cs.constrain(mv.left + (mv.right - 1u));
+}
+// vector_sum_gadget (:41-54)
+inline void vector_sum_gadget(ConstraintSystem& cs, const std::vector<AllocatedQuantity>& vector, uint64_t sum) {
+    std::vector<std::pair<Variable, Scalar>> constraints{{Variable::One(), -Scalar(sum)}};
+    for (auto& i : vector) constraints.push_back({i.variable, Scalar::one()});
+    cs.constrain(LinearCombination(constraints));
+}
+// vector_product_gadget (:58-86)
+inline void vector_product_gadget(ConstraintSystem& cs, const std::vector<uint64_t>& items, const std::vector<AllocatedQuantity>& vector,
+                                  const AllocatedQuantity& value) {
+    std::vector<std::pair<Variable, Scalar>> constraints{{value.variable, -Scalar::one()}};
+    for (size_t i = 0; i < items.size(); i++) {
+        std::optional<std::pair<Scalar, Scalar>> asg;
+        if (vector[i].assignment) asg = std::make_pair(Scalar(*vector[i].assignment), Scalar(items[i]));
+        MulVars mv = cs.allocate_multiplier(asg, WitnessHint::of_lc(LinearCombination(vector[i].variable)),
+                                            WitnessHint::of_lc(LinearCombination(Scalar(items[i]))));
+        constrain_lc_with_scalar(cs, LinearCombination(mv.right), Scalar(items[i]));
+        MulVars m2 = cs.multiply(LinearCombination(mv.left), LinearCombination(value.variable));
+        cs.constrain(mv.out - m2.out);
+        constraints.push_back({mv.out, Scalar::one()});
+    }
+    cs.constrain(LinearCombination(constraints));
+}
+
+// ---- src/gadget_vsmt_4.rs ----------------------------------------------------------------------
+struct ScalarKey {
+    std::array<uint8_t, 32> b;
+    bool operator<(const ScalarKey& o) const { return b < o.b; }
+};
+using ProofNode = std::array<Scalar, 3>;
+// VanillaSparseMerkleTree_4 (gadget_vsmt_4.rs:32-165); TreeDepth is a constructor
+// parameter (the reference hard-codes 128, trap T3): depth = 4-ary levels, LeafIndexBytes = depth/4
+class VanillaSparseMerkleTree_4 {
+public:
+    size_t depth, leaf_index_bytes;
+    const PoseidonParams& hash_params;
+    std::vector<Scalar> empty_tree_hashes;
+    std::map<ScalarKey, std::array<Scalar, 4>> db;
+    Scalar root;
+    VanillaSparseMerkleTree_4(const PoseidonParams& p, size_t tree_depth = 128) : depth(tree_depth), leaf_index_bytes(tree_depth / 4), hash_params(p) {
+        if (tree_depth % 4 != 0) throw R1CSError::GadgetError("Tree depth should be a multiple of 4");
+        empty_tree_hashes.push_back(Scalar::zero());
+        for (size_t i = 1; i <= depth; i++) {
+            Scalar prev = empty_tree_hashes[i - 1];
+            std::array<Scalar, 4> input{prev, prev, prev, prev};
+            Scalar nw = Poseidon_hash_4(input, hash_params, SboxType::Inverse);
+            db[ScalarKey{nw.to_bytes()}] = input;
+            empty_tree_hashes.push_back(nw);
+        }
+        root = empty_tree_hashes[depth];
+    }
+    Scalar update(const Scalar& idx, const Scalar& val) {
+        std::vector<ProofNode> sidenodes;
+        get(idx, &sidenodes);
+        auto cur_idx = get_base_4_repr(idx, leaf_index_bytes);
+        Scalar cur_val = val;
+        for (size_t k = cur_idx.size(); k-- > 0;) {
+            uint8_t d = cur_idx[k];
+            ProofNode pn = sidenodes.back();
+            sidenodes.pop_back();
+            std::array<Scalar, 4> input;
+            for (size_t i = 0, j = 0; i < 4; i++) input[i] = (i == d) ? cur_val : pn[j++];
+            Scalar h = Poseidon_hash_4(input, hash_params, SboxType::Inverse);
+            db[ScalarKey{h.to_bytes()}] = input;
+            cur_val = h;
+        }
+        root = cur_val;
+        return cur_val;
+    }
+    Scalar get(const Scalar& idx, std::vector<ProofNode>* proof) const {
+        auto cur_idx = get_base_4_repr(idx, leaf_index_bytes);
+        Scalar cur_node = root;
+        for (uint8_t d : cur_idx) {
+            const auto& children = db.at(ScalarKey{cur_node.to_bytes()});
+            cur_node = children[d];
+            if (proof) {
+                ProofNode pn;
+                for (size_t i = 0, j = 0; i < 4; i++)
+                    if (i != d) pn[j++] = children[i];
+                proof->push_back(pn);
+            }
+        }
+        return cur_node;
+    }
+    bool verify_proof(const Scalar& idx, const Scalar& val, const std::vector<ProofNode>& proof, const Scalar* root_opt = nullptr) const {
+        auto cur_idx = get_base_4_repr(idx, leaf_index_bytes);
+        Scalar cur_val = val;
+        for (size_t i = 0; i < cur_idx.size(); i++) {
+            uint8_t d = cur_idx[cur_idx.size() - 1 - i];
+            const ProofNode& pn = proof[depth - 1 - i];
+            std::array<Scalar, 4> input;
+            for (size_t t = 0, j = 0; t < 4; t++) input[t] = (t == d) ? cur_val : pn[j++];
+            cur_val = Poseidon_hash_4(input, hash_params, SboxType::Inverse);
+        }
+        return cur_val == (root_opt ? *root_opt : root);
+    }
+};
+
+// vanilla_merkle_merkle_tree_4_verif_gadget (gadget_vsmt_4.rs:199-312).  `depth` is unused as in the
+// reference (trap T3); the level count is LeafIndexBytes*4, passed as `leaf_index_bytes`.
+inline void vanilla_merkle_merkle_tree_4_verif_gadget(ConstraintSystem& cs, size_t depth, const Scalar& root, const AllocatedScalar& leaf_val,
+                                                      const AllocatedScalar& leaf_index, std::vector<AllocatedScalar> proof_nodes,
+                                                      const std::vector<AllocatedScalar>& statics_, const PoseidonParams& poseidon_params,
+                                                      size_t leaf_index_bytes) {
+    (void)depth;
+    LinearCombination prev_hash(leaf_val.variable);
+    std::vector<LinearCombination> statics;
+    for (auto& s : statics_) statics.push_back(LinearCombination(s.variable));
+    std::vector<std::pair<Variable, Scalar>> constraint_leaf_index{{leaf_index.variable, -Scalar::one()}};
+    Scalar exp_4 = Scalar::one(), two(2), four(4);
+    std::optional<std::array<uint8_t, 32>> lbytes;
+    if (leaf_index.assignment) lbytes = leaf_index.assignment->to_bytes();
+    auto LC = [](const Variable& v) { return LinearCombination(v); };
+    for (size_t i = 0; i < leaf_index_bytes; i++) {
+        for (size_t j = 0; j < 4; j++) {
+            auto bit_pair = [&](uint32_t bitpos) {
+                std::optional<std::pair<Scalar, Scalar>> asg;
+                if (lbytes) {
+                    uint64_t bit = ((*lbytes)[i] >> (bitpos & 7)) & 1;
+                    asg = std::make_pair(Scalar(bit), Scalar(1 - bit));
+                }
+                MulVars mv = cs.allocate_multiplier(asg, WitnessHint::bit_of(leaf_index.variable, (uint32_t)(8 * i) + (bitpos & 7), false),
+                                                    WitnessHint::bit_of(leaf_index.variable, (uint32_t)(8 * i) + (bitpos & 7), true));
+                cs.constrain(LinearCombination(mv.out));
+                cs.constrain(mv.left + (mv.right - 1u));
+                return mv;
+            };
+            MulVars m0 = bit_pair((uint32_t)(2 * j));
+            MulVars m1 = bit_pair((uint32_t)(2 * j + 1));
+            Variable b0 = m0.left, b0_1 = m0.right, b1 = m1.left, b1_1 = m1.right;
+            constraint_leaf_index.push_back({b1, two * exp_4});
+            constraint_leaf_index.push_back({b0, exp_4});
+            LinearCombination N3(proof_nodes.back().variable); proof_nodes.pop_back();
+            LinearCombination N2(proof_nodes.back().variable); proof_nodes.pop_back();
+            LinearCombination N1(proof_nodes.back().variable); proof_nodes.pop_back();
+            Variable b0_1_b1_1 = cs.multiply(LC(b0_1), LC(b1_1)).out;
+            Variable b0_1_b1 = cs.multiply(LC(b0_1), LC(b1)).out;
+            Variable b0_b1_1 = cs.multiply(LC(b0), LC(b1_1)).out;
+            Variable b0_b1 = cs.multiply(LC(b0), LC(b1)).out;
+            Variable c0_1 = cs.multiply(LC(b0_1_b1_1), prev_hash).out;
+            Variable c0_2 = cs.multiply(LC(b0), N1).out;
+            Variable c0_3 = cs.multiply(LC(b0_1_b1), N1).out;
+            LinearCombination c0 = c0_1 + c0_2 + LC(c0_3);
+            Variable c1_1 = cs.multiply(LC(b0_1_b1_1), N1).out;
+            Variable c1_2 = cs.multiply(LC(b0_b1_1), prev_hash).out;
+            Variable c1_3 = cs.multiply(LC(b0_1_b1), N2).out;
+            Variable c1_4 = cs.multiply(LC(b0_b1), N2).out;
+            LinearCombination c1 = c1_1 + c1_2 + LC(c1_3) + LC(c1_4);
+            Variable c2_1 = cs.multiply(LC(b1_1), N2).out;
+            Variable c2_2 = cs.multiply(LC(b0_1_b1), prev_hash).out;
+            Variable c2_3 = cs.multiply(LC(b0_b1), N3).out;
+            LinearCombination c2 = c2_1 + c2_2 + LC(c2_3);
+            Variable c3_1 = cs.multiply(LC(b1_1), N3).out;
+            Variable c3_2 = cs.multiply(LC(b0_1_b1), N3).out;
+            Variable c3_3 = cs.multiply(LC(b0_b1), prev_hash).out;
+            LinearCombination c3 = c3_1 + c3_2 + LC(c3_3);
+            prev_hash = Poseidon_hash_4_constraints(cs, {c0, c1, c2, c3}, statics, poseidon_params, SboxType::Inverse);
+            exp_4 = exp_4 * four;
+        }
+    }
+    cs.constrain(LinearCombination(constraint_leaf_index));
+    constrain_lc_with_scalar(cs, prev_hash, root);
+}
+
+// ---- src/gadget_vsmt_2.rs ------------------------------------------------------------------------
+// VanillaSparseMerkleTree (gadget_vsmt_2.rs:27-166); TreeDepth parameterised (reference: 253)
+class VanillaSparseMerkleTree {
+public:
+    size_t depth;
+    const PoseidonParams& hash_params;
+    std::vector<Scalar> empty_tree_hashes;
+    std::map<ScalarKey, std::pair<Scalar, Scalar>> db;
+    Scalar root;
+    VanillaSparseMerkleTree(const PoseidonParams& p, size_t tree_depth = 253) : depth(tree_depth), hash_params(p) {
+        empty_tree_hashes.push_back(Scalar::zero());
+        for (size_t i = 1; i <= depth; i++) {
+            Scalar prev = empty_tree_hashes[i - 1];
+            Scalar nw = Poseidon_hash_2(prev, prev, hash_params, SboxType::Inverse);
+            db[ScalarKey{nw.to_bytes()}] = {prev, prev};
+            empty_tree_hashes.push_back(nw);
+        }
+        root = empty_tree_hashes[depth];
+    }
+    Scalar update(const Scalar& idx, const Scalar& val) {
+        std::vector<Scalar> sidenodes;
+        get(idx, &sidenodes);
+        auto bits = get_bits(idx, depth);
+        Scalar cur_val = val;
+        for (size_t i = 0; i < depth; i++) {
+            Scalar side = sidenodes.back();
+            sidenodes.pop_back();
+            Scalar h;
+            if (bits[i]) { h = Poseidon_hash_2(side, cur_val, hash_params, SboxType::Inverse); db[ScalarKey{h.to_bytes()}] = {side, cur_val}; }
+            else { h = Poseidon_hash_2(cur_val, side, hash_params, SboxType::Inverse); db[ScalarKey{h.to_bytes()}] = {cur_val, side}; }
+            cur_val = h;
+        }
+        root = cur_val;
+        return cur_val;
+    }
+    Scalar get(const Scalar& idx, std::vector<Scalar>* proof) const {
+        auto bits = get_bits(idx, depth);
+        Scalar cur = root;
+        for (size_t i = 0; i < depth; i++) {
+            const auto& v = db.at(ScalarKey{cur.to_bytes()});
+            if (bits[depth - 1 - i]) { cur = v.second; if (proof) proof->push_back(v.first); }
+            else { cur = v.first; if (proof) proof->push_back(v.second); }
+        }
+        return cur;
+    }
+    bool verify_proof(const Scalar& idx, const Scalar& val, const std::vector<Scalar>& proof, const Scalar* root_opt = nullptr) const {
+        auto bits = get_bits(idx, depth);
+        Scalar cur = val;
+        for (size_t i = 0; i < depth; i++) {
+            const Scalar& p = proof[depth - 1 - i];
+            cur = bits[i] ? Poseidon_hash_2(p, cur, hash_params, SboxType::Inverse) : Poseidon_hash_2(cur, p, hash_params, SboxType::Inverse);
+        }
+        return cur == (root_opt ? *root_opt : root);
+    }
+};
+
+// vanilla_merkle_merkle_tree_verif_gadget (gadget_vsmt_2.rs:171-209)
+inline void vanilla_merkle_merkle_tree_verif_gadget(ConstraintSystem& cs, size_t depth, const Scalar& root, const AllocatedScalar& leaf_val,
+                                                    const std::vector<AllocatedScalar>& leaf_index_bits, const std::vector<AllocatedScalar>& proof_nodes,
+                                                    const std::vector<AllocatedScalar>& statics_, const PoseidonParams& poseidon_params) {
+    LinearCombination prev_hash;
+    std::vector<LinearCombination> statics;
+    for (auto& s : statics_) statics.push_back(LinearCombination(s.variable));
+    for (size_t i = 0; i < depth; i++) {
+        LinearCombination leaf_val_lc = (i == 0) ? LinearCombination(leaf_val.variable) : prev_hash;
+        LinearCombination one_minus_leaf_side = Variable::One() - leaf_index_bits[i].variable;
+        Variable left_1 = cs.multiply(one_minus_leaf_side, leaf_val_lc).out;
+        Variable left_2 = cs.multiply(LinearCombination(leaf_index_bits[i].variable), LinearCombination(proof_nodes[i].variable)).out;
+        LinearCombination left = left_1 + left_2;
+        Variable right_1 = cs.multiply(LinearCombination(leaf_index_bits[i].variable), leaf_val_lc).out;
+        Variable right_2 = cs.multiply(one_minus_leaf_side, LinearCombination(proof_nodes[i].variable)).out;
+        LinearCombination right = right_1 + right_2;
+        prev_hash = Poseidon_hash_2_constraints(cs, left, right, statics, poseidon_params, SboxType::Inverse);
+    }
+    constrain_lc_with_scalar(cs, prev_hash, root);
+}
+
+}  // namespace bpr1cs

@@ -13,6 +13,7 @@
 // the prover itself are behind the C ABI (include/bpr1cs.h).
 #pragma once
 #include <stdint.h>
+#include <string.h>
 #include <array>
 #include <optional>
 #include <string>

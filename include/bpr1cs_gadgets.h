@@ -1,0 +1,63 @@
+/* bpr1cs_gadgets.h — C ABI of the host front-end (libbpr1cs_gadgets.so).
+ *
+ * The front-end is a C++ mirror of the reference's gadget layer (L1/L2 of SURVEY §1:
+ * src/gadget_*.rs, src/r1cs_utils.rs, src/scalar_utils.rs) over a C++ mirror of the
+ * `bulletproofs::r1cs` trait boundary (host/r1cs.hpp, host/gadgets.hpp).  This header
+ * exposes, for bindings and tests:
+ *   - gadget -> device circuit compilation (constraints + witness program), the shape a
+ *     Rust shim obtains by running a gadget once under a recording ConstraintSystem;
+ *   - the reference's single-proof proving harnesses over the C++ `Prover`;
+ *   - the native hashes / sparse Merkle trees that generate witnesses.
+ * Gadget names, integer parameters `ip` and scalar parameters `sp` (32-byte LE each):
+ *   "factors"          sp=[r]                                   values: p, q                       (src/factors.rs:48-103)
+ *   "bound_check"      ip=[bits, min_lo,min_hi, max_lo,max_hi]  values: v, v-min, max-v            (src/gadget_bound_check.rs:49-87)
+ *   "set_membership"   ip=[k, item_lo,item_hi ...]              values: k bits, value              (src/gadget_set_membership.rs:93-134)
+ *   "mimc"             ip=[rounds] sp=[constants..., image]     values: xl, xr                     (src/gadget_mimc.rs:92-175)
+ *   "poseidon_hash_2"  ip=[sbox(0 cube,1 inverse), partial_rounds] sp=[output]  values: xl, xr, 0,101,0,0       (src/gadget_poseidon.rs:692-790)
+ *   "poseidon_hash_4"  ip=[sbox, partial_rounds] sp=[output]    values: x0..x3, 0,101                (:792-875)
+ *   "poseidon_perm"    ip=[sbox, partial_rounds] sp=[out0..5]   values: x0..x5                       (:624-690)
+ *   "vsmt_4"           ip=[levels, partial_rounds] sp=[root]    values: leaf, index, 3*levels nodes (root level first), 0,101   (src/gadget_vsmt_4.rs:363-440)
+ *   "vsmt_2"           ip=[depth, partial_rounds]  sp=[root]    values: leaf, depth index bits (LSB first), depth nodes (leaf level first), 0,101,0,0   (src/gadget_vsmt_2.rs:262-352)
+ * The statics (0 / 101 / 0...) are committed with blinding 0 (reference gadget_poseidon.rs:554-578).
+ * `poseidon_blob` = bulletproofs-r1cs-gadgets_amd/data/poseidon_params_ristretto.bin (may be NULL for non-Poseidon gadgets).
+ */
+#ifndef BPR1CS_GADGETS_H
+#define BPR1CS_GADGETS_H
+#include "bpr1cs.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+int bpr1cs_gadget_compile(const char* gadget, const uint32_t* iparams, size_t n_iparams, const uint8_t* sparams, size_t n_sparams,
+                          const uint8_t* poseidon_blob, size_t blob_len, bpr1cs_circuit** out, uint32_t* n, uint32_t* q, uint32_t* m,
+                          int* has_witness_program);
+
+/* commit -> gadget -> prove with the C++ `Prover` (host synthesis, device prove), as the reference tests do */
+int bpr1cs_gadget_prove_single(const char* gadget, const uint32_t* iparams, size_t n_iparams, const uint8_t* sparams, size_t n_sparams,
+                               const uint8_t* poseidon_blob, size_t blob_len, uint32_t gens_capacity, const uint8_t* label, size_t label_len,
+                               const uint8_t* values, const uint8_t* v_blindings, size_t m, const uint8_t rng_seed[32],
+                               uint8_t* proof_out, size_t proof_cap, size_t* proof_len, uint8_t* commitments_out);
+
+/* Poseidon_hash_2 / Poseidon_hash_4 (arity 2 / 4) or the raw permutation (arity 6, out = 192 bytes) */
+int bpr1cs_poseidon_hash(int arity, int sbox_inverse, uint32_t partial_rounds, const uint8_t* blob, size_t blob_len, const uint8_t* inputs,
+                         uint8_t* out);
+int bpr1cs_mimc(const uint8_t* xl, const uint8_t* xr, const uint8_t* constants, size_t rounds, uint8_t out[32]);
+
+typedef struct bpr1cs_vsmt4 bpr1cs_vsmt4; /* VanillaSparseMerkleTree_4, src/gadget_vsmt_4.rs:32-165 */
+int bpr1cs_vsmt4_new(uint32_t levels, uint32_t partial_rounds, const uint8_t* blob, size_t blob_len, bpr1cs_vsmt4** out);
+void bpr1cs_vsmt4_free(bpr1cs_vsmt4* t);
+void bpr1cs_vsmt4_root(const bpr1cs_vsmt4* t, uint8_t out[32]);
+void bpr1cs_vsmt4_update(bpr1cs_vsmt4* t, const uint8_t idx[32], const uint8_t val[32]);
+int bpr1cs_vsmt4_get(const bpr1cs_vsmt4* t, const uint8_t idx[32], uint8_t* leaf_out, uint8_t* proof_out /* levels*3*32 */);
+
+typedef struct bpr1cs_vsmt2 bpr1cs_vsmt2; /* VanillaSparseMerkleTree, src/gadget_vsmt_2.rs:27-166 */
+int bpr1cs_vsmt2_new(uint32_t depth, uint32_t partial_rounds, const uint8_t* blob, size_t blob_len, bpr1cs_vsmt2** out);
+void bpr1cs_vsmt2_free(bpr1cs_vsmt2* t);
+void bpr1cs_vsmt2_root(const bpr1cs_vsmt2* t, uint8_t out[32]);
+void bpr1cs_vsmt2_update(bpr1cs_vsmt2* t, const uint8_t idx[32], const uint8_t val[32]);
+int bpr1cs_vsmt2_get(const bpr1cs_vsmt2* t, const uint8_t idx[32], uint8_t* leaf_out, uint8_t* proof_out /* depth*32, root level first */);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

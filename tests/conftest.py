@@ -40,6 +40,29 @@ def sim_lib():
 
 
 @pytest.fixture(scope="session")
+def sim_glib(sim_lib):
+    """front-end (host/frontend.cpp) linked against the simulator backend"""
+    import importlib
+    bp = importlib.import_module("bulletproofs-r1cs-gadgets_amd")
+    bdir = os.path.join(ROOT, "tests", "hostsim", "_build")
+    src = os.path.join(ROOT, "bulletproofs-r1cs-gadgets_amd", "host", "frontend.cpp")
+    out = os.path.join(bdir, "libbpr1cs_gadgets_sim.so")
+    hdir = os.path.dirname(src)
+    deps = [src] + [os.path.join(hdir, f) for f in os.listdir(hdir)] + [os.path.join(bdir, "libbpr1cs_sim.so")]
+    if not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-DBPR1CS_HOST_ONLY", "-shared", "-fPIC", src, "-o", out,
+                               "-L" + bdir, "-lbpr1cs_sim", "-Wl,-rpath," + bdir])
+    return bp.load_gadgets_library(out)
+
+
+@pytest.fixture(scope="session")
+def hip_glib(hip_lib):
+    import importlib
+    bp = importlib.import_module("bulletproofs-r1cs-gadgets_amd")
+    return bp.load_gadgets_library()
+
+
+@pytest.fixture(scope="session")
 def hip_lib():
     import importlib
     bp = importlib.import_module("bulletproofs-r1cs-gadgets_amd")

@@ -1,0 +1,144 @@
+"""Case table shared by the CPU (simulator) and GPU front-end tests."""
+from pyref import scenarios as S, gadgets as g
+from pyref.ed import sc_to_bytes, L
+import common
+
+bp = common.bp
+SET = [2, 3, 5, 6, 8, 20, 25]
+
+
+def _u64(x):
+    return [x & 0xffffffff, x >> 32]
+
+
+def case(name, j=0):
+    """-> (gadget name, iparams, sparams, oracle scenario, gens capacity, values for the library)"""
+    if name == "bound_check":
+        val, lo, hi, bits = 37 + j, 10, 100, 7
+        return "bound_check", [bits] + _u64(lo) + _u64(hi), [], S.bound_check(val, lo, hi, bits), 16
+    if name == "bound_check_64":
+        hi = (2**64 - 1) // 100000
+        lo = (2**64 - 1) // 100001
+        return "bound_check", [64] + _u64(lo) + _u64(hi), [], S.bound_check(lo + 777 + j, lo, hi, 64), 128
+    if name == "set_membership":
+        ip = [len(SET)]
+        for x in SET:
+            ip += _u64(x)
+        return "set_membership", ip, [], S.set_membership(SET[j % len(SET)], SET), 32
+    if name == "factors":
+        return "factors", [], [323], S.factors(), 4
+    if name.startswith("poseidon_hash_2"):
+        sbox = g.CUBE if "cube" in name else g.INVERSE
+        pr = 1 if name.endswith("pr1") else 140
+        params = S.poseidon_params(pr)
+        sc = S.poseidon_hash_2(S.synth_scalar(b"xl", j), S.synth_scalar(b"xr", j), sbox, params)
+        n = (48 + pr) * (2 if sbox == g.CUBE else 3)
+        cap = 1 << (n - 1).bit_length()
+        return "poseidon_hash_2", [0 if sbox == g.CUBE else 1, pr], [sc.output], sc, cap
+    if name.startswith("poseidon_hash_4"):
+        sbox = g.CUBE if "cube" in name else g.INVERSE
+        params = S.poseidon_params(140)
+        sc = S.poseidon_hash_4([S.synth_scalar(b"x4", 4 * j + i) for i in range(4)], sbox, params)
+        return "poseidon_hash_4", [0 if sbox == g.CUBE else 1, 140], [sc.output], sc, 512 if sbox == g.CUBE else 1024
+    if name.startswith("vsmt_4"):
+        levels, pr = (4, 140) if name == "vsmt_4_l4" else (4, 2)
+        tree = _tree4(levels, pr)
+        sc = S.vsmt_4(tree, 1 + (j % 10))
+        n = 583 * levels if pr == 140 else None
+        return "vsmt_4", [levels, pr], [tree.root], sc, 4096 if pr == 140 else 512
+    if name.startswith("vsmt_2"):
+        depth, pr = 3, 2
+        tree = _tree2(depth, pr)
+        sc = S.vsmt_2(tree, 1 + (j % 7))
+        return "vsmt_2", [depth, pr], [tree.root], sc, 512
+    raise KeyError(name)
+
+
+_T = {}
+
+
+def _tree4(levels, pr):
+    k = (4, levels, pr)
+    if k not in _T:
+        t = g.VanillaSparseMerkleTree_4(S.poseidon_params(pr), depth=levels)
+        for i in range(1, 11):
+            t.update(i, i)
+        _T[k] = t
+    return _T[k]
+
+
+def _tree2(depth, pr):
+    k = (2, depth, pr)
+    if k not in _T:
+        t = g.VanillaSparseMerkleTree(S.poseidon_params(pr), depth=depth)
+        for i in range(1, 8):
+            t.update(i, i)
+        _T[k] = t
+    return _T[k]
+
+
+def check_compiled(lib, glib, name, batch, unfold=4, gens_cache={}):
+    """compile the gadget with the C++ front-end, prove a batch with the DEVICE witness program,
+    compare proof bytes with the oracle (which synthesises on its own)."""
+    gname, ip, sp, _, cap = case(name, 0)
+    ob = common.oracle_batch(lambda j: case(name, j)[3], cap, batch)
+    circ = bp.CompiledGadget(gname, ip, sp, lib=lib, glib=glib)
+    assert (circ.n, circ.q, circ.m) == (ob["n"], ob["q"], ob["m"]), (circ.n, circ.q, circ.m, ob["n"], ob["q"], ob["m"])
+    assert circ.has_witness_program
+    key = (id(lib), cap)
+    if key not in gens_cache:
+        gens_cache[key] = bp.Gens(cap, lib=lib)
+    lib.bpr1cs_set_unfold_rounds(unfold)
+    P, C = bp.prove_batch(gens_cache[key], circ, ob["label"], ob["values"], ob["blindings"], ob["seeds"], batch, wires=None)
+    for j in range(batch):
+        assert P[j] == ob["proofs"][j], "proof %d differs (%s)" % (j, name)
+    return ob, P, C
+
+
+def check_prove_single(glib, name):
+    gname, ip, sp, sc, cap = case(name, 0)
+    ob = common.oracle_batch(lambda j: case(name, 0)[3], cap, 1)
+    m = ob["m"]
+    vals = [ob["values"][32 * i:32 * i + 32] for i in range(m)]
+    bls = [ob["blindings"][32 * i:32 * i + 32] for i in range(m)]
+    proof, comms = bp.prove_single(gname, ip, sp, cap, ob["label"], vals, bls, ob["seeds"][:32], glib=glib)
+    assert proof == ob["proofs"][0]
+    assert comms[:len(ob["comms"][0])] == ob["comms"][0]
+
+
+def check_native_hashes(glib):
+    for pr in (140, 2):
+        params = S.poseidon_params(pr)
+        for inv in (False, True):
+            sbox = g.INVERSE if inv else g.CUBE
+            x = [S.synth_scalar(b"h", i) for i in range(6)]
+            assert bp.poseidon_hash(2, inv, pr, x[:2], glib=glib) == sc_to_bytes(g.Poseidon_hash_2(x[0], x[1], params, sbox))
+            assert bp.poseidon_hash(4, inv, pr, x[:4], glib=glib) == sc_to_bytes(g.Poseidon_hash_4(x[:4], params, sbox))
+            exp = b"".join(sc_to_bytes(v) for v in g.Poseidon_permutation(x, params, sbox))
+            assert bp.poseidon_hash(6, inv, pr, x, glib=glib) == exp
+    # edge inputs: 0, 1, l-1
+    params = S.poseidon_params(140)
+    for a, b in ((0, 0), (1, L - 1), (L - 1, L - 1)):
+        assert bp.poseidon_hash(2, True, 140, [a, b], glib=glib) == sc_to_bytes(g.Poseidon_hash_2(a, b, params, g.INVERSE))
+
+
+def check_trees(glib, levels4, depth2, partial_rounds):
+    t4 = bp.SparseMerkleTree(4, levels4, partial_rounds, glib=glib)
+    o4 = g.VanillaSparseMerkleTree_4(S.poseidon_params(partial_rounds), depth=levels4)
+    assert t4.root() == sc_to_bytes(o4.root)
+    for i in range(1, 8):
+        t4.update(i, i + 100)
+        o4.update(i, i + 100)
+    assert t4.root() == sc_to_bytes(o4.root)
+    leaf, nodes = t4.get(5)
+    oleaf, oproof = o4.get(5, True)
+    assert leaf == sc_to_bytes(oleaf) and nodes == [sc_to_bytes(x) for node in oproof for x in node]
+    t2 = bp.SparseMerkleTree(2, depth2, partial_rounds, glib=glib)
+    o2 = g.VanillaSparseMerkleTree(S.poseidon_params(partial_rounds), depth=depth2)
+    for i in range(1, 6):
+        t2.update(i, i + 7)
+        o2.update(i, i + 7)
+    assert t2.root() == sc_to_bytes(o2.root)
+    leaf, nodes = t2.get(3)
+    oleaf, oproof = o2.get(3, True)
+    assert leaf == sc_to_bytes(oleaf) and nodes == [sc_to_bytes(x) for x in oproof]

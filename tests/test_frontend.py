@@ -1,0 +1,33 @@
+"""C++ gadget front-end (host/) vs the oracle's restatement of the reference gadgets.
+Backend = the CPU simulator of the device code, so this runs without a GPU; the same
+checks run against the HIP backend in test_gpu_frontend.py."""
+import pytest
+
+from pyref import scenarios as S, gadgets as g
+from pyref.ed import sc_to_bytes
+import common
+import frontend_cases as fc
+
+bp = common.bp
+
+
+def test_native_poseidon_matches_oracle(sim_glib):
+    fc.check_native_hashes(sim_glib)
+
+
+def test_trees_match_oracle(sim_glib):
+    fc.check_trees(sim_glib, levels4=4, depth2=3, partial_rounds=2)
+
+
+@pytest.mark.parametrize("case", ["bound_check", "set_membership", "factors"])
+def test_compiled_gadget_batch(sim_lib, sim_glib, case):
+    fc.check_compiled(sim_lib, sim_glib, case, batch=2)
+
+
+def test_compiled_poseidon_cube_small(sim_lib, sim_glib):
+    fc.check_compiled(sim_lib, sim_glib, "poseidon_hash_2_cube_pr1", batch=2)
+
+
+def test_prover_single(sim_lib, sim_glib):
+    fc.check_prove_single(sim_glib, "bound_check")
+    fc.check_prove_single(sim_glib, "set_membership")

@@ -1,0 +1,36 @@
+"""GPU: the C++ gadget front-end compiled circuits + DEVICE witness programs (Poseidon
+S-box / MDS synthesis, sparse-Merkle selection logic) vs the oracle, bit-exact."""
+import pytest
+
+import frontend_cases as fc
+
+pytestmark = pytest.mark.gpu
+
+
+def test_native_hashes_and_trees(hip_glib):
+    fc.check_native_hashes(hip_glib)
+    fc.check_trees(hip_glib, levels4=4, depth2=3, partial_rounds=2)
+
+
+@pytest.mark.parametrize("case", ["bound_check", "bound_check_64", "set_membership", "factors"])
+def test_compiled_small(hip_lib, hip_glib, case):
+    fc.check_compiled(hip_lib, hip_glib, case, batch=3, unfold=2)
+
+
+@pytest.mark.parametrize("case", ["poseidon_hash_2_cube", "poseidon_hash_2_inverse", "poseidon_hash_4_inverse"])
+def test_compiled_poseidon(hip_lib, hip_glib, case):
+    fc.check_compiled(hip_lib, hip_glib, case, batch=2, unfold=4)
+
+
+def test_compiled_vsmt_2(hip_lib, hip_glib):
+    fc.check_compiled(hip_lib, hip_glib, "vsmt_2_d3", batch=2, unfold=4)
+
+
+def test_compiled_vsmt_4_four_levels(hip_lib, hip_glib):
+    # 4 levels of the north-star circuit with the full 148-round Poseidon: n=2332, N=4096
+    fc.check_compiled(hip_lib, hip_glib, "vsmt_4_l4", batch=2, unfold=4)
+
+
+def test_prover_single_host_synthesis(hip_glib):
+    fc.check_prove_single(hip_glib, "bound_check")
+    fc.check_prove_single(hip_glib, "poseidon_hash_2_cube")
