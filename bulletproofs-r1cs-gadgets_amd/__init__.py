@@ -71,6 +71,7 @@ def load_library(path=None):
     lib.bpr1cs_msm_fixed.argtypes = [vp, ctypes.POINTER(u32), sz, cp, sz, cp]
     lib.bpr1cs_set_unfold_rounds.argtypes = [ctypes.c_int]
     lib.bpr1cs_last_timings.argtypes = [ctypes.POINTER(ctypes.c_float), ctypes.c_int]
+    lib.bpr1cs_last_msm_stats.argtypes = [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]
     if path is None:
         _lib = lib
     return lib
@@ -188,6 +189,14 @@ def prove_batch(gens, circuit, label, values, v_blindings, rng_seeds, batch, wir
     P = [proofs.raw[i * plen:(i + 1) * plen] for i in range(batch)]
     C = [[comms.raw[(i * m + j) * 32:(i * m + j + 1) * 32] for j in range(m)] for i in range(batch)]
     return P, C
+
+
+def last_msm_stats(lib=None):
+    """(summed K_msm_fixed launch time in ms, launches, scalar*point terms) of the last prove_batch."""
+    lib = lib or load_library()
+    ms, n, t = ctypes.c_double(), ctypes.c_uint64(), ctypes.c_uint64()
+    lib.bpr1cs_last_msm_stats(ctypes.byref(ms), ctypes.byref(n), ctypes.byref(t))
+    return ms.value, n.value, t.value
 
 
 def last_timings(lib=None):

@@ -256,12 +256,54 @@ struct MsmPlan {
     uint32_t nchunks, chunk;
 };
 
+// HIP-event timing of every launch of the dominant kernel (K_msm_fixed) on its own stream,
+// for bench.py's roofline object.
+struct MsmStats {
+    double ms = 0;
+    uint64_t launches = 0, terms = 0;  // terms = scalar*point products (summed over the batch)
+#if !defined(BPR1CS_HOSTSIM)
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+    std::vector<hipEvent_t> pool;
+    hipEvent_t get() {
+        if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+        hipEvent_t e;
+        HIPCHK(hipEventCreate(&e));
+        return e;
+    }
+#endif
+    void reset() { ms = 0; launches = 0; terms = 0; }
+    void collect() {
+#if !defined(BPR1CS_HOSTSIM)
+        for (auto& p : ev) {
+            float t = 0;
+            HIPCHK(hipEventSynchronize(p.second));
+            HIPCHK(hipEventElapsedTime(&t, p.first, p.second));
+            ms += t;
+            pool.push_back(p.first);
+            pool.push_back(p.second);
+        }
+        ev.clear();
+#endif
+    }
+};
+static MsmStats g_msm;
+
 static void run_msm(const bpr1cs_gens* g, MsmSeg s0, MsmSeg s1, uint32_t B, DevBuf<ge>& partial, MsmPlan& plan, dev_stream_t st) {
     uint32_t total = s0.count + s1.count;
     plan.nchunks = pick_chunks(total, B, 1u << 17, plan.chunk);
     if (partial.n < (size_t)plan.nchunks * B) partial.alloc((size_t)plan.nchunks * B);
     K_msm_fixed k{g->tab.p, {s0, s1}, partial.p, B, plan.chunk};
+#if !defined(BPR1CS_HOSTSIM)
+    hipEvent_t e0 = g_msm.get(), e1 = g_msm.get();
+    HIPCHK(hipEventRecord(e0, st));
+#endif
     launch((uint64_t)plan.nchunks * B, k, st);
+#if !defined(BPR1CS_HOSTSIM)
+    HIPCHK(hipEventRecord(e1, st));
+    g_msm.ev.push_back({e0, e1});
+#endif
+    g_msm.launches++;
+    g_msm.terms += (uint64_t)total * B;
 }
 
 extern "C" int bpr1cs_prove_batch(const bpr1cs_gens* g, const bpr1cs_circuit* c, const uint8_t* label, size_t label_len,
@@ -277,6 +319,7 @@ extern "C" int bpr1cs_prove_batch(const bpr1cs_gens* g, const bpr1cs_circuit* c,
     const uint32_t baseG = 2, baseH = 2 + g->cap;
     dev_stream_t st = g->stream;
     PhaseTimer pt;
+    g_msm.reset();
     pt.mark(st);
 
     // ---- inputs
@@ -400,6 +443,14 @@ extern "C" int bpr1cs_prove_batch(const bpr1cs_gens* g, const bpr1cs_circuit* c,
     dev_d2h(proofs_out, d_out.p, (size_t)B * plen, st);
     if (commitments_out && m) dev_d2h(commitments_out, Vcomp.p, (size_t)B * m * 32, st);
     pt.finish(g_timings);
+    g_msm.collect();
+    return BPR1CS_OK;
+}
+
+extern "C" int bpr1cs_last_msm_stats(double* ms_total, uint64_t* launches, uint64_t* terms) {
+    if (ms_total) *ms_total = g_msm.ms;
+    if (launches) *launches = g_msm.launches;
+    if (terms) *terms = g_msm.terms;
     return BPR1CS_OK;
 }
 

@@ -120,6 +120,11 @@ void bpr1cs_set_unfold_rounds(int r);
  * [0]=total [1]=commitV+transcript/rng [2]=witness [3]=commit MSMs [4]=polys [5]=IPA; returns count */
 int bpr1cs_last_timings(float* out, int cap);
 
+/* HIP-event statistics of the dominant kernel (batched fixed-base MSM) over the last prove_batch:
+ * summed launch durations (ms, events recorded on the kernel's own stream), number of launches and
+ * number of scalar*point terms processed (summed over the batch). */
+int bpr1cs_last_msm_stats(double* ms_total, uint64_t* launches, uint64_t* terms);
+
 #ifdef __cplusplus
 }
 #endif
