@@ -225,7 +225,7 @@ def load_gadgets_library(path=None):
         raise ImportError("bpr1cs: %s is missing — run __graft_entry__.build()" % p)
     if path is None:
         load_library()  # resolve libbpr1cs_hip.so first
-    g = ctypes.CDLL(p, mode=ctypes.RTLD_GLOBAL)
+    g = ctypes.CDLL(p)
     vp, u32, sz, cp, ip = ctypes.c_void_p, ctypes.c_uint32, ctypes.c_size_t, ctypes.c_char_p, ctypes.POINTER(ctypes.c_uint32)
     g.bpr1cs_gadget_compile.argtypes = [cp, ip, sz, cp, sz, cp, sz, ctypes.POINTER(vp), ip, ip, ip, ctypes.POINTER(ctypes.c_int)]
     g.bpr1cs_gadget_prove_single.argtypes = [cp, ip, sz, cp, sz, cp, sz, u32, cp, sz, cp, cp, sz, cp, cp, sz, ctypes.POINTER(sz), cp]
