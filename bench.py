@@ -183,7 +183,7 @@ def main():
                          "alg_bytes_per_launch": (msm_alg_bytes / msm_launches) if msm_launches else None,
                          "note": "path is integer-VALU bound, not HBM bound (DESIGN.md); frac is quoted because BASELINE asks for it"},
             "hbm_frac_whole_path": value / world * alg_bytes_per_proof / (HBM_PEAK_GBS * 1e9),
-            "phase_ms_per_step": {k: v / steps for k, v in zip(["total", "commitV+transcript+rng", "witness", "commit_msm", "poly", "ipa"], phases)},
+            "phase_ms_per_step": {k: v / steps for k, v in zip(["total", "inputs+commitV", "rng||witness", "commit_msm", "poly", "ipa"], phases)},
             "setup_s": {"witness_trees": t_witness, "circuit_compile": t_compile, "generator_tables": t_gens},
         }
         if world == 1 and args.cpu_proofs > 0:

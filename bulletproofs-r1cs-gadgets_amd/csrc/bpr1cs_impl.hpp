@@ -8,6 +8,9 @@
 #include "../../include/bpr1cs.h"
 #include "dev.hpp"
 #include "kernels.hpp"
+#if !defined(BPR1CS_HOSTSIM)
+#include "kernels_hip.hpp"
+#endif
 
 // ------------------------------------------------------------ host-side hashes
 static void host_sponge(uint32_t rate, uint8_t suffix, const uint8_t* in, size_t inlen, uint8_t* out, size_t outlen) {
@@ -39,6 +42,7 @@ struct bpr1cs_gens {
     DevBuf<ge_niels> tab;    // [(2+2cap) * 4096]
     std::vector<uint8_t> comp;  // compressed, host copy
     dev_stream_t stream{};
+    dev_stream_t stream2{};  // RNG draws overlap witness synthesis (both latency bound, independent)
 };
 
 struct bpr1cs_circuit {
@@ -102,6 +106,7 @@ int bpr1cs_gens_create(uint32_t cap, bpr1cs_gens** out) {
     g->cap = cap;
 #if !defined(BPR1CS_HOSTSIM)
     HIPCHK(hipStreamCreate(&g->stream));
+    HIPCHK(hipStreamCreate(&g->stream2));
 #endif
     uint32_t nb = 2 + 2 * cap;
     // uniform bytes: B~ <- SHA3-512(compress(B)); G/H <- SHAKE256("GeneratorsChain"||'G'|'H'||LE32(0))  
@@ -132,6 +137,7 @@ void bpr1cs_gens_destroy(bpr1cs_gens* g) {
     if (!g) return;
 #if !defined(BPR1CS_HOSTSIM)
     hipStreamDestroy(g->stream);
+    hipStreamDestroy(g->stream2);
 #endif
     delete g;
 }
@@ -338,8 +344,20 @@ extern "C" int bpr1cs_prove_batch(const bpr1cs_gens* g, const bpr1cs_circuit* c,
     DevBuf<sc> blind((size_t)8 * B), W((size_t)5 * n * B + 1);
     sc* sL = W.p + (size_t)3 * n * B;
     sc* sR = W.p + (size_t)4 * n * B;
-    launch(B, K_transcript_init{d_label.p, (uint32_t)label_len, Vcomp.p, vbl_raw.p, d_seeds.p, tr.p, blind.p, sL, sR, B, m, n}, st);
     pt.mark(st);
+    K_transcript_init kinit{d_label.p, (uint32_t)label_len, Vcomp.p, vbl_raw.p, d_seeds.p, tr.p, blind.p, sL, sR, B, m, n};
+#if defined(BPR1CS_HOSTSIM)
+    launch(B, kinit, st);
+#else
+    // transcript + TranscriptRng stream on stream2, concurrent with witness synthesis on the main stream
+    hipEvent_t ev_in, ev_rng;
+    HIPCHK(hipEventCreateWithFlags(&ev_in, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&ev_rng, hipEventDisableTiming));
+    HIPCHK(hipEventRecord(ev_in, st));
+    HIPCHK(hipStreamWaitEvent(g->stream2, ev_in, 0));
+    launch(B, kinit, g->stream2);
+    HIPCHK(hipEventRecord(ev_rng, g->stream2));
+#endif
 
     // ---- P7/P8: witness (device program) or host-synthesised wires
     if (wires) {
@@ -348,8 +366,19 @@ extern "C" int bpr1cs_prove_batch(const bpr1cs_gens* g, const bpr1cs_circuit* c,
         launch((uint64_t)3 * n * B, K_load_wires{raw.p, W.p}, st);
         dev_sync(st);
     } else {
-        launch(B, K_witness{c->wops.p, c->lc_off.p, c->lc_var.p, c->lc_coeff.p, v_raw.p, v_m.p, W.p, B, n}, st);
+        K_witness kw{c->wops.p, c->lc_off.p, c->lc_var.p, c->lc_coeff.p, v_raw.p, v_m.p, W.p, B, n};
+#if defined(BPR1CS_HOSTSIM)
+        launch(B, kw, st);
+#else
+        const int T = 16;
+        uint32_t blocks = (uint32_t)(((uint64_t)B * T + 63) / 64);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_witness_team<T>), dim3(blocks), dim3(64), 0, st, kw);
+        HIPCHK(hipGetLastError());
+#endif
     }
+#if !defined(BPR1CS_HOSTSIM)
+    HIPCHK(hipStreamWaitEvent(st, ev_rng, 0));
+#endif
     pt.mark(st);
 
     // ---- P2: A_I1, A_O1, S1
@@ -444,6 +473,10 @@ extern "C" int bpr1cs_prove_batch(const bpr1cs_gens* g, const bpr1cs_circuit* c,
     if (commitments_out && m) dev_d2h(commitments_out, Vcomp.p, (size_t)B * m * 32, st);
     pt.finish(g_timings);
     g_msm.collect();
+#if !defined(BPR1CS_HOSTSIM)
+    HIPCHK(hipEventDestroy(ev_in));
+    HIPCHK(hipEventDestroy(ev_rng));
+#endif
     return BPR1CS_OK;
 }
 

@@ -38,14 +38,57 @@ typedef hipStream_t dev_stream_t;
             abort();                                                                               \
         }                                                                                          \
     } while (0)
-inline void* dev_alloc(size_t n) {
-    void* p = nullptr;
-    HIPCHK(hipMalloc(&p, n ? n : 1));
-    return p;
+// Caching allocator: prove_batch needs ~15 GB of scratch per 1024-proof batch; hipMalloc/hipFree
+// of that size cost seconds per call.  Freed blocks are kept and reused (best fit within 25 %).
+// Safe because every API call runs on ONE stream and ends synchronised: a block is only ever
+// re-used by work that is stream-ordered after the work that freed it.
+#include <map>
+#include <mutex>
+struct DevPool {
+    std::multimap<size_t, void*> free_blocks;
+    std::map<void*, size_t> live;
+    std::mutex mu;
+    void* get(size_t n) {
+        if (n == 0) n = 1;
+        n = (n + 255) & ~(size_t)255;
+        std::lock_guard<std::mutex> lk(mu);
+        auto it = free_blocks.lower_bound(n);
+        if (it != free_blocks.end() && it->first <= n + n / 4 + 4096) {
+            void* p = it->second;
+            live[p] = it->first;
+            free_blocks.erase(it);
+            return p;
+        }
+        void* p = nullptr;
+        hipError_t e = hipMalloc(&p, n);
+        if (e != hipSuccess) {  // out of memory: drop the cache and retry once
+            for (auto& kv : free_blocks) (void)hipFree(kv.second);
+            free_blocks.clear();
+            HIPCHK(hipMalloc(&p, n));
+        }
+        live[p] = n;
+        return p;
+    }
+    void put(void* p) {
+        if (!p) return;
+        std::lock_guard<std::mutex> lk(mu);
+        auto it = live.find(p);
+        if (it == live.end()) return;
+        free_blocks.insert({it->second, p});
+        live.erase(it);
+    }
+    void release_all() {
+        std::lock_guard<std::mutex> lk(mu);
+        for (auto& kv : free_blocks) (void)hipFree(kv.second);
+        free_blocks.clear();
+    }
+};
+inline DevPool& dev_pool() {
+    static DevPool* p = new DevPool();  // intentionally leaked: must outlive static destructors
+    return *p;
 }
-inline void dev_free(void* p) {
-    if (p) HIPCHK(hipFree(p));
-}
+inline void* dev_alloc(size_t n) { return dev_pool().get(n); }
+inline void dev_free(void* p) { dev_pool().put(p); }
 inline void dev_h2d(void* d, const void* h, size_t n, dev_stream_t s) {
     HIPCHK(hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, s));
     HIPCHK(hipStreamSynchronize(s));

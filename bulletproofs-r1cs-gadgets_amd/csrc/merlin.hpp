@@ -196,7 +196,32 @@ HD inline void merlin_rng_fill(strobe& s, uint8_t* out, uint32_t n) {
     strobe_meta_ad(s, len, 4, 0);
     strobe_prf(s, out, n);
 }
-HD inline sc merlin_rng_scalar(strobe& s) {  // Scalar::random -> Montgomery form
+HD inline sc sc_mont_from_wide_lanes(const uint64_t* l) {  // 8 little-endian u64 lanes = 64 bytes
+    sc lo, hi;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        lo.v[2 * k] = (uint32_t)l[k]; lo.v[2 * k + 1] = (uint32_t)(l[k] >> 32);
+        hi.v[2 * k] = (uint32_t)l[4 + k]; hi.v[2 * k + 1] = (uint32_t)(l[4 + k] >> 32);
+    }
+    return sc_add(sc_mul(lo, sc_const(SC_R2)), sc_mul(hi, sc_const(SC_R3)));
+}
+// Scalar::random(&mut rng) -> Montgomery form.
+// Steady state of a run of 64-byte draws: the previous prf left pos = 64, pos_begin = 0, so
+// meta_ad(LE32(64)) + prf framing always lands on bytes 64..73 and 167: the whole STROBE
+// bookkeeping of one draw collapses to three lane XORs + one Keccak-f (exactly
+// one permutation per draw).  Any other position takes the generic byte-wise path.
+HD inline sc merlin_rng_scalar(strobe& s) {
+    if (s.pos == 64 && s.pos_begin == 0) {
+        s.st[8] ^= 0x0741000000401200ull;   // [0x00,0x12] op header, LE32(64), [65,0x07] op header
+        s.st[9] ^= 0x0000000000000447ull;   // run_f: pos_begin = 71, 0x04
+        s.st[20] ^= 0x8000000000000000ull;  // run_f: byte R+1
+        keccak_f1600(s.st);
+        uint64_t out[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) { out[k] = s.st[k]; s.st[k] = 0; }
+        s.cur_flags = SFLAG_I | SFLAG_A | SFLAG_C;
+        return sc_mont_from_wide_lanes(out);
+    }
     uint8_t buf[64];
     merlin_rng_fill(s, buf, 64);
     return sc_mont_from_wide(buf);

@@ -117,7 +117,7 @@ int bpr1cs_msm_fixed(const bpr1cs_gens* g, const uint32_t* bases, size_t terms, 
 void bpr1cs_set_unfold_rounds(int r);
 
 /* last prove_batch phase timings in milliseconds (HIP events), for bench.py:
- * [0]=total [1]=commitV+transcript/rng [2]=witness [3]=commit MSMs [4]=polys [5]=IPA; returns count */
+ * [0]=total [1]=inputs+V commitments [2]=RNG stream || witness synthesis [3]=commit MSMs [4]=polys [5]=IPA; returns count */
 int bpr1cs_last_timings(float* out, int cap);
 
 /* HIP-event statistics of the dominant kernel (batched fixed-base MSM) over the last prove_batch:

@@ -1,0 +1,71 @@
+"""Device arithmetic headers (field, scalars, ristretto, Keccak/STROBE/Merlin) compiled for the
+host and compared with the oracle's big-integer arithmetic."""
+import ctypes
+import random
+
+from pyref.ed import P, L, BASEPOINT, from_uniform_bytes
+from pyref.merlin import Transcript
+from pyref.ed import sc_to_bytes
+
+
+def _call(f, *ins, n=32):
+    o = ctypes.create_string_buffer(n)
+    r = f(*ins, o)
+    return o.raw, r
+
+
+def _vals():
+    rnd = random.Random(7)
+    edge = [0, 1, 2, 19, 38, P - 1, P, P + 1, 2**255 - 1, 2**255, 2**256 - 1, 2**256 - 38, 2**256 - 39, L - 1, L, L + 1, 2**252]
+    return [x.to_bytes(32, "little") for x in edge] + [bytes(rnd.getrandbits(8) for _ in range(32)) for _ in range(120)]
+
+
+def test_field_and_scalar_arithmetic(prim_lib):
+    vals = _vals()
+    for a in vals:
+        ia = int.from_bytes(a, "little")
+        for b in vals[:20]:
+            ib = int.from_bytes(b, "little")
+            for f, op, mod in ((prim_lib.hs_fe_mul, ia * ib, P), (prim_lib.hs_fe_add, ia + ib, P), (prim_lib.hs_fe_sub, ia - ib, P),
+                               (prim_lib.hs_sc_mul, ia * ib, L), (prim_lib.hs_sc_add, ia + ib, L), (prim_lib.hs_sc_sub, ia - ib, L)):
+                assert int.from_bytes(_call(f, a, b)[0], "little") == op % mod
+        assert int.from_bytes(_call(prim_lib.hs_fe_inv, a)[0], "little") == pow(ia % P, P - 2, P)
+        inv = pow(ia % L, L - 2, L)
+        assert int.from_bytes(_call(prim_lib.hs_sc_inv, a)[0], "little") == inv          # safegcd divsteps
+        assert int.from_bytes(_call(prim_lib.hs_sc_inv_fermat, a)[0], "little") == inv   # Fermat ladder
+
+
+def test_group_and_encoding(prim_lib):
+    rnd = random.Random(9)
+    for _ in range(12):
+        w = bytes(rnd.getrandbits(8) for _ in range(64))
+        assert int.from_bytes(_call(prim_lib.hs_sc_wide, w)[0], "little") == int.from_bytes(w, "little") % L
+        assert _call(prim_lib.hs_uniform, w)[0] == from_uniform_bytes(w).compress()
+        k = bytes(rnd.getrandbits(8) for _ in range(32))
+        p = BASEPOINT * int.from_bytes(k, "little")
+        assert _call(prim_lib.hs_basemul, k)[0] == p.compress()
+        out, ok = _call(prim_lib.hs_decompress_recompress, p.compress())
+        assert ok and out == p.compress()
+        q = from_uniform_bytes(bytes(rnd.getrandbits(8) for _ in range(64)))
+        o4, ok = _call(prim_lib.hs_addsub, p.compress(), q.compress(), n=128)
+        assert ok and o4 == (p + q).compress() + (p - q).compress() + (p + q).compress() + (p - q).compress()
+    assert _call(prim_lib.hs_decompress_recompress, b"\x01" + bytes(31))[1] == 0
+
+
+def test_merlin_transcript_and_rng(prim_lib):
+    assert _call(prim_lib.hs_merlin_kat)[0].hex() == "d5a21972d0d5fe320c0d263fac7fffb8145aa640af6e9bca177c03c7efcf0615"
+    rnd = random.Random(11)
+    msgs = bytes(rnd.getrandbits(8) for _ in range(5 * 32))
+    seed = bytes(rnd.getrandbits(8) for _ in range(32))
+    dr, ch = ctypes.create_string_buffer(32 * 300), ctypes.create_string_buffer(32)
+    prim_lib.hs_merlin_script(b"VSMT", 4, msgs, 5, seed, 300, dr, ch)
+    t = Transcript(b"VSMT")
+    for i in range(5):
+        t.append_message(b"V", msgs[32 * i:32 * i + 32])
+    t.append_u64(b"m", 5)
+    b = t.build_rng()
+    for i in range(5):
+        b = b.rekey_with_witness_bytes(b"v_blinding", msgs[32 * i:32 * i + 32])
+    rng = b.finalize(seed)
+    assert dr.raw == b"".join(sc_to_bytes(rng.random_scalar()) for _ in range(300))
+    assert ch.raw == sc_to_bytes(t.challenge_scalar(b"y"))
