@@ -104,7 +104,8 @@ class Gens:
         """scalars: bytes batch*terms*32 (proof-major) -> batch compressed points."""
         out = ctypes.create_string_buffer(32 * batch)
         _chk(self.lib.bpr1cs_msm_fixed(self.h, _u32arr(bases), len(bases), scalars, batch, out))
-        return [out.raw[32 * i:32 * i + 32] for i in range(batch)]
+        raw = out.raw
+        return [raw[32 * i:32 * i + 32] for i in range(batch)]
 
     def close(self):
         if self.h:
@@ -186,8 +187,9 @@ def prove_batch(gens, circuit, label, values, v_blindings, rng_seeds, batch, wir
     comms = ctypes.create_string_buffer(max(1, batch * m * 32))
     _chk(lib.bpr1cs_prove_batch(gens.h, circuit.h, label, len(label), values or b"\0", v_blindings or b"\0", rng_seeds,
                                 wires, batch, proofs, comms))
-    P = [proofs.raw[i * plen:(i + 1) * plen] for i in range(batch)]
-    C = [[comms.raw[(i * m + j) * 32:(i * m + j + 1) * 32] for j in range(m)] for i in range(batch)]
+    praw, craw = proofs.raw, comms.raw  # .raw copies the whole buffer: take it once
+    P = [praw[i * plen:(i + 1) * plen] for i in range(batch)]
+    C = [[craw[(i * m + j) * 32:(i * m + j + 1) * 32] for j in range(m)] for i in range(batch)]
     return P, C
 
 

@@ -345,9 +345,8 @@ extern "C" int bpr1cs_prove_batch(const bpr1cs_gens* g, const bpr1cs_circuit* c,
     sc* sL = W.p + (size_t)3 * n * B;
     sc* sR = W.p + (size_t)4 * n * B;
     pt.mark(st);
-    K_transcript_init kinit{d_label.p, (uint32_t)label_len, Vcomp.p, vbl_raw.p, d_seeds.p, tr.p, blind.p, sL, sR, B, m, n};
 #if defined(BPR1CS_HOSTSIM)
-    launch(B, kinit, st);
+    launch(B, K_transcript_init{d_label.p, (uint32_t)label_len, Vcomp.p, vbl_raw.p, d_seeds.p, tr.p, blind.p, sL, sR, nullptr, B, m, n}, st);
 #else
     // transcript + TranscriptRng stream on stream2, concurrent with witness synthesis on the main stream
     hipEvent_t ev_in, ev_rng;
@@ -355,7 +354,15 @@ extern "C" int bpr1cs_prove_batch(const bpr1cs_gens* g, const bpr1cs_circuit* c,
     HIPCHK(hipEventCreateWithFlags(&ev_rng, hipEventDisableTiming));
     HIPCHK(hipEventRecord(ev_in, st));
     HIPCHK(hipStreamWaitEvent(g->stream2, ev_in, 0));
-    launch(B, kinit, g->stream2);
+    const uint32_t draws = 2 * n + 7;
+    DevBuf<strobe> rng(B);
+    DevBuf<uint64_t> rng_raw((size_t)draws * B * 8);
+    DevBuf<int> rng_err(1);
+    dev_zero(rng_err.p, sizeof(int), g->stream2);
+    launch(B, K_transcript_init{d_label.p, (uint32_t)label_len, Vcomp.p, vbl_raw.p, d_seeds.p, tr.p, blind.p, sL, sR, rng.p, B, m, n}, g->stream2);
+    hipLaunchKernelGGL(k_rng_stream, dim3((B + 1) / 2), dim3(64), 0, g->stream2, rng.p, rng_raw.p, rng_err.p, B, draws);
+    HIPCHK(hipGetLastError());
+    launch((uint64_t)draws * B, K_rng_reduce{rng_raw.p, blind.p, sL, sR, B, n}, g->stream2);
     HIPCHK(hipEventRecord(ev_rng, g->stream2));
 #endif
 
@@ -476,6 +483,9 @@ extern "C" int bpr1cs_prove_batch(const bpr1cs_gens* g, const bpr1cs_circuit* c,
 #if !defined(BPR1CS_HOSTSIM)
     HIPCHK(hipEventDestroy(ev_in));
     HIPCHK(hipEventDestroy(ev_rng));
+    int rerr = 0;
+    dev_d2h(&rerr, rng_err.p, sizeof(int), st);
+    if (rerr) return BPR1CS_ERR_INVALID_ARGUMENT;  // RNG stream kernel found a non-steady STROBE state
 #endif
     return BPR1CS_OK;
 }

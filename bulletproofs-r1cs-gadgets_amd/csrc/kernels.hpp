@@ -150,6 +150,7 @@ struct K_transcript_init {
     sc* blind;              // [8][B]: i_bl o_bl s_bl t1 t3 t4 t5 t6
     sc* sL;                 // [n][B]
     sc* sR;                 // [n][B]
+    strobe* rng_out;        // non-null: stop after the first draw and hand the RNG state over
     uint32_t B, m, n;
     HD void operator()(uint32_t b) const {
         strobe s;
@@ -165,10 +166,31 @@ struct K_transcript_init {
             merlin_rng_rekey(r, "v_blinding", 10, w, 32);
         }
         merlin_rng_finalize(r, seeds + 32 * (size_t)b);
-        for (int k = 0; k < 3; k++) blind[(size_t)k * B + b] = merlin_rng_scalar(r);
+        blind[(size_t)0 * B + b] = merlin_rng_scalar(r);  // i_bl (leaves the RNG in its steady state)
+        if (rng_out) {  // the remaining 2n+7 draws are made by k_rng_stream (lane-parallel Keccak)
+            rng_out[b] = r;
+            return;
+        }
+        for (int k = 1; k < 3; k++) blind[(size_t)k * B + b] = merlin_rng_scalar(r);
         for (uint32_t i = 0; i < n; i++) sL[(size_t)i * B + b] = merlin_rng_scalar(r);
         for (uint32_t i = 0; i < n; i++) sR[(size_t)i * B + b] = merlin_rng_scalar(r);
         for (int k = 3; k < 8; k++) blind[(size_t)k * B + b] = merlin_rng_scalar(r);
+    }
+};
+// raw 64-byte RNG outputs (draw d >= 1 of the stream, proof b) -> Montgomery scalars in their slots
+struct K_rng_reduce {  // gid = d*B + b, d < 2n+7 : o_bl, s_bl, s_L[n], s_R[n], t1 t3 t4 t5 t6 blindings
+    const uint64_t* raw;  // [2n+7][B][8]
+    sc* blind;
+    sc* sL;
+    sc* sR;
+    uint32_t B, n;
+    HD void operator()(uint32_t g) const {
+        uint32_t d = g / B, b = g % B;
+        sc x = sc_mont_from_wide_lanes(raw + (size_t)g * 8);
+        if (d < 2) blind[(size_t)(1 + d) * B + b] = x;
+        else if (d < 2 + n) sL[(size_t)(d - 2) * B + b] = x;
+        else if (d < 2 + 2 * n) sR[(size_t)(d - 2 - n) * B + b] = x;
+        else blind[(size_t)(3 + d - 2 - 2 * n) * B + b] = x;
     }
 };
 
