@@ -98,6 +98,7 @@ def main():
     ap.add_argument("--leaves", type=int, default=32, help="distinct synthetic leaves cycled over the batch")
     ap.add_argument("--cpu-proofs", type=int, default=2, help="proofs timed on the CPU oracle (0 = skip)")
     ap.add_argument("--unfold", type=int, default=-1)
+    ap.add_argument("--window", type=int, default=0, help="fixed-base table window bits (0 = library default)")
     args = ap.parse_args()
 
     import torch
@@ -118,6 +119,8 @@ def main():
     bp.load_gadgets_library()
     if args.unfold >= 0:
         lib.bpr1cs_set_unfold_rounds(args.unfold)
+    if args.window > 0:
+        lib.bpr1cs_set_window_bits(args.window)
 
     levels, B = args.depth, args.batch
     t0 = time.time()

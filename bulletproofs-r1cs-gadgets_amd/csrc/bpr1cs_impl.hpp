@@ -34,10 +34,12 @@ static void host_sponge(uint32_t rate, uint8_t suffix, const uint8_t* in, size_t
 }
 
 static int g_unfold_rounds = 4;
+static int g_window_bits = 8;
 static float g_timings[8];
 
 struct bpr1cs_gens {
     uint32_t cap = 0;
+    TabCfg tc{};             // fixed-base table geometry (window bits chosen at creation)
     DevBuf<ge> pts;          // [2 + 2cap] : B, B~, G.., H..
     DevBuf<ge_niels> tab;    // [(2+2cap) * 4096]
     std::vector<uint8_t> comp;  // compressed, host copy
@@ -93,6 +95,7 @@ int bpr1cs_set_device(int ordinal) {
     return BPR1CS_OK;
 }
 void bpr1cs_set_unfold_rounds(int r) { g_unfold_rounds = r < 0 ? 0 : r; }
+void bpr1cs_set_window_bits(int w) { g_window_bits = w < 4 ? 4 : (w > 12 ? 12 : w); }
 int bpr1cs_last_timings(float* out, int cap) {
     int k = cap < 6 ? cap : 6;
     for (int i = 0; i < k; i++) out[i] = g_timings[i];
@@ -104,6 +107,7 @@ int bpr1cs_gens_create(uint32_t cap, bpr1cs_gens** out) {
     if (!have_device()) return BPR1CS_ERR_NO_DEVICE;
     bpr1cs_gens* g = new bpr1cs_gens();
     g->cap = cap;
+    g->tc = tab_cfg((uint32_t)g_window_bits);
 #if !defined(BPR1CS_HOSTSIM)
     HIPCHK(hipStreamCreate(&g->stream));
     HIPCHK(hipStreamCreate(&g->stream2));
@@ -127,8 +131,8 @@ int bpr1cs_gens_create(uint32_t cap, bpr1cs_gens** out) {
     g->comp.resize((size_t)nb * 32);
     dev_d2h(g->comp.data(), d_comp.p, (size_t)nb * 32, g->stream);
     memcpy(g->comp.data(), bcomp, 32);
-    g->tab.alloc((size_t)nb * TAB_PER_BASE);
-    launch((uint64_t)nb * TAB_WINDOWS, K_build_table{g->pts.p, g->tab.p}, g->stream);
+    g->tab.alloc((size_t)nb * g->tc.per_base);
+    launch((uint64_t)nb * g->tc.windows, K_build_table{g->pts.p, g->tab.p, g->tc}, g->stream);
     dev_sync(g->stream);
     *out = g;
     return BPR1CS_OK;
@@ -298,7 +302,7 @@ static void run_msm(const bpr1cs_gens* g, MsmSeg s0, MsmSeg s1, uint32_t B, DevB
     uint32_t total = s0.count + s1.count;
     plan.nchunks = pick_chunks(total, B, 1u << 17, plan.chunk);
     if (partial.n < (size_t)plan.nchunks * B) partial.alloc((size_t)plan.nchunks * B);
-    K_msm_fixed k{g->tab.p, {s0, s1}, partial.p, B, plan.chunk};
+    K_msm_fixed k{g->tab.p, g->tc, {s0, s1}, partial.p, B, plan.chunk};
 #if !defined(BPR1CS_HOSTSIM)
     hipEvent_t e0 = g_msm.get(), e1 = g_msm.get();
     HIPCHK(hipEventRecord(e0, st));
@@ -339,7 +343,7 @@ extern "C" int bpr1cs_prove_batch(const bpr1cs_gens* g, const bpr1cs_circuit* c,
 
     // ---- P1: V commitments, transcript, RNG stream
     DevBuf<uint8_t> Vcomp((size_t)B * m * 32 + 1);
-    launch((uint64_t)m * B, K_commit_v{g->tab.p, v_raw.p, vbl_raw.p, Vcomp.p, B, m}, st);
+    launch((uint64_t)m * B, K_commit_v{g->tab.p, g->tc, v_raw.p, vbl_raw.p, Vcomp.p, B, m}, st);
     DevBuf<strobe> tr(B);
     DevBuf<sc> blind((size_t)8 * B), W((size_t)5 * n * B + 1);
     sc* sL = W.p + (size_t)3 * n * B;
@@ -397,11 +401,11 @@ extern "C" int bpr1cs_prove_batch(const bpr1cs_gens* g, const bpr1cs_circuit* c,
         MsmSeg none{nullptr, 0, 1, 1, 0, 0, 0};
         auto seg = [&](const sc* p, uint32_t base0) { return MsmSeg{p, n, n ? n : 1, n ? n : 1, 0, base0, 1}; };
         run_msm(g, seg(aL, baseG), seg(aR, baseH), B, partial, plan, st);
-        launch(B, K_msm_finish{g->tab.p, partial.p, blind.p + 0 * (size_t)B, nullptr, AOS.p + 0 * (size_t)B * 32, B, plan.nchunks, 1}, st);
+        launch(B, K_msm_finish{g->tab.p, g->tc, partial.p, blind.p + 0 * (size_t)B, nullptr, AOS.p + 0 * (size_t)B * 32, B, plan.nchunks, 1}, st);
         run_msm(g, seg(aO, baseG), none, B, partial, plan, st);
-        launch(B, K_msm_finish{g->tab.p, partial.p, blind.p + 1 * (size_t)B, nullptr, AOS.p + 1 * (size_t)B * 32, B, plan.nchunks, 1}, st);
+        launch(B, K_msm_finish{g->tab.p, g->tc, partial.p, blind.p + 1 * (size_t)B, nullptr, AOS.p + 1 * (size_t)B * 32, B, plan.nchunks, 1}, st);
         run_msm(g, seg(sL, baseG), seg(sR, baseH), B, partial, plan, st);
-        launch(B, K_msm_finish{g->tab.p, partial.p, blind.p + 2 * (size_t)B, nullptr, AOS.p + 2 * (size_t)B * 32, B, plan.nchunks, 1}, st);
+        launch(B, K_msm_finish{g->tab.p, g->tc, partial.p, blind.p + 2 * (size_t)B, nullptr, AOS.p + 2 * (size_t)B * 32, B, plan.nchunks, 1}, st);
     }
     pt.mark(st);
 
@@ -419,7 +423,7 @@ extern "C" int bpr1cs_prove_batch(const bpr1cs_gens* g, const bpr1cs_circuit* c,
     launch((uint64_t)TC * B, K_tcoef_partial{W.p, wvec.p, plo.p, phi.p, tpart.p, B, H, n, tchunk, TC}, st);
     launch((uint64_t)6 * B, K_sum_partials{tpart.p, tco.p, B, TC}, st);
     DevBuf<uint8_t> Tc((size_t)5 * B * 32);
-    launch((uint64_t)5 * B, K_commit_T{g->tab.p, tco.p, blind.p, Tc.p, B}, st);
+    launch((uint64_t)5 * B, K_commit_T{g->tab.p, g->tc, tco.p, blind.p, Tc.p, B}, st);
     DevBuf<sc> txs((size_t)3 * B);
     launch(B, K_transcript_T{tr.p, Tc.p, tco.p, blind.p, wvec.p + (size_t)3 * n * B, vbl_m.p, chal.p, txs.p, B, m, (uint64_t)N}, st);
     DevBuf<sc> a((size_t)N * B), bb((size_t)N * B), cG((size_t)N * B), cH((size_t)N * B);
@@ -432,6 +436,8 @@ extern "C" int bpr1cs_prove_batch(const bpr1cs_gens* g, const bpr1cs_circuit* c,
     uint32_t r = (uint32_t)g_unfold_rounds < lgN ? (uint32_t)g_unfold_rounds : lgN;
     DevBuf<sc> sG, sH, cpart;
     DevBuf<ge> GH, vtmp, vpart;
+    DevBuf<ge_cached> vtab;
+    DevBuf<sc> linv;
     uint32_t M = N >> r;  // size of the materialised folded generator vectors
     if (r > 0) { sG.alloc((size_t)N * B); sH.alloc((size_t)N * B); }
     const uint32_t VC = 16;
@@ -451,26 +457,29 @@ extern "C" int bpr1cs_prove_batch(const bpr1cs_gens* g, const bpr1cs_circuit* c,
             MsmSeg gL{sG.p, half, mk, Nk, mk, baseG, 0}, hL{sH.p, half, mk, Nk, 0, baseH, 0};
             MsmSeg gR{sG.p, half, mk, Nk, 0, baseG, 0}, hR{sH.p, half, mk, Nk, mk, baseH, 0};
             run_msm(g, gL, hL, B, partial, plan, st);
-            launch(B, K_msm_finish{g->tab.p, partial.p, cross.p, wch, Lout, B, plan.nchunks, 0}, st);
+            launch(B, K_msm_finish{g->tab.p, g->tc, partial.p, cross.p, wch, Lout, B, plan.nchunks, 0}, st);
             run_msm(g, gR, hR, B, partial, plan, st);
-            launch(B, K_msm_finish{g->tab.p, partial.p, cross.p + B, wch, Rout, B, plan.nchunks, 0}, st);
+            launch(B, K_msm_finish{g->tab.p, g->tc, partial.p, cross.p + B, wch, Rout, B, plan.nchunks, 0}, st);
         } else {
             if (k == r) {
                 GH.alloc((size_t)2 * M * B);
-                launch((uint64_t)2 * M * B, K_ipa_fold_from_tables{g->tab.p, cG.p, cH.p, GH.p, B, M, N, baseG, baseH}, st);
+                launch((uint64_t)2 * M * B, K_ipa_fold_from_tables{g->tab.p, g->tc, cG.p, cH.p, GH.p, B, M, N, baseG, baseH}, st);
                 vtmp.alloc((size_t)4 * (M / 2 ? M / 2 : 1) * B);
+                vtab.alloc((size_t)8 * 4 * (M / 2 ? M / 2 : 1) * B);
                 vpart.alloc((size_t)2 * VC * B);
+                linv.alloc((size_t)2 * B);
+                launch((uint64_t)2 * B, K_set_one{linv.p}, st);
             }
-            launch((uint64_t)4 * mk * B, K_ipa_vb_mul{a.p, bb.p, GH.p, vtmp.p, B, mk, M}, st);
+            launch((uint64_t)4 * mk * B, K_ipa_vb_mul{a.p, bb.p, GH.p, linv.p, vtmp.p, vtab.p, B, mk, M}, st);
             launch((uint64_t)2 * VC * B, K_ipa_vb_reduce{vtmp.p, vpart.p, B, mk, VC}, st);
-            launch(B, K_msm_finish{g->tab.p, vpart.p, cross.p, wch, Lout, B, VC, 0}, st);
-            launch(B, K_msm_finish{g->tab.p, vpart.p + (size_t)VC * B, cross.p + B, wch, Rout, B, VC, 0}, st);
+            launch(B, K_msm_finish{g->tab.p, g->tc, vpart.p, cross.p, wch, Lout, B, VC, 0}, st);
+            launch(B, K_msm_finish{g->tab.p, g->tc, vpart.p + (size_t)VC * B, cross.p + B, wch, Rout, B, VC, 0}, st);
         }
         sc* ukk = uk.p + (size_t)k * 2 * B;
         launch(B, K_transcript_LR{tr.p, Lout, ukk, B}, st);
         launch((uint64_t)mk * B, K_ipa_fold_ab{a.p, bb.p, ukk, B, mk}, st);
         if (k < r) launch((uint64_t)N * B, K_ipa_update_c{cG.p, cH.p, ukk, B, Nk}, st);
-        else if (mk > 0 && k + 1 < lgN) launch((uint64_t)2 * mk * B, K_ipa_vb_fold{GH.p, ukk, B, mk, M}, st);
+        else if (mk > 0 && k + 1 < lgN) launch((uint64_t)2 * mk * B, K_ipa_vb_fold{GH.p, ukk, linv.p, B, mk, M}, st);
     }
     size_t plen = bpr1cs_proof_len(c);
     DevBuf<uint8_t> d_out((size_t)B * plen);
@@ -538,12 +547,12 @@ extern "C" int bpr1cs_msm_fixed(const bpr1cs_gens* g, const uint32_t* bases, siz
         MsmSeg s0 = mk(i), s1{nullptr, 0, 1, 1, 0, 0, 0};
         if (i + 1 < runs.size()) s1 = mk(i + 1);
         uint32_t ch, nc = pick_chunks(s0.count + s1.count, B, 1u << 17, ch);
-        K_msm_fixed k{g->tab.p, {s0, s1}, all.p + off * B, B, ch};
+        K_msm_fixed k{g->tab.p, g->tc, {s0, s1}, all.p + off * B, B, ch};
         launch((uint64_t)nc * B, k, st);
         off += nc;
     }
     DevBuf<uint8_t> d_out((size_t)B * 32);
-    launch(B, K_msm_finish{g->tab.p, all.p, nullptr, nullptr, d_out.p, B, (uint32_t)total_chunks, 0}, st);
+    launch(B, K_msm_finish{g->tab.p, g->tc, all.p, nullptr, nullptr, d_out.p, B, (uint32_t)total_chunks, 0}, st);
     dev_d2h(out, d_out.p, (size_t)B * 32, st);
     return BPR1CS_OK;
 }

@@ -122,7 +122,43 @@ HD inline fe fe_mul(const fe& a, const fe& b) {
     return fe_reduce512(t);
 }
 
-HD inline fe fe_sq(const fe& a) { return fe_mul(a, a); }
+// dedicated squaring: 28 cross products (doubled) + 8 squares instead of 64 products
+HD inline fe fe_sq(const fe& a) {
+    uint32_t t[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) t[i] = 0;
+    // cross products a_i*a_j, i<j
+#pragma unroll
+    for (int i = 0; i < 7; i++) {
+        uint64_t c = 0;
+#pragma unroll
+        for (int j = i + 1; j < 8; j++) {
+            c += (uint64_t)a.v[i] * a.v[j] + t[i + j];
+            t[i + j] = (uint32_t)c;
+            c >>= 32;
+        }
+        t[i + 8] = (uint32_t)c;
+    }
+    // double, then add the squares
+    uint32_t top = 0;
+#pragma unroll
+    for (int i = 1; i < 16; i++) {
+        uint32_t nt = t[i] >> 31;
+        t[i] = (t[i] << 1) | top;
+        top = nt;
+    }
+    uint64_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        c += (uint64_t)a.v[i] * a.v[i] + t[2 * i];
+        t[2 * i] = (uint32_t)c;
+        c >>= 32;
+        c += t[2 * i + 1];
+        t[2 * i + 1] = (uint32_t)c;
+        c >>= 32;
+    }
+    return fe_reduce512(t);
+}
 
 HD inline fe fe_mul_small(const fe& a, uint32_t k) {  // k < 2^26
     fe r;

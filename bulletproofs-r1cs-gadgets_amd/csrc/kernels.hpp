@@ -6,7 +6,8 @@
 // Fixed-base tables: for each base P (B, B~, G_i, H_i) and each of the 32 byte
 // windows k, the 128 affine-Niels multiples j*2^(8k)*P, j=1..128 (96 B each):
 //     tab[(base*32 + k)*128 + (j-1)]
-// Signed radix-256 digits turn s*P into <= 32 mixed additions, no doublings.
+// Signed radix-2^W digits turn s*P into <= ceil(254/W) mixed additions, no doublings
+// (W = 8: 32 additions, 25.8 GB of tables at capacity 32768; W = 10: 26 additions, 84 GB).
 //
 // Each functor is one kernel; `gid` enumerates (index, proof) pairs with the
 // proof index fastest.
@@ -16,9 +17,18 @@
 #include "ge.hpp"
 #include "merlin.hpp"
 
-#define TAB_WINDOWS 32
-#define TAB_ENTRIES 128
-#define TAB_PER_BASE (TAB_WINDOWS * TAB_ENTRIES)
+// table geometry: W-bit signed windows -> windows = ceil(254/W), entries = 2^(W-1) per window
+struct TabCfg {
+    uint32_t W, windows, entries, per_base;
+};
+HD inline TabCfg tab_cfg(uint32_t W) {
+    TabCfg t;
+    t.W = W;
+    t.windows = (253 + W) / W;
+    t.entries = 1u << (W - 1);
+    t.per_base = t.windows * t.entries;
+    return t;
+}
 
 // variable encoding shared with the host front-end (kind<<28 | index)
 #define VK_COMMITTED 0u
@@ -34,17 +44,20 @@
 #define WK_NOTBIT 3u    // 1 - that bit
 
 // ------------------------------------------------------------ fixed-base core
-// acc += s * Base, s canonical (< l).  Signed byte digits.
-HD inline ge table_mul_acc(ge acc, const ge_niels* tbase, const sc& s) {
+// acc += s * Base, s canonical (< l).  Signed W-bit digits.
+HD inline ge table_mul_acc(ge acc, const ge_niels* tbase, const sc& s, const TabCfg& tc) {
     int carry = 0;
-    for (int k = 0; k < TAB_WINDOWS; k++) {
-        int d = (int)((s.v[k >> 2] >> (8 * (k & 3))) & 0xffu) + carry;
-        carry = d > 127;
-        d -= carry << 8;
+    const int half = 1 << (tc.W - 1);
+    for (uint32_t k = 0; k < tc.windows; k++) {
+        uint32_t bit = k * tc.W, wi = bit >> 5, sh = bit & 31;
+        uint64_t two = (uint64_t)s.v[wi] | ((wi + 1 < 8) ? ((uint64_t)s.v[wi + 1] << 32) : 0);
+        int d = (int)((two >> sh) & ((1u << tc.W) - 1u)) + carry;
+        carry = d >= half;
+        d -= carry << tc.W;
         if (d != 0) {
             int neg = d < 0;
             int mag = neg ? -d : d;
-            acc = ge_madd(acc, tbase[k * TAB_ENTRIES + mag - 1], neg);
+            acc = ge_madd(acc, tbase[(size_t)k * tc.entries + mag - 1], neg);
         }
     }
     return acc;
@@ -65,6 +78,32 @@ HD inline ge ge_scalarmul(const ge& P, const sc& s) {
     return acc;
 }
 
+// s*P by non-adjacent form, MSB first (253 doublings, ~84 additions).  NAF digit i of k is
+// bit_{i+1}(3k) - bit_{i+1}(k).  Used where the scalar is shared by a whole wavefront (the IPA
+// generator folds), so the digit branches are wave-uniform.
+HD inline ge ge_scalarmul_naf(const ge& P, const sc& k) {
+    uint32_t x3[9];
+    uint64_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        c += (uint64_t)k.v[i] * 3u;
+        x3[i] = (uint32_t)c;
+        c >>= 32;
+    }
+    x3[8] = (uint32_t)c;
+    ge_cached pc = ge_to_cached(P);
+    ge acc = ge_identity();
+    int started = 0;
+    for (int i = 253; i >= 0; i--) {
+        if (started) acc = ge_dbl(acc);
+        int j = i + 1;
+        int d = (int)((x3[j >> 5] >> (j & 31)) & 1u) - (int)((j < 256) ? ((k.v[j >> 5] >> (j & 31)) & 1u) : 0u);
+        if (d > 0) { acc = ge_add(acc, pc); started = 1; }
+        else if (d < 0) { acc = ge_sub(acc, pc); started = 1; }
+    }
+    return acc;
+}
+
 // ------------------------------------------------------------------- setup
 struct K_gen_points {  // uniform[cnt][64] -> pts[cnt]
     const uint8_t* uniform;
@@ -77,19 +116,20 @@ struct K_gen_points {  // uniform[cnt][64] -> pts[cnt]
     }
 };
 
-struct K_build_table {  // gid = base*32 + k
+struct K_build_table {  // gid = base*windows + k
     const ge* pts;
     ge_niels* tab;
+    TabCfg tc;
     HD void operator()(uint32_t g) const {
-        uint32_t base = g / TAB_WINDOWS, k = g % TAB_WINDOWS;
+        uint32_t base = g / tc.windows, k = g % tc.windows;
         ge P = pts[base];
-        for (uint32_t t = 0; t < 8 * k; t++) P = ge_dbl(P);
+        for (uint32_t t = 0; t < tc.W * k; t++) P = ge_dbl(P);
         ge_cached c = ge_to_cached(P);
         ge acc = P;
-        ge_niels* out = tab + (size_t)g * TAB_ENTRIES;
+        ge_niels* out = tab + (size_t)g * tc.entries;
         // affine normalisation with Montgomery's trick, 16 entries per field inversion
         const int CH = 16;
-        for (int j0 = 0; j0 < TAB_ENTRIES; j0 += CH) {
+        for (uint32_t j0 = 0; j0 < tc.entries; j0 += CH) {
             ge q[CH];
             fe pre[CH];
             for (int t = 0; t < CH; t++) {
@@ -126,14 +166,15 @@ struct K_load_inputs {  // canonical v, vbl [m][B] -> Montgomery copies
 
 struct K_commit_v {  // gid = j*B + b : V = v*B + vbl*B~   (Prover::commit, P1)
     const ge_niels* tab;
+    TabCfg tc;
     const sc* v_raw;
     const sc* vbl_raw;
     uint8_t* out;  // [B][m][32]
     uint32_t B, m;
     HD void operator()(uint32_t g) const {
         uint32_t j = g / B, b = g % B;
-        ge acc = table_mul_acc(ge_identity(), tab, v_raw[g]);
-        acc = table_mul_acc(acc, tab + TAB_PER_BASE, vbl_raw[g]);
+        ge acc = table_mul_acc(ge_identity(), tab, v_raw[g], tc);
+        acc = table_mul_acc(acc, tab + tc.per_base, vbl_raw[g], tc);
         ge_compress(acc, out + ((size_t)b * m + j) * 32);
     }
 };
@@ -315,6 +356,7 @@ struct MsmSeg {
 };
 struct K_msm_fixed {  // gid = c*B + b -> partial[c*B + b]
     const ge_niels* tab;
+    TabCfg tc;
     MsmSeg seg[2];
     ge* partial;
     uint32_t B, chunk;  // ordinals per chunk over the concatenated segments
@@ -329,7 +371,7 @@ struct K_msm_fixed {  // gid = c*B + b -> partial[c*B + b]
             uint32_t i = (oo / s.run) * s.period + s.off + (oo % s.run);
             sc x = s.scal[(size_t)i * B + b];
             if (s.mont) x = sc_from_mont(x);
-            acc = table_mul_acc(acc, tab + (size_t)(s.base0 + i) * TAB_PER_BASE, x);
+            acc = table_mul_acc(acc, tab + (size_t)(s.base0 + i) * tc.per_base, x, tc);
         }
         partial[g] = acc;
     }
@@ -337,6 +379,7 @@ struct K_msm_fixed {  // gid = c*B + b -> partial[c*B + b]
 // sum of partials + extra*Base(extra_base) -> compressed (and optional extended copy)
 struct K_msm_finish {  // gid = b
     const ge_niels* tab;
+    TabCfg tc;
     const ge* partial;    // [nchunks][B]
     const sc* extra;      // [B] Montgomery, may be null
     const sc* extra2;     // optional second factor (extra*extra2), Montgomery
@@ -348,7 +391,7 @@ struct K_msm_finish {  // gid = b
         if (extra) {
             sc e = extra[b];
             e = extra2 ? sc_from_mont(sc_mul(e, extra2[b])) : sc_from_mont(e);
-            acc = table_mul_acc(acc, tab + (size_t)extra_base * TAB_PER_BASE, e);
+            acc = table_mul_acc(acc, tab + (size_t)extra_base * tc.per_base, e, tc);
         }
         ge_compress(acc, out + 32 * (size_t)b);
     }
@@ -417,6 +460,7 @@ struct K_sum_partials {  // gid = k*B + b : out[k][b] = sum_c part[k][c][b]
 
 struct K_commit_T {  // gid = k*B + b, k<5 : T = t*B + tau*B~  (t1,t3,t4,t5,t6)
     const ge_niels* tab;
+    TabCfg tc;
     const sc* tco;    // [6][B]
     const sc* blind;  // [8][B]
     uint8_t* out;     // [5][B][32]
@@ -424,8 +468,8 @@ struct K_commit_T {  // gid = k*B + b, k<5 : T = t*B + tau*B~  (t1,t3,t4,t5,t6)
     HD void operator()(uint32_t g) const {
         uint32_t k = g / B, b = g % B;
         const uint32_t ti[5] = {0, 2, 3, 4, 5};
-        ge acc = table_mul_acc(ge_identity(), tab, sc_from_mont(tco[(size_t)ti[k] * B + b]));
-        acc = table_mul_acc(acc, tab + TAB_PER_BASE, sc_from_mont(blind[(size_t)(3 + k) * B + b]));
+        ge acc = table_mul_acc(ge_identity(), tab, sc_from_mont(tco[(size_t)ti[k] * B + b]), tc);
+        acc = table_mul_acc(acc, tab + tc.per_base, sc_from_mont(blind[(size_t)(3 + k) * B + b]), tc);
         ge_compress(acc, out + 32 * (size_t)g);
     }
 };
@@ -597,6 +641,7 @@ struct K_ipa_update_c {  // gid = i*B + b, i<N : fold factors of the original ge
 // materialise the folded generators of round r straight from the tables
 struct K_ipa_fold_from_tables {  // gid = (side*M + j)*B + b
     const ge_niels* tab;
+    TabCfg tc;
     const sc* cG;
     const sc* cH;
     ge* GH;  // [2][M][B]
@@ -607,26 +652,89 @@ struct K_ipa_fold_from_tables {  // gid = (side*M + j)*B + b
         uint32_t base0 = side ? baseH : baseG;
         ge acc = ge_identity();
         for (uint32_t i = j; i < N; i += M)
-            acc = table_mul_acc(acc, tab + (size_t)(base0 + i) * TAB_PER_BASE, sc_from_mont(c[(size_t)i * B + b]));
+            acc = table_mul_acc(acc, tab + (size_t)(base0 + i) * tc.per_base, sc_from_mont(c[(size_t)i * B + b]), tc);
         GH[g] = acc;
     }
 };
-struct K_ipa_vb_mul {  // gid = (w*m + j)*B + b, w<4
+// Variable-base part of the IPA (rounds >= r).  The stored per-proof generators are SCALED:
+//   Ghat = lamG * G_true,  Hhat = lamH * H_true   (lamG = prod u_k, lamH = prod u_k^-1 over the folded rounds)
+// so that a fold needs ONE scalar multiplication per output, Ghat' = Ghat_lo + u^2 * Ghat_hi,
+// instead of upstream's two (u^-1*G_lo + u*G_hi); the scale is divided out of the L/R scalars
+// (linv = lam^-1).  Group elements are exact, so L_k / R_k are bit-identical.
+struct K_ipa_vb_mul {  // gid = (w*m + j)*B + b, w<4 : tmp = s * P by signed radix-16 windows
     const sc* a;
     const sc* bb;
-    const ge* GH;  // [2][M][B] (current size 2m used)
-    ge* tmp;       // [4][m][B]
+    const ge* GH;       // [2][M][B]
+    const sc* linv;     // [2][B] Montgomery: lamG^-1, lamH^-1
+    ge* tmp;            // [4][m][B]
+    ge_cached* vtab;    // [8][4*m*B] per-thread multiples 1P..8P
     uint32_t B, m, M;
     HD void operator()(uint32_t g) const {
         uint32_t b = g % B, wj = g / B, w = wj / m, j = wj % m;
         // branch-free operand selection (w: 0 = a_lo*G_hi, 1 = b_hi*H_lo, 2 = a_hi*G_lo, 3 = b_lo*H_hi)
-        const sc* sv = (w & 1u) ? bb : a;
-        const ge* pv = (w & 1u) ? GH + (size_t)M * B : GH;
+        uint32_t side = w & 1u;
+        const sc* sv = side ? bb : a;
+        const ge* pv = side ? GH + (size_t)M * B : GH;
         uint32_t s_hi = (w == 1u) | (w == 2u), p_hi = (w == 0u) | (w == 3u);
-        sc s = sv[(size_t)(j + s_hi * m) * B + b];
+        sc s = sc_from_mont(sc_mul(sv[(size_t)(j + s_hi * m) * B + b], linv[(size_t)side * B + b]));
         ge P = pv[(size_t)(j + p_hi * m) * B + b];
-        tmp[g] = ge_scalarmul(P, sc_from_mont(s));
+        size_t stride = (size_t)4 * m * B;
+        ge_cached c1 = ge_to_cached(P);
+        ge_cached* T = vtab + g;
+        T[0] = c1;
+        ge q = P;
+        for (int e = 1; e < 8; e++) {
+            q = ge_add(q, c1);
+            T[(size_t)e * stride] = ge_to_cached(q);
+        }
+        ge acc = ge_identity();
+        int started = 0, carry = 0;
+        // signed digits, least significant first, recoded into a local nibble stream
+        uint32_t dig[8];  // 64 x 4-bit two's-complement digits packed
+#pragma unroll
+        for (int i = 0; i < 8; i++) dig[i] = 0;
+        for (int i = 0; i < 64; i++) {
+            int d = (int)((s.v[i >> 3] >> (4 * (i & 7))) & 15u) + carry;
+            carry = d >= 8;
+            d -= carry << 4;  // d in [-8, 7]: fits a 4-bit two's-complement digit
+            dig[i >> 3] |= ((uint32_t)d & 15u) << (4 * (i & 7));
+        }
+        for (int i = 63; i >= 0; i--) {
+            if (started) { acc = ge_dbl(acc); acc = ge_dbl(acc); acc = ge_dbl(acc); acc = ge_dbl(acc); }
+            int d = (int)((dig[i >> 3] >> (4 * (i & 7))) & 15u);
+            if (d & 8) d -= 16;
+            if (d != 0) {
+                int mag = d < 0 ? -d : d;
+                ge_cached e = T[(size_t)(mag - 1) * stride];
+                acc = d < 0 ? ge_sub(acc, e) : ge_add(acc, e);
+                started = 1;
+            }
+        }
+        tmp[g] = acc;
     }
+};
+struct K_ipa_vb_fold {  // gid = (b*2 + side)*m + j : Ghat'[j] = Ghat[j] + u^2 Ghat[j+m] ; Hhat' = Hhat[j] + u^-2 Hhat[j+m]
+    ge* GH;
+    const sc* uk;   // [2][B]: u, u^-1 (Montgomery)
+    sc* linv;       // [2][B]
+    uint32_t B, m, M;
+    HD void operator()(uint32_t g) const {
+        uint32_t j = g % m, bs = g / m, side = bs & 1u, b = bs >> 1;
+        ge* P = GH + (size_t)side * M * B;
+        sc f = uk[(size_t)(side ? 1 : 0) * B + b];   // G: u ; H: u^-1
+        sc w = sc_from_mont(sc_mul(f, f));
+        ge lo = P[(size_t)j * B + b], hi = P[(size_t)(j + m) * B + b];
+        ge r = ge_add_ge(lo, ge_scalarmul_naf(hi, w));
+        P[(size_t)j * B + b] = r;
+        if (j == 0) {  // lam' = lam * f  ->  linv' = linv * f^-1
+            sc finv = uk[(size_t)(side ? 0 : 1) * B + b];
+            linv[(size_t)side * B + b] = sc_mul(linv[(size_t)side * B + b], finv);
+        }
+    }
+};
+struct K_set_one {  // linv = 1
+    sc* p;
+    HD void operator()(uint32_t g) const { p[g] = sc_one_mont(); }
 };
 struct K_ipa_vb_reduce {  // gid = (out*VC + c)*B + b ; out: 0=L (w 0,1) 1=R (w 2,3)
     const ge* tmp;
@@ -641,26 +749,6 @@ struct K_ipa_vb_reduce {  // gid = (out*VC + c)*B + b ; out: 0=L (w 0,1) 1=R (w 
         partial[g] = acc;
     }
 };
-struct K_ipa_vb_fold {  // gid = (side*m + j)*B + b
-    ge* GH;
-    const sc* uk;
-    uint32_t B, m, M;
-    HD void operator()(uint32_t g) const {
-        uint32_t b = g % B, sj = g / B, side = sj / m, j = sj % m;
-        ge* P = GH + (size_t)side * M * B;
-        sc u = sc_from_mont(uk[b]), ui = sc_from_mont(uk[(size_t)B + b]);
-        ge lo = P[(size_t)j * B + b], hi = P[(size_t)(j + m) * B + b];
-        // G' = u^-1*G_lo + u*G_hi ; H' = u*H_lo + u^-1*H_hi
-        sc slo, shi;
-        for (int t = 0; t < 8; t++) {
-            slo.v[t] = side ? u.v[t] : ui.v[t];
-            shi.v[t] = side ? ui.v[t] : u.v[t];
-        }
-        ge r = ge_add_ge(ge_scalarmul(lo, slo), ge_scalarmul(hi, shi));
-        P[(size_t)j * B + b] = r;
-    }
-};
-
 // ---------------------------------------------------------------- proof out
 struct K_assemble {  // gid = b
     const uint8_t* AOS;  // [3][B][32]

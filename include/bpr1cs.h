@@ -116,6 +116,11 @@ int bpr1cs_msm_fixed(const bpr1cs_gens* g, const uint32_t* bases, size_t terms, 
  * folded generators are materialised (default 4; clamped to lg N) */
 void bpr1cs_set_unfold_rounds(int r);
 
+/* tuning knob, read by bpr1cs_gens_create: signed window width W (4..12) of the fixed-base tables.
+ * A term costs ceil(254/W) mixed additions; table bytes = (2+2*cap) * ceil(254/W) * 2^(W-1) * 96
+ * (W=8: 25.8 GB, W=10: 84 GB at capacity 32768).  Default 8. */
+void bpr1cs_set_window_bits(int w);
+
 /* last prove_batch phase timings in milliseconds (HIP events), for bench.py:
  * [0]=total [1]=inputs+V commitments [2]=RNG stream || witness synthesis [3]=commit MSMs [4]=polys [5]=IPA; returns count */
 int bpr1cs_last_timings(float* out, int cap);

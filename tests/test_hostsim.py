@@ -14,3 +14,13 @@ def test_pipeline_varbase_rounds(sim_lib):
 
 def test_pipeline_factors(sim_lib):
     common.check_against_oracle(sim_lib, lambda j: S.factors(), 4, 2, 4)
+
+
+def test_pipeline_other_window_widths(sim_lib):
+    """fixed-base tables with 5- and 10-bit signed windows give the same proofs"""
+    try:
+        for w in (5, 10):
+            sim_lib.bpr1cs_set_window_bits(w)
+            common.check_against_oracle(sim_lib, lambda j: S.bound_check(39 + j, 10, 100, 7), 16, 2, 2)
+    finally:
+        sim_lib.bpr1cs_set_window_bits(8)

@@ -30,6 +30,7 @@ def test_field_and_scalar_arithmetic(prim_lib):
                                (prim_lib.hs_sc_mul, ia * ib, L), (prim_lib.hs_sc_add, ia + ib, L), (prim_lib.hs_sc_sub, ia - ib, L)):
                 assert int.from_bytes(_call(f, a, b)[0], "little") == op % mod
         assert int.from_bytes(_call(prim_lib.hs_fe_inv, a)[0], "little") == pow(ia % P, P - 2, P)
+        assert int.from_bytes(_call(prim_lib.hs_fe_sq, a)[0], "little") == ia * ia % P
         inv = pow(ia % L, L - 2, L)
         assert int.from_bytes(_call(prim_lib.hs_sc_inv, a)[0], "little") == inv          # safegcd divsteps
         assert int.from_bytes(_call(prim_lib.hs_sc_inv_fermat, a)[0], "little") == inv   # Fermat ladder
