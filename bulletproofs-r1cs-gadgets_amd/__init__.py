@@ -68,6 +68,8 @@ def load_library(path=None):
     lib.bpr1cs_proof_len.argtypes = [vp]
     lib.bpr1cs_proof_len.restype = sz
     lib.bpr1cs_prove_batch.argtypes = [vp, vp, cp, sz, cp, cp, cp, cp, sz, cp, cp]
+    lib.bpr1cs_prove_batch_begin.argtypes = [vp, vp, cp, sz, cp, cp, cp, cp, sz, ctypes.POINTER(vp)]
+    lib.bpr1cs_prove_batch_end.argtypes = [vp, cp, cp]
     lib.bpr1cs_msm_fixed.argtypes = [vp, ctypes.POINTER(u32), sz, cp, sz, cp]
     lib.bpr1cs_set_unfold_rounds.argtypes = [ctypes.c_int]
     lib.bpr1cs_set_window_bits.argtypes = [ctypes.c_int]
@@ -192,6 +194,29 @@ def prove_batch(gens, circuit, label, values, v_blindings, rng_seeds, batch, wir
     P = [praw[i * plen:(i + 1) * plen] for i in range(batch)]
     C = [[craw[(i * m + j) * 32:(i * m + j + 1) * 32] for j in range(m)] for i in range(batch)]
     return P, C
+
+
+class ProveJob:
+    """An in-flight bpr1cs_prove_batch_begin; .finish() -> (proofs, commitments)."""
+
+    def __init__(self, gens, circuit, label, values, v_blindings, rng_seeds, batch, wires=None):
+        self.lib, self.batch, self.m, self.plen = gens.lib, batch, circuit.m, circuit.proof_len
+        h = ctypes.c_void_p()
+        _chk(self.lib.bpr1cs_prove_batch_begin(gens.h, circuit.h, label, len(label), values or b"\0", v_blindings or b"\0", rng_seeds,
+                                               wires, batch, ctypes.byref(h)))
+        self.h = h
+
+    def finish(self, split=True):
+        proofs = ctypes.create_string_buffer(self.batch * self.plen)
+        comms = ctypes.create_string_buffer(max(1, self.batch * self.m * 32))
+        h, self.h = self.h, None
+        _chk(self.lib.bpr1cs_prove_batch_end(h, proofs, comms))
+        praw, craw = proofs.raw, comms.raw
+        if not split:
+            return praw, craw
+        m, plen = self.m, self.plen
+        return ([praw[i * plen:(i + 1) * plen] for i in range(self.batch)],
+                [[craw[(i * m + j) * 32:(i * m + j + 1) * 32] for j in range(m)] for i in range(self.batch)])
 
 
 def last_msm_stats(lib=None):

@@ -43,8 +43,11 @@ struct bpr1cs_gens {
     DevBuf<ge> pts;          // [2 + 2cap] : B, B~, G.., H..
     DevBuf<ge_niels> tab;    // [(2+2cap) * 4096]
     std::vector<uint8_t> comp;  // compressed, host copy
-    dev_stream_t stream{};
-    dev_stream_t stream2{};  // RNG draws overlap witness synthesis (both latency bound, independent)
+    dev_stream_t stream{};   // setup / synchronous helpers
+    // two stream pairs so that two prove jobs can be in flight (cross-batch pipelining);
+    // within a job: [0] main, [1] RNG stream (overlaps witness synthesis)
+    dev_stream_t jstream[2][2]{};
+    uint32_t next_job = 0;
 };
 
 struct bpr1cs_circuit {
@@ -110,7 +113,8 @@ int bpr1cs_gens_create(uint32_t cap, bpr1cs_gens** out) {
     g->tc = tab_cfg((uint32_t)g_window_bits);
 #if !defined(BPR1CS_HOSTSIM)
     HIPCHK(hipStreamCreate(&g->stream));
-    HIPCHK(hipStreamCreate(&g->stream2));
+    for (int a = 0; a < 2; a++)
+        for (int b = 0; b < 2; b++) HIPCHK(hipStreamCreate(&g->jstream[a][b]));
 #endif
     uint32_t nb = 2 + 2 * cap;
     // uniform bytes: B~ <- SHA3-512(compress(B)); G/H <- SHAKE256("GeneratorsChain"||'G'|'H'||LE32(0))  
@@ -141,7 +145,8 @@ void bpr1cs_gens_destroy(bpr1cs_gens* g) {
     if (!g) return;
 #if !defined(BPR1CS_HOSTSIM)
     hipStreamDestroy(g->stream);
-    hipStreamDestroy(g->stream2);
+    for (int a = 0; a < 2; a++)
+        for (int b = 0; b < 2; b++) hipStreamDestroy(g->jstream[a][b]);
 #endif
     delete g;
 }
@@ -296,7 +301,8 @@ struct MsmStats {
 #endif
     }
 };
-static MsmStats g_msm;
+static MsmStats g_msm;             // last finished job (reported by bpr1cs_last_msm_stats)
+static MsmStats* g_cur_msm = &g_msm;  // job being enqueued
 
 static void run_msm(const bpr1cs_gens* g, MsmSeg s0, MsmSeg s1, uint32_t B, DevBuf<ge>& partial, MsmPlan& plan, dev_stream_t st) {
     uint32_t total = s0.count + s1.count;
@@ -304,32 +310,83 @@ static void run_msm(const bpr1cs_gens* g, MsmSeg s0, MsmSeg s1, uint32_t B, DevB
     if (partial.n < (size_t)plan.nchunks * B) partial.alloc((size_t)plan.nchunks * B);
     K_msm_fixed k{g->tab.p, g->tc, {s0, s1}, partial.p, B, plan.chunk};
 #if !defined(BPR1CS_HOSTSIM)
-    hipEvent_t e0 = g_msm.get(), e1 = g_msm.get();
+    hipEvent_t e0 = g_cur_msm->get(), e1 = g_cur_msm->get();
     HIPCHK(hipEventRecord(e0, st));
 #endif
     launch((uint64_t)plan.nchunks * B, k, st);
 #if !defined(BPR1CS_HOSTSIM)
     HIPCHK(hipEventRecord(e1, st));
-    g_msm.ev.push_back({e0, e1});
+    g_cur_msm->ev.push_back({e0, e1});
 #endif
-    g_msm.launches++;
-    g_msm.terms += (uint64_t)total * B;
+    g_cur_msm->launches++;
+    g_cur_msm->terms += (uint64_t)total * B;
 }
 
-extern "C" int bpr1cs_prove_batch(const bpr1cs_gens* g, const bpr1cs_circuit* c, const uint8_t* label, size_t label_len,
-                                  const uint8_t* values, const uint8_t* v_blindings, const uint8_t* rng_seeds,
-                                  const uint8_t* wires, size_t batch, uint8_t* proofs_out, uint8_t* commitments_out) {
-    if (!g || !c || !label || !rng_seeds || !proofs_out || batch == 0) return BPR1CS_ERR_INVALID_ARGUMENT;
+struct bpr1cs_job {
+    const bpr1cs_gens* g = nullptr;
+    dev_stream_t st{}, st2{};
+    std::vector<void*> deferred;
+    PhaseTimer pt;
+    MsmStats msm;
+    uint32_t B = 0, m = 0;
+    size_t plen = 0;
+    uint8_t* h_proofs = nullptr;  // pinned staging
+    uint8_t* h_comms = nullptr;
+    int* h_err = nullptr;
+#if !defined(BPR1CS_HOSTSIM)
+    hipEvent_t ev_in{}, ev_rng{}, ev_done{};
+#endif
+};
+static void* host_stage_alloc(size_t n) {
+#if defined(BPR1CS_HOSTSIM)
+    return malloc(n ? n : 1);
+#else
+    void* p = nullptr;
+    HIPCHK(hipHostMalloc(&p, n ? n : 1, hipHostMallocDefault));
+    return p;
+#endif
+}
+static void host_stage_free(void* p) {
+#if defined(BPR1CS_HOSTSIM)
+    free(p);
+#else
+    if (p) HIPCHK(hipHostFree(p));
+#endif
+}
+static void dev_d2h_async(void* h, const void* d, size_t n, dev_stream_t s) {
+#if defined(BPR1CS_HOSTSIM)
+    memcpy(h, d, n);
+#else
+    HIPCHK(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, s));
+#endif
+    (void)s;
+}
+
+extern "C" int bpr1cs_prove_batch_begin(const bpr1cs_gens* g, const bpr1cs_circuit* c, const uint8_t* label, size_t label_len,
+                                        const uint8_t* values, const uint8_t* v_blindings, const uint8_t* rng_seeds,
+                                        const uint8_t* wires, size_t batch, bpr1cs_job** job_out) {
+    if (!g || !c || !label || !rng_seeds || !job_out || batch == 0) return BPR1CS_ERR_INVALID_ARGUMENT;
     if (c->m && (!values || !v_blindings)) return BPR1CS_ERR_INVALID_ARGUMENT;
     if (!have_device()) return BPR1CS_ERR_NO_DEVICE;
     if (g->cap < c->N) return BPR1CS_ERR_INVALID_GENERATORS_LENGTH;
     if (!wires && !c->has_program) return BPR1CS_ERR_MISSING_ASSIGNMENT;
     if (batch > (1u << 20)) return BPR1CS_ERR_INVALID_ARGUMENT;
+    bpr1cs_job* job = new bpr1cs_job();
+    job->g = g;
+    uint32_t slot = const_cast<bpr1cs_gens*>(g)->next_job++ & 1u;
+    job->st = g->jstream[slot][0];
+    job->st2 = g->jstream[slot][1];
+    struct Scope {  // every buffer released while enqueuing stays alive until the job has drained
+        bpr1cs_job* j;
+        explicit Scope(bpr1cs_job* jj) : j(jj) { dev_deferred_frees() = &j->deferred; g_cur_msm = &j->msm; }
+        ~Scope() { dev_deferred_frees() = nullptr; g_cur_msm = &g_msm; }
+    } scope(job);
     const uint32_t B = (uint32_t)batch, n = c->n, m = c->m, N = c->N, lgN = c->lgN;
     const uint32_t baseG = 2, baseH = 2 + g->cap;
-    dev_stream_t st = g->stream;
-    PhaseTimer pt;
-    g_msm.reset();
+    dev_stream_t st = job->st;
+    PhaseTimer& pt = job->pt;
+    job->msm.reset();
+    job->B = B; job->m = m;
     pt.mark(st);
 
     // ---- inputs
@@ -353,21 +410,22 @@ extern "C" int bpr1cs_prove_batch(const bpr1cs_gens* g, const bpr1cs_circuit* c,
     launch(B, K_transcript_init{d_label.p, (uint32_t)label_len, Vcomp.p, vbl_raw.p, d_seeds.p, tr.p, blind.p, sL, sR, nullptr, B, m, n}, st);
 #else
     // transcript + TranscriptRng stream on stream2, concurrent with witness synthesis on the main stream
-    hipEvent_t ev_in, ev_rng;
+    hipEvent_t& ev_in = job->ev_in;
+    hipEvent_t& ev_rng = job->ev_rng;
     HIPCHK(hipEventCreateWithFlags(&ev_in, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&ev_rng, hipEventDisableTiming));
     HIPCHK(hipEventRecord(ev_in, st));
-    HIPCHK(hipStreamWaitEvent(g->stream2, ev_in, 0));
+    HIPCHK(hipStreamWaitEvent(job->st2, ev_in, 0));
     const uint32_t draws = 2 * n + 7;
     DevBuf<strobe> rng(B);
     DevBuf<uint64_t> rng_raw((size_t)draws * B * 8);
     DevBuf<int> rng_err(1);
-    dev_zero(rng_err.p, sizeof(int), g->stream2);
-    launch(B, K_transcript_init{d_label.p, (uint32_t)label_len, Vcomp.p, vbl_raw.p, d_seeds.p, tr.p, blind.p, sL, sR, rng.p, B, m, n}, g->stream2);
-    hipLaunchKernelGGL(k_rng_stream, dim3((B + 1) / 2), dim3(64), 0, g->stream2, rng.p, rng_raw.p, rng_err.p, B, draws);
+    dev_zero(rng_err.p, sizeof(int), job->st2);
+    launch(B, K_transcript_init{d_label.p, (uint32_t)label_len, Vcomp.p, vbl_raw.p, d_seeds.p, tr.p, blind.p, sL, sR, rng.p, B, m, n}, job->st2);
+    hipLaunchKernelGGL(k_rng_stream, dim3((B + 1) / 2), dim3(64), 0, job->st2, rng.p, rng_raw.p, rng_err.p, B, draws);
     HIPCHK(hipGetLastError());
-    launch((uint64_t)draws * B, K_rng_reduce{rng_raw.p, blind.p, sL, sR, B, n}, g->stream2);
-    HIPCHK(hipEventRecord(ev_rng, g->stream2));
+    launch((uint64_t)draws * B, K_rng_reduce{rng_raw.p, blind.p, sL, sR, B, n}, job->st2);
+    HIPCHK(hipEventRecord(ev_rng, job->st2));
 #endif
 
     // ---- P7/P8: witness (device program) or host-synthesised wires
@@ -482,21 +540,59 @@ extern "C" int bpr1cs_prove_batch(const bpr1cs_gens* g, const bpr1cs_circuit* c,
         else if (mk > 0 && k + 1 < lgN) launch((uint64_t)2 * mk * B, K_ipa_vb_fold{GH.p, ukk, linv.p, B, mk, M}, st);
     }
     size_t plen = bpr1cs_proof_len(c);
+    job->plen = plen;
     DevBuf<uint8_t> d_out((size_t)B * plen);
     launch(B, K_assemble{AOS.p, Tc.p, txs.p, LR.p, a.p, bb.p, d_out.p, B, lgN, (uint32_t)plen}, st);
     pt.mark(st);
-    dev_d2h(proofs_out, d_out.p, (size_t)B * plen, st);
-    if (commitments_out && m) dev_d2h(commitments_out, Vcomp.p, (size_t)B * m * 32, st);
-    pt.finish(g_timings);
-    g_msm.collect();
+    job->h_proofs = (uint8_t*)host_stage_alloc((size_t)B * plen);
+    job->h_comms = (uint8_t*)host_stage_alloc((size_t)B * m * 32);
+    job->h_err = (int*)host_stage_alloc(sizeof(int));
+    *job->h_err = 0;
+    dev_d2h_async(job->h_proofs, d_out.p, (size_t)B * plen, st);
+    if (m) dev_d2h_async(job->h_comms, Vcomp.p, (size_t)B * m * 32, st);
 #if !defined(BPR1CS_HOSTSIM)
-    HIPCHK(hipEventDestroy(ev_in));
-    HIPCHK(hipEventDestroy(ev_rng));
-    int rerr = 0;
-    dev_d2h(&rerr, rng_err.p, sizeof(int), st);
-    if (rerr) return BPR1CS_ERR_INVALID_ARGUMENT;  // RNG stream kernel found a non-steady STROBE state
+    dev_d2h_async(job->h_err, rng_err.p, sizeof(int), st);
+    HIPCHK(hipEventCreateWithFlags(&job->ev_done, hipEventDisableTiming));
+    HIPCHK(hipEventRecord(job->ev_done, st));
 #endif
+    *job_out = job;
     return BPR1CS_OK;
+}
+
+extern "C" int bpr1cs_prove_batch_end(bpr1cs_job* job, uint8_t* proofs_out, uint8_t* commitments_out) {
+    if (!job || !proofs_out) return BPR1CS_ERR_INVALID_ARGUMENT;
+#if !defined(BPR1CS_HOSTSIM)
+    HIPCHK(hipEventSynchronize(job->ev_done));
+    HIPCHK(hipStreamSynchronize(job->st2));
+#endif
+    memcpy(proofs_out, job->h_proofs, (size_t)job->B * job->plen);
+    if (commitments_out && job->m) memcpy(commitments_out, job->h_comms, (size_t)job->B * job->m * 32);
+    int rc = *job->h_err ? BPR1CS_ERR_INVALID_ARGUMENT : BPR1CS_OK;  // RNG stream kernel found a non-steady STROBE state
+    job->pt.finish(g_timings);
+    job->msm.collect();
+    g_msm.ms = job->msm.ms; g_msm.launches = job->msm.launches; g_msm.terms = job->msm.terms;
+#if !defined(BPR1CS_HOSTSIM)
+    for (auto e : job->msm.pool) hipEventDestroy(e);
+    HIPCHK(hipEventDestroy(job->ev_in));
+    HIPCHK(hipEventDestroy(job->ev_rng));
+    HIPCHK(hipEventDestroy(job->ev_done));
+#endif
+    for (void* p : job->deferred) dev_free_now(p);
+    host_stage_free(job->h_proofs);
+    host_stage_free(job->h_comms);
+    host_stage_free(job->h_err);
+    delete job;
+    return rc;
+}
+
+extern "C" int bpr1cs_prove_batch(const bpr1cs_gens* g, const bpr1cs_circuit* c, const uint8_t* label, size_t label_len,
+                                  const uint8_t* values, const uint8_t* v_blindings, const uint8_t* rng_seeds,
+                                  const uint8_t* wires, size_t batch, uint8_t* proofs_out, uint8_t* commitments_out) {
+    if (!proofs_out) return BPR1CS_ERR_INVALID_ARGUMENT;
+    bpr1cs_job* job = nullptr;
+    int rc = bpr1cs_prove_batch_begin(g, c, label, label_len, values, v_blindings, rng_seeds, wires, batch, &job);
+    if (rc) return rc;
+    return bpr1cs_prove_batch_end(job, proofs_out, commitments_out);
 }
 
 extern "C" int bpr1cs_last_msm_stats(double* ms_total, uint64_t* launches, uint64_t* terms) {

@@ -15,10 +15,21 @@
 #include <typeinfo>
 #include "hd.hpp"
 
+#include <vector>
+// While an asynchronous job is being enqueued, buffers "freed" by the host code may still be read
+// by kernels in flight: their release is deferred to the job's end (after its stream is idle).
+inline std::vector<void*>*& dev_deferred_frees() {
+    static thread_local std::vector<void*>* p = nullptr;
+    return p;
+}
 #if defined(BPR1CS_HOSTSIM)
 typedef int dev_stream_t;
 inline void* dev_alloc(size_t n) { return calloc(n ? n : 1, 1); }
-inline void dev_free(void* p) { free(p); }
+inline void dev_free_now(void* p) { free(p); }
+inline void dev_free(void* p) {
+    if (p && dev_deferred_frees()) dev_deferred_frees()->push_back(p);
+    else free(p);
+}
 inline void dev_h2d(void* d, const void* h, size_t n, dev_stream_t) { memcpy(d, h, n); }
 inline void dev_d2h(void* h, const void* d, size_t n, dev_stream_t) { memcpy(h, d, n); }
 inline void dev_zero(void* d, size_t n, dev_stream_t) { memset(d, 0, n); }
@@ -88,7 +99,11 @@ inline DevPool& dev_pool() {
     return *p;
 }
 inline void* dev_alloc(size_t n) { return dev_pool().get(n); }
-inline void dev_free(void* p) { dev_pool().put(p); }
+inline void dev_free_now(void* p) { dev_pool().put(p); }
+inline void dev_free(void* p) {
+    if (p && dev_deferred_frees()) dev_deferred_frees()->push_back(p);
+    else dev_pool().put(p);
+}
 inline void dev_h2d(void* d, const void* h, size_t n, dev_stream_t s) {
     HIPCHK(hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, s));
     HIPCHK(hipStreamSynchronize(s));

@@ -105,6 +105,17 @@ int bpr1cs_prove_batch(const bpr1cs_gens* g, const bpr1cs_circuit* c, const uint
                        const uint8_t* values, const uint8_t* v_blindings, const uint8_t* rng_seeds,
                        const uint8_t* wires, size_t batch, uint8_t* proofs_out, uint8_t* commitments_out);
 
+/* Asynchronous form of bpr1cs_prove_batch: `begin` uploads the inputs and enqueues the whole prove on
+ * one of two per-handle HIP stream pairs and returns without waiting; `end` waits for that job and
+ * copies the results out.  Two jobs may be in flight per gens handle: the latency-bound phase of
+ * batch k+1 (TranscriptRng Keccak chain, witness synthesis) then overlaps the VALU-bound MSM/IPA
+ * phase of batch k.  Input buffers may be released as soon as `begin` returns. */
+typedef struct bpr1cs_job bpr1cs_job;
+int bpr1cs_prove_batch_begin(const bpr1cs_gens* g, const bpr1cs_circuit* c, const uint8_t* label, size_t label_len,
+                             const uint8_t* values, const uint8_t* v_blindings, const uint8_t* rng_seeds,
+                             const uint8_t* wires, size_t batch, bpr1cs_job** job_out);
+int bpr1cs_prove_batch_end(bpr1cs_job* job, uint8_t* proofs_out, uint8_t* commitments_out);
+
 /* Low-level, for parity tests and a Rust shim: out = sum_t scalars[t] * Base(bases[t])
  * for `batch` independent scalar vectors over the SAME fixed bases; base index:
  * 0 = B, 1 = B_blinding, 2+i = G[i], 2+capacity+i = H[i].

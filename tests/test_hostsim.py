@@ -24,3 +24,17 @@ def test_pipeline_other_window_widths(sim_lib):
             common.check_against_oracle(sim_lib, lambda j: S.bound_check(39 + j, 10, 100, 7), 16, 2, 2)
     finally:
         sim_lib.bpr1cs_set_window_bits(8)
+
+
+def test_two_jobs_in_flight(sim_lib):
+    """bpr1cs_prove_batch_begin x2 before _end: results independent of the interleaving"""
+    ob1 = common.oracle_batch(lambda j: S.bound_check(37 + j, 10, 100, 7), 16, 2)
+    ob2 = common.oracle_batch(lambda j: S.bound_check(50 + j, 10, 100, 7), 16, 3)
+    gens = common.bp.Gens(16, lib=sim_lib)
+    sim_lib.bpr1cs_set_unfold_rounds(2)
+    c1, c2 = common.circuit_from_oracle(ob1, sim_lib), common.circuit_from_oracle(ob2, sim_lib)
+    j1 = common.bp.ProveJob(gens, c1, ob1["label"], ob1["values"], ob1["blindings"], ob1["seeds"], 2, wires=ob1["wires"])
+    j2 = common.bp.ProveJob(gens, c2, ob2["label"], ob2["values"], ob2["blindings"], ob2["seeds"], 3, wires=ob2["wires"])
+    P2, _ = j2.finish()
+    P1, _ = j1.finish()
+    assert P1 == ob1["proofs"] and P2 == ob2["proofs"]
