@@ -3,6 +3,7 @@
 // prove (inputs are uploaded once, only proofs/commitments come back).
 #pragma once
 #include <vector>
+#include <map>
 #include <algorithm>
 #include <string>
 #include "../../include/bpr1cs.h"
@@ -35,6 +36,7 @@ static void host_sponge(uint32_t rate, uint8_t suffix, const uint8_t* in, size_t
 
 static int g_unfold_rounds = 4;
 static int g_window_bits = 8;
+static uint32_t g_msm_target_threads = 1u << 19;  // short MSM workgroups (~2k of them) so high-priority latency-bound kernels get slots
 static float g_timings[8];
 
 struct bpr1cs_gens {
@@ -45,8 +47,11 @@ struct bpr1cs_gens {
     std::vector<uint8_t> comp;  // compressed, host copy
     dev_stream_t stream{};   // setup / synchronous helpers
     // two stream pairs so that two prove jobs can be in flight (cross-batch pipelining);
-    // within a job: [0] main, [1] RNG stream (overlaps witness synthesis)
-    dev_stream_t jstream[2][2]{};
+    // within a job: [0] main (VALU-bound MSM / IPA), [1] RNG stream, [2] witness synthesis.  [1],[2] are
+    // HIGH-priority streams: their kernels are latency bound (one wave per proof group, few hundred
+    // waves in total) and must get wave slots as soon as any short MSM workgroup retires, so that they
+    // co-run with the other in-flight job's MSM/IPA kernels instead of queueing behind them.
+    dev_stream_t jstream[2][3]{};
     uint32_t next_job = 0;
 };
 
@@ -113,8 +118,10 @@ int bpr1cs_gens_create(uint32_t cap, bpr1cs_gens** out) {
     g->tc = tab_cfg((uint32_t)g_window_bits);
 #if !defined(BPR1CS_HOSTSIM)
     HIPCHK(hipStreamCreate(&g->stream));
+    int prio_lo = 0, prio_hi = 0;
+    HIPCHK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));  // numerically lower = higher priority
     for (int a = 0; a < 2; a++)
-        for (int b = 0; b < 2; b++) HIPCHK(hipStreamCreate(&g->jstream[a][b]));
+        for (int b = 0; b < 3; b++) HIPCHK(hipStreamCreateWithPriority(&g->jstream[a][b], hipStreamNonBlocking, b == 0 ? prio_lo : prio_hi));
 #endif
     uint32_t nb = 2 + 2 * cap;
     // uniform bytes: B~ <- SHA3-512(compress(B)); G/H <- SHAKE256("GeneratorsChain"||'G'|'H'||LE32(0))  
@@ -146,7 +153,7 @@ void bpr1cs_gens_destroy(bpr1cs_gens* g) {
 #if !defined(BPR1CS_HOSTSIM)
     hipStreamDestroy(g->stream);
     for (int a = 0; a < 2; a++)
-        for (int b = 0; b < 2; b++) hipStreamDestroy(g->jstream[a][b]);
+        for (int b = 0; b < 3; b++) hipStreamDestroy(g->jstream[a][b]);
 #endif
     delete g;
 }
@@ -306,7 +313,7 @@ static MsmStats* g_cur_msm = &g_msm;  // job being enqueued
 
 static void run_msm(const bpr1cs_gens* g, MsmSeg s0, MsmSeg s1, uint32_t B, DevBuf<ge>& partial, MsmPlan& plan, dev_stream_t st) {
     uint32_t total = s0.count + s1.count;
-    plan.nchunks = pick_chunks(total, B, 1u << 17, plan.chunk);
+    plan.nchunks = pick_chunks(total, B, g_msm_target_threads, plan.chunk);
     if (partial.n < (size_t)plan.nchunks * B) partial.alloc((size_t)plan.nchunks * B);
     K_msm_fixed k{g->tab.p, g->tc, {s0, s1}, partial.p, B, plan.chunk};
 #if !defined(BPR1CS_HOSTSIM)
@@ -324,7 +331,7 @@ static void run_msm(const bpr1cs_gens* g, MsmSeg s0, MsmSeg s1, uint32_t B, DevB
 
 struct bpr1cs_job {
     const bpr1cs_gens* g = nullptr;
-    dev_stream_t st{}, st2{};
+    dev_stream_t st{}, st2{}, st3{};
     std::vector<void*> deferred;
     PhaseTimer pt;
     MsmStats msm;
@@ -334,15 +341,31 @@ struct bpr1cs_job {
     uint8_t* h_comms = nullptr;
     int* h_err = nullptr;
 #if !defined(BPR1CS_HOSTSIM)
-    hipEvent_t ev_in{}, ev_rng{}, ev_done{};
+    hipEvent_t ev_in{}, ev_rng{}, ev_wit{}, ev_done{};
 #endif
 };
+// pinned staging buffers are cached: hipHostFree (like hipFree) synchronises the whole device, which
+// would serialise the in-flight jobs
+static std::multimap<size_t, void*>& host_stage_cache() {
+    static std::multimap<size_t, void*>* c = new std::multimap<size_t, void*>();
+    return *c;
+}
+static std::map<void*, size_t>& host_stage_live() {
+    static std::map<void*, size_t>* c = new std::map<void*, size_t>();
+    return *c;
+}
 static void* host_stage_alloc(size_t n) {
+    if (n == 0) n = 1;
 #if defined(BPR1CS_HOSTSIM)
-    return malloc(n ? n : 1);
+    return malloc(n);
 #else
+    auto& cache = host_stage_cache();
+    auto it = cache.lower_bound(n);
     void* p = nullptr;
-    HIPCHK(hipHostMalloc(&p, n ? n : 1, hipHostMallocDefault));
+    size_t sz = n;
+    if (it != cache.end() && it->first <= 2 * n + 4096) { p = it->second; sz = it->first; cache.erase(it); }
+    else HIPCHK(hipHostMalloc(&p, n, hipHostMallocDefault));
+    host_stage_live()[p] = sz;
     return p;
 #endif
 }
@@ -350,7 +373,11 @@ static void host_stage_free(void* p) {
 #if defined(BPR1CS_HOSTSIM)
     free(p);
 #else
-    if (p) HIPCHK(hipHostFree(p));
+    if (!p) return;
+    auto it = host_stage_live().find(p);
+    if (it == host_stage_live().end()) return;
+    host_stage_cache().insert({it->second, p});
+    host_stage_live().erase(it);
 #endif
 }
 static void dev_d2h_async(void* h, const void* d, size_t n, dev_stream_t s) {
@@ -374,8 +401,9 @@ extern "C" int bpr1cs_prove_batch_begin(const bpr1cs_gens* g, const bpr1cs_circu
     bpr1cs_job* job = new bpr1cs_job();
     job->g = g;
     uint32_t slot = const_cast<bpr1cs_gens*>(g)->next_job++ & 1u;
-    job->st = g->jstream[slot][0];
+    job->st = g->jstream[0][0];  // ONE heavy stream: MSM/IPA phases of successive jobs run back to back (FIFO)
     job->st2 = g->jstream[slot][1];
+    job->st3 = g->jstream[slot][2];
     struct Scope {  // every buffer released while enqueuing stays alive until the job has drained
         bpr1cs_job* j;
         explicit Scope(bpr1cs_job* jj) : j(jj) { dev_deferred_frees() = &j->deferred; g_cur_msm = &j->msm; }
@@ -387,53 +415,56 @@ extern "C" int bpr1cs_prove_batch_begin(const bpr1cs_gens* g, const bpr1cs_circu
     PhaseTimer& pt = job->pt;
     job->msm.reset();
     job->B = B; job->m = m;
-    pt.mark(st);
+#if defined(BPR1CS_HOSTSIM)
+    dev_stream_t sl = st;
+#else
+    dev_stream_t sl = job->st2;  // the latency-bound front of the job never touches the heavy stream
+#endif
+    pt.mark(sl);
 
     // ---- inputs
     DevBuf<sc> v_raw, vbl_raw, v_m((size_t)m * B), vbl_m((size_t)m * B);
-    upload_transposed(v_raw, values, B, m, st);
-    upload_transposed(vbl_raw, v_blindings, B, m, st);
+    upload_transposed(v_raw, values, B, m, sl);
+    upload_transposed(vbl_raw, v_blindings, B, m, sl);
     DevBuf<uint8_t> d_seeds((size_t)B * 32), d_label(label_len ? label_len : 1);
-    dev_h2d(d_seeds.p, rng_seeds, (size_t)B * 32, st);
-    if (label_len) dev_h2d(d_label.p, label, label_len, st);
-    launch((uint64_t)m * B, K_load_inputs{v_raw.p, vbl_raw.p, v_m.p, vbl_m.p}, st);
+    dev_h2d(d_seeds.p, rng_seeds, (size_t)B * 32, sl);
+    if (label_len) dev_h2d(d_label.p, label, label_len, sl);
+    launch((uint64_t)m * B, K_load_inputs{v_raw.p, vbl_raw.p, v_m.p, vbl_m.p}, sl);
 
     // ---- P1: V commitments, transcript, RNG stream
     DevBuf<uint8_t> Vcomp((size_t)B * m * 32 + 1);
-    launch((uint64_t)m * B, K_commit_v{g->tab.p, g->tc, v_raw.p, vbl_raw.p, Vcomp.p, B, m}, st);
+    launch((uint64_t)m * B, K_commit_v{g->tab.p, g->tc, v_raw.p, vbl_raw.p, Vcomp.p, B, m}, sl);
     DevBuf<strobe> tr(B);
     DevBuf<sc> blind((size_t)8 * B), W((size_t)5 * n * B + 1);
     sc* sL = W.p + (size_t)3 * n * B;
     sc* sR = W.p + (size_t)4 * n * B;
-    pt.mark(st);
+    pt.mark(sl);
 #if defined(BPR1CS_HOSTSIM)
     launch(B, K_transcript_init{d_label.p, (uint32_t)label_len, Vcomp.p, vbl_raw.p, d_seeds.p, tr.p, blind.p, sL, sR, nullptr, B, m, n}, st);
 #else
-    // transcript + TranscriptRng stream on stream2, concurrent with witness synthesis on the main stream
     hipEvent_t& ev_in = job->ev_in;
     hipEvent_t& ev_rng = job->ev_rng;
     HIPCHK(hipEventCreateWithFlags(&ev_in, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&ev_rng, hipEventDisableTiming));
-    HIPCHK(hipEventRecord(ev_in, st));
-    HIPCHK(hipStreamWaitEvent(job->st2, ev_in, 0));
+    HIPCHK(hipEventRecord(ev_in, sl));
     const uint32_t draws = 2 * n + 7;
     DevBuf<strobe> rng(B);
     DevBuf<uint64_t> rng_raw((size_t)draws * B * 8);
     DevBuf<int> rng_err(1);
-    dev_zero(rng_err.p, sizeof(int), job->st2);
-    launch(B, K_transcript_init{d_label.p, (uint32_t)label_len, Vcomp.p, vbl_raw.p, d_seeds.p, tr.p, blind.p, sL, sR, rng.p, B, m, n}, job->st2);
-    hipLaunchKernelGGL(k_rng_stream, dim3((B + 1) / 2), dim3(64), 0, job->st2, rng.p, rng_raw.p, rng_err.p, B, draws);
+    dev_zero(rng_err.p, sizeof(int), sl);
+    launch(B, K_transcript_init{d_label.p, (uint32_t)label_len, Vcomp.p, vbl_raw.p, d_seeds.p, tr.p, blind.p, sL, sR, rng.p, B, m, n}, sl);
+    hipLaunchKernelGGL(k_rng_stream, dim3((B + 1) / 2), dim3(64), 0, sl, rng.p, rng_raw.p, rng_err.p, B, draws);
     HIPCHK(hipGetLastError());
-    launch((uint64_t)draws * B, K_rng_reduce{rng_raw.p, blind.p, sL, sR, B, n}, job->st2);
-    HIPCHK(hipEventRecord(ev_rng, job->st2));
+    launch((uint64_t)draws * B, K_rng_reduce{rng_raw.p, blind.p, sL, sR, B, n}, sl);
+    HIPCHK(hipEventRecord(ev_rng, sl));
 #endif
 
     // ---- P7/P8: witness (device program) or host-synthesised wires
     if (wires) {
         DevBuf<sc> raw;
-        upload_transposed(raw, wires, B, (size_t)3 * n, st);
-        launch((uint64_t)3 * n * B, K_load_wires{raw.p, W.p}, st);
-        dev_sync(st);
+        upload_transposed(raw, wires, B, (size_t)3 * n, sl);
+        launch((uint64_t)3 * n * B, K_load_wires{raw.p, W.p}, sl);
+        dev_sync(sl);
     } else {
         K_witness kw{c->wops.p, c->lc_off.p, c->lc_var.p, c->lc_coeff.p, v_raw.p, v_m.p, W.p, B, n};
 #if defined(BPR1CS_HOSTSIM)
@@ -441,12 +472,16 @@ extern "C" int bpr1cs_prove_batch_begin(const bpr1cs_gens* g, const bpr1cs_circu
 #else
         const int T = 16;
         uint32_t blocks = (uint32_t)(((uint64_t)B * T + 63) / 64);
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_witness_team<T>), dim3(blocks), dim3(64), 0, st, kw);
+        HIPCHK(hipStreamWaitEvent(job->st3, ev_in, 0));
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_witness_team<T>), dim3(blocks), dim3(64), 0, job->st3, kw);
         HIPCHK(hipGetLastError());
+        HIPCHK(hipEventCreateWithFlags(&job->ev_wit, hipEventDisableTiming));
+        HIPCHK(hipEventRecord(job->ev_wit, job->st3));
+        HIPCHK(hipStreamWaitEvent(st, job->ev_wit, 0));
 #endif
     }
 #if !defined(BPR1CS_HOSTSIM)
-    HIPCHK(hipStreamWaitEvent(st, ev_rng, 0));
+    HIPCHK(hipStreamWaitEvent(st, ev_rng, 0));  // (in the wires path everything on `sl` was synchronised above)
 #endif
     pt.mark(st);
 
@@ -564,6 +599,7 @@ extern "C" int bpr1cs_prove_batch_end(bpr1cs_job* job, uint8_t* proofs_out, uint
 #if !defined(BPR1CS_HOSTSIM)
     HIPCHK(hipEventSynchronize(job->ev_done));
     HIPCHK(hipStreamSynchronize(job->st2));
+    HIPCHK(hipStreamSynchronize(job->st3));
 #endif
     memcpy(proofs_out, job->h_proofs, (size_t)job->B * job->plen);
     if (commitments_out && job->m) memcpy(commitments_out, job->h_comms, (size_t)job->B * job->m * 32);
@@ -575,6 +611,7 @@ extern "C" int bpr1cs_prove_batch_end(bpr1cs_job* job, uint8_t* proofs_out, uint
     for (auto e : job->msm.pool) hipEventDestroy(e);
     HIPCHK(hipEventDestroy(job->ev_in));
     HIPCHK(hipEventDestroy(job->ev_rng));
+    if (job->ev_wit) HIPCHK(hipEventDestroy(job->ev_wit));
     HIPCHK(hipEventDestroy(job->ev_done));
 #endif
     for (void* p : job->deferred) dev_free_now(p);
