@@ -61,7 +61,8 @@ def build_workload(bp, levels, batch, n_leaves, seed_base):
         for k in range(m - 2):
             bl += sc(synth_scalar(b"blind", (seed_base + j) * 1024 + k))
         bl += bytes(64)  # statics are committed with blinding 0 (gadget_poseidon.rs:554-578)
-    seeds = b"".join(hashlib.sha256(b"seed" + (seed_base + j).to_bytes(8, "little")).digest() for j in range(batch))
+    sh = importlib.import_module("bulletproofs-r1cs-gadgets_amd.sharding")
+    seeds = b"".join(sh.rng_seed(seed_base + j) for j in range(batch))
     return tree.root(), values, bytes(bl), seeds, m
 
 
@@ -98,8 +99,10 @@ def main():
     ap.add_argument("--leaves", type=int, default=32, help="distinct synthetic leaves cycled over the batch")
     ap.add_argument("--cpu-proofs", type=int, default=2, help="proofs timed on the CPU oracle (0 = skip)")
     ap.add_argument("--pipeline", type=int, default=2, help="batches in flight (1 = synchronous)")
-    ap.add_argument("--unfold", type=int, default=-1)
-    ap.add_argument("--window", type=int, default=0, help="fixed-base table window bits (0 = library default)")
+    ap.add_argument("--latency-cus", type=int, default=-1, help="CUs reserved for the latency-bound kernels (-1 = library default)")
+    ap.add_argument("--team", type=int, default=0, help="witness team size 4/8/16 (0 = library default)")
+    ap.add_argument("--unfold", type=int, default=5, help="IPA rounds computed from the un-folded generator tables")
+    ap.add_argument("--window", type=int, default=11, help="fixed-base table window bits (11: 23 adds/term, 148 GB of tables at capacity 32768)")
     args = ap.parse_args()
 
     import torch
@@ -122,6 +125,10 @@ def main():
         lib.bpr1cs_set_unfold_rounds(args.unfold)
     if args.window > 0:
         lib.bpr1cs_set_window_bits(args.window)
+    if args.team > 0:
+        lib.bpr1cs_set_witness_team(args.team)
+    if args.latency_cus >= 0:
+        lib.bpr1cs_set_latency_cus(args.latency_cus)
 
     levels, B = args.depth, args.batch
     t0 = time.time()

@@ -73,6 +73,8 @@ def load_library(path=None):
     lib.bpr1cs_msm_fixed.argtypes = [vp, ctypes.POINTER(u32), sz, cp, sz, cp]
     lib.bpr1cs_set_unfold_rounds.argtypes = [ctypes.c_int]
     lib.bpr1cs_set_window_bits.argtypes = [ctypes.c_int]
+    lib.bpr1cs_set_witness_team.argtypes = [ctypes.c_int]
+    lib.bpr1cs_set_latency_cus.argtypes = [ctypes.c_int]
     lib.bpr1cs_last_timings.argtypes = [ctypes.POINTER(ctypes.c_float), ctypes.c_int]
     lib.bpr1cs_last_msm_stats.argtypes = [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]
     if path is None:

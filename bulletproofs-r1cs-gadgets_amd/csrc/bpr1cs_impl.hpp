@@ -36,7 +36,9 @@ static void host_sponge(uint32_t rate, uint8_t suffix, const uint8_t* in, size_t
 
 static int g_unfold_rounds = 4;
 static int g_window_bits = 8;
-static uint32_t g_msm_target_threads = 1u << 19;  // short MSM workgroups (~2k of them) so high-priority latency-bound kernels get slots
+static int g_latency_cus = 0;   // >0: CUs reserved for the latency-bound kernels (see bpr1cs_gens_create)
+static int g_witness_team = 16;  // lanes cooperating on one proof in k_witness_team (4, 8 or 16)
+static uint32_t g_msm_target_threads = 1u << 17;  // (chunk, proof) threads per MSM launch
 static float g_timings[8];
 
 struct bpr1cs_gens {
@@ -103,6 +105,8 @@ int bpr1cs_set_device(int ordinal) {
     return BPR1CS_OK;
 }
 void bpr1cs_set_unfold_rounds(int r) { g_unfold_rounds = r < 0 ? 0 : r; }
+void bpr1cs_set_latency_cus(int n) { g_latency_cus = n < 0 ? 0 : n; }
+void bpr1cs_set_witness_team(int t) { g_witness_team = (t == 4 || t == 8) ? t : 16; }
 void bpr1cs_set_window_bits(int w) { g_window_bits = w < 4 ? 4 : (w > 12 ? 12 : w); }
 int bpr1cs_last_timings(float* out, int cap) {
     int k = cap < 6 ? cap : 6;
@@ -120,8 +124,35 @@ int bpr1cs_gens_create(uint32_t cap, bpr1cs_gens** out) {
     HIPCHK(hipStreamCreate(&g->stream));
     int prio_lo = 0, prio_hi = 0;
     HIPCHK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));  // numerically lower = higher priority
-    for (int a = 0; a < 2; a++)
-        for (int b = 0; b < 3; b++) HIPCHK(hipStreamCreateWithPriority(&g->jstream[a][b], hipStreamNonBlocking, b == 0 ? prio_lo : prio_hi));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, 0));
+    int dev = 0;
+    HIPCHK(hipGetDevice(&dev));
+    HIPCHK(hipGetDeviceProperties(&prop, dev));
+    const uint32_t ncu = (uint32_t)prop.multiProcessorCount;
+    if (g_latency_cus > 0 && (uint32_t)g_latency_cus < ncu) {
+        // Partition the CUs: the latency-bound kernels (RNG Keccak chain, witness synthesis) of the NEXT
+        // batch get `g_latency_cus` CUs of their own (spread evenly over the XCDs: every k-th CU), the
+        // VALU-bound MSM/IPA stream gets the rest.  Measured: letting them share CUs costs the MSM kernels
+        // far more than the latency kernels' own issue slots (three large kernels thrash the I-cache).
+        const uint32_t words = (ncu + 31) / 32;
+        std::vector<uint32_t> lat(words, 0), heavy(words, 0);
+        const uint32_t stride = ncu / (uint32_t)g_latency_cus;
+        uint32_t taken = 0;
+        for (uint32_t cu = 0; cu < ncu; cu++) {
+            bool is_lat = (cu % stride == 0) && taken < (uint32_t)g_latency_cus;
+            if (is_lat) { lat[cu / 32] |= 1u << (cu % 32); taken++; }
+            else heavy[cu / 32] |= 1u << (cu % 32);
+        }
+        for (int a = 0; a < 2; a++) {
+            HIPCHK(hipExtStreamCreateWithCUMask(&g->jstream[a][0], words, heavy.data()));
+            HIPCHK(hipExtStreamCreateWithCUMask(&g->jstream[a][1], words, lat.data()));
+            HIPCHK(hipExtStreamCreateWithCUMask(&g->jstream[a][2], words, lat.data()));
+        }
+    } else {
+        for (int a = 0; a < 2; a++)
+            for (int b = 0; b < 3; b++) HIPCHK(hipStreamCreateWithPriority(&g->jstream[a][b], hipStreamNonBlocking, b == 0 ? prio_lo : prio_hi));
+    }
 #endif
     uint32_t nb = 2 + 2 * cap;
     // uniform bytes: B~ <- SHA3-512(compress(B)); G/H <- SHAKE256("GeneratorsChain"||'G'|'H'||LE32(0))  
@@ -470,10 +501,12 @@ extern "C" int bpr1cs_prove_batch_begin(const bpr1cs_gens* g, const bpr1cs_circu
 #if defined(BPR1CS_HOSTSIM)
         launch(B, kw, st);
 #else
-        const int T = 16;
+        const int T = g_witness_team;
         uint32_t blocks = (uint32_t)(((uint64_t)B * T + 63) / 64);
         HIPCHK(hipStreamWaitEvent(job->st3, ev_in, 0));
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_witness_team<T>), dim3(blocks), dim3(64), 0, job->st3, kw);
+        if (T == 4) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_witness_team<4>), dim3(blocks), dim3(64), 0, job->st3, kw);
+        else if (T == 8) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_witness_team<8>), dim3(blocks), dim3(64), 0, job->st3, kw);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_witness_team<16>), dim3(blocks), dim3(64), 0, job->st3, kw);
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventCreateWithFlags(&job->ev_wit, hipEventDisableTiming));
         HIPCHK(hipEventRecord(job->ev_wit, job->st3));

@@ -132,6 +132,15 @@ void bpr1cs_set_unfold_rounds(int r);
  * (W=8: 25.8 GB, W=10: 84 GB at capacity 32768).  Default 8. */
 void bpr1cs_set_window_bits(int w);
 
+/* tuning knob: lanes of a wavefront cooperating on one proof during witness synthesis (4, 8 or 16).
+ * Fewer lanes = fewer wavefronts (less interference with a co-running batch), longer LC evaluation. */
+void bpr1cs_set_witness_team(int t);
+
+/* tuning knob, read by bpr1cs_gens_create: reserve n compute units (spread over the XCDs) for the
+ * latency-bound kernels (TranscriptRng chain, witness synthesis) via HIP CU masks and give the rest to
+ * the MSM/IPA stream.  Only useful with two jobs in flight (bpr1cs_prove_batch_begin/_end); 0 = off. */
+void bpr1cs_set_latency_cus(int n);
+
 /* last prove_batch phase timings in milliseconds (HIP events), for bench.py:
  * [0]=total [1]=inputs+V commitments [2]=RNG stream || witness synthesis [3]=commit MSMs [4]=polys [5]=IPA; returns count */
 int bpr1cs_last_timings(float* out, int cap);
