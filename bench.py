@@ -66,6 +66,21 @@ def build_workload(bp, levels, batch, n_leaves, seed_base):
     return tree.root(), values, bytes(bl), seeds, m
 
 
+def pmc_traffic_bytes(window):
+    """HBM bytes per K_msm_fixed launch from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE,
+    separate runs of this same command; profiles/r01b_pmc_hbm_traffic.txt, W = 11, 1024 proofs).  Returned as
+    reported by the counters (KB * 1024); the gfx950 FETCH_SIZE caveat (x2 under-count for wide coalesced
+    streams, uncalibrated for 96-byte gathers) is discussed in DESIGN.md.  None when no matching profile."""
+    path = os.path.join(ROOT, "profiles", "r01b_pmc_hbm_traffic.txt")
+    if window != 11 or not os.path.exists(path):
+        return None
+    for line in open(path):
+        if line.startswith("K_msm_fixed |"):
+            f = [x.strip() for x in line.split("|")]
+            return (float(f[2]) + float(f[3])) * 1024.0
+    return None
+
+
 def cpu_baseline(levels, root, values, blindings, seeds, m, n_proofs):
     """Oracle leg: the C restatement (oracle/c) proves the SAME first `n_proofs` witnesses on one host
     thread; returns (dict, proofs) or (None, None) when the oracle library is not built."""
@@ -205,10 +220,12 @@ def main():
                        "synthetic_leaves": args.leaves, "batches_in_flight": depth},
             "roofline": {"bound": "hbm", "kernel": "K_msm_fixed (batched fixed-base MSM over generator tables)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": None,
+                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
+                         "traffic": pmc_traffic_bytes(args.window) if B == 1024 and levels == 32 else None,
                          "avg_launch_ms": (msm_ms / msm_launches) if msm_launches else None, "launches_per_step": msm_launches / steps,
                          "alg_bytes_per_launch": (msm_alg_bytes / msm_launches) if msm_launches else None,
-                         "note": "path is integer-VALU bound, not HBM bound (DESIGN.md); frac is quoted because BASELINE asks for it"},
+                         "note": "achieved/frac use ALGORITHMIC bytes (64 B per scalar*point term); the kernel is integer-VALU bound and additionally "
+                                 "streams its fixed-base tables from HBM (traffic, PMC) — see DESIGN.md"},
             "hbm_frac_whole_path": value / world * alg_bytes_per_proof / (HBM_PEAK_GBS * 1e9),
             "phase_ms_per_step": {k: v / steps for k, v in zip(["total", "inputs+commitV", "rng||witness", "commit_msm", "poly", "ipa"], phases)},
             "setup_s": {"witness_trees": t_witness, "circuit_compile": t_compile, "generator_tables": t_gens},
