@@ -230,6 +230,15 @@ def main():
             "phase_ms_per_step": {k: v / steps for k, v in zip(["total", "inputs+commitV", "rng||witness", "commit_msm", "poly", "ipa"], phases)},
             "setup_s": {"witness_trees": t_witness, "circuit_compile": t_compile, "generator_tables": t_gens},
         }
+        # outside the timed region: the device verifier (Verifier::verify, one mega-check MSM per proof) on the last batch
+        try:
+            _, comms = begin().finish()
+            tv = time.perf_counter()
+            oks = bp.verify_batch(gens, circ, b"VSMT", proofs, comms, B)
+            tv = time.perf_counter() - tv
+            out["verify"] = {"accepted": sum(oks), "of": B, "proofs_per_s": B / tv, "note": "bpr1cs_verify_batch, not part of `value`"}
+        except Exception as e:  # pragma: no cover
+            out["verify"] = {"error": repr(e)}
         if world == 1 and args.cpu_proofs > 0:
             cb, cproofs = cpu_baseline(levels, root, values, blindings, seeds, m, args.cpu_proofs)
             out["cpu_baseline"] = cb

@@ -70,6 +70,7 @@ def load_library(path=None):
     lib.bpr1cs_prove_batch.argtypes = [vp, vp, cp, sz, cp, cp, cp, cp, sz, cp, cp]
     lib.bpr1cs_prove_batch_begin.argtypes = [vp, vp, cp, sz, cp, cp, cp, cp, sz, ctypes.POINTER(vp)]
     lib.bpr1cs_prove_batch_end.argtypes = [vp, cp, cp]
+    lib.bpr1cs_verify_batch.argtypes = [vp, vp, cp, sz, cp, cp, cp, sz, ctypes.POINTER(ctypes.c_int)]
     lib.bpr1cs_msm_fixed.argtypes = [vp, ctypes.POINTER(u32), sz, cp, sz, cp]
     lib.bpr1cs_set_unfold_rounds.argtypes = [ctypes.c_int]
     lib.bpr1cs_set_window_bits.argtypes = [ctypes.c_int]
@@ -198,6 +199,17 @@ def prove_batch(gens, circuit, label, values, v_blindings, rng_seeds, batch, wir
     return P, C
 
 
+def verify_batch(gens, circuit, label, proofs, commitments, batch, seeds=None):
+    """proofs: list of bytes or concatenated bytes; commitments: list of lists (each m x 32 bytes) or bytes.
+    -> list of bool (Verifier::verify accepted)."""
+    pf = proofs if isinstance(proofs, (bytes, bytearray)) else b"".join(proofs)
+    cm = commitments if isinstance(commitments, (bytes, bytearray)) else b"".join(b"".join(c) for c in commitments)
+    assert len(pf) == batch * circuit.proof_len and len(cm) == batch * circuit.m * 32
+    ok = (ctypes.c_int * batch)()
+    _chk(gens.lib.bpr1cs_verify_batch(gens.h, circuit.h, label, len(label), pf, cm or b"\0", seeds, batch, ok))
+    return [bool(x) for x in ok]
+
+
 class ProveJob:
     """An in-flight bpr1cs_prove_batch_begin; .finish() -> (proofs, commitments)."""
 
@@ -259,6 +271,7 @@ def load_gadgets_library(path=None):
     vp, u32, sz, cp, ip = ctypes.c_void_p, ctypes.c_uint32, ctypes.c_size_t, ctypes.c_char_p, ctypes.POINTER(ctypes.c_uint32)
     g.bpr1cs_gadget_compile.argtypes = [cp, ip, sz, cp, sz, cp, sz, ctypes.POINTER(vp), ip, ip, ip, ctypes.POINTER(ctypes.c_int)]
     g.bpr1cs_gadget_prove_single.argtypes = [cp, ip, sz, cp, sz, cp, sz, u32, cp, sz, cp, cp, sz, cp, cp, sz, ctypes.POINTER(sz), cp]
+    g.bpr1cs_gadget_verify_single.argtypes = [cp, ip, sz, cp, sz, cp, sz, u32, cp, sz, cp, sz, cp, sz]
     g.bpr1cs_poseidon_hash.argtypes = [ctypes.c_int, ctypes.c_int, u32, cp, sz, cp, cp]
     g.bpr1cs_mimc.argtypes = [cp, cp, cp, sz, cp]
     for nm in ("vsmt4", "vsmt2"):
@@ -316,6 +329,20 @@ def prove_single(name, iparams, sparams, gens_capacity, label, values, blindings
                                       gens_capacity, label, len(label), b"".join(_sc(v) for v in values), b"".join(_sc(v) for v in blindings),
                                       m, rng_seed, proof, len(proof), ctypes.byref(plen), comms))
     return proof.raw[:plen.value], [comms.raw[32 * i:32 * i + 32] for i in range(m)]
+
+
+def verify_single(name, iparams, sparams, gens_capacity, label, proof, commitments, glib=None):
+    """The reference's verifier harness over the C++ `Verifier` -> True / False (VerificationError, FormatError)."""
+    g = glib or load_gadgets_library()
+    blob = poseidon_blob()
+    sp = b"".join(_sc(s) for s in sparams)
+    rc = g.bpr1cs_gadget_verify_single(name.encode(), _u32arr(list(iparams)), len(iparams), sp or b"\0", len(sparams), blob, len(blob),
+                                       gens_capacity, label, len(label), proof, len(proof), b"".join(commitments), len(commitments))
+    if rc in (0,):
+        return True
+    if rc in (-2, -3):
+        return False
+    raise R1CSError(rc)
 
 
 def poseidon_hash(arity, inverse, partial_rounds, inputs, glib=None):

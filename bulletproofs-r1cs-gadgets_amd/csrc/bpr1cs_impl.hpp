@@ -209,13 +209,14 @@ int bpr1cs_circuit_create(const bpr1cs_circuit_desc* d, bpr1cs_circuit** out) {
     c->N = 1; c->lgN = 0;
     while (c->N < d->n) { c->N <<= 1; c->lgN++; }
     dev_stream_t s{};
-    // CSR by row -> CSC by wire slot (LEFT i -> i, RIGHT -> n+i, OUT -> 2n+i, COMMITTED -> 3n+i); One terms dropped (prover)
-    uint32_t nslots = 3 * d->n + d->m;
+    // CSR by row -> CSC by wire slot (LEFT i -> i, RIGHT -> n+i, OUT -> 2n+i, COMMITTED -> 3n+i, One -> 3n+m).
+    // The prover flattens slots [0, 3n+m) (it ignores constant terms); the verifier also needs slot 3n+m (w_c).
+    uint32_t nslots = 3 * d->n + d->m + 1;
     std::vector<uint32_t> cnt(nslots + 1, 0);
     uint32_t nnz = d->q ? d->row_off[d->q] : 0;
     auto slot_of = [&](uint32_t var, uint32_t& slot) -> int {
         uint32_t kind = var >> 28, idx = var & 0x0fffffffu;
-        if (kind == VK_ONE) return 0;
+        if (kind == VK_ONE) { slot = 3 * d->n + d->m; return 1; }
         if (kind == VK_COMMITTED) { if (idx >= d->m) return -1; slot = 3 * d->n + idx; return 1; }
         if (kind > VK_OUT || idx >= d->n) return -1;
         slot = (kind - 1) * d->n + idx;
@@ -669,6 +670,51 @@ extern "C" int bpr1cs_last_msm_stats(double* ms_total, uint64_t* launches, uint6
     if (ms_total) *ms_total = g_msm.ms;
     if (launches) *launches = g_msm.launches;
     if (terms) *terms = g_msm.terms;
+    return BPR1CS_OK;
+}
+
+extern "C" int bpr1cs_verify_batch(const bpr1cs_gens* g, const bpr1cs_circuit* c, const uint8_t* label, size_t label_len,
+                                   const uint8_t* proofs, const uint8_t* commitments, const uint8_t* verifier_rng_seeds, size_t batch,
+                                   int* ok_out) {
+    if (!g || !c || !label || !proofs || !ok_out || batch == 0 || batch > (1u << 20)) return BPR1CS_ERR_INVALID_ARGUMENT;
+    if (c->m && !commitments) return BPR1CS_ERR_INVALID_ARGUMENT;
+    if (!have_device()) return BPR1CS_ERR_NO_DEVICE;
+    if (g->cap < c->N) return BPR1CS_ERR_INVALID_GENERATORS_LENGTH;
+    const uint32_t B = (uint32_t)batch, n = c->n, m = c->m, N = c->N, lgN = c->lgN;
+    const uint32_t baseG = 2, baseH = 2 + g->cap;
+    const size_t plen = bpr1cs_proof_len(c);
+    dev_stream_t st = g->stream;
+    DevBuf<uint8_t> d_pf((size_t)B * plen), d_vc((size_t)B * m * 32 + 1), d_seed((size_t)B * 32), d_label(label_len ? label_len : 1);
+    dev_h2d(d_pf.p, proofs, (size_t)B * plen, st);
+    if (m) dev_h2d(d_vc.p, commitments, (size_t)B * m * 32, st);
+    if (verifier_rng_seeds) dev_h2d(d_seed.p, verifier_rng_seeds, (size_t)B * 32, st);
+    else dev_zero(d_seed.p, (size_t)B * 32, st);
+    if (label_len) dev_h2d(d_label.p, label, label_len, st);
+    DevBuf<sc> chal((size_t)VCH_COUNT * B), uk((size_t)(lgN ? lgN : 1) * 2 * B);
+    DevBuf<int> fail(B), ok(B);
+    dev_zero(fail.p, sizeof(int) * B, st);
+    launch(B, K_verify_transcript{d_label.p, (uint32_t)label_len, d_pf.p, d_vc.p, d_seed.p, chal.p, uk.p, fail.p, B, m, lgN, (uint32_t)plen, (uint64_t)N}, st);
+    uint32_t maxe = std::max<uint32_t>(N, c->q + 1);
+    uint32_t H = (maxe >> 8) + 1;
+    DevBuf<sc> plo((size_t)3 * 256 * B), phi((size_t)3 * H * B);
+    launch((uint64_t)3 * B, K_pow_tables{chal.p, plo.p, phi.p, B, H}, st);
+    const uint32_t nslots = 3 * n + m + 1;
+    DevBuf<sc> wvec((size_t)nslots * B);
+    launch((uint64_t)nslots * B, K_flatten{c->slot_off.p, c->ent_row.p, c->ent_coeff.p, plo.p, phi.p, wvec.p, B, H, 3 * n}, st);
+    DevBuf<sc> gs((size_t)N * B), hs((size_t)N * B), dpart((size_t)N * B), delta(B), bsc((size_t)2 * B);
+    launch((uint64_t)N * B, K_verify_gh{wvec.p, plo.p, phi.p, chal.p, uk.p, gs.p, hs.p, dpart.p, B, H, n, N, lgN}, st);
+    launch(B, K_sum_partials{dpart.p, delta.p, B, N}, st);
+    launch(B, K_verify_bscalars{chal.p, wvec.p + (size_t)(3 * n + m) * B, delta.p, bsc.p, B}, st);
+    DevBuf<ge> partial;
+    MsmPlan plan;
+    MsmSeg sg{gs.p, N, N, N, 0, baseG, 0}, sh{hs.p, N, N, N, 0, baseH, 0};
+    run_msm(g, sg, sh, B, partial, plan, st);
+    const uint32_t P = 8 + m + 2 * lgN;
+    DevBuf<ge> pts((size_t)P * B);
+    launch((uint64_t)P * B, K_verify_points{d_pf.p, d_vc.p, chal.p, uk.p, wvec.p + (size_t)3 * n * B, pts.p, fail.p, B, m, lgN, (uint32_t)plen}, st);
+    launch(B, K_verify_finish{g->tab.p, g->tc, partial.p, pts.p, bsc.p, fail.p, ok.p, B, plan.nchunks, P}, st);
+    dev_d2h(ok_out, ok.p, sizeof(int) * B, st);
+    g_msm.collect();
     return BPR1CS_OK;
 }
 

@@ -41,43 +41,56 @@ HD inline fe fe_one() {
     return r;
 }
 
+// 32-bit add/sub with carry: clang lowers the builtins to v_add_co/v_addc_co chains (the u64
+// formulation compiles to ~3x as many instructions on gfx950); g++ (host simulator) uses u64.
+HD inline uint32_t addc32(uint32_t a, uint32_t b, uint32_t cin, uint32_t& cout) {
+#if defined(__clang__)
+    unsigned co;
+    uint32_t r = __builtin_addc(a, b, cin, &co);
+    cout = co;
+    return r;
+#else
+    uint64_t t = (uint64_t)a + b + cin;
+    cout = (uint32_t)(t >> 32);
+    return (uint32_t)t;
+#endif
+}
+HD inline uint32_t subc32(uint32_t a, uint32_t b, uint32_t bin, uint32_t& bout) {
+#if defined(__clang__)
+    unsigned bo;
+    uint32_t r = __builtin_subc(a, b, bin, &bo);
+    bout = bo;
+    return r;
+#else
+    uint64_t t = (uint64_t)a - b - bin;
+    bout = (uint32_t)(t >> 63);
+    return (uint32_t)t;
+#endif
+}
+
 HD inline fe fe_add(const fe& a, const fe& b) {
     fe r;
-    uint64_t c = 0;
+    uint32_t c = 0;
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-        c += (uint64_t)a.v[i] + b.v[i];
-        r.v[i] = (uint32_t)c;
-        c >>= 32;
-    }
-    c *= 38;  // 2^256 == 38
+    for (int i = 0; i < 8; i++) r.v[i] = addc32(a.v[i], b.v[i], c, c);
+    // 2^256 == 38: fold the carry; a second wrap leaves r < 38 so the last add cannot carry
+    r.v[0] = addc32(r.v[0], c * 38u, 0, c);
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-        c += r.v[i];
-        r.v[i] = (uint32_t)c;
-        c >>= 32;
-    }
-    r.v[0] += 38u * (uint32_t)c;  // second wrap leaves r < 38, cannot carry
+    for (int i = 1; i < 8; i++) r.v[i] = addc32(r.v[i], 0, c, c);
+    r.v[0] += 38u * c;
     return r;
 }
 
 HD inline fe fe_sub(const fe& a, const fe& b) {
     fe r;
-    int64_t c = 0;
+    uint32_t c = 0;
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-        c += (int64_t)a.v[i] - b.v[i];
-        r.v[i] = (uint32_t)c;
-        c >>= 32;  // arithmetic: 0 or -1
-    }
-    c *= 38;  // -38 if borrowed
+    for (int i = 0; i < 8; i++) r.v[i] = subc32(a.v[i], b.v[i], c, c);
+    // a borrow means +2^256 was added: subtract 38; a second borrow leaves r >= 2^256-38
+    r.v[0] = subc32(r.v[0], c * 38u, 0, c);
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-        c += r.v[i];
-        r.v[i] = (uint32_t)c;
-        c >>= 32;
-    }
-    r.v[0] -= 38u * (uint32_t)(-c);  // second borrow leaves r >= 2^256-38, cannot borrow
+    for (int i = 1; i < 8; i++) r.v[i] = subc32(r.v[i], 0, c, c);
+    r.v[0] -= 38u * c;
     return r;
 }
 

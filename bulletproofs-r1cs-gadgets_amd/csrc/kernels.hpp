@@ -749,6 +749,232 @@ struct K_ipa_vb_reduce {  // gid = (out*VC + c)*B + b ; out: 0=L (w 0,1) 1=R (w 
         partial[g] = acc;
     }
 };
+// ---------------------------------------------------------------- verifier
+// Verifier::verify (reference call sites src/gadget_vsmt_4.rs:479, gadget_poseidon.rs:781): replay the
+// transcript, derive the mega-check scalars, evaluate ONE multiscalar multiplication per proof
+//   x*A_I1 + x^2*A_O1 + x^3*S1 + sum wV_j*r*x^2*V_j + r*x^(1,3,4,5,6)*T_(1,3,4,5,6) + cB*B + cBb*B~
+//   + sum g_i*G_i + sum h_i*H_i + sum u_k^2*L_k + sum u_k^-2*R_k   ==  identity
+// G/H/B/B~ terms go through the fixed-base tables, the 8+m+2lgN proof points are decompressed
+// and multiplied individually.
+#define VCH_Y 0
+#define VCH_Z 1
+#define VCH_YINV 2
+#define VCH_U 3
+#define VCH_X 4
+#define VCH_W 5
+#define VCH_R 6
+#define VCH_A 7
+#define VCH_B 8
+#define VCH_TX 9
+#define VCH_TXB 10
+#define VCH_EB 11
+#define VCH_COUNT 12
+
+HD inline int bytes_are_zero32(const uint8_t* p) {
+    uint8_t o = 0;
+    for (int i = 0; i < 32; i++) o |= p[i];
+    return o == 0;
+}
+HD inline int scalar_bytes_canonical(const uint8_t* p) {  // < l
+    sc a = sc_load_raw(p);
+    for (int i = 7; i >= 0; i--) {
+        if (a.v[i] < SC_L[i]) return 1;
+        if (a.v[i] > SC_L[i]) return 0;
+    }
+    return 0;
+}
+struct K_verify_transcript {  // gid = b
+    const uint8_t* label;
+    uint32_t label_len;
+    const uint8_t* proofs;  // [B][plen]
+    const uint8_t* Vc;      // [B][m][32]
+    const uint8_t* seeds;   // [B][32]
+    sc* chal;               // [VCH_COUNT][B]
+    sc* uk;                 // [lgN][2][B] : u_k, u_k^-1
+    int* fail;              // [B]
+    uint32_t B, m, lgN, plen;
+    uint64_t padded_n;
+    HD void operator()(uint32_t b) const {
+        const uint8_t* pf = proofs + (size_t)b * plen;
+        int bad = pf[0] != 0;  // one-phase format byte (R1CSProof::from_bytes -> FormatError)
+        const uint8_t* el = pf + 1;  // 32-byte elements: A_I1 A_O1 S1 T1 T3 T4 T5 T6 t_x t_xb e_b (L R)* a b
+        bad |= !scalar_bytes_canonical(el + 8 * 32) | !scalar_bytes_canonical(el + 9 * 32) | !scalar_bytes_canonical(el + 10 * 32);
+        bad |= !scalar_bytes_canonical(el + (11 + 2 * lgN) * 32) | !scalar_bytes_canonical(el + (12 + 2 * lgN) * 32);
+        strobe s;
+        merlin_new(s, label, label_len);
+        merlin_append(s, "dom-sep", 7, (const uint8_t*)"r1cs v1", 7);
+        for (uint32_t j = 0; j < m; j++) merlin_append(s, "V", 1, Vc + ((size_t)b * m + j) * 32, 32);
+        merlin_append_u64(s, "m", 1, m);
+        // validate_and_append_point: identity encodings are rejected
+        bad |= bytes_are_zero32(el) | bytes_are_zero32(el + 32) | bytes_are_zero32(el + 64);
+        merlin_append(s, "A_I1", 4, el, 32);
+        merlin_append(s, "A_O1", 4, el + 32, 32);
+        merlin_append(s, "S1", 2, el + 64, 32);
+        merlin_append(s, "dom-sep", 7, (const uint8_t*)"r1cs-1phase", 11);
+        uint8_t id[32];
+        for (int i = 0; i < 32; i++) id[i] = 0;
+        merlin_append(s, "A_I2", 4, id, 32);
+        merlin_append(s, "A_O2", 4, id, 32);
+        merlin_append(s, "S2", 2, id, 32);
+        sc y = merlin_challenge_scalar(s, "y", 1);
+        sc z = merlin_challenge_scalar(s, "z", 1);
+        for (int k = 0; k < 5; k++) bad |= bytes_are_zero32(el + (3 + k) * 32);
+        merlin_append(s, "T_1", 3, el + 3 * 32, 32);
+        merlin_append(s, "T_3", 3, el + 4 * 32, 32);
+        merlin_append(s, "T_4", 3, el + 5 * 32, 32);
+        merlin_append(s, "T_5", 3, el + 6 * 32, 32);
+        merlin_append(s, "T_6", 3, el + 7 * 32, 32);
+        sc u = merlin_challenge_scalar(s, "u", 1);
+        sc x = merlin_challenge_scalar(s, "x", 1);
+        merlin_append(s, "t_x", 3, el + 8 * 32, 32);
+        merlin_append(s, "t_x_blinding", 12, el + 9 * 32, 32);
+        merlin_append(s, "e_blinding", 10, el + 10 * 32, 32);
+        sc w = merlin_challenge_scalar(s, "w", 1);
+        merlin_append(s, "dom-sep", 7, (const uint8_t*)"ipp v1", 6);
+        merlin_append_u64(s, "n", 1, padded_n);
+        for (uint32_t k = 0; k < lgN; k++) {
+            const uint8_t* Lp = el + (11 + 2 * k) * 32;
+            bad |= bytes_are_zero32(Lp) | bytes_are_zero32(Lp + 32);
+            merlin_append(s, "L", 1, Lp, 32);
+            merlin_append(s, "R", 1, Lp + 32, 32);
+            sc uu = merlin_challenge_scalar(s, "u", 1);
+            uk[((size_t)k * 2 + 0) * B + b] = uu;
+            uk[((size_t)k * 2 + 1) * B + b] = sc_invert(uu);
+        }
+        // verifier's TranscriptRng: no witness, external 32 bytes made explicit
+        merlin_rng_finalize(s, seeds + 32 * (size_t)b);
+        sc r = merlin_rng_scalar(s);
+        sc* c = chal;
+        c[(size_t)VCH_Y * B + b] = y; c[(size_t)VCH_Z * B + b] = z; c[(size_t)VCH_YINV * B + b] = sc_invert(y);
+        c[(size_t)VCH_U * B + b] = u; c[(size_t)VCH_X * B + b] = x; c[(size_t)VCH_W * B + b] = w; c[(size_t)VCH_R * B + b] = r;
+        c[(size_t)VCH_TX * B + b] = sc_mont_from_bytes_mod_order(el + 8 * 32);
+        c[(size_t)VCH_TXB * B + b] = sc_mont_from_bytes_mod_order(el + 9 * 32);
+        c[(size_t)VCH_EB * B + b] = sc_mont_from_bytes_mod_order(el + 10 * 32);
+        c[(size_t)VCH_A * B + b] = sc_mont_from_bytes_mod_order(el + (11 + 2 * lgN) * 32);
+        c[(size_t)VCH_B * B + b] = sc_mont_from_bytes_mod_order(el + (12 + 2 * lgN) * 32);
+        fail[b] = bad;
+    }
+};
+// g_i, h_i (canonical form, for the table MSM) ; also delta partial = y^-i wR_i wL_i
+struct K_verify_gh {  // gid = i*B + b, i < N
+    const sc* wvec;   // wL wR wO [3][n][B]
+    const sc* plo;
+    const sc* phi;
+    const sc* chal;
+    const sc* uk;     // [lgN][2][B]
+    sc* gs;           // [N][B]
+    sc* hs;           // [N][B]
+    sc* dpart;        // [N][B] (entries >= n are zero)
+    uint32_t B, H, n, N, lgN;
+    HD void operator()(uint32_t g) const {
+        uint32_t i = g / B, b = g % B;
+        // s_i = prod_k (bit_{lgN-1-k}(i) ? u_k : u_k^-1) ;  s_{N-1-i} = 1/s_i
+        sc s = sc_one_mont(), sinv = sc_one_mont();
+        for (uint32_t k = 0; k < lgN; k++) {
+            uint32_t bit = (i >> (lgN - 1 - k)) & 1u;
+            sc uu = uk[((size_t)k * 2 + 0) * B + b], ui = uk[((size_t)k * 2 + 1) * B + b];
+            s = sc_mul(s, bit ? uu : ui);
+            sinv = sc_mul(sinv, bit ? ui : uu);
+        }
+        sc yinv = pow_lookup(plo, phi, 1, H, B, i, b);
+        sc x = chal[(size_t)VCH_X * B + b], a = chal[(size_t)VCH_A * B + b], bb = chal[(size_t)VCH_B * B + b];
+        sc u_or_1 = i < n ? sc_one_mont() : chal[(size_t)VCH_U * B + b];
+        sc wL = sc_zero(), wR = sc_zero(), wO = sc_zero();
+        if (i < n) {
+            size_t ib = (size_t)i * B + b, nb = (size_t)n * B;
+            wL = wvec[ib]; wR = wvec[nb + ib]; wO = wvec[2 * nb + ib];
+        }
+        sc ynwR = sc_mul(yinv, wR);
+        sc gi = sc_mul(u_or_1, sc_sub(sc_mul(x, ynwR), sc_mul(a, s)));
+        sc hi = sc_mul(u_or_1, sc_sub(sc_mul(yinv, sc_sub(sc_add(sc_mul(x, wL), wO), sc_mul(bb, sinv))), sc_one_mont()));
+        gs[g] = sc_from_mont(gi);
+        hs[g] = sc_from_mont(hi);
+        dpart[g] = sc_mul(ynwR, wL);
+    }
+};
+// scalars of B and B~ :  cB = w(t_x - ab) + r(x^2(wc + delta) - t_x) ;  cBb = -e_bl - r t_xb
+struct K_verify_bscalars {  // gid = b
+    const sc* chal;
+    const sc* wc;     // [B] (slot 3n+m of the flattened constraints)
+    const sc* delta;  // [B]
+    sc* out;          // [2][B] Montgomery
+    uint32_t B;
+    HD void operator()(uint32_t b) const {
+        const sc* c = chal;
+        sc x = c[(size_t)VCH_X * B + b], w = c[(size_t)VCH_W * B + b], r = c[(size_t)VCH_R * B + b];
+        sc a = c[(size_t)VCH_A * B + b], bb = c[(size_t)VCH_B * B + b], tx = c[(size_t)VCH_TX * B + b];
+        sc xx = sc_mul(x, x);
+        sc cB = sc_add(sc_mul(w, sc_sub(tx, sc_mul(a, bb))), sc_mul(r, sc_sub(sc_mul(xx, sc_add(wc[b], delta[b])), tx)));
+        sc cBb = sc_sub(sc_neg(c[(size_t)VCH_EB * B + b]), sc_mul(r, c[(size_t)VCH_TXB * B + b]));
+        out[b] = cB;
+        out[(size_t)B + b] = cBb;
+    }
+};
+// the proof's own points: decompress, multiply by their mega-check scalar
+struct K_verify_points {  // gid = p*B + b, p < 8 + m + 2 lgN
+    const uint8_t* proofs;
+    const uint8_t* Vc;
+    const sc* chal;
+    const sc* uk;
+    const sc* wV;     // [m][B]
+    ge* out;          // [P][B]
+    int* fail;
+    uint32_t B, m, lgN, plen;
+    HD void operator()(uint32_t g) const {
+        uint32_t p = g / B, b = g % B;
+        const uint8_t* el = proofs + (size_t)b * plen + 1;
+        const sc* c = chal;
+        sc x = c[(size_t)VCH_X * B + b], r = c[(size_t)VCH_R * B + b];
+        sc xx = sc_mul(x, x), xxx = sc_mul(xx, x), rxx = sc_mul(r, xx);
+        const uint8_t* pt;
+        sc s;
+        if (p < 3) { pt = el + 32 * p; s = p == 0 ? x : (p == 1 ? xx : xxx); }
+        else if (p < 3 + m) { uint32_t j = p - 3; pt = Vc + ((size_t)b * m + j) * 32; s = sc_mul(wV[(size_t)j * B + b], rxx); }
+        else if (p < 8 + m) {
+            uint32_t k = p - 3 - m;  // T_1 T_3 T_4 T_5 T_6 : r x, r x^3, r x^4, r x^5, r x^6
+            pt = el + 32 * (3 + k);
+            sc t = sc_mul(r, x);
+            if (k >= 1) t = sc_mul(rxx, x);
+            if (k >= 2) t = sc_mul(rxx, xx);
+            if (k >= 3) t = sc_mul(rxx, xxx);
+            if (k >= 4) t = sc_mul(sc_mul(rxx, xx), xx);
+            s = t;
+        } else {
+            uint32_t q = p - 8 - m, k = q >> 1, isR = q & 1u;
+            pt = el + 32 * (11 + 2 * k + isR);
+            sc uu = uk[((size_t)k * 2 + isR) * B + b];  // L: u_k^2, R: u_k^-2
+            s = sc_mul(uu, uu);
+        }
+        ge P;
+        if (!ge_decompress(pt, P)) {
+            fail[b] = 1;
+            out[g] = ge_identity();
+            return;
+        }
+        out[g] = ge_scalarmul_naf(P, sc_from_mont(s));
+    }
+};
+struct K_verify_finish {  // gid = b : sum everything, accept iff identity
+    const ge_niels* tab;
+    TabCfg tc;
+    const ge* msm_partial;  // [nchunks][B]
+    const ge* pts;          // [P][B]
+    const sc* bsc;          // [2][B]
+    const int* fail;
+    int* ok;
+    uint32_t B, nchunks, P;
+    HD void operator()(uint32_t b) const {
+        ge acc = ge_identity();
+        for (uint32_t c = 0; c < nchunks; c++) acc = ge_add_ge(acc, msm_partial[(size_t)c * B + b]);
+        for (uint32_t p = 0; p < P; p++) acc = ge_add_ge(acc, pts[(size_t)p * B + b]);
+        acc = table_mul_acc(acc, tab, sc_from_mont(bsc[b]), tc);
+        acc = table_mul_acc(acc, tab + tc.per_base, sc_from_mont(bsc[(size_t)B + b]), tc);
+        uint8_t enc[32];
+        ge_compress(acc, enc);
+        ok[b] = (!fail[b]) && bytes_are_zero32(enc);
+    }
+};
+
 // ---------------------------------------------------------------- proof out
 struct K_assemble {  // gid = b
     const uint8_t* AOS;  // [3][B][32]

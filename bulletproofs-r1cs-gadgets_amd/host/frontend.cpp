@@ -53,6 +53,39 @@ R1CSProof Prover::prove(const BulletproofGens& bp_gens) {
     return proof;
 }
 
+void Verifier::verify(const R1CSProof& proof, const PedersenGens&, const BulletproofGens& bp_gens, const std::array<uint8_t, 32>* rng_seed) {
+    size_t n = num_vars, padded = 1;
+    while (padded < n) padded <<= 1;
+    if (bp_gens.gens_capacity < padded) throw R1CSError::InvalidGeneratorsLength();
+    std::vector<uint32_t> row_off, tvar;
+    std::vector<uint8_t> tcoeff;
+    export_csr(row_off, tvar, tcoeff);
+    bpr1cs_circuit_desc d{};
+    d.n = (uint32_t)n; d.q = (uint32_t)constraints.size(); d.m = (uint32_t)V_.size();
+    d.row_off = row_off.data(); d.term_var = tvar.data(); d.term_coeff = tcoeff.data();
+    bpr1cs_circuit* c = nullptr;
+    int rc = bpr1cs_circuit_create(&d, &c);
+    if (rc) throw R1CSError::Backend(rc);
+    if (proof.bytes.size() != bpr1cs_proof_len(c)) {  // R1CSProof::from_bytes / wrong IPA length
+        bpr1cs_circuit_destroy(c);
+        throw R1CSError::FormatError();
+    }
+    std::vector<uint8_t> comms(32 * V_.size() + 1);
+    for (size_t i = 0; i < V_.size(); i++) memcpy(&comms[32 * i], V_[i].data(), 32);
+    std::array<uint8_t, 32> seed;
+    if (rng_seed) seed = *rng_seed;
+    else {
+        std::random_device rd;
+        for (auto& x : seed) x = (uint8_t)rd();
+    }
+    int ok = 0;
+    rc = bpr1cs_verify_batch(bp_gens.h, c, (const uint8_t*)transcript.label.data(), transcript.label.size(), proof.bytes.data(),
+                             comms.data(), seed.data(), 1, &ok);
+    bpr1cs_circuit_destroy(c);
+    if (rc) throw R1CSError::Backend(rc);
+    if (!ok) throw R1CSError::VerificationError();
+}
+
 bpr1cs_circuit* CircuitCompiler::finish(uint32_t* n_out, uint32_t* q_out, uint32_t* m_out) {
     std::vector<uint32_t> row_off, tvar;
     std::vector<uint8_t> tcoeff;
@@ -299,6 +332,37 @@ int bpr1cs_gadget_prove_single(const char* gadget, const uint32_t* iparams, size
         *proof_len = proof.bytes.size();
         if (commitments_out)
             for (size_t i = 0; i < comms.size(); i++) memcpy(commitments_out + 32 * i, comms[i].data(), 32);
+        return BPR1CS_OK;
+    } catch (const R1CSError& e) {
+        return e.code;
+    } catch (const std::exception&) {
+        return BPR1CS_ERR_INVALID_ARGUMENT;
+    }
+}
+
+// the verifier half of the reference's tests: commit every V, run the gadget with no assignments, verify
+int bpr1cs_gadget_verify_single(const char* gadget, const uint32_t* iparams, size_t n_iparams, const uint8_t* sparams, size_t n_sparams,
+                                const uint8_t* poseidon_blob, size_t blob_len, uint32_t gens_capacity, const uint8_t* label, size_t label_len,
+                                const uint8_t* proof, size_t proof_len, const uint8_t* commitments, size_t m) {
+    try {
+        GadgetSpec g = make_spec(gadget, iparams, n_iparams, sparams, n_sparams, poseidon_blob, blob_len);
+        BulletproofGens bp_gens(gens_capacity, 1);
+        PedersenGens pc_gens(bp_gens);
+        Transcript t((const char*)label, label_len);
+        Verifier verifier(t);
+        Harness h{verifier,
+                  [&](size_t k) {
+                      if (k >= m) throw R1CSError::MissingAssignment();
+                      CompressedRistretto c;
+                      memcpy(c.data(), commitments + 32 * k, 32);
+                      return verifier.commit(c);
+                  },
+                  [](size_t) { return std::optional<Scalar>(); }, [](size_t) { return std::optional<uint64_t>(); }};
+        run_gadget(g, h);
+        R1CSProof p;
+        p.bytes.assign(proof, proof + proof_len);
+        std::array<uint8_t, 32> seed{};
+        verifier.verify(p, pc_gens, bp_gens, &seed);
         return BPR1CS_OK;
     } catch (const R1CSError& e) {
         return e.code;

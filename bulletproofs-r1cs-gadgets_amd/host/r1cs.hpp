@@ -352,6 +352,10 @@ public:
         pending_multiplier.reset();
         return {Variable::MultiplierRight(i), Variable::MultiplierOutput(i)};
     }
+    // Verifier::verify(&proof, &pc_gens, &bp_gens) -> Result<(), R1CSError>: throws VerificationError / FormatError.
+    // `rng_seed`: the 32 bytes upstream takes from thread_rng() for the random weight r (default: OS randomness).
+    void verify(const R1CSProof& proof, const PedersenGens& pc_gens, const BulletproofGens& bp_gens,
+                const std::array<uint8_t, 32>* rng_seed = nullptr);
     Transcript& transcript;
     std::vector<CompressedRistretto> V_;
 };

@@ -116,6 +116,16 @@ int bpr1cs_prove_batch_begin(const bpr1cs_gens* g, const bpr1cs_circuit* c, cons
                              const uint8_t* wires, size_t batch, bpr1cs_job** job_out);
 int bpr1cs_prove_batch_end(bpr1cs_job* job, uint8_t* proofs_out, uint8_t* commitments_out);
 
+/* Batched Verifier::verify (reference src/gadget_vsmt_4.rs:442-479): per proof, replay the transcript over the
+ * commitments and the proof, flatten the constraints and evaluate the single mega-check multiscalar
+ * multiplication; ok_out[i] = 1 iff proof i is accepted (R1CSError::VerificationError / FormatError -> 0).
+ *   proofs               batch * bpr1cs_proof_len(c)
+ *   commitments          batch * m * 32   the V's the verifier `commit`s, in gadget order
+ *   verifier_rng_seeds   batch * 32 or NULL (zeros): the 32 bytes upstream draws from thread_rng() for `r` */
+int bpr1cs_verify_batch(const bpr1cs_gens* g, const bpr1cs_circuit* c, const uint8_t* label, size_t label_len,
+                        const uint8_t* proofs, const uint8_t* commitments, const uint8_t* verifier_rng_seeds, size_t batch,
+                        int* ok_out);
+
 /* Low-level, for parity tests and a Rust shim: out = sum_t scalars[t] * Base(bases[t])
  * for `batch` independent scalar vectors over the SAME fixed bases; base index:
  * 0 = B, 1 = B_blinding, 2+i = G[i], 2+capacity+i = H[i].

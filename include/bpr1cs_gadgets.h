@@ -38,6 +38,13 @@ int bpr1cs_gadget_prove_single(const char* gadget, const uint32_t* iparams, size
                                const uint8_t* values, const uint8_t* v_blindings, size_t m, const uint8_t rng_seed[32],
                                uint8_t* proof_out, size_t proof_cap, size_t* proof_len, uint8_t* commitments_out);
 
+/* Verifier::new -> commit(V) x m -> gadget (no assignments) -> verify, as the second half of every reference test
+ * (e.g. src/gadget_vsmt_4.rs:442-479).  `commitments` = all m commitments in gadget order (statics included).
+ * 0 = accepted, BPR1CS_ERR_VERIFICATION / BPR1CS_ERR_FORMAT otherwise. */
+int bpr1cs_gadget_verify_single(const char* gadget, const uint32_t* iparams, size_t n_iparams, const uint8_t* sparams, size_t n_sparams,
+                                const uint8_t* poseidon_blob, size_t blob_len, uint32_t gens_capacity, const uint8_t* label, size_t label_len,
+                                const uint8_t* proof, size_t proof_len, const uint8_t* commitments, size_t m);
+
 /* Poseidon_hash_2 / Poseidon_hash_4 (arity 2 / 4) or the raw permutation (arity 6, out = 192 bytes) */
 int bpr1cs_poseidon_hash(int arity, int sbox_inverse, uint32_t partial_rounds, const uint8_t* blob, size_t blob_len, const uint8_t* inputs,
                          uint8_t* out);

@@ -142,3 +142,24 @@ def check_trees(glib, levels4, depth2, partial_rounds):
     leaf, nodes = t2.get(3)
     oleaf, oproof = o2.get(3, True)
     assert leaf == sc_to_bytes(oleaf) and nodes == [sc_to_bytes(x) for x in oproof]
+
+
+def check_prove_verify_roundtrip(lib, glib, name, batch=2):
+    """the reference's own test assertion: prove -> verify accepts (device prover AND device verifier),
+    plus rejection of a tampered proof / wrong commitment through both verifier entry points."""
+    gname, ip, sp, _, cap = case(name, 0)
+    ob = common.oracle_batch(lambda j: case(name, j)[3], cap, batch)
+    circ = bp.CompiledGadget(gname, ip, sp, lib=lib, glib=glib)
+    gens = bp.Gens(cap, lib=lib)
+    P, C = bp.prove_batch(gens, circ, ob["label"], ob["values"], ob["blindings"], ob["seeds"], batch, wires=None)
+    assert P == ob["proofs"]
+    per_proof_public = name.startswith("poseidon")   # the hash output (a public constant of the circuit) differs per proof
+    nv = 1 if per_proof_public else batch
+    assert bp.verify_batch(gens, circ, ob["label"], P[:nv], C[:nv], nv) == [True] * nv
+    assert bp.verify_single(gname, ip, sp, cap, ob["label"], P[0], C[0], glib=glib)
+    bad = bytearray(P[0]); bad[77] ^= 4
+    assert bp.verify_batch(gens, circ, ob["label"], [bytes(bad)] + P[1:nv], C[:nv], nv)[0] is False
+    assert not bp.verify_single(gname, ip, sp, cap, ob["label"], bytes(bad), C[0], glib=glib)
+    wrongc = list(C[0]); wrongc[0] = C[0][1] if len(C[0]) > 1 else bytes(32)
+    assert not bp.verify_single(gname, ip, sp, cap, ob["label"], P[0], wrongc, glib=glib)
+    assert not bp.verify_single(gname, ip, sp, cap, ob["label"], P[0][:-32], C[0], glib=glib)   # FormatError

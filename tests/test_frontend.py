@@ -31,3 +31,8 @@ def test_compiled_poseidon_cube_small(sim_lib, sim_glib):
 def test_prover_single(sim_lib, sim_glib):
     fc.check_prove_single(sim_glib, "bound_check")
     fc.check_prove_single(sim_glib, "set_membership")
+
+
+@pytest.mark.parametrize("case", ["bound_check", "set_membership"])
+def test_prove_verify_roundtrip(sim_lib, sim_glib, case):
+    fc.check_prove_verify_roundtrip(sim_lib, sim_glib, case)

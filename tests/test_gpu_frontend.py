@@ -34,3 +34,8 @@ def test_compiled_vsmt_4_four_levels(hip_lib, hip_glib):
 def test_prover_single_host_synthesis(hip_glib):
     fc.check_prove_single(hip_glib, "bound_check")
     fc.check_prove_single(hip_glib, "poseidon_hash_2_cube")
+
+
+@pytest.mark.parametrize("case", ["bound_check_64", "set_membership", "poseidon_hash_2_inverse", "vsmt_2_d3", "vsmt_4_l4"])
+def test_prove_verify_roundtrip_on_device(hip_lib, hip_glib, case):
+    fc.check_prove_verify_roundtrip(hip_lib, hip_glib, case)

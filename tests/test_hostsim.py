@@ -38,3 +38,32 @@ def test_two_jobs_in_flight(sim_lib):
     P2, _ = j2.finish()
     P1, _ = j1.finish()
     assert P1 == ob1["proofs"] and P2 == ob2["proofs"]
+
+
+def test_verifier_accepts_and_rejects(sim_lib):
+    """device Verifier::verify (P10): accepts the oracle's proofs, rejects every tampering the oracle rejects"""
+    st = [2, 3, 5, 6, 8, 20, 25]
+    for scen, cap in ((lambda j: S.bound_check(37 + j, 10, 100, 7), 16), (lambda j: S.set_membership(st[j % 7], st), 32)):
+        ob = common.oracle_batch(scen, cap, 2)
+        gens = common.bp.Gens(cap, lib=sim_lib)
+        circ = common.circuit_from_oracle(ob, sim_lib)
+        m = ob["m"]
+        full_comms = []
+        for j in range(2):   # the verifier commits ALL m values (oracle scenarios return only the user-visible ones)
+            vals = [int.from_bytes(ob["values"][(j * m + i) * 32:(j * m + i + 1) * 32], "little") for i in range(m)]
+            bls = [int.from_bytes(ob["blindings"][(j * m + i) * 32:(j * m + i + 1) * 32], "little") for i in range(m)]
+            full_comms.append([common.PC.commit(v, r).compress() for v, r in zip(vals, bls)])
+        assert common.bp.verify_batch(gens, circ, ob["label"], ob["proofs"], full_comms, 2) == [True, True]
+        # tamper: one byte in each 32-byte element of proof 0; proof 1 untouched
+        pf = ob["proofs"][0]
+        for el in range((len(pf) - 1) // 32):
+            bad = bytearray(pf)
+            bad[1 + 32 * el + 3] ^= 0x10
+            res = common.bp.verify_batch(gens, circ, ob["label"], [bytes(bad), ob["proofs"][1]], full_comms, 2)
+            assert res == [False, True], el
+        bad = bytearray(pf); bad[0] = 1
+        assert common.bp.verify_batch(gens, circ, ob["label"], [bytes(bad), ob["proofs"][1]], full_comms, 2) == [False, True]
+        wrong = [list(full_comms[0]), full_comms[1]]
+        wrong[0][0] = common.PC.commit(12345, 678).compress()
+        assert common.bp.verify_batch(gens, circ, ob["label"], ob["proofs"], wrong, 2) == [False, True]
+        assert common.bp.verify_batch(gens, circ, b"other label", ob["proofs"], full_comms, 2) == [False, False]
