@@ -251,6 +251,15 @@ int bpr1cs_circuit_create(const bpr1cs_circuit_desc* d, bpr1cs_circuit** out) {
         std::vector<uint32_t> lo(d->lc_off, d->lc_off + d->n_lc + 1), lv(d->lc_var, d->lc_var + nt);
         std::vector<sc> lcf(nt);
         for (uint32_t t = 0; t < nt; t++) lcf[t] = host_mont(d->lc_coeff + 32 * (size_t)t);
+        // specialise trivial linear combinations: {1 * var} -> WK_VAR, {} -> WK_ZERO
+        sc one = sc_one_mont();
+        auto special = [&](uint32_t& kind, uint32_t& arg) {
+            if (kind != WK_LC || arg >= d->n_lc) return;
+            uint32_t t0 = lo[arg], t1 = lo[arg + 1];
+            if (t1 == t0) { kind = WK_ZERO; arg = 0; return; }
+            if (t1 == t0 + 1 && memcmp(&lcf[t0], &one, sizeof(sc)) == 0) { kind = WK_VAR; arg = lv[t0]; }
+        };
+        for (auto& op : ops) { special(op.lkind, op.larg); special(op.rkind, op.rarg); }
         upload(c->wops, ops, s);
         upload(c->lc_off, lo, s);
         upload(c->lc_var, lv, s);

@@ -42,6 +42,9 @@ HD inline TabCfg tab_cfg(uint32_t W) {
 #define WK_INV_LEFT 1u  // (right wire only) inverse of this multiplier's left wire
 #define WK_BIT 2u       // bit (arg & 0xff) of committed value (arg >> 8)
 #define WK_NOTBIT 3u    // 1 - that bit
+// internal (produced by bpr1cs_circuit_create from WK_LC operands, never part of the ABI):
+#define WK_VAR 4u       // a linear combination that is exactly 1 * variable(arg): plain copy
+#define WK_ZERO 5u      // empty linear combination
 
 // ------------------------------------------------------------ fixed-base core
 // acc += s * Base, s canonical (< l).  Signed W-bit digits.
@@ -319,6 +322,8 @@ struct K_witness {  // thread per proof (sequential program)
         return W[((size_t)(kind - 1) * n + idx) * B + b];
     }
     HD sc operand(uint32_t kind, uint32_t arg, uint32_t b) const {
+        if (kind == WK_VAR) return value(arg, b);
+        if (kind == WK_ZERO) return sc_zero();
         if (kind == WK_LC) {
             sc acc = sc_zero();
             for (uint32_t t = lc_off[arg]; t < lc_off[arg + 1]; t++) acc = sc_add(acc, sc_mul(lc_coeff[t], value(lc_var[t], b)));
