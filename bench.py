@@ -128,7 +128,7 @@ def main():
         raise SystemExit("bench.py: no GPU visible — the hot path is HIP only (no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ:  # under torchrun the RCCL group is created even for one rank
         import torch.distributed as dist
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 

@@ -118,7 +118,8 @@ __global__ void __launch_bounds__(64) k_rng_stream(const strobe* rng_in, uint64_
         if (j == 8) a ^= 0x0741000000401200ull;
         if (j == 9) a ^= 0x0000000000000447ull;
         if (j == 20) a ^= 0x8000000000000000ull;
-        for (int r = 0; r < 24; r++) {
+#pragma unroll
+        for (int r = 0; r < 24; r++) {  // fully unrolled: the round constants become immediates (no s_load per round)
             A0[i] = a;
             lds_order();
             uint64_t m = A0[xm] ^ A0[xm + 5] ^ A0[xm + 10] ^ A0[xm + 15] ^ A0[xm + 20];
