@@ -46,6 +46,11 @@ def case(name, j=0):
         sc = S.vsmt_4(tree, 1 + (j % 10))
         n = 583 * levels if pr == 140 else None
         return "vsmt_4", [levels, pr], [tree.root], sc, 4096 if pr == 140 else 512
+    if name == "mimc":
+        consts = [S.synth_scalar(b"mimc-const", i) for i in range(g.MIMC_ROUNDS)]   # gadget_mimc.rs:93-96 draws them from the seeded rng
+        sc = S.mimc(S.synth_scalar(b"ml", j), S.synth_scalar(b"mr", j), consts)
+        image = g.mimc(S.synth_scalar(b"ml", j), S.synth_scalar(b"mr", j), consts)
+        return "mimc", [g.MIMC_ROUNDS], consts + [image], sc, 1024
     if name.startswith("vsmt_2"):
         depth, pr = 3, 2
         tree = _tree2(depth, pr)
@@ -153,7 +158,7 @@ def check_prove_verify_roundtrip(lib, glib, name, batch=2):
     gens = bp.Gens(cap, lib=lib)
     P, C = bp.prove_batch(gens, circ, ob["label"], ob["values"], ob["blindings"], ob["seeds"], batch, wires=None)
     assert P == ob["proofs"]
-    per_proof_public = name.startswith("poseidon")   # the hash output (a public constant of the circuit) differs per proof
+    per_proof_public = name.startswith("poseidon") or name == "mimc"   # the hash output (a public constant of the circuit) differs per proof
     nv = 1 if per_proof_public else batch
     assert bp.verify_batch(gens, circ, ob["label"], P[:nv], C[:nv], nv) == [True] * nv
     assert bp.verify_single(gname, ip, sp, cap, ob["label"], P[0], C[0], glib=glib)

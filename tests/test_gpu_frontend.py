@@ -31,6 +31,12 @@ def test_compiled_vsmt_4_four_levels(hip_lib, hip_glib):
     fc.check_compiled(hip_lib, hip_glib, "vsmt_4_l4", batch=2, unfold=4)
 
 
+def test_compiled_mimc_322_rounds(hip_lib, hip_glib):
+    # config 5's preimage half: MiMC-322, n = 644, N = 1024 (per-proof image => one circuit, batch of 1)
+    fc.check_compiled(hip_lib, hip_glib, "mimc", batch=1, unfold=4)
+    fc.check_prove_verify_roundtrip(hip_lib, hip_glib, "mimc", batch=1)
+
+
 def test_prover_single_host_synthesis(hip_glib):
     fc.check_prove_single(hip_glib, "bound_check")
     fc.check_prove_single(hip_glib, "poseidon_hash_2_cube")
