@@ -45,7 +45,7 @@ struct bpr1cs_gens {
     uint32_t cap = 0;
     TabCfg tc{};             // fixed-base table geometry (window bits chosen at creation)
     DevBuf<ge> pts;          // [2 + 2cap] : B, B~, G.., H..
-    DevBuf<ge_niels> tab;    // [(2+2cap) * 4096]
+    DevBuf<ge_niels_packed> tab;  // [(2+2cap) * windows * entries], 96 B per entry
     std::vector<uint8_t> comp;  // compressed, host copy
     dev_stream_t stream{};   // setup / synchronous helpers
     // two stream pairs so that two prove jobs can be in flight (cross-batch pipelining);

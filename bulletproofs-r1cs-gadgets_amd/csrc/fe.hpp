@@ -1,38 +1,49 @@
 // Field arithmetic mod p = 2^255 - 19 for gfx950 (CDNA4).
 //
-// Representation: 8 saturated 32-bit limbs, little-endian, value in [0, 2^256),
-// congruent to the element mod p (lazy reduction: 2^256 == 38 mod p).  Chosen
-// for the 32-bit VALU: one field element = 8 VGPRs, a product = 64
-// v_mad_u64_u32; canonicalisation happens only in fe_tobytes / comparisons.
+// Representation: 9 SIGNED limbs of 29 bits, value = sum v[k] * 2^(29k) (mod p); limbs are not
+// canonical.  Why: on gfx950 the carry-propagating instructions (v_add_co / v_addc_co /
+// v_lshl_add_u64) cost as much as v_mad_u64_u32, and the saturated 8x32 form needs one of them per
+// limb product plus ~2.5 register moves (180 of the 316 instructions of the 8x32 fe_mul were
+// v_mov).  With 29-bit limbs the 81 limb products of a multiplication accumulate in 64-bit column
+// sums with NO carry handling (v_mad_i64_i32 chains), and add / sub / neg are 9 independent 32-bit ops.
 //
-// Replaces (for the hot path) curve25519-dalek's FieldElement51
-// (reference Cargo.toml:8).
+// Bound discipline ("N" = 2^28 + 2^23):
+//   * fe_mul / fe_sq / fe_carry results have |limb| <= N (centred remainders).
+//   * fe_add / fe_sub / fe_neg are limb-wise and do not normalise.
+//   * fe_mul accepts inputs with |limb| <= 4N provided |a|max * |b|max * 9 < 2^63 - every product in
+//     ge.hpp is one of N*N, 2N*2N, 2N*3N, 3N*3N, 3N*4N, 2N*4N (see the comments there);
+//     fe_sq accepts |limb| <= 2N.
+//   * values unpacked from canonical bytes have limbs in [0, 2^29) (class 2N).
+//
+// Replaces (for the hot path) curve25519-dalek's FieldElement51 (reference Cargo.toml:8).
 #pragma once
 #include <stdint.h>
 #include "hd.hpp"
 
 struct fe {
-    uint32_t v[8];
+    int32_t v[9];
 };
 
-HD_CONST uint32_t FE_D_L[8] = {0x135978a3u, 0x75eb4dcau, 0x4141d8abu, 0x00700a4du, 0x7779e898u, 0x8cc74079u, 0x2b6ffe73u, 0x52036ceeu};
-HD_CONST uint32_t FE_2D_L[8] = {0x26b2f159u, 0xebd69b94u, 0x8283b156u, 0x00e0149au, 0xeef3d130u, 0x198e80f2u, 0x56dffce7u, 0x2406d9dcu};
-HD_CONST uint32_t FE_SQRT_M1_L[8] = {0x4a0ea0b0u, 0xc4ee1b27u, 0xad2fe478u, 0x2f431806u, 0x3dfbd7a7u, 0x2b4d0099u, 0x4fc1df0bu, 0x2b832480u};
-HD_CONST uint32_t FE_INVSQRT_A_MINUS_D_L[8] = {0x805d40eau, 0x99c8fdaau, 0x5a4172beu, 0x9d2f1617u, 0xfe01d840u, 0x16c27b91u, 0xcfaffca2u, 0x786c8905u};
-HD_CONST uint32_t FE_ONE_MINUS_D_SQ_L[8] = {0x945fc176u, 0xe27c09c1u, 0xcd5e350fu, 0x2c81a138u, 0xbe70dfe4u, 0x9994abddu, 0xb2b3e0d7u, 0x029072a8u};
-HD_CONST uint32_t FE_D_MINUS_ONE_SQ_L[8] = {0x44ed4d20u, 0x31ad5aaau, 0xb01e1999u, 0xd29e4a2cu, 0x529b4eebu, 0x4cdcd32fu, 0xf66c2241u, 0x5968b37au};
-HD_CONST uint32_t FE_SQRT_AD_MINUS_ONE_L[8] = {0x497b2e1bu, 0x7e97f6a0u, 0x1b7854bdu, 0xaf9d8e0cu, 0x31f5d1fdu, 0x0f3cfcc9u, 0x2b8348acu, 0x376931bfu};
+#define FE_MASK 0x1fffffff
 
-HD inline fe fe_const(const uint32_t* l) {
+HD_CONST int32_t FE_D_L[9] = {324630691, 257584720, 276179677, 1350274, 512327687, 3980220, 432943901, 499478015, 5374828};
+HD_CONST int32_t FE_2D_L[9] = {112390489, 515169441, 15488442, 2700549, 487784462, 7960441, 329016890, 462085119, 2361049};
+HD_CONST int32_t FE_SQRT_M1_L[9] = {168730800, 124836154, 200875569, 103812442, 494564084, 5021437, 472689972, 269088827, 2851620};
+HD_CONST int32_t FE_INVSQRT_A_MINUS_D_L[9] = {6111466, 239594836, 274509734, 506212020, 495192530, 499711744, 310926089, 12187135, 7892105};
+HD_CONST int32_t FE_ONE_MINUS_D_SQ_L[9] = {341819766, 333467148, 395133944, 54686106, 234767048, 367976248, 56518226, 353785468, 168050};
+HD_CONST int32_t FE_D_MINUS_ONE_SQ_L[9] = {82660640, 225105234, 126248524, 479484256, 351190313, 160934221, 151335795, 257871236, 5859507};
+HD_CONST int32_t FE_SQRT_AD_MINUS_ONE_L[9] = {159067675, 348108034, 504704863, 454826038, 488626937, 509909242, 45104371, 400912489, 3631409};
+
+HD inline fe fe_const(const int32_t* l) {
     fe r;
 #pragma unroll
-    for (int i = 0; i < 8; i++) r.v[i] = l[i];
+    for (int i = 0; i < 9; i++) r.v[i] = l[i];
     return r;
 }
 HD inline fe fe_zero() {
     fe r;
 #pragma unroll
-    for (int i = 0; i < 8; i++) r.v[i] = 0;
+    for (int i = 0; i < 9; i++) r.v[i] = 0;
     return r;
 }
 HD inline fe fe_one() {
@@ -40,156 +51,89 @@ HD inline fe fe_one() {
     r.v[0] = 1;
     return r;
 }
-
-// 32-bit add/sub with carry: clang lowers the builtins to v_add_co/v_addc_co chains (the u64
-// formulation compiles to ~3x as many instructions on gfx950); g++ (host simulator) uses u64.
-HD inline uint32_t addc32(uint32_t a, uint32_t b, uint32_t cin, uint32_t& cout) {
-#if defined(__clang__)
-    unsigned co;
-    uint32_t r = __builtin_addc(a, b, cin, &co);
-    cout = co;
-    return r;
-#else
-    uint64_t t = (uint64_t)a + b + cin;
-    cout = (uint32_t)(t >> 32);
-    return (uint32_t)t;
-#endif
-}
-HD inline uint32_t subc32(uint32_t a, uint32_t b, uint32_t bin, uint32_t& bout) {
-#if defined(__clang__)
-    unsigned bo;
-    uint32_t r = __builtin_subc(a, b, bin, &bo);
-    bout = bo;
-    return r;
-#else
-    uint64_t t = (uint64_t)a - b - bin;
-    bout = (uint32_t)(t >> 63);
-    return (uint32_t)t;
-#endif
-}
-
 HD inline fe fe_add(const fe& a, const fe& b) {
     fe r;
-    uint32_t c = 0;
 #pragma unroll
-    for (int i = 0; i < 8; i++) r.v[i] = addc32(a.v[i], b.v[i], c, c);
-    // 2^256 == 38: fold the carry; a second wrap leaves r < 38 so the last add cannot carry
-    r.v[0] = addc32(r.v[0], c * 38u, 0, c);
-#pragma unroll
-    for (int i = 1; i < 8; i++) r.v[i] = addc32(r.v[i], 0, c, c);
-    r.v[0] += 38u * c;
+    for (int i = 0; i < 9; i++) r.v[i] = a.v[i] + b.v[i];
     return r;
 }
-
 HD inline fe fe_sub(const fe& a, const fe& b) {
     fe r;
-    uint32_t c = 0;
 #pragma unroll
-    for (int i = 0; i < 8; i++) r.v[i] = subc32(a.v[i], b.v[i], c, c);
-    // a borrow means +2^256 was added: subtract 38; a second borrow leaves r >= 2^256-38
-    r.v[0] = subc32(r.v[0], c * 38u, 0, c);
+    for (int i = 0; i < 9; i++) r.v[i] = a.v[i] - b.v[i];
+    return r;
+}
+HD inline fe fe_neg(const fe& a) {
+    fe r;
 #pragma unroll
-    for (int i = 1; i < 8; i++) r.v[i] = subc32(r.v[i], 0, c, c);
-    r.v[0] -= 38u * c;
+    for (int i = 0; i < 9; i++) r.v[i] = -a.v[i];
     return r;
 }
 
-HD inline fe fe_neg(const fe& a) { return fe_sub(fe_zero(), a); }
-
-// r = lo + 38*hi for a 16-limb product t
-HD inline fe fe_reduce512(const uint32_t* t) {
+// 17 centred column remainders t[0..16] + final carry t17 -> 9 centred limbs; 2^261 == 1216 (mod p)
+HD inline fe fe_fold18(const int32_t* t, int64_t t17) {
     fe r;
-    uint64_t c = 0;
+    int64_t c = 0;
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-        c += (uint64_t)t[i] + (uint64_t)t[8 + i] * 38u;
-        r.v[i] = (uint32_t)c;
-        c >>= 32;
+    for (int k = 0; k < 9; k++) {
+        int64_t hi = (k < 8) ? (int64_t)t[k + 9] : t17;
+        int64_t acc = (int64_t)t[k] + hi * 1216 + c;
+        c = (acc + (1 << 28)) >> 29;
+        r.v[k] = (int32_t)(acc - c * 536870912LL);
     }
-    c *= 38;  // c <= 38 -> <= 1444
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-        c += r.v[i];
-        r.v[i] = (uint32_t)c;
-        c >>= 32;
-    }
-    r.v[0] += 38u * (uint32_t)c;
+    r.v[0] += (int32_t)(c * 1216);  // |c| < 2^13
     return r;
 }
 
 HD inline fe fe_mul(const fe& a, const fe& b) {
-    uint32_t t[16];
+    int32_t t[17];
+    int64_t c = 0;
 #pragma unroll
-    for (int i = 0; i < 16; i++) t[i] = 0;
+    for (int k = 0; k < 17; k++) {
+        int64_t acc = c;
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-        uint64_t c = 0;
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            c += (uint64_t)a.v[i] * b.v[j] + t[i + j];
-            t[i + j] = (uint32_t)c;
-            c >>= 32;
+        for (int i = 0; i < 9; i++) {
+            int j = k - i;
+            if (j >= 0 && j < 9) acc += (int64_t)a.v[i] * b.v[j];
         }
-        t[i + 8] = (uint32_t)c;
+        c = (acc + (1 << 28)) >> 29;
+        t[k] = (int32_t)(acc - c * 536870912LL);
     }
-    return fe_reduce512(t);
+    return fe_fold18(t, c);
 }
 
-// dedicated squaring: 28 cross products (doubled) + 8 squares instead of 64 products
 HD inline fe fe_sq(const fe& a) {
-    uint32_t t[16];
+    int32_t d[9];
 #pragma unroll
-    for (int i = 0; i < 16; i++) t[i] = 0;
-    // cross products a_i*a_j, i<j
+    for (int i = 0; i < 9; i++) d[i] = 2 * a.v[i];
+    int32_t t[17];
+    int64_t c = 0;
 #pragma unroll
-    for (int i = 0; i < 7; i++) {
-        uint64_t c = 0;
+    for (int k = 0; k < 17; k++) {
+        int64_t acc = c;
 #pragma unroll
-        for (int j = i + 1; j < 8; j++) {
-            c += (uint64_t)a.v[i] * a.v[j] + t[i + j];
-            t[i + j] = (uint32_t)c;
-            c >>= 32;
+        for (int i = 0; i < 9; i++) {
+            int j = k - i;
+            if (j > i && j < 9) acc += (int64_t)d[i] * a.v[j];
         }
-        t[i + 8] = (uint32_t)c;
+        if ((k & 1) == 0) acc += (int64_t)a.v[k >> 1] * a.v[k >> 1];
+        c = (acc + (1 << 28)) >> 29;
+        t[k] = (int32_t)(acc - c * 536870912LL);
     }
-    // double, then add the squares
-    uint32_t top = 0;
-#pragma unroll
-    for (int i = 1; i < 16; i++) {
-        uint32_t nt = t[i] >> 31;
-        t[i] = (t[i] << 1) | top;
-        top = nt;
-    }
-    uint64_t c = 0;
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-        c += (uint64_t)a.v[i] * a.v[i] + t[2 * i];
-        t[2 * i] = (uint32_t)c;
-        c >>= 32;
-        c += t[2 * i + 1];
-        t[2 * i + 1] = (uint32_t)c;
-        c >>= 32;
-    }
-    return fe_reduce512(t);
+    return fe_fold18(t, c);
 }
 
-HD inline fe fe_mul_small(const fe& a, uint32_t k) {  // k < 2^26
+// normalise to centred limbs (|limb| <= N) without changing the value mod p
+HD inline fe fe_carry(const fe& a) {
     fe r;
-    uint64_t c = 0;
+    int64_t c = 0;
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-        c += (uint64_t)a.v[i] * k;
-        r.v[i] = (uint32_t)c;
-        c >>= 32;
+    for (int k = 0; k < 9; k++) {
+        int64_t acc = (int64_t)a.v[k] + c;
+        c = (acc + (1 << 28)) >> 29;
+        r.v[k] = (int32_t)(acc - c * 536870912LL);
     }
-    c *= 38;
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-        c += r.v[i];
-        r.v[i] = (uint32_t)c;
-        c >>= 32;
-    }
-    r.v[0] += 38u * (uint32_t)c;
+    r.v[0] += (int32_t)(c * 1216);
     return r;
 }
 
@@ -221,55 +165,68 @@ HD inline void fe_pow22501(const fe& z, fe& t19, fe& t3) {
     fe t18 = fe_sqn(t17, 50);
     t19 = fe_mul(t18, t13);           // 2^250-1
 }
-
-HD inline fe fe_invert(const fe& z) {
+HD inline fe fe_invert(const fe& z0) {  // any input class: normalise first
+    fe z = fe_carry(z0);
     fe t19, t3;
     fe_pow22501(z, t19, t3);
     return fe_mul(fe_sqn(t19, 5), t3);  // 2^255-21
 }
-
-HD inline fe fe_pow22523(const fe& z) {  // z^((p-5)/8) = z^(2^252-3)
+HD inline fe fe_pow22523(const fe& z0) {  // z^((p-5)/8) = z^(2^252-3)
+    fe z = fe_carry(z0);
     fe t19, t3;
     fe_pow22501(z, t19, t3);
     return fe_mul(fe_sqn(t19, 2), z);
 }
 
-// canonical little-endian bytes
+// canonical value as 8 little-endian 32-bit words
 HD inline void fe_canon(const fe& a, uint32_t out[8]) {
-    uint32_t r[8];
-    // fold bit 255 twice -> value < 2^255 + small
-    uint64_t c = (uint64_t)(a.v[7] >> 31) * 19u;
-    uint32_t top = a.v[7] & 0x7fffffffu;
+    // 1) non-negative 29-bit limbs (floor carries), top carry folded with 1216; three passes suffice
+    int64_t l[10];
 #pragma unroll
-    for (int i = 0; i < 7; i++) {
-        c += a.v[i];
-        r[i] = (uint32_t)c;
-        c >>= 32;
+    for (int k = 0; k < 9; k++) l[k] = a.v[k];
+    l[9] = 0;
+    for (int pass = 0; pass < 3; pass++) {
+        int64_t c = 0;
+#pragma unroll
+        for (int k = 0; k < 9; k++) {
+            int64_t acc = l[k] + c;
+            c = acc >> 29;  // floor
+            l[k] = acc & FE_MASK;
+        }
+        l[0] += c * 1216;  // congruent; in the last pass c == 0 for every reachable input
     }
-    c += top;
-    r[7] = (uint32_t)c;
-    // r < 2^255 + 19 ; r[7] may have bit 31 set again
-    c = (uint64_t)(r[7] >> 31) * 19u;
-    r[7] &= 0x7fffffffu;
+    // 2) value < 2^261 + small: fold bits >= 255 (limb 8 holds bits 232..260) twice
+    for (int pass = 0; pass < 2; pass++) {
+        int64_t c = (l[8] >> 23) * 19;
+        l[8] &= (1 << 23) - 1;
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-        c += r[i];
-        r[i] = (uint32_t)c;
-        c >>= 32;
+        for (int k = 0; k < 9; k++) {
+            int64_t acc = l[k] + c;
+            c = acc >> 29;
+            l[k] = acc & FE_MASK;
+        }
     }
-    // now r < 2^255; subtract p if r >= p  <=> r + 19 >= 2^255
-    uint32_t s[8];
-    c = 19;
+    // 3) 0 <= value < 2^255: conditional subtract p  <=>  value + 19 >= 2^255
+    int64_t s[9], c = 19;
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-        c += r[i];
-        s[i] = (uint32_t)c;
-        c >>= 32;
+    for (int k = 0; k < 9; k++) {
+        int64_t acc = l[k] + c;
+        c = acc >> 29;
+        s[k] = acc & FE_MASK;
     }
-    uint32_t ge = s[7] >> 31;  // 1 if r >= p
-    s[7] &= 0x7fffffffu;
+    int ge = (int)(s[8] >> 23) & 1;
+    s[8] &= (1 << 23) - 1;
 #pragma unroll
-    for (int i = 0; i < 8; i++) out[i] = ge ? s[i] : r[i];
+    for (int k = 0; k < 9; k++) l[k] = ge ? s[k] : l[k];
+    // 4) 9x29 -> 8x32
+#pragma unroll
+    for (int w = 0; w < 8; w++) {
+        int bit = 32 * w, i = bit / 29, sh = bit % 29;
+        uint64_t acc = (uint64_t)l[i] >> sh;
+        acc |= (uint64_t)l[i + 1] << (29 - sh);
+        if (58 - sh < 32) acc |= (uint64_t)l[i + 2] << (58 - sh);
+        out[w] = (uint32_t)acc;
+    }
 }
 
 HD inline void fe_tobytes(const fe& a, uint8_t* b) {
@@ -284,13 +241,24 @@ HD inline void fe_tobytes(const fe& a, uint8_t* b) {
     }
 }
 
-// raw 256-bit load (bit 255 kept; callers mask when the format demands it)
-HD inline fe fe_frombytes(const uint8_t* b) {
+// 8 x 32-bit little-endian words (the full 256-bit value) -> limbs in [0, 2^29)
+HD inline fe fe_fromwords(const uint32_t* w) {
     fe r;
 #pragma unroll
-    for (int i = 0; i < 8; i++)
-        r.v[i] = (uint32_t)b[4 * i] | ((uint32_t)b[4 * i + 1] << 8) | ((uint32_t)b[4 * i + 2] << 16) | ((uint32_t)b[4 * i + 3] << 24);
+    for (int i = 0; i < 9; i++) {
+        int bit = 29 * i, wi = bit >> 5, sh = bit & 31;
+        uint64_t lo = w[wi], hi = (wi + 1 < 8) ? w[wi + 1] : 0;
+        r.v[i] = (int32_t)((((hi << 32) | lo) >> sh) & FE_MASK);
+    }
     return r;
+}
+// raw 256-bit load (bit 255 kept; callers mask when the format demands it)
+HD inline fe fe_frombytes(const uint8_t* b) {
+    uint32_t w[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+        w[i] = (uint32_t)b[4 * i] | ((uint32_t)b[4 * i + 1] << 8) | ((uint32_t)b[4 * i + 2] << 16) | ((uint32_t)b[4 * i + 3] << 24);
+    return fe_fromwords(w);
 }
 
 HD inline int fe_is_negative(const fe& a) {
@@ -311,13 +279,14 @@ HD inline int fe_eq(const fe& a, const fe& b) { return fe_is_zero(fe_sub(a, b));
 HD inline fe fe_select(const fe& a, const fe& b, int pick_b) {
     fe r;
 #pragma unroll
-    for (int i = 0; i < 8; i++) r.v[i] = pick_b ? b.v[i] : a.v[i];
+    for (int i = 0; i < 9; i++) r.v[i] = pick_b ? b.v[i] : a.v[i];
     return r;
 }
 HD inline fe fe_abs(const fe& a) { return fe_select(a, fe_neg(a), fe_is_negative(a)); }
 
-// RFC 9496 SQRT_RATIO_M1: returns was_square, r = |sqrt(u/v)| or |sqrt(i*u/v)|
-HD inline int fe_sqrt_ratio_m1(const fe& u, const fe& v, fe& r_out) {
+// RFC 9496 SQRT_RATIO_M1: returns was_square, r = |sqrt(u/v)| or |sqrt(i*u/v)|  (inputs of any class)
+HD inline int fe_sqrt_ratio_m1(const fe& u0, const fe& v0, fe& r_out) {
+    fe u = fe_carry(u0), v = fe_carry(v0);
     fe v3 = fe_mul(fe_sq(v), v);
     fe v7 = fe_mul(fe_sq(v3), v);
     fe r = fe_mul(fe_mul(u, v3), fe_pow22523(fe_mul(u, v7)));

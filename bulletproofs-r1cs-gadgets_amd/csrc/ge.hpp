@@ -18,6 +18,29 @@ struct ge_niels {    // affine Niels: (y+x, y-x, 2dxy), Z = 1
 struct ge_cached {   // projective Niels: (Y+X, Y-X, Z, 2dT)
     fe YplusX, YminusX, Z, T2d;
 };
+// table storage form of an affine Niels point: 3 x 32 canonical little-endian bytes (96 B per entry)
+struct ge_niels_packed {
+    uint32_t w[24];
+};
+HD inline ge_niels_packed ge_niels_pack(const ge_niels& n) {
+    ge_niels_packed p;
+    fe_canon(n.yplusx, p.w);
+    fe_canon(n.yminusx, p.w + 8);
+    fe_canon(n.xy2d, p.w + 16);
+    return p;
+}
+HD inline ge_niels ge_niels_unpack(const ge_niels_packed& p) {  // limbs in [0, 2^29)
+    ge_niels n;
+    n.yplusx = fe_fromwords(p.w);
+    n.yminusx = fe_fromwords(p.w + 8);
+    n.xy2d = fe_fromwords(p.w + 16);
+    return n;
+}
+// Limb-bound bookkeeping of the formulas below (N = bound of a product, see fe.hpp):
+//   point coordinates X,Y,Z,T are products (N); table / cached operands are sums or unpacked bytes (2N);
+//   add:  (Y+X)*(..)=2N*2N, T*T2d=N*2N, cX,cY=2N, cZ,cT=3N  -> 2N*3N, 3N*3N
+//   dbl:  sq(X+Y)=sq(2N), cX=3N, cY=cZ=2N, cT=4N            -> 3N*4N (2^62.9 < 2^63), 2N*4N
+// all within the 9 * |a| * |b| < 2^63 budget of fe_mul.
 
 HD inline ge ge_identity() {
     ge r;
@@ -184,11 +207,11 @@ HD inline ge ge_from_uniform_bytes(const uint8_t b[64]) {
     return ge_add_ge(p1, p2);
 }
 
-HD_CONST uint32_t GE_BX_L[8] = {0x8f25d51au, 0xc9562d60u, 0x9525a7b2u, 0x692cc760u, 0xfdd6dc5cu, 0xc0a4e231u, 0xcd6e53feu, 0x216936d3u};
-HD_CONST uint32_t GE_BY_L[8] = {0x66666658u, 0x66666666u, 0x66666666u, 0x66666666u, 0x66666666u, 0x66666666u, 0x66666666u, 0x66666666u};
-HD_CONST uint32_t GE_BT_L[8] = {0xa5b7dda3u, 0x6dde8ab3u, 0x775152f5u, 0x20f09f80u, 0x64abe37du, 0x66ea4e8eu, 0xd78b7665u, 0x67875f0fu};
-HD inline ge ge_basepoint() {
+HD_CONST int32_t GE_BX_L[9] = {254137626, 179399428, 157936818, 428785962, 231065234, 286850795, 268108435, 444181962, 2189622};
+HD_CONST int32_t GE_BY_L[9] = {107374168, 322122547, 429496729, 214748364, 107374182, 322122547, 429496729, 214748364, 6710886};
+HD_CONST int32_t GE_BT_L[9] = {95935907, 250893725, 341097819, 20906222, 506974735, 122106453, 429235113, 33223022, 6784863};
+HD inline ge ge_basepoint() {  // coordinates normalised to the centred limb class the formulas expect
     ge r;
-    r.X = fe_const(GE_BX_L); r.Y = fe_const(GE_BY_L); r.Z = fe_one(); r.T = fe_const(GE_BT_L);
+    r.X = fe_carry(fe_const(GE_BX_L)); r.Y = fe_carry(fe_const(GE_BY_L)); r.Z = fe_one(); r.T = fe_carry(fe_const(GE_BT_L));
     return r;
 }

@@ -48,7 +48,7 @@ HD inline TabCfg tab_cfg(uint32_t W) {
 
 // ------------------------------------------------------------ fixed-base core
 // acc += s * Base, s canonical (< l).  Signed W-bit digits.
-HD inline ge table_mul_acc(ge acc, const ge_niels* tbase, const sc& s, const TabCfg& tc) {
+HD inline ge table_mul_acc(ge acc, const ge_niels_packed* tbase, const sc& s, const TabCfg& tc) {
     int carry = 0;
     const int half = 1 << (tc.W - 1);
     for (uint32_t k = 0; k < tc.windows; k++) {
@@ -60,7 +60,7 @@ HD inline ge table_mul_acc(ge acc, const ge_niels* tbase, const sc& s, const Tab
         if (d != 0) {
             int neg = d < 0;
             int mag = neg ? -d : d;
-            acc = ge_madd(acc, tbase[(size_t)k * tc.entries + mag - 1], neg);
+            acc = ge_madd(acc, ge_niels_unpack(tbase[(size_t)k * tc.entries + mag - 1]), neg);
         }
     }
     return acc;
@@ -121,7 +121,7 @@ struct K_gen_points {  // uniform[cnt][64] -> pts[cnt]
 
 struct K_build_table {  // gid = base*windows + k
     const ge* pts;
-    ge_niels* tab;
+    ge_niels_packed* tab;
     TabCfg tc;
     HD void operator()(uint32_t g) const {
         uint32_t base = g / tc.windows, k = g % tc.windows;
@@ -129,7 +129,7 @@ struct K_build_table {  // gid = base*windows + k
         for (uint32_t t = 0; t < tc.W * k; t++) P = ge_dbl(P);
         ge_cached c = ge_to_cached(P);
         ge acc = P;
-        ge_niels* out = tab + (size_t)g * tc.entries;
+        ge_niels_packed* out = tab + (size_t)g * tc.entries;
         // affine normalisation with Montgomery's trick, 16 entries per field inversion
         const int CH = 16;
         for (uint32_t j0 = 0; j0 < tc.entries; j0 += CH) {
@@ -149,7 +149,7 @@ struct K_build_table {  // gid = base*windows + k
                 e.yplusx = fe_add(y, x);
                 e.yminusx = fe_sub(y, x);
                 e.xy2d = fe_mul(fe_mul(x, y), fe_const(FE_2D_L));
-                out[j0 + t] = e;
+                out[j0 + t] = ge_niels_pack(e);
             }
         }
     }
@@ -168,7 +168,7 @@ struct K_load_inputs {  // canonical v, vbl [m][B] -> Montgomery copies
 };
 
 struct K_commit_v {  // gid = j*B + b : V = v*B + vbl*B~   (Prover::commit, P1)
-    const ge_niels* tab;
+    const ge_niels_packed* tab;
     TabCfg tc;
     const sc* v_raw;
     const sc* vbl_raw;
@@ -360,7 +360,7 @@ struct MsmSeg {
     uint32_t count, run, period, off, base0, mont;
 };
 struct K_msm_fixed {  // gid = c*B + b -> partial[c*B + b]
-    const ge_niels* tab;
+    const ge_niels_packed* tab;
     TabCfg tc;
     MsmSeg seg[2];
     ge* partial;
@@ -383,7 +383,7 @@ struct K_msm_fixed {  // gid = c*B + b -> partial[c*B + b]
 };
 // sum of partials + extra*Base(extra_base) -> compressed (and optional extended copy)
 struct K_msm_finish {  // gid = b
-    const ge_niels* tab;
+    const ge_niels_packed* tab;
     TabCfg tc;
     const ge* partial;    // [nchunks][B]
     const sc* extra;      // [B] Montgomery, may be null
@@ -464,7 +464,7 @@ struct K_sum_partials {  // gid = k*B + b : out[k][b] = sum_c part[k][c][b]
 };
 
 struct K_commit_T {  // gid = k*B + b, k<5 : T = t*B + tau*B~  (t1,t3,t4,t5,t6)
-    const ge_niels* tab;
+    const ge_niels_packed* tab;
     TabCfg tc;
     const sc* tco;    // [6][B]
     const sc* blind;  // [8][B]
@@ -645,7 +645,7 @@ struct K_ipa_update_c {  // gid = i*B + b, i<N : fold factors of the original ge
 };
 // materialise the folded generators of round r straight from the tables
 struct K_ipa_fold_from_tables {  // gid = (side*M + j)*B + b
-    const ge_niels* tab;
+    const ge_niels_packed* tab;
     TabCfg tc;
     const sc* cG;
     const sc* cH;
@@ -960,7 +960,7 @@ struct K_verify_points {  // gid = p*B + b, p < 8 + m + 2 lgN
     }
 };
 struct K_verify_finish {  // gid = b : sum everything, accept iff identity
-    const ge_niels* tab;
+    const ge_niels_packed* tab;
     TabCfg tc;
     const ge* msm_partial;  // [nchunks][B]
     const ge* pts;          // [P][B]

@@ -74,3 +74,21 @@ void hs_merlin_script(const uint8_t* label, uint32_t ll, const uint8_t* msgs, ui
 }
 extern "C" void hs_sc_inv_fermat(const uint8_t* a, uint8_t* o) { sc_mont_tobytes(sc_invert_fermat(sc_mont_from_bytes_mod_order(a)), o); }
 extern "C" void hs_fe_sq(const uint8_t* a, uint8_t* o) { fe_tobytes(fe_sq(fe_frombytes(a)), o); }
+// limb-level entry points: the caller supplies raw (non-canonical, signed) 29-bit limbs so that the
+// worst-case bound classes documented in fe.hpp / ge.hpp can be exercised directly
+static fe fe_from_limbs(const int32_t* l) { fe r; for (int i = 0; i < 9; i++) r.v[i] = l[i]; return r; }
+extern "C" void hs_fe_mul_limbs(const int32_t* a, const int32_t* b, uint8_t* o, int32_t* out_limbs) {
+    fe r = fe_mul(fe_from_limbs(a), fe_from_limbs(b));
+    for (int i = 0; i < 9; i++) out_limbs[i] = r.v[i];
+    fe_tobytes(r, o);
+}
+extern "C" void hs_fe_sq_limbs(const int32_t* a, uint8_t* o, int32_t* out_limbs) {
+    fe r = fe_sq(fe_from_limbs(a));
+    for (int i = 0; i < 9; i++) out_limbs[i] = r.v[i];
+    fe_tobytes(r, o);
+}
+extern "C" void hs_fe_canon_limbs(const int32_t* a, uint8_t* o) { fe_tobytes(fe_from_limbs(a), o); }
+extern "C" void hs_fe_carry_limbs(const int32_t* a, int32_t* out_limbs) {
+    fe r = fe_carry(fe_from_limbs(a));
+    for (int i = 0; i < 9; i++) out_limbs[i] = r.v[i];
+}

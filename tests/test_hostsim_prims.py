@@ -70,3 +70,48 @@ def test_merlin_transcript_and_rng(prim_lib):
     rng = b.finalize(seed)
     assert dr.raw == b"".join(sc_to_bytes(rng.random_scalar()) for _ in range(300))
     assert ch.raw == sc_to_bytes(t.challenge_scalar(b"y"))
+
+
+def test_field_limb_bounds(prim_lib):
+    """9x29 signed-limb field (csrc/fe.hpp): worst-case limb classes of every product shape used in ge.hpp
+    (N*N, 2N*2N, 2N*3N, 3N*3N, 3N*4N, 2N*4N; squares up to 2N) stay exact and return limbs within N."""
+    import ctypes, random
+    P = 2**255 - 19
+    N = 2**28 + 2**23
+    I9 = ctypes.c_int32 * 9
+    rnd = random.Random(29)
+
+    def val(l):
+        return sum(int(x) << (29 * i) for i, x in enumerate(l)) % P
+
+    def patterns(bound):
+        yield [bound] * 9
+        yield [-bound] * 9
+        yield [bound if i % 2 else -bound for i in range(9)]
+        yield [-bound if i % 2 else bound for i in range(9)]
+        for _ in range(40):
+            yield [rnd.choice((bound, -bound, rnd.randint(-bound, bound))) for _ in range(9)]
+
+    out = (ctypes.c_uint8 * 32)()
+    ol = I9()
+    for ka, kb in ((1, 1), (2, 2), (2, 3), (3, 3), (3, 4), (2, 4), (4, 1)):
+        for a in patterns(ka * N):
+            for b in list(patterns(kb * N))[:12]:
+                prim_lib.hs_fe_mul_limbs(I9(*a), I9(*b), out, ol)
+                assert int.from_bytes(bytes(out), "little") == val(a) * val(b) % P
+                assert max(abs(x) for x in ol) <= N
+    for a in patterns(2 * N):
+        prim_lib.hs_fe_sq_limbs(I9(*a), out, ol)
+        assert int.from_bytes(bytes(out), "little") == val(a) ** 2 % P
+        assert max(abs(x) for x in ol) <= N
+    for k in (1, 2, 3, 4, 7):
+        for a in patterns(k * N):
+            prim_lib.hs_fe_canon_limbs(I9(*a), out)
+            assert int.from_bytes(bytes(out), "little") == val(a)
+            prim_lib.hs_fe_carry_limbs(I9(*a), ol)
+            assert val(list(ol)) == val(a) and max(abs(x) for x in ol) <= N
+    # canonical edge values
+    for v in (0, 1, 19, P - 1, P, P + 1, 2**255 - 1, 2**255, 2**256 - 1):
+        limbs = [(v >> (29 * i)) & (2**29 - 1) for i in range(9)]
+        prim_lib.hs_fe_canon_limbs(I9(*limbs), out)
+        assert int.from_bytes(bytes(out), "little") == v % P
