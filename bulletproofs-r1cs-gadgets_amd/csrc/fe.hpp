@@ -8,7 +8,7 @@
 // sums with NO carry handling (v_mad_i64_i32 chains), and add / sub / neg are 9 independent 32-bit ops.
 //
 // Bound discipline ("N" = 2^28 + 2^23):
-//   * fe_mul / fe_sq / fe_carry results have |limb| <= N (centred remainders).
+//   * fe_mul / fe_sq / fe_carry results have |limb| <= N (centred remainders; limb 0 takes the wrapped carry).
 //   * fe_add / fe_sub / fe_neg are limb-wise and do not normalise.
 //   * fe_mul accepts inputs with |limb| <= 4N provided |a|max * |b|max * 9 < 2^63 - every product in
 //     ge.hpp is one of N*N, 2N*2N, 2N*3N, 3N*3N, 3N*4N, 2N*4N (see the comments there);
@@ -70,46 +70,59 @@ HD inline fe fe_neg(const fe& a) {
     return r;
 }
 
-// 17 centred column remainders t[0..16] + final carry t17 -> 9 centred limbs; 2^261 == 1216 (mod p)
-HD inline fe fe_fold18(const int32_t* t, int64_t t17) {
-    fe r;
-    int64_t c = 0;
-#pragma unroll
-    for (int k = 0; k < 9; k++) {
-        int64_t hi = (k < 8) ? (int64_t)t[k + 9] : t17;
-        int64_t acc = (int64_t)t[k] + hi * 1216 + c;
-        c = (acc + (1 << 28)) >> 29;
-        r.v[k] = (int32_t)(acc - c * 536870912LL);
-    }
-    r.v[0] += (int32_t)(c * 1216);  // |c| < 2^13
-    return r;
-}
+// Product a*b = sum_k S_k 2^(29k), S_k = sum_{i+j=k} a_i b_j, reduced with 2^261 == 1216 (mod p) in two
+// carry passes that never materialise a separate "fold" step:
+//   pass 1: columns 8..16 with FLOOR carries -> remainders t8..t16 in [0,2^29) and the top carry t17 (fits
+//           int32: |S_16| < 2^60);
+//   pass 2: columns 0..7 get 1216*t[k+9] as one more v_mad_i64_i32 of their accumulation chain; column 8 is
+//           t8 + 1216*t17; carries are centred so the result limbs are in [-2^28, 2^28); the carry out of
+//           column 8 is < 2^13 and wraps into limb 0 (again x1216).
+// Cost: 90 v_mad_i64_i32 + 18 carry steps (pass 1: shift+mask, pass 2: add+shift+mask+sub).
+#define FE_COLUMN_TAIL_FLOOR(acc, c, t) { c = (acc) >> 29; t = (int32_t)((uint32_t)(acc) & FE_MASK); }
+#define FE_COLUMN_TAIL_ROUND(acc, c, t) { int64_t x_ = (acc) + (1 << 28); c = x_ >> 29; t = (int32_t)((uint32_t)x_ & FE_MASK) - (1 << 28); }
 
 HD inline fe fe_mul(const fe& a, const fe& b) {
-    int32_t t[17];
+    int32_t t[18];
     int64_t c = 0;
 #pragma unroll
-    for (int k = 0; k < 17; k++) {
+    for (int k = 8; k < 17; k++) {
         int64_t acc = c;
 #pragma unroll
         for (int i = 0; i < 9; i++) {
             int j = k - i;
             if (j >= 0 && j < 9) acc += (int64_t)a.v[i] * b.v[j];
         }
-        c = (acc + (1 << 28)) >> 29;
-        t[k] = (int32_t)(acc - c * 536870912LL);
+        FE_COLUMN_TAIL_FLOOR(acc, c, t[k]);
     }
-    return fe_fold18(t, c);
+    t[17] = (int32_t)c;
+    fe r;
+    c = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        int64_t acc = c + (int64_t)t[k + 9] * 1216;
+#pragma unroll
+        for (int i = 0; i < 9; i++) {
+            int j = k - i;
+            if (j >= 0 && j < 9) acc += (int64_t)a.v[i] * b.v[j];
+        }
+        FE_COLUMN_TAIL_ROUND(acc, c, r.v[k]);
+    }
+    {
+        int64_t acc = c + (int64_t)t[17] * 1216 + t[8];
+        FE_COLUMN_TAIL_ROUND(acc, c, r.v[8]);
+    }
+    r.v[0] += (int32_t)c * 1216;  // |c| < 2^13
+    return r;
 }
 
 HD inline fe fe_sq(const fe& a) {
     int32_t d[9];
 #pragma unroll
     for (int i = 0; i < 9; i++) d[i] = 2 * a.v[i];
-    int32_t t[17];
+    int32_t t[18];
     int64_t c = 0;
 #pragma unroll
-    for (int k = 0; k < 17; k++) {
+    for (int k = 8; k < 17; k++) {
         int64_t acc = c;
 #pragma unroll
         for (int i = 0; i < 9; i++) {
@@ -117,10 +130,28 @@ HD inline fe fe_sq(const fe& a) {
             if (j > i && j < 9) acc += (int64_t)d[i] * a.v[j];
         }
         if ((k & 1) == 0) acc += (int64_t)a.v[k >> 1] * a.v[k >> 1];
-        c = (acc + (1 << 28)) >> 29;
-        t[k] = (int32_t)(acc - c * 536870912LL);
+        FE_COLUMN_TAIL_FLOOR(acc, c, t[k]);
     }
-    return fe_fold18(t, c);
+    t[17] = (int32_t)c;
+    fe r;
+    c = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        int64_t acc = c + (int64_t)t[k + 9] * 1216;
+#pragma unroll
+        for (int i = 0; i < 9; i++) {
+            int j = k - i;
+            if (j > i && j < 9) acc += (int64_t)d[i] * a.v[j];
+        }
+        if ((k & 1) == 0) acc += (int64_t)a.v[k >> 1] * a.v[k >> 1];
+        FE_COLUMN_TAIL_ROUND(acc, c, r.v[k]);
+    }
+    {
+        int64_t acc = c + (int64_t)t[17] * 1216 + t[8];
+        FE_COLUMN_TAIL_ROUND(acc, c, r.v[8]);
+    }
+    r.v[0] += (int32_t)c * 1216;
+    return r;
 }
 
 // normalise to centred limbs (|limb| <= N) without changing the value mod p

@@ -56,6 +56,38 @@ __global__ void __launch_bounds__(256) k_inst(uint32_t* out, uint32_t seed) {
 #define M(a) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(*(float*)&a) : "v"(*(float*)&x), "v"(*(float*)&y));
             M(a0) M(a1) M(a2) M(a3) M(a4) M(a5) M(a6) M(a7)
 #undef M
+        } else if (OP == 10) {  // v_mad_i64_i32
+#define M(a) asm volatile("v_mad_i64_i32 %0, s[2:3], %1, %2, %0" : "+v"(a) : "v"(x), "v"(y) : "s2", "s3");
+            M(a0) M(a1) M(a2) M(a3) M(a4) M(a5) M(a6) M(a7)
+#undef M
+        } else if (OP == 11) {  // v_ashrrev_i64
+#define M(a) asm volatile("v_ashrrev_i64 %0, 1, %0" : "+v"(a));
+            M(a0) M(a1) M(a2) M(a3) M(a4) M(a5) M(a6) M(a7)
+#undef M
+        } else if (OP == 12) {  // v_bitop3_b32 (chi: a ^ (~b & c))
+#define M(a) asm volatile("v_bitop3_b32 %0, %0, %1, %2 bitop3:0xd2" : "+v"(*(uint32_t*)&a) : "v"(x), "v"(y));
+            M(a0) M(a1) M(a2) M(a3) M(a4) M(a5) M(a6) M(a7)
+#undef M
+        } else if (OP == 13) {  // v_alignbit_b32
+#define M(a) asm volatile("v_alignbit_b32 %0, %0, %1, 7" : "+v"(*(uint32_t*)&a) : "v"(x));
+            M(a0) M(a1) M(a2) M(a3) M(a4) M(a5) M(a6) M(a7)
+#undef M
+        } else if (OP == 14) {  // v_xor_b32 with DPP row_shr:1
+#define M(a) asm volatile("v_xor_b32_dpp %0, %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(*(uint32_t*)&a) : "v"(x));
+            M(a0) M(a1) M(a2) M(a3) M(a4) M(a5) M(a6) M(a7)
+#undef M
+        } else if (OP == 15) {  // ds_bpermute_b32 dependent chain of 8 (latency + throughput)
+#define M(a) asm volatile("ds_bpermute_b32 %0, %1, %0\n s_waitcnt lgkmcnt(0)" : "+v"(*(uint32_t*)&a) : "v"(x));
+            M(a0) M(a1) M(a2) M(a3) M(a4) M(a5) M(a6) M(a7)
+#undef M
+        } else if (OP == 16) {  // v_bfi_b32
+#define M(a) asm volatile("v_bfi_b32 %0, %0, %1, %2" : "+v"(*(uint32_t*)&a) : "v"(x), "v"(y));
+            M(a0) M(a1) M(a2) M(a3) M(a4) M(a5) M(a6) M(a7)
+#undef M
+        } else if (OP == 17) {  // v_mov_b32 dpp row_ror (pure cross-lane move)
+#define M(a) asm volatile("v_mov_b32_dpp %0, %0 row_ror:1 row_mask:0xf bank_mask:0xf" : "+v"(*(uint32_t*)&a));
+            M(a0) M(a1) M(a2) M(a3) M(a4) M(a5) M(a6) M(a7)
+#undef M
         }
     }
     out[t] = (uint32_t)(a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7) ^ (uint32_t)(d0 + d1 + d2 + d3 + d4 + d5 + d6 + d7);
@@ -65,21 +97,25 @@ template <int OP>
 __global__ void __launch_bounds__(256) k_prim(uint32_t* out, const uint32_t* in, int iters) {
     uint32_t t = threadIdx.x + blockIdx.x * 256;
     fe a, b;
-    for (int i = 0; i < 8; i++) { a.v[i] = in[i] + t; b.v[i] = in[8 + i] ^ t; }
+    for (int i = 0; i < 9; i++) { a.v[i] = (int32_t)((in[i] + t) & 0x0fffffff); b.v[i] = (int32_t)((in[7 + i] ^ t) & 0x0fffffff); }
     if (OP == 0) { for (int i = 0; i < iters; i++) a = fe_mul(a, b); }
     if (OP == 1) { for (int i = 0; i < iters; i++) a = fe_add(a, b); }
     if (OP == 2) { for (int i = 0; i < iters; i++) a = fe_sub(a, b); }
+    if (OP == 7) { for (int i = 0; i < iters; i++) a = fe_sq(a); }
+    if (OP == 8) { sc x, y; for (int i = 0; i < 8; i++) { x.v[i] = (uint32_t)a.v[i]; y.v[i] = (uint32_t)b.v[i]; } x.v[7] &= 0x0fffffff;
+        for (int i = 0; i < iters; i++) { x = sc_invert(x); x.v[0] ^= 1; }
+        for (int i = 0; i < 8; i++) a.v[i] = (int32_t)x.v[i]; }
     if (OP == 3) {
         sc x, y;
-        for (int i = 0; i < 8; i++) { x.v[i] = a.v[i]; y.v[i] = b.v[i]; }
+        for (int i = 0; i < 8; i++) { x.v[i] = (uint32_t)a.v[i]; y.v[i] = (uint32_t)b.v[i]; }
         x.v[7] &= 0x0fffffff; y.v[7] &= 0x0fffffff;
         for (int i = 0; i < iters; i++) x = sc_mul(x, y);
-        for (int i = 0; i < 8; i++) a.v[i] = x.v[i];
+        for (int i = 0; i < 8; i++) a.v[i] = (int32_t)x.v[i];
     }
     if (OP == 4 || OP == 5 || OP == 6) {
         ge p = ge_basepoint();
         p.X = fe_add(p.X, a);
-        ge_niels n; n.yplusx = a; n.yminusx = b; n.xy2d = fe_add(a, b);
+        ge_niels n; n.yplusx = a; n.yminusx = b; n.xy2d = fe_carry(fe_add(a, b));
         ge_cached c = ge_to_cached(p);
         for (int i = 0; i < iters; i++) {
             if (OP == 4) p = ge_madd(p, n, i & 1);
@@ -88,7 +124,7 @@ __global__ void __launch_bounds__(256) k_prim(uint32_t* out, const uint32_t* in,
         }
         a = fe_add(fe_add(p.X, p.Y), fe_add(p.Z, p.T));
     }
-    for (int i = 0; i < 8; i++) out[t * 8 + i] = a.v[i];
+    for (int i = 0; i < 8; i++) out[t * 8 + i] = (uint32_t)a.v[i] ^ (uint32_t)a.v[8];
 }
 
 int main() {
@@ -99,18 +135,18 @@ int main() {
     uint32_t h[16]; for (int i = 0; i < 16; i++) h[i] = 0x9e3779b9u * (i + 1);
     CHK(hipMemcpy(in, h, 64, hipMemcpyHostToDevice));
     hipEvent_t e0, e1; CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
-    const char* names[] = {"v_mad_u64_u32", "v_mul_lo_u32", "v_mul_hi_u32", "v_lshl_add_u64", "v_add_u32", "v_fma_f64", "v_mad_u32_u24", "v_mul_hi_u32_u24", "add_co+addc pair", "v_fma_f32"};
+    const char* names[] = {"v_mad_u64_u32", "v_mul_lo_u32", "v_mul_hi_u32", "v_lshl_add_u64", "v_add_u32", "v_fma_f64", "v_mad_u32_u24", "v_mul_hi_u32_u24", "add_co+addc pair", "v_fma_f32", "v_mad_i64_i32", "v_ashrrev_i64", "v_bitop3_b32", "v_alignbit_b32", "v_xor_b32_dpp", "ds_bpermute(dep)", "v_bfi_b32", "v_mov_b32_dpp"};
     float ms;
 #define RUN_INST(OP) { hipLaunchKernelGGL(k_inst<OP>, dim3(blocks), dim3(threads), 0, 0, out, 1u); CHK(hipDeviceSynchronize()); \
     CHK(hipEventRecord(e0)); hipLaunchKernelGGL(k_inst<OP>, dim3(blocks), dim3(threads), 0, 0, out, 2u); CHK(hipEventRecord(e1)); CHK(hipEventSynchronize(e1)); \
     CHK(hipEventElapsedTime(&ms, e0, e1)); double n = (double)blocks * threads * ITER * 8; \
     printf("%-18s %8.3f ms  %8.2f Tlane-op/s  (%.2f cyc/wave-inst/SIMD @2.4GHz)\n", names[OP], ms, n / ms / 1e9, 1024.0 * 2.4e9 * 64 / (n / (ms * 1e-3))); }
-    RUN_INST(0) RUN_INST(1) RUN_INST(2) RUN_INST(3) RUN_INST(4) RUN_INST(5) RUN_INST(6) RUN_INST(7) RUN_INST(8) RUN_INST(9)
-    const char* pn[] = {"fe_mul", "fe_add", "fe_sub", "sc_mul", "ge_madd", "ge_dbl", "ge_add"};
+    RUN_INST(0) RUN_INST(1) RUN_INST(2) RUN_INST(3) RUN_INST(4) RUN_INST(5) RUN_INST(6) RUN_INST(7) RUN_INST(8) RUN_INST(9) RUN_INST(10) RUN_INST(11) RUN_INST(12) RUN_INST(13) RUN_INST(14) RUN_INST(15) RUN_INST(16) RUN_INST(17)
+    const char* pn[] = {"fe_mul", "fe_add", "fe_sub", "sc_mul", "ge_madd", "ge_dbl", "ge_add", "fe_sq", "sc_invert"};
 #define RUN_PRIM(OP, IT) { hipLaunchKernelGGL(k_prim<OP>, dim3(blocks), dim3(threads), 0, 0, out, in, 8); CHK(hipDeviceSynchronize()); \
     CHK(hipEventRecord(e0)); hipLaunchKernelGGL(k_prim<OP>, dim3(blocks), dim3(threads), 0, 0, out, in, IT); CHK(hipEventRecord(e1)); CHK(hipEventSynchronize(e1)); \
     CHK(hipEventElapsedTime(&ms, e0, e1)); double n = (double)blocks * threads * IT; \
     printf("%-18s %8.3f ms  %8.2f Gop/s  (%.0f cyc/wave-op/SIMD @2.4GHz)\n", pn[OP], ms, n / ms / 1e6, 1024.0 * 2.4e9 * 64 / (n / (ms * 1e-3))); }
-    RUN_PRIM(0, 2048) RUN_PRIM(1, 2048) RUN_PRIM(2, 2048) RUN_PRIM(3, 2048) RUN_PRIM(4, 256) RUN_PRIM(5, 256) RUN_PRIM(6, 256)
+    RUN_PRIM(0, 2048) RUN_PRIM(1, 2048) RUN_PRIM(2, 2048) RUN_PRIM(3, 2048) RUN_PRIM(4, 256) RUN_PRIM(5, 256) RUN_PRIM(6, 256) RUN_PRIM(7, 2048) RUN_PRIM(8, 16)
     return 0;
 }
