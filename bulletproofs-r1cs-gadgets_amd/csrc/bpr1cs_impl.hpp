@@ -38,7 +38,7 @@ static int g_unfold_rounds = 4;
 static int g_window_bits = 8;
 static int g_latency_cus = 0;   // >0: CUs reserved for the latency-bound kernels (see bpr1cs_gens_create)
 static int g_witness_team = 16;  // lanes cooperating on one proof in k_witness_team (4, 8 or 16)
-static uint32_t g_msm_target_threads = 1u << 17;  // (chunk, proof) threads per MSM launch
+static uint32_t g_msm_target_threads = 1u << 21;  // (chunk, proof) threads per MSM launch
 static float g_timings[8];
 
 struct bpr1cs_gens {
@@ -352,20 +352,35 @@ struct MsmStats {
 static MsmStats g_msm;             // last finished job (reported by bpr1cs_last_msm_stats)
 static MsmStats* g_cur_msm = &g_msm;  // job being enqueued
 
+// Launch geometry: many more workgroups than the chip holds at once (g_msm_target_threads / 256 >> 2 per CU), so
+// that the hardware dispatcher load-balances them - a launch of exactly one resident set makes every workgroup
+// that shares a SIMD with a co-running front kernel a straggler for the whole launch.  The chunk partials are
+// folded `MSM_REDUCE_GROUP` at a time before the per-proof finish kernel.
+static const uint32_t MSM_REDUCE_GROUP = 16;
 static void run_msm(const bpr1cs_gens* g, MsmSeg s0, MsmSeg s1, uint32_t B, DevBuf<ge>& partial, MsmPlan& plan, dev_stream_t st) {
     uint32_t total = s0.count + s1.count;
-    plan.nchunks = pick_chunks(total, B, g_msm_target_threads, plan.chunk);
-    if (partial.n < (size_t)plan.nchunks * B) partial.alloc((size_t)plan.nchunks * B);
-    K_msm_fixed k{g->tab.p, g->tc, {s0, s1}, partial.p, B, plan.chunk};
+    uint32_t nchunks = pick_chunks(total, B, g_msm_target_threads, plan.chunk);
+    uint32_t reduced = nchunks > 128 ? (nchunks + MSM_REDUCE_GROUP - 1) / MSM_REDUCE_GROUP : 0;
+    size_t need = ((size_t)nchunks + reduced) * B;
+    if (partial.n < need) partial.alloc(need);
+    ge* raw = partial.p + (size_t)reduced * B;  // the reduced partials (what the callers read) sit at the front
+    uint32_t nbk = (B + 63u) / 64u;
+    K_msm_fixed k{g->tab.p, g->tc, {s0, s1}, raw, B, plan.chunk, nbk, nchunks * nbk};
 #if !defined(BPR1CS_HOSTSIM)
     hipEvent_t e0 = g_cur_msm->get(), e1 = g_cur_msm->get();
     HIPCHK(hipEventRecord(e0, st));
 #endif
-    launch((uint64_t)plan.nchunks * B, k, st);
+    launch_wave((uint64_t)nchunks * nbk * 64u, k, st);
 #if !defined(BPR1CS_HOSTSIM)
     HIPCHK(hipEventRecord(e1, st));
     g_cur_msm->ev.push_back({e0, e1});
 #endif
+    if (reduced) {
+        launch((uint64_t)reduced * B, K_ge_reduce{raw, partial.p, B, nchunks, MSM_REDUCE_GROUP}, st);
+        plan.nchunks = reduced;
+    } else {
+        plan.nchunks = nchunks;
+    }
     g_cur_msm->launches++;
     g_cur_msm->terms += (uint64_t)total * B;
 }
@@ -512,6 +527,7 @@ extern "C" int bpr1cs_prove_batch_begin(const bpr1cs_gens* g, const bpr1cs_circu
         launch(B, kw, st);
 #else
         const int T = g_witness_team;
+        kw.prio = 2;  // above the co-resident MSM waves (default 0), below the RNG chain (3)
         uint32_t blocks = (uint32_t)(((uint64_t)B * T + 63) / 64);
         HIPCHK(hipStreamWaitEvent(job->st3, ev_in, 0));
         if (T == 4) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_witness_team<4>), dim3(blocks), dim3(64), 0, job->st3, kw);
@@ -768,8 +784,9 @@ extern "C" int bpr1cs_msm_fixed(const bpr1cs_gens* g, const uint32_t* bases, siz
         MsmSeg s0 = mk(i), s1{nullptr, 0, 1, 1, 0, 0, 0};
         if (i + 1 < runs.size()) s1 = mk(i + 1);
         uint32_t ch, nc = pick_chunks(s0.count + s1.count, B, 1u << 17, ch);
-        K_msm_fixed k{g->tab.p, g->tc, {s0, s1}, all.p + off * B, B, ch};
-        launch((uint64_t)nc * B, k, st);
+        uint32_t nbk = (B + 63u) / 64u;
+        K_msm_fixed k{g->tab.p, g->tc, {s0, s1}, all.p + off * B, B, ch, nbk, nc * nbk};
+        launch_wave((uint64_t)nc * nbk * 64u, k, st);
         off += nc;
     }
     DevBuf<uint8_t> d_out((size_t)B * 32);

@@ -38,6 +38,8 @@ template <class F>
 inline void launch(uint64_t n, const F& f, dev_stream_t) {
     for (uint64_t g = 0; g < n; g++) f((uint32_t)g);
 }
+template <class F>
+inline void launch_wave(uint64_t n, const F& f, dev_stream_t s) { launch(n, f, s); }
 #else
 #include <hip/hip_runtime.h>
 typedef hipStream_t dev_stream_t;
@@ -133,6 +135,29 @@ inline void launch(uint64_t n, const F& f, dev_stream_t s) {
     static const bool dbg = getenv("BPR1CS_DEBUG_SYNC") != nullptr;
     if (dbg) {
         fprintf(stderr, "bpr1cs: launched %s n=%llu\n", typeid(F).name(), (unsigned long long)n);
+        HIPCHK(hipStreamSynchronize(s));
+    }
+}
+// One wavefront per workgroup: the unit the dispatcher places (and retires) is a single wave, so a wave that
+// shares its SIMD with a co-running latency-bound kernel never pins three idle sibling waves' registers.
+template <class F>
+__global__ void __launch_bounds__(64) k_functor_wave(F f, uint32_t n) {
+    uint32_t g = blockIdx.x * 64u + threadIdx.x;
+    if (g < n) f(g);
+}
+template <class F>
+inline void launch_wave(uint64_t n, const F& f, dev_stream_t s) {
+    if (n == 0) return;
+    if (n > 0xffffffffull) {
+        fprintf(stderr, "bpr1cs: grid too large\n");
+        abort();
+    }
+    uint32_t blocks = (uint32_t)((n + 63) / 64);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_functor_wave<F>), dim3(blocks), dim3(64), 0, s, f, (uint32_t)n);
+    HIPCHK(hipGetLastError());
+    static const bool dbg = getenv("BPR1CS_DEBUG_SYNC") != nullptr;
+    if (dbg) {
+        fprintf(stderr, "bpr1cs: launched (wave) %s n=%llu\n", typeid(F).name(), (unsigned long long)n);
         HIPCHK(hipStreamSynchronize(s));
     }
 }

@@ -315,6 +315,7 @@ struct K_witness {  // thread per proof (sequential program)
     const sc* v_m;       // [m][B]
     sc* W;               // [3][n][B] a_L a_R a_O
     uint32_t B, n;
+    uint32_t prio = 0;   // s_setprio level of the team kernel's waves
     HD sc value(uint32_t var, uint32_t b) const {
         uint32_t kind = var >> 28, idx = var & 0x0fffffffu;
         if (kind == VK_COMMITTED) return v_m[(size_t)idx * B + b];
@@ -359,14 +360,23 @@ struct MsmSeg {
     const sc* scal;
     uint32_t count, run, period, off, base0, mont;
 };
-struct K_msm_fixed {  // gid = c*B + b -> partial[c*B + b]
+// One thread = (chunk c of the term list, proof b); a workgroup = ONE wavefront = 64 consecutive proofs of one
+// chunk, so its lanes walk the same table rows.  Workgroups are dealt round-robin to the 8 XCDs (each with a
+// private L2): the workgroup index is remapped so that the `nbk` workgroups sharing a chunk run on the SAME XCD
+// back to back and a table row is pulled from HBM once, not once per XCD.
+struct K_msm_fixed {  // gid = wg*64 + lane -> partial[c*B + b]   (launch_wave)
     const ge_niels_packed* tab;
     TabCfg tc;
     MsmSeg seg[2];
     ge* partial;
     uint32_t B, chunk;  // ordinals per chunk over the concatenated segments
+    uint32_t nbk;       // workgroups per chunk = ceil(B / 64)
+    uint32_t nwg;       // workgroups in the launch = nchunks * nbk
     HD void operator()(uint32_t g) const {
-        uint32_t c = g / B, b = g % B;
+        uint32_t wg = g >> 6, lane = g & 63u;
+        if ((nwg & 7u) == 0) wg = (wg & 7u) * (nwg >> 3) + (wg >> 3);
+        uint32_t c = wg / nbk, b = (wg % nbk) * 64u + lane;
+        if (b >= B) return;
         uint32_t total = seg[0].count + seg[1].count;
         uint32_t lo = c * chunk, hi = lo + chunk < total ? lo + chunk : total;
         ge acc = ge_identity();
@@ -378,7 +388,20 @@ struct K_msm_fixed {  // gid = c*B + b -> partial[c*B + b]
             if (s.mont) x = sc_from_mont(x);
             acc = table_mul_acc(acc, tab + (size_t)(s.base0 + i) * tc.per_base, x, tc);
         }
-        partial[g] = acc;
+        partial[(size_t)c * B + b] = acc;
+    }
+};
+// second-level reduction of chunk partials: out[r*B + b] = sum_{k < group} in[(r*group + k)*B + b]
+struct K_ge_reduce {  // gid = r*B + b
+    const ge* in;
+    ge* out;
+    uint32_t B, nchunks, group;
+    HD void operator()(uint32_t g) const {
+        uint32_t r = g / B, b = g % B;
+        uint32_t lo = r * group, hi = lo + group < nchunks ? lo + group : nchunks;
+        ge acc = in[(size_t)lo * B + b];
+        for (uint32_t c = lo + 1; c < hi; c++) acc = ge_add_ge(acc, in[(size_t)c * B + b]);
+        out[g] = acc;
     }
 };
 // sum of partials + extra*Base(extra_base) -> compressed (and optional extended copy)

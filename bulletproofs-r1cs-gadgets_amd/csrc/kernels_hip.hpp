@@ -56,6 +56,7 @@ __device__ inline sc team_operand(const K_witness& p, uint32_t kind, uint32_t ar
 }
 template <int T>
 __global__ void __launch_bounds__(64) k_witness_team(K_witness p) {
+    if (p.prio == 1) __builtin_amdgcn_s_setprio(1); else if (p.prio == 2) __builtin_amdgcn_s_setprio(2); else if (p.prio == 3) __builtin_amdgcn_s_setprio(3);
     const uint32_t lane = threadIdx.x & (T - 1);
     uint32_t b = (blockIdx.x * 64u + threadIdx.x) / T;
     const bool active = b < p.B;
@@ -93,6 +94,7 @@ __global__ void __launch_bounds__(64) k_witness_team(K_witness p) {
 // the new data; the fences below only stop the compiler from reordering.
 __device__ inline void lds_order() { __syncthreads(); }  // one wavefront per workgroup: lgkmcnt(0) + s_barrier
 __global__ void __launch_bounds__(64) k_rng_stream(const strobe* rng_in, uint64_t* raw_out, int* err, uint32_t B, uint32_t draws) {
+    __builtin_amdgcn_s_setprio(3);  // one long dependent chain per state: take every issue slot it can use
     __shared__ uint64_t xch[2][2][32];  // [buffer][half][lane]
     const uint32_t lane = threadIdx.x, i = lane & 31u, half = lane >> 5;
     uint32_t b = blockIdx.x * 2u + half;
