@@ -39,7 +39,10 @@ class _CircuitDesc(ctypes.Structure):
                 ("term_coeff", ctypes.c_char_p),
                 ("wops", ctypes.POINTER(_WOp)), ("n_lc", ctypes.c_uint32),
                 ("lc_off", ctypes.POINTER(ctypes.c_uint32)), ("lc_var", ctypes.POINTER(ctypes.c_uint32)),
-                ("lc_coeff", ctypes.c_char_p)]
+                ("lc_coeff", ctypes.c_char_p),
+                # optional Poseidon annotations (include/bpr1cs.h); left zero by this wrapper
+                ("n_poseidon_params", ctypes.c_uint32), ("poseidon_params", ctypes.c_void_p),
+                ("n_poseidon_perms", ctypes.c_uint32), ("poseidon_perms", ctypes.c_void_p)]
 
 
 _lib = None
@@ -75,6 +78,9 @@ def load_library(path=None):
     lib.bpr1cs_set_unfold_rounds.argtypes = [ctypes.c_int]
     lib.bpr1cs_set_window_bits.argtypes = [ctypes.c_int]
     lib.bpr1cs_set_witness_team.argtypes = [ctypes.c_int]
+    lib.bpr1cs_set_witness_macro.argtypes = [ctypes.c_int]
+    lib.bpr1cs_circuit_macro_perms.argtypes = [ctypes.c_void_p]
+    lib.bpr1cs_circuit_macro_perms.restype = ctypes.c_int
     lib.bpr1cs_set_latency_cus.argtypes = [ctypes.c_int]
     lib.bpr1cs_last_timings.argtypes = [ctypes.POINTER(ctypes.c_float), ctypes.c_int]
     lib.bpr1cs_last_msm_stats.argtypes = [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]

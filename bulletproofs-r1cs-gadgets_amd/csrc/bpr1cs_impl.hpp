@@ -37,6 +37,7 @@ static void host_sponge(uint32_t rate, uint8_t suffix, const uint8_t* in, size_t
 static int g_unfold_rounds = 4;
 static int g_window_bits = 8;
 static int g_latency_cus = 0;   // >0: CUs reserved for the latency-bound kernels (see bpr1cs_gens_create)
+static int g_witness_macro = 1;  // use the Poseidon annotations of a circuit description (poseidon_team)
 static int g_witness_team = 16;  // lanes cooperating on one proof in k_witness_team (4, 8 or 16)
 static uint32_t g_msm_target_threads = 1u << 21;  // (chunk, proof) threads per MSM launch
 static float g_timings[8];
@@ -65,6 +66,11 @@ struct bpr1cs_circuit {
     DevBuf<WOp> wops;
     DevBuf<uint32_t> lc_off, lc_var;
     DevBuf<sc> lc_coeff;
+    // Poseidon permutations evaluated jointly (empty when the description has no usable annotation)
+    DevBuf<PoseidonTab> ptab;
+    DevBuf<PoseidonPerm> perms;
+    DevBuf<sc> pconst;
+    uint32_t n_perms = 0, px_stride = 0, macro_width = 0;
 };
 
 static bool have_device() {
@@ -107,6 +113,8 @@ int bpr1cs_set_device(int ordinal) {
 void bpr1cs_set_unfold_rounds(int r) { g_unfold_rounds = r < 0 ? 0 : r; }
 void bpr1cs_set_latency_cus(int n) { g_latency_cus = n < 0 ? 0 : n; }
 void bpr1cs_set_witness_team(int t) { g_witness_team = (t == 4 || t == 8) ? t : 16; }
+void bpr1cs_set_witness_macro(int enable) { g_witness_macro = enable ? 1 : 0; }
+int bpr1cs_circuit_macro_perms(const bpr1cs_circuit* c) { return c ? (int)c->n_perms : 0; }
 void bpr1cs_set_window_bits(int w) { g_window_bits = w < 4 ? 4 : (w > 12 ? 12 : w); }
 int bpr1cs_last_timings(float* out, int cap) {
     int k = cap < 6 ? cap : 6;
@@ -259,6 +267,73 @@ int bpr1cs_circuit_create(const bpr1cs_circuit_desc* d, bpr1cs_circuit** out) {
             if (t1 == t0) { kind = WK_ZERO; arg = 0; return; }
             if (t1 == t0 + 1 && memcmp(&lcf[t0], &one, sizeof(sc)) == 0) { kind = WK_VAR; arg = lv[t0]; }
         };
+        // Poseidon annotations: validate, then route the S-box multipliers to the jointly evaluated values.
+        // Anything unexpected leaves the plain program in place (it is complete on its own).
+        if (g_witness_macro && d->n_poseidon_perms && d->poseidon_perms && d->n_poseidon_params && d->poseidon_params) {
+            std::vector<PoseidonTab> tabs;
+            std::vector<sc> pc;
+            bool ok = true;
+            uint32_t max_s = 0, max_w = 0;
+            for (uint32_t k = 0; k < d->n_poseidon_params && ok; k++) {
+                const bpr1cs_poseidon_params& pp = d->poseidon_params[k];
+                uint32_t w = pp.width, rounds = pp.full_rounds_beginning + pp.partial_rounds + pp.full_rounds_end;
+                if (w < 2 || w > 8 || !pp.mds || !pp.round_keys || rounds == 0 || rounds > (1u << 16)) { ok = false; break; }
+                PoseidonTab t{w, pp.full_rounds_beginning, pp.partial_rounds, pp.full_rounds_end, 0, 0, 0};
+                t.mds_off = (uint32_t)pc.size();
+                for (uint32_t i = 0; i < w * w; i++) pc.push_back(host_mont(pp.mds + 32 * (size_t)i));
+                t.rk_off = (uint32_t)pc.size();
+                for (uint32_t i = 0; i < rounds * w; i++) pc.push_back(host_mont(pp.round_keys + 32 * (size_t)i));
+                t.rcomb_off = (uint32_t)pc.size();
+                for (uint32_t rp = 0; rp < pp.partial_rounds; rp++)  // R_i = sum_{j < w-1} M_ij k_j of that round
+                    for (uint32_t i = 0; i < w; i++) {
+                        sc acc = sc_zero();
+                        for (uint32_t j = 0; j + 1 < w; j++)
+                            acc = sc_add(acc, sc_mul(pc[t.mds_off + i * w + j], pc[t.rk_off + (pp.full_rounds_beginning + rp) * w + j]));
+                        pc.push_back(acc);
+                    }
+                tabs.push_back(t);
+                uint32_t S = (t.fb + t.fe) * w + t.pr;
+                if (S > max_s) max_s = S;
+                if (w > max_w) max_w = w;
+            }
+            std::vector<PoseidonPerm> pms;
+            std::vector<WOp> patched = ops;
+            uint32_t prev_first = 0;
+            for (uint32_t k = 0; k < d->n_poseidon_perms && ok; k++) {
+                const bpr1cs_poseidon_perm& pp = d->poseidon_perms[k];
+                if (pp.params >= tabs.size() || !pp.sbox_mul) { ok = false; break; }
+                const PoseidonTab& t = tabs[pp.params];
+                uint32_t S = (t.fb + t.fe) * t.width + t.pr;
+                PoseidonPerm pm{};
+                pm.first_mul = pp.sbox_mul[0];
+                pm.table = pp.params;
+                if (k && pm.first_mul <= prev_first) { ok = false; break; }
+                prev_first = pm.first_mul;
+                for (uint32_t i = 0; i < t.width && ok; i++) {
+                    pm.in_lc[i] = pp.in_lc[i];
+                    if (pp.in_lc[i] >= d->n_lc) { ok = false; break; }
+                    for (uint32_t tt = lo[pp.in_lc[i]]; tt < lo[pp.in_lc[i] + 1]; tt++) {  // inputs must be known by then
+                        uint32_t vk = lv[tt] >> 28, vi = lv[tt] & 0x0fffffffu;
+                        if (vk >= VK_LEFT && vk <= VK_OUT && vi >= pm.first_mul) ok = false;
+                    }
+                }
+                for (uint32_t sidx = 0; sidx < S && ok; sidx++) {
+                    uint32_t mi = pp.sbox_mul[sidx];
+                    if (mi >= d->n || (sidx && mi <= pp.sbox_mul[sidx - 1]) || ops[mi].lkind != WK_LC || ops[mi].rkind != WK_INV_LEFT) { ok = false; break; }
+                    patched[mi] = WOp{WK_PX, sidx, WK_PXINV, sidx};
+                }
+                pms.push_back(pm);
+            }
+            if (ok && !pms.empty()) {
+                ops.swap(patched);
+                c->n_perms = (uint32_t)pms.size();
+                c->px_stride = max_s + 1;
+                c->macro_width = max_w;
+                upload(c->ptab, tabs, s);
+                upload(c->perms, pms, s);
+                upload(c->pconst, pc, s);
+            }
+        }
         for (auto& op : ops) { special(op.lkind, op.larg); special(op.rkind, op.rarg); }
         upload(c->wops, ops, s);
         upload(c->lc_off, lo, s);
@@ -523,10 +598,19 @@ extern "C" int bpr1cs_prove_batch_begin(const bpr1cs_gens* g, const bpr1cs_circu
         dev_sync(sl);
     } else {
         K_witness kw{c->wops.p, c->lc_off.p, c->lc_var.p, c->lc_coeff.p, v_raw.p, v_m.p, W.p, B, n};
+        DevBuf<sc> px;
+        DevBuf<uint8_t> pzf;
+        if (c->n_perms) {
+            px.alloc((size_t)4 * c->px_stride * B);
+            pzf.alloc((size_t)c->px_stride * B);
+            kw.ptab = c->ptab.p; kw.perms = c->perms.p; kw.n_perms = c->n_perms; kw.pconst = c->pconst.p;
+            kw.px = px.p; kw.pzf = pzf.p; kw.px_stride = c->px_stride;
+        }
 #if defined(BPR1CS_HOSTSIM)
         launch(B, kw, st);
 #else
-        const int T = g_witness_team;
+        int T = g_witness_team;
+        if (c->n_perms && (uint32_t)T < c->macro_width + 2) T = 16;  // poseidon_team needs width + 2 lanes
         kw.prio = 2;  // above the co-resident MSM waves (default 0), below the RNG chain (3)
         uint32_t blocks = (uint32_t)(((uint64_t)B * T + 63) / 64);
         HIPCHK(hipStreamWaitEvent(job->st3, ev_in, 0));

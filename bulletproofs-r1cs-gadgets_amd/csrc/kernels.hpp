@@ -45,6 +45,8 @@ HD inline TabCfg tab_cfg(uint32_t W) {
 // internal (produced by bpr1cs_circuit_create from WK_LC operands, never part of the ABI):
 #define WK_VAR 4u       // a linear combination that is exactly 1 * variable(arg): plain copy
 #define WK_ZERO 5u      // empty linear combination
+#define WK_PX 6u        // x of S-box #arg of the Poseidon permutation evaluated last (poseidon_team)
+#define WK_PXINV 7u     // 1/x of that S-box
 
 // ------------------------------------------------------------ fixed-base core
 // acc += s * Base, s canonical (< l).  Signed W-bit digits.
@@ -306,6 +308,180 @@ HD inline sc pow_lookup(const sc* lo, const sc* hi, uint32_t which, uint32_t H, 
 struct WOp {
     uint32_t lkind, larg, rkind, rarg;
 };
+// ---- joint evaluation of an Inverse-S-box Poseidon permutation (the chain that bounds witness latency)
+// The reference evaluates x -> 1/x once per S-box, 188 dependent field inversions per permutation
+// (gadget_poseidon.rs:153-185 inside :282-399).  Here the state is carried as fractions n_i / D over ONE common
+// denominator, so a round costs a handful of multiplications and no inversion:
+//   partial round (S-box on the last element l, a_l = n_l + k_l D):
+//       n'_i = a_l (sum_{j<l} M_ij n_j + R_i D) + M_il D^2,   D' = D a_l,        R_i = sum_{j<l} M_ij k_j
+//   full round (a_j = n_j + k_j D for all j, P = prod a_j):
+//       n'_i = D^2 sum_j M_ij P/a_j,                           D' = D P
+// With C_0 = 1, C_{s+1} = C_s a_s over the S-boxes in program order, the denominator of S-box s is C_{r(s)}
+// (r(s) = first S-box of its round), so x_s = a_s / C_r(s) and 1/x_s = C_r(s) / a_s follow from ONE inversion
+// per lane segment (back-substitution), i.e. one inversion latency per permutation instead of 188.
+// S-box inputs equal to 0 keep the reference's semantics (Scalar::invert(0) = 0): the factor is replaced by 1
+// in the products and both wires are written as 0.
+//
+// The code is phase-structured for a team of T cooperating lanes (T >= width + 2): on the GPU every lane runs
+// its own iteration of TEAM_LANES and TEAM_SYNC is a workgroup barrier; the CPU simulator runs the lanes of a
+// phase one after the other.  Cross-phase state lives in `sh` (LDS on the GPU) and in the px scratch.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define TEAM_LANES(lane, T, mylane) for (uint32_t lane = (mylane), once_ = 1; once_; once_ = 0)
+#define TEAM_SYNC() do { __threadfence_block(); __syncthreads(); } while (0)
+#else
+#define TEAM_LANES(lane, T, mylane) for (uint32_t lane = 0; lane < (T); lane++)
+#define TEAM_SYNC() do { } while (0)
+#endif
+struct PoseidonTab {  // one parameter set (reference PoseidonParams, gadget_poseidon.rs:31-93); offsets into pconst
+    uint32_t width, fb, pr, fe;
+    uint32_t mds_off, rk_off, rcomb_off;
+};
+struct PoseidonPerm {
+    uint32_t first_mul;  // the permutation is evaluated right before this multiplier
+    uint32_t table;
+    uint32_t in_lc[8];   // linear combinations of its inputs (before the first round key)
+};
+enum { PS_N = 0, PS_AV = 8, PS_T1 = 16, PS_PRE = 24, PS_SUF = 32, PS_Z = 40, PS_D = 48, PS_D2 = 50, PS_SIZE = 51 };
+enum { PX_A = 0, PX_C = 1, PX_INVA = 2, PX_UI = 3 };  // after the macro: PX_A holds x, PX_INVA holds 1/x
+struct PoseidonScratch {
+    sc* px;        // [4][stride][B]
+    uint8_t* zf;   // [stride][B]
+    uint32_t stride, B, b;
+    HD sc& at(uint32_t arr, uint32_t s) const { return px[((size_t)arr * stride + s) * B + b]; }
+    HD uint8_t& z(uint32_t s) const { return zf[(size_t)s * B + b]; }
+};
+HD inline uint32_t poseidon_round_start(const PoseidonTab& t, uint32_t k) {
+    uint32_t w = t.width, a = t.fb * w;
+    if (k < a) return (k / w) * w;
+    if (k < a + t.pr) return k;
+    uint32_t base = a + t.pr;
+    return base + ((k - base) / w) * w;
+}
+// sh[PS_N + i] must hold the input state (Montgomery) on entry
+HD inline void poseidon_team(const PoseidonTab& t, const sc* pconst, const PoseidonScratch& ps, sc* sh, uint32_t T, uint32_t mylane) {
+    const uint32_t w = t.width, l = w - 1;
+    const sc* M = pconst + t.mds_off;
+    const sc* RK = pconst + t.rk_off;
+    const sc* RC = pconst + t.rcomb_off;
+    const uint32_t S = (t.fb + t.fe) * w + t.pr, rounds = t.fb + t.pr + t.fe;
+    uint32_t cur = 0, s = 0;
+    TEAM_LANES(lane, T, mylane) {
+        if (lane == 0) { sh[PS_D] = sc_one_mont(); ps.at(PX_C, 0) = sc_one_mont(); }
+    }
+    TEAM_SYNC();
+    for (uint32_t r = 0; r < rounds; r++) {
+        const bool full = r < t.fb || r >= t.fb + t.pr;
+        if (full) {
+            TEAM_LANES(lane, T, mylane) {
+                if (lane < w) {
+                    sc a = sc_add(sh[PS_N + lane], sc_mul(RK[r * w + lane], sh[PS_D + cur]));
+                    uint32_t z = (uint32_t)sc_is_zero(a);
+                    if (z) a = sc_one_mont();
+                    sh[PS_AV + lane] = a;
+                    sh[PS_Z + lane].v[0] = z;
+                    ps.at(PX_A, s + lane) = a;
+                    ps.z(s + lane) = (uint8_t)z;
+                }
+            }
+            TEAM_SYNC();
+            TEAM_LANES(lane, T, mylane) {
+                if (lane < 3) {  // 0: exclusive prefix products, 1: exclusive suffix products, 2: the C chain
+                    sc acc = lane == 2 ? sh[PS_D + cur] : sc_one_mont();
+                    for (uint32_t j = 0; j < w; j++) {
+                        uint32_t idx = lane == 1 ? w - 1 - j : j;
+                        if (lane == 0) sh[PS_PRE + idx] = acc;
+                        if (lane == 1) sh[PS_SUF + idx] = acc;
+                        acc = sc_mul(acc, sh[PS_AV + idx]);
+                        if (lane == 2) ps.at(PX_C, s + j + 1) = acc;
+                    }
+                    if (lane == 2) sh[PS_D + (cur ^ 1u)] = acc;
+                } else if (lane == 3) {
+                    sh[PS_D2] = sc_mul(sh[PS_D + cur], sh[PS_D + cur]);
+                }
+            }
+            TEAM_SYNC();
+            TEAM_LANES(lane, T, mylane) {
+                if (lane < w) {
+                    sc q = sc_mul(sh[PS_PRE + lane], sh[PS_SUF + lane]);
+                    if (sh[PS_Z + lane].v[0]) q = sc_zero();
+                    sh[PS_T1 + lane] = q;
+                }
+            }
+            TEAM_SYNC();
+            TEAM_LANES(lane, T, mylane) {
+                if (lane < w) {
+                    sc bi = sc_zero();
+                    for (uint32_t j = 0; j < w; j++) bi = sc_add(bi, sc_mul(M[lane * w + j], sh[PS_T1 + j]));
+                    sh[PS_N + lane] = sc_mul(sh[PS_D2], bi);
+                }
+            }
+            TEAM_SYNC();
+            cur ^= 1u;
+            s += w;
+        } else {
+            const uint32_t rp = r - t.fb;
+            TEAM_LANES(lane, T, mylane) {
+                if (lane < w) {
+                    sc acc = sc_mul(RC[rp * w + lane], sh[PS_D + cur]);
+                    for (uint32_t j = 0; j < l; j++) acc = sc_add(acc, sc_mul(M[lane * w + j], sh[PS_N + j]));
+                    sh[PS_T1 + lane] = acc;
+                } else if (lane == w) {
+                    sc a = sc_add(sh[PS_N + l], sc_mul(RK[r * w + l], sh[PS_D + cur]));
+                    uint32_t z = (uint32_t)sc_is_zero(a);
+                    if (z) a = sc_one_mont();
+                    sh[PS_AV] = a;
+                    sh[PS_Z].v[0] = z;
+                    ps.at(PX_A, s) = a;
+                    ps.z(s) = (uint8_t)z;
+                } else if (lane == w + 1) {
+                    sh[PS_D2] = sc_mul(sh[PS_D + cur], sh[PS_D + cur]);
+                }
+            }
+            TEAM_SYNC();
+            TEAM_LANES(lane, T, mylane) {
+                if (lane < w) {
+                    sc v = sc_mul(sh[PS_AV], sh[PS_T1 + lane]);
+                    if (!sh[PS_Z].v[0]) v = sc_add(v, sc_mul(M[lane * w + l], sh[PS_D2]));
+                    sh[PS_N + lane] = v;
+                } else if (lane == w) {
+                    sc dn = sc_mul(sh[PS_D + cur], sh[PS_AV]);
+                    sh[PS_D + (cur ^ 1u)] = dn;
+                    ps.at(PX_C, s + 1) = dn;
+                }
+            }
+            TEAM_SYNC();
+            cur ^= 1u;
+            s += 1;
+        }
+    }
+    // back-substitution: lane segments of the S-box list, one inversion each (in lock step)
+    const uint32_t seg = (S + T - 1) / T;
+    TEAM_LANES(lane, T, mylane) {
+        uint32_t s0 = lane * seg, s1 = s0 + seg < S ? s0 + seg : S;
+        bool any = s0 < s1;
+        sc u = sc_invert(any ? ps.at(PX_C, s1) : sc_one_mont());
+        if (any)
+            for (uint32_t k = s1; k-- > s0;) {
+                ps.at(PX_INVA, k) = sc_mul(u, ps.at(PX_C, k));  // 1 / a_k
+                u = sc_mul(u, ps.at(PX_A, k));                  // 1 / C_k
+                ps.at(PX_UI, k) = u;
+            }
+    }
+    TEAM_SYNC();
+    TEAM_LANES(lane, T, mylane) {
+        uint32_t s0 = lane * seg, s1 = s0 + seg < S ? s0 + seg : S;
+        for (uint32_t k = s0; k < s1; k++) {
+            uint32_t rs = poseidon_round_start(t, k);
+            sc x = sc_mul(ps.at(PX_A, k), ps.at(PX_UI, rs));
+            sc xi = sc_mul(ps.at(PX_C, rs), ps.at(PX_INVA, k));
+            if (ps.z(k)) { x = sc_zero(); xi = sc_zero(); }
+            ps.at(PX_A, k) = x;
+            ps.at(PX_INVA, k) = xi;
+        }
+    }
+    TEAM_SYNC();
+}
+
 struct K_witness {  // thread per proof (sequential program)
     const WOp* ops;
     const uint32_t* lc_off;
@@ -316,6 +492,15 @@ struct K_witness {  // thread per proof (sequential program)
     sc* W;               // [3][n][B] a_L a_R a_O
     uint32_t B, n;
     uint32_t prio = 0;   // s_setprio level of the team kernel's waves
+    // Poseidon permutations evaluated jointly (optional)
+    const PoseidonTab* ptab = nullptr;
+    const PoseidonPerm* perms = nullptr;
+    uint32_t n_perms = 0;
+    const sc* pconst = nullptr;
+    sc* px = nullptr;
+    uint8_t* pzf = nullptr;
+    uint32_t px_stride = 0;
+    HD PoseidonScratch scratch(uint32_t b) const { return PoseidonScratch{px, pzf, px_stride, B, b}; }
     HD sc value(uint32_t var, uint32_t b) const {
         uint32_t kind = var >> 28, idx = var & 0x0fffffffu;
         if (kind == VK_COMMITTED) return v_m[(size_t)idx * B + b];
@@ -325,6 +510,8 @@ struct K_witness {  // thread per proof (sequential program)
     HD sc operand(uint32_t kind, uint32_t arg, uint32_t b) const {
         if (kind == WK_VAR) return value(arg, b);
         if (kind == WK_ZERO) return sc_zero();
+        if (kind == WK_PX) return scratch(b).at(PX_A, arg);
+        if (kind == WK_PXINV) return scratch(b).at(PX_INVA, arg);
         if (kind == WK_LC) {
             sc acc = sc_zero();
             for (uint32_t t = lc_off[arg]; t < lc_off[arg + 1]; t++) acc = sc_add(acc, sc_mul(lc_coeff[t], value(lc_var[t], b)));
@@ -337,7 +524,15 @@ struct K_witness {  // thread per proof (sequential program)
         return bit ? sc_one_mont() : sc_zero();
     }
     HD void operator()(uint32_t b) const {
+        uint32_t pi = 0;
         for (uint32_t i = 0; i < n; i++) {
+            if (pi < n_perms && perms[pi].first_mul == i) {
+                const PoseidonPerm& pm = perms[pi++];
+                const PoseidonTab& t = ptab[pm.table];
+                sc sh[PS_SIZE];
+                for (uint32_t k = 0; k < t.width; k++) sh[PS_N + k] = operand(WK_LC, pm.in_lc[k], b);
+                poseidon_team(t, pconst, scratch(b), sh, 8, 0);
+            }
             WOp op = ops[i];
             sc l = operand(op.lkind, op.larg, b);
             W[((size_t)0 * n + i) * B + b] = l;

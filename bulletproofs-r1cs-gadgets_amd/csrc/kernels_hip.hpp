@@ -31,6 +31,8 @@ struct WireCache {
 template <int T>
 __device__ inline sc team_operand(const K_witness& p, uint32_t kind, uint32_t arg, uint32_t b, uint32_t lane, const WireCache& wc, bool& fenced) {
     if (kind == WK_ZERO) return sc_zero();
+    if (kind == WK_PX) return p.scratch(b).at(PX_A, arg);      // written (and fenced) by poseidon_team
+    if (kind == WK_PXINV) return p.scratch(b).at(PX_INVA, arg);
     if (kind == WK_VAR) {
         uint32_t vk = arg >> 28, vi = arg & 0x0fffffffu;
         if (vk >= VK_LEFT && vk <= VK_OUT) {
@@ -64,7 +66,21 @@ __global__ void __launch_bounds__(64) k_witness_team(K_witness p) {
     WireCache wc;
     wc.idx[0] = wc.idx[1] = 0xffffffffu;
     bool fenced = true;
+    __shared__ sc team_sh[64 / T][PS_SIZE];
+    sc* sh = team_sh[(threadIdx.x & 63u) / T];
+    uint32_t pi = 0;
     for (uint32_t i = 0; i < p.n; i++) {
+        if (pi < p.n_perms && p.perms[pi].first_mul == i) {  // an annotated Poseidon permutation starts here
+            const PoseidonPerm pm = p.perms[pi++];
+            const PoseidonTab t = p.ptab[pm.table];
+            for (uint32_t k = 0; k < t.width; k++) {
+                sc v = team_operand<T>(p, WK_LC, pm.in_lc[k], b, lane, wc, fenced);
+                if (lane == 0) sh[PS_N + k] = v;
+            }
+            __syncthreads();
+            poseidon_team(t, p.pconst, p.scratch(b), sh, T, lane);
+            fenced = true;
+        }
         WOp op = p.ops[i];
         sc l = team_operand<T>(p, op.lkind, op.larg, b, lane, wc, fenced);
         sc r = (op.rkind == WK_INV_LEFT) ? sc_invert(l) : team_operand<T>(p, op.rkind, op.rarg, b, lane, wc, fenced);

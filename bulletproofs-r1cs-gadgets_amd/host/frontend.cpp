@@ -97,6 +97,9 @@ bpr1cs_circuit* CircuitCompiler::finish(uint32_t* n_out, uint32_t* q_out, uint32
     std::vector<bpr1cs_wop> wops;
     std::vector<uint32_t> lc_off{0}, lc_var;
     std::vector<uint8_t> lc_coeff;
+    std::vector<std::vector<uint8_t>> pblobs;
+    std::vector<bpr1cs_poseidon_params> pparams;
+    std::vector<bpr1cs_poseidon_perm> pperms;
     if (complete && ops.size() == num_vars) {
         auto add_lc = [&](const LinearCombination& lc0) {
             LinearCombination lc = lc0.simplify();
@@ -124,9 +127,32 @@ bpr1cs_circuit* CircuitCompiler::finish(uint32_t* n_out, uint32_t* q_out, uint32
             enc(op.r, w.rkind, w.rarg);
             wops.push_back(w);
         }
+        // Poseidon annotations (Inverse S-box permutations recorded through poseidon_begin/_sbox/_end)
+        for (auto& sh : shapes) {
+            bpr1cs_poseidon_params pp{};
+            pp.width = (uint32_t)sh.width; pp.full_rounds_beginning = (uint32_t)sh.full_rounds_beginning;
+            pp.partial_rounds = (uint32_t)sh.partial_rounds; pp.full_rounds_end = (uint32_t)sh.full_rounds_end;
+            std::vector<uint8_t> mb, kb;
+            for (auto& e : sh.mds) { auto b = e.to_bytes(); mb.insert(mb.end(), b.begin(), b.end()); }
+            for (auto& e : sh.round_keys) { auto b = e.to_bytes(); kb.insert(kb.end(), b.begin(), b.end()); }
+            pblobs.push_back(std::move(mb)); pblobs.push_back(std::move(kb));
+            pparams.push_back(pp);
+        }
+        for (size_t k = 0; k < pparams.size(); k++) { pparams[k].mds = pblobs[2 * k].data(); pparams[k].round_keys = pblobs[2 * k + 1].data(); }
+        for (auto& r : perms) {
+            bpr1cs_poseidon_perm pm{};
+            pm.params = (uint32_t)r.shape;
+            for (size_t i = 0; i < r.input.size() && i < 8; i++) pm.in_lc[i] = add_lc(r.input[i]);
+            pm.sbox_mul = r.sbox_mul.data();
+            pperms.push_back(pm);
+        }
         d.wops = wops.data();
         d.n_lc = (uint32_t)(lc_off.size() - 1);
         d.lc_off = lc_off.data(); d.lc_var = lc_var.data(); d.lc_coeff = lc_coeff.data();
+        if (!pperms.empty()) {
+            d.n_poseidon_params = (uint32_t)pparams.size(); d.poseidon_params = pparams.data();
+            d.n_poseidon_perms = (uint32_t)pperms.size(); d.poseidon_perms = pperms.data();
+        }
     }
     bpr1cs_circuit* c = nullptr;
     int rc = bpr1cs_circuit_create(&d, &c);

@@ -120,6 +120,7 @@ inline Variable synthesize_sbox(ConstraintSystem& cs, SboxType t, const LinearCo
     std::optional<Scalar> val_l = cs.evaluate_lc(inp_plus_const);
     std::optional<Scalar> val_r;
     if (val_l) val_r = val_l->invert();
+    cs.poseidon_sbox();
     auto l = cs.allocate_single(val_l, WitnessHint::of_lc(inp_plus_const));
     auto r = cs.allocate_single(val_r, WitnessHint::inverse_of_left());
     is_nonzero_gadget(cs, AllocatedScalar{l.first, val_l}, AllocatedScalar{r.first, val_r});
@@ -166,6 +167,12 @@ inline std::vector<LinearCombination> Poseidon_permutation_constraints(Constrain
     };
     std::vector<LinearCombination> input_vars = std::move(input);
     size_t off = 0;
+    if (sbox_type == SboxType::Inverse) {
+        PoseidonShape sh;
+        sh.width = width; sh.full_rounds_beginning = params.full_rounds_beginning; sh.partial_rounds = params.partial_rounds;
+        sh.full_rounds_end = params.full_rounds_end; sh.mds = &params.MDS_matrix; sh.round_keys = &params.round_keys;
+        cs.poseidon_begin(input_vars, sh);
+    }
     for (size_t k = 0; k < params.full_rounds_beginning; k++) {
         std::vector<LinearCombination> outs(width);
         for (size_t i = 0; i < width; i++) outs[i] = LinearCombination(synthesize_sbox(cs, sbox_type, input_vars[i], params.round_keys[off++]));
@@ -186,6 +193,7 @@ inline std::vector<LinearCombination> Poseidon_permutation_constraints(Constrain
         for (size_t i = 0; i < width; i++) outs[i] = LinearCombination(synthesize_sbox(cs, sbox_type, input_vars[i], params.round_keys[off++]));
         input_vars = apply_linear_layer(outs);
     }
+    if (sbox_type == SboxType::Inverse) cs.poseidon_end();
     return input_vars;
 }
 

@@ -161,6 +161,13 @@ struct MulVars {
     Variable left, right, out;
 };
 
+// Shape of a Poseidon parameter set as seen by a recording constraint system (see poseidon_begin below)
+struct PoseidonShape {
+    size_t width = 0, full_rounds_beginning = 0, partial_rounds = 0, full_rounds_end = 0;
+    const std::vector<std::vector<Scalar>>* mds = nullptr;
+    const std::vector<Scalar>* round_keys = nullptr;
+};
+
 // trait bulletproofs::r1cs::ConstraintSystem (+ fork methods)
 class ConstraintSystem {
 public:
@@ -175,6 +182,12 @@ public:
     virtual void constrain(LinearCombination lc) = 0;
     virtual size_t num_constraints() const = 0;
     virtual size_t num_multipliers() const = 0;
+    // Extension over the reference API (no-ops by default): the Inverse-S-box Poseidon gadget brackets a permutation
+    // with begin/end and announces every S-box right before allocating its (x, 1/x) multiplier, so that a
+    // CircuitCompiler can annotate the witness program (bpr1cs_poseidon_perm, include/bpr1cs.h).
+    virtual void poseidon_begin(const std::vector<LinearCombination>&, const PoseidonShape&) {}
+    virtual void poseidon_sbox() {}
+    virtual void poseidon_end() {}
 };
 
 // merlin::Transcript as seen by the reference: created with a label, handed to Prover/Verifier.
@@ -398,6 +411,63 @@ public:
             op.r = h; op.have_r = h.kind != WitnessHint::None;
         }
         return Verifier::allocate_single(a, h);
+    }
+    struct PermRec {
+        size_t shape = 0;
+        std::vector<LinearCombination> input;
+        std::vector<uint32_t> sbox_mul;
+        bool ok = true;
+    };
+    struct ShapeRec {  // parameter set copied by value: the gadget's PoseidonParams need not outlive finish()
+        size_t width = 0, full_rounds_beginning = 0, partial_rounds = 0, full_rounds_end = 0;
+        std::vector<Scalar> mds, round_keys;  // mds row-major
+        bool same(const ShapeRec& o) const {
+            if (width != o.width || full_rounds_beginning != o.full_rounds_beginning || partial_rounds != o.partial_rounds ||
+                full_rounds_end != o.full_rounds_end || mds.size() != o.mds.size() || round_keys.size() != o.round_keys.size()) return false;
+            for (size_t i = 0; i < mds.size(); i++) if (!(mds[i] == o.mds[i])) return false;
+            for (size_t i = 0; i < round_keys.size(); i++) if (!(round_keys[i] == o.round_keys[i])) return false;
+            return true;
+        }
+    };
+    std::vector<ShapeRec> shapes;
+    std::vector<PermRec> perms;
+    bool in_perm = false;
+    void poseidon_begin(const std::vector<LinearCombination>& input, const PoseidonShape& sh) override {
+        if (in_perm) { perms.back().ok = false; return; }  // nested: not a shape the device macro understands
+        ShapeRec rec;
+        rec.width = sh.width; rec.full_rounds_beginning = sh.full_rounds_beginning; rec.partial_rounds = sh.partial_rounds;
+        rec.full_rounds_end = sh.full_rounds_end;
+        size_t nk = (sh.full_rounds_beginning + sh.partial_rounds + sh.full_rounds_end) * sh.width;
+        bool shape_ok = sh.mds && sh.round_keys && sh.round_keys->size() >= nk && sh.mds->size() >= sh.width;
+        if (shape_ok) {
+            for (size_t i = 0; i < sh.width; i++)
+                for (size_t j = 0; j < sh.width; j++) rec.mds.push_back((*sh.mds)[i][j]);
+            rec.round_keys.assign(sh.round_keys->begin(), sh.round_keys->begin() + nk);
+        }
+        size_t k = 0;
+        for (; k < shapes.size(); k++)
+            if (shapes[k].same(rec)) break;
+        if (k == shapes.size()) shapes.push_back(std::move(rec));
+        PermRec r;
+        r.shape = k;
+        r.input = input;
+        r.ok = shape_ok && input.size() == sh.width && sh.width <= 8;
+        perms.push_back(std::move(r));
+        in_perm = true;
+    }
+    void poseidon_sbox() override {
+        if (!in_perm) return;
+        PermRec& r = perms.back();
+        if (pending_multiplier) r.ok = false;  // x would land on a right wire: leave this permutation to the plain program
+        r.sbox_mul.push_back((uint32_t)ops.size());
+    }
+    void poseidon_end() override {
+        if (!in_perm) return;
+        in_perm = false;
+        PermRec& r = perms.back();
+        const ShapeRec& sh = shapes[r.shape];
+        if (r.sbox_mul.size() != (sh.full_rounds_beginning + sh.full_rounds_end) * sh.width + sh.partial_rounds) r.ok = false;
+        if (!r.ok) perms.pop_back();
     }
     // -> device circuit handle (caller owns)
     bpr1cs_circuit* finish(uint32_t* n_out = nullptr, uint32_t* q_out = nullptr, uint32_t* m_out = nullptr);

@@ -55,6 +55,23 @@ typedef struct {
     uint32_t lkind, larg, rkind, rarg;
 } bpr1cs_wop;
 
+/* Optional annotation of a witness program: a Poseidon permutation with the Inverse S-box
+ * (Poseidon_permutation_constraints, gadget_poseidon.rs:282-399, SboxType::Inverse :153-185).  The program stays
+ * complete without it (every S-box multiplier carries BPR1CS_W_LC / BPR1CS_W_INV_LEFT operands); with it the device
+ * evaluates the 2*fb*width + partial S-boxes of the permutation jointly - the state is carried as fractions over one
+ * common denominator and all x, 1/x wires come out of ONE field inversion instead of one per S-box.  The wires
+ * written are identical (tests/test_gpu_frontend.py::test_poseidon_joint_evaluation_equals_plain_program, tests/test_frontend.py). */
+typedef struct {
+    uint32_t width, full_rounds_beginning, partial_rounds, full_rounds_end;
+    const uint8_t* mds;        /* width*width*32, row-major MDS_matrix[i][j] */
+    const uint8_t* round_keys; /* (fb+partial+fe)*width*32 in consumption order */
+} bpr1cs_poseidon_params;
+typedef struct {
+    uint32_t params;           /* index into poseidon_params */
+    uint32_t in_lc[8];         /* ids (as in wops) of the `width` input linear combinations, before the first round key */
+    const uint32_t* sbox_mul;  /* for every S-box in synthesis order: the multiplier whose (left, right) = (x, 1/x) */
+} bpr1cs_poseidon_perm;
+
 typedef struct {
     uint32_t n; /* multipliers (len a_L)          */
     uint32_t q; /* constraints                    */
@@ -69,6 +86,11 @@ typedef struct {
     const uint32_t* lc_off;   /* n_lc+1 */
     const uint32_t* lc_var;   /* terms */
     const uint8_t* lc_coeff;  /* terms * 32 */
+    /* optional Poseidon annotations (zero / NULL when absent) */
+    uint32_t n_poseidon_params;
+    const bpr1cs_poseidon_params* poseidon_params;
+    uint32_t n_poseidon_perms;
+    const bpr1cs_poseidon_perm* poseidon_perms;
 } bpr1cs_circuit_desc;
 
 /* number of visible gfx950 devices (0 when none) */
@@ -145,6 +167,12 @@ void bpr1cs_set_window_bits(int w);
 /* tuning knob: lanes of a wavefront cooperating on one proof during witness synthesis (4, 8 or 16).
  * Fewer lanes = fewer wavefronts (less interference with a co-running batch), longer LC evaluation. */
 void bpr1cs_set_witness_team(int t);
+
+/* test knob, read by bpr1cs_circuit_create: 0 = ignore the Poseidon annotations of a circuit description and run
+ * its witness program op by op (one inversion per S-box); default 1. */
+void bpr1cs_set_witness_macro(int enable);
+/* diagnostic: number of Poseidon permutations of this circuit's witness program that are evaluated jointly */
+int bpr1cs_circuit_macro_perms(const bpr1cs_circuit* c);
 
 /* tuning knob, read by bpr1cs_gens_create: reserve n compute units (spread over the XCDs) for the
  * latency-bound kernels (TranscriptRng chain, witness synthesis) via HIP CU masks and give the rest to

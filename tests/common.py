@@ -17,8 +17,10 @@ def oracle_gens(cap):
     return _BP[cap]
 
 
-def oracle_batch(scenario_fn, cap, batch, nbl=512):
-    """Prove `batch` scenarios with the oracle; returns dict with everything the library needs."""
+def oracle_batch(scenario_fn, cap, batch, nbl=512, satisfiable=True):
+    """Prove `batch` scenarios with the oracle; returns dict with everything the library needs.
+    `satisfiable=False`: the witness violates the circuit on purpose (the proof bytes are still deterministic and
+    must match; the oracle's verifier must reject them)."""
     obp = oracle_gens(cap)
     out = dict(values=b"", blindings=b"", seeds=b"", wires=b"", proofs=[], comms=[], traces=[])
     for j in range(batch):
@@ -26,7 +28,14 @@ def oracle_batch(scenario_fn, cap, batch, nbl=512):
         bl = [S.synth_scalar(b"bl%d" % j, i) for i in range(nbl)]
         tr = {}
         pf, comms = sc.prove(PC, obp, bl, S.synth_seed(j), tr)
-        assert sc.verify(PC, obp, pf, comms)
+        if satisfiable:
+            assert sc.verify(PC, obp, pf, comms)
+        else:
+            try:
+                ok = sc.verify(PC, obp, pf, comms)
+            except Exception:
+                ok = False
+            assert not ok
         out["values"] += b"".join(sc_to_bytes(x) for x in tr["v"])
         out["blindings"] += b"".join(sc_to_bytes(x) for x in tr["v_blinding"])
         out["seeds"] += S.synth_seed(j)

@@ -29,9 +29,12 @@ def case(name, j=0):
         return "factors", [], [323], S.factors(), 4
     if name.startswith("poseidon_hash_2"):
         sbox = g.CUBE if "cube" in name else g.INVERSE
-        pr = 1 if name.endswith("pr1") else 140
+        pr = 1 if "pr1" in name else 140
         params = S.poseidon_params(pr)
-        sc = S.poseidon_hash_2(S.synth_scalar(b"xl", j), S.synth_scalar(b"xr", j), sbox, params)
+        xl = S.synth_scalar(b"xl", j)
+        if name.endswith("_zero"):      # first-round S-box input of element 1 = xl + round_key[1] = 0
+            xl = (-params.round_keys[1]) % L
+        sc = S.poseidon_hash_2(xl, S.synth_scalar(b"xr", j), sbox, params)
         n = (48 + pr) * (2 if sbox == g.CUBE else 3)
         cap = 1 << (n - 1).bit_length()
         return "poseidon_hash_2", [0 if sbox == g.CUBE else 1, pr], [sc.output], sc, cap
@@ -86,7 +89,7 @@ def check_compiled(lib, glib, name, batch, unfold=4, gens_cache={}):
     """compile the gadget with the C++ front-end, prove a batch with the DEVICE witness program,
     compare proof bytes with the oracle (which synthesises on its own)."""
     gname, ip, sp, _, cap = case(name, 0)
-    ob = common.oracle_batch(lambda j: case(name, j)[3], cap, batch)
+    ob = common.oracle_batch(lambda j: case(name, j)[3], cap, batch, satisfiable=not name.endswith("_zero"))
     circ = bp.CompiledGadget(gname, ip, sp, lib=lib, glib=glib)
     assert (circ.n, circ.q, circ.m) == (ob["n"], ob["q"], ob["m"]), (circ.n, circ.q, circ.m, ob["n"], ob["q"], ob["m"])
     assert circ.has_witness_program
@@ -98,6 +101,23 @@ def check_compiled(lib, glib, name, batch, unfold=4, gens_cache={}):
     for j in range(batch):
         assert P[j] == ob["proofs"][j], "proof %d differs (%s)" % (j, name)
     return ob, P, C
+
+
+def check_macro_vs_plain(lib, glib, name, batch):
+    gname, ip, sp, _, cap = case(name, 0)
+    try:
+        lib.bpr1cs_set_witness_macro(1)
+        circ = bp.CompiledGadget(gname, ip, sp, lib=lib, glib=glib)
+        assert lib.bpr1cs_circuit_macro_perms(circ.h) >= 1
+        circ.close()
+        check_compiled(lib, glib, name, batch)
+        lib.bpr1cs_set_witness_macro(0)
+        circ = bp.CompiledGadget(gname, ip, sp, lib=lib, glib=glib)
+        assert lib.bpr1cs_circuit_macro_perms(circ.h) == 0
+        circ.close()
+        check_compiled(lib, glib, name, batch)
+    finally:
+        lib.bpr1cs_set_witness_macro(1)
 
 
 def check_prove_single(glib, name):

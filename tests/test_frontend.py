@@ -36,3 +36,14 @@ def test_prover_single(sim_lib, sim_glib):
 @pytest.mark.parametrize("case", ["bound_check", "set_membership"])
 def test_prove_verify_roundtrip(sim_lib, sim_glib, case):
     fc.check_prove_verify_roundtrip(sim_lib, sim_glib, case)
+
+
+def test_compiled_poseidon_inverse_joint_evaluation(sim_lib, sim_glib):
+    """Inverse-S-box permutation: the annotated witness program (all S-boxes from one inversion, poseidon_team in
+    csrc/kernels.hpp) and the plain op-by-op program must both reproduce the oracle's proof bytes."""
+    fc.check_macro_vs_plain(sim_lib, sim_glib, "poseidon_hash_2_inverse_pr1", batch=2)
+
+
+def test_compiled_poseidon_inverse_zero_sbox_input(sim_lib, sim_glib):
+    """x = 0 at an S-box (Scalar::invert(0) = 0 upstream): both wires must be 0 and the other S-boxes unaffected."""
+    fc.check_macro_vs_plain(sim_lib, sim_glib, "poseidon_hash_2_inverse_pr1_zero", batch=1)

@@ -45,3 +45,11 @@ def test_prover_single_host_synthesis(hip_glib):
 @pytest.mark.parametrize("case", ["bound_check_64", "set_membership", "poseidon_hash_2_inverse", "vsmt_2_d3", "vsmt_4_l4"])
 def test_prove_verify_roundtrip_on_device(hip_lib, hip_glib, case):
     fc.check_prove_verify_roundtrip(hip_lib, hip_glib, case)
+
+
+@pytest.mark.parametrize("case", ["poseidon_hash_2_inverse", "poseidon_hash_2_inverse_pr1_zero", "vsmt_4_l4"])
+def test_poseidon_joint_evaluation_equals_plain_program(hip_lib, hip_glib, case):
+    """team kernel: the annotated program (poseidon_team: fractions over a common denominator, one inversion per
+    permutation) and the plain op-by-op program (one inversion per S-box) give the oracle's proof bytes, including
+    an S-box input of 0."""
+    fc.check_macro_vs_plain(hip_lib, hip_glib, case, batch=2 if not case.endswith("_zero") else 1)
