@@ -37,6 +37,7 @@ static void host_sponge(uint32_t rate, uint8_t suffix, const uint8_t* in, size_t
 static int g_unfold_rounds = 4;
 static int g_window_bits = 8;
 static int g_latency_cus = 0;   // >0: CUs reserved for the latency-bound kernels (see bpr1cs_gens_create)
+static int g_rng_mode = 0;       // 0 auto, 1 lane-parallel chain (k_rng_stream), 2 state per thread (k_rng_thread)
 static int g_witness_macro = 1;  // use the Poseidon annotations of a circuit description (poseidon_team)
 static int g_witness_team = 16;  // lanes cooperating on one proof in k_witness_team (4, 8 or 16)
 static uint32_t g_msm_target_threads = 1u << 21;  // (chunk, proof) threads per MSM launch
@@ -54,8 +55,10 @@ struct bpr1cs_gens {
     // HIGH-priority streams: their kernels are latency bound (one wave per proof group, few hundred
     // waves in total) and must get wave slots as soon as any short MSM workgroup retires, so that they
     // co-run with the other in-flight job's MSM/IPA kernels instead of queueing behind them.
-    dev_stream_t jstream[2][3]{};
+    dev_stream_t jstream[2][4]{};  // [slot][heavy, front, witness, isolated RNG chain]
+    bool rng_isolated = false;
     uint32_t next_job = 0;
+    int in_flight = 0;  // jobs begun and not yet ended
 };
 
 struct bpr1cs_circuit {
@@ -114,6 +117,7 @@ void bpr1cs_set_unfold_rounds(int r) { g_unfold_rounds = r < 0 ? 0 : r; }
 void bpr1cs_set_latency_cus(int n) { g_latency_cus = n < 0 ? 0 : n; }
 void bpr1cs_set_witness_team(int t) { g_witness_team = (t == 4 || t == 8) ? t : 16; }
 void bpr1cs_set_witness_macro(int enable) { g_witness_macro = enable ? 1 : 0; }
+void bpr1cs_set_rng_mode(int mode) { g_rng_mode = (mode == 1 || mode == 2) ? mode : 0; }
 int bpr1cs_circuit_macro_perms(const bpr1cs_circuit* c) { return c ? (int)c->n_perms : 0; }
 void bpr1cs_set_window_bits(int w) { g_window_bits = w < 4 ? 4 : (w > 12 ? 12 : w); }
 int bpr1cs_last_timings(float* out, int cap) {
@@ -139,24 +143,25 @@ int bpr1cs_gens_create(uint32_t cap, bpr1cs_gens** out) {
     HIPCHK(hipGetDeviceProperties(&prop, dev));
     const uint32_t ncu = (uint32_t)prop.multiProcessorCount;
     if (g_latency_cus > 0 && (uint32_t)g_latency_cus < ncu) {
-        // Partition the CUs: the latency-bound kernels (RNG Keccak chain, witness synthesis) of the NEXT
-        // batch get `g_latency_cus` CUs of their own (spread evenly over the XCDs: every k-th CU), the
-        // VALU-bound MSM/IPA stream gets the rest.  Measured: letting them share CUs costs the MSM kernels
-        // far more than the latency kernels' own issue slots (three large kernels thrash the I-cache).
+        // Reserve `g_latency_cus` CUs (every k-th one, so they spread over the XCDs) for the per-thread
+        // TranscriptRng chain (k_rng_thread): a few wavefronts of pure VALU code on the critical path.  Sharing a
+        // SIMD with anything else hurts both ways - an equal-priority neighbour halves the chain's speed, and a
+        // chain wave with raised priority starves the neighbour, which then becomes the straggler of ITS launch
+        // (measured: witness 94 -> 500 ms, K_msm_fixed 31 -> 56 ms).  Every other stream is masked off those CUs.
         const uint32_t words = (ncu + 31) / 32;
-        std::vector<uint32_t> lat(words, 0), heavy(words, 0);
+        std::vector<uint32_t> lat(words, 0), rest(words, 0);
         const uint32_t stride = ncu / (uint32_t)g_latency_cus;
         uint32_t taken = 0;
         for (uint32_t cu = 0; cu < ncu; cu++) {
             bool is_lat = (cu % stride == 0) && taken < (uint32_t)g_latency_cus;
             if (is_lat) { lat[cu / 32] |= 1u << (cu % 32); taken++; }
-            else heavy[cu / 32] |= 1u << (cu % 32);
+            else rest[cu / 32] |= 1u << (cu % 32);
         }
         for (int a = 0; a < 2; a++) {
-            HIPCHK(hipExtStreamCreateWithCUMask(&g->jstream[a][0], words, heavy.data()));
-            HIPCHK(hipExtStreamCreateWithCUMask(&g->jstream[a][1], words, lat.data()));
-            HIPCHK(hipExtStreamCreateWithCUMask(&g->jstream[a][2], words, lat.data()));
+            for (int b = 0; b < 3; b++) HIPCHK(hipExtStreamCreateWithCUMask(&g->jstream[a][b], words, rest.data()));
+            HIPCHK(hipExtStreamCreateWithCUMask(&g->jstream[a][3], words, lat.data()));
         }
+        g->rng_isolated = true;
     } else {
         for (int a = 0; a < 2; a++)
             for (int b = 0; b < 3; b++) HIPCHK(hipStreamCreateWithPriority(&g->jstream[a][b], hipStreamNonBlocking, b == 0 ? prio_lo : prio_hi));
@@ -192,7 +197,7 @@ void bpr1cs_gens_destroy(bpr1cs_gens* g) {
 #if !defined(BPR1CS_HOSTSIM)
     hipStreamDestroy(g->stream);
     for (int a = 0; a < 2; a++)
-        for (int b = 0; b < 3; b++) hipStreamDestroy(g->jstream[a][b]);
+        for (int b = 0; b < 4; b++) if (g->jstream[a][b]) hipStreamDestroy(g->jstream[a][b]);
 #endif
     delete g;
 }
@@ -322,6 +327,17 @@ int bpr1cs_circuit_create(const bpr1cs_circuit_desc* d, bpr1cs_circuit** out) {
                     if (mi >= d->n || (sidx && mi <= pp.sbox_mul[sidx - 1]) || ops[mi].lkind != WK_LC || ops[mi].rkind != WK_INV_LEFT) { ok = false; break; }
                     patched[mi] = WOp{WK_PX, sidx, WK_PXINV, sidx};
                 }
+                // do the S-box multipliers come as contiguous (x,1/x) (x,0) (x,1/x) triples?  then the macro owns them
+                bool triples = ok && (uint64_t)pm.first_mul + 3ull * S <= d->n;
+                for (uint32_t sidx = 0; sidx < S && triples; sidx++) {
+                    uint32_t mi = pm.first_mul + 3u * sidx;
+                    uint32_t L = (VK_LEFT << 28) | mi, R = (VK_RIGHT << 28) | mi;
+                    WOp a = ops[mi + 1], bb = ops[mi + 2];
+                    special(a.lkind, a.larg); special(a.rkind, a.rarg); special(bb.lkind, bb.larg); special(bb.rkind, bb.rarg);
+                    triples = pp.sbox_mul[sidx] == mi && a.lkind == WK_VAR && a.larg == L && a.rkind == WK_ZERO &&
+                              bb.lkind == WK_VAR && bb.larg == L && bb.rkind == WK_VAR && bb.rarg == R;
+                }
+                pm.covers = triples ? 3u * S : 0u;
                 pms.push_back(pm);
             }
             if (ok && !pms.empty()) {
@@ -472,7 +488,7 @@ struct bpr1cs_job {
     uint8_t* h_comms = nullptr;
     int* h_err = nullptr;
 #if !defined(BPR1CS_HOSTSIM)
-    hipEvent_t ev_in{}, ev_rng{}, ev_wit{}, ev_done{};
+    hipEvent_t ev_in{}, ev_rng{}, ev_wit{}, ev_done{}, ev_rng0{}, ev_rng1{};
 #endif
 };
 // pinned staging buffers are cached: hipHostFree (like hipFree) synchronises the whole device, which
@@ -584,7 +600,23 @@ extern "C" int bpr1cs_prove_batch_begin(const bpr1cs_gens* g, const bpr1cs_circu
     DevBuf<int> rng_err(1);
     dev_zero(rng_err.p, sizeof(int), sl);
     launch(B, K_transcript_init{d_label.p, (uint32_t)label_len, Vcomp.p, vbl_raw.p, d_seeds.p, tr.p, blind.p, sL, sR, rng.p, B, m, n}, sl);
-    hipLaunchKernelGGL(k_rng_stream, dim3((B + 1) / 2), dim3(64), 0, sl, rng.p, rng_raw.p, rng_err.p, B, draws);
+    // a batch already in flight hides this chain's latency: then take the variant with the smallest VALU footprint
+    // (only with CUs reserved for it - see bpr1cs_gens_create)
+    const bool rng_per_thread = g_rng_mode == 2 || (g_rng_mode == 0 && g->rng_isolated && g->in_flight > 0);
+    if (rng_per_thread && !g->rng_isolated) {
+        hipLaunchKernelGGL(k_rng_thread, dim3((B + 63) / 64), dim3(64), 0, sl, rng.p, rng_raw.p, rng_err.p, B, draws);
+    } else if (rng_per_thread) {
+        dev_stream_t sr = g->jstream[slot][3];
+        hipEvent_t& e0 = job->ev_rng0;
+        hipEvent_t& e1 = job->ev_rng1;
+        HIPCHK(hipEventCreateWithFlags(&e0, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&e1, hipEventDisableTiming));
+        HIPCHK(hipEventRecord(e0, sl));
+        HIPCHK(hipStreamWaitEvent(sr, e0, 0));
+        hipLaunchKernelGGL(k_rng_thread, dim3((B + 63) / 64), dim3(64), 0, sr, rng.p, rng_raw.p, rng_err.p, B, draws);
+        HIPCHK(hipEventRecord(e1, sr));
+        HIPCHK(hipStreamWaitEvent(sl, e1, 0));
+    } else hipLaunchKernelGGL(k_rng_stream, dim3((B + 1) / 2), dim3(64), 0, sl, rng.p, rng_raw.p, rng_err.p, B, draws);
     HIPCHK(hipGetLastError());
     launch((uint64_t)draws * B, K_rng_reduce{rng_raw.p, blind.p, sL, sR, B, n}, sl);
     HIPCHK(hipEventRecord(ev_rng, sl));
@@ -733,6 +765,7 @@ extern "C" int bpr1cs_prove_batch_begin(const bpr1cs_gens* g, const bpr1cs_circu
     HIPCHK(hipEventCreateWithFlags(&job->ev_done, hipEventDisableTiming));
     HIPCHK(hipEventRecord(job->ev_done, st));
 #endif
+    const_cast<bpr1cs_gens*>(g)->in_flight++;
     *job_out = job;
     return BPR1CS_OK;
 }
@@ -755,12 +788,15 @@ extern "C" int bpr1cs_prove_batch_end(bpr1cs_job* job, uint8_t* proofs_out, uint
     HIPCHK(hipEventDestroy(job->ev_in));
     HIPCHK(hipEventDestroy(job->ev_rng));
     if (job->ev_wit) HIPCHK(hipEventDestroy(job->ev_wit));
+    if (job->ev_rng0) HIPCHK(hipEventDestroy(job->ev_rng0));
+    if (job->ev_rng1) HIPCHK(hipEventDestroy(job->ev_rng1));
     HIPCHK(hipEventDestroy(job->ev_done));
 #endif
     for (void* p : job->deferred) dev_free_now(p);
     host_stage_free(job->h_proofs);
     host_stage_free(job->h_comms);
     host_stage_free(job->h_err);
+    const_cast<bpr1cs_gens*>(job->g)->in_flight--;
     delete job;
     return rc;
 }

@@ -327,10 +327,12 @@ struct WOp {
 // phase one after the other.  Cross-phase state lives in `sh` (LDS on the GPU) and in the px scratch.
 #if defined(__HIP_DEVICE_COMPILE__)
 #define TEAM_LANES(lane, T, mylane) for (uint32_t lane = (mylane), once_ = 1; once_; once_ = 0)
-#define TEAM_SYNC() do { __threadfence_block(); __syncthreads(); } while (0)
+#define TEAM_SYNC() do { __threadfence_block(); __syncthreads(); } while (0)  // LDS + global scratch exchange
+#define TEAM_SYNC_LDS() __syncthreads()                                        // LDS exchange only
 #else
 #define TEAM_LANES(lane, T, mylane) for (uint32_t lane = 0; lane < (T); lane++)
 #define TEAM_SYNC() do { } while (0)
+#define TEAM_SYNC_LDS() do { } while (0)
 #endif
 struct PoseidonTab {  // one parameter set (reference PoseidonParams, gadget_poseidon.rs:31-93); offsets into pconst
     uint32_t width, fb, pr, fe;
@@ -340,6 +342,9 @@ struct PoseidonPerm {
     uint32_t first_mul;  // the permutation is evaluated right before this multiplier
     uint32_t table;
     uint32_t in_lc[8];   // linear combinations of its inputs (before the first round key)
+    uint32_t covers;     // != 0: multipliers [first_mul, first_mul + covers) are exactly the (x,1/x,1) (x,0,0) (x,1/x,1)
+                         // triples of its S-boxes (synthesize_inverse_sbox + is_nonzero_gadget); poseidon_team writes
+                         // their wires itself and the program resumes after them
 };
 enum { PS_N = 0, PS_AV = 8, PS_T1 = 16, PS_PRE = 24, PS_SUF = 32, PS_Z = 40, PS_D = 48, PS_D2 = 50, PS_SIZE = 51 };
 enum { PX_A = 0, PX_C = 1, PX_INVA = 2, PX_UI = 3 };  // after the macro: PX_A holds x, PX_INVA holds 1/x
@@ -347,6 +352,8 @@ struct PoseidonScratch {
     sc* px;        // [4][stride][B]
     uint8_t* zf;   // [stride][B]
     uint32_t stride, B, b;
+    sc* W;         // wires [3][n][B] (written directly when the permutation covers its multipliers)
+    uint32_t n;
     HD sc& at(uint32_t arr, uint32_t s) const { return px[((size_t)arr * stride + s) * B + b]; }
     HD uint8_t& z(uint32_t s) const { return zf[(size_t)s * B + b]; }
 };
@@ -358,7 +365,8 @@ HD inline uint32_t poseidon_round_start(const PoseidonTab& t, uint32_t k) {
     return base + ((k - base) / w) * w;
 }
 // sh[PS_N + i] must hold the input state (Montgomery) on entry
-HD inline void poseidon_team(const PoseidonTab& t, const sc* pconst, const PoseidonScratch& ps, sc* sh, uint32_t T, uint32_t mylane) {
+HD inline void poseidon_team(const PoseidonTab& t, const sc* pconst, const PoseidonScratch& ps, sc* sh, uint32_t T, uint32_t mylane,
+                              uint32_t first_mul, uint32_t covers) {
     const uint32_t w = t.width, l = w - 1;
     const sc* M = pconst + t.mds_off;
     const sc* RK = pconst + t.rk_off;
@@ -383,7 +391,7 @@ HD inline void poseidon_team(const PoseidonTab& t, const sc* pconst, const Posei
                     ps.z(s + lane) = (uint8_t)z;
                 }
             }
-            TEAM_SYNC();
+            TEAM_SYNC_LDS();
             TEAM_LANES(lane, T, mylane) {
                 if (lane < 3) {  // 0: exclusive prefix products, 1: exclusive suffix products, 2: the C chain
                     sc acc = lane == 2 ? sh[PS_D + cur] : sc_one_mont();
@@ -399,7 +407,7 @@ HD inline void poseidon_team(const PoseidonTab& t, const sc* pconst, const Posei
                     sh[PS_D2] = sc_mul(sh[PS_D + cur], sh[PS_D + cur]);
                 }
             }
-            TEAM_SYNC();
+            TEAM_SYNC_LDS();
             TEAM_LANES(lane, T, mylane) {
                 if (lane < w) {
                     sc q = sc_mul(sh[PS_PRE + lane], sh[PS_SUF + lane]);
@@ -407,7 +415,7 @@ HD inline void poseidon_team(const PoseidonTab& t, const sc* pconst, const Posei
                     sh[PS_T1 + lane] = q;
                 }
             }
-            TEAM_SYNC();
+            TEAM_SYNC_LDS();
             TEAM_LANES(lane, T, mylane) {
                 if (lane < w) {
                     sc bi = sc_zero();
@@ -415,7 +423,7 @@ HD inline void poseidon_team(const PoseidonTab& t, const sc* pconst, const Posei
                     sh[PS_N + lane] = sc_mul(sh[PS_D2], bi);
                 }
             }
-            TEAM_SYNC();
+            TEAM_SYNC_LDS();
             cur ^= 1u;
             s += w;
         } else {
@@ -437,7 +445,7 @@ HD inline void poseidon_team(const PoseidonTab& t, const sc* pconst, const Posei
                     sh[PS_D2] = sc_mul(sh[PS_D + cur], sh[PS_D + cur]);
                 }
             }
-            TEAM_SYNC();
+            TEAM_SYNC_LDS();
             TEAM_LANES(lane, T, mylane) {
                 if (lane < w) {
                     sc v = sc_mul(sh[PS_AV], sh[PS_T1 + lane]);
@@ -449,11 +457,12 @@ HD inline void poseidon_team(const PoseidonTab& t, const sc* pconst, const Posei
                     ps.at(PX_C, s + 1) = dn;
                 }
             }
-            TEAM_SYNC();
+            TEAM_SYNC_LDS();
             cur ^= 1u;
             s += 1;
         }
     }
+    TEAM_SYNC();
     // back-substitution: lane segments of the S-box list, one inversion each (in lock step)
     const uint32_t seg = (S + T - 1) / T;
     TEAM_LANES(lane, T, mylane) {
@@ -474,9 +483,17 @@ HD inline void poseidon_team(const PoseidonTab& t, const sc* pconst, const Posei
             uint32_t rs = poseidon_round_start(t, k);
             sc x = sc_mul(ps.at(PX_A, k), ps.at(PX_UI, rs));
             sc xi = sc_mul(ps.at(PX_C, rs), ps.at(PX_INVA, k));
-            if (ps.z(k)) { x = sc_zero(); xi = sc_zero(); }
+            sc o = sc_one_mont();
+            if (ps.z(k)) { x = sc_zero(); xi = sc_zero(); o = sc_zero(); }
             ps.at(PX_A, k) = x;
             ps.at(PX_INVA, k) = xi;
+            if (covers) {
+                size_t m0 = (size_t)first_mul + 3u * k, nB = (size_t)ps.n * ps.B;
+                sc* w = ps.W + m0 * ps.B + ps.b;
+                w[0] = x;             w[nB] = xi;                     w[2 * nB] = o;            // allocate_single pair
+                w[ps.B] = x;          w[nB + ps.B] = sc_zero();       w[2 * nB + ps.B] = sc_zero();  // x * (1 - 1)
+                w[2 * (size_t)ps.B] = x; w[nB + 2 * (size_t)ps.B] = xi; w[2 * nB + 2 * (size_t)ps.B] = o;  // x * x_inv
+            }
         }
     }
     TEAM_SYNC();
@@ -500,7 +517,7 @@ struct K_witness {  // thread per proof (sequential program)
     sc* px = nullptr;
     uint8_t* pzf = nullptr;
     uint32_t px_stride = 0;
-    HD PoseidonScratch scratch(uint32_t b) const { return PoseidonScratch{px, pzf, px_stride, B, b}; }
+    HD PoseidonScratch scratch(uint32_t b) const { return PoseidonScratch{px, pzf, px_stride, B, b, W, n}; }
     HD sc value(uint32_t var, uint32_t b) const {
         uint32_t kind = var >> 28, idx = var & 0x0fffffffu;
         if (kind == VK_COMMITTED) return v_m[(size_t)idx * B + b];
@@ -531,7 +548,8 @@ struct K_witness {  // thread per proof (sequential program)
                 const PoseidonTab& t = ptab[pm.table];
                 sc sh[PS_SIZE];
                 for (uint32_t k = 0; k < t.width; k++) sh[PS_N + k] = operand(WK_LC, pm.in_lc[k], b);
-                poseidon_team(t, pconst, scratch(b), sh, 8, 0);
+                poseidon_team(t, pconst, scratch(b), sh, 8, 0, pm.first_mul, pm.covers);
+                if (pm.covers) { i += pm.covers - 1; continue; }
             }
             WOp op = ops[i];
             sc l = operand(op.lkind, op.larg, b);

@@ -78,8 +78,12 @@ __global__ void __launch_bounds__(64) k_witness_team(K_witness p) {
                 if (lane == 0) sh[PS_N + k] = v;
             }
             __syncthreads();
-            poseidon_team(t, p.pconst, p.scratch(b), sh, T, lane);
+            poseidon_team(t, p.pconst, p.scratch(b), sh, T, lane, pm.first_mul, pm.covers);
             fenced = true;
+            if (pm.covers) {  // its multipliers are written; none of them is in the register cache
+                i += pm.covers - 1;
+                continue;
+            }
         }
         WOp op = p.ops[i];
         sc l = team_operand<T>(p, op.lkind, op.larg, b, lane, wc, fenced);
@@ -153,6 +157,91 @@ __global__ void __launch_bounds__(64) k_rng_stream(const strobe* rng_in, uint64_
         if (i < 8) {
             if (valid) raw_out[((size_t)d * B + b) * 8 + i] = a;
             a = 0;  // prf squeeze zeroes the bytes it returns
+        }
+    }
+}
+
+// ---- Keccak-f[1600] on 32-bit halves with the gfx950 three-input logic op (v_bitop3_b32: one instruction for
+// a^b^c and for a^(~b&c)) and v_alignbit_b32 funnel shifts: 180 VALU instructions per round instead of ~330.
+#define K_XOR3(a, b, c) __builtin_amdgcn_bitop3_b32((a), (b), (c), 0x96)
+#define K_CHI(a, b, c) __builtin_amdgcn_bitop3_b32((a), (b), (c), 0xd2)  // a ^ (~b & c)
+template <int N>
+__device__ inline void k_rol(uint32_t lo, uint32_t hi, uint32_t& olo, uint32_t& ohi) {
+    if (N == 0) { olo = lo; ohi = hi; }
+    else if (N == 32) { olo = hi; ohi = lo; }
+    else if (N < 32) { ohi = __builtin_amdgcn_alignbit(hi, lo, 32 - N); olo = __builtin_amdgcn_alignbit(lo, hi, 32 - N); }
+    else { ohi = __builtin_amdgcn_alignbit(lo, hi, 64 - N); olo = __builtin_amdgcn_alignbit(hi, lo, 64 - N); }
+}
+__device__ inline void keccak_f1600_halves(uint32_t* L, uint32_t* H) {
+    for (int r = 0; r < 24; r++) {
+        uint32_t cl[5], ch[5], rl[5], rh[5];
+#pragma unroll
+        for (int x = 0; x < 5; x++) {
+            cl[x] = K_XOR3(K_XOR3(L[x], L[x + 5], L[x + 10]), L[x + 15], L[x + 20]);
+            ch[x] = K_XOR3(K_XOR3(H[x], H[x + 5], H[x + 10]), H[x + 15], H[x + 20]);
+        }
+#pragma unroll
+        for (int x = 0; x < 5; x++) k_rol<1>(cl[x], ch[x], rl[x], rh[x]);
+#pragma unroll
+        for (int x = 0; x < 5; x++)
+#pragma unroll
+            for (int y = 0; y < 5; y++) {  // theta: a ^= c[x-1] ^ rol(c[x+1], 1)
+                L[x + 5 * y] = K_XOR3(L[x + 5 * y], cl[(x + 4) % 5], rl[(x + 1) % 5]);
+                H[x + 5 * y] = K_XOR3(H[x + 5 * y], ch[(x + 4) % 5], rh[(x + 1) % 5]);
+            }
+        uint32_t bl[25], bh[25];  // rho + pi: B[y][2x+3y] = rol(A[x][y], r[x][y]);  index = x + 5y
+#define RP(dst, src, n) k_rol<n>(L[src], H[src], bl[dst], bh[dst]);
+        RP(0, 0, 0) RP(10, 1, 1) RP(20, 2, 62) RP(5, 3, 28) RP(15, 4, 27)
+        RP(16, 5, 36) RP(1, 6, 44) RP(11, 7, 6) RP(21, 8, 55) RP(6, 9, 20)
+        RP(7, 10, 3) RP(17, 11, 10) RP(2, 12, 43) RP(12, 13, 25) RP(22, 14, 39)
+        RP(23, 15, 41) RP(8, 16, 45) RP(18, 17, 15) RP(3, 18, 21) RP(13, 19, 8)
+        RP(14, 20, 18) RP(24, 21, 2) RP(9, 22, 61) RP(19, 23, 56) RP(4, 24, 14)
+#undef RP
+#pragma unroll
+        for (int y = 0; y < 5; y++)
+#pragma unroll
+            for (int x = 0; x < 5; x++) {
+                L[x + 5 * y] = K_CHI(bl[x + 5 * y], bl[(x + 1) % 5 + 5 * y], bl[(x + 2) % 5 + 5 * y]);
+                H[x + 5 * y] = K_CHI(bh[x + 5 * y], bh[(x + 1) % 5 + 5 * y], bh[(x + 2) % 5 + 5 * y]);
+            }
+        uint64_t rc = KECCAK_RC[r];
+        L[0] ^= (uint32_t)rc;
+        H[0] ^= (uint32_t)(rc >> 32);
+    }
+}
+
+// The same chain, ONE Keccak state per thread (all 25 lanes in registers, no cross-lane traffic): ~7x fewer
+// wavefront-instructions per permutation than k_rng_stream (64 states per wavefront-instruction instead of 2) at
+// ~1.5x the latency of a draw.  Used when another batch is in flight (bpr1cs_prove_batch_begin/_end): there the
+// chain's latency hides behind that batch's MSM/IPA phases and what counts is how few VALU issue slots it takes
+// from them.
+__global__ void __launch_bounds__(64) k_rng_thread(const strobe* rng_in, uint64_t* raw_out, int* err, uint32_t B, uint32_t draws) {
+    __builtin_amdgcn_s_setprio(3);  // a handful of wavefronts on the critical path: never wait behind co-resident MSM waves
+    const uint32_t b = blockIdx.x * 64u + threadIdx.x;
+    if (b >= B) return;
+    if (rng_in[b].pos != 64 || rng_in[b].pos_begin != 0) {
+        atomicExch(err, 1);
+        return;
+    }
+    uint32_t L[25], H[25];
+#pragma unroll
+    for (int i = 0; i < 25; i++) {
+        uint64_t v = rng_in[b].st[i];
+        L[i] = (uint32_t)v;
+        H[i] = (uint32_t)(v >> 32);
+    }
+    for (uint32_t d = 0; d < draws; d++) {
+        // STROBE framing of fill_bytes(64) in the steady state (see k_rng_stream): lanes 8, 9, 20
+        L[8] ^= 0x00401200u; H[8] ^= 0x07410000u;
+        L[9] ^= 0x00000447u;
+        H[20] ^= 0x80000000u;
+        keccak_f1600_halves(L, H);
+        uint64_t* o = raw_out + ((size_t)d * B + b) * 8;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            o[i] = ((uint64_t)H[i] << 32) | L[i];
+            L[i] = 0;  // prf squeeze zeroes the bytes it returns
+            H[i] = 0;
         }
     }
 }

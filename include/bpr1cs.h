@@ -168,15 +168,22 @@ void bpr1cs_set_window_bits(int w);
  * Fewer lanes = fewer wavefronts (less interference with a co-running batch), longer LC evaluation. */
 void bpr1cs_set_witness_team(int t);
 
+/* tuning knob: how the sequential TranscriptRng chain of a proof (one Keccak-f[1600] per blinding draw) is mapped.
+ * 1 = one state over 25 lanes of a wavefront (lowest latency), 2 = one state per thread (12x fewer wavefront
+ * instructions, ~1.4x the latency; its wavefronts are pure VALU code and only pay off on SIMDs of their own,
+ * see bpr1cs_set_latency_cus), 0 = automatic: 1 unless CUs are reserved and another batch is in flight. */
+void bpr1cs_set_rng_mode(int mode);
+
 /* test knob, read by bpr1cs_circuit_create: 0 = ignore the Poseidon annotations of a circuit description and run
  * its witness program op by op (one inversion per S-box); default 1. */
 void bpr1cs_set_witness_macro(int enable);
 /* diagnostic: number of Poseidon permutations of this circuit's witness program that are evaluated jointly */
 int bpr1cs_circuit_macro_perms(const bpr1cs_circuit* c);
 
-/* tuning knob, read by bpr1cs_gens_create: reserve n compute units (spread over the XCDs) for the
- * latency-bound kernels (TranscriptRng chain, witness synthesis) via HIP CU masks and give the rest to
- * the MSM/IPA stream.  Only useful with two jobs in flight (bpr1cs_prove_batch_begin/_end); 0 = off. */
+/* experimental knob, read by bpr1cs_gens_create: reserve n compute units (HIP CU masks) for the per-thread
+ * TranscriptRng chain (rng mode 2) and mask every other stream off them; rng mode 0 then picks mode 2 while another
+ * batch is in flight.  Default 0 = off: on ROCm 7.2 / MI355X CU-masked streams cost far more than they save
+ * (measured 1270 -> 830 proofs/s synchronous), see DESIGN.md. */
 void bpr1cs_set_latency_cus(int n);
 
 /* last prove_batch phase timings in milliseconds (HIP events), for bench.py:

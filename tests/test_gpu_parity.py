@@ -57,3 +57,15 @@ def test_bound_check_64bit(hip_lib):
 
 def test_poseidon_hash_2_cube(hip_lib):
     common.check_against_oracle(hip_lib, lambda j: S.poseidon_hash_2(S.synth_scalar(b"xl", j), S.synth_scalar(b"xr", j), g.CUBE), 512, 2, 4)
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+def test_rng_chain_mappings_agree(hip_lib, mode):
+    """TranscriptRng chain: one Keccak state over 25 lanes (k_rng_stream) and one state per thread (k_rng_thread)
+    must both reproduce the oracle's blinding factors, i.e. its proof bytes; ragged batch (not a multiple of 64)."""
+    try:
+        hip_lib.bpr1cs_set_rng_mode(mode)
+        common.check_against_oracle(hip_lib, lambda j: S.bound_check(37 + j, 10, 100, 7), 16, 3, 2)
+        common.check_against_oracle(hip_lib, lambda j: S.set_membership([2, 3, 5, 6, 8, 20, 25][j % 7], [2, 3, 5, 6, 8, 20, 25]), 32, 2, 2)
+    finally:
+        hip_lib.bpr1cs_set_rng_mode(0)
