@@ -80,6 +80,15 @@ HD inline fe fe_neg(const fe& a) {
 // Cost: 90 v_mad_i64_i32 + 18 carry steps (pass 1: shift+mask, pass 2: add+shift+mask+sub).
 #define FE_COLUMN_TAIL_FLOOR(acc, c, t) { c = (acc) >> 29; t = (int32_t)((uint32_t)(acc) & FE_MASK); }
 #define FE_COLUMN_TAIL_ROUND(acc, c, t) { int64_t x_ = (acc) + (1 << 28); c = x_ >> 29; t = (int32_t)((uint32_t)x_ & FE_MASK) - (1 << 28); }
+// acc += x * y (32x32 -> 64 signed).  On the device the multiply-add is pinned as ONE v_mad_i64_i32 whose addend is
+// the running column sum, so a column chain starts from the carry of the previous column; left to itself the
+// compiler starts every chain from 0 and spends a 64-bit add (as expensive as the multiply-add) per column to
+// bring the carry in.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define FE_MAD(acc, x, y) { uint64_t sd_; asm("v_mad_i64_i32 %0, %1, %2, %3, %0" : "+v"(acc), "=s"(sd_) : "v"(x), "v"(y)); }
+#else
+#define FE_MAD(acc, x, y) acc += (int64_t)(x) * (int64_t)(y)
+#endif
 
 HD inline fe fe_mul(const fe& a, const fe& b) {
     int32_t t[18];
@@ -90,26 +99,31 @@ HD inline fe fe_mul(const fe& a, const fe& b) {
 #pragma unroll
         for (int i = 0; i < 9; i++) {
             int j = k - i;
-            if (j >= 0 && j < 9) acc += (int64_t)a.v[i] * b.v[j];
+            if (j >= 0 && j < 9) FE_MAD(acc, a.v[i], b.v[j]);
         }
         FE_COLUMN_TAIL_FLOOR(acc, c, t[k]);
     }
     t[17] = (int32_t)c;
     fe r;
-    c = 0;
+    const int32_t k1216 = 1216;
+    c = 1 << 28;  // rounding bias of column 0; later columns get theirs with the carry
 #pragma unroll
     for (int k = 0; k < 8; k++) {
-        int64_t acc = c + (int64_t)t[k + 9] * 1216;
+        int64_t acc = c;
+        FE_MAD(acc, t[k + 9], k1216);
 #pragma unroll
         for (int i = 0; i < 9; i++) {
             int j = k - i;
-            if (j >= 0 && j < 9) acc += (int64_t)a.v[i] * b.v[j];
+            if (j >= 0 && j < 9) FE_MAD(acc, a.v[i], b.v[j]);
         }
-        FE_COLUMN_TAIL_ROUND(acc, c, r.v[k]);
+        c = (acc >> 29) + (1 << 28);
+        r.v[k] = (int32_t)((uint32_t)acc & FE_MASK) - (1 << 28);
     }
     {
-        int64_t acc = c + (int64_t)t[17] * 1216 + t[8];
-        FE_COLUMN_TAIL_ROUND(acc, c, r.v[8]);
+        int64_t acc = c + t[8];
+        FE_MAD(acc, t[17], k1216);
+        c = acc >> 29;
+        r.v[8] = (int32_t)((uint32_t)acc & FE_MASK) - (1 << 28);
     }
     r.v[0] += (int32_t)c * 1216;  // |c| < 2^13
     return r;
@@ -127,28 +141,33 @@ HD inline fe fe_sq(const fe& a) {
 #pragma unroll
         for (int i = 0; i < 9; i++) {
             int j = k - i;
-            if (j > i && j < 9) acc += (int64_t)d[i] * a.v[j];
+            if (j > i && j < 9) FE_MAD(acc, d[i], a.v[j]);
         }
-        if ((k & 1) == 0) acc += (int64_t)a.v[k >> 1] * a.v[k >> 1];
+        if ((k & 1) == 0) FE_MAD(acc, a.v[k >> 1], a.v[k >> 1]);
         FE_COLUMN_TAIL_FLOOR(acc, c, t[k]);
     }
     t[17] = (int32_t)c;
     fe r;
-    c = 0;
+    const int32_t k1216 = 1216;
+    c = 1 << 28;
 #pragma unroll
     for (int k = 0; k < 8; k++) {
-        int64_t acc = c + (int64_t)t[k + 9] * 1216;
+        int64_t acc = c;
+        FE_MAD(acc, t[k + 9], k1216);
 #pragma unroll
         for (int i = 0; i < 9; i++) {
             int j = k - i;
-            if (j > i && j < 9) acc += (int64_t)d[i] * a.v[j];
+            if (j > i && j < 9) FE_MAD(acc, d[i], a.v[j]);
         }
-        if ((k & 1) == 0) acc += (int64_t)a.v[k >> 1] * a.v[k >> 1];
-        FE_COLUMN_TAIL_ROUND(acc, c, r.v[k]);
+        if ((k & 1) == 0) FE_MAD(acc, a.v[k >> 1], a.v[k >> 1]);
+        c = (acc >> 29) + (1 << 28);
+        r.v[k] = (int32_t)((uint32_t)acc & FE_MASK) - (1 << 28);
     }
     {
-        int64_t acc = c + (int64_t)t[17] * 1216 + t[8];
-        FE_COLUMN_TAIL_ROUND(acc, c, r.v[8]);
+        int64_t acc = c + t[8];
+        FE_MAD(acc, t[17], k1216);
+        c = acc >> 29;
+        r.v[8] = (int32_t)((uint32_t)acc & FE_MASK) - (1 << 28);
     }
     r.v[0] += (int32_t)c * 1216;
     return r;
