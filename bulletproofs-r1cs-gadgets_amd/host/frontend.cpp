@@ -213,6 +213,31 @@ static size_t run_gadget(const GadgetSpec& g, Harness& h) {
         vector_product_gadget(h.cs, items, bit_vars, val);
         return k + 1;
     }
+    if (g.name == "is_zero") {  // src/gadget_zero_nonzero.rs:76-110
+        is_zero_gadget(h.cs, AS(0));
+        return 1;
+    }
+    if (g.name == "not_equals") {  // src/gadget_not_equals.rs:44-110 ; ip = [expected(lo,hi)]
+        auto v = AS(0), d = AS(1), di = AS(2);
+        not_equals_gadget(h.cs, v, d, di, u64_of(g.ip, 0));
+        return 3;
+    }
+    if (g.name == "set_membership_1" || g.name == "set_non_membership") {  // ip = [k, items(lo,hi)...]
+        size_t k = g.ip.at(0);
+        std::vector<uint64_t> items;
+        for (size_t i = 0; i < k; i++) items.push_back(u64_of(g.ip, 1 + 2 * i));
+        auto v = AS(0);
+        if (g.name == "set_membership_1") {  // src/gadget_set_membership_1.rs:43-112: value, then set[i] - value
+            std::vector<AllocatedScalar> diffs;
+            for (size_t i = 0; i < k; i++) diffs.push_back(AS(1 + i));
+            set_membership_1_gadget(h.cs, v, diffs, items);
+            return k + 1;
+        }
+        std::vector<AllocatedScalar> diffs, invs;  // src/gadget_set_non_membership.rs:38-128: value, then (diff, diff^-1) pairs
+        for (size_t i = 0; i < k; i++) { diffs.push_back(AS(1 + 2 * i)); invs.push_back(AS(2 + 2 * i)); }
+        set_non_membership_gadget(h.cs, v, diffs, invs, items);
+        return 2 * k + 1;
+    }
     if (g.name == "mimc") {  // src/gadget_mimc.rs:92-175 ; sp = constants[rounds] ++ [image]
         size_t rounds = g.ip.at(0);
         std::vector<Scalar> consts(g.sp.begin(), g.sp.begin() + rounds);

@@ -68,6 +68,43 @@ inline void is_nonzero_gadget(ConstraintSystem& cs, const AllocatedScalar& x, co
     cs.constrain(m2.out - y_lc);
 }
 
+// is_zero_gadget (gadget_zero_nonzero.rs:21-43): y = inv = 0
+inline void is_zero_gadget(ConstraintSystem& cs, const AllocatedScalar& x) {
+    LinearCombination x_lc(x.variable);
+    LinearCombination one_minus_y_lc = LinearCombination(Variable::One()) * Scalar(1u);
+    LinearCombination y_lc = LinearCombination(Variable::One()) * Scalar(0u);
+    LinearCombination inv_lc = LinearCombination(Variable::One()) * Scalar(0u);
+    MulVars m1 = cs.multiply(x_lc, one_minus_y_lc);
+    cs.constrain(LinearCombination(m1.out));
+    MulVars m2 = cs.multiply(x_lc, inv_lc);
+    cs.constrain(LinearCombination(m2.out) - y_lc);
+}
+// ---- src/gadget_not_equals.rs:11-26 -----------------------------------------------
+inline void not_equals_gadget(ConstraintSystem& cs, const AllocatedScalar& v, const AllocatedScalar& diff_var,
+                              const AllocatedScalar& diff_inv_var, uint64_t expected) {
+    constrain_lc_with_scalar(cs, LinearCombination(diff_var.variable) + LinearCombination(v.variable), Scalar(expected));
+    is_nonzero_gadget(cs, diff_var, diff_inv_var);
+}
+// ---- src/gadget_set_membership_1.rs:16-38 ------------------------------------------
+inline void set_membership_1_gadget(ConstraintSystem& cs, const AllocatedScalar& v, const std::vector<AllocatedScalar>& diff_vars,
+                                    const std::vector<uint64_t>& set) {
+    LinearCombination product(Variable::One());
+    for (size_t i = 0; i < set.size(); i++) {
+        constrain_lc_with_scalar(cs, LinearCombination(diff_vars[i].variable) + LinearCombination(v.variable), Scalar(set[i]));
+        MulVars m = cs.multiply(product, LinearCombination(diff_vars[i].variable));
+        product = LinearCombination(m.out);
+    }
+    cs.constrain(product);
+}
+// ---- src/gadget_set_non_membership.rs:17-35 -----------------------------------------
+inline void set_non_membership_gadget(ConstraintSystem& cs, const AllocatedScalar& v, const std::vector<AllocatedScalar>& diff_vars,
+                                      const std::vector<AllocatedScalar>& diff_inv_vars, const std::vector<uint64_t>& set) {
+    for (size_t i = 0; i < set.size(); i++) {
+        constrain_lc_with_scalar(cs, LinearCombination(diff_vars[i].variable) + LinearCombination(v.variable), Scalar(set[i]));
+        is_nonzero_gadget(cs, diff_vars[i], diff_inv_vars[i]);
+    }
+}
+
 // ---- src/gadget_bound_check.rs:18-45 ---------------------------------------------
 inline void bound_check_gadget(ConstraintSystem& cs, const AllocatedQuantity& v, const AllocatedQuantity& a,
                                const AllocatedQuantity& b, uint64_t max, uint64_t min, size_t bit_size) {

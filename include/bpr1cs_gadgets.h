@@ -12,6 +12,10 @@
  *   "factors"          sp=[r]                                   values: p, q                       (src/factors.rs:48-103)
  *   "bound_check"      ip=[bits, min_lo,min_hi, max_lo,max_hi]  values: v, v-min, max-v            (src/gadget_bound_check.rs:49-87)
  *   "set_membership"   ip=[k, item_lo,item_hi ...]              values: k bits, value              (src/gadget_set_membership.rs:93-134)
+ *   "set_membership_1" ip=[k, item_lo,item_hi ...]              values: value, item_i - value ...  (src/gadget_set_membership_1.rs:43-112)
+ *   "set_non_membership" ip=[k, item_lo,item_hi ...]            values: value, (item_i - value, its inverse) ... (src/gadget_set_non_membership.rs:38-128)
+ *   "not_equals"       ip=[expected_lo, expected_hi]            values: value, expected - value, its inverse (src/gadget_not_equals.rs:44-110)
+ *   "is_zero"          -                                        values: x (must be 0)              (src/gadget_zero_nonzero.rs:21-43,76-110)
  *   "mimc"             ip=[rounds] sp=[constants..., image]     values: xl, xr                     (src/gadget_mimc.rs:92-175)
  *   "poseidon_hash_2"  ip=[sbox(0 cube,1 inverse), partial_rounds] sp=[output]  values: xl, xr, 0,101,0,0       (src/gadget_poseidon.rs:692-790)
  *   "poseidon_hash_4"  ip=[sbox, partial_rounds] sp=[output]    values: x0..x3, 0,101                (:792-875)

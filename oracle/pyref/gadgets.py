@@ -82,6 +82,32 @@ def is_zero_gadget(cs, x):
     cs.constrain(o2 - LinearCombination([(One(), 0)]))
 
 
+# ---- src/gadget_not_equals.rs ------------------------------------------------
+def not_equals_gadget(cs, v, diff_var, diff_inv_var, expected):
+    """gadget_not_equals.rs:11-26."""
+    constrain_lc_with_scalar(cs, diff_var.variable + v.variable, expected)
+    is_nonzero_gadget(cs, diff_var, diff_inv_var)
+
+
+# ---- src/gadget_set_membership_1.rs -------------------------------------------
+def set_membership_1_gadget(cs, v, diff_vars, set_):
+    """gadget_set_membership_1.rs:16-38: product of (set[i] - v) must be 0."""
+    product = LinearCombination.of(One())
+    for i in range(len(set_)):
+        constrain_lc_with_scalar(cs, diff_vars[i].variable + v.variable, set_[i])
+        _, _, o = cs.multiply(product, LinearCombination.of(diff_vars[i].variable))
+        product = LinearCombination.of(o)
+    cs.constrain(product)
+
+
+# ---- src/gadget_set_non_membership.rs ------------------------------------------
+def set_non_membership_gadget(cs, v, diff_vars, diff_inv_vars, set_):
+    """gadget_set_non_membership.rs:17-35: every set[i] - v has an inverse."""
+    for i in range(len(set_)):
+        constrain_lc_with_scalar(cs, diff_vars[i].variable + v.variable, set_[i])
+        is_nonzero_gadget(cs, diff_vars[i], diff_inv_vars[i])
+
+
 # ---- src/gadget_bound_check.rs ----------------------------------------------
 def bound_check_gadget(cs, v, a, b, max_, min_, bit_size):
     """gadget_bound_check.rs:18-45."""

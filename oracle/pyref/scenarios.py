@@ -245,3 +245,72 @@ def set_membership(value, set_, label=b"SetMemebershipTest"):
         v = vr.commit(comms[len(set_)])
         g.vector_product_gadget(vr, set_, bit_vars, Alloc(v, None))
     return Scenario(label, bit_map + [value], bp, bv)
+
+
+def _commit_all(pr, vals, bl):
+    comms, allocs = [], []
+    for k, x in enumerate(vals):
+        c, v = pr.commit(x % L, bl[k])
+        comms.append(c); allocs.append(Alloc(v, x % L))
+    return comms, allocs
+
+
+def is_zero(value=0, label=b"ZeroTest"):
+    """gadget_zero_nonzero.rs:76-110 (test_is_zero_non_zero, zero half): one committed value that must be 0."""
+    def bp(pr, bl):
+        comms, a = _commit_all(pr, [value], bl)
+        g.is_zero_gadget(pr, a[0])
+        return comms
+
+    def bv(vr, comms, pc):
+        g.is_zero_gadget(vr, Alloc(vr.commit(comms[0]), None))
+    return Scenario(label, [value % L], bp, bv)
+
+
+def not_equals(value, expected, label=b"NotEqualsTest"):
+    """gadget_not_equals.rs:44-110: commits value, expected - value and its inverse."""
+    diff = (expected - value) % L
+    vals = [value % L, diff, pow(diff, L - 2, L)]
+
+    def bp(pr, bl):
+        comms, a = _commit_all(pr, vals, bl)
+        g.not_equals_gadget(pr, a[0], a[1], a[2], expected)
+        return comms
+
+    def bv(vr, comms, pc):
+        a = [Alloc(vr.commit(c), None) for c in comms]
+        g.not_equals_gadget(vr, a[0], a[1], a[2], expected)
+    return Scenario(label, vals, bp, bv)
+
+
+def set_membership_1(value, set_, label=b"SetMemebership1Test"):
+    """gadget_set_membership_1.rs:43-112: commits value and set[i] - value for every i."""
+    vals = [value % L] + [(e - value) % L for e in set_]
+
+    def bp(pr, bl):
+        comms, a = _commit_all(pr, vals, bl)
+        g.set_membership_1_gadget(pr, a[0], a[1:], set_)
+        return comms
+
+    def bv(vr, comms, pc):
+        a = [Alloc(vr.commit(c), None) for c in comms]
+        g.set_membership_1_gadget(vr, a[0], a[1:], set_)
+    return Scenario(label, vals, bp, bv)
+
+
+def set_non_membership(value, set_, label=b"SetNonMemebershipTest"):
+    """gadget_set_non_membership.rs:38-128: commits value, then (set[i] - value, its inverse) for every i."""
+    vals = [value % L]
+    for e in set_:
+        d = (e - value) % L
+        vals += [d, pow(d, L - 2, L)]
+
+    def bp(pr, bl):
+        comms, a = _commit_all(pr, vals, bl)
+        g.set_non_membership_gadget(pr, a[0], a[1::2], a[2::2], set_)
+        return comms
+
+    def bv(vr, comms, pc):
+        a = [Alloc(vr.commit(c), None) for c in comms]
+        g.set_non_membership_gadget(vr, a[0], a[1::2], a[2::2], set_)
+    return Scenario(label, vals, bp, bv)

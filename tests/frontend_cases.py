@@ -27,6 +27,22 @@ def case(name, j=0):
         return "set_membership", ip, [], S.set_membership(SET[j % len(SET)], SET), 32
     if name == "factors":
         return "factors", [], [323], S.factors(), 4
+    if name == "is_zero":
+        return "is_zero", [], [], S.is_zero(0), 2
+    if name == "is_zero_violated":
+        return "is_zero", [], [], S.is_zero(5 + j), 2
+    if name == "not_equals":
+        return "not_equals", _u64(5), [], S.not_equals(10 + j, 5), 2
+    if name == "set_membership_1":
+        ip = [len(SET)]
+        for x in SET:
+            ip += _u64(x)
+        return "set_membership_1", ip, [], S.set_membership_1(SET[(5 + j) % len(SET)], SET), 8
+    if name == "set_non_membership":
+        ip = [len(SET)]
+        for x in SET:
+            ip += _u64(x)
+        return "set_non_membership", ip, [], S.set_non_membership(10 + 30 * j, SET), 16
     if name.startswith("poseidon_hash_2"):
         sbox = g.CUBE if "cube" in name else g.INVERSE
         pr = 1 if "pr1" in name else 140
@@ -89,7 +105,7 @@ def check_compiled(lib, glib, name, batch, unfold=4, gens_cache={}):
     """compile the gadget with the C++ front-end, prove a batch with the DEVICE witness program,
     compare proof bytes with the oracle (which synthesises on its own)."""
     gname, ip, sp, _, cap = case(name, 0)
-    ob = common.oracle_batch(lambda j: case(name, j)[3], cap, batch, satisfiable=not name.endswith("_zero"))
+    ob = common.oracle_batch(lambda j: case(name, j)[3], cap, batch, satisfiable=not (name.endswith("pr1_zero") or name.endswith("_violated")))
     circ = bp.CompiledGadget(gname, ip, sp, lib=lib, glib=glib)
     assert (circ.n, circ.q, circ.m) == (ob["n"], ob["q"], ob["m"]), (circ.n, circ.q, circ.m, ob["n"], ob["q"], ob["m"])
     assert circ.has_witness_program

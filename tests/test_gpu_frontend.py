@@ -12,7 +12,8 @@ def test_native_hashes_and_trees(hip_glib):
     fc.check_trees(hip_glib, levels4=4, depth2=3, partial_rounds=2)
 
 
-@pytest.mark.parametrize("case", ["bound_check", "bound_check_64", "set_membership", "factors"])
+@pytest.mark.parametrize("case", ["bound_check", "bound_check_64", "set_membership", "factors", "is_zero", "not_equals",
+                                  "set_membership_1", "set_non_membership"])
 def test_compiled_small(hip_lib, hip_glib, case):
     fc.check_compiled(hip_lib, hip_glib, case, batch=3, unfold=2)
 
@@ -52,4 +53,4 @@ def test_poseidon_joint_evaluation_equals_plain_program(hip_lib, hip_glib, case)
     """team kernel: the annotated program (poseidon_team: fractions over a common denominator, one inversion per
     permutation) and the plain op-by-op program (one inversion per S-box) give the oracle's proof bytes, including
     an S-box input of 0."""
-    fc.check_macro_vs_plain(hip_lib, hip_glib, case, batch=2 if not case.endswith("_zero") else 1)
+    fc.check_macro_vs_plain(hip_lib, hip_glib, case, batch=2 if not case.endswith("pr1_zero") else 1)
