@@ -204,6 +204,27 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    # Outside the timed region, on every rank: cross-proof batched verification of the last batch
+    # (bpr1cs_verify_batch_combined) and the path's only exchange step, an all_gather of one 32-byte point per rank.
+    batched = None
+    comms = None
+    try:
+        _, comms = begin().finish()
+        sh = importlib.import_module("bulletproofs-r1cs-gadgets_amd.sharding")
+        torch.cuda.synchronize()
+        tb = time.perf_counter()
+        try:
+            pt, wf = bp.verify_batch_combined(gens, circ, b"VSMT", proofs, comms, B, bytes(range(32)), index_base=rank * B)
+        except Exception:  # keep the collective below matched on every rank
+            pt, wf = b"\xff" * 32, False
+        pts, all_wf = sh.gather_partial_points(pt, wf, device="cuda" if dist is not None else None)
+        accepted = bool(all_wf) and bp.points_sum_is_identity(pts)
+        tb = time.perf_counter() - tb
+        batched = {"accepted_all": accepted, "proofs": B * world, "proofs_per_s": B * world / tb,
+                   "note": "bpr1cs_verify_batch_combined + all_gather of one point per rank; not part of `value`"}
+    except Exception as e:  # pragma: no cover
+        batched = {"error": repr(e)}
+
     if rank == 0:
         steps = max(1, args.steps)
         value = world * B * steps / dt
@@ -235,13 +256,13 @@ def main():
         }
         # outside the timed region: the device verifier (Verifier::verify, one mega-check MSM per proof) on the last batch
         try:
-            _, comms = begin().finish()
             tv = time.perf_counter()
             oks = bp.verify_batch(gens, circ, b"VSMT", proofs, comms, B)
             tv = time.perf_counter() - tv
             out["verify"] = {"accepted": sum(oks), "of": B, "proofs_per_s": B / tv, "note": "bpr1cs_verify_batch, not part of `value`"}
         except Exception as e:  # pragma: no cover
             out["verify"] = {"error": repr(e)}
+        out["verify_batched"] = batched
         if world == 1 and args.cpu_proofs > 0:
             cb, cproofs = cpu_baseline(levels, root, values, blindings, seeds, m, args.cpu_proofs)
             out["cpu_baseline"] = cb

@@ -75,6 +75,8 @@ def load_library(path=None):
     lib.bpr1cs_prove_batch_end.argtypes = [vp, cp, cp]
     lib.bpr1cs_verify_batch.argtypes = [vp, vp, cp, sz, cp, cp, cp, sz, ctypes.POINTER(ctypes.c_int)]
     lib.bpr1cs_msm_fixed.argtypes = [vp, ctypes.POINTER(u32), sz, cp, sz, cp]
+    lib.bpr1cs_verify_batch_combined.argtypes = [vp, vp, cp, sz, cp, cp, cp, cp, ctypes.c_uint64, sz, cp, ctypes.POINTER(ctypes.c_int)]
+    lib.bpr1cs_points_sum.argtypes = [cp, sz, cp]
     lib.bpr1cs_set_unfold_rounds.argtypes = [ctypes.c_int]
     lib.bpr1cs_set_window_bits.argtypes = [ctypes.c_int]
     lib.bpr1cs_set_witness_team.argtypes = [ctypes.c_int]
@@ -215,6 +217,31 @@ def verify_batch(gens, circuit, label, proofs, commitments, batch, seeds=None):
     ok = (ctypes.c_int * batch)()
     _chk(gens.lib.bpr1cs_verify_batch(gens.h, circuit.h, label, len(label), pf, cm or b"\0", seeds, batch, ok))
     return [bool(x) for x in ok]
+
+
+def verify_batch_combined(gens, circuit, label, proofs, commitments, batch, batch_seed, index_base=0, seeds=None):
+    """Cross-proof batched mega-check of this caller's `batch` proofs -> (partial point: 32 bytes, wellformed: bool).
+    The whole job is accepted iff points_sum_is_identity(all callers' points) and all callers were well-formed."""
+    pf = proofs if isinstance(proofs, (bytes, bytearray)) else b"".join(proofs)
+    cm = commitments if isinstance(commitments, (bytes, bytearray)) else b"".join(b"".join(c) for c in commitments)
+    assert len(pf) == batch * circuit.proof_len and len(cm) == batch * circuit.m * 32 and len(batch_seed) == 32
+    out = ctypes.create_string_buffer(32)
+    wf = ctypes.c_int()
+    _chk(gens.lib.bpr1cs_verify_batch_combined(gens.h, circuit.h, label, len(label), pf, cm or b"\0", seeds, batch_seed, index_base, batch,
+                                               out, ctypes.byref(wf)))
+    return out.raw, bool(wf.value)
+
+
+def points_sum(points, lib=None):
+    """compressed ristretto points -> compressed sum (raises FormatError if one does not decode)"""
+    lib = lib or load_library()
+    out = ctypes.create_string_buffer(32)
+    _chk(lib.bpr1cs_points_sum(b"".join(points), len(points), out))
+    return out.raw
+
+
+def points_sum_is_identity(points, lib=None):
+    return points_sum(points, lib=lib) == bytes(32)
 
 
 class ProveJob:

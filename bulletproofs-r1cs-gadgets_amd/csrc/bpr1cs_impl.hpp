@@ -63,7 +63,8 @@ struct bpr1cs_gens {
 
 struct bpr1cs_circuit {
     uint32_t n = 0, q = 0, m = 0, N = 1, lgN = 0;
-    DevBuf<uint32_t> slot_off, ent_row;
+    DevBuf<uint32_t> slot_off, ent_row, chunk_lo, slot_chunk;
+    std::vector<uint32_t> h_slot_chunk;  // host copy: first chunk of every slot
     DevBuf<sc> ent_coeff;
     bool has_program = false;
     DevBuf<WOp> wops;
@@ -255,6 +256,18 @@ int bpr1cs_circuit_create(const bpr1cs_circuit_desc* d, bpr1cs_circuit** out) {
         }
     upload(c->slot_off, cnt, s);
     upload(c->ent_row, ent_row, s);
+    {   // chunk lists for K_flatten_chunks / K_flatten
+        std::vector<uint32_t> clo, sch(nslots + 1);
+        for (uint32_t sl = 0; sl < nslots; sl++) {
+            sch[sl] = (uint32_t)clo.size();
+            for (uint32_t t = cnt[sl]; t < cnt[sl + 1]; t += FLATTEN_CHUNK) clo.push_back(t);
+        }
+        sch[nslots] = (uint32_t)clo.size();
+        clo.push_back(cnt[nslots]);
+        c->h_slot_chunk = sch;
+        upload(c->chunk_lo, clo, s);
+        upload(c->slot_chunk, sch, s);
+    }
     upload(c->ent_coeff, ent_coeff, s);
     if (d->wops) {
         c->has_program = true;
@@ -476,6 +489,14 @@ static void run_msm(const bpr1cs_gens* g, MsmSeg s0, MsmSeg s1, uint32_t B, DevB
     g_cur_msm->terms += (uint64_t)total * B;
 }
 
+// constraint columns weighted by powers of z: wvec[slot][b] (first `nslots` slots of the circuit)
+static void run_flatten(const bpr1cs_circuit* c, uint32_t nslots, const sc* plo, const sc* phi, sc* wvec, uint32_t B, uint32_t H, dev_stream_t st) {
+    uint32_t nch = c->h_slot_chunk[nslots];
+    DevBuf<sc> part((size_t)(nch ? nch : 1) * B);
+    launch((uint64_t)nch * B, K_flatten_chunks{c->chunk_lo.p, c->ent_row.p, c->ent_coeff.p, plo, phi, part.p, B, H}, st);
+    launch((uint64_t)nslots * B, K_flatten{c->slot_chunk.p, part.p, wvec, B, 3 * c->n}, st);
+}
+
 struct bpr1cs_job {
     const bpr1cs_gens* g = nullptr;
     dev_stream_t st{}, st2{}, st3{};
@@ -685,7 +706,7 @@ extern "C" int bpr1cs_prove_batch_begin(const bpr1cs_gens* g, const bpr1cs_circu
     DevBuf<sc> plo((size_t)3 * 256 * B), phi((size_t)3 * H * B);
     launch((uint64_t)3 * B, K_pow_tables{chal.p, plo.p, phi.p, B, H}, st);
     DevBuf<sc> wvec((size_t)(3 * n + m) * B + 1);
-    launch((uint64_t)(3 * n + m) * B, K_flatten{c->slot_off.p, c->ent_row.p, c->ent_coeff.p, plo.p, phi.p, wvec.p, B, H, 3 * n}, st);
+    run_flatten(c, 3 * n + m, plo.p, phi.p, wvec.p, B, H, st);
     uint32_t tchunk, TC = pick_chunks(n, B, 1u << 16, tchunk);
     DevBuf<sc> tpart((size_t)6 * TC * B), tco((size_t)6 * B);
     launch((uint64_t)TC * B, K_tcoef_partial{W.p, wvec.p, plo.p, phi.p, tpart.p, B, H, n, tchunk, TC}, st);
@@ -845,7 +866,7 @@ extern "C" int bpr1cs_verify_batch(const bpr1cs_gens* g, const bpr1cs_circuit* c
     launch((uint64_t)3 * B, K_pow_tables{chal.p, plo.p, phi.p, B, H}, st);
     const uint32_t nslots = 3 * n + m + 1;
     DevBuf<sc> wvec((size_t)nslots * B);
-    launch((uint64_t)nslots * B, K_flatten{c->slot_off.p, c->ent_row.p, c->ent_coeff.p, plo.p, phi.p, wvec.p, B, H, 3 * n}, st);
+    run_flatten(c, nslots, plo.p, phi.p, wvec.p, B, H, st);
     DevBuf<sc> gs((size_t)N * B), hs((size_t)N * B), dpart((size_t)N * B), delta(B), bsc((size_t)2 * B);
     launch((uint64_t)N * B, K_verify_gh{wvec.p, plo.p, phi.p, chal.p, uk.p, gs.p, hs.p, dpart.p, B, H, n, N, lgN}, st);
     launch(B, K_sum_partials{dpart.p, delta.p, B, N}, st);
@@ -861,6 +882,105 @@ extern "C" int bpr1cs_verify_batch(const bpr1cs_gens* g, const bpr1cs_circuit* c
     dev_d2h(ok_out, ok.p, sizeof(int) * B, st);
     g_msm.collect();
     return BPR1CS_OK;
+}
+
+// Cross-proof batched verification: one identity test for the whole batch (and, summed over ranks, for the whole job).
+// Returns this rank's partial point; the caller adds the ranks' points (bpr1cs_points_sum) and accepts iff the sum
+// is the identity (32 zero bytes) and every rank reported `wellformed`.
+extern "C" int bpr1cs_verify_batch_combined(const bpr1cs_gens* g, const bpr1cs_circuit* c, const uint8_t* label, size_t label_len,
+                                            const uint8_t* proofs, const uint8_t* commitments, const uint8_t* verifier_rng_seeds,
+                                            const uint8_t* batch_seed, uint64_t index_base, size_t batch, uint8_t* partial_point_out,
+                                            int* wellformed_out) {
+    if (!g || !c || !label || !proofs || !batch_seed || !partial_point_out || !wellformed_out || batch == 0 || batch > (1u << 20))
+        return BPR1CS_ERR_INVALID_ARGUMENT;
+    if (c->m && !commitments) return BPR1CS_ERR_INVALID_ARGUMENT;
+    if (!have_device()) return BPR1CS_ERR_NO_DEVICE;
+    if (g->cap < c->N) return BPR1CS_ERR_INVALID_GENERATORS_LENGTH;
+    const uint32_t B = (uint32_t)batch, n = c->n, m = c->m, N = c->N, lgN = c->lgN;
+    const uint32_t baseG = 2, baseH = 2 + g->cap;
+    const size_t plen = bpr1cs_proof_len(c);
+    dev_stream_t st = g->stream;
+    DevBuf<uint8_t> d_pf((size_t)B * plen), d_vc((size_t)B * m * 32 + 1), d_seed((size_t)B * 32), d_label(label_len ? label_len : 1), d_bseed(32);
+    dev_h2d(d_pf.p, proofs, (size_t)B * plen, st);
+    if (m) dev_h2d(d_vc.p, commitments, (size_t)B * m * 32, st);
+    if (verifier_rng_seeds) dev_h2d(d_seed.p, verifier_rng_seeds, (size_t)B * 32, st);
+    else dev_zero(d_seed.p, (size_t)B * 32, st);
+    if (label_len) dev_h2d(d_label.p, label, label_len, st);
+    dev_h2d(d_bseed.p, batch_seed, 32, st);
+    DevBuf<sc> chal((size_t)VCH_COUNT * B), uk((size_t)(lgN ? lgN : 1) * 2 * B), rho(B);
+    DevBuf<int> fail(B);
+    dev_zero(fail.p, sizeof(int) * B, st);
+    launch(B, K_verify_transcript{d_label.p, (uint32_t)label_len, d_pf.p, d_vc.p, d_seed.p, chal.p, uk.p, fail.p, B, m, lgN, (uint32_t)plen, (uint64_t)N}, st);
+    launch(B, K_batch_weights{d_bseed.p, rho.p, index_base}, st);
+    uint32_t maxe = std::max<uint32_t>(N, c->q + 1);
+    uint32_t H = (maxe >> 8) + 1;
+    DevBuf<sc> plo((size_t)3 * 256 * B), phi((size_t)3 * H * B);
+    launch((uint64_t)3 * B, K_pow_tables{chal.p, plo.p, phi.p, B, H}, st);
+    const uint32_t nslots = 3 * n + m + 1;
+    DevBuf<sc> wvec((size_t)nslots * B);
+    run_flatten(c, nslots, plo.p, phi.p, wvec.p, B, H, st);
+    DevBuf<sc> gh((size_t)2 * N * B), dpart((size_t)N * B), delta(B), bsc((size_t)2 * B);
+    sc* gs = gh.p; sc* hs = gh.p + (size_t)N * B;
+    launch((uint64_t)N * B, K_verify_gh{wvec.p, plo.p, phi.p, chal.p, uk.p, gs, hs, dpart.p, B, H, n, N, lgN}, st);
+    launch(B, K_sum_partials{dpart.p, delta.p, B, N}, st);
+    launch(B, K_verify_bscalars{chal.p, wvec.p + (size_t)(3 * n + m) * B, delta.p, bsc.p, B}, st);
+    // one combined scalar per shared base
+    DevBuf<sc> cgh((size_t)2 * N), cb(2);
+    launch((uint64_t)2 * N, K_combine_scalars{gh.p, rho.p, cgh.p, B}, st);
+    launch(2, K_combine_scalars{bsc.p, rho.p, cb.p, B}, st);
+    DevBuf<ge> partial;
+    MsmPlan plan;
+    MsmSeg sg{cgh.p, N, N, N, 0, baseG, 0}, sh{cgh.p + N, N, N, N, 0, baseH, 0};
+    run_msm(g, sg, sh, 1, partial, plan, st);
+    // the proofs' own points, weighted, then summed over (point, proof)
+    const uint32_t P = 8 + m + 2 * lgN;
+    DevBuf<ge> pts((size_t)P * B), red[2];
+    K_verify_points kp{d_pf.p, d_vc.p, chal.p, uk.p, wvec.p + (size_t)3 * n * B, pts.p, fail.p, B, m, lgN, (uint32_t)plen};
+    kp.rho = rho.p;
+    launch((uint64_t)P * B, kp, st);
+    const ge* cur = pts.p;
+    uint32_t cnt = P * B;
+    int flip = 0;
+    while (cnt > 64) {
+        uint32_t outc = (cnt + 63) / 64;
+        red[flip].alloc(outc);
+        launch(outc, K_ge_reduce{cur, red[flip].p, 1, cnt, 64}, st);
+        cur = red[flip].p;
+        cnt = outc;
+        flip ^= 1;
+    }
+    const ge* mcur = partial.p;
+    uint32_t mcnt = plan.nchunks;
+    DevBuf<ge> mred[2];
+    for (int f = 0; mcnt > 64; f ^= 1) {
+        uint32_t outc = (mcnt + 63) / 64;
+        mred[f].alloc(outc);
+        launch(outc, K_ge_reduce{mcur, mred[f].p, 1, mcnt, 64}, st);
+        mcur = mred[f].p;
+        mcnt = outc;
+    }
+    DevBuf<uint8_t> d_out(32);
+    DevBuf<int> d_wf(1);
+    launch(1, K_batch_finish{g->tab.p, g->tc, mcur, cur, cb.p, fail.p, d_out.p, d_wf.p, mcnt, cnt, B}, st);
+    dev_d2h(partial_point_out, d_out.p, 32, st);
+    dev_d2h(wellformed_out, d_wf.p, sizeof(int), st);
+    g_msm.collect();
+    return BPR1CS_OK;
+}
+
+// out = compress(sum of `count` compressed points); returns FormatError if one does not decode
+extern "C" int bpr1cs_points_sum(const uint8_t* points, size_t count, uint8_t* out) {
+    if (!points || !out || count == 0 || count > (1u << 20)) return BPR1CS_ERR_INVALID_ARGUMENT;
+    if (!have_device()) return BPR1CS_ERR_NO_DEVICE;
+    dev_stream_t st{};
+    DevBuf<uint8_t> d_in(32 * count), d_out(32);
+    DevBuf<int> d_ok(1);
+    dev_h2d(d_in.p, points, 32 * count, st);
+    launch(1, K_points_sum{d_in.p, d_out.p, d_ok.p, (uint32_t)count}, st);
+    int ok = 0;
+    dev_d2h(out, d_out.p, 32, st);
+    dev_d2h(&ok, d_ok.p, sizeof(int), st);
+    return ok ? BPR1CS_OK : BPR1CS_ERR_FORMAT;
 }
 
 extern "C" int bpr1cs_msm_fixed(const bpr1cs_gens* g, const uint32_t* bases, size_t terms, const uint8_t* scalars, size_t batch,

@@ -640,19 +640,35 @@ struct K_msm_finish {  // gid = b
 
 // ------------------------------------------------------ constraints / polys
 // wvec[s][b] = sum over entries (j, c) of slot s : z^(j+1) * c   (slots 3n.. are wV, negated)
-struct K_flatten {  // gid = s*B + b
-    const uint32_t* slot_off;
+// Slots with many entries (a committed value or the constant column can appear in tens of thousands of
+// constraints) are cut into chunks of <= FLATTEN_CHUNK entries so that no single thread walks them alone:
+// pass 1 sums a chunk, pass 2 sums the chunks of a slot.
+#define FLATTEN_CHUNK 256u
+struct K_flatten_chunks {  // gid = c*B + b -> part[c][b]
+    const uint32_t* chunk_lo;  // [nchunks + 1] entry ranges (chunks of one slot are consecutive)
     const uint32_t* ent_row;
     const sc* ent_coeff;  // Montgomery
     const sc* plo;
     const sc* phi;
-    sc* wvec;  // [3n+m][B]
-    uint32_t B, H, n3;
+    sc* part;  // [nchunks][B]
+    uint32_t B, H;
+    HD void operator()(uint32_t g) const {
+        uint32_t c = g / B, b = g % B;
+        sc acc = sc_zero();
+        for (uint32_t t = chunk_lo[c]; t < chunk_lo[c + 1]; t++)
+            acc = sc_add(acc, sc_mul(pow_lookup(plo, phi, 2, H, B, ent_row[t] + 1, b), ent_coeff[t]));
+        part[g] = acc;
+    }
+};
+struct K_flatten {  // gid = s*B + b
+    const uint32_t* slot_chunk;  // [nslots + 1] first chunk of every slot
+    const sc* part;
+    sc* wvec;  // [3n+m(+1)][B]
+    uint32_t B, n3;
     HD void operator()(uint32_t g) const {
         uint32_t s = g / B, b = g % B;
         sc acc = sc_zero();
-        for (uint32_t t = slot_off[s]; t < slot_off[s + 1]; t++)
-            acc = sc_add(acc, sc_mul(pow_lookup(plo, phi, 2, H, B, ent_row[t] + 1, b), ent_coeff[t]));
+        for (uint32_t c = slot_chunk[s]; c < slot_chunk[s + 1]; c++) acc = sc_add(acc, part[(size_t)c * B + b]);
         wvec[g] = s >= n3 ? sc_neg(acc) : acc;
     }
 };
@@ -1161,6 +1177,7 @@ struct K_verify_points {  // gid = p*B + b, p < 8 + m + 2 lgN
     ge* out;          // [P][B]
     int* fail;
     uint32_t B, m, lgN, plen;
+    const sc* rho = nullptr;  // optional per-proof weight (cross-proof batching), Montgomery
     HD void operator()(uint32_t g) const {
         uint32_t p = g / B, b = g % B;
         const uint8_t* el = proofs + (size_t)b * plen + 1;
@@ -1192,7 +1209,74 @@ struct K_verify_points {  // gid = p*B + b, p < 8 + m + 2 lgN
             out[g] = ge_identity();
             return;
         }
+        if (rho) s = sc_mul(s, rho[b]);
         out[g] = ge_scalarmul_naf(P, sc_from_mont(s));
+    }
+};
+// ---- cross-proof batching of the mega-check (SURVEY §8a P10 "batchable across proofs", §8e): with per-proof
+// weights rho_b the B checks collapse into ONE identity test; the 2N+2 shared bases get one combined scalar each.
+struct K_batch_weights {  // gid = b : rho_b = challenge("rho") of Merlin("bpr1cs batch verify") <- seed, index
+    const uint8_t* seed;  // 32 bytes
+    sc* rho;              // [B] Montgomery
+    uint64_t index_base;
+    HD void operator()(uint32_t b) const {
+        strobe t;
+        const char lab[] = "bpr1cs batch verify";
+        merlin_new(t, (const uint8_t*)lab, sizeof(lab) - 1);
+        merlin_append(t, "seed", 4, seed, 32);
+        merlin_append_u64(t, "j", 1, index_base + b);
+        rho[b] = merlin_challenge_scalar(t, "rho", 3);
+    }
+};
+struct K_combine_scalars {  // gid = row : out[row] = sum_b in[row*B + b] * rho[b]   (in plain or Montgomery; out likewise)
+    const sc* in;
+    const sc* rho;  // Montgomery
+    sc* out;
+    uint32_t B;
+    HD void operator()(uint32_t row) const {
+        sc acc = sc_zero();
+        const sc* r = in + (size_t)row * B;
+        for (uint32_t b = 0; b < B; b++) acc = sc_add(acc, sc_mul(r[b], rho[b]));
+        out[row] = acc;
+    }
+};
+struct K_batch_finish {  // single thread: sum of the partial sums -> compressed point, AND of the format checks
+    const ge_niels_packed* tab;
+    TabCfg tc;
+    const ge* a;      // na points
+    const ge* b;      // nb points
+    const sc* bsc;    // [2] Montgomery: combined scalars of B and B~
+    const int* fail;  // [B]
+    uint8_t* out;     // 32 bytes
+    int* wellformed;
+    uint32_t na, nb, B;
+    HD void operator()(uint32_t) const {
+        ge acc = ge_identity();
+        for (uint32_t i = 0; i < na; i++) acc = ge_add_ge(acc, a[i]);
+        for (uint32_t i = 0; i < nb; i++) acc = ge_add_ge(acc, b[i]);
+        acc = table_mul_acc(acc, tab, sc_from_mont(bsc[0]), tc);
+        acc = table_mul_acc(acc, tab + tc.per_base, sc_from_mont(bsc[1]), tc);
+        ge_compress(acc, out);
+        int ok = 1;
+        for (uint32_t i = 0; i < B; i++) ok &= !fail[i];
+        *wellformed = ok;
+    }
+};
+struct K_points_sum {  // single thread: out = compress(sum decompress(in[i])); *ok = all decoded
+    const uint8_t* in;
+    uint8_t* out;
+    int* ok;
+    uint32_t count;
+    HD void operator()(uint32_t) const {
+        ge acc = ge_identity();
+        int good = 1;
+        for (uint32_t i = 0; i < count; i++) {
+            ge P;
+            if (!ge_decompress(in + 32 * (size_t)i, P)) { good = 0; continue; }
+            acc = ge_add_ge(acc, P);
+        }
+        ge_compress(acc, out);
+        *ok = good;
     }
 };
 struct K_verify_finish {  // gid = b : sum everything, accept iff identity

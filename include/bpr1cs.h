@@ -148,6 +148,22 @@ int bpr1cs_verify_batch(const bpr1cs_gens* g, const bpr1cs_circuit* c, const uin
                         const uint8_t* proofs, const uint8_t* commitments, const uint8_t* verifier_rng_seeds, size_t batch,
                         int* ok_out);
 
+/* Cross-proof batched verification (SURVEY §8a P10 "batchable across proofs", §8e; the reference verifies one proof
+ * at a time, gadget_vsmt_4.rs:479).  With weights rho_j = Merlin("bpr1cs batch verify", seed, index_base + j) the
+ * `batch` mega-checks collapse into one: the 2N+2 shared bases B, B~, G_i, H_i get ONE combined scalar each
+ * (sum_j rho_j * scalar_j) and a single fixed-base MSM; only the proofs' own points are handled per proof.
+ * Output: this caller's partial point (32-byte compressed) and whether all proofs were well-formed.  A job sharded
+ * over several GPUs gives every rank a disjoint `index_base` range, gathers the ranks' points (RCCL all_gather of
+ * 32 bytes per rank, see bulletproofs-r1cs-gadgets_amd/sharding.py) and accepts iff bpr1cs_points_sum of them is the
+ * identity (32 zero bytes) and every rank was well-formed.  A failing batch is then re-checked with
+ * bpr1cs_verify_batch to find the culprit. */
+int bpr1cs_verify_batch_combined(const bpr1cs_gens* gens, const bpr1cs_circuit* circuit, const uint8_t* label, size_t label_len,
+                                 const uint8_t* proofs, const uint8_t* commitments, const uint8_t* verifier_rng_seeds,
+                                 const uint8_t* batch_seed /* 32 */, uint64_t index_base, size_t batch,
+                                 uint8_t* partial_point_out /* 32 */, int* wellformed_out);
+/* out = compress(sum of `count` compressed ristretto points); BPR1CS_ERR_FORMAT if one of them does not decode */
+int bpr1cs_points_sum(const uint8_t* points, size_t count, uint8_t* out);
+
 /* Low-level, for parity tests and a Rust shim: out = sum_t scalars[t] * Base(bases[t])
  * for `batch` independent scalar vectors over the SAME fixed bases; base index:
  * 0 = B, 1 = B_blinding, 2+i = G[i], 2+capacity+i = H[i].

@@ -1,0 +1,120 @@
+"""Cross-proof batched verification (bpr1cs_verify_batch_combined + bpr1cs_points_sum): properties on the CPU
+simulator; the 2-rank exchange step runs over gloo.  GPU twin in tests/test_gpu_batched_verify.py."""
+import os
+import socket
+import sys
+
+import pytest
+
+from pyref import scenarios as S
+import common
+
+bp = common.bp
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SEED = bytes(range(32))
+
+
+def make_batch(lib, glib, batch, first=0, cap=16):
+    """bound_check(v in [10, 100], 7 bits) proofs made by the library itself (their parity with the oracle is the
+    subject of the other tests): -> (gens, circuit, label, proofs, commitments)"""
+    from pyref.ed import sc_to_bytes
+    circ = bp.CompiledGadget("bound_check", [7, 10, 0, 100, 0], [], lib=lib, glib=glib)
+    gens = bp.Gens(cap, lib=lib)
+    vals = b"".join(sc_to_bytes(x) for j in range(first, first + batch) for x in (37 + j, 27 + j, 63 - j))
+    bls = b"".join(sc_to_bytes(S.synth_scalar(b"bvb%d" % j, i)) for j in range(first, first + batch) for i in range(3))
+    seeds = b"".join(S.synth_seed(j) for j in range(first, first + batch))
+    lib.bpr1cs_set_unfold_rounds(2)
+    P, C = bp.prove_batch(gens, circ, b"BoundsTest", vals, bls, seeds, batch, wires=None)
+    return gens, circ, b"BoundsTest", P, C
+
+
+def check_batched_verify(lib, glib, batch=4):
+    gens, circ, label, P, C = make_batch(lib, glib, batch)
+    ob = {"label": label}
+    assert bp.verify_batch(gens, circ, label, P, C, batch) == [True] * batch
+    cm = C
+    # all valid: one combined identity test
+    pt, wf = bp.verify_batch_combined(gens, circ, ob["label"], P, cm, batch, SEED)
+    assert wf and pt == bytes(32)
+    # split in two "ranks" with disjoint weight indices: partial points are NOT the identity, their sum is
+    h = batch // 2
+    p0, w0 = bp.verify_batch_combined(gens, circ, ob["label"], P[:h], cm[:h], h, SEED, index_base=0)
+    p1, w1 = bp.verify_batch_combined(gens, circ, ob["label"], P[h:], cm[h:], batch - h, SEED, index_base=h)
+    assert w0 and w1 and bp.points_sum_is_identity([p0, p1], lib=lib)
+    # the per-proof partial point of a VALID shard is the identity as well (each check holds on its own)
+    assert p0 == bytes(32) and p1 == bytes(32)
+    # one tampered proof (scalar t_x changed): combined test fails, the per-proof verifier names it
+    bad = bytearray(P[1]); bad[1 + 8 * 32 + 3] ^= 1
+    Pb = [P[0], bytes(bad)] + P[2:]
+    pt, wf = bp.verify_batch_combined(gens, circ, ob["label"], Pb, cm, batch, SEED)
+    assert wf and pt != bytes(32)
+    assert bp.verify_batch(gens, circ, ob["label"], Pb, cm, batch) == [True, False] + [True] * (batch - 2)
+    # two tampered proofs cannot cancel for a different seed
+    bad2 = bytearray(P[2]); bad2[1 + 9 * 32 + 5] ^= 4
+    Pb2 = [P[0], bytes(bad), bytes(bad2)] + P[3:]
+    for sd in (SEED, bytes(32), b"\x07" * 32):
+        assert bp.verify_batch_combined(gens, circ, ob["label"], Pb2, cm, batch, sd)[0] != bytes(32)
+    # a point that does not decode: not well-formed
+    bad3 = bytearray(P[0]); bad3[1:33] = b"\xff" * 32
+    pt, wf = bp.verify_batch_combined(gens, circ, ob["label"], [bytes(bad3)] + P[1:], cm, batch, SEED)
+    assert not wf
+    # wrong commitment
+    cm2 = [list(c) for c in cm]; cm2[0][0] = cm[1][0]
+    assert bp.verify_batch_combined(gens, circ, ob["label"], P, cm2, batch, SEED)[0] != bytes(32)
+    return True
+
+
+def test_batched_verify_properties(sim_lib, sim_glib):
+    check_batched_verify(sim_lib, sim_glib)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, sim_path, gsim_path, gb, tamper, q):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import importlib
+    bpm = importlib.import_module("bulletproofs-r1cs-gadgets_amd")
+    sh = importlib.import_module("bulletproofs-r1cs-gadgets_amd.sharding")
+    import test_batched_verify as tb
+    lib = bpm.load_library(sim_path)
+    glib = bpm.load_gadgets_library(gsim_path)
+    lo, hi = sh.shard_range(gb, rank, world)
+    gens, circ, label, P, comms = tb.make_batch(lib, glib, hi - lo, first=lo)
+    ob = {"label": label}
+    P = list(P)
+    if tamper and rank == 1:
+        b = bytearray(P[0]); b[1 + 8 * 32] ^= 1; P[0] = bytes(b)
+    pt, wf = bpm.verify_batch_combined(gens, circ, ob["label"], P, comms, hi - lo, SEED, index_base=lo)
+    pts, all_wf = sh.gather_partial_points(pt, wf)     # the only collective of the path: 33 bytes per rank
+    ok = all_wf and bpm.points_sum_is_identity(pts, lib=lib)
+    q.put((rank, ok))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("tamper", [False, True])
+def test_two_rank_batched_verify_gloo(sim_lib, sim_glib, tamper):
+    import torch.multiprocessing as mp
+    world, gb = 2, 4
+    sim_path = os.path.join(ROOT, "tests", "hostsim", "_build", "libbpr1cs_sim.so")
+    gsim_path = os.path.join(ROOT, "tests", "hostsim", "_build", "libbpr1cs_gadgets_sim.so")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, sim_path, gsim_path, gb, tamper, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res == {0: not tamper, 1: not tamper}
