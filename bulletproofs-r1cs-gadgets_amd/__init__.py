@@ -77,6 +77,7 @@ def load_library(path=None):
     lib.bpr1cs_msm_fixed.argtypes = [vp, ctypes.POINTER(u32), sz, cp, sz, cp]
     lib.bpr1cs_verify_batch_combined.argtypes = [vp, vp, cp, sz, cp, cp, cp, cp, ctypes.c_uint64, sz, cp, ctypes.POINTER(ctypes.c_int)]
     lib.bpr1cs_points_sum.argtypes = [cp, sz, cp]
+    lib.bpr1cs_poseidon_permutation_batch.argtypes = [vp, ctypes.c_int, cp, sz, cp]
     lib.bpr1cs_set_unfold_rounds.argtypes = [ctypes.c_int]
     lib.bpr1cs_set_window_bits.argtypes = [ctypes.c_int]
     lib.bpr1cs_set_witness_team.argtypes = [ctypes.c_int]
@@ -232,6 +233,25 @@ def verify_batch_combined(gens, circuit, label, proofs, commitments, batch, batc
     return out.raw, bool(wf.value)
 
 
+class _PoseidonParams(ctypes.Structure):
+    _fields_ = [("width", ctypes.c_uint32), ("full_rounds_beginning", ctypes.c_uint32), ("partial_rounds", ctypes.c_uint32),
+                ("full_rounds_end", ctypes.c_uint32), ("mds", ctypes.c_char_p), ("round_keys", ctypes.c_char_p)]
+
+
+def poseidon_permutation_batch(states, inverse=True, partial_rounds=140, lib=None):
+    """Device bulk form of the reference's Poseidon_permutation (width 6, 4 + partial_rounds + 4 rounds, the
+    constants of poseidon_constants.rs): states = list of 6-lists of ints -> list of 6-lists of ints."""
+    lib = lib or load_library()
+    blob = poseidon_blob()
+    nk = (8 + partial_rounds) * 6
+    pp = _PoseidonParams(6, 4, partial_rounds, 4, blob[:36 * 32], blob[36 * 32:36 * 32 + nk * 32])
+    n = len(states)
+    inp = b"".join(_sc(x) for st in states for x in st)
+    out = ctypes.create_string_buffer(n * 6 * 32)
+    _chk(lib.bpr1cs_poseidon_permutation_batch(ctypes.byref(pp), 1 if inverse else 0, inp, n, out))
+    return [[int.from_bytes(out.raw[32 * (6 * h + i):32 * (6 * h + i) + 32], "little") for i in range(6)] for h in range(n)]
+
+
 def points_sum(points, lib=None):
     """compressed ristretto points -> compressed sum (raises FormatError if one does not decode)"""
     lib = lib or load_library()
@@ -314,6 +334,8 @@ def load_gadgets_library(path=None):
         getattr(g, "bpr1cs_%s_root" % nm).argtypes = [vp, cp]
         getattr(g, "bpr1cs_%s_update" % nm).argtypes = [vp, cp, cp]
         getattr(g, "bpr1cs_%s_get" % nm).argtypes = [vp, cp, cp, cp]
+    g.bpr1cs_vsmt4_update_many.argtypes = [vp, cp, cp, sz]
+    g.bpr1cs_vsmt4_get_many.argtypes = [vp, cp, sz, cp, cp]
     if path is None:
         _glib = g
     return g
@@ -406,6 +428,22 @@ class SparseMerkleTree:
 
     def update(self, idx, val):
         getattr(self.g, "bpr1cs_%s_update" % self.nm)(self.h, _sc(idx), _sc(val))
+
+    def update_many(self, leaves):
+        """[(idx, val), ...] with DISTINCT indices, arity 4 only: every tree level is hashed by one device launch."""
+        assert self.arity == 4
+        idx = b"".join(_sc(i) for i, _ in leaves)
+        vals = b"".join(_sc(v) for _, v in leaves)
+        _chk(self.g.bpr1cs_vsmt4_update_many(self.h, idx, vals, len(leaves)))
+
+    def get_many(self, indices):
+        """-> (leaves: bytes count*32, paths: bytes count*levels*3*32), arity 4 only; no re-hashing of the paths."""
+        assert self.arity == 4
+        n = len(indices)
+        leaves = ctypes.create_string_buffer(32 * n)
+        proofs = ctypes.create_string_buffer(32 * 3 * self.levels * n)
+        _chk(self.g.bpr1cs_vsmt4_get_many(self.h, b"".join(_sc(i) for i in indices), n, leaves, proofs))
+        return leaves.raw, proofs.raw
 
     def get(self, idx):
         """-> (leaf bytes, [node bytes...]) with the Merkle path root level first."""

@@ -96,6 +96,26 @@ static void upload(DevBuf<T>& d, const std::vector<T>& h, dev_stream_t s) {
 // canonical 32-byte scalars on the host -> Montgomery sc (host uses the same HD code)
 static sc host_mont(const uint8_t* b) { return sc_mont_from_bytes_mod_order(b); }
 
+// one Poseidon parameter set -> Montgomery tables appended to `pc` (MDS, round keys, R_i = sum_{j<w-1} M_ij k_j per partial round)
+static bool build_poseidon_tab(const bpr1cs_poseidon_params& pp, PoseidonTab& t, std::vector<sc>& pc) {
+    uint32_t w = pp.width, rounds = pp.full_rounds_beginning + pp.partial_rounds + pp.full_rounds_end;
+    if (w < 2 || w > 6 || !pp.mds || !pp.round_keys || rounds == 0 || rounds > (1u << 16)) return false;  // poseidon_team: w + 2 <= 8 lanes
+    t = PoseidonTab{w, pp.full_rounds_beginning, pp.partial_rounds, pp.full_rounds_end, 0, 0, 0};
+    t.mds_off = (uint32_t)pc.size();
+    for (uint32_t i = 0; i < w * w; i++) pc.push_back(host_mont(pp.mds + 32 * (size_t)i));
+    t.rk_off = (uint32_t)pc.size();
+    for (uint32_t i = 0; i < rounds * w; i++) pc.push_back(host_mont(pp.round_keys + 32 * (size_t)i));
+    t.rcomb_off = (uint32_t)pc.size();
+    for (uint32_t rp = 0; rp < pp.partial_rounds; rp++)
+        for (uint32_t i = 0; i < w; i++) {
+            sc acc = sc_zero();
+            for (uint32_t j = 0; j + 1 < w; j++)
+                acc = sc_add(acc, sc_mul(pc[t.mds_off + i * w + j], pc[t.rk_off + (pp.full_rounds_beginning + rp) * w + j]));
+            pc.push_back(acc);
+        }
+    return true;
+}
+
 extern "C" {
 
 int bpr1cs_device_count(void) {
@@ -293,26 +313,12 @@ int bpr1cs_circuit_create(const bpr1cs_circuit_desc* d, bpr1cs_circuit** out) {
             bool ok = true;
             uint32_t max_s = 0, max_w = 0;
             for (uint32_t k = 0; k < d->n_poseidon_params && ok; k++) {
-                const bpr1cs_poseidon_params& pp = d->poseidon_params[k];
-                uint32_t w = pp.width, rounds = pp.full_rounds_beginning + pp.partial_rounds + pp.full_rounds_end;
-                if (w < 2 || w > 8 || !pp.mds || !pp.round_keys || rounds == 0 || rounds > (1u << 16)) { ok = false; break; }
-                PoseidonTab t{w, pp.full_rounds_beginning, pp.partial_rounds, pp.full_rounds_end, 0, 0, 0};
-                t.mds_off = (uint32_t)pc.size();
-                for (uint32_t i = 0; i < w * w; i++) pc.push_back(host_mont(pp.mds + 32 * (size_t)i));
-                t.rk_off = (uint32_t)pc.size();
-                for (uint32_t i = 0; i < rounds * w; i++) pc.push_back(host_mont(pp.round_keys + 32 * (size_t)i));
-                t.rcomb_off = (uint32_t)pc.size();
-                for (uint32_t rp = 0; rp < pp.partial_rounds; rp++)  // R_i = sum_{j < w-1} M_ij k_j of that round
-                    for (uint32_t i = 0; i < w; i++) {
-                        sc acc = sc_zero();
-                        for (uint32_t j = 0; j + 1 < w; j++)
-                            acc = sc_add(acc, sc_mul(pc[t.mds_off + i * w + j], pc[t.rk_off + (pp.full_rounds_beginning + rp) * w + j]));
-                        pc.push_back(acc);
-                    }
+                PoseidonTab t;
+                if (!build_poseidon_tab(d->poseidon_params[k], t, pc)) { ok = false; break; }
                 tabs.push_back(t);
-                uint32_t S = (t.fb + t.fe) * w + t.pr;
+                uint32_t S = (t.fb + t.fe) * t.width + t.pr;
                 if (S > max_s) max_s = S;
-                if (w > max_w) max_w = w;
+                if (t.width > max_w) max_w = t.width;
             }
             std::vector<PoseidonPerm> pms;
             std::vector<WOp> patched = ops;
@@ -965,6 +971,37 @@ extern "C" int bpr1cs_verify_batch_combined(const bpr1cs_gens* g, const bpr1cs_c
     dev_d2h(partial_point_out, d_out.p, 32, st);
     dev_d2h(wellformed_out, d_wf.p, sizeof(int), st);
     g_msm.collect();
+    return BPR1CS_OK;
+}
+
+// `count` native Poseidon permutations on the device (reference Poseidon_permutation, gadget_poseidon.rs:189-280)
+extern "C" int bpr1cs_poseidon_permutation_batch(const bpr1cs_poseidon_params* params, int sbox_inverse, const uint8_t* inputs, size_t count,
+                                                 uint8_t* outputs) {
+    if (!params || !inputs || !outputs || count == 0 || count > (1u << 24)) return BPR1CS_ERR_INVALID_ARGUMENT;
+    if (!have_device()) return BPR1CS_ERR_NO_DEVICE;
+    PoseidonTab t;
+    std::vector<sc> pc;
+    if (!build_poseidon_tab(*params, t, pc)) return BPR1CS_ERR_INVALID_ARGUMENT;
+    const uint32_t w = t.width, n = (uint32_t)count;
+    std::vector<sc> hin((size_t)n * w), hout((size_t)n * w);
+    for (size_t i = 0; i < hin.size(); i++) hin[i] = host_mont(inputs + 32 * i);
+    dev_stream_t st{};
+    DevBuf<sc> d_pc, d_in, d_out((size_t)n * w);
+    upload(d_pc, pc, st);
+    upload(d_in, hin, st);
+    K_poseidon_batch k{t, d_pc.p, d_in.p, d_out.p, sbox_inverse ? 1u : 0u};
+#if defined(BPR1CS_HOSTSIM)
+    launch(n, k, st);
+#else
+    if (sbox_inverse) {
+        hipLaunchKernelGGL(k_poseidon_team, dim3((n + 7) / 8), dim3(64), 0, st, k, n);
+        HIPCHK(hipGetLastError());
+    } else {
+        launch(n, k, st);
+    }
+#endif
+    dev_d2h(hout.data(), d_out.p, hout.size() * sizeof(sc), st);
+    for (size_t i = 0; i < hout.size(); i++) sc_mont_tobytes(hout[i], outputs + 32 * i);
     return BPR1CS_OK;
 }
 

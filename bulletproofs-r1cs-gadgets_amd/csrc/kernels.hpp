@@ -365,8 +365,10 @@ HD inline uint32_t poseidon_round_start(const PoseidonTab& t, uint32_t k) {
     return base + ((k - base) / w) * w;
 }
 // sh[PS_N + i] must hold the input state (Montgomery) on entry
+// `record` = false: native evaluation only (no S-box wires are kept); the permutation output n_i / D is left in
+// sh[PS_T1 + i] after ONE inversion of the final denominator.
 HD inline void poseidon_team(const PoseidonTab& t, const sc* pconst, const PoseidonScratch& ps, sc* sh, uint32_t T, uint32_t mylane,
-                              uint32_t first_mul, uint32_t covers) {
+                              uint32_t first_mul, uint32_t covers, bool record = true) {
     const uint32_t w = t.width, l = w - 1;
     const sc* M = pconst + t.mds_off;
     const sc* RK = pconst + t.rk_off;
@@ -374,7 +376,7 @@ HD inline void poseidon_team(const PoseidonTab& t, const sc* pconst, const Posei
     const uint32_t S = (t.fb + t.fe) * w + t.pr, rounds = t.fb + t.pr + t.fe;
     uint32_t cur = 0, s = 0;
     TEAM_LANES(lane, T, mylane) {
-        if (lane == 0) { sh[PS_D] = sc_one_mont(); ps.at(PX_C, 0) = sc_one_mont(); }
+        if (lane == 0) { sh[PS_D] = sc_one_mont(); if (record) ps.at(PX_C, 0) = sc_one_mont(); }
     }
     TEAM_SYNC();
     for (uint32_t r = 0; r < rounds; r++) {
@@ -387,8 +389,7 @@ HD inline void poseidon_team(const PoseidonTab& t, const sc* pconst, const Posei
                     if (z) a = sc_one_mont();
                     sh[PS_AV + lane] = a;
                     sh[PS_Z + lane].v[0] = z;
-                    ps.at(PX_A, s + lane) = a;
-                    ps.z(s + lane) = (uint8_t)z;
+                    if (record) { ps.at(PX_A, s + lane) = a; ps.z(s + lane) = (uint8_t)z; }
                 }
             }
             TEAM_SYNC_LDS();
@@ -400,7 +401,7 @@ HD inline void poseidon_team(const PoseidonTab& t, const sc* pconst, const Posei
                         if (lane == 0) sh[PS_PRE + idx] = acc;
                         if (lane == 1) sh[PS_SUF + idx] = acc;
                         acc = sc_mul(acc, sh[PS_AV + idx]);
-                        if (lane == 2) ps.at(PX_C, s + j + 1) = acc;
+                        if (lane == 2 && record) ps.at(PX_C, s + j + 1) = acc;
                     }
                     if (lane == 2) sh[PS_D + (cur ^ 1u)] = acc;
                 } else if (lane == 3) {
@@ -439,8 +440,7 @@ HD inline void poseidon_team(const PoseidonTab& t, const sc* pconst, const Posei
                     if (z) a = sc_one_mont();
                     sh[PS_AV] = a;
                     sh[PS_Z].v[0] = z;
-                    ps.at(PX_A, s) = a;
-                    ps.z(s) = (uint8_t)z;
+                    if (record) { ps.at(PX_A, s) = a; ps.z(s) = (uint8_t)z; }
                 } else if (lane == w + 1) {
                     sh[PS_D2] = sc_mul(sh[PS_D + cur], sh[PS_D + cur]);
                 }
@@ -454,13 +454,21 @@ HD inline void poseidon_team(const PoseidonTab& t, const sc* pconst, const Posei
                 } else if (lane == w) {
                     sc dn = sc_mul(sh[PS_D + cur], sh[PS_AV]);
                     sh[PS_D + (cur ^ 1u)] = dn;
-                    ps.at(PX_C, s + 1) = dn;
+                    if (record) ps.at(PX_C, s + 1) = dn;
                 }
             }
             TEAM_SYNC_LDS();
             cur ^= 1u;
             s += 1;
         }
+    }
+    if (!record) {
+        TEAM_LANES(lane, T, mylane) {
+            sc dinv = sc_invert(sh[PS_D + cur]);
+            if (lane < w) sh[PS_T1 + lane] = sc_mul(sh[PS_N + lane], dinv);
+        }
+        TEAM_SYNC_LDS();
+        return;
     }
     TEAM_SYNC();
     // back-substitution: lane segments of the S-box list, one inversion each (in lock step)
@@ -498,6 +506,46 @@ HD inline void poseidon_team(const PoseidonTab& t, const sc* pconst, const Posei
     }
     TEAM_SYNC();
 }
+
+// native Poseidon permutations in bulk (witness generation for the sparse Merkle trees)
+struct K_poseidon_batch {  // gid = h ; in/out [count][width] Montgomery.  Inverse S-box: simulator form of k_poseidon_team
+    PoseidonTab t;
+    const sc* pconst;
+    const sc* in;
+    sc* out;
+    uint32_t inverse;
+    HD void operator()(uint32_t h) const {
+        const uint32_t w = t.width;
+        if (inverse) {
+            sc sh[PS_SIZE];
+            for (uint32_t i = 0; i < w; i++) sh[PS_N + i] = in[(size_t)h * w + i];
+            poseidon_team(t, pconst, PoseidonScratch{nullptr, nullptr, 0, 1, 0, nullptr, 0}, sh, 8, 0, 0, 0, false);
+            for (uint32_t i = 0; i < w; i++) out[(size_t)h * w + i] = sh[PS_T1 + i];
+            return;
+        }
+        // Cube S-box (gadget_poseidon.rs:189-280 with apply_sbox = x^3): no inversions, plain evaluation
+        const sc* M = pconst + t.mds_off;
+        const sc* RK = pconst + t.rk_off;
+        sc st[8], nx[8];
+        for (uint32_t i = 0; i < w; i++) st[i] = in[(size_t)h * w + i];
+        const uint32_t rounds = t.fb + t.pr + t.fe;
+        for (uint32_t r = 0; r < rounds; r++) {
+            const bool full = r < t.fb || r >= t.fb + t.pr;
+            for (uint32_t i = 0; i < w; i++) {
+                sc a = sc_add(st[i], RK[r * w + i]);
+                if (full || i == w - 1) a = sc_mul(sc_mul(a, a), a);
+                st[i] = a;
+            }
+            for (uint32_t i = 0; i < w; i++) {
+                sc acc = sc_zero();
+                for (uint32_t j = 0; j < w; j++) acc = sc_add(acc, sc_mul(M[i * w + j], st[j]));
+                nx[i] = acc;
+            }
+            for (uint32_t i = 0; i < w; i++) st[i] = nx[i];
+        }
+        for (uint32_t i = 0; i < w; i++) out[(size_t)h * w + i] = st[i];
+    }
+};
 
 struct K_witness {  // thread per proof (sequential program)
     const WOp* ops;

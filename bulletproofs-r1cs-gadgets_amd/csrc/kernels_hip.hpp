@@ -100,6 +100,21 @@ __global__ void __launch_bounds__(64) k_witness_team(K_witness p) {
     }
 }
 
+// Inverse-S-box permutations in bulk: 8 lanes per permutation, 8 permutations per wavefront
+__global__ void __launch_bounds__(64) k_poseidon_team(K_poseidon_batch p, uint32_t count) {
+    __shared__ sc team_sh[8][PS_SIZE];
+    const uint32_t lane = threadIdx.x & 7u, team = (threadIdx.x & 63u) >> 3;
+    uint32_t h = blockIdx.x * 8u + team;
+    const bool active = h < count;
+    if (!active) h = count - 1;  // keep the workgroup barrier matched; the duplicate's store is masked
+    sc* sh = team_sh[team];
+    const uint32_t w = p.t.width;
+    if (lane < w) sh[PS_N + lane] = p.in[(size_t)h * w + lane];
+    __syncthreads();
+    poseidon_team(p.t, p.pconst, PoseidonScratch{nullptr, nullptr, 0, 1, 0, nullptr, 0}, sh, 8, lane, 0, 0, false);
+    if (active && lane < w) p.out[(size_t)h * w + lane] = sh[PS_T1 + lane];
+}
+
 // ---------------------------------------------------------------- TranscriptRng stream
 // The 2n+8 blinding draws of a proof are a strictly sequential chain of Keccak-f[1600]
 // permutations (STROBE prf, one permutation per 64-byte draw: SURVEY §8a P6), 37k of them for

@@ -470,6 +470,61 @@ void bpr1cs_vsmt4_root(const bpr1cs_vsmt4* t, uint8_t out[32]) { memcpy(out, t->
 void bpr1cs_vsmt4_update(bpr1cs_vsmt4* t, const uint8_t idx[32], const uint8_t val[32]) {
     t->tree->update(Scalar::from_bytes_mod_order(idx), Scalar::from_bytes_mod_order(val));
 }
+// Poseidon_hash_4 (gadget_poseidon.rs:488-503) of many inputs through the device's bulk permutation
+static std::vector<Scalar> device_hash4_batch(const PoseidonParams& p, const std::vector<std::array<Scalar, 4>>& inputs) {
+    std::vector<uint8_t> mds, rk, in(inputs.size() * 6 * 32), out(inputs.size() * 6 * 32);
+    for (size_t i = 0; i < p.width; i++)
+        for (size_t j = 0; j < p.width; j++) { auto b = p.MDS_matrix[i][j].to_bytes(); mds.insert(mds.end(), b.begin(), b.end()); }
+    size_t nk = p.get_total_rounds() * p.width;
+    for (size_t i = 0; i < nk; i++) { auto b = p.round_keys[i].to_bytes(); rk.insert(rk.end(), b.begin(), b.end()); }
+    bpr1cs_poseidon_params pp{};
+    pp.width = (uint32_t)p.width; pp.full_rounds_beginning = (uint32_t)p.full_rounds_beginning;
+    pp.partial_rounds = (uint32_t)p.partial_rounds; pp.full_rounds_end = (uint32_t)p.full_rounds_end;
+    pp.mds = mds.data(); pp.round_keys = rk.data();
+    auto put = [&](size_t k, const Scalar& x) { auto b = x.to_bytes(); memcpy(&in[32 * k], b.data(), 32); };
+    for (size_t h = 0; h < inputs.size(); h++) {
+        put(6 * h + 0, Scalar(ZERO_CONST));
+        for (size_t i = 0; i < 4; i++) put(6 * h + 1 + i, inputs[h][i]);
+        put(6 * h + 5, Scalar(PADDING_CONST));
+    }
+    std::vector<Scalar> res;
+    if (inputs.empty()) return res;
+    int rc = bpr1cs_poseidon_permutation_batch(&pp, 1, in.data(), inputs.size(), out.data());
+    if (rc) throw R1CSError::Backend(rc);
+    for (size_t h = 0; h < inputs.size(); h++) res.push_back(Scalar::from_bytes_mod_order(&out[32 * (6 * h + 1)]));
+    return res;
+}
+// bulk insert of `count` DISTINCT leaves; every tree level is hashed by one device launch
+int bpr1cs_vsmt4_update_many(bpr1cs_vsmt4* t, const uint8_t* idx, const uint8_t* vals, size_t count) {
+    try {
+        std::vector<std::pair<Scalar, Scalar>> leaves;
+        for (size_t i = 0; i < count; i++) leaves.push_back({Scalar::from_bytes_mod_order(idx + 32 * i), Scalar::from_bytes_mod_order(vals + 32 * i)});
+        const PoseidonParams& p = *t->params;
+        t->tree->update_many(leaves, [&](const std::vector<std::array<Scalar, 4>>& in) { return device_hash4_batch(p, in); });
+        return BPR1CS_OK;
+    } catch (const R1CSError& e) {
+        return e.code;
+    } catch (const std::exception&) {
+        return BPR1CS_ERR_INVALID_ARGUMENT;
+    }
+}
+// paths of many leaves without re-hashing them (the proofs made from them are what checks them)
+int bpr1cs_vsmt4_get_many(const bpr1cs_vsmt4* t, const uint8_t* idx, size_t count, uint8_t* leaves_out, uint8_t* proofs_out) {
+    try {
+        size_t per = t->tree->depth * 3 * 32;
+        for (size_t i = 0; i < count; i++) {
+            std::vector<ProofNode> proof;
+            Scalar leaf = t->tree->get(Scalar::from_bytes_mod_order(idx + 32 * i), &proof);
+            memcpy(leaves_out + 32 * i, leaf.to_bytes().data(), 32);
+            size_t k = 0;
+            for (auto& pn : proof)
+                for (auto& s : pn) memcpy(proofs_out + per * i + 32 * (k++), s.to_bytes().data(), 32);
+        }
+        return BPR1CS_OK;
+    } catch (const std::exception&) {
+        return BPR1CS_ERR_INVALID_ARGUMENT;
+    }
+}
 // leaf_out[32], proof_out[levels*3*32] root level first (the order the reference test commits them)
 int bpr1cs_vsmt4_get(const bpr1cs_vsmt4* t, const uint8_t idx[32], uint8_t* leaf_out, uint8_t* proof_out) {
     try {

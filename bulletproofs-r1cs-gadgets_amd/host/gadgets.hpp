@@ -4,6 +4,7 @@
 // the only additions are the optional WitnessHint arguments that let the
 // CircuitCompiler move constraint synthesis onto the GPU.
 #pragma once
+#include <functional>
 #include <map>
 #include "r1cs.hpp"
 
@@ -435,6 +436,57 @@ public:
             }
         }
         return cur_node;
+    }
+    // Bulk form of `update` for DISTINCT leaf indices (extension; the reference inserts one leaf at a time,
+    // gadget_vsmt_4.rs:71-100): the affected nodes are recomputed level by level, all parents of a level through ONE call
+    // of `hash4_batch` (on the device: bpr1cs_poseidon_permutation_batch).  Final root and all paths equal those of the
+    // sequential updates; intermediate historical roots are not materialised in `db`.
+    using Hash4Batch = std::function<std::vector<Scalar>(const std::vector<std::array<Scalar, 4>>&)>;
+    Scalar update_many(const std::vector<std::pair<Scalar, Scalar>>& leaves, const Hash4Batch& hash4_batch) {
+        using Prefix = std::vector<uint8_t>;
+        // top-down: the present node value at every prefix of every new leaf index
+        std::map<Prefix, Scalar> old_node;
+        std::vector<std::map<Prefix, Scalar>> fresh(depth + 1);  // level (prefix length) -> new values
+        old_node[Prefix{}] = root;
+        for (auto& lv : leaves) {
+            auto digits = get_base_4_repr(lv.first, leaf_index_bytes);
+            Prefix p;
+            Scalar cur = root;
+            for (size_t k = 0; k < digits.size(); k++) {
+                const auto& children = db.at(ScalarKey{cur.to_bytes()});
+                cur = children[digits[k]];
+                p.push_back(digits[k]);
+                old_node.emplace(p, cur);
+            }
+            if (!fresh[depth].emplace(p, lv.second).second) throw R1CSError::GadgetError("update_many: duplicate leaf index");
+        }
+        // bottom-up: one batch of hashes per level
+        for (size_t level = depth; level-- > 0;) {
+            std::vector<Prefix> parents;
+            for (auto& kv : fresh[level + 1]) {
+                Prefix par(kv.first.begin(), kv.first.end() - 1);
+                if (parents.empty() || parents.back() != par) parents.push_back(par);  // map order keeps siblings adjacent
+            }
+            std::vector<std::array<Scalar, 4>> inputs;
+            for (auto& par : parents) {
+                const auto& oldc = db.at(ScalarKey{old_node.at(par).to_bytes()});
+                std::array<Scalar, 4> in;
+                for (uint8_t i = 0; i < 4; i++) {
+                    Prefix ch = par;
+                    ch.push_back(i);
+                    auto it = fresh[level + 1].find(ch);
+                    in[i] = it != fresh[level + 1].end() ? it->second : oldc[i];
+                }
+                inputs.push_back(in);
+            }
+            std::vector<Scalar> hashes = hash4_batch(inputs);
+            for (size_t k = 0; k < parents.size(); k++) {
+                db[ScalarKey{hashes[k].to_bytes()}] = inputs[k];
+                fresh[level].emplace(parents[k], hashes[k]);
+            }
+        }
+        if (!leaves.empty()) root = fresh[0].at(Prefix{});
+        return root;
     }
     bool verify_proof(const Scalar& idx, const Scalar& val, const std::vector<ProofNode>& proof, const Scalar* root_opt = nullptr) const {
         auto cur_idx = get_base_4_repr(idx, leaf_index_bytes);

@@ -161,6 +161,12 @@ int bpr1cs_verify_batch_combined(const bpr1cs_gens* gens, const bpr1cs_circuit* 
                                  const uint8_t* proofs, const uint8_t* commitments, const uint8_t* verifier_rng_seeds,
                                  const uint8_t* batch_seed /* 32 */, uint64_t index_base, size_t batch,
                                  uint8_t* partial_point_out /* 32 */, int* wellformed_out);
+/* `count` native Poseidon permutations (reference Poseidon_permutation, gadget_poseidon.rs:189-280; sbox_inverse
+ * selects SboxType::Inverse / Cube): inputs/outputs are count*width canonical scalars.  With the Inverse S-box each
+ * permutation costs ONE inversion (state carried as fractions, as in the witness program).  Used by the sparse
+ * Merkle tree builders of bpr1cs_gadgets.h to hash a whole tree level per call. */
+int bpr1cs_poseidon_permutation_batch(const bpr1cs_poseidon_params* params, int sbox_inverse, const uint8_t* inputs, size_t count,
+                                      uint8_t* outputs);
 /* out = compress(sum of `count` compressed ristretto points); BPR1CS_ERR_FORMAT if one of them does not decode */
 int bpr1cs_points_sum(const uint8_t* points, size_t count, uint8_t* out);
 

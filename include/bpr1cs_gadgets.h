@@ -60,6 +60,12 @@ void bpr1cs_vsmt4_free(bpr1cs_vsmt4* t);
 void bpr1cs_vsmt4_root(const bpr1cs_vsmt4* t, uint8_t out[32]);
 void bpr1cs_vsmt4_update(bpr1cs_vsmt4* t, const uint8_t idx[32], const uint8_t val[32]);
 int bpr1cs_vsmt4_get(const bpr1cs_vsmt4* t, const uint8_t idx[32], uint8_t* leaf_out, uint8_t* proof_out /* levels*3*32 */);
+/* bulk forms: insert `count` DISTINCT leaves with every tree level hashed by ONE device launch
+ * (bpr1cs_poseidon_permutation_batch); root and paths equal those of `count` sequential bpr1cs_vsmt4_update calls.
+ * get_many returns the paths without re-hashing them. */
+int bpr1cs_vsmt4_update_many(bpr1cs_vsmt4* t, const uint8_t* idx /* count*32 */, const uint8_t* vals /* count*32 */, size_t count);
+int bpr1cs_vsmt4_get_many(const bpr1cs_vsmt4* t, const uint8_t* idx, size_t count, uint8_t* leaves_out /* count*32 */,
+                          uint8_t* proofs_out /* count*levels*3*32 */);
 
 typedef struct bpr1cs_vsmt2 bpr1cs_vsmt2; /* VanillaSparseMerkleTree, src/gadget_vsmt_2.rs:27-166 */
 int bpr1cs_vsmt2_new(uint32_t depth, uint32_t partial_rounds, const uint8_t* blob, size_t blob_len, bpr1cs_vsmt2** out);

@@ -1,4 +1,5 @@
 """Case table shared by the CPU (simulator) and GPU front-end tests."""
+import pytest
 from pyref import scenarios as S, gadgets as g
 from pyref.ed import sc_to_bytes, L
 import common
@@ -183,6 +184,37 @@ def check_trees(glib, levels4, depth2, partial_rounds):
     leaf, nodes = t2.get(3)
     oleaf, oproof = o2.get(3, True)
     assert leaf == sc_to_bytes(oleaf) and nodes == [sc_to_bytes(x) for x in oproof]
+
+
+def check_bulk_tree(lib, glib, levels=4, partial_rounds=2, count=9):
+    """N2: bulk permutation on the device and level-by-level tree construction vs the oracle's sequential tree."""
+    from pyref.ed import L as ELL
+    params = S.poseidon_params(partial_rounds)
+    states = [[S.synth_scalar(b"perm%d" % h, i) for i in range(6)] for h in range(5)]
+    states.append([0, 0, 0, 0, 0, 0])
+    states.append([(-params.round_keys[0]) % ELL, 1, 2, 3, 4, 5])   # first S-box input = 0 (invert(0) = 0 upstream)
+    for inverse in (True, False):
+        got = bp.poseidon_permutation_batch(states, inverse=inverse, partial_rounds=partial_rounds, lib=lib)
+        exp = [g.Poseidon_permutation(st, params, g.INVERSE if inverse else g.CUBE) for st in states]
+        assert got == [[x % ELL for x in e] for e in exp]
+    t = bp.SparseMerkleTree(4, levels, partial_rounds, glib=glib)
+    o = g.VanillaSparseMerkleTree_4(params, depth=levels)
+    for i in (3, 200):                       # a non-empty tree to start from
+        t.update(i, i + 5); o.update(i, i + 5)
+    leaves = [(1 + 7 * k, 1000 + k) for k in range(count)] + [(201, 77), (255, 1)]
+    t.update_many(leaves)
+    for i, v in leaves:
+        o.update(i, v)
+    assert t.root() == sc_to_bytes(o.root)
+    idxs = [i for i, _ in leaves] + [3, 200, 42]
+    lv, paths = t.get_many(idxs)
+    per = 32 * 3 * levels
+    for k, i in enumerate(idxs):
+        oleaf, oproof = o.get(i, True)
+        assert lv[32 * k:32 * k + 32] == sc_to_bytes(oleaf)
+        assert paths[per * k:per * (k + 1)] == b"".join(sc_to_bytes(x) for node in oproof for x in node)
+    with pytest.raises(Exception):
+        t.update_many([(9, 1), (9, 2)])      # duplicate index
 
 
 def check_prove_verify_roundtrip(lib, glib, name, batch=2):

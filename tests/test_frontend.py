@@ -48,3 +48,7 @@ def test_compiled_poseidon_inverse_joint_evaluation(sim_lib, sim_glib):
 def test_compiled_poseidon_inverse_zero_sbox_input(sim_lib, sim_glib):
     """x = 0 at an S-box (Scalar::invert(0) = 0 upstream): both wires must be 0 and the other S-boxes unaffected."""
     fc.check_macro_vs_plain(sim_lib, sim_glib, "poseidon_hash_2_inverse_pr1_zero", batch=1)
+
+
+def test_bulk_poseidon_and_tree_construction(sim_lib, sim_glib):
+    fc.check_bulk_tree(sim_lib, sim_glib)

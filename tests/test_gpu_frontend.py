@@ -54,3 +54,8 @@ def test_poseidon_joint_evaluation_equals_plain_program(hip_lib, hip_glib, case)
     permutation) and the plain op-by-op program (one inversion per S-box) give the oracle's proof bytes, including
     an S-box input of 0."""
     fc.check_macro_vs_plain(hip_lib, hip_glib, case, batch=2 if not case.endswith("pr1_zero") else 1)
+
+
+def test_bulk_poseidon_and_tree_construction_on_device(hip_lib, hip_glib):
+    """N2: k_poseidon_team (8 lanes per permutation, one inversion each) and the level-by-level tree builder"""
+    fc.check_bulk_tree(hip_lib, hip_glib, levels=8, partial_rounds=140, count=40)
