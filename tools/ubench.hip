@@ -127,6 +127,35 @@ __global__ void __launch_bounds__(256) k_prim(uint32_t* out, const uint32_t* in,
     for (int i = 0; i < 8; i++) out[t * 8 + i] = (uint32_t)a.v[i] ^ (uint32_t)a.v[8];
 }
 
+// dependent v_mad_i64_i32 chain: (0) one inline-asm statement per instruction (hipcc adds an s_nop after each: it must
+// assume a dst_sel forwarding hazard), (1) the same 16 instructions inside ONE asm statement (no s_nop)
+template <int MODE>
+__global__ void __launch_bounds__(256) k_chain(uint32_t* out, uint32_t seed) {
+    uint32_t t = threadIdx.x + blockIdx.x * 256;
+    int32_t x = (int32_t)(t | 1), y = (int32_t)(t * 2654435761u) | 1;
+    int64_t acc = seed, acc2 = seed + 1;
+    for (int i = 0; i < ITER / 4; i++) {
+        if (MODE == 0) {
+#define M1 asm("v_mad_i64_i32 %0, vcc, %1, %2, %0" : "+v"(acc) : "v"(x), "v"(y) : "vcc");
+            M1 M1 M1 M1 M1 M1 M1 M1 M1 M1 M1 M1 M1 M1 M1 M1
+#undef M1
+        } else if (MODE == 1) {
+            asm("v_mad_i64_i32 %0, vcc, %1, %2, %0\n v_mad_i64_i32 %0, vcc, %1, %2, %0\n v_mad_i64_i32 %0, vcc, %1, %2, %0\n v_mad_i64_i32 %0, vcc, %1, %2, %0\n"
+                "v_mad_i64_i32 %0, vcc, %1, %2, %0\n v_mad_i64_i32 %0, vcc, %1, %2, %0\n v_mad_i64_i32 %0, vcc, %1, %2, %0\n v_mad_i64_i32 %0, vcc, %1, %2, %0\n"
+                "v_mad_i64_i32 %0, vcc, %1, %2, %0\n v_mad_i64_i32 %0, vcc, %1, %2, %0\n v_mad_i64_i32 %0, vcc, %1, %2, %0\n v_mad_i64_i32 %0, vcc, %1, %2, %0\n"
+                "v_mad_i64_i32 %0, vcc, %1, %2, %0\n v_mad_i64_i32 %0, vcc, %1, %2, %0\n v_mad_i64_i32 %0, vcc, %1, %2, %0\n v_mad_i64_i32 %0, vcc, %1, %2, %0"
+                : "+v"(acc) : "v"(x), "v"(y) : "vcc");
+        } else {  // two interleaved independent chains in one statement
+            asm("v_mad_i64_i32 %0, vcc, %2, %3, %0\n v_mad_i64_i32 %1, vcc, %2, %3, %1\n v_mad_i64_i32 %0, vcc, %2, %3, %0\n v_mad_i64_i32 %1, vcc, %2, %3, %1\n"
+                "v_mad_i64_i32 %0, vcc, %2, %3, %0\n v_mad_i64_i32 %1, vcc, %2, %3, %1\n v_mad_i64_i32 %0, vcc, %2, %3, %0\n v_mad_i64_i32 %1, vcc, %2, %3, %1\n"
+                "v_mad_i64_i32 %0, vcc, %2, %3, %0\n v_mad_i64_i32 %1, vcc, %2, %3, %1\n v_mad_i64_i32 %0, vcc, %2, %3, %0\n v_mad_i64_i32 %1, vcc, %2, %3, %1\n"
+                "v_mad_i64_i32 %0, vcc, %2, %3, %0\n v_mad_i64_i32 %1, vcc, %2, %3, %1\n v_mad_i64_i32 %0, vcc, %2, %3, %0\n v_mad_i64_i32 %1, vcc, %2, %3, %1"
+                : "+v"(acc), "+v"(acc2) : "v"(x), "v"(y) : "vcc");
+        }
+    }
+    out[t] = (uint32_t)acc ^ (uint32_t)(acc >> 32) ^ (uint32_t)acc2;
+}
+
 int main() {
     const int blocks = 256 * 8, threads = 256;
     uint32_t* out; uint32_t* in;
@@ -142,6 +171,12 @@ int main() {
     CHK(hipEventElapsedTime(&ms, e0, e1)); double n = (double)blocks * threads * ITER * 8; \
     printf("%-18s %8.3f ms  %8.2f Tlane-op/s  (%.2f cyc/wave-inst/SIMD @2.4GHz)\n", names[OP], ms, n / ms / 1e9, 1024.0 * 2.4e9 * 64 / (n / (ms * 1e-3))); }
     RUN_INST(0) RUN_INST(1) RUN_INST(2) RUN_INST(3) RUN_INST(4) RUN_INST(5) RUN_INST(6) RUN_INST(7) RUN_INST(8) RUN_INST(9) RUN_INST(10) RUN_INST(11) RUN_INST(12) RUN_INST(13) RUN_INST(14) RUN_INST(15) RUN_INST(16) RUN_INST(17)
+    const char* cn[] = {"mad chain, asm per instr (+s_nop)", "mad chain, one asm block", "2 interleaved chains, one block"};
+#define RUN_CHAIN(M) { hipLaunchKernelGGL(k_chain<M>, dim3(blocks), dim3(threads), 0, 0, out, 1u); CHK(hipDeviceSynchronize()); \
+    CHK(hipEventRecord(e0)); hipLaunchKernelGGL(k_chain<M>, dim3(blocks), dim3(threads), 0, 0, out, 2u); CHK(hipEventRecord(e1)); CHK(hipEventSynchronize(e1)); \
+    CHK(hipEventElapsedTime(&ms, e0, e1)); double n = (double)blocks * threads * (ITER / 4) * 16; \
+    printf("%-36s %8.3f ms  (%.2f cyc/wave-inst/SIMD @2.4GHz)\n", cn[M], ms, 1024.0 * 2.4e9 * 64 / (n / (ms * 1e-3))); }
+    RUN_CHAIN(0) RUN_CHAIN(1) RUN_CHAIN(2)
     const char* pn[] = {"fe_mul", "fe_add", "fe_sub", "sc_mul", "ge_madd", "ge_dbl", "ge_add", "fe_sq", "sc_invert"};
 #define RUN_PRIM(OP, IT) { hipLaunchKernelGGL(k_prim<OP>, dim3(blocks), dim3(threads), 0, 0, out, in, 8); CHK(hipDeviceSynchronize()); \
     CHK(hipEventRecord(e0)); hipLaunchKernelGGL(k_prim<OP>, dim3(blocks), dim3(threads), 0, 0, out, in, IT); CHK(hipEventRecord(e1)); CHK(hipEventSynchronize(e1)); \
