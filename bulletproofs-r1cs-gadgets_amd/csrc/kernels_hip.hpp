@@ -260,3 +260,60 @@ __global__ void __launch_bounds__(64) k_rng_thread(const strobe* rng_in, uint64_
         }
     }
 }
+
+// The same chain once more, on the SCALAR unit: one Keccak state per wavefront, all 25 lanes in SGPRs, every round
+// instruction an s_xor_b64 / s_lshl_b64 / s_andn2_b64.  The scalar ALU has native 64-bit logic and its own issue
+// port, which the MSM / IPA kernels of a co-running batch leave almost idle - so the chain costs them no VALU issue
+// slots at all (the lane-parallel variant takes ~40 % of a SIMD's slots on 512 wavefronts).  Per-draw latency is
+// higher (one scalar instruction at a time), so it is chosen only while another batch is in flight.
+__device__ inline uint64_t s_uniform(uint64_t v) {
+    uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return ((uint64_t)hi << 32) | lo;
+}
+__global__ void __launch_bounds__(64) k_rng_scalar(const strobe* rng_in, uint64_t* raw_out, int* err, uint32_t B, uint32_t draws) {
+    __builtin_amdgcn_s_setprio(3);
+    const uint32_t b = blockIdx.x;  // wave-uniform
+    if (rng_in[b].pos != 64 || rng_in[b].pos_begin != 0) {
+        if (threadIdx.x == 0) atomicExch(err, 1);
+        return;
+    }
+    uint64_t a[25];
+#pragma unroll
+    for (int i = 0; i < 25; i++) a[i] = s_uniform(rng_in[b].st[i]);
+    for (uint32_t d = 0; d < draws; d++) {
+        a[8] ^= 0x0741000000401200ull;  // STROBE framing of fill_bytes(64) in the steady state (see k_rng_stream)
+        a[9] ^= 0x0000000000000447ull;
+        a[20] ^= 0x8000000000000000ull;
+        for (int r = 0; r < 24; r++) {
+            uint64_t c0 = a[0] ^ a[5] ^ a[10] ^ a[15] ^ a[20], c1 = a[1] ^ a[6] ^ a[11] ^ a[16] ^ a[21];
+            uint64_t c2 = a[2] ^ a[7] ^ a[12] ^ a[17] ^ a[22], c3 = a[3] ^ a[8] ^ a[13] ^ a[18] ^ a[23];
+            uint64_t c4 = a[4] ^ a[9] ^ a[14] ^ a[19] ^ a[24];
+            uint64_t d0 = c4 ^ rol64(c1, 1), d1 = c0 ^ rol64(c2, 1), d2 = c1 ^ rol64(c3, 1), d3 = c2 ^ rol64(c4, 1), d4 = c3 ^ rol64(c0, 1);
+#pragma unroll
+            for (int y = 0; y < 25; y += 5) { a[y] ^= d0; a[y + 1] ^= d1; a[y + 2] ^= d2; a[y + 3] ^= d3; a[y + 4] ^= d4; }
+            // rho + pi in place along the single 24-cycle of pi (one temporary)
+            uint64_t t = a[1], u;
+#define RP(j, n) u = a[j]; a[j] = rol64(t, n); t = u;
+            RP(10, 1) RP(7, 3) RP(11, 6) RP(17, 10) RP(18, 15) RP(3, 21) RP(5, 28) RP(16, 36) RP(8, 45) RP(21, 55) RP(24, 2) RP(4, 14)
+            RP(15, 27) RP(23, 41) RP(19, 56) RP(13, 8) RP(12, 25) RP(2, 43) RP(20, 62) RP(14, 18) RP(22, 39) RP(9, 61) RP(6, 20) RP(1, 44)
+#undef RP
+#pragma unroll
+            for (int y = 0; y < 25; y += 5) {  // chi row by row (two saved lanes)
+                uint64_t b0 = a[y], b1 = a[y + 1];
+                a[y] = b0 ^ (~b1 & a[y + 2]);
+                a[y + 1] = b1 ^ (~a[y + 2] & a[y + 3]);
+                a[y + 2] ^= ~a[y + 3] & a[y + 4];
+                a[y + 3] ^= ~a[y + 4] & b0;
+                a[y + 4] ^= ~b0 & b1;
+            }
+            a[0] ^= KECCAK_RC[r];
+        }
+        if (threadIdx.x == 0) {
+            uint64_t* o = raw_out + ((size_t)d * B + b) * 8;
+#pragma unroll
+            for (int i = 0; i < 8; i++) o[i] = a[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 8; i++) a[i] = 0;  // prf squeeze zeroes the bytes it returns
+    }
+}

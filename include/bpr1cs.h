@@ -191,9 +191,13 @@ void bpr1cs_set_window_bits(int w);
 void bpr1cs_set_witness_team(int t);
 
 /* tuning knob: how the sequential TranscriptRng chain of a proof (one Keccak-f[1600] per blinding draw) is mapped.
- * 1 = one state over 25 lanes of a wavefront (lowest latency), 2 = one state per thread (12x fewer wavefront
- * instructions, ~1.4x the latency; its wavefronts are pure VALU code and only pay off on SIMDs of their own,
- * see bpr1cs_set_latency_cus), 0 = automatic: 1 unless CUs are reserved and another batch is in flight. */
+ * 1 = one state over 25 lanes of a wavefront, cross-lane exchange through LDS (lowest latency);
+ * 2 = one state per thread (fewest instructions, but its pure-VALU wavefronts only pay off on SIMDs of their own,
+ *     see bpr1cs_set_latency_cus);
+ * 3 = one state per wavefront on the SCALAR unit (all lanes in SGPRs, s_xor_b64 / s_andn2_b64 ...): no VALU issue
+ *     slots, but 3.7x the latency of 1 (a wavefront issues one scalar instruction per ~9 cycles) - kept as a
+ *     measured alternative, never chosen automatically;
+ * 0 = automatic: 1 (2 if CUs are reserved for it and another batch is in flight). */
 void bpr1cs_set_rng_mode(int mode);
 
 /* test knob, read by bpr1cs_circuit_create: 0 = ignore the Poseidon annotations of a circuit description and run
