@@ -39,7 +39,7 @@ static int g_window_bits = 8;
 static int g_latency_cus = 0;   // >0: CUs reserved for the latency-bound kernels (see bpr1cs_gens_create)
 static int g_rng_mode = 0;       // 0 auto, 1 lane-parallel chain (k_rng_stream), 2 state per thread (k_rng_thread), 3 scalar unit (k_rng_scalar)
 static int g_witness_macro = 1;  // use the Poseidon annotations of a circuit description (poseidon_team)
-static int g_witness_team = 16;  // lanes cooperating on one proof in k_witness_team (4, 8 or 16)
+static int g_witness_team = 8;   // lanes cooperating on one proof in k_witness_team (4, 8 or 16)
 static uint32_t g_msm_target_threads = 1u << 21;  // (chunk, proof) threads per MSM launch
 static float g_timings[8];
 
