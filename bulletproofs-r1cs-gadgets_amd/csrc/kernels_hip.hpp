@@ -127,6 +127,10 @@ __global__ void __launch_bounds__(64) k_poseidon_team(K_poseidon_batch p, uint32
 // instruction, 256 B/clk) instead of ds_bpermute_b32 (4 bytes, crossbar): measured 3.3x faster per round.
 // A wavefront's DS operations are executed in order, so a lane's read issued after the wave's write sees
 // the new data; the fences below only stop the compiler from reordering.
+// ---- Keccak-f[1600] on 32-bit halves with the gfx950 three-input logic op (v_bitop3_b32: one instruction for
+// a^b^c and for a^(~b&c)) and v_alignbit_b32 funnel shifts: 180 VALU instructions per round instead of ~330.
+#define K_XOR3(a, b, c) __builtin_amdgcn_bitop3_b32((a), (b), (c), 0x96)
+#define K_CHI(a, b, c) __builtin_amdgcn_bitop3_b32((a), (b), (c), 0xd2)  // a ^ (~b & c)
 __device__ inline void lds_order() { __syncthreads(); }  // one wavefront per workgroup: lgkmcnt(0) + s_barrier
 __global__ void __launch_bounds__(64) k_rng_stream(const strobe* rng_in, uint64_t* raw_out, int* err, uint32_t B, uint32_t draws) {
     __builtin_amdgcn_s_setprio(3);  // one long dependent chain per state: take every issue slot it can use
@@ -143,6 +147,9 @@ __global__ void __launch_bounds__(64) k_rng_stream(const strobe* rng_in, uint64_
     }
     const int ROT[25] = {0, 1, 62, 28, 27, 36, 44, 6, 55, 20, 3, 10, 43, 25, 39, 41, 45, 15, 21, 8, 18, 2, 61, 56, 14};  // [x + 5y]
     const int rot = ROT[j];
+    // rho as two funnel shifts on 32-bit halves: rotl64 by r = (swap halves if r >= 32) then alignbit by 32 - (r & 31)
+    const bool rot_swap = rot >= 32, rot_none = rot == 0;
+    const uint32_t rot_k = (32u - ((uint32_t)rot & 31u)) & 31u;  // no lane has r & 31 == 0 except r == 0 (handled by rot_none)
     const uint32_t xm = (x + 4u) % 5u, xp = (x + 1u) % 5u;
     // chi operands pulled straight from the pre-pi lanes: B[X][Y] = rot(A)[(X + 3Y) % 5 + 5X]
     const uint32_t s0 = (x + 3u * y) % 5u + 5u * x;
@@ -150,6 +157,8 @@ __global__ void __launch_bounds__(64) k_rng_stream(const strobe* rng_in, uint64_
     const uint32_t s1 = (x1 + 3u * y) % 5u + 5u * x1, s2 = (x2 + 3u * y) % 5u + 5u * x2;
     uint64_t* A0 = xch[0][half];
     uint64_t* A1 = xch[1][half];
+#define LO(v) ((uint32_t)(v))
+#define HI(v) ((uint32_t)((v) >> 32))
     for (uint32_t d = 0; d < draws; d++) {
         // STROBE framing of fill_bytes(64) in the steady state (see merlin_rng_scalar)
         if (j == 8) a ^= 0x0741000000401200ull;
@@ -159,27 +168,32 @@ __global__ void __launch_bounds__(64) k_rng_stream(const strobe* rng_in, uint64_
         for (int r = 0; r < 24; r++) {  // fully unrolled: the round constants become immediates (no s_load per round)
             A0[i] = a;
             lds_order();
-            uint64_t m = A0[xm] ^ A0[xm + 5] ^ A0[xm + 10] ^ A0[xm + 15] ^ A0[xm + 20];
-            uint64_t p = A0[xp] ^ A0[xp + 5] ^ A0[xp + 10] ^ A0[xp + 15] ^ A0[xp + 20];
-            a ^= m ^ ((p << 1) | (p >> 63));                            // theta
-            uint64_t ar = rot ? ((a << rot) | (a >> (64 - rot))) : a;     // rho
-            A1[i] = ar;
+            uint64_t m0 = A0[xm], m1 = A0[xm + 5], m2 = A0[xm + 10], m3 = A0[xm + 15], m4 = A0[xm + 20];
+            uint64_t p0 = A0[xp], p1 = A0[xp + 5], p2 = A0[xp + 10], p3 = A0[xp + 15], p4 = A0[xp + 20];
+            uint32_t ml = K_XOR3(K_XOR3(LO(m0), LO(m1), LO(m2)), LO(m3), LO(m4)), mh = K_XOR3(K_XOR3(HI(m0), HI(m1), HI(m2)), HI(m3), HI(m4));
+            uint32_t pl = K_XOR3(K_XOR3(LO(p0), LO(p1), LO(p2)), LO(p3), LO(p4)), ph = K_XOR3(K_XOR3(HI(p0), HI(p1), HI(p2)), HI(p3), HI(p4));
+            uint32_t tl = K_XOR3(LO(a), ml, __builtin_amdgcn_alignbit(pl, ph, 31));   // theta: a ^ C[x-1] ^ rol(C[x+1], 1)
+            uint32_t th = K_XOR3(HI(a), mh, __builtin_amdgcn_alignbit(ph, pl, 31));
+            uint32_t ul = rot_swap ? th : tl, uh = rot_swap ? tl : th;             // rho
+            uint32_t nl = __builtin_amdgcn_alignbit(ul, uh, rot_k), nh = __builtin_amdgcn_alignbit(uh, ul, rot_k);
+            nl = rot_none ? tl : nl;
+            nh = rot_none ? th : nh;
+            A1[i] = ((uint64_t)nh << 32) | nl;
             lds_order();
-            uint64_t b0 = A1[s0], b1 = A1[s1], b2 = A1[s2];              // pi
-            a = b0 ^ (~b1 & b2);                                          // chi
-            if (j == 0) a ^= KECCAK_RC[r];                                // iota
+            uint64_t b0 = A1[s0], b1 = A1[s1], b2 = A1[s2];                         // pi
+            uint32_t cl = K_CHI(LO(b0), LO(b1), LO(b2)), ch = K_CHI(HI(b0), HI(b1), HI(b2));  // chi
+            a = ((uint64_t)ch << 32) | cl;
+            if (j == 0) a ^= KECCAK_RC[r];                                          // iota
         }
         if (i < 8) {
             if (valid) raw_out[((size_t)d * B + b) * 8 + i] = a;
             a = 0;  // prf squeeze zeroes the bytes it returns
         }
     }
+#undef LO
+#undef HI
 }
 
-// ---- Keccak-f[1600] on 32-bit halves with the gfx950 three-input logic op (v_bitop3_b32: one instruction for
-// a^b^c and for a^(~b&c)) and v_alignbit_b32 funnel shifts: 180 VALU instructions per round instead of ~330.
-#define K_XOR3(a, b, c) __builtin_amdgcn_bitop3_b32((a), (b), (c), 0x96)
-#define K_CHI(a, b, c) __builtin_amdgcn_bitop3_b32((a), (b), (c), 0xd2)  // a ^ (~b & c)
 template <int N>
 __device__ inline void k_rol(uint32_t lo, uint32_t hi, uint32_t& olo, uint32_t& ohi) {
     if (N == 0) { olo = lo; ohi = hi; }
