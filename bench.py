@@ -121,7 +121,7 @@ def main():
     ap.add_argument("--latency-cus", type=int, default=-1, help="CUs reserved for the latency-bound kernels (-1 = library default)")
     ap.add_argument("--team", type=int, default=0, help="witness team size 4/8/16 (0 = library default)")
     ap.add_argument("--rng-mode", type=int, default=-1, help="TranscriptRng chain mapping: 0 auto, 1 lane-parallel, 2 state per thread (-1 = library default)")
-    ap.add_argument("--unfold", type=int, default=5, help="IPA rounds computed from the un-folded generator tables")
+    ap.add_argument("--unfold", type=int, default=4, help="IPA rounds computed from the un-folded generator tables")
     ap.add_argument("--window", type=int, default=11, help="fixed-base table window bits (11: 23 adds/term, 148 GB of tables at capacity 32768)")
     args = ap.parse_args()
 

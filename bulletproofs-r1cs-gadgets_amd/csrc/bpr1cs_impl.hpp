@@ -736,8 +736,9 @@ extern "C" int bpr1cs_prove_batch_begin(const bpr1cs_gens* g, const bpr1cs_circu
     DevBuf<sc> uk((size_t)(lgN ? lgN : 1) * 2 * B), cross((size_t)2 * B);
     uint32_t r = (uint32_t)g_unfold_rounds < lgN ? (uint32_t)g_unfold_rounds : lgN;
     DevBuf<sc> sG, sH, cpart;
-    DevBuf<ge> GH, vtmp, vpart;
+    DevBuf<ge> GH, vwin, vsum, vout;
     DevBuf<ge_cached> vtab;
+    DevBuf<uint32_t> vdig;
     DevBuf<sc> linv;
     uint32_t M = N >> r;  // size of the materialised folded generator vectors
     if (r > 0) { sG.alloc((size_t)N * B); sH.alloc((size_t)N * B); }
@@ -765,16 +766,21 @@ extern "C" int bpr1cs_prove_batch_begin(const bpr1cs_gens* g, const bpr1cs_circu
             if (k == r) {
                 GH.alloc((size_t)2 * M * B);
                 launch((uint64_t)2 * M * B, K_ipa_fold_from_tables{g->tab.p, g->tc, cG.p, cH.p, GH.p, B, M, N, baseG, baseH}, st);
-                vtmp.alloc((size_t)4 * (M / 2 ? M / 2 : 1) * B);
                 vtab.alloc((size_t)8 * 4 * (M / 2 ? M / 2 : 1) * B);
-                vpart.alloc((size_t)2 * VC * B);
+                vdig.alloc((size_t)8 * 4 * (M / 2 ? M / 2 : 1) * B);
+                vwin.alloc((size_t)2 * 64 * VC * B);
+                vsum.alloc((size_t)2 * 64 * B);
+                vout.alloc((size_t)2 * B);
                 linv.alloc((size_t)2 * B);
                 launch((uint64_t)2 * B, K_set_one{linv.p}, st);
             }
-            launch((uint64_t)4 * mk * B, K_ipa_vb_mul{a.p, bb.p, GH.p, linv.p, vtmp.p, vtab.p, B, mk, M}, st);
-            launch((uint64_t)2 * VC * B, K_ipa_vb_reduce{vtmp.p, vpart.p, B, mk, VC}, st);
-            launch(B, K_msm_finish{g->tab.p, g->tc, vpart.p, cross.p, wch, Lout, B, VC, 0}, st);
-            launch(B, K_msm_finish{g->tab.p, g->tc, vpart.p + (size_t)VC * B, cross.p + B, wch, Rout, B, VC, 0}, st);
+            const uint32_t vc = 2 * mk < VC ? 2 * mk : VC;  // chunks of the 2*mk terms of one output
+            launch((uint64_t)4 * mk * B, K_ipa_vb_tab{a.p, bb.p, GH.p, linv.p, vtab.p, vdig.p, B, mk, M}, st);
+            launch((uint64_t)2 * 64 * vc * B, K_ipa_vb_win{vtab.p, vdig.p, vwin.p, B, mk, vc}, st);
+            launch((uint64_t)2 * 64 * B, K_ge_reduce{vwin.p, vsum.p, B, 2 * 64 * vc, vc}, st);  // chunk sums -> window sums
+            launch((uint64_t)2 * B, K_ipa_vb_horner{vsum.p, vout.p, B, 1}, st);
+            launch(B, K_msm_finish{g->tab.p, g->tc, vout.p, cross.p, wch, Lout, B, 1, 0}, st);
+            launch(B, K_msm_finish{g->tab.p, g->tc, vout.p + (size_t)B, cross.p + B, wch, Rout, B, 1, 0}, st);
         }
         sc* ukk = uk.p + (size_t)k * 2 * B;
         launch(B, K_transcript_LR{tr.p, Lout, ukk, B}, st);

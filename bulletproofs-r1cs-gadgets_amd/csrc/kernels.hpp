@@ -966,18 +966,21 @@ struct K_ipa_fold_from_tables {  // gid = (side*M + j)*B + b
 // so that a fold needs ONE scalar multiplication per output, Ghat' = Ghat_lo + u^2 * Ghat_hi,
 // instead of upstream's two (u^-1*G_lo + u*G_hi); the scale is divided out of the L/R scalars
 // (linv = lam^-1).  Group elements are exact, so L_k / R_k are bit-identical.
-struct K_ipa_vb_mul {  // gid = (w*m + j)*B + b, w<4 : tmp = s * P by signed radix-16 windows
+// L_k / R_k of a variable-base round are multiscalar multiplications over 2m per-proof points each.  Straus with the
+// doublings SHARED by all terms: (1) per term, the multiples 1P..8P and the 64 signed radix-16 digits of its scalar;
+// (2) per (output, window, chunk of terms) the sum of the selected multiples - no doublings at all; (3) per output
+// one Horner pass over the 64 window sums (252 doublings in total instead of 253 per term).
+struct K_ipa_vb_tab {  // gid = (w*m + j)*B + b, w<4 (0 = a_lo*G_hi, 1 = b_hi*H_lo, 2 = a_hi*G_lo, 3 = b_lo*H_hi)
     const sc* a;
     const sc* bb;
     const ge* GH;       // [2][M][B]
     const sc* linv;     // [2][B] Montgomery: lamG^-1, lamH^-1
-    ge* tmp;            // [4][m][B]
-    ge_cached* vtab;    // [8][4*m*B] per-thread multiples 1P..8P
+    ge_cached* vtab;    // [8][4*m*B] multiples 1P..8P
+    uint32_t* vdig;     // [8][4*m*B] 64 x 4-bit two's-complement digits, least significant first
     uint32_t B, m, M;
     HD void operator()(uint32_t g) const {
         uint32_t b = g % B, wj = g / B, w = wj / m, j = wj % m;
-        // branch-free operand selection (w: 0 = a_lo*G_hi, 1 = b_hi*H_lo, 2 = a_hi*G_lo, 3 = b_lo*H_hi)
-        uint32_t side = w & 1u;
+        uint32_t side = w & 1u;  // branch-free operand selection
         const sc* sv = side ? bb : a;
         const ge* pv = side ? GH + (size_t)M * B : GH;
         uint32_t s_hi = (w == 1u) | (w == 2u), p_hi = (w == 0u) | (w == 3u);
@@ -992,30 +995,57 @@ struct K_ipa_vb_mul {  // gid = (w*m + j)*B + b, w<4 : tmp = s * P by signed rad
             q = ge_add(q, c1);
             T[(size_t)e * stride] = ge_to_cached(q);
         }
-        ge acc = ge_identity();
-        int started = 0, carry = 0;
-        // signed digits, least significant first, recoded into a local nibble stream
-        uint32_t dig[8];  // 64 x 4-bit two's-complement digits packed
+        uint32_t dig[8];
 #pragma unroll
         for (int i = 0; i < 8; i++) dig[i] = 0;
+        int carry = 0;
         for (int i = 0; i < 64; i++) {
             int d = (int)((s.v[i >> 3] >> (4 * (i & 7))) & 15u) + carry;
             carry = d >= 8;
-            d -= carry << 4;  // d in [-8, 7]: fits a 4-bit two's-complement digit
+            d -= carry << 4;  // d in [-8, 7]: fits a 4-bit two's-complement digit (s < 2^253: no carry out of digit 63)
             dig[i >> 3] |= ((uint32_t)d & 15u) << (4 * (i & 7));
         }
-        for (int i = 63; i >= 0; i--) {
-            if (started) { acc = ge_dbl(acc); acc = ge_dbl(acc); acc = ge_dbl(acc); acc = ge_dbl(acc); }
-            int d = (int)((dig[i >> 3] >> (4 * (i & 7))) & 15u);
+#pragma unroll
+        for (int i = 0; i < 8; i++) vdig[(size_t)i * stride + g] = dig[i];
+    }
+};
+struct K_ipa_vb_win {  // gid = ((out*64 + win)*VC + c)*B + b : sum over the chunk's terms of digit_win(term) * P_term
+    const ge_cached* vtab;
+    const uint32_t* vdig;
+    ge* part;  // [2][64][VC][B]
+    uint32_t B, m, VC;
+    HD void operator()(uint32_t g) const {
+        uint32_t b = g % B, r0 = g / B, c = r0 % VC, ow = r0 / VC, win = ow & 63u, out = ow >> 6;
+        uint32_t total = 2 * m, per = (total + VC - 1) / VC;
+        uint32_t lo = c * per, hi = lo + per < total ? lo + per : total;
+        size_t stride = (size_t)4 * m * B;
+        ge acc = ge_identity();
+        for (uint32_t o = lo; o < hi; o++) {
+            size_t t = ((size_t)(2 * out) * m + o) * B + b;  // terms of output `out` are w = 2*out and 2*out + 1
+            int d = (int)((vdig[(size_t)(win >> 3) * stride + t] >> (4 * (win & 7u))) & 15u);
             if (d & 8) d -= 16;
             if (d != 0) {
                 int mag = d < 0 ? -d : d;
-                ge_cached e = T[(size_t)(mag - 1) * stride];
+                ge_cached e = vtab[(size_t)(mag - 1) * stride + t];
                 acc = d < 0 ? ge_sub(acc, e) : ge_add(acc, e);
-                started = 1;
             }
         }
-        tmp[g] = acc;
+        part[g] = acc;
+    }
+};
+struct K_ipa_vb_horner {  // gid = out*B + b : sum_w 16^w * S_w, S_w = sum of the VC chunk sums of window w
+    const ge* part;  // [2][64][VC][B]
+    ge* out;         // [2][B]
+    uint32_t B, VC;
+    HD void operator()(uint32_t g) const {
+        uint32_t b = g % B, o = g / B;
+        ge acc = ge_identity();
+        for (int w = 63; w >= 0; w--) {
+            if (w != 63) { acc = ge_dbl(acc); acc = ge_dbl(acc); acc = ge_dbl(acc); acc = ge_dbl(acc); }
+            const ge* p = part + (((size_t)o * 64 + (uint32_t)w) * VC) * B + b;
+            for (uint32_t c = 0; c < VC; c++) acc = ge_add_ge(acc, p[(size_t)c * B]);
+        }
+        out[g] = acc;
     }
 };
 struct K_ipa_vb_fold {  // gid = (b*2 + side)*m + j : Ghat'[j] = Ghat[j] + u^2 Ghat[j+m] ; Hhat' = Hhat[j] + u^-2 Hhat[j+m]
@@ -1040,19 +1070,6 @@ struct K_ipa_vb_fold {  // gid = (b*2 + side)*m + j : Ghat'[j] = Ghat[j] + u^2 G
 struct K_set_one {  // linv = 1
     sc* p;
     HD void operator()(uint32_t g) const { p[g] = sc_one_mont(); }
-};
-struct K_ipa_vb_reduce {  // gid = (out*VC + c)*B + b ; out: 0=L (w 0,1) 1=R (w 2,3)
-    const ge* tmp;
-    ge* partial;  // [2][VC][B]
-    uint32_t B, m, VC;
-    HD void operator()(uint32_t g) const {
-        uint32_t b = g % B, oc = g / B, out = oc / VC, c = oc % VC;
-        uint32_t total = 2 * m, per = (total + VC - 1) / VC;
-        uint32_t lo = c * per, hi = lo + per < total ? lo + per : total;
-        ge acc = ge_identity();
-        for (uint32_t o = lo; o < hi; o++) acc = ge_add_ge(acc, tmp[((size_t)(2 * out) * m + o) * B + b]);
-        partial[g] = acc;
-    }
 };
 // ---------------------------------------------------------------- verifier
 // Verifier::verify (reference call sites src/gadget_vsmt_4.rs:479, gadget_poseidon.rs:781): replay the
