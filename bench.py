@@ -111,7 +111,7 @@ def cpu_baseline(levels, root, values, blindings, seeds, m, n_proofs):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=1024, help="proofs per GPU per step")
     ap.add_argument("--depth", type=int, default=32, help="4-ary tree levels (BASELINE: 32)")
