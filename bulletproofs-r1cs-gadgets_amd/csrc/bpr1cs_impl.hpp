@@ -38,6 +38,7 @@ static int g_unfold_rounds = 4;
 static int g_window_bits = 8;
 static int g_latency_cus = 0;   // >0: CUs reserved for the latency-bound kernels (see bpr1cs_gens_create)
 static int g_rng_mode = 0;       // 0 auto, 1 lane-parallel chain (k_rng_stream), 2 state per thread (k_rng_thread), 3 scalar unit (k_rng_scalar)
+static int g_merge_triples = 1;  // A_I1: one merged table per Inverse-S-box triple (needs the annotated witness program)
 static int g_witness_macro = 1;  // use the Poseidon annotations of a circuit description (poseidon_team)
 static int g_witness_team = 8;   // lanes cooperating on one proof in k_witness_team (4, 8 or 16)
 static uint32_t g_msm_target_threads = 1u << 21;  // (chunk, proof) threads per MSM launch
@@ -75,6 +76,13 @@ struct bpr1cs_circuit {
     DevBuf<PoseidonPerm> perms;
     DevBuf<sc> pconst;
     uint32_t n_perms = 0, px_stride = 0, macro_width = 0;
+    // S-box triples covered by the permutations (a_L = x,x,x ; a_R = 1/x,0,1/x) and the multipliers outside them:
+    // the A_I commitment uses one merged table per triple and side (K_merge_points)
+    std::vector<uint32_t> h_trip, h_rest;
+    DevBuf<uint32_t> trip, rest;
+    const bpr1cs_gens* mt_gens = nullptr;  // merged tables are built for one generator set at a time
+    uint32_t mt_W = 0, mt_cap = 0;
+    DevBuf<ge_niels_packed> mtab;
 };
 
 static bool have_device() {
@@ -360,6 +368,20 @@ int bpr1cs_circuit_create(const bpr1cs_circuit_desc* d, bpr1cs_circuit** out) {
                 pms.push_back(pm);
             }
             if (ok && !pms.empty()) {
+                bool all_cover = true;
+                for (auto& pm : pms) all_cover = all_cover && pm.covers;
+                if (all_cover) {
+                    std::vector<uint8_t> covered(d->n, 0);
+                    for (auto& pm : pms)
+                        for (uint32_t mi = pm.first_mul; mi < pm.first_mul + pm.covers; mi += 3) {
+                            c->h_trip.push_back(mi);
+                            covered[mi] = covered[mi + 1] = covered[mi + 2] = 1;
+                        }
+                    for (uint32_t mi = 0; mi < d->n; mi++)
+                        if (!covered[mi]) c->h_rest.push_back(mi);
+                    upload(c->trip, c->h_trip, s);
+                    upload(c->rest, c->h_rest, s);
+                }
                 ops.swap(patched);
                 c->n_perms = (uint32_t)pms.size();
                 c->px_stride = max_s + 1;
@@ -467,7 +489,8 @@ static MsmStats* g_cur_msm = &g_msm;  // job being enqueued
 // that shares a SIMD with a co-running front kernel a straggler for the whole launch.  The chunk partials are
 // folded `MSM_REDUCE_GROUP` at a time before the per-proof finish kernel.
 static const uint32_t MSM_REDUCE_GROUP = 16;
-static void run_msm(const bpr1cs_gens* g, MsmSeg s0, MsmSeg s1, uint32_t B, DevBuf<ge>& partial, MsmPlan& plan, dev_stream_t st) {
+static void run_msm(const bpr1cs_gens* g, MsmSeg s0, MsmSeg s1, uint32_t B, DevBuf<ge>& partial, MsmPlan& plan, dev_stream_t st,
+                    const ge_niels_packed* table = nullptr) {
     uint32_t total = s0.count + s1.count;
     uint32_t nchunks = pick_chunks(total, B, g_msm_target_threads, plan.chunk);
     uint32_t reduced = nchunks > 128 ? (nchunks + MSM_REDUCE_GROUP - 1) / MSM_REDUCE_GROUP : 0;
@@ -475,7 +498,7 @@ static void run_msm(const bpr1cs_gens* g, MsmSeg s0, MsmSeg s1, uint32_t B, DevB
     if (partial.n < need) partial.alloc(need);
     ge* raw = partial.p + (size_t)reduced * B;  // the reduced partials (what the callers read) sit at the front
     uint32_t nbk = (B + 63u) / 64u;
-    K_msm_fixed k{g->tab.p, g->tc, {s0, s1}, raw, B, plan.chunk, nbk, nchunks * nbk};
+    K_msm_fixed k{table ? table : g->tab.p, g->tc, {s0, s1}, raw, B, plan.chunk, nbk, nchunks * nbk};
 #if !defined(BPR1CS_HOSTSIM)
     hipEvent_t e0 = g_cur_msm->get(), e1 = g_cur_msm->get();
     HIPCHK(hipEventRecord(e0, st));
@@ -701,8 +724,34 @@ extern "C" int bpr1cs_prove_batch_begin(const bpr1cs_gens* g, const bpr1cs_circu
         sc* aL = W.p; sc* aR = W.p + (size_t)n * B; sc* aO = W.p + (size_t)2 * n * B;
         MsmSeg none{nullptr, 0, 1, 1, 0, 0, 0};
         auto seg = [&](const sc* p, uint32_t base0) { return MsmSeg{p, n, n ? n : 1, n ? n : 1, 0, base0, 1}; };
-        run_msm(g, seg(aL, baseG), seg(aR, baseH), B, partial, plan, st);
-        launch(B, K_msm_finish{g->tab.p, g->tc, partial.p, blind.p + 0 * (size_t)B, nullptr, AOS.p + 0 * (size_t)B * 32, B, plan.nchunks, 1}, st);
+        const uint32_t T3 = (uint32_t)c->h_trip.size();
+        if (!wires && T3 && g_merge_triples) {
+            // A_I1 with the repeated S-box wires merged: 2 terms per S-box instead of 5 (see K_merge_points)
+            bpr1cs_circuit* cm = const_cast<bpr1cs_circuit*>(c);
+            if (cm->mt_gens != g || cm->mt_W != g->tc.W || cm->mt_cap != g->cap) {
+                DevBuf<ge> mp((size_t)2 * T3);
+                launch(T3, K_merge_points{g->pts.p, c->trip.p, mp.p, T3, baseG, baseH}, st);
+                cm->mtab.alloc((size_t)2 * T3 * g->tc.per_base);
+                launch((uint64_t)2 * T3 * g->tc.windows, K_build_table{mp.p, cm->mtab.p, g->tc}, st);
+                cm->mt_gens = g;
+                cm->mt_W = g->tc.W;
+                cm->mt_cap = g->cap;
+            }
+            const uint32_t nr = (uint32_t)c->h_rest.size();
+            MsmSeg rG{aL, nr, 1, 1, 0, baseG, 1, c->rest.p, 0}, rH{aR, nr, 1, 1, 0, baseH, 1, c->rest.p, 0};
+            MsmSeg mG{aL, T3, 1, 1, 0, 0, 1, c->trip.p, 1}, mH{aR, T3, 1, 1, 0, T3, 1, c->trip.p, 1};
+            DevBuf<ge> partial2;
+            MsmPlan plan2;
+            run_msm(g, rG, rH, B, partial, plan, st);
+            run_msm(g, mG, mH, B, partial2, plan2, st, c->mtab.p);
+            K_msm_finish fin{g->tab.p, g->tc, partial.p, blind.p + 0 * (size_t)B, nullptr, AOS.p + 0 * (size_t)B * 32, B, plan.nchunks, 1};
+            fin.partial_b = partial2.p;
+            fin.nchunks_b = plan2.nchunks;
+            launch(B, fin, st);
+        } else {
+            run_msm(g, seg(aL, baseG), seg(aR, baseH), B, partial, plan, st);
+            launch(B, K_msm_finish{g->tab.p, g->tc, partial.p, blind.p + 0 * (size_t)B, nullptr, AOS.p + 0 * (size_t)B * 32, B, plan.nchunks, 1}, st);
+        }
         run_msm(g, seg(aO, baseG), none, B, partial, plan, st);
         launch(B, K_msm_finish{g->tab.p, g->tc, partial.p, blind.p + 1 * (size_t)B, nullptr, AOS.p + 1 * (size_t)B * 32, B, plan.nchunks, 1}, st);
         run_msm(g, seg(sL, baseG), seg(sR, baseH), B, partial, plan, st);

@@ -157,6 +157,21 @@ struct K_build_table {  // gid = base*windows + k
     }
 };
 
+// Wires that repeat by construction share ONE table: the three multipliers of an Inverse S-box carry
+// a_L = (x, x, x) and a_R = (1/x, 0, 1/x) (synthesize_inverse_sbox + is_nonzero_gadget, gadget_poseidon.rs:153-185,
+// gadget_zero_nonzero.rs:46-66), so  x G_m + x G_m+1 + x G_m+2 = x (G_m + G_m+1 + G_m+2)  and likewise for H.
+struct K_merge_points {  // gid = s (< T): out[s] = G-sum ; out[T + s] = H-sum of triple s
+    const ge* pts;
+    const uint32_t* trip;  // first multiplier of every triple
+    ge* out;
+    uint32_t T, baseG, baseH;
+    HD void operator()(uint32_t s) const {
+        uint32_t m0 = trip[s];
+        out[s] = ge_add_ge(ge_add_ge(pts[baseG + m0], pts[baseG + m0 + 1]), pts[baseG + m0 + 2]);
+        out[T + s] = ge_add_ge(pts[baseH + m0], pts[baseH + m0 + 2]);
+    }
+};
+
 // ------------------------------------------------------- inputs / V commitments
 struct K_load_inputs {  // canonical v, vbl [m][B] -> Montgomery copies
     const sc* v_raw;
@@ -620,6 +635,9 @@ struct K_load_wires {  // host-synthesised a_L a_R a_O (canonical) -> Montgomery
 struct MsmSeg {
     const sc* scal;
     uint32_t count, run, period, off, base0, mont;
+    // optional gather form: element index = sidx[o]; base = base0 + (bdense ? o : sidx[o])
+    const uint32_t* sidx = nullptr;
+    uint32_t bdense = 0;
 };
 // One thread = (chunk c of the term list, proof b); a workgroup = ONE wavefront = 64 consecutive proofs of one
 // chunk, so its lanes walk the same table rows.  Workgroups are dealt round-robin to the 8 XCDs (each with a
@@ -644,10 +662,11 @@ struct K_msm_fixed {  // gid = wg*64 + lane -> partial[c*B + b]   (launch_wave)
         for (uint32_t o = lo; o < hi; o++) {
             const MsmSeg& s = o < seg[0].count ? seg[0] : seg[1];
             uint32_t oo = o < seg[0].count ? o : o - seg[0].count;
-            uint32_t i = (oo / s.run) * s.period + s.off + (oo % s.run);
+            uint32_t i = s.sidx ? s.sidx[oo] : (oo / s.run) * s.period + s.off + (oo % s.run);
+            uint32_t base = s.base0 + (s.bdense ? oo : i);
             sc x = s.scal[(size_t)i * B + b];
             if (s.mont) x = sc_from_mont(x);
-            acc = table_mul_acc(acc, tab + (size_t)(s.base0 + i) * tc.per_base, x, tc);
+            acc = table_mul_acc(acc, tab + (size_t)base * tc.per_base, x, tc);
         }
         partial[(size_t)c * B + b] = acc;
     }
@@ -674,9 +693,12 @@ struct K_msm_finish {  // gid = b
     const sc* extra2;     // optional second factor (extra*extra2), Montgomery
     uint8_t* out;         // [B][32]
     uint32_t B, nchunks, extra_base;
+    const ge* partial_b = nullptr;  // optional second list of partial sums (a second launch's)
+    uint32_t nchunks_b = 0;
     HD void operator()(uint32_t b) const {
         ge acc = ge_identity();
         for (uint32_t c = 0; c < nchunks; c++) acc = ge_add_ge(acc, partial[(size_t)c * B + b]);
+        for (uint32_t c = 0; c < nchunks_b; c++) acc = ge_add_ge(acc, partial_b[(size_t)c * B + b]);
         if (extra) {
             sc e = extra[b];
             e = extra2 ? sc_from_mont(sc_mul(e, extra2[b])) : sc_from_mont(e);
