@@ -9,7 +9,20 @@ def test_pipeline_bound_check(sim_lib):
 
 
 def test_pipeline_varbase_rounds(sim_lib):
-    common.check_against_oracle(sim_lib, lambda j: S.bound_check(41 + j, 10, 100, 7), 16, 2, 1)
+    """lg N = 4 rounds; `unfold` of them from the tables, the rest variable-base: 3 = one plain round, 1 = a plain
+    round then a PAIR (second round on un-folded generators + fold by two challenges), 0 = two pairs"""
+    ob = common.oracle_batch(lambda j: S.bound_check(41 + j, 10, 100, 7), 16, 2)
+    import importlib
+    bp = common.bp
+    g = bp.Gens(16, lib=sim_lib)
+    circ = common.circuit_from_oracle(ob, sim_lib)
+    try:
+        for unfold in (1, 0, 3):
+            sim_lib.bpr1cs_set_unfold_rounds(unfold)
+            P, _ = bp.prove_batch(g, circ, ob["label"], ob["values"], ob["blindings"], ob["seeds"], 2, wires=ob["wires"])
+            assert P == ob["proofs"], "unfold=%d" % unfold
+    finally:
+        sim_lib.bpr1cs_set_unfold_rounds(4)
 
 
 def test_pipeline_factors(sim_lib):
