@@ -814,7 +814,7 @@ extern "C" int bpr1cs_prove_batch_begin(const bpr1cs_gens* g, const bpr1cs_circu
         } else {
             if (k == r) {
                 GH.alloc((size_t)2 * M * B);
-                launch((uint64_t)2 * M * B, K_ipa_fold_from_tables{g->tab.p, g->tc, cG.p, cH.p, GH.p, B, M, N, baseG, baseH}, st);
+                launch_wave((uint64_t)2 * M * B, K_ipa_fold_from_tables{g->tab.p, g->tc, cG.p, cH.p, GH.p, B, M, N, baseG, baseH}, st);
                 vtab.alloc((size_t)8 * 4 * (M / 2 ? M / 2 : 1) * B);
                 vdig.alloc((size_t)8 * 4 * (M / 2 ? M / 2 : 1) * B);
                 vwin.alloc((size_t)2 * 64 * VC * B);
@@ -825,7 +825,7 @@ extern "C" int bpr1cs_prove_batch_begin(const bpr1cs_gens* g, const bpr1cs_circu
             }
             const uint32_t vc = 2 * mk < VC ? 2 * mk : VC;  // chunks of the 2*mk terms of one output
             launch((uint64_t)4 * mk * B, K_ipa_vb_tab{a.p, bb.p, GH.p, linv.p, vtab.p, vdig.p, B, mk, M}, st);
-            launch((uint64_t)2 * 64 * vc * B, K_ipa_vb_win{vtab.p, vdig.p, vwin.p, B, mk, vc}, st);
+            launch_wave((uint64_t)2 * 64 * vc * B, K_ipa_vb_win{vtab.p, vdig.p, vwin.p, B, mk, vc}, st);
             launch((uint64_t)2 * 64 * B, K_ge_reduce{vwin.p, vsum.p, B, 2 * 64 * vc, vc}, st);  // chunk sums -> window sums
             launch((uint64_t)2 * B, K_ipa_vb_horner{vsum.p, vout.p, B, 1}, st);
             launch(B, K_msm_finish{g->tab.p, g->tc, vout.p, cross.p, wch, Lout, B, 1, 0}, st);
@@ -835,7 +835,7 @@ extern "C" int bpr1cs_prove_batch_begin(const bpr1cs_gens* g, const bpr1cs_circu
         launch(B, K_transcript_LR{tr.p, Lout, ukk, B}, st);
         launch((uint64_t)mk * B, K_ipa_fold_ab{a.p, bb.p, ukk, B, mk}, st);
         if (k < r) launch((uint64_t)N * B, K_ipa_update_c{cG.p, cH.p, ukk, B, Nk}, st);
-        else if (mk > 0 && k + 1 < lgN) launch((uint64_t)2 * mk * B, K_ipa_vb_fold{GH.p, ukk, linv.p, B, mk, M}, st);
+        else if (mk > 0 && k + 1 < lgN) launch_wave((uint64_t)2 * mk * B, K_ipa_vb_fold{GH.p, ukk, linv.p, B, mk, M}, st);
     }
     size_t plen = bpr1cs_proof_len(c);
     job->plen = plen;
