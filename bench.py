@@ -72,10 +72,10 @@ def build_workload(bp, levels, batch, n_leaves, seed_base):
 
 def pmc_traffic_bytes(window):
     """HBM bytes per K_msm_fixed launch from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE,
-    separate runs of this same command; profiles/r01e_pmc_hbm_traffic.txt, W = 11, 1024 proofs).  Returned as
+    separate runs of this same command; profiles/r01f_pmc_hbm_traffic.txt, W = 11, 1024 proofs).  Returned as
     reported by the counters (KB * 1024); the gfx950 FETCH_SIZE caveat (x2 under-count for wide coalesced
     streams, uncalibrated for 96-byte gathers) is discussed in DESIGN.md.  None when no matching profile."""
-    path = os.path.join(ROOT, "profiles", "r01e_pmc_hbm_traffic.txt")
+    path = os.path.join(ROOT, "profiles", "r01f_pmc_hbm_traffic.txt")
     if window != 11 or not os.path.exists(path):
         return None
     for line in open(path):
