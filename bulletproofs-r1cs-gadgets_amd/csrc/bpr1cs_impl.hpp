@@ -224,9 +224,9 @@ int bpr1cs_gens_create(uint32_t cap, bpr1cs_gens** out) {
 void bpr1cs_gens_destroy(bpr1cs_gens* g) {
     if (!g) return;
 #if !defined(BPR1CS_HOSTSIM)
-    hipStreamDestroy(g->stream);
+    (void)hipStreamDestroy(g->stream);
     for (int a = 0; a < 2; a++)
-        for (int b = 0; b < 4; b++) if (g->jstream[a][b]) hipStreamDestroy(g->jstream[a][b]);
+        for (int b = 0; b < 4; b++) if (g->jstream[a][b]) (void)hipStreamDestroy(g->jstream[a][b]);
 #endif
     delete g;
 }
@@ -423,7 +423,7 @@ struct PhaseTimer {
         HIPCHK(hipEventSynchronize(ev.back()));
         HIPCHK(hipEventElapsedTime(&out[0], ev.front(), ev.back()));
         for (size_t i = 1; i < ev.size() && i < 6; i++) HIPCHK(hipEventElapsedTime(&out[i], ev[i - 1], ev[i]));
-        for (auto e : ev) hipEventDestroy(e);
+        for (auto e : ev) (void)hipEventDestroy(e);
         ev.clear();
     }
 #endif
@@ -872,7 +872,7 @@ extern "C" int bpr1cs_prove_batch_end(bpr1cs_job* job, uint8_t* proofs_out, uint
     job->msm.collect();
     g_msm.ms = job->msm.ms; g_msm.launches = job->msm.launches; g_msm.terms = job->msm.terms;
 #if !defined(BPR1CS_HOSTSIM)
-    for (auto e : job->msm.pool) hipEventDestroy(e);
+    for (auto e : job->msm.pool) (void)hipEventDestroy(e);
     HIPCHK(hipEventDestroy(job->ev_in));
     HIPCHK(hipEventDestroy(job->ev_rng));
     if (job->ev_wit) HIPCHK(hipEventDestroy(job->ev_wit));
