@@ -148,8 +148,10 @@ __global__ void __launch_bounds__(64) k_rng_stream(const strobe* rng_in, uint64_
     const int ROT[25] = {0, 1, 62, 28, 27, 36, 44, 6, 55, 20, 3, 10, 43, 25, 39, 41, 45, 15, 21, 8, 18, 2, 61, 56, 14};  // [x + 5y]
     const int rot = ROT[j];
     // rho as two funnel shifts on 32-bit halves: rotl64 by r = (swap halves if r >= 32) then alignbit by 32 - (r & 31)
-    const bool rot_swap = rot >= 32, rot_none = rot == 0;
-    const uint32_t rot_k = (32u - ((uint32_t)rot & 31u)) & 31u;  // no lane has r & 31 == 0 except r == 0 (handled by rot_none)
+    // (lane 0, r = 0: swap and shift by 0 - alignbit(x, y, 0) = y undoes the swap; no other lane has r & 31 == 0)
+    const bool rot_swap = rot >= 32 || rot == 0;
+    const uint32_t rot_k = (32u - ((uint32_t)rot & 31u)) & 31u;
+    const uint32_t iota_mask = j == 0 ? 0xffffffffu : 0u;
     const uint32_t xm = (x + 4u) % 5u, xp = (x + 1u) % 5u;
     // chi operands pulled straight from the pre-pi lanes: B[X][Y] = rot(A)[(X + 3Y) % 5 + 5X]
     const uint32_t s0 = (x + 3u * y) % 5u + 5u * x;
@@ -176,14 +178,13 @@ __global__ void __launch_bounds__(64) k_rng_stream(const strobe* rng_in, uint64_
             uint32_t th = K_XOR3(HI(a), mh, __builtin_amdgcn_alignbit(ph, pl, 31));
             uint32_t ul = rot_swap ? th : tl, uh = rot_swap ? tl : th;             // rho
             uint32_t nl = __builtin_amdgcn_alignbit(ul, uh, rot_k), nh = __builtin_amdgcn_alignbit(uh, ul, rot_k);
-            nl = rot_none ? tl : nl;
-            nh = rot_none ? th : nh;
             A1[i] = ((uint64_t)nh << 32) | nl;
             lds_order();
             uint64_t b0 = A1[s0], b1 = A1[s1], b2 = A1[s2];                         // pi
             uint32_t cl = K_CHI(LO(b0), LO(b1), LO(b2)), ch = K_CHI(HI(b0), HI(b1), HI(b2));  // chi
+            cl = __builtin_amdgcn_bitop3_b32(cl, (uint32_t)KECCAK_RC[r], iota_mask, 0x78);          // iota: a ^ (RC & lane-0 mask)
+            ch = __builtin_amdgcn_bitop3_b32(ch, (uint32_t)(KECCAK_RC[r] >> 32), iota_mask, 0x78);
             a = ((uint64_t)ch << 32) | cl;
-            if (j == 0) a ^= KECCAK_RC[r];                                          // iota
         }
         if (i < 8) {
             if (valid) raw_out[((size_t)d * B + b) * 8 + i] = a;
