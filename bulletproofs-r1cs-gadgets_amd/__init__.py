@@ -334,8 +334,9 @@ def load_gadgets_library(path=None):
         getattr(g, "bpr1cs_%s_root" % nm).argtypes = [vp, cp]
         getattr(g, "bpr1cs_%s_update" % nm).argtypes = [vp, cp, cp]
         getattr(g, "bpr1cs_%s_get" % nm).argtypes = [vp, cp, cp, cp]
-    g.bpr1cs_vsmt4_update_many.argtypes = [vp, cp, cp, sz]
-    g.bpr1cs_vsmt4_get_many.argtypes = [vp, cp, sz, cp, cp]
+    for nm in ("vsmt4", "vsmt2"):
+        getattr(g, "bpr1cs_%s_update_many" % nm).argtypes = [vp, cp, cp, sz]
+        getattr(g, "bpr1cs_%s_get_many" % nm).argtypes = [vp, cp, sz, cp, cp]
     if path is None:
         _glib = g
     return g
@@ -430,19 +431,18 @@ class SparseMerkleTree:
         getattr(self.g, "bpr1cs_%s_update" % self.nm)(self.h, _sc(idx), _sc(val))
 
     def update_many(self, leaves):
-        """[(idx, val), ...] with DISTINCT indices, arity 4 only: every tree level is hashed by one device launch."""
-        assert self.arity == 4
+        """[(idx, val), ...] with DISTINCT indices: every tree level is hashed by one device launch."""
         idx = b"".join(_sc(i) for i, _ in leaves)
         vals = b"".join(_sc(v) for _, v in leaves)
-        _chk(self.g.bpr1cs_vsmt4_update_many(self.h, idx, vals, len(leaves)))
+        _chk(getattr(self.g, "bpr1cs_%s_update_many" % self.nm)(self.h, idx, vals, len(leaves)))
 
     def get_many(self, indices):
-        """-> (leaves: bytes count*32, paths: bytes count*levels*3*32), arity 4 only; no re-hashing of the paths."""
-        assert self.arity == 4
+        """-> (leaves: bytes count*32, paths: bytes count*levels*(arity-1)*32); no re-hashing of the paths."""
         n = len(indices)
+        per = 3 if self.arity == 4 else 1
         leaves = ctypes.create_string_buffer(32 * n)
-        proofs = ctypes.create_string_buffer(32 * 3 * self.levels * n)
-        _chk(self.g.bpr1cs_vsmt4_get_many(self.h, b"".join(_sc(i) for i in indices), n, leaves, proofs))
+        proofs = ctypes.create_string_buffer(32 * per * self.levels * n)
+        _chk(getattr(self.g, "bpr1cs_%s_get_many" % self.nm)(self.h, b"".join(_sc(i) for i in indices), n, leaves, proofs))
         return leaves.raw, proofs.raw
 
     def get(self, idx):

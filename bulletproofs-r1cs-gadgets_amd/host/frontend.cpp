@@ -470,9 +470,9 @@ void bpr1cs_vsmt4_root(const bpr1cs_vsmt4* t, uint8_t out[32]) { memcpy(out, t->
 void bpr1cs_vsmt4_update(bpr1cs_vsmt4* t, const uint8_t idx[32], const uint8_t val[32]) {
     t->tree->update(Scalar::from_bytes_mod_order(idx), Scalar::from_bytes_mod_order(val));
 }
-// Poseidon_hash_4 (gadget_poseidon.rs:488-503) of many inputs through the device's bulk permutation
-static std::vector<Scalar> device_hash4_batch(const PoseidonParams& p, const std::vector<std::array<Scalar, 4>>& inputs) {
-    std::vector<uint8_t> mds, rk, in(inputs.size() * 6 * 32), out(inputs.size() * 6 * 32);
+// many Poseidon permutations of width-6 states through the device; returns element [1] of every output (the hash)
+static std::vector<Scalar> device_perm_batch_elem1(const PoseidonParams& p, const std::vector<std::array<Scalar, 6>>& states) {
+    std::vector<uint8_t> mds, rk, in(states.size() * 6 * 32), out(states.size() * 6 * 32);
     for (size_t i = 0; i < p.width; i++)
         for (size_t j = 0; j < p.width; j++) { auto b = p.MDS_matrix[i][j].to_bytes(); mds.insert(mds.end(), b.begin(), b.end()); }
     size_t nk = p.get_total_rounds() * p.width;
@@ -481,18 +481,26 @@ static std::vector<Scalar> device_hash4_batch(const PoseidonParams& p, const std
     pp.width = (uint32_t)p.width; pp.full_rounds_beginning = (uint32_t)p.full_rounds_beginning;
     pp.partial_rounds = (uint32_t)p.partial_rounds; pp.full_rounds_end = (uint32_t)p.full_rounds_end;
     pp.mds = mds.data(); pp.round_keys = rk.data();
-    auto put = [&](size_t k, const Scalar& x) { auto b = x.to_bytes(); memcpy(&in[32 * k], b.data(), 32); };
-    for (size_t h = 0; h < inputs.size(); h++) {
-        put(6 * h + 0, Scalar(ZERO_CONST));
-        for (size_t i = 0; i < 4; i++) put(6 * h + 1 + i, inputs[h][i]);
-        put(6 * h + 5, Scalar(PADDING_CONST));
-    }
+    for (size_t h = 0; h < states.size(); h++)
+        for (size_t i = 0; i < 6; i++) { auto b = states[h][i].to_bytes(); memcpy(&in[32 * (6 * h + i)], b.data(), 32); }
     std::vector<Scalar> res;
-    if (inputs.empty()) return res;
-    int rc = bpr1cs_poseidon_permutation_batch(&pp, 1, in.data(), inputs.size(), out.data());
+    if (states.empty()) return res;
+    int rc = bpr1cs_poseidon_permutation_batch(&pp, 1, in.data(), states.size(), out.data());
     if (rc) throw R1CSError::Backend(rc);
-    for (size_t h = 0; h < inputs.size(); h++) res.push_back(Scalar::from_bytes_mod_order(&out[32 * (6 * h + 1)]));
+    for (size_t h = 0; h < states.size(); h++) res.push_back(Scalar::from_bytes_mod_order(&out[32 * (6 * h + 1)]));
     return res;
+}
+// Poseidon_hash_2 (gadget_poseidon.rs:428-443) of many pairs
+static std::vector<Scalar> device_hash2_batch(const PoseidonParams& p, const std::vector<std::pair<Scalar, Scalar>>& inputs) {
+    std::vector<std::array<Scalar, 6>> st;
+    for (auto& in : inputs) st.push_back({Scalar(ZERO_CONST), in.first, in.second, Scalar(PADDING_CONST), Scalar(ZERO_CONST), Scalar(ZERO_CONST)});
+    return device_perm_batch_elem1(p, st);
+}
+// Poseidon_hash_4 (gadget_poseidon.rs:488-503) of many inputs through the device's bulk permutation
+static std::vector<Scalar> device_hash4_batch(const PoseidonParams& p, const std::vector<std::array<Scalar, 4>>& inputs) {
+    std::vector<std::array<Scalar, 6>> st;
+    for (auto& in : inputs) st.push_back({Scalar(ZERO_CONST), in[0], in[1], in[2], in[3], Scalar(PADDING_CONST)});
+    return device_perm_batch_elem1(p, st);
 }
 // bulk insert of `count` DISTINCT leaves; every tree level is hashed by one device launch
 int bpr1cs_vsmt4_update_many(bpr1cs_vsmt4* t, const uint8_t* idx, const uint8_t* vals, size_t count) {
@@ -563,6 +571,33 @@ int bpr1cs_vsmt2_get(const bpr1cs_vsmt2* t, const uint8_t idx[32], uint8_t* leaf
         memcpy(leaf_out, leaf.to_bytes().data(), 32);
         for (size_t k = 0; k < proof.size(); k++) memcpy(proof_out + 32 * k, proof[k].to_bytes().data(), 32);
         return t->tree->verify_proof(Scalar::from_bytes_mod_order(idx), leaf, proof) ? BPR1CS_OK : BPR1CS_ERR_VERIFICATION;
+    } catch (const std::exception&) {
+        return BPR1CS_ERR_INVALID_ARGUMENT;
+    }
+}
+int bpr1cs_vsmt2_update_many(bpr1cs_vsmt2* t, const uint8_t* idx, const uint8_t* vals, size_t count) {
+    try {
+        std::vector<std::pair<Scalar, Scalar>> leaves;
+        for (size_t i = 0; i < count; i++) leaves.push_back({Scalar::from_bytes_mod_order(idx + 32 * i), Scalar::from_bytes_mod_order(vals + 32 * i)});
+        const PoseidonParams& p = *t->params;
+        t->tree->update_many(leaves, [&](const std::vector<std::pair<Scalar, Scalar>>& in) { return device_hash2_batch(p, in); });
+        return BPR1CS_OK;
+    } catch (const R1CSError& e) {
+        return e.code;
+    } catch (const std::exception&) {
+        return BPR1CS_ERR_INVALID_ARGUMENT;
+    }
+}
+int bpr1cs_vsmt2_get_many(const bpr1cs_vsmt2* t, const uint8_t* idx, size_t count, uint8_t* leaves_out, uint8_t* proofs_out) {
+    try {
+        size_t per = t->tree->depth * 32;
+        for (size_t i = 0; i < count; i++) {
+            std::vector<Scalar> proof;
+            Scalar leaf = t->tree->get(Scalar::from_bytes_mod_order(idx + 32 * i), &proof);
+            memcpy(leaves_out + 32 * i, leaf.to_bytes().data(), 32);
+            for (size_t k2 = 0; k2 < proof.size(); k2++) memcpy(proofs_out + per * i + 32 * k2, proof[k2].to_bytes().data(), 32);
+        }
+        return BPR1CS_OK;
     } catch (const std::exception&) {
         return BPR1CS_ERR_INVALID_ARGUMENT;
     }

@@ -613,6 +613,54 @@ public:
         }
         return cur;
     }
+    // Bulk form of `update` for DISTINCT leaf indices (extension, as VanillaSparseMerkleTree_4::update_many): one
+    // `hash2_batch` call (on the device: bpr1cs_poseidon_permutation_batch) per tree level.
+    using Hash2Batch = std::function<std::vector<Scalar>(const std::vector<std::pair<Scalar, Scalar>>&)>;
+    Scalar update_many(const std::vector<std::pair<Scalar, Scalar>>& leaves, const Hash2Batch& hash2_batch) {
+        using Prefix = std::vector<uint8_t>;  // path bits, root level first
+        std::map<Prefix, Scalar> old_node;
+        std::vector<std::map<Prefix, Scalar>> fresh(depth + 1);
+        old_node[Prefix{}] = root;
+        for (auto& lv : leaves) {
+            auto bits = get_bits(lv.first, depth);
+            Prefix p;
+            Scalar cur = root;
+            for (size_t i = 0; i < depth; i++) {
+                const auto& v = db.at(ScalarKey{cur.to_bytes()});
+                uint8_t bit = bits[depth - 1 - i];
+                cur = bit ? v.second : v.first;
+                p.push_back(bit);
+                old_node.emplace(p, cur);
+            }
+            if (!fresh[depth].emplace(p, lv.second).second) throw R1CSError::GadgetError("update_many: duplicate leaf index");
+        }
+        for (size_t level = depth; level-- > 0;) {
+            std::vector<Prefix> parents;
+            for (auto& kv : fresh[level + 1]) {
+                Prefix par(kv.first.begin(), kv.first.end() - 1);
+                if (parents.empty() || parents.back() != par) parents.push_back(par);
+            }
+            std::vector<std::pair<Scalar, Scalar>> inputs;
+            for (auto& par : parents) {
+                const auto& oldc = db.at(ScalarKey{old_node.at(par).to_bytes()});
+                Scalar in[2] = {oldc.first, oldc.second};
+                for (uint8_t i = 0; i < 2; i++) {
+                    Prefix ch = par;
+                    ch.push_back(i);
+                    auto it = fresh[level + 1].find(ch);
+                    if (it != fresh[level + 1].end()) in[i] = it->second;
+                }
+                inputs.push_back({in[0], in[1]});
+            }
+            std::vector<Scalar> hashes = hash2_batch(inputs);
+            for (size_t k = 0; k < parents.size(); k++) {
+                db[ScalarKey{hashes[k].to_bytes()}] = inputs[k];
+                fresh[level].emplace(parents[k], hashes[k]);
+            }
+        }
+        if (!leaves.empty()) root = fresh[0].at(Prefix{});
+        return root;
+    }
     bool verify_proof(const Scalar& idx, const Scalar& val, const std::vector<Scalar>& proof, const Scalar* root_opt = nullptr) const {
         auto bits = get_bits(idx, depth);
         Scalar cur = val;

@@ -73,6 +73,8 @@ void bpr1cs_vsmt2_free(bpr1cs_vsmt2* t);
 void bpr1cs_vsmt2_root(const bpr1cs_vsmt2* t, uint8_t out[32]);
 void bpr1cs_vsmt2_update(bpr1cs_vsmt2* t, const uint8_t idx[32], const uint8_t val[32]);
 int bpr1cs_vsmt2_get(const bpr1cs_vsmt2* t, const uint8_t idx[32], uint8_t* leaf_out, uint8_t* proof_out /* depth*32, root level first */);
+int bpr1cs_vsmt2_update_many(bpr1cs_vsmt2* t, const uint8_t* idx, const uint8_t* vals, size_t count);   /* as bpr1cs_vsmt4_update_many */
+int bpr1cs_vsmt2_get_many(const bpr1cs_vsmt2* t, const uint8_t* idx, size_t count, uint8_t* leaves_out, uint8_t* proofs_out /* count*depth*32 */);
 
 #ifdef __cplusplus
 }

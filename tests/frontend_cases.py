@@ -215,6 +215,23 @@ def check_bulk_tree(lib, glib, levels=4, partial_rounds=2, count=9):
         assert paths[per * k:per * (k + 1)] == b"".join(sc_to_bytes(x) for node in oproof for x in node)
     with pytest.raises(Exception):
         t.update_many([(9, 1), (9, 2)])      # duplicate index
+    # arity 2 (VanillaSparseMerkleTree, gadget_vsmt_2.rs:33-131)
+    d2 = min(levels, 6)
+    t2 = bp.SparseMerkleTree(2, d2, partial_rounds, glib=glib)
+    o2 = g.VanillaSparseMerkleTree(params, depth=d2)
+    t2.update(5, 50); o2.update(5, 50)
+    leaves2 = [(1 + 3 * k, 700 + k) for k in range(min(count, (1 << d2) // 3 - 1))]
+    leaves2 = [(i, v) for i, v in leaves2 if i != 5]
+    t2.update_many(leaves2)
+    for i, v in leaves2:
+        o2.update(i, v)
+    assert t2.root() == sc_to_bytes(o2.root)
+    idx2 = [i for i, _ in leaves2] + [5, 2]
+    lv2, p2 = t2.get_many(idx2)
+    for k, i in enumerate(idx2):
+        oleaf, oproof = o2.get(i, True)
+        assert lv2[32 * k:32 * k + 32] == sc_to_bytes(oleaf)
+        assert p2[32 * d2 * k:32 * d2 * (k + 1)] == b"".join(sc_to_bytes(x) for x in oproof)
 
 
 def check_prove_verify_roundtrip(lib, glib, name, batch=2):
