@@ -69,3 +69,21 @@ def test_rng_chain_mappings_agree(hip_lib, mode):
         common.check_against_oracle(hip_lib, lambda j: S.set_membership([2, 3, 5, 6, 8, 20, 25][j % 7], [2, 3, 5, 6, 8, 20, 25]), 32, 2, 2)
     finally:
         hip_lib.bpr1cs_set_rng_mode(0)
+
+
+def test_two_batches_in_flight_on_device(hip_lib):
+    """bpr1cs_prove_batch_begin x2 before _end: the second job's front runs next to the first one's back; ragged batch sizes; proofs equal the oracle's."""
+    bp = common.bp
+    ob = common.oracle_batch(lambda j: S.bound_check(37 + j, 10, 100, 7), 16, 3)
+    gens = bp.Gens(16, lib=hip_lib)
+    circ = common.circuit_from_oracle(ob, hip_lib)
+    hip_lib.bpr1cs_set_unfold_rounds(2)
+    n32 = lambda x, k: x[:32 * circ.m * k]
+    j1 = bp.ProveJob(gens, circ, ob["label"], ob["values"], ob["blindings"], ob["seeds"], 3, wires=ob["wires"])
+    j2 = bp.ProveJob(gens, circ, ob["label"], n32(ob["values"], 2), n32(ob["blindings"], 2), ob["seeds"][:64], 2,
+                     wires=b"".join(ob["wires"][96 * circ.n * k:96 * circ.n * (k + 1)] for k in range(2)))
+    j3 = bp.ProveJob(gens, circ, ob["label"], ob["values"], ob["blindings"], ob["seeds"], 3, wires=ob["wires"])
+    P1, _ = j1.finish()
+    P2, _ = j2.finish()
+    P3, _ = j3.finish()
+    assert P1 == ob["proofs"] and P2 == ob["proofs"][:2] and P3 == ob["proofs"]
