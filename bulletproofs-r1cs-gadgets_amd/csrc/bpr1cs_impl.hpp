@@ -1101,6 +1101,22 @@ extern "C" int bpr1cs_msm_fixed(const bpr1cs_gens* g, const uint32_t* bases, siz
         runs.push_back({t, e - t});
         t = e;
     }
+    if (runs.size() <= 2) {  // the common shapes (one or two runs of consecutive bases): the prover's own launch geometry
+        auto mk1 = [&](size_t ri) {
+            uint32_t len = (uint32_t)runs[ri].second;
+            return MsmSeg{sc_dev.p + runs[ri].first * (size_t)B, len, len, len, 0, bases[runs[ri].first], 0};
+        };
+        MsmSeg s0 = mk1(0), s1{nullptr, 0, 1, 1, 0, 0, 0};
+        if (runs.size() == 2) s1 = mk1(1);
+        DevBuf<ge> partial;
+        MsmPlan plan;
+        run_msm(g, s0, s1, B, partial, plan, st);
+        DevBuf<uint8_t> d_out1((size_t)B * 32);
+        launch(B, K_msm_finish{g->tab.p, g->tc, partial.p, nullptr, nullptr, d_out1.p, B, plan.nchunks, 0}, st);
+        dev_d2h(out, d_out1.p, (size_t)B * 32, st);
+        g_msm.collect();
+        return BPR1CS_OK;
+    }
     // accumulate the runs pairwise into chunk partials, then finish once
     size_t total_chunks = 0;
     std::vector<ge> dummy;
