@@ -94,40 +94,70 @@ HD inline int sc_is_zero(const sc& a) {
     return o == 0;
 }
 
-// Montgomery product a*b*R^-1 mod l.  Requires a*b < l*R (e.g. b < l, a < 2^256).
+// Montgomery product a*b*R^-1 mod l, R = 2^256.  Requires a*b < l*R (e.g. b < l, a < 2^256).
+// Internally 9 limbs of 29 bits (as csrc/fe.hpp): the 81 limb products and the 54 products of the reduction
+// (l = 2^252 + delta has only six non-zero 29-bit limbs) accumulate in 64-bit column sums without carry handling.
+// The radix-2^29 reduction divides by 2^261, so b enters pre-multiplied by 2^5 (a shifted unpack): a*(32 b)/2^261.
+HD_CONST uint32_t SC_L29[9] = {485872621u, 9640146u, 501691798u, 502512965u, 333u, 0u, 0u, 0u, 1048576u};
+#define SC_LINV29 0x12547e1bu  // -l^{-1} mod 2^29
+#define SC_MASK29 0x1fffffffu
 HD inline sc sc_mul(const sc& a, const sc& b) {
-    uint32_t t[9];
+    uint32_t A[9], Bs[9];
 #pragma unroll
-    for (int i = 0; i < 9; i++) t[i] = 0;
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-        uint64_t c = 0;
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            c += (uint64_t)a.v[i] * b.v[j] + t[j];
-            t[j] = (uint32_t)c;
-            c >>= 32;
-        }
-        c += t[8];
-        t[8] = (uint32_t)c;
-        uint32_t t9 = (uint32_t)(c >> 32);
-        uint32_t m = t[0] * SC_LPRIME;
-        c = (uint64_t)m * SC_L[0] + t[0];
-        c >>= 32;
-#pragma unroll
-        for (int j = 1; j < 8; j++) {
-            c += (uint64_t)m * SC_L[j] + t[j];
-            t[j - 1] = (uint32_t)c;
-            c >>= 32;
-        }
-        c += t[8];
-        t[7] = (uint32_t)c;
-        t[8] = t9 + (uint32_t)(c >> 32);
+    for (int i = 0; i < 9; i++) {
+        int bit = 29 * i, wi = bit >> 5, sh = bit & 31;
+        uint64_t two = (uint64_t)a.v[wi] | ((wi + 1 < 8) ? ((uint64_t)a.v[wi + 1] << 32) : 0);
+        A[i] = (uint32_t)(two >> sh) & SC_MASK29;
     }
-    sc r;
+    Bs[0] = (b.v[0] << 5) & SC_MASK29;
 #pragma unroll
-    for (int i = 0; i < 8; i++) r.v[i] = t[i];
-    // result < 2l (t[8] == 0 because l < 2^253)
+    for (int i = 1; i < 9; i++) {  // bits [29 i - 5, 29 i + 24) of b
+        int bit = 29 * i - 5, wi = bit >> 5, sh = bit & 31;
+        uint64_t two = (uint64_t)b.v[wi] | ((wi + 1 < 8) ? ((uint64_t)b.v[wi + 1] << 32) : 0);
+        Bs[i] = (uint32_t)(two >> sh) & SC_MASK29;
+    }
+    uint64_t T[18];
+#pragma unroll
+    for (int k = 0; k < 17; k++) {
+        uint64_t acc = 0;
+#pragma unroll
+        for (int i = 0; i < 9; i++) {
+            int j = k - i;
+            if (j >= 0 && j < 9) acc += (uint64_t)A[i] * Bs[j];
+        }
+        T[k] = acc;
+    }
+    T[17] = 0;
+    uint64_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        uint64_t t = T[i] + c;
+        uint32_t m = ((uint32_t)t * SC_LINV29) & SC_MASK29;
+        t += (uint64_t)m * SC_L29[0];  // low 29 bits are zero now
+        c = t >> 29;
+        T[i + 1] += (uint64_t)m * SC_L29[1];
+        T[i + 2] += (uint64_t)m * SC_L29[2];
+        T[i + 3] += (uint64_t)m * SC_L29[3];
+        T[i + 4] += (uint64_t)m * SC_L29[4];
+        T[i + 8] += (uint64_t)m * SC_L29[8];
+    }
+    uint32_t Rl[10];
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+        uint64_t t = T[9 + k] + c;
+        Rl[k] = (uint32_t)t & SC_MASK29;
+        c = t >> 29;
+    }
+    Rl[9] = 0;
+    sc r;  // value < 2 l < 2^254: 9 x 29 -> 8 x 32
+#pragma unroll
+    for (int w = 0; w < 8; w++) {
+        int bit = 32 * w, i = bit / 29, sh = bit % 29;
+        uint64_t acc = (uint64_t)Rl[i] >> sh;
+        acc |= (uint64_t)Rl[i + 1] << (29 - sh);
+        if (58 - sh < 32) acc |= (uint64_t)Rl[i + 2] << (58 - sh);
+        r.v[w] = (uint32_t)acc;
+    }
     return sc_cond_sub_l(r);
 }
 
