@@ -27,7 +27,7 @@ sys.path.insert(0, ROOT)
 
 L = 2**252 + 27742317777372353535851937790883648493
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
-UBENCH_MADD_PEAK_G = 33.7  # G ge_madd/s on one MI355X with every SIMD busy (tools/ubench.hip, profiles/r01g_ubench_gfx950.txt)
+UBENCH_MADD_PEAK_G = 33.7  # G ge_madd/s on one MI355X with every SIMD busy (tools/ubench.hip, profiles/r01h_ubench_gfx950.txt)
 
 
 def synth_scalar(tag, i):
@@ -256,7 +256,7 @@ def main():
                          "note": "achieved/frac use ALGORITHMIC bytes (64 B per scalar*point term); the kernel is integer-VALU bound and additionally "
                                  "streams its fixed-base tables from HBM (traffic, PMC) — see DESIGN.md"},
             # second, honest ceiling: the kernel is bound by 32-bit integer multiply-add issue.  One term =
-            # ceil(253 / W) table additions; peak = ge_madd throughput of tools/ubench on this chip (profiles/r01g_ubench_gfx950.txt)
+            # ceil(253 / W) table additions; peak = ge_madd throughput of tools/ubench on this chip (profiles/r01h_ubench_gfx950.txt)
             "roofline_valu": {"bound": "valu-int32-mad", "unit": "G table-add/s",
                               "achieved": (msm_terms * ((253 + args.window - 1) // args.window) / 1e9) / (msm_ms / 1e3) if msm_ms > 0 else None,
                               "peak": UBENCH_MADD_PEAK_G,
