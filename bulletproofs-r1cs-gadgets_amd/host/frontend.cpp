@@ -238,6 +238,24 @@ static size_t run_gadget(const GadgetSpec& g, Harness& h) {
         set_non_membership_gadget(h.cs, v, diffs, invs, items);
         return 2 * k + 1;
     }
+    if (g.name == "mimc_set_membership") {  // both circuits on one prover; ip = [rounds, k, items(lo,hi)...]
+        size_t rounds = g.ip.at(0), k = g.ip.at(1);
+        std::vector<Scalar> consts(g.sp.begin(), g.sp.begin() + rounds);
+        auto l = AS(0), r = AS(1);
+        mimc_gadget(h.cs, l, r, rounds, consts, g.sp.at(rounds));
+        std::vector<uint64_t> items;
+        for (size_t i = 0; i < k; i++) items.push_back(u64_of(g.ip, 2 + 2 * i));
+        std::vector<AllocatedQuantity> bit_vars;
+        for (size_t i = 0; i < k; i++) {
+            auto q = AQ(2 + i);
+            bit_gadget(h.cs, q);
+            bit_vars.push_back(q);
+        }
+        vector_sum_gadget(h.cs, bit_vars, 1);
+        auto val = AQ(2 + k);
+        vector_product_gadget(h.cs, items, bit_vars, val);
+        return k + 3;
+    }
     if (g.name == "mimc") {  // src/gadget_mimc.rs:92-175 ; sp = constants[rounds] ++ [image]
         size_t rounds = g.ip.at(0);
         std::vector<Scalar> consts(g.sp.begin(), g.sp.begin() + rounds);

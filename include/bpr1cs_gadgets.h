@@ -17,6 +17,7 @@
  *   "not_equals"       ip=[expected_lo, expected_hi]            values: value, expected - value, its inverse (src/gadget_not_equals.rs:44-110)
  *   "is_zero"          -                                        values: x (must be 0)              (src/gadget_zero_nonzero.rs:21-43,76-110)
  *   "mimc"             ip=[rounds] sp=[constants..., image]     values: xl, xr                     (src/gadget_mimc.rs:92-175)
+ *   "mimc_set_membership" ip=[rounds, k, item_lo,item_hi ...] sp=[constants..., image]  values: xl, xr, k bits, value  (both circuits on one prover)
  *   "poseidon_hash_2"  ip=[sbox(0 cube,1 inverse), partial_rounds] sp=[output]  values: xl, xr, 0,101,0,0       (src/gadget_poseidon.rs:692-790)
  *   "poseidon_hash_4"  ip=[sbox, partial_rounds] sp=[output]    values: x0..x3, 0,101                (:792-875)
  *   "poseidon_perm"    ip=[sbox, partial_rounds] sp=[out0..5]   values: x0..x5                       (:624-690)

@@ -314,3 +314,35 @@ def set_non_membership(value, set_, label=b"SetNonMemebershipTest"):
         a = [Alloc(vr.commit(c), None) for c in comms]
         g.set_non_membership_gadget(vr, a[0], a[1::2], a[2::2], set_)
     return Scenario(label, vals, bp, bv)
+
+
+def mimc_set_membership(xl, xr, constants, value, set_, label=b"MiMC+SetMembership"):
+    """the MiMC-322 preimage circuit (gadget_mimc.rs:92-175) and set_membership
+    (gadget_set_membership.rs:93-134) on ONE prover - the composition is the build's; each half follows its reference test."""
+    image = g.mimc(xl, xr, constants)
+    bit_map = [1 if e == value else 0 for e in set_]
+
+    def bp(pr, bl):
+        cl, vl = pr.commit(xl, bl[0]); cr, vr_ = pr.commit(xr, bl[1])
+        g.mimc_gadget(pr, Alloc(vl, xl), Alloc(vr_, xr), len(constants), constants, image)
+        comms, bit_vars = [cl, cr], []
+        for k, b in enumerate(bit_map):
+            c, v = pr.commit(b, bl[2 + k]); q = Alloc(v, b)
+            g.bit_gadget(pr, q); comms.append(c); bit_vars.append(q)
+        g.vector_sum_gadget(pr, bit_vars, 1)
+        c, v = pr.commit(value, bl[2 + len(set_)])
+        g.vector_product_gadget(pr, set_, bit_vars, Alloc(v, value))
+        comms.append(c)
+        return comms
+
+    def bv(vr, comms, pc):
+        lv, rv = vr.commit(comms[0]), vr.commit(comms[1])
+        g.mimc_gadget(vr, Alloc(lv, None), Alloc(rv, None), len(constants), constants, image)
+        bit_vars = []
+        for i in range(len(set_)):
+            q = Alloc(vr.commit(comms[2 + i]), None)
+            g.bit_gadget(vr, q); bit_vars.append(q)
+        g.vector_sum_gadget(vr, bit_vars, 1)
+        v = vr.commit(comms[2 + len(set_)])
+        g.vector_product_gadget(vr, set_, bit_vars, Alloc(v, None))
+    return Scenario(label, [xl, xr] + bit_map + [value], bp, bv)

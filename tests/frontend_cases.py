@@ -71,6 +71,16 @@ def case(name, j=0):
         sc = S.mimc(S.synth_scalar(b"ml", j), S.synth_scalar(b"mr", j), consts)
         image = g.mimc(S.synth_scalar(b"ml", j), S.synth_scalar(b"mr", j), consts)
         return "mimc", [g.MIMC_ROUNDS], consts + [image], sc, 1024
+    if name.startswith("mimc_set_membership"):
+        rounds = 8 if name.endswith("_r8") else g.MIMC_ROUNDS
+        consts = [S.synth_scalar(b"mimc-const", i) for i in range(rounds)]
+        xl, xr = S.synth_scalar(b"ml", j), S.synth_scalar(b"mr", j)
+        sc = S.mimc_set_membership(xl, xr, consts, SET[j % len(SET)], SET)
+        ip = [rounds, len(SET)]
+        for x in SET:
+            ip += _u64(x)
+        n = 2 * rounds + 3 * len(SET)
+        return "mimc_set_membership", ip, consts + [g.mimc(xl, xr, consts)], sc, 1 << (n - 1).bit_length()
     if name.startswith("vsmt_2"):
         depth, pr = 3, 2
         tree = _tree2(depth, pr)
@@ -243,7 +253,7 @@ def check_prove_verify_roundtrip(lib, glib, name, batch=2):
     gens = bp.Gens(cap, lib=lib)
     P, C = bp.prove_batch(gens, circ, ob["label"], ob["values"], ob["blindings"], ob["seeds"], batch, wires=None)
     assert P == ob["proofs"]
-    per_proof_public = name.startswith("poseidon") or name == "mimc"   # the hash output (a public constant of the circuit) differs per proof
+    per_proof_public = name.startswith("poseidon") or name.startswith("mimc")   # the hash output (a public constant of the circuit) differs per proof
     nv = 1 if per_proof_public else batch
     assert bp.verify_batch(gens, circ, ob["label"], P[:nv], C[:nv], nv) == [True] * nv
     assert bp.verify_single(gname, ip, sp, cap, ob["label"], P[0], C[0], glib=glib)

@@ -52,3 +52,8 @@ def test_compiled_poseidon_inverse_zero_sbox_input(sim_lib, sim_glib):
 
 def test_bulk_poseidon_and_tree_construction(sim_lib, sim_glib):
     fc.check_bulk_tree(sim_lib, sim_glib)
+
+
+def test_compiled_mimc_plus_set_membership_small(sim_lib, sim_glib):
+    """SURVEY §8d config C5 at 8 MiMC rounds (the 322-round circuit runs in the GPU suite)"""
+    fc.check_compiled(sim_lib, sim_glib, "mimc_set_membership_r8", batch=2)

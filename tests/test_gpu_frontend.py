@@ -59,3 +59,10 @@ def test_poseidon_joint_evaluation_equals_plain_program(hip_lib, hip_glib, case)
 def test_bulk_poseidon_and_tree_construction_on_device(hip_lib, hip_glib):
     """N2: k_poseidon_team (8 lanes per permutation, one inversion each) and the level-by-level tree builder"""
     fc.check_bulk_tree(hip_lib, hip_glib, levels=8, partial_rounds=140, count=40)
+
+
+def test_config_c5_mimc_plus_set_membership(hip_lib, hip_glib):
+    """MiMC-322 preimage + set membership (k = 7) on one prover: n = 665, N = 1024, m = 10"""
+    ob, P, C = fc.check_compiled(hip_lib, hip_glib, "mimc_set_membership", batch=2, unfold=4)
+    assert (ob["n"], ob["m"]) == (665, 10)
+    fc.check_prove_verify_roundtrip(hip_lib, hip_glib, "mimc_set_membership", batch=1)
