@@ -52,3 +52,51 @@ def test_vsmt4_depth32_ragged_batch(hip_lib, hip_glib):
     P2, _ = bp.prove_batch(gens, circ, b"VSMT", values[:3 * m * 32], blindings[:3 * m * 32], seeds[:96], 3)
     hip_lib.bpr1cs_set_unfold_rounds(5)
     assert P2 == P[:3]
+
+
+def test_vsmt2_depth32_config_c3(hip_lib, hip_glib):
+    """binary sparse Merkle tree, depth 32 (n = 18 176, N = 32 768, m = 69).  No oracle runs at
+    this size in the test budget, so size-independent properties: every proof verifies (per proof and batched), tampering
+    is rejected, and the bytes do not depend on HOW they were computed (annotated vs plain witness program, IPA switch
+    round) - the small-depth twin of this circuit is compared with the oracle in test_gpu_frontend.py."""
+    bp = importlib.import_module("bulletproofs-r1cs-gadgets_amd")
+    sys.path.insert(0, ROOT)
+    import bench
+    depth, B = 32, 6
+    tree = bp.SparseMerkleTree(2, depth, 140, glib=hip_glib)
+    leaves = [(i, i) for i in range(1, 11)] + [(bench.synth_scalar(b"l2-idx", k) & 0xffffffff, bench.synth_scalar(b"l2-val", k)) for k in range(B)]
+    tree.update_many(leaves)
+    sel = leaves[10:10 + B]
+    lv, paths = tree.get_many([i for i, _ in sel])
+    sc = bench.sc
+    values, bl = b"", b""
+    m = 2 * depth + 5
+    for k, (idx, val) in enumerate(sel):
+        assert lv[32 * k:32 * k + 32] == sc(val)
+        nodes = [paths[32 * (depth * k + t):32 * (depth * k + t) + 32] for t in range(depth)]   # root level first
+        values += sc(val) + b"".join(sc((idx >> t) & 1) for t in range(depth)) + b"".join(reversed(nodes)) + sc(0) + sc(101) + sc(0) + sc(0)
+        bl += b"".join(sc(bench.synth_scalar(b"bl2", k * 1024 + t)) for t in range(m - 4)) + bytes(128)  # statics: blinding 0
+    seeds = b"".join(bytes([k + 1]) * 32 for k in range(B))
+    root = tree.root()
+    hip_lib.bpr1cs_set_window_bits(8)
+    gens = bp.Gens(32768, lib=hip_lib)
+    out = {}
+    try:
+        for macro, unfold in ((1, 4), (0, 2)):
+            hip_lib.bpr1cs_set_witness_macro(macro)
+            hip_lib.bpr1cs_set_unfold_rounds(unfold)
+            circ = bp.CompiledGadget("vsmt_2", [depth, 140], [root], lib=hip_lib, glib=hip_glib)
+            assert (circ.n, circ.q, circ.m) == (18176, 42369, 69)
+            assert (hip_lib.bpr1cs_circuit_macro_perms(circ.h) > 0) == bool(macro)
+            out[macro] = bp.prove_batch(gens, circ, b"VSMT", values, bl, seeds, B)
+    finally:
+        hip_lib.bpr1cs_set_witness_macro(1)
+        hip_lib.bpr1cs_set_unfold_rounds(4)
+    P, C = out[1]
+    assert out[0][0] == P and out[0][1] == C
+    assert bp.verify_batch(gens, circ, b"VSMT", P, C, B) == [True] * B
+    pt, wf = bp.verify_batch_combined(gens, circ, b"VSMT", P, C, B, bytes(range(32)))
+    assert wf and pt == bytes(32)
+    bad = bytearray(P[2]); bad[1 + 32 * 9 + 1] ^= 2
+    res = bp.verify_batch(gens, circ, b"VSMT", P[:2] + [bytes(bad)] + P[3:], C, B)
+    assert res[2] is False and sum(res) == B - 1
