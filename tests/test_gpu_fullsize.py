@@ -100,3 +100,35 @@ def test_vsmt2_depth32_config_c3(hip_lib, hip_glib):
     bad = bytearray(P[2]); bad[1 + 32 * 9 + 1] ^= 2
     res = bp.verify_batch(gens, circ, b"VSMT", P[:2] + [bytes(bad)] + P[3:], C, B)
     assert res[2] is False and sum(res) == B - 1
+
+
+def test_poseidon_2to1_cube_batch_4096_config_c2(hip_lib, hip_glib):
+    """Poseidon 2:1 Cube preimage (n = 376, N = 512, m = 6), 4096 proofs in one batch: sampled
+    proofs equal the C oracle's byte for byte, all of them pass the per-proof and the batched device verifier."""
+    import json
+    bp = importlib.import_module("bulletproofs-r1cs-gadgets_amd")
+    sys.path.insert(0, ROOT)
+    import bench
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle", "c")])
+    from cref import COracle
+    gd = json.load(open(os.path.join(ROOT, "tests", "golden", "proofs.json")))["poseidon_hash_2_cube"]
+    B, m = 4096, gd["m"]
+    vals1 = bytes.fromhex(gd["values"])[:m * 32]
+    image = bytes.fromhex(gd["sparams"][0])
+    label = gd["label"].encode()
+    values = vals1 * B
+    bl = b"".join(b"".join(bench.sc(bench.synth_scalar(b"c2bl", j * 8 + t)) for t in range(2)) + bytes(128) for j in range(B))
+    seeds = b"".join(bench.synth_scalar(b"c2seed", j).to_bytes(32, "little") for j in range(B))
+    circ = bp.CompiledGadget("poseidon_hash_2", gd["iparams"], [image], lib=hip_lib, glib=hip_glib)
+    assert (circ.n, circ.m) == (376, 6)
+    hip_lib.bpr1cs_set_window_bits(8)
+    hip_lib.bpr1cs_set_unfold_rounds(4)
+    gens = bp.Gens(512, lib=hip_lib)
+    P, C = bp.prove_batch(gens, circ, label, values, bl, seeds, B)
+    o = COracle()
+    for j in (0, 1777, B - 1):
+        r = o.prove(1, gd["iparams"], image, label, vals1, bl[j * m * 32:(j + 1) * m * 32], seeds[32 * j:32 * j + 32])
+        assert P[j] == r["proof"], "proof %d differs from the C oracle" % j
+    assert bp.verify_batch(gens, circ, label, P, C, B) == [True] * B
+    pt, wf = bp.verify_batch_combined(gens, circ, label, P, C, B, bytes(range(32)))
+    assert wf and pt == bytes(32)
