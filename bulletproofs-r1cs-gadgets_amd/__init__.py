@@ -77,6 +77,12 @@ def load_library(path=None):
     lib.bpr1cs_msm_fixed.argtypes = [vp, ctypes.POINTER(u32), sz, cp, sz, cp]
     lib.bpr1cs_verify_batch_combined.argtypes = [vp, vp, cp, sz, cp, cp, cp, cp, ctypes.c_uint64, sz, cp, ctypes.POINTER(ctypes.c_int)]
     lib.bpr1cs_points_sum.argtypes = [cp, sz, cp]
+    lib.bpr1cs_msm.argtypes = [cp, cp, sz, cp]
+    lib.bpr1cs_transcript_new.argtypes = [cp, sz]
+    lib.bpr1cs_transcript_new.restype = vp
+    lib.bpr1cs_transcript_free.argtypes = [vp]
+    lib.bpr1cs_transcript_append_message.argtypes = [vp, cp, sz, cp, sz]
+    lib.bpr1cs_transcript_challenge_bytes.argtypes = [vp, cp, sz, cp, sz]
     lib.bpr1cs_poseidon_permutation_batch.argtypes = [vp, ctypes.c_int, cp, sz, cp]
     lib.bpr1cs_set_unfold_rounds.argtypes = [ctypes.c_int]
     lib.bpr1cs_set_window_bits.argtypes = [ctypes.c_int]
@@ -250,6 +256,36 @@ def poseidon_permutation_batch(states, inverse=True, partial_rounds=140, lib=Non
     out = ctypes.create_string_buffer(n * 6 * 32)
     _chk(lib.bpr1cs_poseidon_permutation_batch(ctypes.byref(pp), 1 if inverse else 0, inp, n, out))
     return [[int.from_bytes(out.raw[32 * (6 * h + i):32 * (6 * h + i) + 32], "little") for i in range(6)] for h in range(n)]
+
+
+def msm(scalars, points, lib=None):
+    """sum_i scalars[i] * points[i] over arbitrary compressed ristretto points (ints / 32-byte strings) -> 32 bytes"""
+    lib = lib or load_library()
+    out = ctypes.create_string_buffer(32)
+    _chk(lib.bpr1cs_msm(b"".join(_sc(x) for x in scalars), b"".join(points), len(points), out))
+    return out.raw
+
+
+class Transcript:
+    """merlin::Transcript through the C ABI (host side)."""
+
+    def __init__(self, label, lib=None):
+        self.lib = lib or load_library()
+        self.h = self.lib.bpr1cs_transcript_new(label, len(label))
+
+    def append_message(self, label, msg):
+        self.lib.bpr1cs_transcript_append_message(self.h, label, len(label), msg, len(msg))
+
+    def challenge_bytes(self, label, n):
+        out = ctypes.create_string_buffer(n)
+        self.lib.bpr1cs_transcript_challenge_bytes(self.h, label, len(label), out, n)
+        return out.raw
+
+    def __del__(self):
+        try:
+            self.lib.bpr1cs_transcript_free(self.h)
+        except Exception:
+            pass
 
 
 def points_sum(points, lib=None):

@@ -1066,6 +1066,46 @@ extern "C" int bpr1cs_poseidon_permutation_batch(const bpr1cs_poseidon_params* p
     return BPR1CS_OK;
 }
 
+// ---- low-level entry points: Merlin transcript on the host, general variable-base MSM on the device
+struct bpr1cs_transcript {
+    strobe s;
+};
+extern "C" bpr1cs_transcript* bpr1cs_transcript_new(const uint8_t* label, size_t label_len) {
+    bpr1cs_transcript* t = new bpr1cs_transcript();
+    merlin_new(t->s, label, (uint32_t)label_len);
+    return t;
+}
+extern "C" void bpr1cs_transcript_free(bpr1cs_transcript* t) { delete t; }
+extern "C" void bpr1cs_transcript_append_message(bpr1cs_transcript* t, const uint8_t* label, size_t label_len, const uint8_t* msg, size_t msg_len) {
+    if (t) merlin_append(t->s, (const char*)label, (uint32_t)label_len, msg, (uint32_t)msg_len);
+}
+extern "C" void bpr1cs_transcript_challenge_bytes(bpr1cs_transcript* t, const uint8_t* label, size_t label_len, uint8_t* out, size_t out_len) {
+    if (t) merlin_challenge_bytes(t->s, (const char*)label, (uint32_t)label_len, out, (uint32_t)out_len);
+}
+extern "C" int bpr1cs_msm(const uint8_t* scalars, const uint8_t* points, size_t n, uint8_t* out) {
+    if (!scalars || !points || !out || n == 0 || n > (1u << 24)) return BPR1CS_ERR_INVALID_ARGUMENT;
+    if (!have_device()) return BPR1CS_ERR_NO_DEVICE;
+    dev_stream_t st{};
+    const uint32_t N = (uint32_t)n, VC = N < 4096 ? (N + 63) / 64 : 64;
+    DevBuf<uint8_t> d_s(32 * n), d_p(32 * n), d_out(32);
+    DevBuf<ge_cached> vtab((size_t)8 * n);
+    DevBuf<uint32_t> vdig((size_t)8 * n);
+    DevBuf<ge> part((size_t)64 * VC), sum(64), res(1);
+    DevBuf<int> fail(1);
+    dev_h2d(d_s.p, scalars, 32 * n, st);
+    dev_h2d(d_p.p, points, 32 * n, st);
+    dev_zero(fail.p, sizeof(int), st);
+    launch(N, K_msm_var_tab{d_s.p, d_p.p, vtab.p, vdig.p, fail.p, N}, st);
+    launch((uint64_t)64 * VC, K_msm_var_win{vtab.p, vdig.p, part.p, N, VC}, st);
+    launch(64, K_ge_reduce{part.p, sum.p, 1, 64 * VC, VC}, st);
+    launch(1, K_ipa_vb_horner{sum.p, res.p, 1, 1}, st);
+    launch(1, K_compress_one{res.p, d_out.p}, st);
+    int f = 0;
+    dev_d2h(out, d_out.p, 32, st);
+    dev_d2h(&f, fail.p, sizeof(int), st);
+    return f ? BPR1CS_ERR_FORMAT : BPR1CS_OK;
+}
+
 // out = compress(sum of `count` compressed points); returns FormatError if one does not decode
 extern "C" int bpr1cs_points_sum(const uint8_t* points, size_t count, uint8_t* out) {
     if (!points || !out || count == 0 || count > (1u << 20)) return BPR1CS_ERR_INVALID_ARGUMENT;

@@ -1349,6 +1349,64 @@ struct K_batch_finish {  // single thread: sum of the partial sums -> compressed
         *wellformed = ok;
     }
 };
+// general variable-base MSM (bpr1cs_msm): per term the multiples 1P..8P and the signed radix-16 digits ...
+struct K_msm_var_tab {  // gid = i < n
+    const uint8_t* scalars;  // [n][32] canonical
+    const uint8_t* points;   // [n][32] compressed
+    ge_cached* vtab;         // [8][n]
+    uint32_t* vdig;          // [8][n]
+    int* fail;
+    uint32_t n;
+    HD void operator()(uint32_t g) const {
+        ge P;
+        if (!ge_decompress(points + 32 * (size_t)g, P)) { *fail = 1; P = ge_identity(); }
+        sc s = sc_load_raw(scalars + 32 * (size_t)g);
+        ge_cached c1 = ge_to_cached(P);
+        vtab[g] = c1;
+        ge q = P;
+        for (int e = 1; e < 8; e++) {
+            q = ge_add(q, c1);
+            vtab[(size_t)e * n + g] = ge_to_cached(q);
+        }
+        uint32_t dig[8];
+        for (int i = 0; i < 8; i++) dig[i] = 0;
+        int carry = 0;
+        for (int i = 0; i < 64; i++) {
+            int d = (int)((s.v[i >> 3] >> (4 * (i & 7))) & 15u) + carry;
+            carry = d >= 8;
+            d -= carry << 4;
+            dig[i >> 3] |= ((uint32_t)d & 15u) << (4 * (i & 7));
+        }
+        for (int i = 0; i < 8; i++) vdig[(size_t)i * n + g] = dig[i];
+    }
+};
+// ... per (window, chunk) the sum of the selected multiples, then K_ge_reduce over the chunks and K_ipa_vb_horner
+struct K_msm_var_win {  // gid = win*VC + c
+    const ge_cached* vtab;
+    const uint32_t* vdig;
+    ge* part;  // [64][VC]
+    uint32_t n, VC;
+    HD void operator()(uint32_t g) const {
+        uint32_t c = g % VC, win = g / VC;
+        uint32_t per = (n + VC - 1) / VC, lo = c * per, hi = lo + per < n ? lo + per : n;
+        ge acc = ge_identity();
+        for (uint32_t o = lo; o < hi; o++) {
+            int d = (int)((vdig[(size_t)(win >> 3) * n + o] >> (4 * (win & 7u))) & 15u);
+            if (d & 8) d -= 16;
+            if (d != 0) {
+                int mag = d < 0 ? -d : d;
+                ge_cached e = vtab[(size_t)(mag - 1) * n + o];
+                acc = d < 0 ? ge_sub(acc, e) : ge_add(acc, e);
+            }
+        }
+        part[g] = acc;
+    }
+};
+struct K_compress_one {  // single thread
+    const ge* in;
+    uint8_t* out;
+    HD void operator()(uint32_t) const { ge_compress(in[0], out); }
+};
 struct K_points_sum {  // single thread: out = compress(sum decompress(in[i])); *ok = all decoded
     const uint8_t* in;
     uint8_t* out;

@@ -167,6 +167,17 @@ int bpr1cs_verify_batch_combined(const bpr1cs_gens* gens, const bpr1cs_circuit* 
  * Merkle tree builders of bpr1cs_gadgets.h to hash a whole tree level per call. */
 int bpr1cs_poseidon_permutation_batch(const bpr1cs_poseidon_params* params, int sbox_inverse, const uint8_t* inputs, size_t count,
                                       uint8_t* outputs);
+/* ---- low-level entry points for parity tests and for a Rust shim -------------------------------------------
+ * merlin::Transcript (merlin 2.0: STROBE-128 over Keccak-f[1600]) exactly as the prover kernels run it; host-side. */
+typedef struct bpr1cs_transcript bpr1cs_transcript;
+bpr1cs_transcript* bpr1cs_transcript_new(const uint8_t* label, size_t label_len);                 /* Transcript::new(label)      */
+void bpr1cs_transcript_free(bpr1cs_transcript* t);
+void bpr1cs_transcript_append_message(bpr1cs_transcript* t, const uint8_t* label, size_t label_len, const uint8_t* msg, size_t msg_len);
+void bpr1cs_transcript_challenge_bytes(bpr1cs_transcript* t, const uint8_t* label, size_t label_len, uint8_t* out, size_t out_len);
+/* RistrettoPoint::vartime_multiscalar_mul over arbitrary (compressed) points: out = sum_i scalars[i] * points[i], on the
+ * device (Straus with shared doublings, as the variable-base IPA rounds).  BPR1CS_ERR_FORMAT if a point does not decode. */
+int bpr1cs_msm(const uint8_t* scalars /* n*32 canonical */, const uint8_t* points /* n*32 compressed */, size_t n, uint8_t* out /* 32 */);
+
 /* out = compress(sum of `count` compressed ristretto points); BPR1CS_ERR_FORMAT if one of them does not decode */
 int bpr1cs_points_sum(const uint8_t* points, size_t count, uint8_t* out);
 

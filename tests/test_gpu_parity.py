@@ -87,3 +87,14 @@ def test_two_batches_in_flight_on_device(hip_lib):
     P2, _ = j2.finish()
     P3, _ = j3.finish()
     assert P1 == ob["proofs"] and P2 == ob["proofs"][:2] and P3 == ob["proofs"]
+
+
+def test_low_level_abi_on_device(hip_lib):
+    """bpr1cs_msm (general variable-base MSM, Straus on the device) and the host-side Merlin transcript of the C ABI"""
+    import test_hostsim as th
+    th.test_low_level_abi_transcript_and_msm(hip_lib)
+    from pyref.ed import msm
+    o = common.oracle_gens(64)
+    pts = o.G[:64] + o.H[:37]                      # more terms than one chunk
+    sc = [S.synth_scalar(b"lowmsm2", i) for i in range(len(pts))]
+    assert common.bp.msm(sc, [p.compress() for p in pts], lib=hip_lib) == msm(sc, pts).compress()

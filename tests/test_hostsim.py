@@ -80,3 +80,20 @@ def test_verifier_accepts_and_rejects(sim_lib):
         wrong[0][0] = common.PC.commit(12345, 678).compress()
         assert common.bp.verify_batch(gens, circ, ob["label"], ob["proofs"], wrong, 2) == [False, True]
         assert common.bp.verify_batch(gens, circ, b"other label", ob["proofs"], full_comms, 2) == [False, False]
+
+
+def test_low_level_abi_transcript_and_msm(sim_lib):
+    """bpr1cs_transcript_* reproduces Merlin's published equivalence vector; bpr1cs_msm equals the oracle's msm on
+    arbitrary points (incl. scalars 0, 1, l-1) and rejects a non-canonical encoding"""
+    import pytest
+    from pyref.ed import msm, sc_to_bytes, L
+    t = common.bp.Transcript(b"test protocol", lib=sim_lib)
+    t.append_message(b"some label", b"some data")
+    assert t.challenge_bytes(b"challenge", 32).hex() == "d5a21972d0d5fe320c0d263fac7fffb8145aa640af6e9bca177c03c7efcf0615"
+    o = common.oracle_gens(16)
+    pts = [common.PC.B, common.PC.B_blinding] + o.G[:9] + o.H[:6]
+    sc = [S.synth_scalar(b"lowmsm", i) for i in range(len(pts))]
+    sc[0], sc[1], sc[2] = 0, 1, L - 1
+    assert common.bp.msm(sc, [p.compress() for p in pts], lib=sim_lib) == msm(sc, pts).compress()
+    with pytest.raises(Exception):
+        common.bp.msm([1], [b"\xff" * 32], lib=sim_lib)
