@@ -711,13 +711,9 @@ extern "C" int bpr1cs_prove_batch_begin(const bpr1cs_gens* g, const bpr1cs_circu
         HIPCHK(hipStreamWaitEvent(st, job->ev_wit, 0));
 #endif
     }
-#if !defined(BPR1CS_HOSTSIM)
-    HIPCHK(hipStreamWaitEvent(st, ev_rng, 0));  // (in the wires path everything on `sl` was synchronised above)
-#endif
-    pt.mark(st);
-
-    // ---- P2: A_I1, A_O1, S1
-    DevBuf<ge> partial;
+    // ---- P2: A_I1, A_O1, S1.  The sums of A_I1 and A_O1 need the wires only, so they are enqueued BEFORE the heavy stream
+    // waits for the TranscriptRng chain (the longer of the two front kernels); their blinding terms and all of S1 follow it.
+    DevBuf<ge> partial, partialO;
     DevBuf<uint8_t> AOS((size_t)3 * B * 32);
     MsmPlan plan;
     {
@@ -725,6 +721,8 @@ extern "C" int bpr1cs_prove_batch_begin(const bpr1cs_gens* g, const bpr1cs_circu
         MsmSeg none{nullptr, 0, 1, 1, 0, 0, 0};
         auto seg = [&](const sc* p, uint32_t base0) { return MsmSeg{p, n, n ? n : 1, n ? n : 1, 0, base0, 1}; };
         const uint32_t T3 = (uint32_t)c->h_trip.size();
+        DevBuf<ge> partial2;
+        K_msm_finish finI{g->tab.p, g->tc, nullptr, blind.p + 0 * (size_t)B, nullptr, AOS.p + 0 * (size_t)B * 32, B, 0, 1};
         if (!wires && T3 && g_merge_triples) {
             // A_I1 with the repeated S-box wires merged: 2 terms per S-box instead of 5 (see K_merge_points)
             bpr1cs_circuit* cm = const_cast<bpr1cs_circuit*>(c);
@@ -740,20 +738,26 @@ extern "C" int bpr1cs_prove_batch_begin(const bpr1cs_gens* g, const bpr1cs_circu
             const uint32_t nr = (uint32_t)c->h_rest.size();
             MsmSeg rG{aL, nr, 1, 1, 0, baseG, 1, c->rest.p, 0}, rH{aR, nr, 1, 1, 0, baseH, 1, c->rest.p, 0};
             MsmSeg mG{aL, T3, 1, 1, 0, 0, 1, c->trip.p, 1}, mH{aR, T3, 1, 1, 0, T3, 1, c->trip.p, 1};
-            DevBuf<ge> partial2;
             MsmPlan plan2;
             run_msm(g, rG, rH, B, partial, plan, st);
             run_msm(g, mG, mH, B, partial2, plan2, st, c->mtab.p);
-            K_msm_finish fin{g->tab.p, g->tc, partial.p, blind.p + 0 * (size_t)B, nullptr, AOS.p + 0 * (size_t)B * 32, B, plan.nchunks, 1};
-            fin.partial_b = partial2.p;
-            fin.nchunks_b = plan2.nchunks;
-            launch(B, fin, st);
+            finI.partial = partial.p;
+            finI.nchunks = plan.nchunks;
+            finI.partial_b = partial2.p;
+            finI.nchunks_b = plan2.nchunks;
         } else {
             run_msm(g, seg(aL, baseG), seg(aR, baseH), B, partial, plan, st);
-            launch(B, K_msm_finish{g->tab.p, g->tc, partial.p, blind.p + 0 * (size_t)B, nullptr, AOS.p + 0 * (size_t)B * 32, B, plan.nchunks, 1}, st);
+            finI.partial = partial.p;
+            finI.nchunks = plan.nchunks;
         }
-        run_msm(g, seg(aO, baseG), none, B, partial, plan, st);
-        launch(B, K_msm_finish{g->tab.p, g->tc, partial.p, blind.p + 1 * (size_t)B, nullptr, AOS.p + 1 * (size_t)B * 32, B, plan.nchunks, 1}, st);
+        MsmPlan planO;
+        run_msm(g, seg(aO, baseG), none, B, partialO, planO, st);
+#if !defined(BPR1CS_HOSTSIM)
+        HIPCHK(hipStreamWaitEvent(st, ev_rng, 0));  // (in the wires path everything on `sl` was synchronised above)
+#endif
+        pt.mark(st);
+        launch(B, finI, st);
+        launch(B, K_msm_finish{g->tab.p, g->tc, partialO.p, blind.p + 1 * (size_t)B, nullptr, AOS.p + 1 * (size_t)B * 32, B, planO.nchunks, 1}, st);
         run_msm(g, seg(sL, baseG), seg(sR, baseH), B, partial, plan, st);
         launch(B, K_msm_finish{g->tab.p, g->tc, partial.p, blind.p + 2 * (size_t)B, nullptr, AOS.p + 2 * (size_t)B * 32, B, plan.nchunks, 1}, st);
     }
