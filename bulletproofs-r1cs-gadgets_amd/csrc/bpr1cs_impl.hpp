@@ -37,7 +37,7 @@ static void host_sponge(uint32_t rate, uint8_t suffix, const uint8_t* in, size_t
 static int g_unfold_rounds = 4;
 static int g_window_bits = 8;
 static int g_latency_cus = 0;   // >0: CUs reserved for the latency-bound kernels (see bpr1cs_gens_create)
-static int g_rng_mode = 0;       // 0 auto, 1 lane-parallel chain (k_rng_stream), 2 state per thread (k_rng_thread), 3 scalar unit (k_rng_scalar)
+static int g_rng_mode = 0;       // 0 auto, 1 lane-parallel via LDS (k_rng_stream), 2 state per thread, 3 scalar unit, 4 lane-parallel via DPP (k_rng_dpp)
 static int g_merge_triples = 1;  // A_I1: one merged table per Inverse-S-box triple (needs the annotated witness program)
 static int g_witness_macro = 1;  // use the Poseidon annotations of a circuit description (poseidon_team)
 static int g_witness_team = 8;   // lanes cooperating on one proof in k_witness_team (4, 8 or 16)
@@ -146,7 +146,7 @@ void bpr1cs_set_unfold_rounds(int r) { g_unfold_rounds = r < 0 ? 0 : r; }
 void bpr1cs_set_latency_cus(int n) { g_latency_cus = n < 0 ? 0 : n; }
 void bpr1cs_set_witness_team(int t) { g_witness_team = (t == 4 || t == 8) ? t : 16; }
 void bpr1cs_set_witness_macro(int enable) { g_witness_macro = enable ? 1 : 0; }
-void bpr1cs_set_rng_mode(int mode) { g_rng_mode = (mode >= 1 && mode <= 3) ? mode : 0; }
+void bpr1cs_set_rng_mode(int mode) { g_rng_mode = (mode >= 1 && mode <= 4) ? mode : 0; }
 int bpr1cs_circuit_macro_perms(const bpr1cs_circuit* c) { return c ? (int)c->n_perms : 0; }
 void bpr1cs_set_window_bits(int w) { g_window_bits = w < 4 ? 4 : (w > 12 ? 12 : w); }
 int bpr1cs_last_timings(float* out, int cap) {
@@ -657,7 +657,9 @@ extern "C" int bpr1cs_prove_batch_begin(const bpr1cs_gens* g, const bpr1cs_circu
     // issues one scalar instruction per ~9 cycles, so the chain is 3.7x slower (717 ms per batch) and its 1024 resident
     // wavefronts still slow the co-running MSM launches by 40 % - measured 1000 proofs/s against 1590
     const bool rng_scalar = g_rng_mode == 3;
-    if (rng_scalar) {
+    if (g_rng_mode == 4) {
+        hipLaunchKernelGGL(k_rng_dpp, dim3(B), dim3(64), 0, sl, rng.p, rng_raw.p, rng_err.p, B, draws);
+    } else if (rng_scalar) {
         hipLaunchKernelGGL(k_rng_scalar, dim3(B), dim3(64), 0, sl, rng.p, rng_raw.p, rng_err.p, B, draws);
     } else if (rng_per_thread && !g->rng_isolated) {
         hipLaunchKernelGGL(k_rng_thread, dim3((B + 63) / 64), dim3(64), 0, sl, rng.p, rng_raw.p, rng_err.p, B, draws);

@@ -332,3 +332,83 @@ __global__ void __launch_bounds__(64) k_rng_scalar(const strobe* rng_in, uint64_
         for (int i = 0; i < 8; i++) a[i] = 0;  // prf squeeze zeroes the bytes it returns
     }
 }
+
+// The chain with NO LDS traffic except the pi permutation: one state per wavefront, lane = 8 y + x holds A[x][y]
+// (rows of 16 lanes = two y values; lanes with x > 4 or y > 4 are zero padding).  theta's column parity is one DPP
+// row rotation plus the gfx950 row/half swaps (v_permlane16_swap / v_permlane32_swap: an all-reduce over the four rows
+// in four VALU instructions); the cyclic x +- 1 neighbours are DPP row shifts; only pi/chi gather through the LDS
+// crossbar (ds_bpermute).  Fewer dependent memory round trips per round than k_rng_stream (one instead of two plus
+// barriers), more VALU instructions per proof - used when nothing else runs on the chip (no batch in flight).
+#define DPP_ROW_SHL(n) (0x100 + (n))
+#define DPP_ROW_SHR(n) (0x110 + (n))
+#define DPP_ROW_ROR(n) (0x120 + (n))
+__device__ inline uint32_t rows_allreduce_xor(uint32_t s) {
+    auto p = __builtin_amdgcn_permlane32_swap(s, s, false, false);   // [lo, lo] , [hi, hi]
+    uint32_t u = p[0] ^ p[1];
+    auto q = __builtin_amdgcn_permlane16_swap(u, u, false, false);   // [r0, r0, r2, r2] , [r1, r1, r3, r3]
+    return q[0] ^ q[1];
+}
+__global__ void __launch_bounds__(64) k_rng_dpp(const strobe* rng_in, uint64_t* raw_out, int* err, uint32_t B, uint32_t draws) {
+    __builtin_amdgcn_s_setprio(3);
+    const uint32_t b = blockIdx.x, lane = threadIdx.x, x = lane & 7u, y = lane >> 3;
+    const bool active = x < 5u && y < 5u;
+    const uint32_t j = active ? x + 5u * y : 0u;
+    if (rng_in[b].pos != 64 || rng_in[b].pos_begin != 0) {
+        if (lane == 0) atomicExch(err, 1);
+        return;
+    }
+    uint64_t a0 = active ? rng_in[b].st[j] : 0ull;
+    uint32_t al = (uint32_t)a0, ah = (uint32_t)(a0 >> 32);
+    const int ROT[25] = {0, 1, 62, 28, 27, 36, 44, 6, 55, 20, 3, 10, 43, 25, 39, 41, 45, 15, 21, 8, 18, 2, 61, 56, 14};  // [x + 5y]
+    const int rot = ROT[j];
+    const bool rot_swap = rot >= 32 || rot == 0;  // see k_rng_stream
+    const uint32_t rot_k = (32u - ((uint32_t)rot & 31u)) & 31u;
+    const uint32_t amask = active ? 0xffffffffu : 0u, iota_mask = lane == 0 ? 0xffffffffu : 0u;
+    const bool x_first = x == 0u, x_last = x == 4u;
+    // pi + chi operands: B[X][Y] = rot(A)[(X + 3Y) % 5][X]  ->  source lane 8 X + (X + 3Y) % 5
+    auto src = [&](uint32_t X) { X %= 5u; return active ? (int)(4u * (8u * X + (X + 3u * y) % 5u)) : (int)(4u * lane); };
+    const int s0 = src(x), s1 = src(x + 1u), s2 = src(x + 2u);
+    const uint32_t f8l = lane == 11u ? 0x00401200u : (lane == 12u ? 0x00000447u : 0u);   // STROBE framing (words 8, 9, 20)
+    const uint32_t f8h = lane == 11u ? 0x07410000u : (lane == 32u ? 0x80000000u : 0u);
+    for (uint32_t d = 0; d < draws; d++) {
+        al ^= f8l;
+        ah ^= f8h;
+#pragma unroll
+        for (int r = 0; r < 24; r++) {
+            // theta: column parity in every lane of the column
+            uint32_t sl = al ^ (uint32_t)__builtin_amdgcn_update_dpp(0, (int)al, DPP_ROW_ROR(8), 0xf, 0xf, false);
+            uint32_t sh = ah ^ (uint32_t)__builtin_amdgcn_update_dpp(0, (int)ah, DPP_ROW_ROR(8), 0xf, 0xf, false);
+            uint32_t cl = rows_allreduce_xor(sl), ch = rows_allreduce_xor(sh);
+            // C[x-1], C[x+1] cyclically within the five lanes of a group
+            uint32_t m1l = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cl, DPP_ROW_SHR(1), 0xf, 0xf, false);
+            uint32_t m4l = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cl, DPP_ROW_SHL(4), 0xf, 0xf, false);
+            uint32_t m1h = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)ch, DPP_ROW_SHR(1), 0xf, 0xf, false);
+            uint32_t m4h = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)ch, DPP_ROW_SHL(4), 0xf, 0xf, false);
+            uint32_t p1l = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cl, DPP_ROW_SHL(1), 0xf, 0xf, false);
+            uint32_t p4l = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cl, DPP_ROW_SHR(4), 0xf, 0xf, false);
+            uint32_t p1h = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)ch, DPP_ROW_SHL(1), 0xf, 0xf, false);
+            uint32_t p4h = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)ch, DPP_ROW_SHR(4), 0xf, 0xf, false);
+            uint32_t cml = x_first ? m4l : m1l, cmh = x_first ? m4h : m1h;
+            uint32_t cpl = x_last ? p4l : p1l, cph = x_last ? p4h : p1h;
+            uint32_t tl = K_XOR3(al, cml, __builtin_amdgcn_alignbit(cpl, cph, 31));
+            uint32_t th = K_XOR3(ah, cmh, __builtin_amdgcn_alignbit(cph, cpl, 31));
+            // rho
+            uint32_t ul = rot_swap ? th : tl, uh = rot_swap ? tl : th;
+            uint32_t nl = __builtin_amdgcn_alignbit(ul, uh, rot_k), nh = __builtin_amdgcn_alignbit(uh, ul, rot_k);
+            // pi + chi through the LDS crossbar
+            uint32_t b0l = (uint32_t)__builtin_amdgcn_ds_bpermute(s0, (int)nl), b0h = (uint32_t)__builtin_amdgcn_ds_bpermute(s0, (int)nh);
+            uint32_t b1l = (uint32_t)__builtin_amdgcn_ds_bpermute(s1, (int)nl), b1h = (uint32_t)__builtin_amdgcn_ds_bpermute(s1, (int)nh);
+            uint32_t b2l = (uint32_t)__builtin_amdgcn_ds_bpermute(s2, (int)nl), b2h = (uint32_t)__builtin_amdgcn_ds_bpermute(s2, (int)nh);
+            uint32_t xl = K_CHI(b0l, b1l, b2l), xh = K_CHI(b0h, b1h, b2h);
+            xl = __builtin_amdgcn_bitop3_b32(xl, (uint32_t)KECCAK_RC[r], iota_mask, 0x78);
+            xh = __builtin_amdgcn_bitop3_b32(xh, (uint32_t)(KECCAK_RC[r] >> 32), iota_mask, 0x78);
+            al = xl & amask;   // the padding lanes must stay zero: they take part in the column parity
+            ah = xh & amask;
+        }
+        if (active && j < 8u) {
+            raw_out[((size_t)d * B + b) * 8 + j] = ((uint64_t)ah << 32) | al;
+            al = 0;  // prf squeeze zeroes the bytes it returns
+            ah = 0;
+        }
+    }
+}

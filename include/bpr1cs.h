@@ -208,6 +208,8 @@ void bpr1cs_set_witness_team(int t);
  * 3 = one state per wavefront on the SCALAR unit (all lanes in SGPRs, s_xor_b64 / s_andn2_b64 ...): no VALU issue
  *     slots, but 3.7x the latency of 1 (a wavefront issues one scalar instruction per ~9 cycles) - kept as a
  *     measured alternative, never chosen automatically;
+ * 4 = one state per wavefront, lane = 8y + x, theta by DPP row shifts and the gfx950 v_permlane16/32_swap row
+ *     all-reduce, pi/chi by ds_bpermute: no LDS memory or barriers, but more VALU instructions - 8 % slower than 1;
  * 0 = automatic: 1 (2 if CUs are reserved for it and another batch is in flight). */
 void bpr1cs_set_rng_mode(int mode);
 
