@@ -213,6 +213,17 @@ static size_t run_gadget(const GadgetSpec& g, Harness& h) {
         vector_product_gadget(h.cs, items, bit_vars, val);
         return k + 1;
     }
+    if (g.name == "range_proof") {  // src/gadget_range_proof.rs:123-200 ; ip = [min(lo,hi), max(lo,hi)]
+        uint64_t mn = u64_of(g.ip, 0), mx = u64_of(g.ip, 2);
+        size_t nbits = 0;
+        for (uint64_t t = mx; t; t >>= 1) nbits++;  // count_bits(max), :102-105
+        auto a = AQ(0);
+        positive_no_gadget(h.cs, a, nbits);
+        auto b = AQ(1);
+        positive_no_gadget(h.cs, b, nbits);
+        constrain_lc_with_scalar(h.cs, LinearCombination(a.variable) + LinearCombination(b.variable), Scalar(mx - mn));
+        return 2;
+    }
     if (g.name == "is_zero") {  // src/gadget_zero_nonzero.rs:76-110
         is_zero_gadget(h.cs, AS(0));
         return 1;

@@ -11,6 +11,7 @@
  * Gadget names, integer parameters `ip` and scalar parameters `sp` (32-byte LE each):
  *   "factors"          sp=[r]                                   values: p, q                       (src/factors.rs:48-103)
  *   "bound_check"      ip=[bits, min_lo,min_hi, max_lo,max_hi]  values: v, v-min, max-v            (src/gadget_bound_check.rs:49-87)
+ *   "range_proof"      ip=[min_lo,min_hi, max_lo,max_hi]        values: v-min, max-v               (src/gadget_range_proof.rs:123-200)
  *   "set_membership"   ip=[k, item_lo,item_hi ...]              values: k bits, value              (src/gadget_set_membership.rs:93-134)
  *   "set_membership_1" ip=[k, item_lo,item_hi ...]              values: value, item_i - value ...  (src/gadget_set_membership_1.rs:43-112)
  *   "set_non_membership" ip=[k, item_lo,item_hi ...]            values: value, (item_i - value, its inverse) ... (src/gadget_set_non_membership.rs:38-128)

@@ -346,3 +346,26 @@ def mimc_set_membership(xl, xr, constants, value, set_, label=b"MiMC+SetMembersh
         v = vr.commit(comms[2 + len(set_)])
         g.vector_product_gadget(vr, set_, bit_vars, Alloc(v, None))
     return Scenario(label, [xl, xr] + bit_map + [value], bp, bv)
+
+
+def range_proof(v, lower, upper, label=b"BoundsTest"):
+    """gadget_range_proof.rs:123-200 (test_range_proof_gadget): commits a = v - min and b = max - v, both in
+    [0, 2^n) with n = bit length of max, and a + b = max - min."""
+    n = max(upper, 1).bit_length() if upper else 0
+    a, b = v - lower, upper - v
+
+    def bp(pr, bl):
+        ca, va = pr.commit(a % L, bl[0])
+        g.positive_no_gadget(pr, Alloc(va, a), n)
+        cb, vb = pr.commit(b % L, bl[1])
+        g.positive_no_gadget(pr, Alloc(vb, b), n)
+        g.constrain_lc_with_scalar(pr, va + vb, upper - lower)
+        return [ca, cb]
+
+    def bv(vr, comms, pc):
+        va = vr.commit(comms[0])
+        g.positive_no_gadget(vr, Alloc(va, None), n)
+        vb = vr.commit(comms[1])
+        g.positive_no_gadget(vr, Alloc(vb, None), n)
+        g.constrain_lc_with_scalar(vr, va + vb, upper - lower)
+    return Scenario(label, [a % L, b % L], bp, bv)

@@ -28,6 +28,8 @@ def case(name, j=0):
         return "set_membership", ip, [], S.set_membership(SET[j % len(SET)], SET), 32
     if name == "factors":
         return "factors", [], [323], S.factors(), 4
+    if name == "range_proof":
+        return "range_proof", _u64(10) + _u64(100), [], S.range_proof(37 + j, 10, 100), 16
     if name == "is_zero":
         return "is_zero", [], [], S.is_zero(0), 2
     if name == "is_zero_violated":

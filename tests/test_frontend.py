@@ -19,7 +19,7 @@ def test_trees_match_oracle(sim_glib):
     fc.check_trees(sim_glib, levels4=4, depth2=3, partial_rounds=2)
 
 
-@pytest.mark.parametrize("case", ["bound_check", "set_membership", "factors", "is_zero", "is_zero_violated", "not_equals",
+@pytest.mark.parametrize("case", ["bound_check", "set_membership", "factors", "range_proof", "is_zero", "is_zero_violated", "not_equals",
                                   "set_membership_1", "set_non_membership"])
 def test_compiled_gadget_batch(sim_lib, sim_glib, case):
     fc.check_compiled(sim_lib, sim_glib, case, batch=2)

@@ -12,7 +12,7 @@ def test_native_hashes_and_trees(hip_glib):
     fc.check_trees(hip_glib, levels4=4, depth2=3, partial_rounds=2)
 
 
-@pytest.mark.parametrize("case", ["bound_check", "bound_check_64", "set_membership", "factors", "is_zero", "not_equals",
+@pytest.mark.parametrize("case", ["bound_check", "bound_check_64", "set_membership", "factors", "range_proof", "is_zero", "not_equals",
                                   "set_membership_1", "set_non_membership"])
 def test_compiled_small(hip_lib, hip_glib, case):
     fc.check_compiled(hip_lib, hip_glib, case, batch=3, unfold=2)
