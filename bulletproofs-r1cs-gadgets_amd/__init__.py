@@ -86,6 +86,7 @@ def load_library(path=None):
     lib.bpr1cs_poseidon_permutation_batch.argtypes = [vp, ctypes.c_int, cp, sz, cp]
     lib.bpr1cs_set_unfold_rounds.argtypes = [ctypes.c_int]
     lib.bpr1cs_set_window_bits.argtypes = [ctypes.c_int]
+    lib.bpr1cs_set_table_format.argtypes = [ctypes.c_int]
     lib.bpr1cs_set_witness_team.argtypes = [ctypes.c_int]
     lib.bpr1cs_set_witness_macro.argtypes = [ctypes.c_int]
     lib.bpr1cs_set_rng_mode.argtypes = [ctypes.c_int]

@@ -11,6 +11,7 @@
 #include "kernels.hpp"
 #if !defined(BPR1CS_HOSTSIM)
 #include "kernels_hip.hpp"
+#include "msm_hip.hpp"
 #endif
 
 // ------------------------------------------------------------ host-side hashes
@@ -36,6 +37,7 @@ static void host_sponge(uint32_t rate, uint8_t suffix, const uint8_t* in, size_t
 
 static int g_unfold_rounds = 4;
 static int g_window_bits = 8;
+static int g_table_format = -1;   // -1 auto, 0 packed (96 B per entry), 1 limb form in 128-B slots (see bpr1cs_set_table_format)
 static int g_latency_cus = 0;   // >0: CUs reserved for the latency-bound kernels (see bpr1cs_gens_create)
 static int g_rng_mode = 0;       // 0 auto, 1 lane-parallel via LDS (k_rng_stream), 2 state per thread, 3 scalar unit, 4 lane-parallel via DPP (k_rng_dpp)
 static int g_merge_triples = 1;  // A_I1: one merged table per Inverse-S-box triple (needs the annotated witness program)
@@ -48,7 +50,7 @@ struct bpr1cs_gens {
     uint32_t cap = 0;
     TabCfg tc{};             // fixed-base table geometry (window bits chosen at creation)
     DevBuf<ge> pts;          // [2 + 2cap] : B, B~, G.., H..
-    DevBuf<ge_niels_packed> tab;  // [(2+2cap) * windows * entries], 96 B per entry
+    DevBuf<uint8_t> tab;     // [(2+2cap) * windows * row] slots of tc.stride bytes
     std::vector<uint8_t> comp;  // compressed, host copy
     dev_stream_t stream{};   // setup / synchronous helpers
     // two stream pairs so that two prove jobs can be in flight (cross-batch pipelining);
@@ -82,7 +84,7 @@ struct bpr1cs_circuit {
     DevBuf<uint32_t> trip, rest;
     const bpr1cs_gens* mt_gens = nullptr;  // merged tables are built for one generator set at a time
     uint32_t mt_W = 0, mt_cap = 0;
-    DevBuf<ge_niels_packed> mtab;
+    DevBuf<uint8_t> mtab;
 };
 
 static bool have_device() {
@@ -149,6 +151,7 @@ void bpr1cs_set_witness_macro(int enable) { g_witness_macro = enable ? 1 : 0; }
 void bpr1cs_set_rng_mode(int mode) { g_rng_mode = (mode >= 1 && mode <= 4) ? mode : 0; }
 int bpr1cs_circuit_macro_perms(const bpr1cs_circuit* c) { return c ? (int)c->n_perms : 0; }
 void bpr1cs_set_window_bits(int w) { g_window_bits = w < 4 ? 4 : (w > 12 ? 12 : w); }
+void bpr1cs_set_table_format(int f) { g_table_format = (f == 0 || f == 1) ? f : -1; }
 int bpr1cs_last_timings(float* out, int cap) {
     int k = cap < 6 ? cap : 6;
     for (int i = 0; i < k; i++) out[i] = g_timings[i];
@@ -160,7 +163,20 @@ int bpr1cs_gens_create(uint32_t cap, bpr1cs_gens** out) {
     if (!have_device()) return BPR1CS_ERR_NO_DEVICE;
     bpr1cs_gens* g = new bpr1cs_gens();
     g->cap = cap;
-    g->tc = tab_cfg((uint32_t)g_window_bits);
+    {   // table entry format: the limb form (no unpacking in the inner loop, 128-byte aligned slots) costs a third more
+        // HBM than the packed one - take it when the device keeps >= 100 GB free for circuits' merged tables and the
+        // per-batch workspace (two 1024-proof jobs of the depth-32 circuit in flight need ~55 GB)
+        int fmt = g_table_format;
+        if (fmt < 0) {
+            fmt = 0;
+#if !defined(BPR1CS_HOSTSIM)
+            size_t mfree = 0, mtotal = 0;
+            TabCfg lim = tab_cfg((uint32_t)g_window_bits, TAB_FMT_LIMB, 128);
+            if (hipMemGetInfo(&mfree, &mtotal) == hipSuccess && mfree > (size_t)(2 + 2 * (size_t)cap) * lim.base_bytes() + (100ull << 30)) fmt = 1;
+#endif
+        }
+        g->tc = fmt ? tab_cfg((uint32_t)g_window_bits, TAB_FMT_LIMB, 128) : tab_cfg((uint32_t)g_window_bits, TAB_FMT_PACKED, 96);
+    }
 #if !defined(BPR1CS_HOSTSIM)
     HIPCHK(hipStreamCreate(&g->stream));
     int prio_lo = 0, prio_hi = 0;
@@ -215,7 +231,7 @@ int bpr1cs_gens_create(uint32_t cap, bpr1cs_gens** out) {
     g->comp.resize((size_t)nb * 32);
     dev_d2h(g->comp.data(), d_comp.p, (size_t)nb * 32, g->stream);
     memcpy(g->comp.data(), bcomp, 32);
-    g->tab.alloc((size_t)nb * g->tc.per_base);
+    g->tab.alloc((size_t)nb * g->tc.base_bytes());
     launch((uint64_t)nb * g->tc.windows, K_build_table{g->pts.p, g->tab.p, g->tc}, g->stream);
     dev_sync(g->stream);
     *out = g;
@@ -484,38 +500,74 @@ struct MsmStats {
 static MsmStats g_msm;             // last finished job (reported by bpr1cs_last_msm_stats)
 static MsmStats* g_cur_msm = &g_msm;  // job being enqueued
 
-// Launch geometry: many more workgroups than the chip holds at once (g_msm_target_threads / 256 >> 2 per CU), so
+// Launch geometry: many more workgroups than the chip holds at once (g_msm_target_threads / 64 >> 16 per CU), so
 // that the hardware dispatcher load-balances them - a launch of exactly one resident set makes every workgroup
-// that shares a SIMD with a co-running front kernel a straggler for the whole launch.  The chunk partials are
-// folded `MSM_REDUCE_GROUP` at a time before the per-proof finish kernel.
+// that shares a SIMD with a co-running front kernel a straggler for the whole launch.  Up to MSM_MAX_JOBS independent
+// sums share one launch (k_msm_fixed2).  The chunk partials are folded `MSM_REDUCE_GROUP` at a time (twice when
+// there are many) before the per-proof finish kernel, which then adds at most MSM_REDUCE_GROUP points.
 static const uint32_t MSM_REDUCE_GROUP = 16;
-static void run_msm(const bpr1cs_gens* g, MsmSeg s0, MsmSeg s1, uint32_t B, DevBuf<ge>& partial, MsmPlan& plan, dev_stream_t st,
-                    const ge_niels_packed* table = nullptr) {
-    uint32_t total = s0.count + s1.count;
-    uint32_t nchunks = pick_chunks(total, B, g_msm_target_threads, plan.chunk);
-    uint32_t reduced = nchunks > 128 ? (nchunks + MSM_REDUCE_GROUP - 1) / MSM_REDUCE_GROUP : 0;
-    size_t need = ((size_t)nchunks + reduced) * B;
-    if (partial.n < need) partial.alloc(need);
-    ge* raw = partial.p + (size_t)reduced * B;  // the reduced partials (what the callers read) sit at the front
-    uint32_t nbk = (B + 63u) / 64u;
-    K_msm_fixed k{table ? table : g->tab.p, g->tc, {s0, s1}, raw, B, plan.chunk, nbk, nchunks * nbk};
+struct MsmReq {
+    MsmSeg s0, s1;
+    DevBuf<ge>* partial;  // out: the reduced partial sums sit at the front, [plan->nchunks][B]
+    MsmPlan* plan;
+    const uint8_t* table;  // nullptr = the generator tables of `g`
+};
+static void run_msm_multi(const bpr1cs_gens* g, MsmReq* reqs, uint32_t nreq, uint32_t B, dev_stream_t st) {
+    const uint32_t nbk = (B + 63u) / 64u;
+    struct Lay { uint32_t nchunks, l1, l2; ge* raw; ge* p1; ge* p2; };
+    Lay lay[MSM_MAX_JOBS];
 #if !defined(BPR1CS_HOSTSIM)
+    MsmLaunch L{};
+    L.B = B; L.nbk = nbk; L.tc = g->tc;
+    L.njobs = nreq;
+#endif
+    uint32_t wg = 0;
+    uint64_t terms = 0;
+    for (uint32_t r = 0; r < nreq; r++) {
+        MsmReq& q = reqs[r];
+        uint32_t total = q.s0.count + q.s1.count;
+        uint32_t nchunks = pick_chunks(total, B, g_msm_target_threads / (nreq > 1 ? 1u : 1u), q.plan->chunk);
+        uint32_t l1 = nchunks > MSM_REDUCE_GROUP ? (nchunks + MSM_REDUCE_GROUP - 1) / MSM_REDUCE_GROUP : 0;
+        uint32_t l2 = l1 > MSM_REDUCE_GROUP ? (l1 + MSM_REDUCE_GROUP - 1) / MSM_REDUCE_GROUP : 0;
+        size_t need = ((size_t)nchunks + l1 + l2) * B;
+        if (q.partial->n < need) q.partial->alloc(need);
+        lay[r] = Lay{nchunks, l1, l2, q.partial->p + (size_t)(l1 + l2) * B, q.partial->p + (size_t)l2 * B, q.partial->p};
+        q.plan->nchunks = l2 ? l2 : (l1 ? l1 : nchunks);
+        terms += (uint64_t)total * B;
+        wg += nchunks * nbk;
+#if !defined(BPR1CS_HOSTSIM)
+        L.job[r] = MsmJob{{q.s0, q.s1}, q.table ? q.table : g->tab.p, lay[r].raw, q.plan->chunk, nchunks};
+        L.wg_end[r] = wg;
+#endif
+    }
+#if defined(BPR1CS_HOSTSIM)
+    for (uint32_t r = 0; r < nreq; r++) {
+        MsmReq& q = reqs[r];
+        K_msm_fixed k{q.table ? q.table : g->tab.p, g->tc, {q.s0, q.s1}, lay[r].raw, B, q.plan->chunk, nbk, lay[r].nchunks * nbk};
+        launch_wave((uint64_t)lay[r].nchunks * nbk * 64u, k, st);
+    }
+#else
     hipEvent_t e0 = g_cur_msm->get(), e1 = g_cur_msm->get();
     HIPCHK(hipEventRecord(e0, st));
-#endif
-    launch_wave((uint64_t)nchunks * nbk * 64u, k, st);
-#if !defined(BPR1CS_HOSTSIM)
+    L.nwg = (wg + 7u) & ~7u;  // a multiple of 8 keeps the XCD-aware remap on
+    const size_t lds = (size_t)2 * g->tc.windows * 64 * sizeof(uint16_t);
+    if (g->tc.fmt == TAB_FMT_PACKED) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_msm_fixed2<(int)TAB_FMT_PACKED, 3>), dim3(L.nwg), dim3(64), lds, st, L);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_msm_fixed2<(int)TAB_FMT_LIMB, 3>), dim3(L.nwg), dim3(64), lds, st, L);
+    HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(e1, st));
     g_cur_msm->ev.push_back({e0, e1});
 #endif
-    if (reduced) {
-        launch((uint64_t)reduced * B, K_ge_reduce{raw, partial.p, B, nchunks, MSM_REDUCE_GROUP}, st);
-        plan.nchunks = reduced;
-    } else {
-        plan.nchunks = nchunks;
+    for (uint32_t r = 0; r < nreq; r++) {
+        if (lay[r].l1) launch((uint64_t)lay[r].l1 * B, K_ge_reduce{lay[r].raw, lay[r].p1, B, lay[r].nchunks, MSM_REDUCE_GROUP}, st);
+        if (lay[r].l2) launch((uint64_t)lay[r].l2 * B, K_ge_reduce{lay[r].p1, lay[r].p2, B, lay[r].l1, MSM_REDUCE_GROUP}, st);
     }
     g_cur_msm->launches++;
-    g_cur_msm->terms += (uint64_t)total * B;
+    g_cur_msm->terms += terms;
+}
+static void run_msm(const bpr1cs_gens* g, MsmSeg s0, MsmSeg s1, uint32_t B, DevBuf<ge>& partial, MsmPlan& plan, dev_stream_t st,
+                    const uint8_t* table = nullptr) {
+    MsmReq q{s0, s1, &partial, &plan, table};
+    run_msm_multi(g, &q, 1, B, st);
 }
 
 // constraint columns weighted by powers of z: wvec[slot][b] (first `nslots` slots of the circuit)
@@ -724,6 +776,7 @@ extern "C" int bpr1cs_prove_batch_begin(const bpr1cs_gens* g, const bpr1cs_circu
         auto seg = [&](const sc* p, uint32_t base0) { return MsmSeg{p, n, n ? n : 1, n ? n : 1, 0, base0, 1}; };
         const uint32_t T3 = (uint32_t)c->h_trip.size();
         DevBuf<ge> partial2;
+        MsmPlan planO;
         K_msm_finish finI{g->tab.p, g->tc, nullptr, blind.p + 0 * (size_t)B, nullptr, AOS.p + 0 * (size_t)B * 32, B, 0, 1};
         if (!wires && T3 && g_merge_triples) {
             // A_I1 with the repeated S-box wires merged: 2 terms per S-box instead of 5 (see K_merge_points)
@@ -731,7 +784,7 @@ extern "C" int bpr1cs_prove_batch_begin(const bpr1cs_gens* g, const bpr1cs_circu
             if (cm->mt_gens != g || cm->mt_W != g->tc.W || cm->mt_cap != g->cap) {
                 DevBuf<ge> mp((size_t)2 * T3);
                 launch(T3, K_merge_points{g->pts.p, c->trip.p, mp.p, T3, baseG, baseH}, st);
-                cm->mtab.alloc((size_t)2 * T3 * g->tc.per_base);
+                cm->mtab.alloc((size_t)2 * T3 * g->tc.base_bytes());
                 launch((uint64_t)2 * T3 * g->tc.windows, K_build_table{mp.p, cm->mtab.p, g->tc}, st);
                 cm->mt_gens = g;
                 cm->mt_W = g->tc.W;
@@ -741,19 +794,18 @@ extern "C" int bpr1cs_prove_batch_begin(const bpr1cs_gens* g, const bpr1cs_circu
             MsmSeg rG{aL, nr, 1, 1, 0, baseG, 1, c->rest.p, 0}, rH{aR, nr, 1, 1, 0, baseH, 1, c->rest.p, 0};
             MsmSeg mG{aL, T3, 1, 1, 0, 0, 1, c->trip.p, 1}, mH{aR, T3, 1, 1, 0, T3, 1, c->trip.p, 1};
             MsmPlan plan2;
-            run_msm(g, rG, rH, B, partial, plan, st);
-            run_msm(g, mG, mH, B, partial2, plan2, st, c->mtab.p);
+            MsmReq rq[3] = {{rG, rH, &partial, &plan, nullptr}, {mG, mH, &partial2, &plan2, c->mtab.p}, {seg(aO, baseG), none, &partialO, &planO, nullptr}};
+            run_msm_multi(g, rq, 3, B, st);  // the three sums that need the wires only share one launch
             finI.partial = partial.p;
             finI.nchunks = plan.nchunks;
             finI.partial_b = partial2.p;
             finI.nchunks_b = plan2.nchunks;
         } else {
-            run_msm(g, seg(aL, baseG), seg(aR, baseH), B, partial, plan, st);
+            MsmReq rq[2] = {{seg(aL, baseG), seg(aR, baseH), &partial, &plan, nullptr}, {seg(aO, baseG), none, &partialO, &planO, nullptr}};
+            run_msm_multi(g, rq, 2, B, st);
             finI.partial = partial.p;
             finI.nchunks = plan.nchunks;
         }
-        MsmPlan planO;
-        run_msm(g, seg(aO, baseG), none, B, partialO, planO, st);
 #if !defined(BPR1CS_HOSTSIM)
         HIPCHK(hipStreamWaitEvent(st, ev_rng, 0));  // (in the wires path everything on `sl` was synchronised above)
 #endif
@@ -813,10 +865,11 @@ extern "C" int bpr1cs_prove_batch_begin(const bpr1cs_gens* g, const bpr1cs_circu
             // L: G-terms with pos >= m, H-terms with pos < m ; R: the complement
             MsmSeg gL{sG.p, half, mk, Nk, mk, baseG, 0}, hL{sH.p, half, mk, Nk, 0, baseH, 0};
             MsmSeg gR{sG.p, half, mk, Nk, 0, baseG, 0}, hR{sH.p, half, mk, Nk, mk, baseH, 0};
-            run_msm(g, gL, hL, B, partial, plan, st);
+            MsmPlan planR;
+            MsmReq rq[2] = {{gL, hL, &partial, &plan, nullptr}, {gR, hR, &partialO, &planR, nullptr}};
+            run_msm_multi(g, rq, 2, B, st);  // L_k and R_k share one launch
             launch(B, K_msm_finish{g->tab.p, g->tc, partial.p, cross.p, wch, Lout, B, plan.nchunks, 0}, st);
-            run_msm(g, gR, hR, B, partial, plan, st);
-            launch(B, K_msm_finish{g->tab.p, g->tc, partial.p, cross.p + B, wch, Rout, B, plan.nchunks, 0}, st);
+            launch(B, K_msm_finish{g->tab.p, g->tc, partialO.p, cross.p + B, wch, Rout, B, planR.nchunks, 0}, st);
         } else {
             if (k == r) {
                 GH.alloc((size_t)2 * M * B);

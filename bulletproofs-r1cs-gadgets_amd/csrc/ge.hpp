@@ -18,22 +18,47 @@ struct ge_niels {    // affine Niels: (y+x, y-x, 2dxy), Z = 1
 struct ge_cached {   // projective Niels: (Y+X, Y-X, Z, 2dT)
     fe YplusX, YminusX, Z, T2d;
 };
-// table storage form of an affine Niels point: 3 x 32 canonical little-endian bytes (96 B per entry)
-struct ge_niels_packed {
+// Table storage forms of an affine Niels point (y+x, y-x, 2dxy; all canonical):
+//   TAB_FMT_PACKED  3 x 32 canonical little-endian bytes                     (96 B per entry, unpacked on load)
+//   TAB_FMT_LIMB    3 x 9 limbs of 29 bits in 32-bit words, ready to multiply (108 B used, stride 108 or 128)
+#define TAB_FMT_PACKED 0u
+#define TAB_FMT_LIMB 1u
+HD inline void ge_niels_store(const ge_niels& n, uint8_t* dst, uint32_t fmt) {
     uint32_t w[24];
-};
-HD inline ge_niels_packed ge_niels_pack(const ge_niels& n) {
-    ge_niels_packed p;
-    fe_canon(n.yplusx, p.w);
-    fe_canon(n.yminusx, p.w + 8);
-    fe_canon(n.xy2d, p.w + 16);
-    return p;
+    fe_canon(n.yplusx, w);
+    fe_canon(n.yminusx, w + 8);
+    fe_canon(n.xy2d, w + 16);
+    uint32_t* o = (uint32_t*)dst;
+    if (fmt == TAB_FMT_PACKED) {
+#pragma unroll
+        for (int i = 0; i < 24; i++) o[i] = w[i];
+    } else {
+#pragma unroll
+        for (int f = 0; f < 3; f++) {
+            fe t = fe_fromwords(w + 8 * f);
+#pragma unroll
+            for (int i = 0; i < 9; i++) o[9 * f + i] = (uint32_t)t.v[i];
+        }
+    }
 }
-HD inline ge_niels ge_niels_unpack(const ge_niels_packed& p) {  // limbs in [0, 2^29)
+HD inline ge_niels ge_niels_load(const uint8_t* src, uint32_t fmt) {  // limbs in [0, 2^29)
+    const uint32_t* w = (const uint32_t*)src;
     ge_niels n;
-    n.yplusx = fe_fromwords(p.w);
-    n.yminusx = fe_fromwords(p.w + 8);
-    n.xy2d = fe_fromwords(p.w + 16);
+    if (fmt == TAB_FMT_PACKED) {
+        uint32_t t[24];
+#pragma unroll
+        for (int i = 0; i < 24; i++) t[i] = w[i];
+        n.yplusx = fe_fromwords(t);
+        n.yminusx = fe_fromwords(t + 8);
+        n.xy2d = fe_fromwords(t + 16);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 9; i++) {
+            n.yplusx.v[i] = (int32_t)w[i];
+            n.yminusx.v[i] = (int32_t)w[9 + i];
+            n.xy2d.v[i] = (int32_t)w[18 + i];
+        }
+    }
     return n;
 }
 // Limb-bound bookkeeping of the formulas below (N = bound of a product, see fe.hpp):
@@ -103,6 +128,51 @@ HD inline ge ge_madd(const ge& p, const ge_niels& q, int negate) {
     fe cZ = fe_select(zp, zm, negate), cT = fe_select(zm, zp, negate);
     ge r;
     r.X = fe_mul(cX, cT); r.Y = fe_mul(cY, cZ); r.Z = fe_mul(cZ, cT); r.T = fe_mul(cX, cY);
+    return r;
+}
+// Table addition.  Two savings over ge_madd:
+//  (1) the table operand is the HALVED Niels form  q = ((y+x)/2, (y-x)/2, d x y)  (ge_to_table_niels): with A, B, C all
+//      halved the formulas below need Z instead of 2Z and produce (X/4 : Y/4 : Z/4 : T/4) - the same point, still with
+//      T Z = X Y - one limb-wise doubling less per addition and tighter limbs for cZ, cT;
+//  (2) the cheaper floor-carry multiplier where the limb budget allows it.  Invariant of the accumulator p between
+//      calls ("table class"): X, Y, T are fe_mul_f outputs (limbs in [-2^24, F'), F' = 2^29 + 2^24), Z is centred
+//      (|limb| <= N = 2^28 + 2^23); a point in the ordinary class (all coordinates N) is also accepted.  q: limbs in [0, 2^29).
+//   U = Y+X <= 2F', |V = Y-X| <= F' + 2^24 ;  A = U a, B = V b : 9 * 2F' * 2^29 = 2^62.2          (fe_mul_f)
+//   C = T q.dxy : F' * 2^29, centred output (N) ;  |cZ|, |cT| <= 2N ;  |cX| <= F' + 2^24 ;  cY <= 2F'
+//   X' = cX cT : 9 * 1.04F' * 2N = 2^61.3 ;  Y' = cY cZ : 9 * 2F' * 2N = 2^62.3 ;  T' = cX cY : 9 * 1.04F' * 2F' = 2^62.3  (fe_mul_f)
+//   Z' = cZ cT : 9 * 2N * 2N = 2^61.2                                                               (fe_mul, centred)
+// all below the 2^63 limit of the signed 64-bit column sums.  Five of the seven products use the floor-carry form.
+HD inline ge ge_madd_t(const ge& p, const ge_niels& q, int negate) {
+    fe a = fe_select(q.yplusx, q.yminusx, negate);
+    fe b = fe_select(q.yminusx, q.yplusx, negate);
+    fe PP = fe_mul_f(fe_add(p.Y, p.X), a);
+    fe MM = fe_mul_f(fe_sub(p.Y, p.X), b);
+    fe Tdxy = fe_mul(p.T, q.xy2d);
+    fe cX = fe_sub(PP, MM), cY = fe_add(PP, MM);
+    fe zp = fe_add(p.Z, Tdxy), zm = fe_sub(p.Z, Tdxy);
+    fe cZ = fe_select(zp, zm, negate), cT = fe_select(zm, zp, negate);
+    ge r;
+    r.X = fe_mul_f(cX, cT); r.Y = fe_mul_f(cY, cZ); r.Z = fe_mul(cZ, cT); r.T = fe_mul_f(cX, cY);
+    return r;
+}
+// affine (x, y) -> halved Niels form stored in the fixed-base tables
+HD inline ge_niels ge_to_table_niels(const fe& x, const fe& y) {
+    fe half = fe_const(FE_HALF_L);
+    ge_niels e;
+    e.yplusx = fe_mul(fe_add(y, x), half);
+    e.yminusx = fe_mul(fe_sub(y, x), half);
+    e.xy2d = fe_mul(fe_mul(x, y), fe_const(FE_D_L));  // d x y (the field keeps the name of the standard form)
+    return e;
+}
+HD inline ge_niels ge_table_niels_identity() {  // x = 0, y = 1
+    ge_niels r;
+    r.yplusx = fe_const(FE_HALF_L); r.yminusx = fe_const(FE_HALF_L); r.xy2d = fe_zero();
+    return r;
+}
+// table class -> ordinary class (centred limbs), same point
+HD inline ge ge_from_table_class(const ge& p) {
+    ge r;
+    r.X = fe_carry(p.X); r.Y = fe_carry(p.Y); r.Z = p.Z; r.T = fe_carry(p.T);
     return r;
 }
 // 2p: 4S + 4M

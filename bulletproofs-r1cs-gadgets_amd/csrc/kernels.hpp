@@ -17,17 +17,35 @@
 #include "ge.hpp"
 #include "merlin.hpp"
 
-// table geometry: W-bit signed windows -> windows = ceil(254/W), entries = 2^(W-1) per window
+// table geometry: W-bit signed windows -> windows = ceil(253/W), entries = 2^(W-1) per window.  A window row holds
+// entries + 1 slots: slot 0 is the identity (digit 0: the pipelined MSM kernel never branches on a digit), slot j
+// is j * 2^(W k) * P.  Scalars are canonical (< l < 2^252 + 2^125), so with signed digits the TOP window never
+// carries out: its digit is at most 2^(W-1) (when W divides 253, i.e. W = 11, the value 2^(W-1) is reached only for
+// s >= 2^252, whose lower windows are zero and send no carry) - 23 windows at W = 11, not 24.
 struct TabCfg {
-    uint32_t W, windows, entries, per_base;
+    uint32_t W, windows, entries, row, per_base;  // per_base = windows * row slots
+    uint32_t fmt, stride;                         // entry format (ge.hpp) and byte stride of a slot
+    HD size_t base_bytes() const { return (size_t)per_base * stride; }
 };
-HD inline TabCfg tab_cfg(uint32_t W) {
+HD inline TabCfg tab_cfg(uint32_t W, uint32_t fmt = TAB_FMT_PACKED, uint32_t stride = 96) {
     TabCfg t;
     t.W = W;
-    t.windows = (253 + W) / W;
+    t.windows = (252 + W) / W;
     t.entries = 1u << (W - 1);
-    t.per_base = t.windows * t.entries;
+    t.row = t.entries + 1;
+    t.per_base = t.windows * t.row;
+    t.fmt = fmt;
+    t.stride = stride;
     return t;
+}
+// signed digit of window k (carry in/out through `carry`); the top window keeps its value (see above)
+HD inline int tab_digit(const sc& s, uint32_t k, int& carry, const TabCfg& tc) {
+    uint32_t bit = k * tc.W, wi = bit >> 5, sh = bit & 31;
+    uint64_t two = (uint64_t)s.v[wi] | ((wi + 1 < 8) ? ((uint64_t)s.v[wi + 1] << 32) : 0);
+    int d = (int)((two >> sh) & ((1u << tc.W) - 1u)) + carry;
+    carry = (k + 1 < tc.windows) & (d >= (int)tc.entries);
+    d -= carry << tc.W;
+    return d;
 }
 
 // variable encoding shared with the host front-end (kind<<28 | index)
@@ -49,23 +67,22 @@ HD inline TabCfg tab_cfg(uint32_t W) {
 #define WK_PXINV 7u     // 1/x of that S-box
 
 // ------------------------------------------------------------ fixed-base core
-// acc += s * Base, s canonical (< l).  Signed W-bit digits.
-HD inline ge table_mul_acc(ge acc, const ge_niels_packed* tbase, const sc& s, const TabCfg& tc) {
+// acc += s * Base, s canonical (< l).  Signed W-bit digits.  `acc` in the ordinary or the table class (ge_madd_t);
+// the result is in the table class.
+HD inline ge table_mul_acc_raw(ge acc, const uint8_t* tbase, const sc& s, const TabCfg& tc) {
     int carry = 0;
-    const int half = 1 << (tc.W - 1);
     for (uint32_t k = 0; k < tc.windows; k++) {
-        uint32_t bit = k * tc.W, wi = bit >> 5, sh = bit & 31;
-        uint64_t two = (uint64_t)s.v[wi] | ((wi + 1 < 8) ? ((uint64_t)s.v[wi + 1] << 32) : 0);
-        int d = (int)((two >> sh) & ((1u << tc.W) - 1u)) + carry;
-        carry = d >= half;
-        d -= carry << tc.W;
+        int d = tab_digit(s, k, carry, tc);
         if (d != 0) {
             int neg = d < 0;
             int mag = neg ? -d : d;
-            acc = ge_madd(acc, ge_niels_unpack(tbase[(size_t)k * tc.entries + mag - 1]), neg);
+            acc = ge_madd_t(acc, ge_niels_load(tbase + ((size_t)k * tc.row + (uint32_t)mag) * tc.stride, tc.fmt), neg);
         }
     }
     return acc;
+}
+HD inline ge table_mul_acc(const ge& acc, const uint8_t* tbase, const sc& s, const TabCfg& tc) {
+    return ge_from_table_class(table_mul_acc_raw(acc, tbase, s, tc));
 }
 
 // s*P for an arbitrary point (double-and-add, MSB first); s canonical
@@ -123,7 +140,7 @@ struct K_gen_points {  // uniform[cnt][64] -> pts[cnt]
 
 struct K_build_table {  // gid = base*windows + k
     const ge* pts;
-    ge_niels_packed* tab;
+    uint8_t* tab;
     TabCfg tc;
     HD void operator()(uint32_t g) const {
         uint32_t base = g / tc.windows, k = g % tc.windows;
@@ -131,27 +148,26 @@ struct K_build_table {  // gid = base*windows + k
         for (uint32_t t = 0; t < tc.W * k; t++) P = ge_dbl(P);
         ge_cached c = ge_to_cached(P);
         ge acc = P;
-        ge_niels_packed* out = tab + (size_t)g * tc.entries;
-        // affine normalisation with Montgomery's trick, 16 entries per field inversion
+        uint8_t* out = tab + (size_t)g * tc.row * tc.stride;
+        ge_niels_store(ge_table_niels_identity(), out, tc.fmt);
+        out += tc.stride;
+        // affine normalisation with Montgomery's trick, up to 16 entries per field inversion
         const int CH = 16;
         for (uint32_t j0 = 0; j0 < tc.entries; j0 += CH) {
             ge q[CH];
             fe pre[CH];
-            for (int t = 0; t < CH; t++) {
+            const int cnt = tc.entries - j0 < (uint32_t)CH ? (int)(tc.entries - j0) : CH;
+            for (int t = 0; t < cnt; t++) {
                 if (j0 + t > 0) acc = ge_add(acc, c);
                 q[t] = acc;
                 pre[t] = t ? fe_mul(pre[t - 1], acc.Z) : acc.Z;
             }
-            fe inv = fe_invert(pre[CH - 1]);
-            for (int t = CH - 1; t >= 0; t--) {
+            fe inv = fe_invert(pre[cnt - 1]);
+            for (int t = cnt - 1; t >= 0; t--) {
                 fe zi = t ? fe_mul(inv, pre[t - 1]) : inv;
                 inv = fe_mul(inv, q[t].Z);
                 fe x = fe_mul(q[t].X, zi), y = fe_mul(q[t].Y, zi);
-                ge_niels e;
-                e.yplusx = fe_add(y, x);
-                e.yminusx = fe_sub(y, x);
-                e.xy2d = fe_mul(fe_mul(x, y), fe_const(FE_2D_L));
-                out[j0 + t] = ge_niels_pack(e);
+                ge_niels_store(ge_to_table_niels(x, y), out + (size_t)(j0 + t) * tc.stride, tc.fmt);
             }
         }
     }
@@ -185,7 +201,7 @@ struct K_load_inputs {  // canonical v, vbl [m][B] -> Montgomery copies
 };
 
 struct K_commit_v {  // gid = j*B + b : V = v*B + vbl*B~   (Prover::commit, P1)
-    const ge_niels_packed* tab;
+    const uint8_t* tab;
     TabCfg tc;
     const sc* v_raw;
     const sc* vbl_raw;
@@ -194,7 +210,7 @@ struct K_commit_v {  // gid = j*B + b : V = v*B + vbl*B~   (Prover::commit, P1)
     HD void operator()(uint32_t g) const {
         uint32_t j = g / B, b = g % B;
         ge acc = table_mul_acc(ge_identity(), tab, v_raw[g], tc);
-        acc = table_mul_acc(acc, tab + tc.per_base, vbl_raw[g], tc);
+        acc = table_mul_acc(acc, tab + tc.base_bytes(), vbl_raw[g], tc);
         ge_compress(acc, out + ((size_t)b * m + j) * 32);
     }
 };
@@ -639,12 +655,13 @@ struct MsmSeg {
     const uint32_t* sidx = nullptr;
     uint32_t bdense = 0;
 };
+#define MSM_MAX_JOBS 4  // independent sums that may share one launch of the shipped kernel (csrc/msm_hip.hpp)
 // One thread = (chunk c of the term list, proof b); a workgroup = ONE wavefront = 64 consecutive proofs of one
 // chunk, so its lanes walk the same table rows.  Workgroups are dealt round-robin to the 8 XCDs (each with a
 // private L2): the workgroup index is remapped so that the `nbk` workgroups sharing a chunk run on the SAME XCD
 // back to back and a table row is pulled from HBM once, not once per XCD.
 struct K_msm_fixed {  // gid = wg*64 + lane -> partial[c*B + b]   (launch_wave)
-    const ge_niels_packed* tab;
+    const uint8_t* tab;
     TabCfg tc;
     MsmSeg seg[2];
     ge* partial;
@@ -666,9 +683,9 @@ struct K_msm_fixed {  // gid = wg*64 + lane -> partial[c*B + b]   (launch_wave)
             uint32_t base = s.base0 + (s.bdense ? oo : i);
             sc x = s.scal[(size_t)i * B + b];
             if (s.mont) x = sc_from_mont(x);
-            acc = table_mul_acc(acc, tab + (size_t)base * tc.per_base, x, tc);
+            acc = table_mul_acc_raw(acc, tab + (size_t)base * tc.base_bytes(), x, tc);
         }
-        partial[(size_t)c * B + b] = acc;
+        partial[(size_t)c * B + b] = ge_from_table_class(acc);
     }
 };
 // second-level reduction of chunk partials: out[r*B + b] = sum_{k < group} in[(r*group + k)*B + b]
@@ -686,7 +703,7 @@ struct K_ge_reduce {  // gid = r*B + b
 };
 // sum of partials + extra*Base(extra_base) -> compressed (and optional extended copy)
 struct K_msm_finish {  // gid = b
-    const ge_niels_packed* tab;
+    const uint8_t* tab;
     TabCfg tc;
     const ge* partial;    // [nchunks][B]
     const sc* extra;      // [B] Montgomery, may be null
@@ -702,7 +719,7 @@ struct K_msm_finish {  // gid = b
         if (extra) {
             sc e = extra[b];
             e = extra2 ? sc_from_mont(sc_mul(e, extra2[b])) : sc_from_mont(e);
-            acc = table_mul_acc(acc, tab + (size_t)extra_base * tc.per_base, e, tc);
+            acc = table_mul_acc(acc, tab + (size_t)extra_base * tc.base_bytes(), e, tc);
         }
         ge_compress(acc, out + 32 * (size_t)b);
     }
@@ -786,7 +803,7 @@ struct K_sum_partials {  // gid = k*B + b : out[k][b] = sum_c part[k][c][b]
 };
 
 struct K_commit_T {  // gid = k*B + b, k<5 : T = t*B + tau*B~  (t1,t3,t4,t5,t6)
-    const ge_niels_packed* tab;
+    const uint8_t* tab;
     TabCfg tc;
     const sc* tco;    // [6][B]
     const sc* blind;  // [8][B]
@@ -796,7 +813,7 @@ struct K_commit_T {  // gid = k*B + b, k<5 : T = t*B + tau*B~  (t1,t3,t4,t5,t6)
         uint32_t k = g / B, b = g % B;
         const uint32_t ti[5] = {0, 2, 3, 4, 5};
         ge acc = table_mul_acc(ge_identity(), tab, sc_from_mont(tco[(size_t)ti[k] * B + b]), tc);
-        acc = table_mul_acc(acc, tab + tc.per_base, sc_from_mont(blind[(size_t)(3 + k) * B + b]), tc);
+        acc = table_mul_acc(acc, tab + tc.base_bytes(), sc_from_mont(blind[(size_t)(3 + k) * B + b]), tc);
         ge_compress(acc, out + 32 * (size_t)g);
     }
 };
@@ -967,7 +984,7 @@ struct K_ipa_update_c {  // gid = i*B + b, i<N : fold factors of the original ge
 };
 // materialise the folded generators of round r straight from the tables
 struct K_ipa_fold_from_tables {  // gid = (side*M + j)*B + b
-    const ge_niels_packed* tab;
+    const uint8_t* tab;
     TabCfg tc;
     const sc* cG;
     const sc* cH;
@@ -979,8 +996,8 @@ struct K_ipa_fold_from_tables {  // gid = (side*M + j)*B + b
         uint32_t base0 = side ? baseH : baseG;
         ge acc = ge_identity();
         for (uint32_t i = j; i < N; i += M)
-            acc = table_mul_acc(acc, tab + (size_t)(base0 + i) * tc.per_base, sc_from_mont(c[(size_t)i * B + b]), tc);
-        GH[g] = acc;
+            acc = table_mul_acc_raw(acc, tab + (size_t)(base0 + i) * tc.base_bytes(), sc_from_mont(c[(size_t)i * B + b]), tc);
+        GH[g] = ge_from_table_class(acc);
     }
 };
 // Variable-base part of the IPA (rounds >= r).  The stored per-proof generators are SCALED:
@@ -1328,7 +1345,7 @@ struct K_combine_scalars {  // gid = row : out[row] = sum_b in[row*B + b] * rho[
     }
 };
 struct K_batch_finish {  // single thread: sum of the partial sums -> compressed point, AND of the format checks
-    const ge_niels_packed* tab;
+    const uint8_t* tab;
     TabCfg tc;
     const ge* a;      // na points
     const ge* b;      // nb points
@@ -1342,7 +1359,7 @@ struct K_batch_finish {  // single thread: sum of the partial sums -> compressed
         for (uint32_t i = 0; i < na; i++) acc = ge_add_ge(acc, a[i]);
         for (uint32_t i = 0; i < nb; i++) acc = ge_add_ge(acc, b[i]);
         acc = table_mul_acc(acc, tab, sc_from_mont(bsc[0]), tc);
-        acc = table_mul_acc(acc, tab + tc.per_base, sc_from_mont(bsc[1]), tc);
+        acc = table_mul_acc(acc, tab + tc.base_bytes(), sc_from_mont(bsc[1]), tc);
         ge_compress(acc, out);
         int ok = 1;
         for (uint32_t i = 0; i < B; i++) ok &= !fail[i];
@@ -1425,7 +1442,7 @@ struct K_points_sum {  // single thread: out = compress(sum decompress(in[i])); 
     }
 };
 struct K_verify_finish {  // gid = b : sum everything, accept iff identity
-    const ge_niels_packed* tab;
+    const uint8_t* tab;
     TabCfg tc;
     const ge* msm_partial;  // [nchunks][B]
     const ge* pts;          // [P][B]
@@ -1438,7 +1455,7 @@ struct K_verify_finish {  // gid = b : sum everything, accept iff identity
         for (uint32_t c = 0; c < nchunks; c++) acc = ge_add_ge(acc, msm_partial[(size_t)c * B + b]);
         for (uint32_t p = 0; p < P; p++) acc = ge_add_ge(acc, pts[(size_t)p * B + b]);
         acc = table_mul_acc(acc, tab, sc_from_mont(bsc[b]), tc);
-        acc = table_mul_acc(acc, tab + tc.per_base, sc_from_mont(bsc[(size_t)B + b]), tc);
+        acc = table_mul_acc(acc, tab + tc.base_bytes(), sc_from_mont(bsc[(size_t)B + b]), tc);
         uint8_t enc[32];
         ge_compress(acc, enc);
         ok[b] = (!fail[b]) && bytes_are_zero32(enc);

@@ -1,0 +1,193 @@
+// The dominant kernel: batched fixed-base multiscalar multiplication over the generator tables (SURVEY §8a P2, P5,
+// P10) as a hand-scheduled gfx950 kernel.  kernels.hpp's K_msm_fixed functor computes the same partial sums term by
+// term and is what the CPU simulator of the tests runs; this file is what ships.
+//
+//   * One wavefront per workgroup = 64 consecutive proofs of one chunk of the term list (they walk the same table
+//     rows); workgroups that share a chunk are remapped onto the same XCD so a row is pulled from HBM once per XCD.
+//   * Up to MSM_MAX_JOBS independent MSMs (e.g. L_k and R_k of an IPA round, or the three commit-phase sums) share ONE
+//     launch: twice the workgroups per launch halves the tail in which SIMDs idle waiting for the last workgroups.
+//   * The signed digits of a term's scalar are recoded once into LDS (uint16 per window, next term double-buffered),
+//     so the window loop only does ds_read_u16 -> address.
+//   * Software pipeline across the TWO LAYERS of the mixed addition: the table entry of the next window is requested
+//     right after the first layer (3 of the 7 field multiplications - the only ones that read the entry) and lands
+//     during the second layer (4 multiplications, ~2800 issue cycles), so the HBM gather latency never stalls a wave.
+//     The entry registers are dead between the layers: the prefetch costs no extra VGPRs.
+//   * Digit 0 selects slot 0 of the row (the identity, see TabCfg): no divergent branch inside the pipeline.
+//   * Accumulator in the "table class" (ge_madd_t): five of seven products use the cheaper floor-carry multiplier.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "kernels.hpp"
+
+struct MsmJob {
+    MsmSeg seg[2];
+    const uint8_t* tab;  // table the job's base indices refer to
+    ge* partial;         // [nchunks][B] chunk sums (ordinary class)
+    uint32_t chunk, nchunks;
+};
+struct MsmLaunch {
+    MsmJob job[MSM_MAX_JOBS];
+    uint32_t wg_end[MSM_MAX_JOBS];  // exclusive end of every job's workgroup range
+    uint32_t njobs, B, nbk, nwg;    // nbk = ceil(B / 64) workgroups per chunk; nwg = workgroups launched
+    TabCfg tc;
+};
+
+template <int FMT>
+struct MsmEntry {
+    static constexpr int WORDS = FMT == (int)TAB_FMT_PACKED ? 24 : 27;
+    uint32_t w[WORDS];
+};
+struct __attribute__((packed, aligned(4))) msm_u4 { uint32_t x, y, z, w; };
+struct __attribute__((packed, aligned(4))) msm_u3 { uint32_t x, y, z; };
+
+template <int FMT>
+__device__ inline void msm_entry_load(MsmEntry<FMT>& e, const uint8_t* p) {
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        msm_u4 v = *(const msm_u4*)(p + 16 * i);
+        e.w[4 * i] = v.x; e.w[4 * i + 1] = v.y; e.w[4 * i + 2] = v.z; e.w[4 * i + 3] = v.w;
+    }
+    if (FMT != (int)TAB_FMT_PACKED) {
+        msm_u3 v = *(const msm_u3*)(p + 96);
+        e.w[24] = v.x; e.w[25] = v.y; e.w[26] = v.z;
+    }
+}
+template <int FMT>
+__device__ inline ge_niels msm_entry_unpack(const MsmEntry<FMT>& e) {
+    ge_niels n;
+    if (FMT == (int)TAB_FMT_PACKED) {
+        n.yplusx = fe_fromwords(e.w);
+        n.yminusx = fe_fromwords(e.w + 8);
+        n.xy2d = fe_fromwords(e.w + 16);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 9; i++) {
+            n.yplusx.v[i] = (int32_t)e.w[i];
+            n.yminusx.v[i] = (int32_t)e.w[9 + i];
+            n.xy2d.v[i] = (int32_t)e.w[18 + i];
+        }
+    }
+    return n;
+}
+
+// wave-uniform description of term ordinal o of a job: where its scalars live, which table rows it uses
+struct MsmTerm {
+    const sc* scal;      // + b
+    const uint8_t* tab;  // rows of its base
+    uint32_t mont;
+};
+__device__ inline MsmTerm msm_term(const MsmJob& J, uint32_t o, uint32_t B, const TabCfg& tc) {
+    const bool first = o < J.seg[0].count;
+    const MsmSeg& s = first ? J.seg[0] : J.seg[1];
+    uint32_t oo = first ? o : o - J.seg[0].count;
+    uint32_t i = s.sidx ? s.sidx[oo] : (oo / s.run) * s.period + s.off + (oo % s.run);
+    uint32_t base = s.base0 + (s.bdense ? oo : i);
+    MsmTerm t;
+    t.scal = s.scal + (size_t)i * B;
+    t.tab = J.tab + (size_t)base * tc.base_bytes();
+    t.mont = s.mont;
+    return t;
+}
+// signed digits of a canonical scalar -> one uint16 per window: bit 15 = negative, low bits = magnitude (slot index).
+// Register-only bit stream (the word index is a compile-time constant in the unrolled outer loop; a run-time word
+// index would send the scalar through scratch memory).  Same digits as tab_digit.
+__device__ inline void msm_recode(const sc& x, uint16_t* dst, const TabCfg& tc) {
+    const uint32_t W = tc.W, mask = (1u << W) - 1u;
+    uint64_t buf = 0;
+    uint32_t bits = 0, k = 0;
+    int carry = 0;
+    auto emit = [&]() {
+        int d = (int)((uint32_t)buf & mask) + carry;
+        carry = (k + 1 < tc.windows) & (d >= (int)tc.entries);
+        d -= carry << W;
+        uint32_t mag = (uint32_t)(d < 0 ? -d : d);
+        dst[(size_t)k * 64] = (uint16_t)(mag | (d < 0 ? 0x8000u : 0u));
+        buf >>= W;
+        k++;
+    };
+#pragma unroll
+    for (int wi = 0; wi < 8; wi++) {
+        buf |= (uint64_t)x.v[wi] << bits;
+        bits += 32;
+        while (bits >= W && k < tc.windows) { emit(); bits -= W; }
+    }
+    while (k < tc.windows) emit();  // the top window holds the remaining (< W) bits
+}
+
+template <int FMT, int WAVES_PER_SIMD>
+__global__ void __launch_bounds__(64, WAVES_PER_SIMD) k_msm_fixed2(const MsmLaunch L) {
+    extern __shared__ uint16_t msm_dig[];  // [2][windows][64]
+    const TabCfg tc = L.tc;
+    const uint32_t lane = threadIdx.x;
+    uint32_t wg = blockIdx.x;
+    if ((L.nwg & 7u) == 0) wg = (wg & 7u) * (L.nwg >> 3) + (wg >> 3);  // XCD-aware: consecutive logical workgroups share an XCD
+    uint32_t j = 0, w0 = 0;
+#pragma unroll
+    for (uint32_t t = 0; t + 1 < MSM_MAX_JOBS; t++)
+        if (t + 1 < L.njobs && wg >= L.wg_end[t]) { j = t + 1; w0 = L.wg_end[t]; }
+    if (wg >= L.wg_end[L.njobs - 1]) return;  // padding up to a multiple of 8
+    j = __builtin_amdgcn_readfirstlane(j);
+    const MsmJob& J = L.job[j];
+    wg -= w0;
+    const uint32_t B = L.B, c = wg / L.nbk;
+    uint32_t b = (wg % L.nbk) * 64u + lane;
+    const bool active = b < B;
+    if (!active) b = B - 1;  // ragged batch: the spare lanes repeat the last proof and do not store
+    const uint32_t total = J.seg[0].count + J.seg[1].count;
+    const uint32_t lo = c * J.chunk, hi = lo + J.chunk < total ? lo + J.chunk : total;
+    const uint32_t dig_buf = tc.windows * 64u;  // digits of term parity p start at msm_dig[p * dig_buf + lane]
+
+    // fetch the next term whose scalars are not all zero (IPA round 0: the l-vector is zero beyond n)
+    auto fetch = [&](uint32_t& o, sc& x, MsmTerm& t) -> bool {
+        for (; o < hi; o++) {
+            t = msm_term(J, o, B, tc);
+            x = t.scal[b];
+            if (__ballot(!sc_is_zero(x)) != 0ull) return true;
+        }
+        return false;
+    };
+    ge acc = ge_identity();
+    uint32_t o = lo, cur = 0;
+    sc x;
+    MsmTerm T;
+    bool have = fetch(o, x, T);
+    if (have) msm_recode(T.mont ? sc_from_mont(x) : x, msm_dig + lane, tc);
+    MsmEntry<FMT> E;
+    uint32_t d = 0;
+    if (have) {
+        d = msm_dig[lane];
+        msm_entry_load(E, T.tab + (size_t)(d & 0x7fffu) * tc.stride);
+    }
+    while (have) {
+        uint32_t o2 = o + 1;
+        sc x2;
+        MsmTerm T2;
+        bool have2 = fetch(o2, x2, T2);
+        if (have2) msm_recode(T2.mont ? sc_from_mont(x2) : x2, msm_dig + (cur ^ 1u) * dig_buf + lane, tc);
+        for (uint32_t k = 0; k < tc.windows; k++) {
+            // ---- layer 1: the three products that read the table entry
+            const int neg = (int)(d >> 15);
+            ge_niels q = msm_entry_unpack(E);
+            fe a = fe_select(q.yplusx, q.yminusx, neg), bq = fe_select(q.yminusx, q.yplusx, neg);
+            fe PP = fe_mul_f(fe_add(acc.Y, acc.X), a);
+            fe MM = fe_mul_f(fe_sub(acc.Y, acc.X), bq);
+            fe Txy2d = fe_mul(acc.T, q.xy2d);
+            // ---- request the next entry: it lands while layer 2 runs
+            __builtin_amdgcn_sched_barrier(0);
+            if (k + 1 < tc.windows) {
+                d = msm_dig[cur * dig_buf + (k + 1) * 64u + lane];
+                msm_entry_load(E, T.tab + ((size_t)(k + 1) * tc.row + (d & 0x7fffu)) * tc.stride);
+            } else if (have2) {
+                d = msm_dig[(cur ^ 1u) * dig_buf + lane];
+                msm_entry_load(E, T2.tab + (size_t)(d & 0x7fffu) * tc.stride);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- layer 2
+            fe cX = fe_sub(PP, MM), cY = fe_add(PP, MM);
+            fe zp = fe_add(acc.Z, Txy2d), zm = fe_sub(acc.Z, Txy2d);  // halved table operands: Z, not 2Z (ge_madd_t)
+            fe cZ = fe_select(zp, zm, neg), cT = fe_select(zm, zp, neg);
+            acc.X = fe_mul_f(cX, cT); acc.Y = fe_mul_f(cY, cZ); acc.Z = fe_mul(cZ, cT); acc.T = fe_mul_f(cX, cY);
+        }
+        o = o2; T = T2; have = have2; cur ^= 1u;
+    }
+    if (active) J.partial[(size_t)c * B + b] = ge_from_table_class(acc);
+}

@@ -193,9 +193,16 @@ int bpr1cs_msm_fixed(const bpr1cs_gens* g, const uint32_t* bases, size_t terms, 
 void bpr1cs_set_unfold_rounds(int r);
 
 /* tuning knob, read by bpr1cs_gens_create: signed window width W (4..12) of the fixed-base tables.
- * A term costs ceil(254/W) mixed additions; table bytes = (2+2*cap) * ceil(254/W) * 2^(W-1) * 96
- * (W=8: 25.8 GB, W=10: 84 GB at capacity 32768).  Default 8. */
+ * A term costs ceil(253/W) mixed additions (the top window of a canonical scalar never carries out); table bytes =
+ * (2+2*cap) * ceil(253/W) * (2^(W-1) + 1) * 96 (packed) or 128 (limb form)  (W=8: 26 / 35 GB, W=11: 148 / 198 GB at
+ * capacity 32768).  Default 8.  Capacity limit: W=11 serves N <= 32768 on a 288 GB device; the reference's as-shipped
+ * tree depths (N = 131072 / 262144, gadget_vsmt_4.rs:25, gadget_vsmt_2.rs:23) need W <= 8. */
 void bpr1cs_set_window_bits(int w);
+
+/* tuning knob, read by bpr1cs_gens_create: storage format of the fixed-base tables.  0 = packed (96 B per entry, unpacked
+ * on load), 1 = limb form in 128-byte slots (no unpacking, one aligned slot per gather; a third more HBM), -1 (default) =
+ * limb form when the device keeps >= 100 GB free after the tables, packed otherwise.  Results do not depend on it. */
+void bpr1cs_set_table_format(int fmt);
 
 /* tuning knob: lanes of a wavefront cooperating on one proof during witness synthesis (4, 8 or 16).
  * Fewer lanes = fewer wavefronts (less interference with a co-running batch), longer LC evaluation. */

@@ -92,3 +92,39 @@ extern "C" void hs_fe_carry_limbs(const int32_t* a, int32_t* out_limbs) {
     fe r = fe_carry(fe_from_limbs(a));
     for (int i = 0; i < 9; i++) out_limbs[i] = r.v[i];
 }
+extern "C" void hs_fe_mul_f_limbs(const int32_t* a, const int32_t* b, uint8_t* o, int32_t* out_limbs) {
+    fe r = fe_mul_f(fe_from_limbs(a), fe_from_limbs(b));
+    for (int i = 0; i < 9; i++) out_limbs[i] = r.v[i];
+    fe_tobytes(r, o);
+}
+// table addition on raw limbs (accumulator in the "table class" of ge.hpp, table operand limbs in [0, 2^29)):
+// in: X Y Z T (4 x 9 limbs), q: y+x, y-x, 2dxy (3 x 9 limbs); out: 4 x 9 limbs + the 4 canonical coordinates
+extern "C" void hs_ge_madd_t_limbs(const int32_t* p, const int32_t* q, int negate, int32_t* out_limbs, uint8_t* out_bytes) {
+    ge a;
+    a.X = fe_from_limbs(p); a.Y = fe_from_limbs(p + 9); a.Z = fe_from_limbs(p + 18); a.T = fe_from_limbs(p + 27);
+    ge_niels n;
+    n.yplusx = fe_from_limbs(q); n.yminusx = fe_from_limbs(q + 9); n.xy2d = fe_from_limbs(q + 18);
+    ge r = ge_madd_t(a, n, negate);
+    const fe* c[4] = {&r.X, &r.Y, &r.Z, &r.T};
+    for (int k = 0; k < 4; k++) {
+        for (int i = 0; i < 9; i++) out_limbs[9 * k + i] = c[k]->v[i];
+        fe_tobytes(*c[k], out_bytes + 32 * k);
+    }
+}
+// sum_k s_k * P_k over a freshly built table (both storage formats, any window width): exercises tab_digit's
+// top-window rule, the identity slot and the table-class accumulator chain.  pts: compressed; scalars canonical.
+#include "kernels.hpp"
+#include <vector>
+extern "C" int hs_table_msm(const uint8_t* pts, const uint8_t* scalars, uint32_t n, uint32_t W, uint32_t fmt, uint32_t stride, uint8_t* out) {
+    TabCfg tc = tab_cfg(W, fmt, stride);
+    std::vector<ge> P(n);
+    for (uint32_t i = 0; i < n; i++)
+        if (!ge_decompress(pts + 32 * i, P[i])) return 0;
+    std::vector<uint8_t> tab((size_t)n * tc.base_bytes());
+    K_build_table kb{P.data(), tab.data(), tc};
+    for (uint32_t g = 0; g < n * tc.windows; g++) kb(g);
+    ge acc = ge_identity();
+    for (uint32_t i = 0; i < n; i++) acc = table_mul_acc_raw(acc, tab.data() + (size_t)i * tc.base_bytes(), sc_load_raw(scalars + 32 * i), tc);
+    ge_compress(ge_from_table_class(acc), out);
+    return 1;
+}

@@ -115,3 +115,89 @@ def test_field_limb_bounds(prim_lib):
         limbs = [(v >> (29 * i)) & (2**29 - 1) for i in range(9)]
         prim_lib.hs_fe_canon_limbs(I9(*limbs), out)
         assert int.from_bytes(bytes(out), "little") == v % P
+
+
+def test_table_class_limb_bounds(prim_lib):
+    """ge_madd_t (csrc/ge.hpp): the table-addition chain keeps X, Y, T as floor-carry products (limbs in [-2^24, F'),
+    F' = 2^29 + 2^24) and Z centred; worst-case limb patterns of that class must multiply exactly and return
+    limbs of the same class, for both signs of the digit."""
+    import ctypes, random
+    P = 2**255 - 19
+    N = 2**28 + 2**23
+    FP = 2**29 + 2**24
+    I9, I27, I36 = ctypes.c_int32 * 9, ctypes.c_int32 * 27, ctypes.c_int32 * 36
+    rnd = random.Random(31)
+
+    def val(l):
+        return sum(int(x) << (29 * i) for i, x in enumerate(l)) % P
+
+    def floor_pat():
+        yield [FP - 1] * 9
+        yield [-2**24] * 9
+        yield [FP - 1 if i % 2 else -2**24 for i in range(9)]
+        for _ in range(6):
+            yield [rnd.choice((FP - 1, -2**24, 0, rnd.randint(0, 2**29 - 1))) for _ in range(9)]
+
+    def cent_pat():
+        yield [N] * 9
+        yield [-N] * 9
+        yield [N if i % 2 else -N for i in range(9)]
+        for _ in range(4):
+            yield [rnd.choice((N, -N, rnd.randint(-N, N))) for _ in range(9)]
+
+    def tab_pat():
+        yield [2**29 - 1] * 9
+        yield [0] * 9
+        for _ in range(3):
+            yield [rnd.choice((2**29 - 1, 0, rnd.randint(0, 2**29 - 1))) for _ in range(9)]
+
+    out, ol = (ctypes.c_uint8 * 32)(), I9()
+    # the floor-carry multiplier alone, on the largest operand classes ge_madd_t feeds it
+    for a in floor_pat():
+        for b in floor_pat():
+            a2 = [2 * x for x in a]                      # cY <= 2F'
+            b3 = [min(3 * N, max(-3 * N, 3 * x)) for x in b]  # |cZ| <= 2N in ge_madd_t; 3N leaves margin
+            prim_lib.hs_fe_mul_f_limbs(I9(*a2), I9(*b3), out, ol)
+            assert int.from_bytes(bytes(out), "little") == val(a2) * val(b3) % P
+            assert min(ol) >= -2**24 and max(ol) < FP
+    o36, ob = I36(), (ctypes.c_uint8 * 128)()
+    for X in floor_pat():
+        for Y in list(floor_pat())[:4]:
+            for Z in list(cent_pat())[:4]:
+                for T in list(floor_pat())[:3]:
+                    for q in tab_pat():
+                        qq = list(q) + list(reversed(q)) + [q[(i * 5) % 9] for i in range(9)]
+                        for neg in (0, 1):
+                            prim_lib.hs_ge_madd_t_limbs(I36(*(X + Y + Z + T)), I27(*qq), neg, o36, ob)
+                            x, y, z, t = val(X), val(Y), val(Z), val(T)
+                            ypx, ymx, xy2d = val(qq[:9]), val(qq[9:18]), val(qq[18:])
+                            if neg:
+                                ypx, ymx, xy2d = ymx, ypx, -xy2d
+                            A, B, C, D = (y + x) * ypx, (y - x) * ymx, t * xy2d, z   # halved table form: Z, not 2Z
+                            cX, cY, cZ, cT = A - B, A + B, D + C, D - C
+                            want = [cX * cT % P, cY * cZ % P, cZ * cT % P, cX * cY % P]
+                            got = [int.from_bytes(bytes(ob)[32 * k:32 * k + 32], "little") for k in range(4)]
+                            assert got == want
+                            lim = list(o36)
+                            for k in (0, 1, 3):
+                                assert min(lim[9 * k:9 * k + 9]) >= -2**24 and max(lim[9 * k:9 * k + 9]) < FP
+                            assert max(abs(v) for v in lim[18:27]) <= N
+
+
+def test_table_msm_formats_and_windows(prim_lib):
+    """Fixed-base tables in both storage formats and several window widths (W = 11: 23 windows, the top window keeps
+    its digit) against the oracle's big-integer MSM, with edge scalars (0, 1, l-1, 2^252, 2^252 - 1, all-ones windows)."""
+    import ctypes, random
+    from pyref.ed import Point
+    rnd = random.Random(37)
+    pts = [from_uniform_bytes(bytes(rnd.getrandbits(8) for _ in range(64))) for _ in range(6)]
+    edge = [0, 1, L - 1, 2**252, 2**252 - 1, L - 2**121, int("1" * 252, 2), (2**252 // 3)]
+    sets = [edge[i:i + 6] for i in (0, 2)] + [[rnd.randrange(L) for _ in range(6)] for _ in range(2)]
+    out = ctypes.create_string_buffer(32)
+    for W, fmt, stride in ((11, 0, 96), (11, 1, 108), (11, 1, 128), (8, 1, 108), (5, 0, 96), (4, 1, 108), (12, 0, 96), (10, 1, 108)):
+        for ss in sets:
+            ok = prim_lib.hs_table_msm(b"".join(p.compress() for p in pts), b"".join(sc_to_bytes(s) for s in ss), 6, W, fmt, stride, out)
+            want = Point.identity()
+            for p, s in zip(pts, ss):
+                want = want + p * s
+            assert ok and out.raw == want.compress(), (W, fmt, stride)

@@ -1,0 +1,148 @@
+// Stand-alone timing + cross-check harness for the batched fixed-base MSM kernel (csrc/msm_hip.hpp) on REAL tables.
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -I../bulletproofs-r1cs-gadgets_amd/csrc msm_ubench.hip -o msm_ubench
+// Run:   ./msm_ubench [cap=32768] [B=1024] [W=11] [reps=3]
+// For every table format: build the tables of 2*cap generators, run one IPA-round-shaped MSM (cap terms per proof: the
+// "hi" halves of G and the "lo" halves of H) with (a) the one-thread-per-(chunk,proof) functor the simulator runs,
+// (b) k_msm_fixed2 as one job, (c) k_msm_fixed2 with the L and R sums of a round merged into one launch.  All
+// variants must produce the same compressed points.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <vector>
+#include <string.h>
+#include "dev.hpp"
+#include "msm_hip.hpp"
+
+static uint64_t rng_state = 0x9e3779b97f4a7c15ull;
+static uint64_t rnd64() { rng_state ^= rng_state << 13; rng_state ^= rng_state >> 7; rng_state ^= rng_state << 17; return rng_state; }
+
+static float time_ms(hipEvent_t e0, hipEvent_t e1) { float ms = 0; HIPCHK(hipEventElapsedTime(&ms, e0, e1)); return ms; }
+
+int main(int argc, char** argv) {
+    uint32_t cap = argc > 1 ? atoi(argv[1]) : 32768, B = argc > 2 ? atoi(argv[2]) : 1024, W = argc > 3 ? atoi(argv[3]) : 11;
+    int reps = argc > 4 ? atoi(argv[4]) : 3;
+    uint32_t target_threads = argc > 5 ? atoi(argv[5]) : (1u << 21);
+    hipStream_t st;
+    HIPCHK(hipStreamCreate(&st));
+    size_t mfree = 0, mtotal = 0;
+    HIPCHK(hipMemGetInfo(&mfree, &mtotal));
+    printf("device memory: %.1f GB free of %.1f GB\n", mfree / 1e9, mtotal / 1e9);
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+    const uint32_t nb = 2 * cap;
+    // generators from random uniform bytes
+    std::vector<uint8_t> uni((size_t)nb * 64);
+    for (auto& x : uni) x = (uint8_t)rnd64();
+    DevBuf<uint8_t> d_uni(uni.size()), d_comp((size_t)nb * 32);
+    DevBuf<ge> pts(nb);
+    dev_h2d(d_uni.p, uni.data(), uni.size(), st);
+    launch(nb, K_gen_points{d_uni.p, pts.p, d_comp.p}, st);
+    // scalars: [cap][B] for G and H each, canonical (< 2^252), a few edge values
+    std::vector<sc> hs((size_t)2 * cap * B);
+    const int pattern = argc > 7 ? atoi(argv[7]) : 0;  // 1: every window digit = 1 for every proof (all lanes of a wave gather the SAME entry: no HBM gather traffic)
+    for (auto& s : hs) { for (int i = 0; i < 8; i++) s.v[i] = (uint32_t)rnd64(); s.v[7] &= 0x0fffffffu; }
+    if (pattern == 1) {
+        sc one = sc_zero();
+        for (uint32_t k = 0; k * W < 253; k++) one.v[(k * W) >> 5] |= 1u << ((k * W) & 31);
+        for (auto& s : hs) s = one;
+    }
+    for (uint32_t bb = 0; bb < B; bb++) { memset(&hs[(size_t)5 * B + bb], 0, sizeof(sc)); }
+    hs[0] = sc_zero(); hs[1] = sc_zero(); hs[1].v[0] = 1;
+    for (int i = 0; i < 8; i++) hs[2].v[i] = SC_L[i];
+    hs[2].v[0] -= 1;
+    DevBuf<sc> d_s(hs.size());
+    dev_h2d(d_s.p, hs.data(), hs.size() * sizeof(sc), st);
+    const sc* sG = d_s.p;
+    const sc* sH = d_s.p + (size_t)cap * B;
+    const uint32_t half = cap / 2;
+    // L-shaped and R-shaped sums of IPA round 0 (Nk = cap, mk = cap/2)
+    MsmSeg gL{sG, half, half, cap, half, 0, 0}, hL{sH, half, half, cap, 0, cap, 0};
+    MsmSeg gR{sG, half, half, cap, 0, 0, 0}, hR{sH, half, half, cap, half, cap, 0};
+    struct Fmt { uint32_t fmt, stride; const char* name; } all_fmts[] = {{TAB_FMT_PACKED, 96, "packed-96"}, {TAB_FMT_LIMB, 108, "limb-108"}, {TAB_FMT_LIMB, 112, "limb-112"}, {TAB_FMT_LIMB, 128, "limb-128"}};
+    int only = argc > 6 ? atoi(argv[6]) : -1;  // index of the only format to run (-1: all)
+    std::vector<Fmt> fmts;
+    for (int i = 0; i < 4; i++) if (only < 0 || only == i) fmts.push_back(all_fmts[i]);
+    std::vector<uint8_t> ref;
+    const uint32_t nbk = (B + 63) / 64;
+    for (auto& f : fmts) {
+        TabCfg tc = tab_cfg(W, f.fmt, f.stride);
+        size_t bytes = (size_t)nb * tc.base_bytes();
+        printf("== %s: W=%u windows=%u row=%u  table %.1f GB\n", f.name, W, tc.windows, tc.row, bytes / 1e9);
+        fflush(stdout);
+        uint8_t* tab = nullptr;
+        if (hipMalloc(&tab, bytes) != hipSuccess) { printf("   (does not fit)\n"); continue; }
+        HIPCHK(hipEventRecord(e0, st));
+        launch((uint64_t)nb * tc.windows, K_build_table{pts.p, tab, tc}, st);
+        HIPCHK(hipEventRecord(e1, st));
+        HIPCHK(hipStreamSynchronize(st));
+        printf("   K_build_table %.1f ms\n", time_ms(e0, e1));
+        uint32_t chunk = (cap + (target_threads / B) - 1) / (target_threads / B);
+        if (chunk == 0) chunk = 1;
+        uint32_t nchunks = (cap + chunk - 1) / chunk;
+        DevBuf<ge> partL((size_t)nchunks * B), partR((size_t)nchunks * B);
+        DevBuf<uint8_t> outL((size_t)B * 32), outR((size_t)B * 32);
+        std::vector<uint8_t> hL_((size_t)B * 32), hR_((size_t)B * 32);
+        auto finish = [&](const char* what) {
+            launch(B, K_msm_finish{tab, tc, partL.p, nullptr, nullptr, outL.p, B, nchunks, 0}, st);
+            launch(B, K_msm_finish{tab, tc, partR.p, nullptr, nullptr, outR.p, B, nchunks, 0}, st);
+            dev_d2h(hL_.data(), outL.p, hL_.size(), st);
+            dev_d2h(hR_.data(), outR.p, hR_.size(), st);
+            std::vector<uint8_t> all(hL_);
+            all.insert(all.end(), hR_.begin(), hR_.end());
+            if (ref.empty()) ref = all;
+            printf("   %-28s results %s\n", what, all == ref ? "== reference" : "DIFFER");
+            fflush(stdout);
+        };
+        // (a) functor, L then R
+        for (int r = 0; r < reps; r++) {
+            HIPCHK(hipEventRecord(e0, st));
+            launch_wave((uint64_t)nchunks * nbk * 64, K_msm_fixed{tab, tc, {gL, hL}, partL.p, B, chunk, nbk, nchunks * nbk}, st);
+            launch_wave((uint64_t)nchunks * nbk * 64, K_msm_fixed{tab, tc, {gR, hR}, partR.p, B, chunk, nbk, nchunks * nbk}, st);
+            HIPCHK(hipEventRecord(e1, st));
+            HIPCHK(hipStreamSynchronize(st));
+            printf("   functor (no prefetch)   L+R  %8.3f ms  = %.3f ms per %u-term MSM, %.2f G madd/s\n", time_ms(e0, e1), time_ms(e0, e1) / 2, cap,
+                   2.0 * cap * B * tc.windows / time_ms(e0, e1) / 1e6);
+        }
+        finish("functor");
+        // (b)/(c) k_msm_fixed2
+        auto run2 = [&](bool merged, int occ) {
+            MsmLaunch L{};
+            L.B = B; L.nbk = nbk; L.tc = tc;
+            L.job[0] = MsmJob{{gL, hL}, tab, partL.p, chunk, nchunks};
+            L.job[1] = MsmJob{{gR, hR}, tab, partR.p, chunk, nchunks};
+            size_t lds = (size_t)2 * tc.windows * 64 * sizeof(uint16_t);
+            auto go = [&](MsmLaunch LL) {
+                uint32_t wgs = LL.wg_end[LL.njobs - 1];
+                LL.nwg = (wgs + 7u) & ~7u;
+                if (f.fmt == TAB_FMT_PACKED && occ == 4) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_msm_fixed2<(int)TAB_FMT_PACKED, 4>), dim3(LL.nwg), dim3(64), lds, st, LL);
+                else if (f.fmt == TAB_FMT_PACKED) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_msm_fixed2<(int)TAB_FMT_PACKED, 3>), dim3(LL.nwg), dim3(64), lds, st, LL);
+                else if (occ == 4) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_msm_fixed2<(int)TAB_FMT_LIMB, 4>), dim3(LL.nwg), dim3(64), lds, st, LL);
+                else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_msm_fixed2<(int)TAB_FMT_LIMB, 3>), dim3(LL.nwg), dim3(64), lds, st, LL);
+                HIPCHK(hipGetLastError());
+            };
+            HIPCHK(hipEventRecord(e0, st));
+            if (merged) {
+                L.njobs = 2; L.wg_end[0] = nchunks * nbk; L.wg_end[1] = 2 * nchunks * nbk;
+                go(L);
+            } else {
+                MsmLaunch A = L; A.njobs = 1; A.wg_end[0] = nchunks * nbk;
+                go(A);
+                MsmLaunch Bq = L; Bq.job[0] = L.job[1]; Bq.njobs = 1; Bq.wg_end[0] = nchunks * nbk;
+                go(Bq);
+            }
+            HIPCHK(hipEventRecord(e1, st));
+            HIPCHK(hipStreamSynchronize(st));
+            printf("   k_msm_fixed2 occ%d %-10s L+R  %8.3f ms  = %.3f ms per %u-term MSM, %.2f G madd/s\n", occ, merged ? "(merged)" : "(2 launches)", time_ms(e0, e1),
+                   time_ms(e0, e1) / 2, cap, 2.0 * cap * B * tc.windows / time_ms(e0, e1) / 1e6);
+        };
+        for (int occ = 3; occ <= 4; occ++) {
+            for (int r = 0; r < reps; r++) run2(false, occ);
+            finish("k_msm_fixed2 (2 launches)");
+            for (int r = 0; r < reps; r++) run2(true, occ);
+            finish("k_msm_fixed2 (merged)");
+        }
+        HIPCHK(hipFree(tab));
+    }
+    return 0;
+}

@@ -102,6 +102,14 @@ __global__ void __launch_bounds__(256) k_prim(uint32_t* out, const uint32_t* in,
     if (OP == 1) { for (int i = 0; i < iters; i++) a = fe_add(a, b); }
     if (OP == 2) { for (int i = 0; i < iters; i++) a = fe_sub(a, b); }
     if (OP == 7) { for (int i = 0; i < iters; i++) a = fe_sq(a); }
+    if (OP == 9) { for (int i = 0; i < iters; i++) a = fe_mul_f(a, b); }
+    if (OP == 10) {
+        ge p = ge_basepoint();
+        p.X = fe_add(p.X, a);
+        ge_niels n; n.yplusx = a; n.yminusx = b; n.xy2d = fe_carry(fe_add(a, b));
+        for (int i = 0; i < iters; i++) p = ge_madd_t(p, n, i & 1);
+        a = fe_add(fe_add(p.X, p.Y), fe_add(p.Z, p.T));
+    }
     if (OP == 8) { sc x, y; for (int i = 0; i < 8; i++) { x.v[i] = (uint32_t)a.v[i]; y.v[i] = (uint32_t)b.v[i]; } x.v[7] &= 0x0fffffff;
         for (int i = 0; i < iters; i++) { x = sc_invert(x); x.v[0] ^= 1; }
         for (int i = 0; i < 8; i++) a.v[i] = (int32_t)x.v[i]; }
@@ -177,11 +185,13 @@ int main() {
     CHK(hipEventElapsedTime(&ms, e0, e1)); double n = (double)blocks * threads * (ITER / 4) * 16; \
     printf("%-36s %8.3f ms  (%.2f cyc/wave-inst/SIMD @2.4GHz)\n", cn[M], ms, 1024.0 * 2.4e9 * 64 / (n / (ms * 1e-3))); }
     RUN_CHAIN(0) RUN_CHAIN(1) RUN_CHAIN(2)
-    const char* pn[] = {"fe_mul", "fe_add", "fe_sub", "sc_mul", "ge_madd", "ge_dbl", "ge_add", "fe_sq", "sc_invert"};
+    const char* pn[] = {"fe_mul", "fe_add", "fe_sub", "sc_mul", "ge_madd", "ge_dbl", "ge_add", "fe_sq", "sc_invert", "fe_mul_f", "ge_madd_t"};
 #define RUN_PRIM(OP, IT) { hipLaunchKernelGGL(k_prim<OP>, dim3(blocks), dim3(threads), 0, 0, out, in, 8); CHK(hipDeviceSynchronize()); \
     CHK(hipEventRecord(e0)); hipLaunchKernelGGL(k_prim<OP>, dim3(blocks), dim3(threads), 0, 0, out, in, IT); CHK(hipEventRecord(e1)); CHK(hipEventSynchronize(e1)); \
     CHK(hipEventElapsedTime(&ms, e0, e1)); double n = (double)blocks * threads * IT; \
     printf("%-18s %8.3f ms  %8.2f Gop/s  (%.0f cyc/wave-op/SIMD @2.4GHz)\n", pn[OP], ms, n / ms / 1e6, 1024.0 * 2.4e9 * 64 / (n / (ms * 1e-3))); }
-    RUN_PRIM(0, 2048) RUN_PRIM(1, 2048) RUN_PRIM(2, 2048) RUN_PRIM(3, 2048) RUN_PRIM(4, 256) RUN_PRIM(5, 256) RUN_PRIM(6, 256) RUN_PRIM(7, 2048) RUN_PRIM(8, 16)
+    RUN_PRIM(0, 2048) RUN_PRIM(1, 2048) RUN_PRIM(2, 2048) RUN_PRIM(3, 2048) RUN_PRIM(4, 256) RUN_PRIM(5, 256) RUN_PRIM(6, 256) RUN_PRIM(7, 2048) RUN_PRIM(8, 16) RUN_PRIM(9, 2048) RUN_PRIM(10, 256)
+    // the same primitives under sustained load (DVFS: the chip clocks to its power budget)
+    RUN_PRIM(0, 65536) RUN_PRIM(10, 16384)
     return 0;
 }
