@@ -533,6 +533,73 @@ static void bound_check_gadget(prover* p, u64 a, u64 b, u64 max, u64 min, u32 bi
     positive_no_gadget(p, A, a, bits); positive_no_gadget(p, Bv, b, bits);
 }
 
+static void lc_append(lc* dst, const lc* src) { for (u32 i = 0; i < src->n; i++) lc_push(dst, src->t[i].var, src->t[i].c); }
+/* vanilla_merkle_merkle_tree_verif_gadget (gadget_vsmt_2.rs:171-209) with Poseidon_hash_2_constraints
+   (gadget_poseidon.rs:445-468: inputs [statics[0], xl, xr, statics[1], statics[2], statics[3]]).
+   committed layout: 0 leaf, 1..d index bits (LSB first), d+1..2d proof nodes (leaf level first), then 4 statics */
+static void vsmt2_gadget(prover* p, u32 depth, sc root, const poseidon_params* pp) {
+    lc prev = lc_new();
+    u32 sb = 1 + 2 * depth;
+    sc one = SC_R;
+    for (u32 i = 0; i < depth; i++) {
+        lc leaf = i == 0 ? lc_var(VAR(VK_COMMITTED, 0)) : prev;
+        u32 bit = VAR(VK_COMMITTED, 1 + i), node = VAR(VK_COMMITTED, 1 + depth + i);
+        lc om = lc_new(); lc_push(&om, VAR(VK_ONE, 0), one); lc_push(&om, bit, sc_neg(one));  /* Variable::One() - leaf_side */
+        u32 l1 = pr_multiply(p, lc_clone(&om), lc_clone(&leaf));
+        u32 l2 = pr_multiply(p, lc_var(bit), lc_var(node));
+        u32 r1 = pr_multiply(p, lc_var(bit), leaf);
+        u32 r2 = pr_multiply(p, om, lc_var(node));
+        lc st[6];
+        st[0] = lc_var(VAR(VK_COMMITTED, sb));
+        st[1] = lc_var(VAR(VK_OUT, l1)); lc_push(&st[1], VAR(VK_OUT, l2), one);
+        st[2] = lc_var(VAR(VK_OUT, r1)); lc_push(&st[2], VAR(VK_OUT, r2), one);
+        st[3] = lc_var(VAR(VK_COMMITTED, sb + 1)); st[4] = lc_var(VAR(VK_COMMITTED, sb + 2)); st[5] = lc_var(VAR(VK_COMMITTED, sb + 3));
+        poseidon_perm_constraints(p, st, pp, 1);
+        prev = st[1];
+        for (int k = 0; k < 6; k++) if (k != 1) lc_free(&st[k]);
+    }
+    constrain_lc_with_scalar(p, prev, root);
+}
+/* mimc_hash_2 + mimc_gadget (gadget_mimc.rs:41-79); committed 0 = left, 1 = right (at `c0`, `c0 + 1`) */
+static void mimc_gadget(prover* p, u32 c0, u32 rounds, const sc* consts, sc image) {
+    lc left = lc_var(VAR(VK_COMMITTED, c0)), right = lc_var(VAR(VK_COMMITTED, c0 + 1));
+    for (u32 j = 0; j < rounds; j++) {
+        lc lpc = lc_clone(&left); lc_push(&lpc, VAR(VK_ONE, 0), consts[j]);
+        u32 m1 = pr_multiply(p, lc_clone(&lpc), lpc);                                  /* (l, _, l_sqr) */
+        u32 m2 = pr_multiply(p, lc_var(VAR(VK_OUT, m1)), lc_var(VAR(VK_LEFT, m1)));    /* l_cube */
+        lc tmp = lc_var(VAR(VK_OUT, m2)); lc_append(&tmp, &right);
+        lc_free(&right);
+        right = left; left = tmp;
+    }
+    lc_free(&right);
+    constrain_lc_with_scalar(p, left, image);
+}
+/* set_membership (gadget_set_membership.rs:16-86, test :93-134): committed c0..c0+k-1 the bitmap, c0+k the value */
+static void set_membership_gadget(prover* p, u32 c0, u32 k, const u64* items) {
+    sc one = SC_R, m1 = sc_neg(SC_R);
+    for (u32 i = 0; i < k; i++) {  /* bit_gadget */
+        u64 bit = !sc_is_zero(p->v[c0 + i]);
+        u32 m = pr_alloc_mul(p, sc_from_u64(1 - bit), sc_from_u64(bit));
+        lc c = lc_var(VAR(VK_RIGHT, m)); lc_push(&c, VAR(VK_COMMITTED, c0 + i), m1); pr_constrain(p, c);
+        pr_constrain(p, lc_var(VAR(VK_OUT, m)));
+        lc d = lc_var(VAR(VK_LEFT, m)); lc_push(&d, VAR(VK_RIGHT, m), one); lc_push(&d, VAR(VK_ONE, 0), m1); pr_constrain(p, d);
+    }
+    lc sum = lc_new(); lc_push(&sum, VAR(VK_ONE, 0), m1);  /* vector_sum_gadget, sum = 1 */
+    for (u32 i = 0; i < k; i++) lc_push(&sum, VAR(VK_COMMITTED, c0 + i), one);
+    pr_constrain(p, sum);
+    u32 value = VAR(VK_COMMITTED, c0 + k);  /* vector_product_gadget */
+    lc tot = lc_new(); lc_push(&tot, value, m1);
+    for (u32 i = 0; i < k; i++) {
+        u64 bit = !sc_is_zero(p->v[c0 + i]);
+        u32 m = pr_alloc_mul(p, sc_from_u64(bit), sc_from_u64(items[i]));
+        constrain_lc_with_scalar(p, lc_var(VAR(VK_RIGHT, m)), sc_from_u64(items[i]));
+        u32 m2 = pr_multiply(p, lc_var(VAR(VK_LEFT, m)), lc_var(value));
+        lc c = lc_var(VAR(VK_OUT, m)); lc_push(&c, VAR(VK_OUT, m2), m1); pr_constrain(p, c);
+        lc_push(&tot, VAR(VK_OUT, m), one);
+    }
+    pr_constrain(p, tot);
+}
+
 /* ============================================================ Prover::prove */
 static sc ip(const sc* a, const sc* b, u32 n) { sc acc = SC_ZERO; for (u32 i = 0; i < n; i++) acc = sc_add(acc, sc_mul(a[i], b[i])); return acc; }
 static size_t prove_core(prover* p, const u8* label, u32 label_len, const u8* seed, u8* out, u8* comm_out) {
@@ -663,19 +730,42 @@ static void load_params(poseidon_params* pp, const u8* blob, u32 partial_rounds)
 /* gadget: 0 = vsmt_4 (ip0 = levels, ip1 = partial rounds, sp = root)
            1 = poseidon_hash_2, 2 = poseidon_hash_4 (ip0 = sbox 0 cube/1 inverse, ip1 = partial rounds, sp = output)
            3 = bound_check (ip0 = bits, min = ip1|ip2<<32, max = ip3|ip4<<32)
+           4 = vsmt_2 (ip0 = depth, ip1 = partial rounds, sp = root)
+           5 = mimc (ip0 = rounds, sp = image; aux blob = the round constants, rounds * 32 bytes)
+           6 = set_membership (ip0 = k, then k items as lo,hi words)
+           7 = mimc preimage + set_membership on one prover (ip0 = rounds, ip1 = k, items; sp = image; aux blob = constants)
+   `poseidon_blob` is the auxiliary table of the gadget: parsed Poseidon constants (0,1,2,4) or MiMC constants (5,7).
    returns proof length; stats[0..2] = n, q, m */
 size_t oracle_prove(int gadget, const u32* ip, const u8* sp, const u8* poseidon_blob, const u8* label, u32 label_len,
                     const u8* values, const u8* blindings, u32 m, const u8* seed, u8* proof_out, u8* comm_out, u32* stats,
                     u8* wires_out /* optional: n_max*3*32, a_L|a_R|a_O */, u32 wires_cap) {
     prover* p = pr_new(values, blindings, m);
     poseidon_params pp;
-    if (gadget <= 2) load_params(&pp, poseidon_blob, ip[1]);
+    if (gadget <= 2 || gadget == 4) load_params(&pp, poseidon_blob, ip[1]);
     if (gadget == 0) vsmt4_gadget(p, ip[0], sc_from_bytes(sp), &pp);
     else if (gadget == 1) poseidon_hash_gadget(p, 2, (int)ip[0], sc_from_bytes(sp), &pp);
     else if (gadget == 2) poseidon_hash_gadget(p, 4, (int)ip[0], sc_from_bytes(sp), &pp);
     else if (gadget == 3) {
         u8 ab[32], bb[32]; sc_tobytes(p->v[1], ab); sc_tobytes(p->v[2], bb); u64 a, b; memcpy(&a, ab, 8); memcpy(&b, bb, 8);
         bound_check_gadget(p, a, b, (u64)ip[3] | ((u64)ip[4] << 32), (u64)ip[1] | ((u64)ip[2] << 32), ip[0]);
+    } else if (gadget == 4) vsmt2_gadget(p, ip[0], sc_from_bytes(sp), &pp);
+    else if (gadget == 5 || gadget == 7) {
+        u32 rounds = ip[0];
+        sc* consts = malloc(32 * (size_t)(rounds ? rounds : 1));
+        for (u32 j = 0; j < rounds; j++) consts[j] = sc_from_bytes(poseidon_blob + 32 * (size_t)j);
+        mimc_gadget(p, 0, rounds, consts, sc_from_bytes(sp));
+        free(consts);
+        if (gadget == 7) {
+            u32 k = ip[1]; u64* items = malloc(8 * (size_t)(k ? k : 1));
+            for (u32 i = 0; i < k; i++) items[i] = (u64)ip[2 + 2 * i] | ((u64)ip[3 + 2 * i] << 32);
+            set_membership_gadget(p, 2, k, items);
+            free(items);
+        }
+    } else if (gadget == 6) {
+        u32 k = ip[0]; u64* items = malloc(8 * (size_t)(k ? k : 1));
+        for (u32 i = 0; i < k; i++) items[i] = (u64)ip[1 + 2 * i] | ((u64)ip[2 + 2 * i] << 32);
+        set_membership_gadget(p, 0, k, items);
+        free(items);
     }
     if (stats) { stats[0] = p->n; stats[1] = p->q; stats[2] = p->m; }
     if (wires_out && wires_cap >= p->n)

@@ -6,7 +6,9 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB = os.path.join(_HERE, "_build", "libbpr1cs_oracle.so")
 BLOB = os.path.join(_HERE, "..", "tests", "golden", "poseidon_params_ristretto.bin")
-VSMT_4, POSEIDON_HASH_2, POSEIDON_HASH_4, BOUND_CHECK = 0, 1, 2, 3
+VSMT_4, POSEIDON_HASH_2, POSEIDON_HASH_4, BOUND_CHECK, VSMT_2, MIMC, SET_MEMBERSHIP, MIMC_SET_MEMBERSHIP = range(8)
+GADGET_IDS = {"vsmt_4": VSMT_4, "poseidon_hash_2": POSEIDON_HASH_2, "poseidon_hash_4": POSEIDON_HASH_4, "bound_check": BOUND_CHECK,
+              "vsmt_2": VSMT_2, "mimc": MIMC, "set_membership": SET_MEMBERSHIP, "mimc_set_membership": MIMC_SET_MEMBERSHIP}
 
 
 def _sc(x):
@@ -27,9 +29,11 @@ class COracle:
         self.lib.oracle_warm_gens.argtypes = [u32]
         self.blob = open(BLOB, "rb").read()
 
-    def prove(self, gadget, ip, sp, label, values, blindings, seed, want_wires=False, prove=True):
-        """-> dict(proof, comms, n, q, m[, wires])."""
+    def prove(self, gadget, ip, sp, label, values, blindings, seed, want_wires=False, prove=True, aux=None):
+        """-> dict(proof, comms, n, q, m[, wires]).  `aux`: the gadget's auxiliary table when it is not the Poseidon
+        constants (MiMC round constants, rounds * 32 bytes)."""
         m = len(values) // 32
+        blob = self.blob if aux is None else aux
         ipa = (ctypes.c_uint32 * max(1, len(ip)))(*ip)
         proof = ctypes.create_string_buffer(1 + 32 * (13 + 64)) if prove else None
         comms = ctypes.create_string_buffer(32 * max(1, m))
@@ -37,10 +41,10 @@ class COracle:
         wires, cap = None, 0
         if want_wires:
             st = (ctypes.c_uint32 * 3)()
-            self.lib.oracle_prove(gadget, ipa, _sc(sp), self.blob, label, len(label), values, blindings, m, seed, None, None, st, None, 0)
+            self.lib.oracle_prove(gadget, ipa, _sc(sp), blob, label, len(label), values, blindings, m, seed, None, None, st, None, 0)
             cap = st[0]
             wires = ctypes.create_string_buffer(96 * cap)
-        n = self.lib.oracle_prove(gadget, ipa, _sc(sp), self.blob, label, len(label), values, blindings, m, seed, proof, comms, stats, wires, cap)
+        n = self.lib.oracle_prove(gadget, ipa, _sc(sp), blob, label, len(label), values, blindings, m, seed, proof, comms, stats, wires, cap)
         out = dict(proof=proof.raw[:n] if prove else None, comms=[comms.raw[32 * i:32 * i + 32] for i in range(m)],
                    n=stats[0], q=stats[1], m=stats[2])
         if want_wires:
@@ -56,6 +60,16 @@ class COracle:
     def prove_vsmt4(self, circ, values, blindings, seed):
         levels, pr, root = circ
         return self.prove(VSMT_4, [levels, pr], root, b"VSMT", values, blindings, seed)["proof"]
+
+    def prove_case(self, gname, ip, sp, label, values, blindings, seed, **kw):
+        """Front-end style call (gadget name, iparams, sparams as in include/bpr1cs_gadgets.h): MiMC gadgets carry their
+        round constants as the leading sparams and the image as the last one."""
+        gid = GADGET_IDS[gname]
+        if gid in (MIMC, MIMC_SET_MEMBERSHIP):
+            rounds = ip[0]
+            aux = b"".join(_sc(x) for x in sp[:rounds])
+            return self.prove(gid, ip, sp[rounds], label, values, blindings, seed, aux=aux, **kw)
+        return self.prove(gid, ip, sp[0] if sp else bytes(32), label, values, blindings, seed, **kw)
 
     def gen_point(self, which, i, cap):
         out = ctypes.create_string_buffer(32)

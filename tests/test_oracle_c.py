@@ -16,7 +16,8 @@ def corc():
     return COracle()
 
 
-CASES = {"bound_check_64": 3, "poseidon_hash_2_cube": 1, "poseidon_hash_2_inverse": 1, "poseidon_hash_4_inverse": 2, "vsmt_4_l4": 0}
+CASES = {"bound_check_64": 3, "poseidon_hash_2_cube": 1, "poseidon_hash_2_inverse": 1, "poseidon_hash_4_inverse": 2, "vsmt_4_l4": 0,
+         "vsmt_2_d3": 4, "set_membership": 6}
 
 
 @pytest.mark.parametrize("name", list(CASES))
@@ -35,3 +36,24 @@ def test_c_oracle_matches_golden(corc, name):
         assert r["proof"].hex() == gd["proofs"][j]
         gc = gd["commitments"][j]
         assert [c.hex() for c in r["comms"]][:len(gc)] == gc
+
+
+@pytest.mark.parametrize("name", ["mimc", "mimc_set_membership", "mimc_set_membership_r8", "set_membership", "vsmt_2_d3"])
+def test_c_oracle_matches_pyref_on_the_front_end_cases(corc, name):
+    """gadget_vsmt_2.rs:171-209, gadget_mimc.rs:41-79, gadget_set_membership.rs:16-86 (and the C5 composition) restated in
+    C: wires, commitments and proof bytes equal the Python oracle's on the seeded scenarios of tests/frontend_cases.py."""
+    import common
+    import frontend_cases as fc
+    gname, ip, sp, _, cap = fc.case(name, 0)
+    ob = common.oracle_batch(lambda j: fc.case(name, j)[3], cap, 2)
+    m = ob["m"]
+    for j in range(2):
+        gname, ip, sp, _, cap = fc.case(name, j)   # per-proof public scalars (images) differ
+        r = corc.prove_case(gname, ip, sp, ob["label"], ob["values"][j * m * 32:(j + 1) * m * 32], ob["blindings"][j * m * 32:(j + 1) * m * 32],
+                            ob["seeds"][32 * j:32 * j + 32], want_wires=True)
+        assert (r["n"], r["q"], r["m"]) == (ob["n"], ob["q"], ob["m"])
+        n = ob["n"]
+        assert r["wires"][:96 * n] == ob["wires"][j * 96 * n:(j + 1) * 96 * n]
+        oc = ob["comms"][j]   # (statics committed inside the scenario are not in its returned list)
+        assert r["comms"][:len(oc)] == oc
+        assert r["proof"] == ob["proofs"][j]
