@@ -6,6 +6,9 @@
 #include <map>
 #include <algorithm>
 #include <string>
+#include <atomic>
+#include <mutex>
+#include <new>
 #include "../../include/bpr1cs.h"
 #include "dev.hpp"
 #include "kernels.hpp"
@@ -35,16 +38,66 @@ static void host_sponge(uint32_t rate, uint8_t suffix, const uint8_t* in, size_t
     }
 }
 
-static int g_unfold_rounds = 4;
-static int g_window_bits = 8;
-static int g_table_format = -1;   // -1 auto, 0 packed (96 B per entry), 1 limb form in 128-B slots (see bpr1cs_set_table_format)
-static int g_latency_cus = 0;   // >0: CUs reserved for the latency-bound kernels (see bpr1cs_gens_create)
-static int g_rng_mode = 0;       // 0 auto, 1 lane-parallel via LDS (k_rng_stream), 2 state per thread, 3 scalar unit, 4 lane-parallel via DPP (k_rng_dpp)
-static int g_merge_triples = 1;  // A_I1: one merged table per Inverse-S-box triple (needs the annotated witness program)
-static int g_witness_macro = 1;  // use the Poseidon annotations of a circuit description (poseidon_team)
-static int g_witness_team = 8;   // lanes cooperating on one proof in k_witness_team (4, 8 or 16)
-static uint32_t g_msm_target_threads = 1u << 21;  // (chunk, proof) threads per MSM launch
-static float g_timings[8];
+// Process-wide DEFAULTS of the tuning knobs (the bpr1cs_set_* entry points).  They are read once - when a handle is
+// created (table geometry) or when a call starts (per-call knobs) - and a handle can override the per-call ones for
+// itself (bpr1cs_gens_set_option), so two threads working on distinct handles never depend on each other's settings.
+static std::atomic<int> g_unfold_rounds{4};
+static std::atomic<int> g_window_bits{8};
+static std::atomic<int> g_table_format{-1};  // -1 auto, 0 packed (96 B per entry), 1 limb form in 128-B slots (see bpr1cs_set_table_format)
+static std::atomic<int> g_latency_cus{0};    // >0: CUs reserved for the latency-bound kernels (see bpr1cs_gens_create)
+static std::atomic<int> g_rng_mode{0};       // 0 auto, 1 lane-parallel via LDS (k_rng_stream), 2 state per thread, 3 scalar unit, 4 lane-parallel via DPP (k_rng_dpp)
+static std::atomic<int> g_merge_triples{1};  // A_I1: one merged table per Inverse-S-box wire triple (needs the annotated witness program)
+static std::atomic<int> g_witness_macro{1};  // use the Poseidon annotations of a circuit description (poseidon_team)
+static std::atomic<int> g_witness_team{8};   // lanes cooperating on one proof in k_witness_team (4, 8 or 16)
+static const uint32_t g_msm_target_threads = 1u << 21;  // (chunk, proof) threads per MSM launch
+struct BpOpts {  // per-handle overrides; -1 = process default
+    std::atomic<int> unfold{-1}, rng_mode{-1}, witness_team{-1};
+};
+// statistics of the last prove job that ENDED ON THIS THREAD (bpr1cs_last_timings / bpr1cs_last_msm_stats)
+struct LastStats {
+    float timings[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    double msm_ms = 0;
+    uint64_t msm_launches = 0, msm_terms = 0;
+};
+static thread_local LastStats tl_last;
+
+// ---- C ABI boundary: failures inside (HIP errors, allocation failures, oversized launches) become return codes
+#define API_TRY try {
+#define API_CATCH                                                   \
+    }                                                               \
+    catch (const DevError& e_) { return e_.code; }                  \
+    catch (const std::bad_alloc&) { return BPR1CS_ERR_OUT_OF_MEMORY; } \
+    catch (...) { return BPR1CS_ERR_DEVICE; }
+// Buffers released while a synchronous entry point runs may still be read by kernels it has enqueued: they are
+// collected and go back to the allocator only after the call's stream has drained (declare FIRST in the function).
+struct CallScope {
+    std::vector<void*> frees;
+    std::vector<void*>* prev;
+    dev_stream_t st;
+    explicit CallScope(dev_stream_t s) : prev(dev_deferred_frees()), st(s) { dev_deferred_frees() = &frees; }
+    ~CallScope() {
+        dev_deferred_frees() = prev;
+#if !defined(BPR1CS_HOSTSIM)
+        (void)hipStreamSynchronize(st);
+#endif
+        for (void* p : frees) dev_free_now(p);
+    }
+};
+// 32-byte little-endian scalar < l ?  (Scalar::from_canonical_bytes; inputs of the ABI must be canonical: the signed-window
+// recoding of the fixed-base tables relies on it)
+static bool host_scalar_canonical(const uint8_t* p) {
+    for (int i = 7; i >= 0; i--) {
+        uint32_t w = (uint32_t)p[4 * i] | ((uint32_t)p[4 * i + 1] << 8) | ((uint32_t)p[4 * i + 2] << 16) | ((uint32_t)p[4 * i + 3] << 24);
+        if (w < SC_L[i]) return true;
+        if (w > SC_L[i]) return false;
+    }
+    return false;
+}
+static bool host_scalars_canonical(const uint8_t* p, size_t count) {
+    for (size_t i = 0; i < count; i++)
+        if (!host_scalar_canonical(p + 32 * i)) return false;
+    return true;
+}
 
 struct bpr1cs_gens {
     uint32_t cap = 0;
@@ -60,8 +113,9 @@ struct bpr1cs_gens {
     // co-run with the other in-flight job's MSM/IPA kernels instead of queueing behind them.
     dev_stream_t jstream[2][4]{};  // [slot][heavy, front, witness, isolated RNG chain]
     bool rng_isolated = false;
-    uint32_t next_job = 0;
-    int in_flight = 0;  // jobs begun and not yet ended
+    mutable std::atomic<uint32_t> next_job{0};
+    mutable std::atomic<int> in_flight{0};  // jobs begun and not yet ended
+    mutable BpOpts opts;
 };
 
 struct bpr1cs_circuit {
@@ -82,9 +136,14 @@ struct bpr1cs_circuit {
     // the A_I commitment uses one merged table per triple and side (K_merge_points)
     std::vector<uint32_t> h_trip, h_rest;
     DevBuf<uint32_t> trip, rest;
-    const bpr1cs_gens* mt_gens = nullptr;  // merged tables are built for one generator set at a time
-    uint32_t mt_W = 0, mt_cap = 0;
-    DevBuf<uint8_t> mtab;
+    // merged tables, one set per generator handle that has proved this circuit (built on first use, under mt_mu)
+    struct MergedTab {
+        uint32_t W = 0, cap = 0, fmt = 0;
+        DevBuf<uint8_t> tab;
+    };
+    mutable std::mutex mt_mu;
+    mutable std::map<const bpr1cs_gens*, MergedTab*> mt;
+    ~bpr1cs_circuit() { for (auto& kv : mt) delete kv.second; }
 };
 
 static bool have_device() {
@@ -152,53 +211,79 @@ void bpr1cs_set_rng_mode(int mode) { g_rng_mode = (mode >= 1 && mode <= 4) ? mod
 int bpr1cs_circuit_macro_perms(const bpr1cs_circuit* c) { return c ? (int)c->n_perms : 0; }
 void bpr1cs_set_window_bits(int w) { g_window_bits = w < 4 ? 4 : (w > 12 ? 12 : w); }
 void bpr1cs_set_table_format(int f) { g_table_format = (f == 0 || f == 1) ? f : -1; }
+int bpr1cs_gens_set_option(bpr1cs_gens* g, int option, int value) {
+    if (!g) return BPR1CS_ERR_INVALID_ARGUMENT;
+    if (option == BPR1CS_OPT_UNFOLD_ROUNDS) g->opts.unfold = value < 0 ? -1 : value;
+    else if (option == BPR1CS_OPT_RNG_MODE) g->opts.rng_mode = (value >= 0 && value <= 4) ? value : -1;
+    else if (option == BPR1CS_OPT_WITNESS_TEAM) g->opts.witness_team = (value == 4 || value == 8 || value == 16) ? value : -1;
+    else return BPR1CS_ERR_INVALID_ARGUMENT;
+    return BPR1CS_OK;
+}
+int bpr1cs_gens_table_info(const bpr1cs_gens* g, uint32_t* window_bits, uint32_t* windows, uint32_t* format, uint64_t* bytes) {
+    if (!g) return BPR1CS_ERR_INVALID_ARGUMENT;
+    if (window_bits) *window_bits = g->tc.W;
+    if (windows) *windows = g->tc.windows;
+    if (format) *format = g->tc.fmt;
+    if (bytes) *bytes = (uint64_t)(2 + 2 * (size_t)g->cap) * g->tc.base_bytes();
+    return BPR1CS_OK;
+}
+int bpr1cs_release_cached_memory(void) {
+#if !defined(BPR1CS_HOSTSIM)
+    dev_pool().release_all();
+#endif
+    return BPR1CS_OK;
+}
 int bpr1cs_last_timings(float* out, int cap) {
     int k = cap < 6 ? cap : 6;
-    for (int i = 0; i < k; i++) out[i] = g_timings[i];
+    for (int i = 0; i < k; i++) out[i] = tl_last.timings[i];
     return k;
 }
 
+void bpr1cs_gens_destroy(bpr1cs_gens* g);
 int bpr1cs_gens_create(uint32_t cap, bpr1cs_gens** out) {
     if (!out || cap == 0) return BPR1CS_ERR_INVALID_ARGUMENT;
     if (!have_device()) return BPR1CS_ERR_NO_DEVICE;
-    bpr1cs_gens* g = new bpr1cs_gens();
+    if (cap > (1u << 24)) return BPR1CS_ERR_INVALID_ARGUMENT;
+    bpr1cs_gens* g = nullptr;
+    API_TRY
+    g = new bpr1cs_gens();
     g->cap = cap;
+    const int window_bits = g_window_bits.load(), latency_cus = g_latency_cus.load();
     {   // table entry format: the limb form (no unpacking in the inner loop, 128-byte aligned slots) costs a third more
         // HBM than the packed one - take it when the device keeps >= 100 GB free for circuits' merged tables and the
         // per-batch workspace (two 1024-proof jobs of the depth-32 circuit in flight need ~55 GB)
-        int fmt = g_table_format;
+        int fmt = g_table_format.load();
         if (fmt < 0) {
             fmt = 0;
 #if !defined(BPR1CS_HOSTSIM)
             size_t mfree = 0, mtotal = 0;
-            TabCfg lim = tab_cfg((uint32_t)g_window_bits, TAB_FMT_LIMB, 128);
+            TabCfg lim = tab_cfg((uint32_t)window_bits, TAB_FMT_LIMB, 128);
             if (hipMemGetInfo(&mfree, &mtotal) == hipSuccess && mfree > (size_t)(2 + 2 * (size_t)cap) * lim.base_bytes() + (100ull << 30)) fmt = 1;
 #endif
         }
-        g->tc = fmt ? tab_cfg((uint32_t)g_window_bits, TAB_FMT_LIMB, 128) : tab_cfg((uint32_t)g_window_bits, TAB_FMT_PACKED, 96);
+        g->tc = fmt ? tab_cfg((uint32_t)window_bits, TAB_FMT_LIMB, 128) : tab_cfg((uint32_t)window_bits, TAB_FMT_PACKED, 96);
     }
 #if !defined(BPR1CS_HOSTSIM)
     HIPCHK(hipStreamCreate(&g->stream));
     int prio_lo = 0, prio_hi = 0;
     HIPCHK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));  // numerically lower = higher priority
     hipDeviceProp_t prop;
-    HIPCHK(hipGetDeviceProperties(&prop, 0));
     int dev = 0;
     HIPCHK(hipGetDevice(&dev));
     HIPCHK(hipGetDeviceProperties(&prop, dev));
     const uint32_t ncu = (uint32_t)prop.multiProcessorCount;
-    if (g_latency_cus > 0 && (uint32_t)g_latency_cus < ncu) {
-        // Reserve `g_latency_cus` CUs (every k-th one, so they spread over the XCDs) for the per-thread
+    if (latency_cus > 0 && (uint32_t)latency_cus < ncu) {
+        // Reserve `latency_cus` CUs (every k-th one, so they spread over the XCDs) for the per-thread
         // TranscriptRng chain (k_rng_thread): a few wavefronts of pure VALU code on the critical path.  Sharing a
         // SIMD with anything else hurts both ways - an equal-priority neighbour halves the chain's speed, and a
         // chain wave with raised priority starves the neighbour, which then becomes the straggler of ITS launch
         // (measured: witness 94 -> 500 ms, K_msm_fixed 31 -> 56 ms).  Every other stream is masked off those CUs.
         const uint32_t words = (ncu + 31) / 32;
         std::vector<uint32_t> lat(words, 0), rest(words, 0);
-        const uint32_t stride = ncu / (uint32_t)g_latency_cus;
+        const uint32_t stride = ncu / (uint32_t)latency_cus;
         uint32_t taken = 0;
         for (uint32_t cu = 0; cu < ncu; cu++) {
-            bool is_lat = (cu % stride == 0) && taken < (uint32_t)g_latency_cus;
+            bool is_lat = (cu % stride == 0) && taken < (uint32_t)latency_cus;
             if (is_lat) { lat[cu / 32] |= 1u << (cu % 32); taken++; }
             else rest[cu / 32] |= 1u << (cu % 32);
         }
@@ -212,6 +297,7 @@ int bpr1cs_gens_create(uint32_t cap, bpr1cs_gens** out) {
             for (int b = 0; b < 3; b++) HIPCHK(hipStreamCreateWithPriority(&g->jstream[a][b], hipStreamNonBlocking, b == 0 ? prio_lo : prio_hi));
     }
 #endif
+    CallScope scope(g->stream);
     uint32_t nb = 2 + 2 * cap;
     // uniform bytes: B~ <- SHA3-512(compress(B)); G/H <- SHAKE256("GeneratorsChain"||'G'|'H'||LE32(0))  
     std::vector<uint8_t> uni((size_t)(1 + 2 * cap) * 64);
@@ -236,11 +322,15 @@ int bpr1cs_gens_create(uint32_t cap, bpr1cs_gens** out) {
     dev_sync(g->stream);
     *out = g;
     return BPR1CS_OK;
+    }
+    catch (const DevError& e_) { bpr1cs_gens_destroy(g); return e_.code; }
+    catch (const std::bad_alloc&) { bpr1cs_gens_destroy(g); return BPR1CS_ERR_OUT_OF_MEMORY; }
+    catch (...) { bpr1cs_gens_destroy(g); return BPR1CS_ERR_DEVICE; }
 }
 void bpr1cs_gens_destroy(bpr1cs_gens* g) {
     if (!g) return;
 #if !defined(BPR1CS_HOSTSIM)
-    (void)hipStreamDestroy(g->stream);
+    if (g->stream) (void)hipStreamDestroy(g->stream);
     for (int a = 0; a < 2; a++)
         for (int b = 0; b < 4; b++) if (g->jstream[a][b]) (void)hipStreamDestroy(g->jstream[a][b]);
 #endif
@@ -262,11 +352,54 @@ int bpr1cs_gens_point(const bpr1cs_gens* g, int which, uint32_t i, uint8_t out[3
 int bpr1cs_circuit_create(const bpr1cs_circuit_desc* d, bpr1cs_circuit** out) {
     if (!d || !out) return BPR1CS_ERR_INVALID_ARGUMENT;
     if (!have_device()) return BPR1CS_ERR_NO_DEVICE;
-    bpr1cs_circuit* c = new bpr1cs_circuit();
+    if (d->n > (1u << 24) || d->m > (1u << 20) || d->q > (1u << 26)) return BPR1CS_ERR_INVALID_ARGUMENT;
+    if (d->q && (!d->row_off || !d->term_var || !d->term_coeff)) return BPR1CS_ERR_INVALID_ARGUMENT;
+    // ---- validate every index and offset of the description before anything reaches the device: a malformed
+    // description must fail here, not read or write out of bounds in a kernel
+    if (d->q) {
+        if (d->row_off[0] != 0) return BPR1CS_ERR_INVALID_ARGUMENT;
+        for (uint32_t j = 0; j < d->q; j++)
+            if (d->row_off[j + 1] < d->row_off[j]) return BPR1CS_ERR_INVALID_ARGUMENT;
+    }
+    auto var_ok = [&](uint32_t var, uint32_t wire_limit) {  // wire_limit: multipliers a reference may point at
+        uint32_t kind = var >> 28, idx = var & 0x0fffffffu;
+        if (kind == VK_ONE) return true;
+        if (kind == VK_COMMITTED) return idx < d->m;
+        return kind <= VK_OUT && idx < wire_limit;
+    };
+    if (d->wops) {
+        if (d->n_lc && (!d->lc_off || !d->lc_var || !d->lc_coeff)) return BPR1CS_ERR_INVALID_ARGUMENT;
+        if (d->n_lc) {
+            if (d->lc_off[0] != 0) return BPR1CS_ERR_INVALID_ARGUMENT;
+            for (uint32_t k = 0; k < d->n_lc; k++)
+                if (d->lc_off[k + 1] < d->lc_off[k]) return BPR1CS_ERR_INVALID_ARGUMENT;
+        }
+        // a multiplier's operands may only read committed values, the constant, and wires of EARLIER multipliers
+        // (the sequential program of K_witness / k_witness_team writes multiplier i after evaluating both operands)
+        auto operand_ok = [&](uint32_t kind, uint32_t arg, uint32_t i, bool right) {
+            if (kind == WK_LC) {
+                if (arg >= d->n_lc) return false;
+                for (uint32_t t = d->lc_off[arg]; t < d->lc_off[arg + 1]; t++)
+                    if (!var_ok(d->lc_var[t], i)) return false;
+                return true;
+            }
+            if (kind == WK_INV_LEFT) return right;
+            if (kind == WK_BIT || kind == WK_NOTBIT) return (arg >> 8) < d->m && (arg & 0xffu) < 253u;
+            return false;
+        };
+        for (uint32_t i = 0; i < d->n; i++)
+            if (!operand_ok(d->wops[i].lkind, d->wops[i].larg, i, false) || !operand_ok(d->wops[i].rkind, d->wops[i].rarg, i, true))
+                return BPR1CS_ERR_INVALID_ARGUMENT;
+    }
+    bpr1cs_circuit* c = nullptr;
+    API_TRY
+    c = new bpr1cs_circuit();
     c->n = d->n; c->q = d->q; c->m = d->m;
     c->N = 1; c->lgN = 0;
     while (c->N < d->n) { c->N <<= 1; c->lgN++; }
     dev_stream_t s{};
+    CallScope scope(s);
+    const int witness_macro = g_witness_macro.load();
     // CSR by row -> CSC by wire slot (LEFT i -> i, RIGHT -> n+i, OUT -> 2n+i, COMMITTED -> 3n+i, One -> 3n+m).
     // The prover flattens slots [0, 3n+m) (it ignores constant terms); the verifier also needs slot 3n+m (w_c).
     uint32_t nslots = 3 * d->n + d->m + 1;
@@ -331,7 +464,7 @@ int bpr1cs_circuit_create(const bpr1cs_circuit_desc* d, bpr1cs_circuit** out) {
         };
         // Poseidon annotations: validate, then route the S-box multipliers to the jointly evaluated values.
         // Anything unexpected leaves the plain program in place (it is complete on its own).
-        if (g_witness_macro && d->n_poseidon_perms && d->poseidon_perms && d->n_poseidon_params && d->poseidon_params) {
+        if (witness_macro && d->n_poseidon_perms && d->poseidon_perms && d->n_poseidon_params && d->poseidon_params) {
             std::vector<PoseidonTab> tabs;
             std::vector<sc> pc;
             bool ok = true;
@@ -415,6 +548,10 @@ int bpr1cs_circuit_create(const bpr1cs_circuit_desc* d, bpr1cs_circuit** out) {
     }
     *out = c;
     return BPR1CS_OK;
+    }
+    catch (const DevError& e_) { delete c; return e_.code; }
+    catch (const std::bad_alloc&) { delete c; return BPR1CS_ERR_OUT_OF_MEMORY; }
+    catch (...) { delete c; return BPR1CS_ERR_DEVICE; }
 }
 void bpr1cs_circuit_destroy(bpr1cs_circuit* c) { delete c; }
 size_t bpr1cs_proof_len(const bpr1cs_circuit* c) { return c ? 1 + 32 * (size_t)(13 + 2 * c->lgN) : 0; }
@@ -467,38 +604,34 @@ struct MsmPlan {
     uint32_t nchunks, chunk;
 };
 
-// HIP-event timing of every launch of the dominant kernel (K_msm_fixed) on its own stream,
-// for bench.py's roofline object.
+// HIP-event timing of every launch of the dominant kernel (k_msm_fixed2) on its own stream, for bench.py's roofline
+// object.  One instance per prove job (or per synchronous call): nothing is shared between handles or threads.
 struct MsmStats {
     double ms = 0;
     uint64_t launches = 0, terms = 0;  // terms = scalar*point products (summed over the batch)
 #if !defined(BPR1CS_HOSTSIM)
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
-    std::vector<hipEvent_t> pool;
     hipEvent_t get() {
-        if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
         hipEvent_t e;
         HIPCHK(hipEventCreate(&e));
         return e;
     }
+    ~MsmStats() {
+        for (auto& p : ev) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
+    }
 #endif
-    void reset() { ms = 0; launches = 0; terms = 0; }
-    void collect() {
+    void collect() {  // after the stream has drained
 #if !defined(BPR1CS_HOSTSIM)
         for (auto& p : ev) {
             float t = 0;
-            HIPCHK(hipEventSynchronize(p.second));
-            HIPCHK(hipEventElapsedTime(&t, p.first, p.second));
-            ms += t;
-            pool.push_back(p.first);
-            pool.push_back(p.second);
+            if (hipEventSynchronize(p.second) == hipSuccess && hipEventElapsedTime(&t, p.first, p.second) == hipSuccess) ms += t;
+            (void)hipEventDestroy(p.first);
+            (void)hipEventDestroy(p.second);
         }
         ev.clear();
 #endif
     }
 };
-static MsmStats g_msm;             // last finished job (reported by bpr1cs_last_msm_stats)
-static MsmStats* g_cur_msm = &g_msm;  // job being enqueued
 
 // Launch geometry: many more workgroups than the chip holds at once (g_msm_target_threads / 64 >> 16 per CU), so
 // that the hardware dispatcher load-balances them - a launch of exactly one resident set makes every workgroup
@@ -512,7 +645,7 @@ struct MsmReq {
     MsmPlan* plan;
     const uint8_t* table;  // nullptr = the generator tables of `g`
 };
-static void run_msm_multi(const bpr1cs_gens* g, MsmReq* reqs, uint32_t nreq, uint32_t B, dev_stream_t st) {
+static void run_msm_multi(const bpr1cs_gens* g, MsmReq* reqs, uint32_t nreq, uint32_t B, dev_stream_t st, MsmStats* stats) {
     const uint32_t nbk = (B + 63u) / 64u;
     struct Lay { uint32_t nchunks, l1, l2; ge* raw; ge* p1; ge* p2; };
     Lay lay[MSM_MAX_JOBS];
@@ -526,7 +659,7 @@ static void run_msm_multi(const bpr1cs_gens* g, MsmReq* reqs, uint32_t nreq, uin
     for (uint32_t r = 0; r < nreq; r++) {
         MsmReq& q = reqs[r];
         uint32_t total = q.s0.count + q.s1.count;
-        uint32_t nchunks = pick_chunks(total, B, g_msm_target_threads / (nreq > 1 ? 1u : 1u), q.plan->chunk);
+        uint32_t nchunks = pick_chunks(total, B, g_msm_target_threads, q.plan->chunk);
         uint32_t l1 = nchunks > MSM_REDUCE_GROUP ? (nchunks + MSM_REDUCE_GROUP - 1) / MSM_REDUCE_GROUP : 0;
         uint32_t l2 = l1 > MSM_REDUCE_GROUP ? (l1 + MSM_REDUCE_GROUP - 1) / MSM_REDUCE_GROUP : 0;
         size_t need = ((size_t)nchunks + l1 + l2) * B;
@@ -547,27 +680,32 @@ static void run_msm_multi(const bpr1cs_gens* g, MsmReq* reqs, uint32_t nreq, uin
         launch_wave((uint64_t)lay[r].nchunks * nbk * 64u, k, st);
     }
 #else
-    hipEvent_t e0 = g_cur_msm->get(), e1 = g_cur_msm->get();
-    HIPCHK(hipEventRecord(e0, st));
+    hipEvent_t e0{}, e1{};
+    if (stats) {
+        e0 = stats->get(); e1 = stats->get();
+        stats->ev.push_back({e0, e1});
+        HIPCHK(hipEventRecord(e0, st));
+    }
     L.nwg = (wg + 7u) & ~7u;  // a multiple of 8 keeps the XCD-aware remap on
     const size_t lds = (size_t)2 * g->tc.windows * 64 * sizeof(uint16_t);
     if (g->tc.fmt == TAB_FMT_PACKED) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_msm_fixed2<(int)TAB_FMT_PACKED, 3>), dim3(L.nwg), dim3(64), lds, st, L);
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_msm_fixed2<(int)TAB_FMT_LIMB, 3>), dim3(L.nwg), dim3(64), lds, st, L);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipEventRecord(e1, st));
-    g_cur_msm->ev.push_back({e0, e1});
+    if (stats) HIPCHK(hipEventRecord(e1, st));
 #endif
     for (uint32_t r = 0; r < nreq; r++) {
         if (lay[r].l1) launch((uint64_t)lay[r].l1 * B, K_ge_reduce{lay[r].raw, lay[r].p1, B, lay[r].nchunks, MSM_REDUCE_GROUP}, st);
         if (lay[r].l2) launch((uint64_t)lay[r].l2 * B, K_ge_reduce{lay[r].p1, lay[r].p2, B, lay[r].l1, MSM_REDUCE_GROUP}, st);
     }
-    g_cur_msm->launches++;
-    g_cur_msm->terms += terms;
+    if (stats) {
+        stats->launches++;
+        stats->terms += terms;
+    }
 }
 static void run_msm(const bpr1cs_gens* g, MsmSeg s0, MsmSeg s1, uint32_t B, DevBuf<ge>& partial, MsmPlan& plan, dev_stream_t st,
-                    const uint8_t* table = nullptr) {
+                    MsmStats* stats, const uint8_t* table = nullptr) {
     MsmReq q{s0, s1, &partial, &plan, table};
-    run_msm_multi(g, &q, 1, B, st);
+    run_msm_multi(g, &q, 1, B, st, stats);
 }
 
 // constraint columns weighted by powers of z: wvec[slot][b] (first `nslots` slots of the circuit)
@@ -576,6 +714,93 @@ static void run_flatten(const bpr1cs_circuit* c, uint32_t nslots, const sc* plo,
     DevBuf<sc> part((size_t)(nch ? nch : 1) * B);
     launch((uint64_t)nch * B, K_flatten_chunks{c->chunk_lo.p, c->ent_row.p, c->ent_coeff.p, plo, phi, part.p, B, H}, st);
     launch((uint64_t)nslots * B, K_flatten{c->slot_chunk.p, part.p, wvec, B, 3 * c->n}, st);
+}
+
+// ---------------------------------------------------------------- inner-product argument
+// InnerProductProof::create for B independent proofs whose transcripts already hold ("dom-sep","ipp v1"), ("n", N).
+// Rounds 0..unfold-1 take L_k, R_k from the UN-folded generator tables with product scalars; at round `unfold` the
+// folded generators are materialised once and the remaining rounds are variable-base.
+struct IpaIO {
+    const bpr1cs_gens* g;
+    uint32_t B, N, lgN, unfold;
+    strobe* tr;      // [B] transcript states (updated)
+    sc* a;           // [N][B] Montgomery, folded in place; a[0][b] = final a
+    sc* bb;          // [N][B]
+    sc* cG;          // [N][B] G_factors (consumed)
+    sc* cH;          // [N][B] H_factors (consumed)
+    const sc* qw;    // [B] Montgomery w with Q = w * B (the prover's case), or nullptr ...
+    const ge* qpt;   // ... [B] arbitrary points Q (bpr1cs_ipa_create)
+    uint8_t* LR;     // out [lgN][2][B][32]
+    sc* uk;          // out [lgN][2][B]: u_k, u_k^-1
+};
+static void enqueue_ipa(const IpaIO& io, dev_stream_t st, MsmStats* stats) {
+    const bpr1cs_gens* g = io.g;
+    const uint32_t B = io.B, N = io.N, lgN = io.lgN;
+    const uint32_t baseG = 2, baseH = 2 + g->cap;
+    sc* a = io.a; sc* bb = io.bb; sc* cG = io.cG; sc* cH = io.cH;
+    DevBuf<sc> cross((size_t)2 * B);
+    const uint32_t r = io.unfold < lgN ? io.unfold : lgN;
+    DevBuf<sc> sG, sH, cpart;
+    DevBuf<ge> GH, vwin, vsum, vout, partial, partialR;
+    DevBuf<ge_cached> vtab;
+    DevBuf<uint32_t> vdig;
+    DevBuf<sc> linv;
+    MsmPlan plan;
+    const uint32_t M = N >> r;  // size of the materialised folded generator vectors
+    if (r > 0) { sG.alloc((size_t)N * B); sH.alloc((size_t)N * B); }
+    const uint32_t VC = 16;
+    auto finish = [&](const ge* part, uint32_t nch, const sc* c, uint8_t* out) {
+        K_msm_finish f{g->tab.p, g->tc, part, c, io.qw, out, B, nch, 0};
+        if (io.qpt) { f.extra2 = nullptr; f.extra_pt = io.qpt; }
+        launch(B, f, st);
+    };
+    for (uint32_t k = 0; k < lgN; k++) {
+        uint32_t Nk = N >> k, mk = Nk >> 1;
+        uint32_t cchunk, CC = pick_chunks(mk, B, 1u << 16, cchunk);
+        if (cpart.n < (size_t)2 * CC * B) cpart.alloc((size_t)2 * CC * B);
+        launch((uint64_t)CC * B, K_ipa_cross{a, bb, cpart.p, B, mk, cchunk, CC}, st);
+        launch((uint64_t)2 * B, K_sum_partials{cpart.p, cross.p, B, CC}, st);
+        uint8_t* Lout = io.LR + ((size_t)k * 2 + 0) * B * 32;
+        uint8_t* Rout = io.LR + ((size_t)k * 2 + 1) * B * 32;
+        if (k < r) {
+            launch((uint64_t)N * B, K_ipa_scalars{a, bb, cG, cH, sG.p, sH.p, B, Nk}, st);
+            uint32_t half = N / 2;
+            // L: G-terms with pos >= m, H-terms with pos < m ; R: the complement
+            MsmSeg gL{sG.p, half, mk, Nk, mk, baseG, 0}, hL{sH.p, half, mk, Nk, 0, baseH, 0};
+            MsmSeg gR{sG.p, half, mk, Nk, 0, baseG, 0}, hR{sH.p, half, mk, Nk, mk, baseH, 0};
+            MsmPlan planR;
+            MsmReq rq[2] = {{gL, hL, &partial, &plan, nullptr}, {gR, hR, &partialR, &planR, nullptr}};
+            run_msm_multi(g, rq, 2, B, st, stats);  // L_k and R_k share one launch
+            finish(partial.p, plan.nchunks, cross.p, Lout);
+            finish(partialR.p, planR.nchunks, cross.p + B, Rout);
+        } else {
+            if (k == r) {
+                GH.alloc((size_t)2 * M * B);
+                launch_wave((uint64_t)2 * M * B, K_ipa_fold_from_tables{g->tab.p, g->tc, cG, cH, GH.p, B, M, N, baseG, baseH}, st);
+                vtab.alloc((size_t)8 * 4 * (M / 2 ? M / 2 : 1) * B);
+                vdig.alloc((size_t)8 * 4 * (M / 2 ? M / 2 : 1) * B);
+                vwin.alloc((size_t)2 * 64 * VC * B);
+                vsum.alloc((size_t)2 * 64 * B);
+                vout.alloc((size_t)2 * B);
+                linv.alloc((size_t)2 * B);
+                launch((uint64_t)2 * B, K_set_one{linv.p}, st);
+            }
+            const uint32_t vc = 2 * mk < VC ? 2 * mk : VC;  // chunks of the 2*mk terms of one output
+            launch((uint64_t)4 * mk * B, K_ipa_vb_tab{a, bb, GH.p, linv.p, vtab.p, vdig.p, B, mk, M}, st);
+            launch_wave((uint64_t)2 * 64 * vc * B, K_ipa_vb_win{vtab.p, vdig.p, vwin.p, B, mk, vc}, st);
+            launch((uint64_t)2 * 64 * B, K_ge_reduce{vwin.p, vsum.p, B, 2 * 64 * vc, vc}, st);  // chunk sums -> window sums
+            launch((uint64_t)2 * B, K_ipa_vb_horner{vsum.p, vout.p, B, 1}, st);
+            finish(vout.p, 1, cross.p, Lout);
+            finish(vout.p + (size_t)B, 1, cross.p + B, Rout);
+        }
+        sc* ukk = io.uk + (size_t)k * 2 * B;
+        launch(B, K_transcript_LR{io.tr, Lout, ukk, B}, st);
+        launch((uint64_t)mk * B, K_ipa_fold_ab{a, bb, ukk, B, mk}, st);
+        if (k < r) launch((uint64_t)N * B, K_ipa_update_c{cG, cH, ukk, B, Nk}, st);
+        else if (mk > 0 && k + 1 < lgN) launch_wave((uint64_t)2 * mk * B, K_ipa_vb_fold{GH.p, ukk, linv.p, B, mk, M}, st);
+    }
+    if (sG.p) dev_zero(sG.p, sG.bytes(), st);  // products of the secret l / r vectors
+    if (sH.p) dev_zero(sH.p, sH.bytes(), st);
 }
 
 struct bpr1cs_job {
@@ -589,32 +814,35 @@ struct bpr1cs_job {
     uint8_t* h_proofs = nullptr;  // pinned staging
     uint8_t* h_comms = nullptr;
     int* h_err = nullptr;
+    bool counted = false;         // contributes to g->in_flight
 #if !defined(BPR1CS_HOSTSIM)
     hipEvent_t ev_in{}, ev_rng{}, ev_wit{}, ev_done{}, ev_rng0{}, ev_rng1{};
 #endif
 };
 // pinned staging buffers are cached: hipHostFree (like hipFree) synchronises the whole device, which
 // would serialise the in-flight jobs
-static std::multimap<size_t, void*>& host_stage_cache() {
-    static std::multimap<size_t, void*>* c = new std::multimap<size_t, void*>();
-    return *c;
-}
-static std::map<void*, size_t>& host_stage_live() {
-    static std::map<void*, size_t>* c = new std::map<void*, size_t>();
-    return *c;
+struct HostStage {
+    std::mutex mu;
+    std::multimap<size_t, void*> cache;
+    std::map<void*, size_t> live;
+};
+static HostStage& host_stage() {
+    static HostStage* h = new HostStage();  // intentionally leaked: must outlive static destructors
+    return *h;
 }
 static void* host_stage_alloc(size_t n) {
     if (n == 0) n = 1;
 #if defined(BPR1CS_HOSTSIM)
     return malloc(n);
 #else
-    auto& cache = host_stage_cache();
-    auto it = cache.lower_bound(n);
+    HostStage& hs = host_stage();
+    std::lock_guard<std::mutex> lk(hs.mu);
+    auto it = hs.cache.lower_bound(n);
     void* p = nullptr;
     size_t sz = n;
-    if (it != cache.end() && it->first <= 2 * n + 4096) { p = it->second; sz = it->first; cache.erase(it); }
+    if (it != hs.cache.end() && it->first <= 2 * n + 4096) { p = it->second; sz = it->first; hs.cache.erase(it); }
     else HIPCHK(hipHostMalloc(&p, n, hipHostMallocDefault));
-    host_stage_live()[p] = sz;
+    hs.live[p] = sz;
     return p;
 #endif
 }
@@ -623,10 +851,12 @@ static void host_stage_free(void* p) {
     free(p);
 #else
     if (!p) return;
-    auto it = host_stage_live().find(p);
-    if (it == host_stage_live().end()) return;
-    host_stage_cache().insert({it->second, p});
-    host_stage_live().erase(it);
+    HostStage& hs = host_stage();
+    std::lock_guard<std::mutex> lk(hs.mu);
+    auto it = hs.live.find(p);
+    if (it == hs.live.end()) return;
+    hs.cache.insert({it->second, p});
+    hs.live.erase(it);
 #endif
 }
 static void dev_d2h_async(void* h, const void* d, size_t n, dev_stream_t s) {
@@ -637,6 +867,27 @@ static void dev_d2h_async(void* h, const void* d, size_t n, dev_stream_t s) {
 #endif
     (void)s;
 }
+// wait for everything a job has enqueued and release what it holds (normal end and error paths)
+static void job_release(bpr1cs_job* job) {
+    if (!job) return;
+#if !defined(BPR1CS_HOSTSIM)
+    if (job->st) (void)hipStreamSynchronize(job->st);
+    if (job->st2) (void)hipStreamSynchronize(job->st2);
+    if (job->st3) (void)hipStreamSynchronize(job->st3);
+    hipEvent_t* evs[6] = {&job->ev_in, &job->ev_rng, &job->ev_wit, &job->ev_done, &job->ev_rng0, &job->ev_rng1};
+    for (auto e : evs)
+        if (*e) { (void)hipEventDestroy(*e); *e = nullptr; }
+    for (auto e : job->pt.ev) (void)hipEventDestroy(e);
+    job->pt.ev.clear();
+#endif
+    for (void* p : job->deferred) dev_free_now(p);
+    job->deferred.clear();
+    host_stage_free(job->h_proofs);
+    host_stage_free(job->h_comms);
+    host_stage_free(job->h_err);
+    if (job->counted) job->g->in_flight--;
+    delete job;
+}
 
 extern "C" int bpr1cs_prove_batch_begin(const bpr1cs_gens* g, const bpr1cs_circuit* c, const uint8_t* label, size_t label_len,
                                         const uint8_t* values, const uint8_t* v_blindings, const uint8_t* rng_seeds,
@@ -646,23 +897,35 @@ extern "C" int bpr1cs_prove_batch_begin(const bpr1cs_gens* g, const bpr1cs_circu
     if (!have_device()) return BPR1CS_ERR_NO_DEVICE;
     if (g->cap < c->N) return BPR1CS_ERR_INVALID_GENERATORS_LENGTH;
     if (!wires && !c->has_program) return BPR1CS_ERR_MISSING_ASSIGNMENT;
-    if (batch > (1u << 20)) return BPR1CS_ERR_INVALID_ARGUMENT;
-    bpr1cs_job* job = new bpr1cs_job();
+    // the largest grid of the call must fit 2^32 threads (N = 32768: batch <= 26 000; serve larger jobs in several calls)
+    if (batch > (1u << 20) || ((uint64_t)4 * c->N + 3ull * c->n + c->m + 64) * batch > 0xffffffffull) return BPR1CS_ERR_INVALID_ARGUMENT;
+    // Scalar inputs are canonical encodings (Scalar::to_bytes); anything else is refused here
+    if (c->m && (!host_scalars_canonical(values, batch * c->m) || !host_scalars_canonical(v_blindings, batch * c->m))) return BPR1CS_ERR_INVALID_ARGUMENT;
+    if (wires && !host_scalars_canonical(wires, batch * 3 * (size_t)c->n)) return BPR1CS_ERR_INVALID_ARGUMENT;
+    bpr1cs_job* job = nullptr;
+    struct Scope {  // every buffer released while enqueuing stays alive until the job has drained
+        std::vector<void*>* prev;
+        explicit Scope(bpr1cs_job* j) : prev(dev_deferred_frees()) { dev_deferred_frees() = &j->deferred; }
+        ~Scope() { dev_deferred_frees() = prev; }
+    };
+    try {
+    job = new bpr1cs_job();
     job->g = g;
-    uint32_t slot = const_cast<bpr1cs_gens*>(g)->next_job++ & 1u;
+    uint32_t slot = g->next_job++ & 1u;
     job->st = g->jstream[0][0];  // ONE heavy stream: MSM/IPA phases of successive jobs run back to back (FIFO)
     job->st2 = g->jstream[slot][1];
     job->st3 = g->jstream[slot][2];
-    struct Scope {  // every buffer released while enqueuing stays alive until the job has drained
-        bpr1cs_job* j;
-        explicit Scope(bpr1cs_job* jj) : j(jj) { dev_deferred_frees() = &j->deferred; g_cur_msm = &j->msm; }
-        ~Scope() { dev_deferred_frees() = nullptr; g_cur_msm = &g_msm; }
-    } scope(job);
+    Scope scope(job);
+    // per-call knobs: the handle's own setting, else the process default
+    const int o_unfold = g->opts.unfold.load() >= 0 ? g->opts.unfold.load() : g_unfold_rounds.load();
+    const int o_rng = g->opts.rng_mode.load() >= 0 ? g->opts.rng_mode.load() : g_rng_mode.load();
+    const int o_team = g->opts.witness_team.load() >= 0 ? g->opts.witness_team.load() : g_witness_team.load();
+    const int o_merge = g_merge_triples.load();
     const uint32_t B = (uint32_t)batch, n = c->n, m = c->m, N = c->N, lgN = c->lgN;
     const uint32_t baseG = 2, baseH = 2 + g->cap;
     dev_stream_t st = job->st;
     PhaseTimer& pt = job->pt;
-    job->msm.reset();
+    MsmStats* stats = &job->msm;
     job->B = B; job->m = m;
 #if defined(BPR1CS_HOSTSIM)
     dev_stream_t sl = st;
@@ -689,6 +952,7 @@ extern "C" int bpr1cs_prove_batch_begin(const bpr1cs_gens* g, const bpr1cs_circu
     sc* sR = W.p + (size_t)4 * n * B;
     pt.mark(sl);
 #if defined(BPR1CS_HOSTSIM)
+    (void)o_rng; (void)o_team;
     launch(B, K_transcript_init{d_label.p, (uint32_t)label_len, Vcomp.p, vbl_raw.p, d_seeds.p, tr.p, blind.p, sL, sR, nullptr, B, m, n}, st);
 #else
     hipEvent_t& ev_in = job->ev_in;
@@ -704,12 +968,12 @@ extern "C" int bpr1cs_prove_batch_begin(const bpr1cs_gens* g, const bpr1cs_circu
     launch(B, K_transcript_init{d_label.p, (uint32_t)label_len, Vcomp.p, vbl_raw.p, d_seeds.p, tr.p, blind.p, sL, sR, rng.p, B, m, n}, sl);
     // a batch already in flight hides this chain's latency: then take the variant with the smallest VALU footprint
     // (only with CUs reserved for it - see bpr1cs_gens_create)
-    const bool rng_per_thread = g_rng_mode == 2 || (g_rng_mode == 0 && g->rng_isolated && g->in_flight > 0);
+    const bool rng_per_thread = o_rng == 2 || (o_rng == 0 && g->rng_isolated && g->in_flight.load() > 0);
     // ... or (explicit request only) the variant on the scalar unit: it takes no VALU issue slots, but a wavefront
     // issues one scalar instruction per ~9 cycles, so the chain is 3.7x slower (717 ms per batch) and its 1024 resident
     // wavefronts still slow the co-running MSM launches by 40 % - measured 1000 proofs/s against 1590
-    const bool rng_scalar = g_rng_mode == 3;
-    if (g_rng_mode == 4) {
+    const bool rng_scalar = o_rng == 3;
+    if (o_rng == 4) {
         hipLaunchKernelGGL(k_rng_dpp, dim3(B), dim3(64), 0, sl, rng.p, rng_raw.p, rng_err.p, B, draws);
     } else if (rng_scalar) {
         hipLaunchKernelGGL(k_rng_scalar, dim3(B), dim3(64), 0, sl, rng.p, rng_raw.p, rng_err.p, B, draws);
@@ -729,18 +993,21 @@ extern "C" int bpr1cs_prove_batch_begin(const bpr1cs_gens* g, const bpr1cs_circu
     } else hipLaunchKernelGGL(k_rng_stream, dim3((B + 1) / 2), dim3(64), 0, sl, rng.p, rng_raw.p, rng_err.p, B, draws);
     HIPCHK(hipGetLastError());
     launch((uint64_t)draws * B, K_rng_reduce{rng_raw.p, blind.p, sL, sR, B, n}, sl);
+    dev_zero(rng_raw.p, rng_raw.bytes(), sl);  // raw blinding material
+    dev_zero(rng.p, rng.bytes(), sl);
     HIPCHK(hipEventRecord(ev_rng, sl));
 #endif
 
     // ---- P7/P8: witness (device program) or host-synthesised wires
+    DevBuf<sc> px;
     if (wires) {
         DevBuf<sc> raw;
         upload_transposed(raw, wires, B, (size_t)3 * n, sl);
         launch((uint64_t)3 * n * B, K_load_wires{raw.p, W.p}, sl);
+        dev_zero(raw.p, raw.bytes(), sl);
         dev_sync(sl);
     } else {
         K_witness kw{c->wops.p, c->lc_off.p, c->lc_var.p, c->lc_coeff.p, v_raw.p, v_m.p, W.p, B, n};
-        DevBuf<sc> px;
         DevBuf<uint8_t> pzf;
         if (c->n_perms) {
             px.alloc((size_t)4 * c->px_stride * B);
@@ -751,7 +1018,7 @@ extern "C" int bpr1cs_prove_batch_begin(const bpr1cs_gens* g, const bpr1cs_circu
 #if defined(BPR1CS_HOSTSIM)
         launch(B, kw, st);
 #else
-        int T = g_witness_team;
+        int T = o_team;
         if (c->n_perms && (uint32_t)T < c->macro_width + 2) T = 16;  // poseidon_team needs width + 2 lanes
         kw.prio = 2;  // above the co-resident MSM waves (default 0), below the RNG chain (3)
         uint32_t blocks = (uint32_t)(((uint64_t)B * T + 63) / 64);
@@ -778,31 +1045,36 @@ extern "C" int bpr1cs_prove_batch_begin(const bpr1cs_gens* g, const bpr1cs_circu
         DevBuf<ge> partial2;
         MsmPlan planO;
         K_msm_finish finI{g->tab.p, g->tc, nullptr, blind.p + 0 * (size_t)B, nullptr, AOS.p + 0 * (size_t)B * 32, B, 0, 1};
-        if (!wires && T3 && g_merge_triples) {
-            // A_I1 with the repeated S-box wires merged: 2 terms per S-box instead of 5 (see K_merge_points)
-            bpr1cs_circuit* cm = const_cast<bpr1cs_circuit*>(c);
-            if (cm->mt_gens != g || cm->mt_W != g->tc.W || cm->mt_cap != g->cap) {
-                DevBuf<ge> mp((size_t)2 * T3);
-                launch(T3, K_merge_points{g->pts.p, c->trip.p, mp.p, T3, baseG, baseH}, st);
-                cm->mtab.alloc((size_t)2 * T3 * g->tc.base_bytes());
-                launch((uint64_t)2 * T3 * g->tc.windows, K_build_table{mp.p, cm->mtab.p, g->tc}, st);
-                cm->mt_gens = g;
-                cm->mt_W = g->tc.W;
-                cm->mt_cap = g->cap;
+        if (!wires && T3 && o_merge) {
+            // A_I1 with the repeated S-box wires merged: 2 terms per S-box instead of 5 (see K_merge_points).  The merged
+            // tables belong to (circuit, generator handle); the first job that needs them builds them on the heavy stream.
+            const uint8_t* mtab = nullptr;
+            {
+                std::lock_guard<std::mutex> lk(c->mt_mu);
+                bpr1cs_circuit::MergedTab*& mt = c->mt[g];
+                if (!mt) mt = new bpr1cs_circuit::MergedTab();
+                if (mt->W != g->tc.W || mt->cap != g->cap || mt->fmt != g->tc.fmt || !mt->tab.p) {
+                    DevBuf<ge> mp((size_t)2 * T3);
+                    launch(T3, K_merge_points{g->pts.p, c->trip.p, mp.p, T3, baseG, baseH}, st);
+                    mt->tab.alloc((size_t)2 * T3 * g->tc.base_bytes());
+                    launch((uint64_t)2 * T3 * g->tc.windows, K_build_table{mp.p, mt->tab.p, g->tc}, st);
+                    mt->W = g->tc.W; mt->cap = g->cap; mt->fmt = g->tc.fmt;
+                }
+                mtab = mt->tab.p;
             }
             const uint32_t nr = (uint32_t)c->h_rest.size();
             MsmSeg rG{aL, nr, 1, 1, 0, baseG, 1, c->rest.p, 0}, rH{aR, nr, 1, 1, 0, baseH, 1, c->rest.p, 0};
             MsmSeg mG{aL, T3, 1, 1, 0, 0, 1, c->trip.p, 1}, mH{aR, T3, 1, 1, 0, T3, 1, c->trip.p, 1};
             MsmPlan plan2;
-            MsmReq rq[3] = {{rG, rH, &partial, &plan, nullptr}, {mG, mH, &partial2, &plan2, c->mtab.p}, {seg(aO, baseG), none, &partialO, &planO, nullptr}};
-            run_msm_multi(g, rq, 3, B, st);  // the three sums that need the wires only share one launch
+            MsmReq rq[3] = {{rG, rH, &partial, &plan, nullptr}, {mG, mH, &partial2, &plan2, mtab}, {seg(aO, baseG), none, &partialO, &planO, nullptr}};
+            run_msm_multi(g, rq, 3, B, st, stats);  // the three sums that need the wires only share one launch
             finI.partial = partial.p;
             finI.nchunks = plan.nchunks;
             finI.partial_b = partial2.p;
             finI.nchunks_b = plan2.nchunks;
         } else {
             MsmReq rq[2] = {{seg(aL, baseG), seg(aR, baseH), &partial, &plan, nullptr}, {seg(aO, baseG), none, &partialO, &planO, nullptr}};
-            run_msm_multi(g, rq, 2, B, st);
+            run_msm_multi(g, rq, 2, B, st, stats);
             finI.partial = partial.p;
             finI.nchunks = plan.nchunks;
         }
@@ -812,7 +1084,7 @@ extern "C" int bpr1cs_prove_batch_begin(const bpr1cs_gens* g, const bpr1cs_circu
         pt.mark(st);
         launch(B, finI, st);
         launch(B, K_msm_finish{g->tab.p, g->tc, partialO.p, blind.p + 1 * (size_t)B, nullptr, AOS.p + 1 * (size_t)B * 32, B, planO.nchunks, 1}, st);
-        run_msm(g, seg(sL, baseG), seg(sR, baseH), B, partial, plan, st);
+        run_msm(g, seg(sL, baseG), seg(sR, baseH), B, partial, plan, st, stats);
         launch(B, K_msm_finish{g->tab.p, g->tc, partial.p, blind.p + 2 * (size_t)B, nullptr, AOS.p + 2 * (size_t)B * 32, B, plan.nchunks, 1}, st);
     }
     pt.mark(st);
@@ -840,62 +1112,9 @@ extern "C" int bpr1cs_prove_batch_begin(const bpr1cs_gens* g, const bpr1cs_circu
 
     // ---- P5: inner-product argument
     DevBuf<uint8_t> LR((size_t)(lgN ? lgN : 1) * 2 * B * 32);
-    DevBuf<sc> uk((size_t)(lgN ? lgN : 1) * 2 * B), cross((size_t)2 * B);
-    uint32_t r = (uint32_t)g_unfold_rounds < lgN ? (uint32_t)g_unfold_rounds : lgN;
-    DevBuf<sc> sG, sH, cpart;
-    DevBuf<ge> GH, vwin, vsum, vout;
-    DevBuf<ge_cached> vtab;
-    DevBuf<uint32_t> vdig;
-    DevBuf<sc> linv;
-    uint32_t M = N >> r;  // size of the materialised folded generator vectors
-    if (r > 0) { sG.alloc((size_t)N * B); sH.alloc((size_t)N * B); }
-    const uint32_t VC = 16;
-    for (uint32_t k = 0; k < lgN; k++) {
-        uint32_t Nk = N >> k, mk = Nk >> 1;
-        uint32_t cchunk, CC = pick_chunks(mk, B, 1u << 16, cchunk);
-        if (cpart.n < (size_t)2 * CC * B) cpart.alloc((size_t)2 * CC * B);
-        launch((uint64_t)CC * B, K_ipa_cross{a.p, bb.p, cpart.p, B, mk, cchunk, CC}, st);
-        launch((uint64_t)2 * B, K_sum_partials{cpart.p, cross.p, B, CC}, st);
-        uint8_t* Lout = LR.p + ((size_t)k * 2 + 0) * B * 32;
-        uint8_t* Rout = LR.p + ((size_t)k * 2 + 1) * B * 32;
-        const sc* wch = chal.p + (size_t)CH_W * B;
-        if (k < r) {
-            launch((uint64_t)N * B, K_ipa_scalars{a.p, bb.p, cG.p, cH.p, sG.p, sH.p, B, Nk}, st);
-            uint32_t half = N / 2;
-            // L: G-terms with pos >= m, H-terms with pos < m ; R: the complement
-            MsmSeg gL{sG.p, half, mk, Nk, mk, baseG, 0}, hL{sH.p, half, mk, Nk, 0, baseH, 0};
-            MsmSeg gR{sG.p, half, mk, Nk, 0, baseG, 0}, hR{sH.p, half, mk, Nk, mk, baseH, 0};
-            MsmPlan planR;
-            MsmReq rq[2] = {{gL, hL, &partial, &plan, nullptr}, {gR, hR, &partialO, &planR, nullptr}};
-            run_msm_multi(g, rq, 2, B, st);  // L_k and R_k share one launch
-            launch(B, K_msm_finish{g->tab.p, g->tc, partial.p, cross.p, wch, Lout, B, plan.nchunks, 0}, st);
-            launch(B, K_msm_finish{g->tab.p, g->tc, partialO.p, cross.p + B, wch, Rout, B, planR.nchunks, 0}, st);
-        } else {
-            if (k == r) {
-                GH.alloc((size_t)2 * M * B);
-                launch_wave((uint64_t)2 * M * B, K_ipa_fold_from_tables{g->tab.p, g->tc, cG.p, cH.p, GH.p, B, M, N, baseG, baseH}, st);
-                vtab.alloc((size_t)8 * 4 * (M / 2 ? M / 2 : 1) * B);
-                vdig.alloc((size_t)8 * 4 * (M / 2 ? M / 2 : 1) * B);
-                vwin.alloc((size_t)2 * 64 * VC * B);
-                vsum.alloc((size_t)2 * 64 * B);
-                vout.alloc((size_t)2 * B);
-                linv.alloc((size_t)2 * B);
-                launch((uint64_t)2 * B, K_set_one{linv.p}, st);
-            }
-            const uint32_t vc = 2 * mk < VC ? 2 * mk : VC;  // chunks of the 2*mk terms of one output
-            launch((uint64_t)4 * mk * B, K_ipa_vb_tab{a.p, bb.p, GH.p, linv.p, vtab.p, vdig.p, B, mk, M}, st);
-            launch_wave((uint64_t)2 * 64 * vc * B, K_ipa_vb_win{vtab.p, vdig.p, vwin.p, B, mk, vc}, st);
-            launch((uint64_t)2 * 64 * B, K_ge_reduce{vwin.p, vsum.p, B, 2 * 64 * vc, vc}, st);  // chunk sums -> window sums
-            launch((uint64_t)2 * B, K_ipa_vb_horner{vsum.p, vout.p, B, 1}, st);
-            launch(B, K_msm_finish{g->tab.p, g->tc, vout.p, cross.p, wch, Lout, B, 1, 0}, st);
-            launch(B, K_msm_finish{g->tab.p, g->tc, vout.p + (size_t)B, cross.p + B, wch, Rout, B, 1, 0}, st);
-        }
-        sc* ukk = uk.p + (size_t)k * 2 * B;
-        launch(B, K_transcript_LR{tr.p, Lout, ukk, B}, st);
-        launch((uint64_t)mk * B, K_ipa_fold_ab{a.p, bb.p, ukk, B, mk}, st);
-        if (k < r) launch((uint64_t)N * B, K_ipa_update_c{cG.p, cH.p, ukk, B, Nk}, st);
-        else if (mk > 0 && k + 1 < lgN) launch_wave((uint64_t)2 * mk * B, K_ipa_vb_fold{GH.p, ukk, linv.p, B, mk, M}, st);
-    }
+    DevBuf<sc> uk((size_t)(lgN ? lgN : 1) * 2 * B);
+    IpaIO io{g, B, N, lgN, (uint32_t)o_unfold, tr.p, a.p, bb.p, cG.p, cH.p, chal.p + (size_t)CH_W * B, nullptr, LR.p, uk.p};
+    enqueue_ipa(io, st, stats);
     size_t plen = bpr1cs_proof_len(c);
     job->plen = plen;
     DevBuf<uint8_t> d_out((size_t)B * plen);
@@ -907,44 +1126,49 @@ extern "C" int bpr1cs_prove_batch_begin(const bpr1cs_gens* g, const bpr1cs_circu
     *job->h_err = 0;
     dev_d2h_async(job->h_proofs, d_out.p, (size_t)B * plen, st);
     if (m) dev_d2h_async(job->h_comms, Vcomp.p, (size_t)B * m * 32, st);
+    // secrets do not stay in the allocator's cache (upstream wipes them with clear_on_drop): witness, blindings, the
+    // blinding vectors s_L / s_R, the l / r vectors and the Poseidon scratch are zeroed before their blocks are released
+    dev_zero(W.p, W.bytes(), st);
+    dev_zero(blind.p, blind.bytes(), st);
+    dev_zero(v_raw.p, v_raw.bytes(), st); dev_zero(vbl_raw.p, vbl_raw.bytes(), st);
+    dev_zero(v_m.p, v_m.bytes(), st); dev_zero(vbl_m.p, vbl_m.bytes(), st);
+    dev_zero(a.p, a.bytes(), st); dev_zero(bb.p, bb.bytes(), st);
+    if (px.p) dev_zero(px.p, px.bytes(), st);
+    dev_zero(d_seeds.p, d_seeds.bytes(), st);
 #if !defined(BPR1CS_HOSTSIM)
     dev_d2h_async(job->h_err, rng_err.p, sizeof(int), st);
     HIPCHK(hipEventCreateWithFlags(&job->ev_done, hipEventDisableTiming));
     HIPCHK(hipEventRecord(job->ev_done, st));
 #endif
-    const_cast<bpr1cs_gens*>(g)->in_flight++;
+    g->in_flight++;
+    job->counted = true;
     *job_out = job;
     return BPR1CS_OK;
+    }
+    catch (const DevError& e_) { job_release(job); return e_.code; }
+    catch (const std::bad_alloc&) { job_release(job); return BPR1CS_ERR_OUT_OF_MEMORY; }
+    catch (...) { job_release(job); return BPR1CS_ERR_DEVICE; }
 }
 
 extern "C" int bpr1cs_prove_batch_end(bpr1cs_job* job, uint8_t* proofs_out, uint8_t* commitments_out) {
     if (!job || !proofs_out) return BPR1CS_ERR_INVALID_ARGUMENT;
+    int rc = BPR1CS_OK;
 #if !defined(BPR1CS_HOSTSIM)
-    HIPCHK(hipEventSynchronize(job->ev_done));
-    HIPCHK(hipStreamSynchronize(job->st2));
-    HIPCHK(hipStreamSynchronize(job->st3));
+    if (hipEventSynchronize(job->ev_done) != hipSuccess) rc = BPR1CS_ERR_DEVICE;
+    (void)hipStreamSynchronize(job->st2);
+    (void)hipStreamSynchronize(job->st3);
 #endif
-    memcpy(proofs_out, job->h_proofs, (size_t)job->B * job->plen);
-    if (commitments_out && job->m) memcpy(commitments_out, job->h_comms, (size_t)job->B * job->m * 32);
-    int rc = *job->h_err ? BPR1CS_ERR_INVALID_ARGUMENT : BPR1CS_OK;  // RNG stream kernel found a non-steady STROBE state
-    job->pt.finish(g_timings);
-    job->msm.collect();
-    g_msm.ms = job->msm.ms; g_msm.launches = job->msm.launches; g_msm.terms = job->msm.terms;
-#if !defined(BPR1CS_HOSTSIM)
-    for (auto e : job->msm.pool) (void)hipEventDestroy(e);
-    HIPCHK(hipEventDestroy(job->ev_in));
-    HIPCHK(hipEventDestroy(job->ev_rng));
-    if (job->ev_wit) HIPCHK(hipEventDestroy(job->ev_wit));
-    if (job->ev_rng0) HIPCHK(hipEventDestroy(job->ev_rng0));
-    if (job->ev_rng1) HIPCHK(hipEventDestroy(job->ev_rng1));
-    HIPCHK(hipEventDestroy(job->ev_done));
-#endif
-    for (void* p : job->deferred) dev_free_now(p);
-    host_stage_free(job->h_proofs);
-    host_stage_free(job->h_comms);
-    host_stage_free(job->h_err);
-    const_cast<bpr1cs_gens*>(job->g)->in_flight--;
-    delete job;
+    if (rc == BPR1CS_OK) {
+        memcpy(proofs_out, job->h_proofs, (size_t)job->B * job->plen);
+        if (commitments_out && job->m) memcpy(commitments_out, job->h_comms, (size_t)job->B * job->m * 32);
+        if (*job->h_err) rc = BPR1CS_ERR_INVALID_ARGUMENT;  // RNG stream kernel found a non-steady STROBE state
+        try {
+            job->pt.finish(tl_last.timings);
+        } catch (...) {}
+        job->msm.collect();
+        tl_last.msm_ms = job->msm.ms; tl_last.msm_launches = job->msm.launches; tl_last.msm_terms = job->msm.terms;
+    }
+    job_release(job);
     return rc;
 }
 
@@ -959,55 +1183,121 @@ extern "C" int bpr1cs_prove_batch(const bpr1cs_gens* g, const bpr1cs_circuit* c,
 }
 
 extern "C" int bpr1cs_last_msm_stats(double* ms_total, uint64_t* launches, uint64_t* terms) {
-    if (ms_total) *ms_total = g_msm.ms;
-    if (launches) *launches = g_msm.launches;
-    if (terms) *terms = g_msm.terms;
+    if (ms_total) *ms_total = tl_last.msm_ms;
+    if (launches) *launches = tl_last.msm_launches;
+    if (terms) *terms = tl_last.msm_terms;
     return BPR1CS_OK;
+}
+
+// ---------------------------------------------------------------- verifier
+struct VerifyCtx {  // device state shared by the per-proof and the cross-proof verifier
+    uint32_t B, n, m, N, lgN, H, P;
+    size_t plen;
+    DevBuf<uint8_t> d_pf, d_vc, d_seed, d_label, bind;
+    DevBuf<sc> chal, uk, plo, phi, wvec, gh, dpart, delta, bsc;
+    DevBuf<int> fail;
+};
+static int verify_args_ok(const bpr1cs_gens* g, const bpr1cs_circuit* c, const uint8_t* label, const uint8_t* proofs, const uint8_t* commitments, size_t batch) {
+    if (!g || !c || !label || !proofs || batch == 0 || batch > (1u << 20)) return BPR1CS_ERR_INVALID_ARGUMENT;
+    if (c->m && !commitments) return BPR1CS_ERR_INVALID_ARGUMENT;
+    if (!have_device()) return BPR1CS_ERR_NO_DEVICE;
+    if (g->cap < c->N) return BPR1CS_ERR_INVALID_GENERATORS_LENGTH;
+    if (((uint64_t)4 * c->N + 3ull * c->n + c->m + 64) * batch > 0xffffffffull) return BPR1CS_ERR_INVALID_ARGUMENT;
+    return BPR1CS_OK;
+}
+// transcript replay, flattened constraints, mega-check scalars of the shared bases: gh = g_i | h_i (canonical), bsc (Montgomery)
+static void verify_front(VerifyCtx& v, const bpr1cs_gens* g, const bpr1cs_circuit* c, const uint8_t* label, size_t label_len, const uint8_t* proofs,
+                         const uint8_t* commitments, const uint8_t* verifier_rng_seeds, size_t batch, bool want_bind, dev_stream_t st) {
+    const uint32_t B = v.B = (uint32_t)batch, n = v.n = c->n, m = v.m = c->m, N = v.N = c->N, lgN = v.lgN = c->lgN;
+    v.plen = bpr1cs_proof_len(c);
+    v.d_pf.alloc((size_t)B * v.plen); v.d_vc.alloc((size_t)B * m * 32 + 1); v.d_seed.alloc((size_t)B * 32); v.d_label.alloc(label_len ? label_len : 1);
+    dev_h2d(v.d_pf.p, proofs, (size_t)B * v.plen, st);
+    if (m) dev_h2d(v.d_vc.p, commitments, (size_t)B * m * 32, st);
+    if (verifier_rng_seeds) dev_h2d(v.d_seed.p, verifier_rng_seeds, (size_t)B * 32, st);
+    else dev_zero(v.d_seed.p, (size_t)B * 32, st);
+    if (label_len) dev_h2d(v.d_label.p, label, label_len, st);
+    v.chal.alloc((size_t)VCH_COUNT * B); v.uk.alloc((size_t)(lgN ? lgN : 1) * 2 * B);
+    v.fail.alloc(B);
+    dev_zero(v.fail.p, sizeof(int) * B, st);
+    K_verify_transcript kt{v.d_label.p, (uint32_t)label_len, v.d_pf.p, v.d_vc.p, v.d_seed.p, v.chal.p, v.uk.p, v.fail.p, B, m, lgN, (uint32_t)v.plen, (uint64_t)N};
+    if (want_bind) { v.bind.alloc((size_t)B * 32); kt.bind = v.bind.p; }
+    launch(B, kt, st);
+    uint32_t maxe = std::max<uint32_t>(N, c->q + 1);
+    v.H = (maxe >> 8) + 1;
+    v.plo.alloc((size_t)3 * 256 * B); v.phi.alloc((size_t)3 * v.H * B);
+    launch((uint64_t)3 * B, K_pow_tables{v.chal.p, v.plo.p, v.phi.p, B, v.H}, st);
+    const uint32_t nslots = 3 * n + m + 1;
+    v.wvec.alloc((size_t)nslots * B);
+    run_flatten(c, nslots, v.plo.p, v.phi.p, v.wvec.p, B, v.H, st);
+    v.gh.alloc((size_t)2 * N * B); v.dpart.alloc((size_t)N * B); v.delta.alloc(B); v.bsc.alloc((size_t)2 * B);
+    launch((uint64_t)N * B, K_verify_gh{v.wvec.p, v.plo.p, v.phi.p, v.chal.p, v.uk.p, v.gh.p, v.gh.p + (size_t)N * B, v.dpart.p, B, v.H, n, N, lgN}, st);
+    launch(B, K_sum_partials{v.dpart.p, v.delta.p, B, N}, st);
+    launch(B, K_verify_bscalars{v.chal.p, v.wvec.p + (size_t)(3 * n + m) * B, v.delta.p, v.bsc.p, B}, st);
+    v.P = 8 + m + 2 * lgN;
 }
 
 extern "C" int bpr1cs_verify_batch(const bpr1cs_gens* g, const bpr1cs_circuit* c, const uint8_t* label, size_t label_len,
                                    const uint8_t* proofs, const uint8_t* commitments, const uint8_t* verifier_rng_seeds, size_t batch,
                                    int* ok_out) {
-    if (!g || !c || !label || !proofs || !ok_out || batch == 0 || batch > (1u << 20)) return BPR1CS_ERR_INVALID_ARGUMENT;
-    if (c->m && !commitments) return BPR1CS_ERR_INVALID_ARGUMENT;
-    if (!have_device()) return BPR1CS_ERR_NO_DEVICE;
-    if (g->cap < c->N) return BPR1CS_ERR_INVALID_GENERATORS_LENGTH;
-    const uint32_t B = (uint32_t)batch, n = c->n, m = c->m, N = c->N, lgN = c->lgN;
-    const uint32_t baseG = 2, baseH = 2 + g->cap;
-    const size_t plen = bpr1cs_proof_len(c);
+    if (!ok_out) return BPR1CS_ERR_INVALID_ARGUMENT;
+    int rc = verify_args_ok(g, c, label, proofs, commitments, batch);
+    if (rc) return rc;
+    API_TRY
     dev_stream_t st = g->stream;
-    DevBuf<uint8_t> d_pf((size_t)B * plen), d_vc((size_t)B * m * 32 + 1), d_seed((size_t)B * 32), d_label(label_len ? label_len : 1);
-    dev_h2d(d_pf.p, proofs, (size_t)B * plen, st);
-    if (m) dev_h2d(d_vc.p, commitments, (size_t)B * m * 32, st);
-    if (verifier_rng_seeds) dev_h2d(d_seed.p, verifier_rng_seeds, (size_t)B * 32, st);
-    else dev_zero(d_seed.p, (size_t)B * 32, st);
-    if (label_len) dev_h2d(d_label.p, label, label_len, st);
-    DevBuf<sc> chal((size_t)VCH_COUNT * B), uk((size_t)(lgN ? lgN : 1) * 2 * B);
-    DevBuf<int> fail(B), ok(B);
-    dev_zero(fail.p, sizeof(int) * B, st);
-    launch(B, K_verify_transcript{d_label.p, (uint32_t)label_len, d_pf.p, d_vc.p, d_seed.p, chal.p, uk.p, fail.p, B, m, lgN, (uint32_t)plen, (uint64_t)N}, st);
-    uint32_t maxe = std::max<uint32_t>(N, c->q + 1);
-    uint32_t H = (maxe >> 8) + 1;
-    DevBuf<sc> plo((size_t)3 * 256 * B), phi((size_t)3 * H * B);
-    launch((uint64_t)3 * B, K_pow_tables{chal.p, plo.p, phi.p, B, H}, st);
-    const uint32_t nslots = 3 * n + m + 1;
-    DevBuf<sc> wvec((size_t)nslots * B);
-    run_flatten(c, nslots, plo.p, phi.p, wvec.p, B, H, st);
-    DevBuf<sc> gs((size_t)N * B), hs((size_t)N * B), dpart((size_t)N * B), delta(B), bsc((size_t)2 * B);
-    launch((uint64_t)N * B, K_verify_gh{wvec.p, plo.p, phi.p, chal.p, uk.p, gs.p, hs.p, dpart.p, B, H, n, N, lgN}, st);
-    launch(B, K_sum_partials{dpart.p, delta.p, B, N}, st);
-    launch(B, K_verify_bscalars{chal.p, wvec.p + (size_t)(3 * n + m) * B, delta.p, bsc.p, B}, st);
+    CallScope scope(st);
+    MsmStats stats;
+    VerifyCtx v;
+    verify_front(v, g, c, label, label_len, proofs, commitments, verifier_rng_seeds, batch, false, st);
+    const uint32_t B = v.B, N = v.N, baseG = 2, baseH = 2 + g->cap;
     DevBuf<ge> partial;
     MsmPlan plan;
-    MsmSeg sg{gs.p, N, N, N, 0, baseG, 0}, sh{hs.p, N, N, N, 0, baseH, 0};
-    run_msm(g, sg, sh, B, partial, plan, st);
-    const uint32_t P = 8 + m + 2 * lgN;
-    DevBuf<ge> pts((size_t)P * B);
-    launch((uint64_t)P * B, K_verify_points{d_pf.p, d_vc.p, chal.p, uk.p, wvec.p + (size_t)3 * n * B, pts.p, fail.p, B, m, lgN, (uint32_t)plen}, st);
-    launch(B, K_verify_finish{g->tab.p, g->tc, partial.p, pts.p, bsc.p, fail.p, ok.p, B, plan.nchunks, P}, st);
+    MsmSeg sg{v.gh.p, N, N, N, 0, baseG, 0}, sh{v.gh.p + (size_t)N * B, N, N, N, 0, baseH, 0};
+    run_msm(g, sg, sh, B, partial, plan, st, &stats);
+    DevBuf<ge> pts((size_t)v.P * B);
+    DevBuf<int> ok(B);
+    launch((uint64_t)v.P * B, K_verify_points{v.d_pf.p, v.d_vc.p, v.chal.p, v.uk.p, v.wvec.p + (size_t)3 * v.n * B, pts.p, v.fail.p, B, v.m, v.lgN, (uint32_t)v.plen}, st);
+    launch(B, K_verify_finish{g->tab.p, g->tc, partial.p, pts.p, v.bsc.p, v.fail.p, ok.p, B, plan.nchunks, v.P}, st);
     dev_d2h(ok_out, ok.p, sizeof(int) * B, st);
-    g_msm.collect();
+    stats.collect();
     return BPR1CS_OK;
+    API_CATCH
+}
+
+// Cross-proof batching, first half (shared by the two entry points below): weights, ONE combined scalar per shared
+// base (cgh: G | H canonical; cb: B, B~ Montgomery), and the weighted sum of the proofs' own points reduced to <= 64 points.
+struct CombinedCtx {
+    DevBuf<uint8_t> d_bseed, digest;
+    DevBuf<sc> rho, cgh, cb;
+    DevBuf<ge> pts, red[2];
+    const ge* own = nullptr;
+    uint32_t own_cnt = 0;
+};
+static void verify_combine(CombinedCtx& k, VerifyCtx& v, const uint8_t* batch_seed, uint64_t index_base, dev_stream_t st) {
+    const uint32_t B = v.B, N = v.N;
+    k.d_bseed.alloc(32); k.digest.alloc(32); k.rho.alloc(B);
+    dev_h2d(k.d_bseed.p, batch_seed, 32, st);
+    launch(1, K_batch_digest{k.d_bseed.p, v.bind.p, k.digest.p, index_base, B}, st);
+    launch(B, K_batch_weights{k.digest.p, k.rho.p, index_base}, st);
+    k.cgh.alloc((size_t)2 * N); k.cb.alloc(2);
+    launch((uint64_t)2 * N, K_combine_scalars{v.gh.p, k.rho.p, k.cgh.p, B}, st);
+    launch(2, K_combine_scalars{v.bsc.p, k.rho.p, k.cb.p, B}, st);
+    k.pts.alloc((size_t)v.P * B);
+    K_verify_points kp{v.d_pf.p, v.d_vc.p, v.chal.p, v.uk.p, v.wvec.p + (size_t)3 * v.n * B, k.pts.p, v.fail.p, B, v.m, v.lgN, (uint32_t)v.plen};
+    kp.rho = k.rho.p;
+    launch((uint64_t)v.P * B, kp, st);
+    const ge* cur = k.pts.p;
+    uint32_t cnt = v.P * B;
+    int flip = 0;
+    while (cnt > 64) {
+        uint32_t outc = (cnt + 63) / 64;
+        k.red[flip].alloc(outc);
+        launch(outc, K_ge_reduce{cur, k.red[flip].p, 1, cnt, 64}, st);
+        cur = k.red[flip].p;
+        cnt = outc;
+        flip ^= 1;
+    }
+    k.own = cur;
+    k.own_cnt = cnt;
 }
 
 // Cross-proof batched verification: one identity test for the whole batch (and, summed over ranks, for the whole job).
@@ -1017,64 +1307,22 @@ extern "C" int bpr1cs_verify_batch_combined(const bpr1cs_gens* g, const bpr1cs_c
                                             const uint8_t* proofs, const uint8_t* commitments, const uint8_t* verifier_rng_seeds,
                                             const uint8_t* batch_seed, uint64_t index_base, size_t batch, uint8_t* partial_point_out,
                                             int* wellformed_out) {
-    if (!g || !c || !label || !proofs || !batch_seed || !partial_point_out || !wellformed_out || batch == 0 || batch > (1u << 20))
-        return BPR1CS_ERR_INVALID_ARGUMENT;
-    if (c->m && !commitments) return BPR1CS_ERR_INVALID_ARGUMENT;
-    if (!have_device()) return BPR1CS_ERR_NO_DEVICE;
-    if (g->cap < c->N) return BPR1CS_ERR_INVALID_GENERATORS_LENGTH;
-    const uint32_t B = (uint32_t)batch, n = c->n, m = c->m, N = c->N, lgN = c->lgN;
-    const uint32_t baseG = 2, baseH = 2 + g->cap;
-    const size_t plen = bpr1cs_proof_len(c);
+    if (!batch_seed || !partial_point_out || !wellformed_out) return BPR1CS_ERR_INVALID_ARGUMENT;
+    int rc = verify_args_ok(g, c, label, proofs, commitments, batch);
+    if (rc) return rc;
+    API_TRY
     dev_stream_t st = g->stream;
-    DevBuf<uint8_t> d_pf((size_t)B * plen), d_vc((size_t)B * m * 32 + 1), d_seed((size_t)B * 32), d_label(label_len ? label_len : 1), d_bseed(32);
-    dev_h2d(d_pf.p, proofs, (size_t)B * plen, st);
-    if (m) dev_h2d(d_vc.p, commitments, (size_t)B * m * 32, st);
-    if (verifier_rng_seeds) dev_h2d(d_seed.p, verifier_rng_seeds, (size_t)B * 32, st);
-    else dev_zero(d_seed.p, (size_t)B * 32, st);
-    if (label_len) dev_h2d(d_label.p, label, label_len, st);
-    dev_h2d(d_bseed.p, batch_seed, 32, st);
-    DevBuf<sc> chal((size_t)VCH_COUNT * B), uk((size_t)(lgN ? lgN : 1) * 2 * B), rho(B);
-    DevBuf<int> fail(B);
-    dev_zero(fail.p, sizeof(int) * B, st);
-    launch(B, K_verify_transcript{d_label.p, (uint32_t)label_len, d_pf.p, d_vc.p, d_seed.p, chal.p, uk.p, fail.p, B, m, lgN, (uint32_t)plen, (uint64_t)N}, st);
-    launch(B, K_batch_weights{d_bseed.p, rho.p, index_base}, st);
-    uint32_t maxe = std::max<uint32_t>(N, c->q + 1);
-    uint32_t H = (maxe >> 8) + 1;
-    DevBuf<sc> plo((size_t)3 * 256 * B), phi((size_t)3 * H * B);
-    launch((uint64_t)3 * B, K_pow_tables{chal.p, plo.p, phi.p, B, H}, st);
-    const uint32_t nslots = 3 * n + m + 1;
-    DevBuf<sc> wvec((size_t)nslots * B);
-    run_flatten(c, nslots, plo.p, phi.p, wvec.p, B, H, st);
-    DevBuf<sc> gh((size_t)2 * N * B), dpart((size_t)N * B), delta(B), bsc((size_t)2 * B);
-    sc* gs = gh.p; sc* hs = gh.p + (size_t)N * B;
-    launch((uint64_t)N * B, K_verify_gh{wvec.p, plo.p, phi.p, chal.p, uk.p, gs, hs, dpart.p, B, H, n, N, lgN}, st);
-    launch(B, K_sum_partials{dpart.p, delta.p, B, N}, st);
-    launch(B, K_verify_bscalars{chal.p, wvec.p + (size_t)(3 * n + m) * B, delta.p, bsc.p, B}, st);
-    // one combined scalar per shared base
-    DevBuf<sc> cgh((size_t)2 * N), cb(2);
-    launch((uint64_t)2 * N, K_combine_scalars{gh.p, rho.p, cgh.p, B}, st);
-    launch(2, K_combine_scalars{bsc.p, rho.p, cb.p, B}, st);
+    CallScope scope(st);
+    MsmStats stats;
+    VerifyCtx v;
+    verify_front(v, g, c, label, label_len, proofs, commitments, verifier_rng_seeds, batch, true, st);
+    CombinedCtx k;
+    verify_combine(k, v, batch_seed, index_base, st);
+    const uint32_t N = v.N, baseG = 2, baseH = 2 + g->cap;
     DevBuf<ge> partial;
     MsmPlan plan;
-    MsmSeg sg{cgh.p, N, N, N, 0, baseG, 0}, sh{cgh.p + N, N, N, N, 0, baseH, 0};
-    run_msm(g, sg, sh, 1, partial, plan, st);
-    // the proofs' own points, weighted, then summed over (point, proof)
-    const uint32_t P = 8 + m + 2 * lgN;
-    DevBuf<ge> pts((size_t)P * B), red[2];
-    K_verify_points kp{d_pf.p, d_vc.p, chal.p, uk.p, wvec.p + (size_t)3 * n * B, pts.p, fail.p, B, m, lgN, (uint32_t)plen};
-    kp.rho = rho.p;
-    launch((uint64_t)P * B, kp, st);
-    const ge* cur = pts.p;
-    uint32_t cnt = P * B;
-    int flip = 0;
-    while (cnt > 64) {
-        uint32_t outc = (cnt + 63) / 64;
-        red[flip].alloc(outc);
-        launch(outc, K_ge_reduce{cur, red[flip].p, 1, cnt, 64}, st);
-        cur = red[flip].p;
-        cnt = outc;
-        flip ^= 1;
-    }
+    MsmSeg sg{k.cgh.p, N, N, N, 0, baseG, 0}, sh{k.cgh.p + N, N, N, N, 0, baseH, 0};
+    run_msm(g, sg, sh, 1, partial, plan, st, &stats);
     const ge* mcur = partial.p;
     uint32_t mcnt = plan.nchunks;
     DevBuf<ge> mred[2];
@@ -1087,10 +1335,60 @@ extern "C" int bpr1cs_verify_batch_combined(const bpr1cs_gens* g, const bpr1cs_c
     }
     DevBuf<uint8_t> d_out(32);
     DevBuf<int> d_wf(1);
-    launch(1, K_batch_finish{g->tab.p, g->tc, mcur, cur, cb.p, fail.p, d_out.p, d_wf.p, mcnt, cnt, B}, st);
+    launch(1, K_batch_finish{g->tab.p, g->tc, mcur, k.own, k.cb.p, v.fail.p, d_out.p, d_wf.p, mcnt, k.own_cnt, v.B}, st);
     dev_d2h(partial_point_out, d_out.p, 32, st);
     dev_d2h(wellformed_out, d_wf.p, sizeof(int), st);
-    g_msm.collect();
+    stats.collect();
+    return BPR1CS_OK;
+    API_CATCH
+}
+
+// Multi-GPU form of the batched verifier: instead of evaluating the shared-base MSM itself, a rank
+// returns its combined scalar vector; the ranks add their vectors (all_gather / all_reduce of 2N+2 scalars, ~2 MB at
+// N = 32768), each evaluates 1/world of the bases with bpr1cs_msm_fixed, and the points are gathered and summed.
+extern "C" int bpr1cs_verify_batch_scalars(const bpr1cs_gens* g, const bpr1cs_circuit* c, const uint8_t* label, size_t label_len,
+                                           const uint8_t* proofs, const uint8_t* commitments, const uint8_t* verifier_rng_seeds,
+                                           const uint8_t* batch_seed, uint64_t index_base, size_t batch, uint8_t* combined_scalars_out,
+                                           uint8_t* own_points_sum_out, int* wellformed_out) {
+    if (!batch_seed || !combined_scalars_out || !own_points_sum_out || !wellformed_out) return BPR1CS_ERR_INVALID_ARGUMENT;
+    int rc = verify_args_ok(g, c, label, proofs, commitments, batch);
+    if (rc) return rc;
+    API_TRY
+    dev_stream_t st = g->stream;
+    CallScope scope(st);
+    VerifyCtx v;
+    verify_front(v, g, c, label, label_len, proofs, commitments, verifier_rng_seeds, batch, true, st);
+    CombinedCtx k;
+    verify_combine(k, v, batch_seed, index_base, st);
+    const uint32_t N = v.N;
+    // own points only (no shared-base part, no B / B~ terms): K_batch_finish with zero scalars for B, B~
+    DevBuf<sc> zero2(2);
+    dev_zero(zero2.p, 2 * sizeof(sc), st);
+    DevBuf<uint8_t> d_out(32);
+    DevBuf<int> d_wf(1);
+    launch(1, K_batch_finish{g->tab.p, g->tc, nullptr, k.own, zero2.p, v.fail.p, d_out.p, d_wf.p, 0, k.own_cnt, v.B}, st);
+    dev_d2h(own_points_sum_out, d_out.p, 32, st);
+    dev_d2h(wellformed_out, d_wf.p, sizeof(int), st);
+    // scalars in base order B, B~, G[0..N), H[0..N), canonical bytes
+    std::vector<sc> hb(2), hgh((size_t)2 * N);
+    dev_d2h(hb.data(), k.cb.p, 2 * sizeof(sc), st);
+    dev_d2h(hgh.data(), k.cgh.p, (size_t)2 * N * sizeof(sc), st);
+    sc_mont_tobytes(hb[0], combined_scalars_out);
+    sc_mont_tobytes(hb[1], combined_scalars_out + 32);
+    for (size_t i = 0; i < (size_t)2 * N; i++) sc_store_raw(hgh[i], combined_scalars_out + 64 + 32 * i);
+    return BPR1CS_OK;
+    API_CATCH
+}
+// out = sum of `count` scalar vectors of `len` canonical scalars each (mod l): the reduction step between the two halves
+// of the multi-GPU batched verifier when the host gathers instead of all-reducing
+extern "C" int bpr1cs_scalars_sum(const uint8_t* vectors, size_t count, size_t len, uint8_t* out) {
+    if (!vectors || !out || count == 0 || len == 0) return BPR1CS_ERR_INVALID_ARGUMENT;
+    if (!host_scalars_canonical(vectors, count * len)) return BPR1CS_ERR_INVALID_ARGUMENT;
+    for (size_t i = 0; i < len; i++) {
+        sc acc = sc_load_raw(vectors + 32 * i);
+        for (size_t r = 1; r < count; r++) acc = sc_add(acc, sc_load_raw(vectors + 32 * (r * len + i)));
+        sc_store_raw(acc, out + 32 * i);
+    }
     return BPR1CS_OK;
 }
 
@@ -1099,6 +1397,7 @@ extern "C" int bpr1cs_poseidon_permutation_batch(const bpr1cs_poseidon_params* p
                                                  uint8_t* outputs) {
     if (!params || !inputs || !outputs || count == 0 || count > (1u << 24)) return BPR1CS_ERR_INVALID_ARGUMENT;
     if (!have_device()) return BPR1CS_ERR_NO_DEVICE;
+    API_TRY
     PoseidonTab t;
     std::vector<sc> pc;
     if (!build_poseidon_tab(*params, t, pc)) return BPR1CS_ERR_INVALID_ARGUMENT;
@@ -1106,6 +1405,7 @@ extern "C" int bpr1cs_poseidon_permutation_batch(const bpr1cs_poseidon_params* p
     std::vector<sc> hin((size_t)n * w), hout((size_t)n * w);
     for (size_t i = 0; i < hin.size(); i++) hin[i] = host_mont(inputs + 32 * i);
     dev_stream_t st{};
+    CallScope scope(st);
     DevBuf<sc> d_pc, d_in, d_out((size_t)n * w);
     upload(d_pc, pc, st);
     upload(d_in, hin, st);
@@ -1123,6 +1423,7 @@ extern "C" int bpr1cs_poseidon_permutation_batch(const bpr1cs_poseidon_params* p
     dev_d2h(hout.data(), d_out.p, hout.size() * sizeof(sc), st);
     for (size_t i = 0; i < hout.size(); i++) sc_mont_tobytes(hout[i], outputs + 32 * i);
     return BPR1CS_OK;
+    API_CATCH
 }
 
 // ---- low-level entry points: Merlin transcript on the host, general variable-base MSM on the device
@@ -1130,8 +1431,8 @@ struct bpr1cs_transcript {
     strobe s;
 };
 extern "C" bpr1cs_transcript* bpr1cs_transcript_new(const uint8_t* label, size_t label_len) {
-    bpr1cs_transcript* t = new bpr1cs_transcript();
-    merlin_new(t->s, label, (uint32_t)label_len);
+    bpr1cs_transcript* t = new (std::nothrow) bpr1cs_transcript();
+    if (t) merlin_new(t->s, label, (uint32_t)label_len);
     return t;
 }
 extern "C" void bpr1cs_transcript_free(bpr1cs_transcript* t) { delete t; }
@@ -1141,10 +1442,70 @@ extern "C" void bpr1cs_transcript_append_message(bpr1cs_transcript* t, const uin
 extern "C" void bpr1cs_transcript_challenge_bytes(bpr1cs_transcript* t, const uint8_t* label, size_t label_len, uint8_t* out, size_t out_len) {
     if (t) merlin_challenge_bytes(t->s, (const char*)label, (uint32_t)label_len, out, (uint32_t)out_len);
 }
+// InnerProductProof::create (bulletproofs inner_product_proof.rs; reached from every prove() of the
+// reference, e.g. src/gadget_vsmt_4.rs:434) over the handle's generators G[0..n), H[0..n), for ONE proof, on the device.
+extern "C" int bpr1cs_ipa_create(const bpr1cs_gens* g, bpr1cs_transcript* t, const uint8_t* Q, const uint8_t* G_factors, const uint8_t* H_factors,
+                                 const uint8_t* a, const uint8_t* b, size_t n, uint8_t* L_out, uint8_t* R_out, uint8_t* a_out, uint8_t* b_out) {
+    if (!g || !t || !Q || !G_factors || !H_factors || !a || !b || !a_out || !b_out || n == 0 || (n & (n - 1)) != 0) return BPR1CS_ERR_INVALID_ARGUMENT;
+    if (n > g->cap) return BPR1CS_ERR_INVALID_GENERATORS_LENGTH;
+    if (n > 1 && (!L_out || !R_out)) return BPR1CS_ERR_INVALID_ARGUMENT;
+    if (!have_device()) return BPR1CS_ERR_NO_DEVICE;
+    if (!host_scalars_canonical(G_factors, n) || !host_scalars_canonical(H_factors, n) || !host_scalars_canonical(a, n) || !host_scalars_canonical(b, n))
+        return BPR1CS_ERR_INVALID_ARGUMENT;
+    ge q;
+    if (!ge_decompress(Q, q)) return BPR1CS_ERR_FORMAT;
+    API_TRY
+    const uint32_t N = (uint32_t)n;
+    uint32_t lgN = 0;
+    while ((1u << lgN) < N) lgN++;
+    dev_stream_t st = g->stream;
+    CallScope scope(st);
+    MsmStats stats;
+    // transcript: ("dom-sep", "ipp v1"), ("n", n) are appended by create() itself
+    merlin_append(t->s, "dom-sep", 7, (const uint8_t*)"ipp v1", 6);
+    merlin_append_u64(t->s, "n", 1, (uint64_t)N);
+    DevBuf<strobe> tr(1);
+    DevBuf<ge> dq(1);
+    dev_h2d(tr.p, &t->s, sizeof(strobe), st);
+    dev_h2d(dq.p, &q, sizeof(ge), st);
+    DevBuf<sc> raw((size_t)4 * N), vec((size_t)4 * N);  // a | b | G_factors | H_factors
+    std::vector<sc> h((size_t)4 * N);
+    const uint8_t* src[4] = {a, b, G_factors, H_factors};
+    for (int k = 0; k < 4; k++)
+        for (uint32_t i = 0; i < N; i++) h[(size_t)k * N + i] = sc_load_raw(src[k] + 32 * (size_t)i);
+    dev_h2d(raw.p, h.data(), h.size() * sizeof(sc), st);
+    launch((uint64_t)4 * N, K_load_wires{raw.p, vec.p}, st);
+    DevBuf<uint8_t> LR((size_t)(lgN ? lgN : 1) * 2 * 32), ab(64);
+    DevBuf<sc> uk((size_t)(lgN ? lgN : 1) * 2);
+    const int unfold = g->opts.unfold.load() >= 0 ? g->opts.unfold.load() : g_unfold_rounds.load();
+    IpaIO io{g, 1, N, lgN, (uint32_t)unfold, tr.p, vec.p, vec.p + N, vec.p + (size_t)2 * N, vec.p + (size_t)3 * N, nullptr, dq.p, LR.p, uk.p};
+    enqueue_ipa(io, st, &stats);
+    std::vector<sc> fin(N + 1);
+    dev_d2h(fin.data(), vec.p, (size_t)(N + 1) * sizeof(sc), st);  // a' = vec[0], b' = vec[N]
+    sc_mont_tobytes(fin[0], a_out);
+    sc_mont_tobytes(fin[N], b_out);
+    if (lgN) {
+        std::vector<uint8_t> lr((size_t)lgN * 64);
+        dev_d2h(lr.data(), LR.p, lr.size(), st);
+        for (uint32_t k = 0; k < lgN; k++) {
+            memcpy(L_out + 32 * (size_t)k, lr.data() + 64 * (size_t)k, 32);
+            memcpy(R_out + 32 * (size_t)k, lr.data() + 64 * (size_t)k + 32, 32);
+        }
+    }
+    dev_d2h(&t->s, tr.p, sizeof(strobe), st);
+    dev_zero(raw.p, raw.bytes(), st);
+    dev_zero(vec.p, vec.bytes(), st);
+    stats.collect();
+    return BPR1CS_OK;
+    API_CATCH
+}
 extern "C" int bpr1cs_msm(const uint8_t* scalars, const uint8_t* points, size_t n, uint8_t* out) {
     if (!scalars || !points || !out || n == 0 || n > (1u << 24)) return BPR1CS_ERR_INVALID_ARGUMENT;
     if (!have_device()) return BPR1CS_ERR_NO_DEVICE;
+    if (!host_scalars_canonical(scalars, n)) return BPR1CS_ERR_INVALID_ARGUMENT;
+    API_TRY
     dev_stream_t st{};
+    CallScope scope(st);
     const uint32_t N = (uint32_t)n, VC = N < 4096 ? (N + 63) / 64 : 64;
     DevBuf<uint8_t> d_s(32 * n), d_p(32 * n), d_out(32);
     DevBuf<ge_cached> vtab((size_t)8 * n);
@@ -1163,13 +1524,16 @@ extern "C" int bpr1cs_msm(const uint8_t* scalars, const uint8_t* points, size_t 
     dev_d2h(out, d_out.p, 32, st);
     dev_d2h(&f, fail.p, sizeof(int), st);
     return f ? BPR1CS_ERR_FORMAT : BPR1CS_OK;
+    API_CATCH
 }
 
 // out = compress(sum of `count` compressed points); returns FormatError if one does not decode
 extern "C" int bpr1cs_points_sum(const uint8_t* points, size_t count, uint8_t* out) {
     if (!points || !out || count == 0 || count > (1u << 20)) return BPR1CS_ERR_INVALID_ARGUMENT;
     if (!have_device()) return BPR1CS_ERR_NO_DEVICE;
+    API_TRY
     dev_stream_t st{};
+    CallScope scope(st);
     DevBuf<uint8_t> d_in(32 * count), d_out(32);
     DevBuf<int> d_ok(1);
     dev_h2d(d_in.p, points, 32 * count, st);
@@ -1178,21 +1542,25 @@ extern "C" int bpr1cs_points_sum(const uint8_t* points, size_t count, uint8_t* o
     dev_d2h(out, d_out.p, 32, st);
     dev_d2h(&ok, d_ok.p, sizeof(int), st);
     return ok ? BPR1CS_OK : BPR1CS_ERR_FORMAT;
+    API_CATCH
 }
 
 extern "C" int bpr1cs_msm_fixed(const bpr1cs_gens* g, const uint32_t* bases, size_t terms, const uint8_t* scalars, size_t batch,
                                 uint8_t* out) {
-    if (!g || !bases || !scalars || !out || batch == 0) return BPR1CS_ERR_INVALID_ARGUMENT;
+    if (!g || !bases || !scalars || !out || batch == 0 || terms == 0 || batch > (1u << 20) || terms > (1u << 26)) return BPR1CS_ERR_INVALID_ARGUMENT;
     if (!have_device()) return BPR1CS_ERR_NO_DEVICE;
     uint32_t nb = 2 + 2 * g->cap;
     for (size_t t = 0; t < terms; t++)
         if (bases[t] >= nb) return BPR1CS_ERR_INVALID_ARGUMENT;
-    // general base lists are served as runs of consecutive bases (the common case: one or two runs)
+    if (!host_scalars_canonical(scalars, batch * terms)) return BPR1CS_ERR_INVALID_ARGUMENT;
+    API_TRY
     const uint32_t B = (uint32_t)batch;
     dev_stream_t st = g->stream;
+    CallScope scope(st);
+    MsmStats stats;
     DevBuf<sc> sc_dev;
     upload_transposed(sc_dev, scalars, B, terms, st);
-    DevBuf<ge> acc_partial, partial;
+    // a base list is served as runs of consecutive bases, two runs per job, up to MSM_MAX_JOBS jobs per launch
     std::vector<std::pair<size_t, size_t>> runs;  // [start, len)
     for (size_t t = 0; t < terms;) {
         size_t e = t + 1;
@@ -1200,50 +1568,91 @@ extern "C" int bpr1cs_msm_fixed(const bpr1cs_gens* g, const uint32_t* bases, siz
         runs.push_back({t, e - t});
         t = e;
     }
-    if (runs.size() <= 2) {  // the common shapes (one or two runs of consecutive bases): the prover's own launch geometry
-        auto mk1 = [&](size_t ri) {
-            uint32_t len = (uint32_t)runs[ri].second;
-            return MsmSeg{sc_dev.p + runs[ri].first * (size_t)B, len, len, len, 0, bases[runs[ri].first], 0};
-        };
-        MsmSeg s0 = mk1(0), s1{nullptr, 0, 1, 1, 0, 0, 0};
-        if (runs.size() == 2) s1 = mk1(1);
-        DevBuf<ge> partial;
-        MsmPlan plan;
-        run_msm(g, s0, s1, B, partial, plan, st);
-        DevBuf<uint8_t> d_out1((size_t)B * 32);
-        launch(B, K_msm_finish{g->tab.p, g->tc, partial.p, nullptr, nullptr, d_out1.p, B, plan.nchunks, 0}, st);
-        dev_d2h(out, d_out1.p, (size_t)B * 32, st);
-        g_msm.collect();
-        return BPR1CS_OK;
+    auto mk = [&](size_t ri) {
+        uint32_t len = (uint32_t)runs[ri].second;
+        return MsmSeg{sc_dev.p + runs[ri].first * (size_t)B, len, len, len, 0, bases[runs[ri].first], 0};
+    };
+    const MsmSeg none{nullptr, 0, 1, 1, 0, 0, 0};
+    const size_t njobs = (runs.size() + 1) / 2;
+    std::vector<DevBuf<ge>> parts(njobs);
+    std::vector<MsmPlan> plans(njobs);
+    for (size_t j0 = 0; j0 < njobs; j0 += MSM_MAX_JOBS) {
+        MsmReq rq[MSM_MAX_JOBS];
+        uint32_t cnt = 0;
+        for (size_t j = j0; j < njobs && cnt < MSM_MAX_JOBS; j++, cnt++)
+            rq[cnt] = MsmReq{mk(2 * j), 2 * j + 1 < runs.size() ? mk(2 * j + 1) : none, &parts[j], &plans[j], nullptr};
+        run_msm_multi(g, rq, cnt, B, st, &stats);
     }
-    // accumulate the runs pairwise into chunk partials, then finish once
-    size_t total_chunks = 0;
-    std::vector<ge> dummy;
-    DevBuf<ge> all;
-    std::vector<MsmPlan> plans;
-    // first pass: size
-    for (size_t i = 0; i < runs.size(); i += 2) {
-        uint32_t cnt = (uint32_t)runs[i].second + (i + 1 < runs.size() ? (uint32_t)runs[i + 1].second : 0);
-        uint32_t ch;
-        total_chunks += pick_chunks(cnt, B, 1u << 17, ch);
-    }
-    all.alloc((total_chunks ? total_chunks : 1) * (size_t)B);
+    // gather the jobs' reduced partials into one list for the finish kernel
+    size_t total = 0;
+    for (auto& pl : plans) total += pl.nchunks;
+    DevBuf<ge> all(total * (size_t)B);
     size_t off = 0;
-    for (size_t i = 0; i < runs.size(); i += 2) {
-        auto mk = [&](size_t ri) {
-            uint32_t len = (uint32_t)runs[ri].second;
-            return MsmSeg{sc_dev.p + runs[ri].first * (size_t)B, len, len, len, 0, bases[runs[ri].first], 0};
-        };
-        MsmSeg s0 = mk(i), s1{nullptr, 0, 1, 1, 0, 0, 0};
-        if (i + 1 < runs.size()) s1 = mk(i + 1);
-        uint32_t ch, nc = pick_chunks(s0.count + s1.count, B, 1u << 17, ch);
-        uint32_t nbk = (B + 63u) / 64u;
-        K_msm_fixed k{g->tab.p, g->tc, {s0, s1}, all.p + off * B, B, ch, nbk, nc * nbk};
-        launch_wave((uint64_t)nc * nbk * 64u, k, st);
-        off += nc;
+    for (size_t j = 0; j < njobs; j++) {
+#if defined(BPR1CS_HOSTSIM)
+        memcpy(all.p + off * B, parts[j].p, (size_t)plans[j].nchunks * B * sizeof(ge));
+#else
+        HIPCHK(hipMemcpyAsync(all.p + off * B, parts[j].p, (size_t)plans[j].nchunks * B * sizeof(ge), hipMemcpyDeviceToDevice, st));
+#endif
+        off += plans[j].nchunks;
     }
     DevBuf<uint8_t> d_out((size_t)B * 32);
-    launch(B, K_msm_finish{g->tab.p, g->tc, all.p, nullptr, nullptr, d_out.p, B, (uint32_t)total_chunks, 0}, st);
+    launch(B, K_msm_finish{g->tab.p, g->tc, all.p, nullptr, nullptr, d_out.p, B, (uint32_t)total, 0}, st);
     dev_d2h(out, d_out.p, (size_t)B * 32, st);
+    stats.collect();
+    return BPR1CS_OK;
+    API_CATCH
+}
+
+// ---------------------------------------------------------------- proof wire format
+// R1CSProof::to_bytes / from_bytes of the bulletproofs crate the reference depends on (Cargo.toml:22-26): a version byte
+// (0 = one-phase: the phase-2 commitments are the identity and are not written; 1 = two-phase: 14 leading elements),
+// 32-byte elements, the inner-product proof last.  from_bytes copies points undecoded and demands canonical scalars.
+extern "C" int bpr1cs_proof_parse(const uint8_t* bytes, size_t len, bpr1cs_proof* out) {
+    if (!bytes || !out) return BPR1CS_ERR_INVALID_ARGUMENT;
+    if (len < 1 || (len - 1) % 32 != 0) return BPR1CS_ERR_FORMAT;
+    const uint8_t version = bytes[0];
+    if (version > 1) return BPR1CS_ERR_FORMAT;
+    const size_t k = (len - 1) / 32, lead = version ? 14 : 11;
+    if (k < lead + 2 || ((k - lead - 2) & 1) != 0) return BPR1CS_ERR_FORMAT;
+    const size_t lg = (k - lead - 2) / 2;
+    if (lg >= 32) return BPR1CS_ERR_FORMAT;
+    const uint8_t* el = bytes + 1;
+    memset(out, 0, sizeof *out);
+    auto take = [&](uint8_t* dst) { memcpy(dst, el, 32); el += 32; };
+    take(out->A_I1); take(out->A_O1); take(out->S1);
+    if (version) { take(out->A_I2); take(out->A_O2); take(out->S2); }
+    take(out->T_1); take(out->T_3); take(out->T_4); take(out->T_5); take(out->T_6);
+    take(out->t_x); take(out->t_x_blinding); take(out->e_blinding);
+    out->lg_n = (uint32_t)lg;
+    for (size_t i = 0; i < lg; i++) { take(out->L[i]); take(out->R[i]); }
+    take(out->ipp_a); take(out->ipp_b);
+    if (!host_scalar_canonical(out->t_x) || !host_scalar_canonical(out->t_x_blinding) || !host_scalar_canonical(out->e_blinding) ||
+        !host_scalar_canonical(out->ipp_a) || !host_scalar_canonical(out->ipp_b))
+        return BPR1CS_ERR_FORMAT;
+    return BPR1CS_OK;
+}
+extern "C" size_t bpr1cs_proof_serialized_len(const bpr1cs_proof* p) {
+    if (!p || p->lg_n >= 32) return 0;
+    bool phase2 = false;
+    for (int i = 0; i < 32; i++) phase2 = phase2 || p->A_I2[i] || p->A_O2[i] || p->S2[i];
+    return 1 + 32 * ((phase2 ? 14 : 11) + 2 * (size_t)p->lg_n + 2);
+}
+extern "C" int bpr1cs_proof_serialize(const bpr1cs_proof* p, uint8_t* out, size_t cap, size_t* len_out) {
+    if (!p || !out) return BPR1CS_ERR_INVALID_ARGUMENT;
+    const size_t len = bpr1cs_proof_serialized_len(p);
+    if (len == 0) return BPR1CS_ERR_FORMAT;
+    if (cap < len) return BPR1CS_ERR_INVALID_ARGUMENT;
+    const bool phase2 = len == 1 + 32 * (14 + 2 * (size_t)p->lg_n + 2);
+    uint8_t* o = out;
+    *o++ = phase2 ? 1 : 0;
+    auto put = [&](const uint8_t* src) { memcpy(o, src, 32); o += 32; };
+    put(p->A_I1); put(p->A_O1); put(p->S1);
+    if (phase2) { put(p->A_I2); put(p->A_O2); put(p->S2); }
+    put(p->T_1); put(p->T_3); put(p->T_4); put(p->T_5); put(p->T_6);
+    put(p->t_x); put(p->t_x_blinding); put(p->e_blinding);
+    for (uint32_t i = 0; i < p->lg_n; i++) { put(p->L[i]); put(p->R[i]); }
+    put(p->ipp_a); put(p->ipp_b);
+    if (len_out) *len_out = len;
     return BPR1CS_OK;
 }

@@ -16,6 +16,14 @@
 #include "hd.hpp"
 
 #include <vector>
+// Failures below the C ABI travel as DevError (negative bpr1cs_error code) and are turned into return codes at the
+// boundary (API_TRY / API_CATCH in bpr1cs_impl.hpp): no abort(), no exception crosses the ABI.
+struct DevError {
+    int code;
+};
+#define DEV_ERR_DEVICE (-18)         /* BPR1CS_ERR_DEVICE */
+#define DEV_ERR_OUT_OF_MEMORY (-19)  /* BPR1CS_ERR_OUT_OF_MEMORY */
+#define DEV_ERR_INVALID_ARGUMENT (-17)
 // While an asynchronous job is being enqueued, buffers "freed" by the host code may still be read
 // by kernels in flight: their release is deferred to the job's end (after its stream is idle).
 inline std::vector<void*>*& dev_deferred_frees() {
@@ -36,6 +44,7 @@ inline void dev_zero(void* d, size_t n, dev_stream_t) { memset(d, 0, n); }
 inline void dev_sync(dev_stream_t) {}
 template <class F>
 inline void launch(uint64_t n, const F& f, dev_stream_t) {
+    if (n > 0xffffffffull) throw DevError{DEV_ERR_INVALID_ARGUMENT};
     for (uint64_t g = 0; g < n; g++) f((uint32_t)g);
 }
 template <class F>
@@ -48,13 +57,15 @@ typedef hipStream_t dev_stream_t;
         hipError_t e_ = (x);                                                                       \
         if (e_ != hipSuccess) {                                                                    \
             fprintf(stderr, "bpr1cs: HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); \
-            abort();                                                                               \
+            (void)hipGetLastError();                                                               \
+            throw DevError{e_ == hipErrorOutOfMemory ? DEV_ERR_OUT_OF_MEMORY : DEV_ERR_DEVICE};    \
         }                                                                                          \
     } while (0)
 // Caching allocator: prove_batch needs ~15 GB of scratch per 1024-proof batch; hipMalloc/hipFree
 // of that size cost seconds per call.  Freed blocks are kept and reused (best fit within 25 %).
-// Safe because every API call runs on ONE stream and ends synchronised: a block is only ever
-// re-used by work that is stream-ordered after the work that freed it.
+// A block only reaches the pool once no kernel can still touch it: every API entry point collects the buffers it
+// releases (dev_deferred_frees) and hands them back after its stream has drained (CallScope / bpr1cs_prove_batch_end),
+// so a block handed to another thread or stream is never live.
 #include <map>
 #include <mutex>
 struct DevPool {
@@ -75,6 +86,7 @@ struct DevPool {
         void* p = nullptr;
         hipError_t e = hipMalloc(&p, n);
         if (e != hipSuccess) {  // out of memory: drop the cache and retry once
+            (void)hipGetLastError();
             for (auto& kv : free_blocks) (void)hipFree(kv.second);
             free_blocks.clear();
             HIPCHK(hipMalloc(&p, n));
@@ -125,10 +137,7 @@ __global__ void __launch_bounds__(256) k_functor(F f, uint32_t n) {
 template <class F>
 inline void launch(uint64_t n, const F& f, dev_stream_t s) {
     if (n == 0) return;
-    if (n > 0xffffffffull) {
-        fprintf(stderr, "bpr1cs: grid too large\n");
-        abort();
-    }
+    if (n > 0xffffffffull) throw DevError{DEV_ERR_INVALID_ARGUMENT};  // entry points bound their batch so that this cannot happen
     uint32_t blocks = (uint32_t)((n + 255) / 256);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_functor<F>), dim3(blocks), dim3(256), 0, s, f, (uint32_t)n);
     HIPCHK(hipGetLastError());
@@ -148,10 +157,7 @@ __global__ void __launch_bounds__(64) k_functor_wave(F f, uint32_t n) {
 template <class F>
 inline void launch_wave(uint64_t n, const F& f, dev_stream_t s) {
     if (n == 0) return;
-    if (n > 0xffffffffull) {
-        fprintf(stderr, "bpr1cs: grid too large\n");
-        abort();
-    }
+    if (n > 0xffffffffull) throw DevError{DEV_ERR_INVALID_ARGUMENT};
     uint32_t blocks = (uint32_t)((n + 63) / 64);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_functor_wave<F>), dim3(blocks), dim3(64), 0, s, f, (uint32_t)n);
     HIPCHK(hipGetLastError());

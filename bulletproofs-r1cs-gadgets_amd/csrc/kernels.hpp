@@ -712,6 +712,7 @@ struct K_msm_finish {  // gid = b
     uint32_t B, nchunks, extra_base;
     const ge* partial_b = nullptr;  // optional second list of partial sums (a second launch's)
     uint32_t nchunks_b = 0;
+    const ge* extra_pt = nullptr;   // optional: the extra term is extra * extra_pt[b] (an arbitrary point: Q of bpr1cs_ipa_create)
     HD void operator()(uint32_t b) const {
         ge acc = ge_identity();
         for (uint32_t c = 0; c < nchunks; c++) acc = ge_add_ge(acc, partial[(size_t)c * B + b]);
@@ -719,7 +720,8 @@ struct K_msm_finish {  // gid = b
         if (extra) {
             sc e = extra[b];
             e = extra2 ? sc_from_mont(sc_mul(e, extra2[b])) : sc_from_mont(e);
-            acc = table_mul_acc(acc, tab + (size_t)extra_base * tc.base_bytes(), e, tc);
+            if (extra_pt) acc = ge_add_ge(acc, ge_scalarmul_naf(extra_pt[b], e));
+            else acc = table_mul_acc(acc, tab + (size_t)extra_base * tc.base_bytes(), e, tc);
         }
         ge_compress(acc, out + 32 * (size_t)b);
     }
@@ -1155,6 +1157,7 @@ struct K_verify_transcript {  // gid = b
     int* fail;              // [B]
     uint32_t B, m, lgN, plen;
     uint64_t padded_n;
+    uint8_t* bind = nullptr;  // optional [B][32]
     HD void operator()(uint32_t b) const {
         const uint8_t* pf = proofs + (size_t)b * plen;
         int bad = pf[0] != 0;  // one-phase format byte (R1CSProof::from_bytes -> FormatError)
@@ -1201,6 +1204,10 @@ struct K_verify_transcript {  // gid = b
             sc uu = merlin_challenge_scalar(s, "u", 1);
             uk[((size_t)k * 2 + 0) * B + b] = uu;
             uk[((size_t)k * 2 + 1) * B + b] = sc_invert(uu);
+        }
+        if (bind) {  // 32 bytes that depend on every byte of this proof and of its commitments (cross-proof batching)
+            strobe t = s;
+            merlin_challenge_bytes(t, "bpr1cs-bind", 11, bind + 32 * (size_t)b, 32);
         }
         // verifier's TranscriptRng: no witness, external 32 bytes made explicit
         merlin_rng_finalize(s, seeds + 32 * (size_t)b);
@@ -1319,15 +1326,35 @@ struct K_verify_points {  // gid = p*B + b, p < 8 + m + 2 lgN
 };
 // ---- cross-proof batching of the mega-check (SURVEY §8a P10 "batchable across proofs", §8e): with per-proof
 // weights rho_b the B checks collapse into ONE identity test; the 2N+2 shared bases get one combined scalar each.
-struct K_batch_weights {  // gid = b : rho_b = challenge("rho") of Merlin("bpr1cs batch verify") <- seed, index
+// The weights must be unpredictable to whoever chose the proofs: they are drawn from a transcript that absorbs the
+// caller's seed (fresh randomness) AND a binding value of every proof and commitment of the batch, so no proof can be
+// crafted against weights known in advance (a forger would need sum_j rho_j * defect_j = 0).
+struct K_batch_digest {  // single thread: D = challenge("digest") of Merlin("bpr1cs batch verify") <- seed, index_base, B, bind[0..B)
     const uint8_t* seed;  // 32 bytes
-    sc* rho;              // [B] Montgomery
+    const uint8_t* bind;  // [B][32]
+    uint8_t* digest;      // 32 bytes
     uint64_t index_base;
-    HD void operator()(uint32_t b) const {
+    uint32_t B;
+    HD void operator()(uint32_t) const {
         strobe t;
         const char lab[] = "bpr1cs batch verify";
         merlin_new(t, (const uint8_t*)lab, sizeof(lab) - 1);
         merlin_append(t, "seed", 4, seed, 32);
+        merlin_append_u64(t, "base", 4, index_base);
+        merlin_append_u64(t, "count", 5, B);
+        for (uint32_t b = 0; b < B; b++) merlin_append(t, "proof", 5, bind + 32 * (size_t)b, 32);
+        merlin_challenge_bytes(t, "digest", 6, digest, 32);
+    }
+};
+struct K_batch_weights {  // gid = b : rho_b = challenge("rho") of Merlin("bpr1cs batch weight") <- digest, index_base + b
+    const uint8_t* digest;  // 32 bytes
+    sc* rho;                // [B] Montgomery
+    uint64_t index_base;
+    HD void operator()(uint32_t b) const {
+        strobe t;
+        const char lab[] = "bpr1cs batch weight";
+        merlin_new(t, (const uint8_t*)lab, sizeof(lab) - 1);
+        merlin_append(t, "digest", 6, digest, 32);
         merlin_append_u64(t, "j", 1, index_base + b);
         rho[b] = merlin_challenge_scalar(t, "rho", 3);
     }

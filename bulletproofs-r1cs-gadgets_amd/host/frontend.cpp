@@ -44,13 +44,12 @@ R1CSProof Prover::prove(const BulletproofGens& bp_gens) {
         std::random_device rd;  // stands in for rand::thread_rng()
         for (auto& x : seed) x = (uint8_t)rd();
     }
-    R1CSProof proof;
-    proof.bytes.resize(bpr1cs_proof_len(c));
+    std::vector<uint8_t> bytes(bpr1cs_proof_len(c));
     rc = bpr1cs_prove_batch(bp_gens.h, c, (const uint8_t*)transcript.label.data(), transcript.label.size(), vals.data(), bls.data(),
-                            seed.data(), wires.data(), 1, proof.bytes.data(), nullptr);
+                            seed.data(), wires.data(), 1, bytes.data(), nullptr);
     bpr1cs_circuit_destroy(c);
     if (rc) throw R1CSError::Backend(rc);
-    return proof;
+    return R1CSProof::from_bytes(bytes);
 }
 
 void Verifier::verify(const R1CSProof& proof, const PedersenGens&, const BulletproofGens& bp_gens, const std::array<uint8_t, 32>* rng_seed) {
@@ -66,9 +65,10 @@ void Verifier::verify(const R1CSProof& proof, const PedersenGens&, const Bulletp
     bpr1cs_circuit* c = nullptr;
     int rc = bpr1cs_circuit_create(&d, &c);
     if (rc) throw R1CSError::Backend(rc);
-    if (proof.bytes.size() != bpr1cs_proof_len(c)) {  // R1CSProof::from_bytes / wrong IPA length
-        bpr1cs_circuit_destroy(c);
-        throw R1CSError::FormatError();
+    std::vector<uint8_t> bytes = proof.to_bytes();
+    if (bytes.size() != bpr1cs_proof_len(c)) {  // wrong number of IPA rounds for this circuit, or phase-2 commitments present
+        bpr1cs_circuit_destroy(c);               // (this repository's gadgets have no randomized constraints: upstream rejects likewise)
+        throw R1CSError::VerificationError();
     }
     std::vector<uint8_t> comms(32 * V_.size() + 1);
     for (size_t i = 0; i < V_.size(); i++) memcpy(&comms[32 * i], V_[i].data(), 32);
@@ -79,7 +79,7 @@ void Verifier::verify(const R1CSProof& proof, const PedersenGens&, const Bulletp
         for (auto& x : seed) x = (uint8_t)rd();
     }
     int ok = 0;
-    rc = bpr1cs_verify_batch(bp_gens.h, c, (const uint8_t*)transcript.label.data(), transcript.label.size(), proof.bytes.data(),
+    rc = bpr1cs_verify_batch(bp_gens.h, c, (const uint8_t*)transcript.label.data(), transcript.label.size(), bytes.data(),
                              comms.data(), seed.data(), 1, &ok);
     bpr1cs_circuit_destroy(c);
     if (rc) throw R1CSError::Backend(rc);
@@ -407,9 +407,10 @@ int bpr1cs_gadget_prove_single(const char* gadget, const uint32_t* iparams, size
         memcpy(seed.data(), rng_seed, 32);
         prover.set_rng_seed(seed);
         R1CSProof proof = prover.prove(bp_gens);
-        if (proof.bytes.size() > proof_cap) return BPR1CS_ERR_INVALID_ARGUMENT;
-        memcpy(proof_out, proof.bytes.data(), proof.bytes.size());
-        *proof_len = proof.bytes.size();
+        std::vector<uint8_t> bytes = proof.to_bytes();
+        if (bytes.size() > proof_cap) return BPR1CS_ERR_INVALID_ARGUMENT;
+        memcpy(proof_out, bytes.data(), bytes.size());
+        *proof_len = bytes.size();
         if (commitments_out)
             for (size_t i = 0; i < comms.size(); i++) memcpy(commitments_out + 32 * i, comms[i].data(), 32);
         return BPR1CS_OK;
@@ -439,10 +440,8 @@ int bpr1cs_gadget_verify_single(const char* gadget, const uint32_t* iparams, siz
                   },
                   [](size_t) { return std::optional<Scalar>(); }, [](size_t) { return std::optional<uint64_t>(); }};
         run_gadget(g, h);
-        R1CSProof p;
-        p.bytes.assign(proof, proof + proof_len);
-        std::array<uint8_t, 32> seed{};
-        verifier.verify(p, pc_gens, bp_gens, &seed);
+        R1CSProof p = R1CSProof::from_bytes(proof, proof_len);  // FormatError: bad version / length / non-canonical scalar
+        verifier.verify(p, pc_gens, bp_gens, nullptr);          // the verifier's r from fresh randomness (rand::thread_rng upstream)
         return BPR1CS_OK;
     } catch (const R1CSError& e) {
         return e.code;

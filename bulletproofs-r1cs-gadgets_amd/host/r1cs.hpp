@@ -233,9 +233,26 @@ public:
     CompressedRistretto B, B_blinding;
 };
 
+// bulletproofs::r1cs::R1CSProof: the typed proof the reference's helpers return and consume
+// (src/gadget_bound_check.rs:49-116, src/gadget_set_membership.rs:93-171) with upstream's wire format
+// (to_bytes / from_bytes; one-phase form when the phase-2 commitments are the identity).
 struct R1CSProof {
-    std::vector<uint8_t> bytes;
-    const std::vector<uint8_t>& to_bytes() const { return bytes; }
+    bpr1cs_proof f{};  // A_I1 .. e_blinding, inner-product proof (L, R, a, b): see include/bpr1cs.h
+    std::vector<uint8_t> to_bytes() const {
+        std::vector<uint8_t> out(bpr1cs_proof_serialized_len(&f));
+        size_t len = 0;
+        int rc = bpr1cs_proof_serialize(&f, out.data(), out.size(), &len);
+        if (rc) throw R1CSError::FormatError();
+        out.resize(len);
+        return out;
+    }
+    static R1CSProof from_bytes(const uint8_t* b, size_t len) {
+        R1CSProof p;
+        if (bpr1cs_proof_parse(b, len, &p.f) != 0) throw R1CSError::FormatError();
+        return p;
+    }
+    static R1CSProof from_bytes(const std::vector<uint8_t>& b) { return from_bytes(b.data(), b.size()); }
+    size_t ipp_rounds() const { return f.lg_n; }
 };
 
 // shared bookkeeping of the three constraint systems

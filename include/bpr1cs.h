@@ -12,9 +12,16 @@
  * encodings (Scalar::to_bytes / CompressedRistretto); all buffers are
  * caller-owned host memory unless a name ends in `_dev`; return 0 = OK,
  * negative = bpr1cs_error (mirrors R1CSError).  No exceptions cross the ABI.
- * Handles may be used from one thread at a time; distinct handles are
- * independent.  There is NO CPU fallback: every compute entry point fails with
- * BPR1CS_ERR_NO_DEVICE when no gfx950 device is visible.
+ * Threading: a handle may be used from one thread at a time; distinct handles are
+ * independent (two threads may prove / verify concurrently on two bpr1cs_gens handles,
+ * sharing a bpr1cs_circuit); the bpr1cs_set_* knobs only set process-wide DEFAULTS that
+ * are read when a handle is created or a call starts - per-handle overrides:
+ * bpr1cs_gens_set_option.  bpr1cs_last_* report the last prove job that ended on the
+ * calling thread.  There is NO CPU fallback: every compute entry point fails with
+ * BPR1CS_ERR_NO_DEVICE when no gfx950 device is visible.  Device failures (HIP errors,
+ * out of memory) are reported as BPR1CS_ERR_DEVICE / BPR1CS_ERR_OUT_OF_MEMORY; the
+ * library never aborts the process.  All scalar inputs must be canonical (< l);
+ * non-canonical scalars are refused with BPR1CS_ERR_INVALID_ARGUMENT.
  */
 #ifndef BPR1CS_H
 #define BPR1CS_H
@@ -32,7 +39,9 @@ typedef enum {
     BPR1CS_ERR_MISSING_ASSIGNMENT = -4,        /* R1CSError::MissingAssignment      */
     BPR1CS_ERR_GADGET = -5,                    /* R1CSError::GadgetError            */
     BPR1CS_ERR_NO_DEVICE = -16,
-    BPR1CS_ERR_INVALID_ARGUMENT = -17
+    BPR1CS_ERR_INVALID_ARGUMENT = -17,
+    BPR1CS_ERR_DEVICE = -18,       /* a HIP call failed */
+    BPR1CS_ERR_OUT_OF_MEMORY = -19 /* device (or host) memory exhausted, also after dropping the allocator cache */
 } bpr1cs_error;
 
 typedef struct bpr1cs_gens bpr1cs_gens;       /* PedersenGens::default() + BulletproofGens::new(cap, 1) */
@@ -106,6 +115,19 @@ uint32_t bpr1cs_gens_capacity(const bpr1cs_gens* g);
 /* which: 0 = B, 1 = B_blinding, 2 = G[i], 3 = H[i]; compressed encoding */
 int bpr1cs_gens_point(const bpr1cs_gens* g, int which, uint32_t i, uint8_t out[32]);
 
+/* geometry of the handle's fixed-base tables: window bits W, windows per scalar, storage format (bpr1cs_set_table_format), bytes */
+int bpr1cs_gens_table_info(const bpr1cs_gens* g, uint32_t* window_bits, uint32_t* windows, uint32_t* format, uint64_t* bytes);
+/* per-handle override of a per-call knob (value < 0: back to the process default set by bpr1cs_set_*) */
+#define BPR1CS_OPT_UNFOLD_ROUNDS 0 /* bpr1cs_set_unfold_rounds */
+#define BPR1CS_OPT_RNG_MODE 1      /* bpr1cs_set_rng_mode      */
+#define BPR1CS_OPT_WITNESS_TEAM 2  /* bpr1cs_set_witness_team  */
+int bpr1cs_gens_set_option(bpr1cs_gens* g, int option, int value);
+/* give the device memory cached by the library's allocator (freed tables, workspaces) back to the driver */
+int bpr1cs_release_cached_memory(void);
+
+/* Every index, offset and operand kind of `desc` is validated (constraint terms, witness program, linear combinations:
+ * a multiplier's operands may only refer to committed values and to wires of EARLIER multipliers);
+ * BPR1CS_ERR_INVALID_ARGUMENT otherwise.  poseidon_perm.sbox_mul must hold one entry per S-box of its parameter set. */
 int bpr1cs_circuit_create(const bpr1cs_circuit_desc* desc, bpr1cs_circuit** out);
 void bpr1cs_circuit_destroy(bpr1cs_circuit* c);
 /* proof length in bytes: 1 + 32*(13 + 2*lg(next_pow2(n))) */
@@ -152,6 +174,11 @@ int bpr1cs_verify_batch(const bpr1cs_gens* g, const bpr1cs_circuit* c, const uin
  * at a time, gadget_vsmt_4.rs:479).  With weights rho_j = Merlin("bpr1cs batch verify", seed, index_base + j) the
  * `batch` mega-checks collapse into one: the 2N+2 shared bases B, B~, G_i, H_i get ONE combined scalar each
  * (sum_j rho_j * scalar_j) and a single fixed-base MSM; only the proofs' own points are handled per proof.
+ * SECURITY: `batch_seed` must be 32 bytes of FRESH SECRET randomness drawn by the verifier after the proofs were
+ * received (e.g. getrandom); the weights are derived from it together with a binding value of every proof and
+ * commitment of the batch, so they cannot be predicted by whoever produced the proofs.  A public or constant seed
+ * only leaves the binding (deterministic, proof-dependent weights).  `verifier_rng_seeds` = NULL likewise makes
+ * each proof's own challenge r deterministic; pass fresh randomness in production.
  * Output: this caller's partial point (32-byte compressed) and whether all proofs were well-formed.  A job sharded
  * over several GPUs gives every rank a disjoint `index_base` range, gathers the ranks' points (RCCL all_gather of
  * 32 bytes per rank, see bulletproofs-r1cs-gadgets_amd/sharding.py) and accepts iff bpr1cs_points_sum of them is the
@@ -161,6 +188,20 @@ int bpr1cs_verify_batch_combined(const bpr1cs_gens* gens, const bpr1cs_circuit* 
                                  const uint8_t* proofs, const uint8_t* commitments, const uint8_t* verifier_rng_seeds,
                                  const uint8_t* batch_seed /* 32 */, uint64_t index_base, size_t batch,
                                  uint8_t* partial_point_out /* 32 */, int* wellformed_out);
+/* Multi-GPU form: the same checks, but instead of evaluating the shared-base part itself the caller gets
+ *   combined_scalars_out  (2N+2)*32 canonical scalars in base order B, B_blinding, G[0..N), H[0..N)   (N = padded n)
+ *   own_points_sum_out    the weighted sum of its proofs' own points (A_I1.., V, T, L, R), compressed
+ * The ranks add their scalar vectors (all_reduce / all_gather + bpr1cs_scalars_sum, ~2 MB at N = 32768), every rank
+ * evaluates a 1/world slice of the bases with bpr1cs_msm_fixed(bases [first, first+count), batch 1), the slice points
+ * and the own-points sums are gathered, and the job is accepted iff bpr1cs_points_sum of all of them is the identity
+ * and every rank was well-formed.  The shared-base MSM is then computed ONCE per job instead of once per rank. */
+int bpr1cs_verify_batch_scalars(const bpr1cs_gens* gens, const bpr1cs_circuit* circuit, const uint8_t* label, size_t label_len,
+                                const uint8_t* proofs, const uint8_t* commitments, const uint8_t* verifier_rng_seeds,
+                                const uint8_t* batch_seed /* 32 */, uint64_t index_base, size_t batch,
+                                uint8_t* combined_scalars_out, uint8_t* own_points_sum_out /* 32 */, int* wellformed_out);
+/* out[i] = sum_r vectors[r*len + i] mod l   (count vectors of len canonical scalars; host side) */
+int bpr1cs_scalars_sum(const uint8_t* vectors, size_t count, size_t len, uint8_t* out);
+
 /* `count` native Poseidon permutations (reference Poseidon_permutation, gadget_poseidon.rs:189-280; sbox_inverse
  * selects SboxType::Inverse / Cube): inputs/outputs are count*width canonical scalars.  With the Inverse S-box each
  * permutation costs ONE inversion (state carried as fractions, as in the witness program).  Used by the sparse
@@ -174,6 +215,14 @@ bpr1cs_transcript* bpr1cs_transcript_new(const uint8_t* label, size_t label_len)
 void bpr1cs_transcript_free(bpr1cs_transcript* t);
 void bpr1cs_transcript_append_message(bpr1cs_transcript* t, const uint8_t* label, size_t label_len, const uint8_t* msg, size_t msg_len);
 void bpr1cs_transcript_challenge_bytes(bpr1cs_transcript* t, const uint8_t* label, size_t label_len, uint8_t* out, size_t out_len);
+/* InnerProductProof::create(transcript, &Q, G_factors, H_factors, G, H, a, b) of the bulletproofs crate (the last step of
+ * every Prover::prove, reference src/gadget_vsmt_4.rs:434) for ONE proof over the handle's generators G[0..n), H[0..n):
+ * appends ("dom-sep","ipp v1"), ("n", n) to `t`, runs the lg n rounds on the device (appending L_k, R_k and drawing u_k),
+ * leaves `t` in the state the caller's protocol continues from.  n: a power of two <= capacity; scalars canonical.
+ * L_out / R_out: lg n compressed points each; a_out / b_out: the final scalars. */
+int bpr1cs_ipa_create(const bpr1cs_gens* g, bpr1cs_transcript* t, const uint8_t* Q /* 32, compressed */, const uint8_t* G_factors /* n*32 */,
+                      const uint8_t* H_factors /* n*32 */, const uint8_t* a /* n*32 */, const uint8_t* b /* n*32 */, size_t n,
+                      uint8_t* L_out /* lg n * 32 */, uint8_t* R_out /* lg n * 32 */, uint8_t* a_out /* 32 */, uint8_t* b_out /* 32 */);
 /* RistrettoPoint::vartime_multiscalar_mul over arbitrary (compressed) points: out = sum_i scalars[i] * points[i], on the
  * device (Straus with shared doublings, as the variable-base IPA rounds).  BPR1CS_ERR_FORMAT if a point does not decode. */
 int bpr1cs_msm(const uint8_t* scalars /* n*32 canonical */, const uint8_t* points /* n*32 compressed */, size_t n, uint8_t* out /* 32 */);
@@ -187,6 +236,26 @@ int bpr1cs_points_sum(const uint8_t* points, size_t count, uint8_t* out);
  * (replaces RistrettoPoint::multiscalar_mul over the generators). */
 int bpr1cs_msm_fixed(const bpr1cs_gens* g, const uint32_t* bases, size_t terms, const uint8_t* scalars /* batch*terms*32 */,
                      size_t batch, uint8_t* out /* batch*32 */);
+
+/* ---- proof wire format: R1CSProof::to_bytes / from_bytes of the bulletproofs crate behind the reference's
+ * typed helpers (src/gadget_bound_check.rs:49-116, src/gadget_set_membership.rs:93-171).  Version byte 0 = one-phase (the
+ * phase-2 commitments are the identity and are not written; what this library's prover emits), 1 = two-phase.  Points are
+ * kept as their 32-byte encodings (not decoded, as upstream); scalars must be canonical. */
+typedef struct {
+    uint8_t A_I1[32], A_O1[32], S1[32];
+    uint8_t A_I2[32], A_O2[32], S2[32]; /* all zero (identity) in a one-phase proof */
+    uint8_t T_1[32], T_3[32], T_4[32], T_5[32], T_6[32];
+    uint8_t t_x[32], t_x_blinding[32], e_blinding[32];
+    uint32_t lg_n;                      /* rounds of the inner-product proof, < 32 */
+    uint8_t L[32][32], R[32][32];
+    uint8_t ipp_a[32], ipp_b[32];
+} bpr1cs_proof;
+/* BPR1CS_ERR_FORMAT: unknown version byte, (len-1) not a multiple of 32, too few / an odd number of IPA elements,
+ * lg_n >= 32, or a non-canonical scalar. */
+int bpr1cs_proof_parse(const uint8_t* bytes, size_t len, bpr1cs_proof* out);
+size_t bpr1cs_proof_serialized_len(const bpr1cs_proof* p);
+/* one-phase form when A_I2 = A_O2 = S2 = identity, two-phase form otherwise (as R1CSProof::to_bytes) */
+int bpr1cs_proof_serialize(const bpr1cs_proof* p, uint8_t* out, size_t cap, size_t* len_out);
 
 /* tuning knob: IPA rounds computed from the un-folded generator tables before the
  * folded generators are materialised (default 4; clamped to lg N) */
@@ -232,11 +301,11 @@ int bpr1cs_circuit_macro_perms(const bpr1cs_circuit* c);
  * (measured 1270 -> 830 proofs/s synchronous), see DESIGN.md. */
 void bpr1cs_set_latency_cus(int n);
 
-/* last prove_batch phase timings in milliseconds (HIP events), for bench.py:
+/* phase timings in milliseconds (HIP events) of the last prove job that ended on the calling thread, for bench.py:
  * [0]=total [1]=inputs+V commitments [2]=RNG stream || witness synthesis [3]=commit MSMs [4]=polys [5]=IPA; returns count */
 int bpr1cs_last_timings(float* out, int cap);
 
-/* HIP-event statistics of the dominant kernel (batched fixed-base MSM) over the last prove_batch:
+/* HIP-event statistics of the dominant kernel (batched fixed-base MSM) over the last prove job that ended on this thread:
  * summed launch durations (ms, events recorded on the kernel's own stream), number of launches and
  * number of scalar*point terms processed (summed over the batch). */
 int bpr1cs_last_msm_stats(double* ms_total, uint64_t* launches, uint64_t* terms);
