@@ -38,6 +38,13 @@ def sc(x):
     return int(x).to_bytes(32, "little")
 
 
+def synth_rng_seed(global_index):
+    """SYNTHETIC stand-in for the 32 bytes upstream draws from thread_rng() in TranscriptRng::finalize: SHA-256("seed" ||
+    LE64(j)) of the global proof index - reproducible proofs for the parity check; a deployment passes
+    fresh randomness."""
+    return hashlib.sha256(b"seed" + int(global_index).to_bytes(8, "little")).digest()
+
+
 def build_workload(bp, levels, batch, n_leaves, seed_base):
     """Synthetic leaves in a depth-`levels` 4-ary sparse Merkle tree (reference
     src/gadget_vsmt_4.rs:363-419): leaves i->i for i in 1..=10 plus synthetic (idx, val) pairs;
@@ -65,8 +72,7 @@ def build_workload(bp, levels, batch, n_leaves, seed_base):
         for k in range(m - 2):
             bl += sc(synth_scalar(b"blind", (seed_base + j) * 1024 + k))
         bl += bytes(64)  # statics are committed with blinding 0 (gadget_poseidon.rs:554-578)
-    sh = importlib.import_module("bulletproofs-r1cs-gadgets_amd.sharding")
-    seeds = b"".join(sh.rng_seed(seed_base + j) for j in range(batch))
+    seeds = b"".join(synth_rng_seed(seed_base + j) for j in range(batch))
     return tree.root(), values, bytes(bl), seeds, m
 
 

@@ -48,6 +48,18 @@ class _CircuitDesc(ctypes.Structure):
 _lib = None
 
 
+_B32 = ctypes.c_uint8 * 32
+
+
+class ProofStruct(ctypes.Structure):
+    """bpr1cs_proof (include/bpr1cs.h): the typed R1CSProof."""
+    _fields_ = [(k, _B32) for k in ("A_I1", "A_O1", "S1", "A_I2", "A_O2", "S2", "T_1", "T_3", "T_4", "T_5", "T_6", "t_x", "t_x_blinding", "e_blinding")] + \
+               [("lg_n", ctypes.c_uint32), ("L", _B32 * 32), ("R", _B32 * 32), ("ipp_a", _B32), ("ipp_b", _B32)]
+
+
+OPT_UNFOLD_ROUNDS, OPT_RNG_MODE, OPT_WITNESS_TEAM = 0, 1, 2
+
+
 def load_library(path=None):
     """Load libbpr1cs_hip.so (or an ABI-compatible test build when `path` is given)."""
     global _lib
@@ -93,6 +105,15 @@ def load_library(path=None):
     lib.bpr1cs_circuit_macro_perms.argtypes = [ctypes.c_void_p]
     lib.bpr1cs_circuit_macro_perms.restype = ctypes.c_int
     lib.bpr1cs_set_latency_cus.argtypes = [ctypes.c_int]
+    lib.bpr1cs_gens_set_option.argtypes = [vp, ctypes.c_int, ctypes.c_int]
+    lib.bpr1cs_gens_table_info.argtypes = [vp, ctypes.POINTER(u32), ctypes.POINTER(u32), ctypes.POINTER(u32), ctypes.POINTER(ctypes.c_uint64)]
+    lib.bpr1cs_verify_batch_scalars.argtypes = [vp, vp, cp, sz, cp, cp, cp, cp, ctypes.c_uint64, sz, cp, cp, ctypes.POINTER(ctypes.c_int)]
+    lib.bpr1cs_scalars_sum.argtypes = [cp, sz, sz, cp]
+    lib.bpr1cs_ipa_create.argtypes = [vp, vp, cp, cp, cp, cp, cp, sz, cp, cp, cp, cp]
+    lib.bpr1cs_proof_parse.argtypes = [cp, sz, ctypes.POINTER(ProofStruct)]
+    lib.bpr1cs_proof_serialize.argtypes = [ctypes.POINTER(ProofStruct), cp, sz, ctypes.POINTER(sz)]
+    lib.bpr1cs_proof_serialized_len.argtypes = [ctypes.POINTER(ProofStruct)]
+    lib.bpr1cs_proof_serialized_len.restype = sz
     lib.bpr1cs_last_timings.argtypes = [ctypes.POINTER(ctypes.c_float), ctypes.c_int]
     lib.bpr1cs_last_msm_stats.argtypes = [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]
     if path is None:
@@ -129,6 +150,16 @@ class Gens:
         _chk(self.lib.bpr1cs_msm_fixed(self.h, _u32arr(bases), len(bases), scalars, batch, out))
         raw = out.raw
         return [raw[32 * i:32 * i + 32] for i in range(batch)]
+
+    def set_option(self, option, value):
+        """per-handle override of a per-call knob (OPT_UNFOLD_ROUNDS / OPT_RNG_MODE / OPT_WITNESS_TEAM; value < 0: process default)"""
+        _chk(self.lib.bpr1cs_gens_set_option(self.h, option, value))
+
+    def table_info(self):
+        """-> dict(window_bits, windows, format, bytes) of the fixed-base tables"""
+        w, k, f, b = ctypes.c_uint32(), ctypes.c_uint32(), ctypes.c_uint32(), ctypes.c_uint64()
+        _chk(self.lib.bpr1cs_gens_table_info(self.h, ctypes.byref(w), ctypes.byref(k), ctypes.byref(f), ctypes.byref(b)))
+        return dict(window_bits=w.value, windows=k.value, format=f.value, bytes=b.value)
 
     def close(self):
         if self.h:
@@ -218,7 +249,10 @@ def prove_batch(gens, circuit, label, values, v_blindings, rng_seeds, batch, wir
 
 def verify_batch(gens, circuit, label, proofs, commitments, batch, seeds=None):
     """proofs: list of bytes or concatenated bytes; commitments: list of lists (each m x 32 bytes) or bytes.
-    -> list of bool (Verifier::verify accepted)."""
+    -> list of bool (Verifier::verify accepted).  seeds: batch*32 bytes for the verifier's TranscriptRng
+    (default: fresh os.urandom, as upstream's thread_rng)."""
+    if seeds is None:
+        seeds = os.urandom(32 * batch)
     pf = proofs if isinstance(proofs, (bytes, bytearray)) else b"".join(proofs)
     cm = commitments if isinstance(commitments, (bytes, bytearray)) else b"".join(b"".join(c) for c in commitments)
     assert len(pf) == batch * circuit.proof_len and len(cm) == batch * circuit.m * 32
@@ -227,9 +261,14 @@ def verify_batch(gens, circuit, label, proofs, commitments, batch, seeds=None):
     return [bool(x) for x in ok]
 
 
-def verify_batch_combined(gens, circuit, label, proofs, commitments, batch, batch_seed, index_base=0, seeds=None):
+def verify_batch_combined(gens, circuit, label, proofs, commitments, batch, batch_seed=None, index_base=0, seeds=None):
     """Cross-proof batched mega-check of this caller's `batch` proofs -> (partial point: 32 bytes, wellformed: bool).
-    The whole job is accepted iff points_sum_is_identity(all callers' points) and all callers were well-formed."""
+    The whole job is accepted iff points_sum_is_identity(all callers' points) and all callers were well-formed.
+    batch_seed / seeds default to fresh os.urandom (the weights must not be predictable, see include/bpr1cs.h)."""
+    if batch_seed is None:
+        batch_seed = os.urandom(32)
+    if seeds is None:
+        seeds = os.urandom(32 * batch)
     pf = proofs if isinstance(proofs, (bytes, bytearray)) else b"".join(proofs)
     cm = commitments if isinstance(commitments, (bytes, bytearray)) else b"".join(b"".join(c) for c in commitments)
     assert len(pf) == batch * circuit.proof_len and len(cm) == batch * circuit.m * 32 and len(batch_seed) == 32
@@ -238,6 +277,79 @@ def verify_batch_combined(gens, circuit, label, proofs, commitments, batch, batc
     _chk(gens.lib.bpr1cs_verify_batch_combined(gens.h, circuit.h, label, len(label), pf, cm or b"\0", seeds, batch_seed, index_base, batch,
                                                out, ctypes.byref(wf)))
     return out.raw, bool(wf.value)
+
+
+def verify_batch_scalars(gens, circuit, label, proofs, commitments, batch, batch_seed=None, index_base=0, seeds=None):
+    """First half of the multi-GPU batched verifier -> (combined scalar vector: (2N+2)*32 bytes in base order
+    B, B~, G.., H.., own-points sum: 32 bytes, wellformed)."""
+    if batch_seed is None:
+        batch_seed = os.urandom(32)
+    if seeds is None:
+        seeds = os.urandom(32 * batch)
+    pf = proofs if isinstance(proofs, (bytes, bytearray)) else b"".join(proofs)
+    cm = commitments if isinstance(commitments, (bytes, bytearray)) else b"".join(b"".join(c) for c in commitments)
+    N = 1 << max(0, (circuit.n - 1).bit_length())
+    out = ctypes.create_string_buffer(32 * (2 * N + 2))
+    own = ctypes.create_string_buffer(32)
+    wf = ctypes.c_int()
+    _chk(gens.lib.bpr1cs_verify_batch_scalars(gens.h, circuit.h, label, len(label), pf, cm or b"\0", seeds, batch_seed, index_base, batch,
+                                              out, own, ctypes.byref(wf)))
+    return out.raw, own.raw, bool(wf.value)
+
+
+def scalars_sum(vectors, lib=None):
+    """element-wise sum mod l of equally long vectors of canonical scalars (bytes each) -> bytes"""
+    lib = lib or load_library()
+    n = len(vectors[0]) // 32
+    out = ctypes.create_string_buffer(32 * n)
+    _chk(lib.bpr1cs_scalars_sum(b"".join(vectors), len(vectors), n, out))
+    return out.raw
+
+
+def ipa_create(gens, transcript, Q, G_factors, H_factors, a, b):
+    """InnerProductProof::create on the device over gens.G/H[0..n) -> (L list, R list, a, b) ; `transcript` (Transcript) advances."""
+    n = len(a)
+    lg = max(0, n.bit_length() - 1)
+    Lb, Rb = ctypes.create_string_buffer(32 * max(1, lg)), ctypes.create_string_buffer(32 * max(1, lg))
+    ao, bo = ctypes.create_string_buffer(32), ctypes.create_string_buffer(32)
+    j = lambda xs: b"".join(_sc(x) for x in xs)
+    _chk(gens.lib.bpr1cs_ipa_create(gens.h, transcript.h, Q, j(G_factors), j(H_factors), j(a), j(b), n, Lb, Rb, ao, bo))
+    return ([Lb.raw[32 * i:32 * i + 32] for i in range(lg)], [Rb.raw[32 * i:32 * i + 32] for i in range(lg)],
+            int.from_bytes(ao.raw, "little"), int.from_bytes(bo.raw, "little"))
+
+
+_PROOF_FIELDS = ("A_I1", "A_O1", "S1", "A_I2", "A_O2", "S2", "T_1", "T_3", "T_4", "T_5", "T_6", "t_x", "t_x_blinding", "e_blinding", "ipp_a", "ipp_b")
+
+
+def proof_parse(data, lib=None):
+    """R1CSProof::from_bytes -> dict of 32-byte fields + lists L, R (raises R1CSError(FormatError))."""
+    lib = lib or load_library()
+    ps = ProofStruct()
+    _chk(lib.bpr1cs_proof_parse(data, len(data), ctypes.byref(ps)))
+    d = {k: bytes(getattr(ps, k)) for k in _PROOF_FIELDS}
+    d["L"] = [bytes(ps.L[i]) for i in range(ps.lg_n)]
+    d["R"] = [bytes(ps.R[i]) for i in range(ps.lg_n)]
+    return d
+
+
+def proof_serialize(d, lib=None):
+    """R1CSProof::to_bytes of a dict as returned by proof_parse."""
+    lib = lib or load_library()
+    ps = ProofStruct()
+    for k in _PROOF_FIELDS:
+        setattr(ps, k, _B32(*d[k]))
+    ps.lg_n = len(d["L"])
+    for i, (l, r) in enumerate(zip(d["L"], d["R"])):
+        ps.L[i] = _B32(*l)
+        ps.R[i] = _B32(*r)
+    out = ctypes.create_string_buffer(lib.bpr1cs_proof_serialized_len(ctypes.byref(ps)))
+    n = ctypes.c_size_t()
+    _chk(lib.bpr1cs_proof_serialize(ctypes.byref(ps), out, len(out), ctypes.byref(n)))
+    return out.raw[:n.value]
+
+
+def release_cached_memory(lib=None):
+    (lib or load_library()).bpr1cs_release_cached_memory()
 
 
 class _PoseidonParams(ctypes.Structure):

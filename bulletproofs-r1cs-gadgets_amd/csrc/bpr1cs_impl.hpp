@@ -871,7 +871,10 @@ static void dev_d2h_async(void* h, const void* d, size_t n, dev_stream_t s) {
 static void job_release(bpr1cs_job* job) {
     if (!job) return;
 #if !defined(BPR1CS_HOSTSIM)
-    if (job->st) (void)hipStreamSynchronize(job->st);
+    // the heavy stream is shared with the NEXT job in flight: wait for this job's own completion event, and for the
+    // whole stream only when the job failed before recording it
+    if (job->ev_done) (void)hipEventSynchronize(job->ev_done);
+    else if (job->st) (void)hipStreamSynchronize(job->st);
     if (job->st2) (void)hipStreamSynchronize(job->st2);
     if (job->st3) (void)hipStreamSynchronize(job->st3);
     hipEvent_t* evs[6] = {&job->ev_in, &job->ev_rng, &job->ev_wit, &job->ev_done, &job->ev_rng0, &job->ev_rng1};

@@ -1,6 +1,6 @@
 """Proof-level sharding across ranks: proofs are independent, so rank r of W proves a
-contiguous block of the global batch; no data-path collective.  Used by bench.py and the gloo test."""
-import hashlib
+contiguous block of the global batch; no data-path collective.  The batched verifier is the path's only exchange
+step.  Used by bench.py and the gloo tests."""
 
 
 def shard_range(global_batch, rank, world):
@@ -8,11 +8,6 @@ def shard_range(global_batch, rank, world):
     base, rem = divmod(global_batch, world)
     lo = rank * base + min(rank, rem)
     return lo, lo + base + (1 if rank < rem else 0)
-
-
-def rng_seed(global_index):
-    """rng_seed_j = SHA-256("seed" || LE64(j)) of the GLOBAL proof index j."""
-    return hashlib.sha256(b"seed" + int(global_index).to_bytes(8, "little")).digest()
 
 
 def gather_partial_points(point, wellformed, group=None, device=None):
@@ -29,3 +24,44 @@ def gather_partial_points(point, wellformed, group=None, device=None):
     dist.all_gather(outs, t, group=group)
     pts = [bytes(o[:32].cpu().tolist()) for o in outs]
     return pts, all(int(o[32]) == 1 for o in outs)
+
+
+def _all_gather_bytes(payload, group=None, device=None):
+    """all_gather of equally long byte strings -> list over ranks (RCCL on the GPU box, gloo on CPU; [payload] without a group)"""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return [bytes(payload)]
+    ws = dist.get_world_size(group)
+    t = torch.frombuffer(bytearray(payload), dtype=torch.uint8)
+    if device is not None:
+        t = t.to(device)
+    outs = [torch.zeros_like(t) for _ in range(ws)]
+    dist.all_gather(outs, t, group=group)
+    return [bytes(o.cpu().numpy().tobytes()) for o in outs]
+
+
+def verify_sharded(bp, gens, circuit, label, proofs, commitments, batch, rank, world, index_base, batch_seed=None, group=None, device=None):
+    """Batched verification of a job sharded over `world` ranks with the shared-base MSM computed ONCE per job:
+      1. every rank: bpr1cs_verify_batch_scalars -> its combined scalar vector over B, B~, G.., H.. and the weighted sum of
+         its proofs' own points;
+      2. all_gather of the scalar vectors ((2N+2)*32 bytes per rank, ~2 MB at N = 32768), summed mod l (bpr1cs_scalars_sum);
+      3. every rank evaluates its 1/world slice of the bases with bpr1cs_msm_fixed;
+      4. all_gather of (slice point, own-points sum, well-formed flag): 65 bytes per rank; accept iff the sum of all
+         points is the identity and every rank was well-formed.
+    Every rank returns the same verdict."""
+    vec, own, wf = bp.verify_batch_scalars(gens, circuit, label, proofs, commitments, batch, batch_seed=batch_seed, index_base=index_base)
+    total = bp.scalars_sum(_all_gather_bytes(vec, group, device), lib=gens.lib)
+    nb = len(total) // 32
+    lo, hi = shard_range(nb, rank, world)
+    if hi > lo:
+        # base order of the vector == base indices of bpr1cs_msm_fixed (0 = B, 1 = B~, 2+i = G[i], 2+cap+i = H[i]) when N == capacity;
+        # for N < capacity the H block starts at 2 + capacity
+        N = (nb - 2) // 2
+        bases = [i if i < 2 + N else i - N + gens.capacity for i in range(lo, hi)]
+        slice_pt = gens.msm_fixed(bases, total[32 * lo:32 * hi], 1)[0]
+    else:
+        slice_pt = bytes(32)
+    parts = _all_gather_bytes(slice_pt + own + bytes([1 if wf else 0]), group, device)
+    pts = [p[:32] for p in parts] + [p[32:64] for p in parts]
+    return all(p[64] == 1 for p in parts) and bp.points_sum_is_identity(pts, lib=gens.lib)

@@ -388,17 +388,25 @@ class R1CSProof:
         self.A_I2 = self.A_O2 = self.S2 = bytes(32)
 
     def to_bytes(self):
-        out = b"\x00" + b"".join(getattr(self, f) for f in self.FIELDS)
+        """R1CSProof::to_bytes: version 0 (one-phase) when the phase-2 commitments are the identity, else version 1."""
+        phase2 = any(x != bytes(32) for x in (self.A_I2, self.A_O2, self.S2))
+        lead = [self.A_I1, self.A_O1, self.S1] + ([self.A_I2, self.A_O2, self.S2] if phase2 else []) + \
+               [self.T_1, self.T_3, self.T_4, self.T_5, self.T_6]
+        out = (b"\x01" if phase2 else b"\x00") + b"".join(lead)
         out += sc_to_bytes(self.t_x) + sc_to_bytes(self.t_x_blinding) + sc_to_bytes(self.e_blinding)
         return out + self.ipp_proof.to_bytes()
 
     @staticmethod
     def from_bytes(b):
-        if len(b) < 1 or b[0] != 0 or (len(b) - 1) % 32 != 0:
+        """R1CSProof::from_bytes: version byte 0 / 1, 32-byte elements, canonical scalars, InnerProductProof::from_bytes
+        on the tail (an even number of L/R elements, lg n < 32); points are kept undecoded."""
+        if len(b) < 1 or b[0] > 1 or (len(b) - 1) % 32 != 0:
             raise R1CSError("FormatError")
+        version = b[0]
         body = b[1:]
         k = len(body) // 32
-        if k < 13 or (k - 13) % 2 != 0:
+        lead = 14 if version else 11
+        if k < lead + 2 or (k - lead - 2) % 2 != 0 or (k - lead - 2) // 2 >= 32:
             raise R1CSError("FormatError")
         el = [body[32 * i:32 * i + 32] for i in range(k)]
 
@@ -407,11 +415,15 @@ class R1CSProof:
             if v >= L:
                 raise R1CSError("FormatError")
             return v
-        lg = (k - 13) // 2
-        Ls = [el[11 + 2 * i] for i in range(lg)]
-        Rs = [el[12 + 2 * i] for i in range(lg)]
+        pts = el[:3] + el[(6 if version else 3):lead - 3]
+        lg = (k - lead - 2) // 2
+        Ls = [el[lead + 2 * i] for i in range(lg)]
+        Rs = [el[lead + 1 + 2 * i] for i in range(lg)]
         ipp = InnerProductProof(Ls, Rs, sc(el[-2]), sc(el[-1]))
-        return R1CSProof(*el[:8], sc(el[8]), sc(el[9]), sc(el[10]), ipp)
+        pf = R1CSProof(*pts, sc(el[lead - 3]), sc(el[lead - 2]), sc(el[lead - 1]), ipp)
+        if version:
+            pf.A_I2, pf.A_O2, pf.S2 = el[3], el[4], el[5]
+        return pf
 
 
 class Verifier(ConstraintSystem):

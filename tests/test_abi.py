@@ -39,3 +39,19 @@ def test_no_cpu_fallback_without_device():
         assert False, "expected R1CSError"
     except bp.R1CSError as e:
         assert e.code == -16
+
+
+def test_integration_md_binding_block_is_generated_from_the_header():
+    """INTEGRATION.md's Rust binding (every struct field, every function) is regenerated from include/bpr1cs.h and compared."""
+    import subprocess, sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_rust_bindings.py"), "--check"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    # and the struct a shim passes has exactly the fields the C side reads
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import gen_rust_bindings as g
+    _, structs, _, funcs = g.parse(open(g.HEADER).read())
+    desc = dict(structs)["bpr1cs_circuit_desc"]
+    assert [f for f, _ in desc][-4:] == ["n_poseidon_params", "poseidon_params", "n_poseidon_perms", "poseidon_perms"]
+    bp = importlib.import_module("bulletproofs-r1cs-gadgets_amd")
+    assert [f for f, _ in desc] == [f for f, _ in bp._CircuitDesc._fields_]
+    assert sorted(n for n, _, _ in funcs) == _declared("bpr1cs.h")

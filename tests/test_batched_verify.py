@@ -76,7 +76,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, sim_path, gsim_path, gb, tamper, q):
+def _worker(rank, world, port, sim_path, gsim_path, gb, tamper, q, split=False):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.path.insert(0, os.path.join(ROOT, "tests"))
     import torch.distributed as dist
@@ -93,16 +93,21 @@ def _worker(rank, world, port, sim_path, gsim_path, gb, tamper, q):
     P = list(P)
     if tamper and rank == 1:
         b = bytearray(P[0]); b[1 + 8 * 32] ^= 1; P[0] = bytes(b)
-    pt, wf = bpm.verify_batch_combined(gens, circ, ob["label"], P, comms, hi - lo, SEED, index_base=lo)
-    pts, all_wf = sh.gather_partial_points(pt, wf)     # the only collective of the path: 33 bytes per rank
-    ok = all_wf and bpm.points_sum_is_identity(pts, lib=lib)
+    if split:
+        # shared-base MSM split by base range: all_gather of the combined scalar vectors, 1/world of the bases per rank,
+        # all_gather of the slice points (sharding.verify_sharded); every rank draws its OWN fresh batch seed
+        ok = sh.verify_sharded(bpm, gens, circ, ob["label"], P, comms, hi - lo, rank, world, lo)
+    else:
+        pt, wf = bpm.verify_batch_combined(gens, circ, ob["label"], P, comms, hi - lo, SEED, index_base=lo)
+        pts, all_wf = sh.gather_partial_points(pt, wf)     # the only collective of the path: 33 bytes per rank
+        ok = all_wf and bpm.points_sum_is_identity(pts, lib=lib)
     q.put((rank, ok))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("tamper", [False, True])
-def test_two_rank_batched_verify_gloo(sim_lib, sim_glib, tamper):
+@pytest.mark.parametrize("tamper,split", [(False, False), (True, False), (False, True), (True, True)])
+def test_two_rank_batched_verify_gloo(sim_lib, sim_glib, tamper, split):
     import torch.multiprocessing as mp
     world, gb = 2, 4
     sim_path = os.path.join(ROOT, "tests", "hostsim", "_build", "libbpr1cs_sim.so")
@@ -110,7 +115,7 @@ def test_two_rank_batched_verify_gloo(sim_lib, sim_glib, tamper):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, sim_path, gsim_path, gb, tamper, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, sim_path, gsim_path, gb, tamper, q, split)) for r in range(world)]
     for p in procs:
         p.start()
     res = dict(q.get(timeout=300) for _ in range(world))

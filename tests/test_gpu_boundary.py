@@ -1,0 +1,29 @@
+"""GPU twins of tests/test_boundary.py: the low-level C-ABI entry points on the device."""
+import pytest
+
+import boundary_cases as bc
+
+pytestmark = pytest.mark.gpu
+
+
+def test_ipa_create_matches_oracle(hip_lib):
+    bc.check_ipa_create(hip_lib, n=64, unfold=2)   # two rounds from the tables, then variable-base
+    bc.check_ipa_create(hip_lib, n=16, unfold=0)
+    bc.check_ipa_create(hip_lib, n=8, unfold=9)
+    bc.check_ipa_create(hip_lib, n=1, unfold=2)
+
+
+def test_proof_wire_format(hip_lib):
+    bc.check_proof_format(hip_lib)
+
+
+def test_malformed_inputs_are_refused(hip_lib):
+    bc.check_validation(hip_lib)
+
+
+def test_split_shared_base_verifier(hip_lib, hip_glib):
+    bc.check_split_verifier(hip_lib, hip_glib, batch=6)
+
+
+def test_two_threads_two_handles(hip_lib, hip_glib):
+    bc.check_two_threads_two_handles(hip_lib, hip_glib, rounds=4)

@@ -35,7 +35,7 @@ def _worker(rank, world, port, sim_path, global_batch, q):
     lo, hi = sh.shard_range(global_batch, rank, world)
     # every rank builds the inputs of ITS proofs from the global index (values 37+j, seeds by global j)
     ob = common.oracle_batch(lambda j: S.bound_check(37 + lo + j, 10, 100, 7), 16, hi - lo)
-    seeds = b"".join(sh.rng_seed(j) for j in range(lo, hi))
+    seeds = b"".join(S.synth_seed(j) for j in range(lo, hi))
     circ = common.circuit_from_oracle(ob, lib)
     gens = bp.Gens(16, lib=lib)
     lib.bpr1cs_set_unfold_rounds(2)
@@ -83,6 +83,6 @@ def test_two_rank_sharding_matches_oracle(sim_lib):
         for j in range(hi - lo):
             sc = S.bound_check(37 + lo + j, 10, 100, 7)
             bl = [S.synth_scalar(b"bl%d" % j, i) for i in range(512)]
-            pf, _ = sc.prove(common.PC, common.oracle_gens(16), bl, sh.rng_seed(lo + j))
+            pf, _ = sc.prove(common.PC, common.oracle_gens(16), bl, S.synth_seed(lo + j))
             proofs.append(pf)
         assert hashlib.sha256(b"".join(proofs)).digest() == digests[r]
