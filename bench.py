@@ -27,7 +27,6 @@ sys.path.insert(0, ROOT)
 
 L = 2**252 + 27742317777372353535851937790883648493
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
-UBENCH_MADD_PEAK_G = 33.7  # G ge_madd/s on one MI355X with every SIMD busy (tools/ubench.hip, profiles/r01h_ubench_gfx950.txt)
 
 
 def synth_scalar(tag, i):
@@ -76,24 +75,63 @@ def build_workload(bp, levels, batch, n_leaves, seed_base):
     return tree.root(), values, bytes(bl), seeds, m
 
 
-def pmc_traffic_bytes(window):
-    """HBM bytes per K_msm_fixed launch from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE,
-    separate runs of this same command; profiles/r01f_pmc_hbm_traffic.txt, W = 11, 1024 proofs).  Returned as
-    reported by the counters (KB * 1024); the gfx950 FETCH_SIZE caveat (x2 under-count for wide coalesced
-    streams, uncalibrated for 96-byte gathers) is discussed in DESIGN.md.  None when no matching profile."""
-    path = os.path.join(ROOT, "profiles", "r01f_pmc_hbm_traffic.txt")
-    if window != 11 or not os.path.exists(path):
-        return None
-    for line in open(path):
-        if line.startswith("K_msm_fixed |"):
-            f = [x.strip() for x in line.split("|")]
-            return (float(f[2]) + float(f[3])) * 1024.0
-    return None
+MADS_PER_TABLE_ADD = 7 * 99   # 7 field multiplications (ge_madd_t) x (81 limb products + 9 fold + 9 carry re-entries) v_mad_i64_i32 / v_mad_u64_u32
 
 
-def cpu_baseline(levels, root, values, blindings, seeds, m, n_proofs):
-    """Oracle leg: the C restatement (oracle/c) proves the SAME first `n_proofs` witnesses on one host
-    thread; returns (dict, proofs) or (None, None) when the oracle library is not built."""
+def pmc_traffic(table_format):
+    """HBM bytes per k_msm_fixed2 launch from the committed rocprofv3 PMC passes of THIS kernel build (FETCH_SIZE and
+    WRITE_SIZE in separate runs of `bench.py --steps 3`, profiles/r02*_pmc_hbm_traffic.txt): -> (bytes, launches per step of
+    the profiled run, source) or (None, None, None).  Counter values are taken as reported (KB * 1024); MI355X_MICROARCH.md:
+    on gfx950 FETCH_SIZE under-reports wide coalesced streams 2x and is uncalibrated for the 128-byte gathers this kernel
+    issues, so the figure is a lower bound."""
+    import glob
+    import re
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r02*_pmc_hbm_traffic.txt")), reverse=True):
+        text = open(path).read()
+        lps = re.search(r"launches_per_step=(\d+)", text)
+        if ("table_format=%d" % table_format) not in text or not lps:
+            continue
+        for line in text.split("\n"):
+            if line.startswith("k_msm_fixed2"):
+                f = [x.strip() for x in line.split("|")]
+                return (float(f[2]) + float(f[3])) * 1024.0, float(lps.group(1)), os.path.relpath(path, ROOT)
+    return None, None, None
+
+
+def cpu_info():
+    """-> (CPU model, logical CPUs, CPUs this process may run on, CPU-time quota of its cgroup in CPUs or None)"""
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = os.cpu_count() or 1
+    quota = None
+    try:    # cgroup v2, then v1: a container may see every CPU of the host but be limited to a few CPUs' worth of time
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            quota = float(q) / float(per)
+    except (OSError, ValueError):
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            pass
+    return model, os.cpu_count() or 1, usable, quota
+
+
+def cpu_baseline(levels, root, values, blindings, seeds, m, n_proofs, max_threads):
+    """Oracle leg, same run, same inputs, host cores of this box: the C restatement (oracle/c) proves witnesses of the batch
+    (gadget synthesis + prove, as reference src/gadget_vsmt_4.rs:421-435; generator setup excluded) (i) on ONE thread (the
+    reference is single-threaded) and (ii) on all usable cores, one proof per thread.  -> (dict, proofs of (i))."""
     try:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         from cref import COracle  # noqa
@@ -102,16 +140,51 @@ def cpu_baseline(levels, root, values, blindings, seeds, m, n_proofs):
     o = COracle()
     t0 = time.time()
     circ = o.compile_vsmt4(levels, 140, root)
-    t_compile = time.time() - t0
-    proofs = []
+    t_setup = time.time() - t0
+
+    def one(j):
+        return o.prove_vsmt4(circ, values[j * m * 32:(j + 1) * m * 32], blindings[j * m * 32:(j + 1) * m * 32], seeds[32 * j:32 * j + 32])
     t0 = time.time()
-    for j in range(n_proofs):
-        proofs.append(o.prove_vsmt4(circ, values[j * m * 32:(j + 1) * m * 32], blindings[j * m * 32:(j + 1) * m * 32], seeds[32 * j:32 * j + 32]))
-    dt = time.time() - t0
-    return ({"value": n_proofs / dt, "unit": "proofs/s", "cores": 1, "kind": "port",
-             "sample": "%d proof(s) of the same workload (VSMT-4 depth %d), gadget synthesis + prove, 1 thread, %.1f s; "
-                       "C restatement (oracle/c), not dalek-AVX2; generator setup and circuit compile (%.1f s) excluded"
-                       % (n_proofs, levels, dt, t_compile)}, proofs)
+    proofs = [one(j) for j in range(n_proofs)]
+    dt1 = time.time() - t0
+    model, logical, usable, quota = cpu_info()
+    import math
+    threads = max(1, min(usable, max_threads, len(seeds) // 32, math.ceil(quota) if quota else usable))
+    # all cores this process is entitled to (affinity mask and cgroup CPU quota): one proof per WORKER PROCESS (forked after the generators are warm; the children only run the C oracle and
+    # leave through os._exit).  Threads of one process would serialise on the kernel's mmap lock: the oracle allocates and frees
+    # hundreds of MB per proof (256 threads: 30x slower per proof than one thread alone).
+    sys.stdout.flush()
+    t0 = time.time()
+    kids = []
+    for k in range(threads):
+        r, w = os.pipe()
+        pid = os.fork()
+        if pid == 0:
+            code = 1
+            try:
+                os.close(r)
+                pf = one(k)
+                os.write(w, hashlib.sha256(pf).digest())
+                code = 0
+            finally:
+                os._exit(code)
+        os.close(w)
+        kids.append((pid, r))
+    digests = []
+    for pid, r in kids:
+        digests.append(os.read(r, 32))
+        os.close(r)
+        os.waitpid(pid, 0)
+    dtn = time.time() - t0
+    assert all(len(d) == 32 for d in digests), "a CPU worker failed"
+    assert digests[:n_proofs] == [hashlib.sha256(p).digest() for p in proofs[:min(n_proofs, threads)]]
+    return ({"value": threads / dtn, "unit": "proofs/s", "cores": threads, "kind": "port",
+             "single_thread": {"value": n_proofs / dt1, "proofs": n_proofs, "seconds": dt1},
+             "cpu_model": model, "logical_cpus": logical, "usable_cpus": usable, "cgroup_cpu_quota": quota,
+             "sample": "%d proofs of the same workload (VSMT-4 depth %d, gadget synthesis + prove), one per worker process on %d CPUs, %.1f s wall "
+                       "(%.0f core-seconds); single thread: %d proof(s) in %.1f s; C restatement (oracle/c: 5x51-bit field, Pippenger / Straus), "
+                       "not dalek-AVX2; generator setup (%.1f s) excluded"
+                       % (threads, levels, threads, dtn, threads * dtn, n_proofs, dt1, t_setup)}, proofs)
 
 
 def main():
@@ -122,13 +195,15 @@ def main():
     ap.add_argument("--batch", type=int, default=1024, help="proofs per GPU per step")
     ap.add_argument("--depth", type=int, default=32, help="4-ary tree levels (BASELINE: 32)")
     ap.add_argument("--leaves", type=int, default=0, help="distinct synthetic leaves cycled over the batch (0 = one per proof of the batch)")
-    ap.add_argument("--cpu-proofs", type=int, default=2, help="proofs timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--cpu-proofs", type=int, default=2, help="proofs timed on ONE thread of the CPU oracle (0 = skip the CPU leg)")
+    ap.add_argument("--cpu-threads", type=int, default=128, help="upper bound of the all-cores CPU run (one proof per thread)")
+    ap.add_argument("--table-format", type=int, default=-1, help="fixed-base table storage: 0 packed 96 B, 1 limb form in 128-B slots, -1 automatic")
     ap.add_argument("--pipeline", type=int, default=2, help="batches in flight (1 = synchronous)")
     ap.add_argument("--latency-cus", type=int, default=-1, help="CUs reserved for the latency-bound kernels (-1 = library default)")
     ap.add_argument("--team", type=int, default=0, help="witness team size 4/8/16 (0 = library default)")
     ap.add_argument("--rng-mode", type=int, default=-1, help="TranscriptRng chain mapping: 0 auto, 1 lane-parallel, 2 state per thread (-1 = library default)")
     ap.add_argument("--unfold", type=int, default=4, help="IPA rounds computed from the un-folded generator tables")
-    ap.add_argument("--window", type=int, default=11, help="fixed-base table window bits (11: 23 adds/term, 148 GB of tables at capacity 32768)")
+    ap.add_argument("--window", type=int, default=11, help="fixed-base table window bits (11: 23 adds/term, 148 / 198 GB of tables at capacity 32768)")
     args = ap.parse_args()
 
     import torch
@@ -151,6 +226,7 @@ def main():
         lib.bpr1cs_set_unfold_rounds(args.unfold)
     if args.window > 0:
         lib.bpr1cs_set_window_bits(args.window)
+    lib.bpr1cs_set_table_format(args.table_format)
     if args.team > 0:
         lib.bpr1cs_set_witness_team(args.team)
     if args.rng_mode >= 0:
@@ -224,14 +300,21 @@ def main():
         sh = importlib.import_module("bulletproofs-r1cs-gadgets_amd.sharding")
         torch.cuda.synchronize()
         tb = time.perf_counter()
-        try:
-            pt, wf = bp.verify_batch_combined(gens, circ, b"VSMT", proofs, comms, B, bytes(range(32)), index_base=rank * B)
+        try:   # fresh randomness for the weights (include/bpr1cs.h: batch_seed must not be predictable)
+            pt, wf = bp.verify_batch_combined(gens, circ, b"VSMT", proofs, comms, B, os.urandom(32), index_base=rank * B)
         except Exception:  # keep the collective below matched on every rank
             pt, wf = b"\xff" * 32, False
         pts, all_wf = sh.gather_partial_points(pt, wf, device="cuda" if dist is not None else None)
         accepted = bool(all_wf) and bp.points_sum_is_identity(pts)
         tb = time.perf_counter() - tb
+        # the multi-GPU form: shared-base MSM split by base range over the ranks (all_gather of the combined scalar vectors)
+        torch.cuda.synchronize()
+        ts = time.perf_counter()
+        accepted_split = sh.verify_sharded(bp, gens, circ, b"VSMT", proofs, comms, B, rank, world, rank * B, device="cuda" if dist is not None else None)
+        ts = time.perf_counter() - ts
         batched = {"accepted_all": accepted, "proofs": B * world, "proofs_per_s": B * world / tb,
+                   "split_shared_base": {"accepted_all": accepted_split, "proofs_per_s": B * world / ts,
+                                         "note": "bpr1cs_verify_batch_scalars + all_gather of the scalar vectors + 1/world of the bases per rank"},
                    "note": "bpr1cs_verify_batch_combined + all_gather of one point per rank; not part of `value`"}
     except Exception as e:  # pragma: no cover
         batched = {"error": repr(e)}
@@ -245,29 +328,48 @@ def main():
         # dominant kernel: algorithmic bytes = 64 B per scalar*point term + 32 B per output (MSM_BYTES(t) = 64 t + 32)
         msm_alg_bytes = 64.0 * msm_terms + 32.0 * msm_launches * B
         achieved = (msm_alg_bytes / 1e9) / (msm_ms / 1e3) if msm_ms > 0 else None
+        tinfo = gens.table_info()
+        traffic, traffic_lps, traffic_src = pmc_traffic(tinfo["format"]) if (B == 1024 and levels == 32 and args.window == 11) else (None, None, None)
+        launches_per_step = msm_launches / steps
+        # integer ceilings, measured NOW on this device by the library's probes (bpr1cs_device_rates, ~80 ms each)
+        mad_rate, madd_chain_rate = bp.device_rates(0.08, lib)
+        adds = msm_terms * tinfo["windows"]
+        adds_per_s = adds / (msm_ms / 1e3) if msm_ms > 0 else None
         out = {
             "metric": "R1CS proofs/sec (Poseidon VSMT-4 depth-%d)" % levels, "value": value, "unit": "proofs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
             "config": {"workload": "gadget_vsmt_4 sparse-Merkle depth-%d membership (Poseidon 4:1 inverse S-box, 148 rounds)" % levels,
                        "batch_per_gpu": B, "global_batch": B * world, "n_multipliers": n, "padded_n": N, "constraints": circ.q,
                        "commitments": m, "proof_bytes": circ.proof_len, "sharding": "independent proofs per rank, no collective",
-                       "synthetic_leaves": n_leaves, "batches_in_flight": depth},
-            "roofline": {"bound": "hbm", "kernel": "K_msm_fixed (batched fixed-base MSM over generator tables)",
+                       "synthetic_leaves": n_leaves, "batches_in_flight": depth, "ipa_unfold_rounds": args.unfold,
+                       "table_window_bits": tinfo["window_bits"], "table_windows": tinfo["windows"], "table_format": tinfo["format"],
+                       "table_bytes": tinfo["bytes"]},
+            "roofline": {"bound": "hbm", "kernel": "k_msm_fixed2 (batched fixed-base MSM over the generator tables; a launch carries 1-3 sums)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
-                         "traffic": pmc_traffic_bytes(args.window) if B == 1024 and levels == 32 else None,
-                         "avg_launch_ms": (msm_ms / msm_launches) if msm_launches else None, "launches_per_step": msm_launches / steps,
+                         "traffic": (traffic * traffic_lps / launches_per_step) if (traffic and launches_per_step) else None,
+                         "traffic_source": traffic_src,
+                         "traffic_note": "PMC FETCH_SIZE + WRITE_SIZE per launch of the same kernel build and configuration, from the named profile (separate "
+                                         "rocprofv3 --pmc passes; rescaled by launches per step if the profiled run grouped the sums differently); as reported by the counters: "
+                                         "on gfx950 FETCH_SIZE under-reports wide reads 2x and is uncalibrated for 128-byte gathers - a lower bound",
+                         "avg_launch_ms": (msm_ms / msm_launches) if msm_launches else None, "launches_per_step": launches_per_step,
                          "alg_bytes_per_launch": (msm_alg_bytes / msm_launches) if msm_launches else None,
-                         "note": "achieved/frac use ALGORITHMIC bytes (64 B per scalar*point term); the kernel is integer-VALU bound and additionally "
-                                 "streams its fixed-base tables from HBM (traffic, PMC) — see DESIGN.md"},
-            # second, honest ceiling: the kernel is bound by 32-bit integer multiply-add issue.  One term =
-            # ceil(253 / W) table additions; peak = ge_madd throughput of tools/ubench on this chip (profiles/r01h_ubench_gfx950.txt)
+                         "note": "achieved/frac use ALGORITHMIC bytes (64 B per scalar*point term); the kernel is bound by integer multiply-add issue "
+                                 "and by the power its table gathers cost (DVFS), not by HBM bandwidth - see roofline_valu and DESIGN.md"},
+            # second, honest ceiling: 32-bit integer multiply-add issue.  One table addition = 693 multiply-adds;
+            # peak = measured v_mad_i64_i32 rate of this device / 693.  The self-benchmarked ge_madd_t chain (the kernel's inner loop
+            # without its table gathers) is reported next to it.
             "roofline_valu": {"bound": "valu-int32-mad", "unit": "G table-add/s",
-                              "achieved": (msm_terms * ((253 + args.window - 1) // args.window) / 1e9) / (msm_ms / 1e3) if msm_ms > 0 else None,
-                              "peak": UBENCH_MADD_PEAK_G,
-                              "frac": ((msm_terms * ((253 + args.window - 1) // args.window) / 1e9) / (msm_ms / 1e3)) / UBENCH_MADD_PEAK_G if msm_ms > 0 else None,
-                              "note": "zero scalars / zero digits are skipped, so `achieved` (which counts them) slightly overstates the adds executed"},
+                              "achieved": adds_per_s / 1e9 if adds_per_s else None,
+                              "peak": mad_rate / MADS_PER_TABLE_ADD / 1e9,
+                              "frac": (adds_per_s / (mad_rate / MADS_PER_TABLE_ADD)) if adds_per_s else None,
+                              "mad_lane_ops_per_s": mad_rate, "mads_per_table_add": MADS_PER_TABLE_ADD,
+                              "ge_madd_t_chain_G_per_s": madd_chain_rate / 1e9,
+                              "frac_of_madd_chain": (adds_per_s / madd_chain_rate) if adds_per_s else None,
+                              "note": "peak = sustained v_mad_i64_i32 lane-ops/s measured in this run (bpr1cs_device_rates) / 693 multiply-adds per "
+                                      "table addition; ge_madd_t chain = the same additions on register operands (no gathers); zero scalars / zero "
+                                      "digits are counted in `achieved`"},
             "hbm_frac_whole_path": value / world * alg_bytes_per_proof / (HBM_PEAK_GBS * 1e9),
             "phase_ms_per_step": {k: v / steps for k, v in zip(["total", "inputs+commitV", "rng||witness", "commit_msm", "poly", "ipa"], phases)},
             "setup_s": {"witness_trees": t_witness, "circuit_compile": t_compile, "generator_tables": t_gens},
@@ -282,7 +384,7 @@ def main():
             out["verify"] = {"error": repr(e)}
         out["verify_batched"] = batched
         if world == 1 and args.cpu_proofs > 0:
-            cb, cproofs = cpu_baseline(levels, root, values, blindings, seeds, m, args.cpu_proofs)
+            cb, cproofs = cpu_baseline(levels, root, values, blindings, seeds, m, args.cpu_proofs, args.cpu_threads)
             out["cpu_baseline"] = cb
             if cproofs is not None:
                 out["parity_vs_cpu_oracle"] = all(cproofs[j] == proofs[j] for j in range(len(cproofs)))

@@ -114,6 +114,7 @@ def load_library(path=None):
     lib.bpr1cs_proof_serialize.argtypes = [ctypes.POINTER(ProofStruct), cp, sz, ctypes.POINTER(sz)]
     lib.bpr1cs_proof_serialized_len.argtypes = [ctypes.POINTER(ProofStruct)]
     lib.bpr1cs_proof_serialized_len.restype = sz
+    lib.bpr1cs_device_rates.argtypes = [ctypes.c_double, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
     lib.bpr1cs_last_timings.argtypes = [ctypes.POINTER(ctypes.c_float), ctypes.c_int]
     lib.bpr1cs_last_msm_stats.argtypes = [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]
     if path is None:
@@ -346,6 +347,14 @@ def proof_serialize(d, lib=None):
     n = ctypes.c_size_t()
     _chk(lib.bpr1cs_proof_serialize(ctypes.byref(ps), out, len(out), ctypes.byref(n)))
     return out.raw[:n.value]
+
+
+def device_rates(seconds_each=0.08, lib=None):
+    """-> (v_mad_i64_i32 lane-ops/s, ge_madd_t table adds/s), sustained, measured on the current device"""
+    lib = lib or load_library()
+    a, b = ctypes.c_double(), ctypes.c_double()
+    _chk(lib.bpr1cs_device_rates(seconds_each, ctypes.byref(a), ctypes.byref(b)))
+    return a.value, b.value
 
 
 def release_cached_memory(lib=None):

@@ -207,14 +207,14 @@ void bpr1cs_set_unfold_rounds(int r) { g_unfold_rounds = r < 0 ? 0 : r; }
 void bpr1cs_set_latency_cus(int n) { g_latency_cus = n < 0 ? 0 : n; }
 void bpr1cs_set_witness_team(int t) { g_witness_team = (t == 4 || t == 8) ? t : 16; }
 void bpr1cs_set_witness_macro(int enable) { g_witness_macro = enable ? 1 : 0; }
-void bpr1cs_set_rng_mode(int mode) { g_rng_mode = (mode >= 1 && mode <= 4) ? mode : 0; }
+void bpr1cs_set_rng_mode(int mode) { g_rng_mode = (mode >= 1 && mode <= 5) ? mode : 0; }
 int bpr1cs_circuit_macro_perms(const bpr1cs_circuit* c) { return c ? (int)c->n_perms : 0; }
 void bpr1cs_set_window_bits(int w) { g_window_bits = w < 4 ? 4 : (w > 12 ? 12 : w); }
 void bpr1cs_set_table_format(int f) { g_table_format = (f == 0 || f == 1) ? f : -1; }
 int bpr1cs_gens_set_option(bpr1cs_gens* g, int option, int value) {
     if (!g) return BPR1CS_ERR_INVALID_ARGUMENT;
     if (option == BPR1CS_OPT_UNFOLD_ROUNDS) g->opts.unfold = value < 0 ? -1 : value;
-    else if (option == BPR1CS_OPT_RNG_MODE) g->opts.rng_mode = (value >= 0 && value <= 4) ? value : -1;
+    else if (option == BPR1CS_OPT_RNG_MODE) g->opts.rng_mode = (value >= 0 && value <= 5) ? value : -1;
     else if (option == BPR1CS_OPT_WITNESS_TEAM) g->opts.witness_team = (value == 4 || value == 8 || value == 16) ? value : -1;
     else return BPR1CS_ERR_INVALID_ARGUMENT;
     return BPR1CS_OK;
@@ -646,6 +646,22 @@ struct MsmReq {
     const uint8_t* table;  // nullptr = the generator tables of `g`
 };
 static void run_msm_multi(const bpr1cs_gens* g, MsmReq* reqs, uint32_t nreq, uint32_t B, dev_stream_t st, MsmStats* stats) {
+    if (B < 32) {  // a wavefront per (chunk, 64 proofs) would be mostly idle: lanes take different chunks instead
+        for (uint32_t r = 0; r < nreq; r++) {
+            MsmReq& q = reqs[r];
+            uint32_t total = q.s0.count + q.s1.count;
+            uint32_t nchunks = pick_chunks(total, B, 1u << 16, q.plan->chunk);
+            uint32_t l1 = nchunks > MSM_REDUCE_GROUP ? (nchunks + MSM_REDUCE_GROUP - 1) / MSM_REDUCE_GROUP : 0;
+            size_t need = ((size_t)nchunks + l1) * B;
+            if (q.partial->n < need) q.partial->alloc(need);
+            ge* raw = q.partial->p + (size_t)l1 * B;
+            launch_wave((uint64_t)nchunks * B, K_msm_fixed_small{q.table ? q.table : g->tab.p, g->tc, {q.s0, q.s1}, raw, B, q.plan->chunk, nchunks}, st);
+            if (l1) launch((uint64_t)l1 * B, K_ge_reduce{raw, q.partial->p, B, nchunks, MSM_REDUCE_GROUP}, st);
+            q.plan->nchunks = l1 ? l1 : nchunks;
+            if (stats) { stats->launches++; stats->terms += (uint64_t)total * B; }
+        }
+        return;
+    }
     const uint32_t nbk = (B + 63u) / 64u;
     struct Lay { uint32_t nchunks, l1, l2; ge* raw; ge* p1; ge* p2; };
     Lay lay[MSM_MAX_JOBS];
@@ -669,7 +685,7 @@ static void run_msm_multi(const bpr1cs_gens* g, MsmReq* reqs, uint32_t nreq, uin
         terms += (uint64_t)total * B;
         wg += nchunks * nbk;
 #if !defined(BPR1CS_HOSTSIM)
-        L.job[r] = MsmJob{{q.s0, q.s1}, q.table ? q.table : g->tab.p, lay[r].raw, q.plan->chunk, nchunks};
+        L.job[r] = MsmJob{{q.s0, q.s1}, q.table ? q.table : g->tab.p, lay[r].raw, q.plan->chunk, nchunks, 0};
         L.wg_end[r] = wg;
 #endif
     }
@@ -776,7 +792,28 @@ static void enqueue_ipa(const IpaIO& io, dev_stream_t st, MsmStats* stats) {
         } else {
             if (k == r) {
                 GH.alloc((size_t)2 * M * B);
+#if defined(BPR1CS_HOSTSIM)
                 launch_wave((uint64_t)2 * M * B, K_ipa_fold_from_tables{g->tab.p, g->tc, cG, cH, GH.p, B, M, N, baseG, baseH}, st);
+#else
+                static const bool fold_functor = getenv("BPR1CS_FOLD_FUNCTOR") != nullptr;  // measurement knob
+                if (B < 32 || fold_functor) {
+                    launch_wave((uint64_t)2 * M * B, K_ipa_fold_from_tables{g->tab.p, g->tc, cG, cH, GH.p, B, M, N, baseG, baseH}, st);
+                } else {
+                    // the folded generators through the MSM kernel: output j of a side = the "chunk" of terms i = j (mod M), two
+                    // sides = two jobs of one launch (prefetch pipeline, XCD-aware placement of the workgroups sharing a row)
+                    MsmLaunch L{};
+                    L.B = B; L.nbk = (B + 63u) / 64u; L.tc = g->tc; L.njobs = 2;
+                    const MsmSeg none{nullptr, 0, 1, 1, 0, 0, 0};
+                    L.job[0] = MsmJob{{MsmSeg{cG, N, N, N, 0, baseG, 1}, none}, g->tab.p, GH.p, N / M, M, 1};
+                    L.job[1] = MsmJob{{MsmSeg{cH, N, N, N, 0, baseH, 1}, none}, g->tab.p, GH.p + (size_t)M * B, N / M, M, 1};
+                    L.wg_end[0] = M * L.nbk; L.wg_end[1] = 2 * M * L.nbk;
+                    L.nwg = (L.wg_end[1] + 7u) & ~7u;
+                    const size_t lds = (size_t)2 * g->tc.windows * 64 * sizeof(uint16_t);
+                    if (g->tc.fmt == TAB_FMT_PACKED) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_msm_fixed2<(int)TAB_FMT_PACKED, 3>), dim3(L.nwg), dim3(64), lds, st, L);
+                    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_msm_fixed2<(int)TAB_FMT_LIMB, 3>), dim3(L.nwg), dim3(64), lds, st, L);
+                    HIPCHK(hipGetLastError());
+                }
+#endif
                 vtab.alloc((size_t)8 * 4 * (M / 2 ? M / 2 : 1) * B);
                 vdig.alloc((size_t)8 * 4 * (M / 2 ? M / 2 : 1) * B);
                 vwin.alloc((size_t)2 * 64 * VC * B);
@@ -797,7 +834,7 @@ static void enqueue_ipa(const IpaIO& io, dev_stream_t st, MsmStats* stats) {
         launch(B, K_transcript_LR{io.tr, Lout, ukk, B}, st);
         launch((uint64_t)mk * B, K_ipa_fold_ab{a, bb, ukk, B, mk}, st);
         if (k < r) launch((uint64_t)N * B, K_ipa_update_c{cG, cH, ukk, B, Nk}, st);
-        else if (mk > 0 && k + 1 < lgN) launch_wave((uint64_t)2 * mk * B, K_ipa_vb_fold{GH.p, ukk, linv.p, B, mk, M}, st);
+        else if (mk > 0 && k + 1 < lgN) launch_wave((uint64_t)2 * mk * B, K_ipa_vb_fold{GH.p, ukk, linv.p, vtab.p, B, mk, M}, st);
     }
     if (sG.p) dev_zero(sG.p, sG.bytes(), st);  // products of the secret l / r vectors
     if (sH.p) dev_zero(sH.p, sH.bytes(), st);
@@ -976,7 +1013,9 @@ extern "C" int bpr1cs_prove_batch_begin(const bpr1cs_gens* g, const bpr1cs_circu
     // issues one scalar instruction per ~9 cycles, so the chain is 3.7x slower (717 ms per batch) and its 1024 resident
     // wavefronts still slow the co-running MSM launches by 40 % - measured 1000 proofs/s against 1590
     const bool rng_scalar = o_rng == 3;
-    if (o_rng == 4) {
+    if (o_rng == 5) {
+        hipLaunchKernelGGL(k_rng_rows, dim3((B + 7) / 8), dim3(64), 0, sl, rng.p, rng_raw.p, rng_err.p, B, draws);
+    } else if (o_rng == 4) {
         hipLaunchKernelGGL(k_rng_dpp, dim3(B), dim3(64), 0, sl, rng.p, rng_raw.p, rng_err.p, B, draws);
     } else if (rng_scalar) {
         hipLaunchKernelGGL(k_rng_scalar, dim3(B), dim3(64), 0, sl, rng.p, rng_raw.p, rng_err.p, B, draws);
@@ -1605,6 +1644,56 @@ extern "C" int bpr1cs_msm_fixed(const bpr1cs_gens* g, const uint32_t* bases, siz
     stats.collect();
     return BPR1CS_OK;
     API_CATCH
+}
+
+// Sustained instruction / primitive rates of the device this process runs on (bench.py's integer ceilings)
+extern "C" int bpr1cs_device_rates(double seconds_each, double* mad_lane_ops_per_s, double* table_adds_per_s) {
+    if (!mad_lane_ops_per_s || !table_adds_per_s || !(seconds_each > 0) || seconds_each > 2.0) return BPR1CS_ERR_INVALID_ARGUMENT;
+    if (!have_device()) return BPR1CS_ERR_NO_DEVICE;
+#if defined(BPR1CS_HOSTSIM)
+    *mad_lane_ops_per_s = 0; *table_adds_per_s = 0;
+    return BPR1CS_OK;
+#else
+    API_TRY
+    hipDeviceProp_t prop;
+    int dev = 0;
+    HIPCHK(hipGetDevice(&dev));
+    HIPCHK(hipGetDeviceProperties(&prop, dev));
+    const uint32_t blocks = (uint32_t)prop.multiProcessorCount * 8u, threads = 256;  // 8 wavefronts per SIMD
+    dev_stream_t st{};
+    CallScope scope(st);
+    DevBuf<uint32_t> out((size_t)blocks * threads);
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0));
+    HIPCHK(hipEventCreate(&e1));
+    auto timed = [&](int which, uint32_t iters) {
+        HIPCHK(hipEventRecord(e0, st));
+        if (which == 0) hipLaunchKernelGGL(k_probe_mad, dim3(blocks), dim3(threads), 0, st, out.p, iters);
+        else hipLaunchKernelGGL(k_probe_madd, dim3(blocks), dim3(threads), 0, st, out.p, iters);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipEventRecord(e1, st));
+        HIPCHK(hipEventSynchronize(e1));
+        float ms = 0;
+        HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+        return (double)ms * 1e-3;
+    };
+    double rate[2];
+    for (int which = 0; which < 2; which++) {
+        uint32_t iters = which == 0 ? 4096u : 64u;
+        double t = timed(which, iters);                       // calibration (also warms the clocks up)
+        double scale = seconds_each / (t > 1e-6 ? t : 1e-6);
+        uint64_t want = (uint64_t)((double)iters * (scale < 1 ? 1 : scale));
+        if (want > 0x7fffffffull) want = 0x7fffffffull;
+        t = timed(which, (uint32_t)want);
+        rate[which] = (double)blocks * threads * (double)want * (which == 0 ? 8.0 : 1.0) / t;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *mad_lane_ops_per_s = rate[0];
+    *table_adds_per_s = rate[1];
+    return BPR1CS_OK;
+    API_CATCH
+#endif
 }
 
 // ---------------------------------------------------------------- proof wire format

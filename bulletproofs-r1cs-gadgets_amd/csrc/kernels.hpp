@@ -688,6 +688,32 @@ struct K_msm_fixed {  // gid = wg*64 + lane -> partial[c*B + b]   (launch_wave)
         partial[(size_t)c * B + b] = ge_from_table_class(acc);
     }
 };
+// Small batches (B < 32: the cross-proof batched verifier evaluates ONE combined scalar vector): a wavefront of
+// K_msm_fixed / k_msm_fixed2 would carry B active lanes only, so here the lanes of a wave take different CHUNKS - thread
+// g = c * B + b sums chunk c for proof b; table rows differ per lane (gathers), scalar loads stay coalesced over b.
+struct K_msm_fixed_small {  // gid = c*B + b -> partial[c*B + b]
+    const uint8_t* tab;
+    TabCfg tc;
+    MsmSeg seg[2];
+    ge* partial;
+    uint32_t B, chunk, nchunks;
+    HD void operator()(uint32_t g) const {
+        uint32_t c = g / B, b = g % B;
+        uint32_t total = seg[0].count + seg[1].count;
+        uint32_t lo = c * chunk, hi = lo + chunk < total ? lo + chunk : total;
+        ge acc = ge_identity();
+        for (uint32_t o = lo; o < hi; o++) {
+            const MsmSeg& s = o < seg[0].count ? seg[0] : seg[1];
+            uint32_t oo = o < seg[0].count ? o : o - seg[0].count;
+            uint32_t i = s.sidx ? s.sidx[oo] : (oo / s.run) * s.period + s.off + (oo % s.run);
+            uint32_t base = s.base0 + (s.bdense ? oo : i);
+            sc x = s.scal[(size_t)i * B + b];
+            if (s.mont) x = sc_from_mont(x);
+            acc = table_mul_acc_raw(acc, tab + (size_t)base * tc.base_bytes(), x, tc);
+        }
+        partial[g] = ge_from_table_class(acc);
+    }
+};
 // second-level reduction of chunk partials: out[r*B + b] = sum_{k < group} in[(r*group + k)*B + b]
 struct K_ge_reduce {  // gid = r*B + b
     const ge* in;
@@ -992,7 +1018,16 @@ struct K_ipa_fold_from_tables {  // gid = (side*M + j)*B + b
     const sc* cH;
     ge* GH;  // [2][M][B]
     uint32_t B, M, N, baseG, baseH;
-    HD void operator()(uint32_t g) const {
+    HD void operator()(uint32_t g0) const {
+        // XCD-aware order (launch_wave: one wavefront per workgroup, workgroups dealt round-robin to the 8 XCDs): the
+        // wavefronts of one output (same table rows, different proofs) run on the same XCD
+        uint32_t g = g0;
+        const uint32_t nwg = (uint32_t)(((uint64_t)2 * M * B + 63u) / 64u);
+        if ((B & 63u) == 0 && (nwg & 7u) == 0) {
+            uint32_t wg = g0 >> 6;
+            wg = (wg & 7u) * (nwg >> 3) + (wg >> 3);
+            g = (wg << 6) | (g0 & 63u);
+        }
         uint32_t b = g % B, sj = g / B, side = sj / M, j = sj % M;
         const sc* c = side ? cH : cG;
         uint32_t base0 = side ? baseH : baseG;
@@ -1082,7 +1117,7 @@ struct K_ipa_vb_horner {  // gid = out*B + b : sum_w 16^w * S_w, S_w = sum of th
         uint32_t b = g % B, o = g / B;
         ge acc = ge_identity();
         for (int w = 63; w >= 0; w--) {
-            if (w != 63) { acc = ge_dbl(acc); acc = ge_dbl(acc); acc = ge_dbl(acc); acc = ge_dbl(acc); }
+            if (w != 63) acc = ge_dbl4(acc);
             const ge* p = part + (((size_t)o * 64 + (uint32_t)w) * VC) * B + b;
             for (uint32_t c = 0; c < VC; c++) acc = ge_add_ge(acc, p[(size_t)c * B]);
         }
@@ -1093,15 +1128,52 @@ struct K_ipa_vb_fold {  // gid = (b*2 + side)*m + j : Ghat'[j] = Ghat[j] + u^2 G
     ge* GH;
     const sc* uk;   // [2][B]: u, u^-1 (Montgomery)
     sc* linv;       // [2][B]
+    // the multiples 1P..8P of every "hi" generator were built for this round's L/R sums (K_ipa_vb_tab: w = 0 holds
+    // G_hi, w = 3 holds H_hi): the fold reuses them - signed radix-16 digits of the shared scalar, 63 x 4 doublings of
+    // which three in four skip the T coordinate, <= 64 additions of a ready multiple (instead of 253 full doublings +
+    // ~84 additions of the NAF ladder)
+    const ge_cached* vtab;  // [8][4*m*B]
     uint32_t B, m, M;
     HD void operator()(uint32_t g) const {
         uint32_t j = g % m, bs = g / m, side = bs & 1u, b = bs >> 1;
         ge* P = GH + (size_t)side * M * B;
         sc f = uk[(size_t)(side ? 1 : 0) * B + b];   // G: u ; H: u^-1
         sc w = sc_from_mont(sc_mul(f, f));
-        ge lo = P[(size_t)j * B + b], hi = P[(size_t)(j + m) * B + b];
-        ge r = ge_add_ge(lo, ge_scalarmul_naf(hi, w));
-        P[(size_t)j * B + b] = r;
+        const size_t stride = (size_t)4 * m * B;
+        const ge_cached* T = vtab + ((size_t)(side ? 3u : 0u) * m + j) * B + b;
+        ge acc = ge_identity();
+        // signed digits d_i in [-8, 7] as 4-bit two's complement, 8 per word (w < l < 2^253: digit 63 <= 1, no carry out);
+        // consumed most significant first with the word index a compile-time constant (no scratch-memory array)
+        uint32_t pk[8];
+        int carry = 0;
+#pragma unroll
+        for (int wi = 0; wi < 8; wi++) {
+            uint32_t o = 0;
+            for (int k = 0; k < 8; k++) {
+                int d = (int)((w.v[wi] >> (4 * k)) & 15u) + carry;
+                carry = d >= 8;
+                o |= ((uint32_t)(d - (carry << 4)) & 15u) << (4 * k);
+            }
+            pk[wi] = o;
+        }
+        bool started = false;
+#pragma unroll
+        for (int wi = 7; wi >= 0; wi--) {
+            const uint32_t word = pk[wi];
+            for (int k = 7; k >= 0; k--) {
+                if (started) acc = ge_dbl4(acc);
+                int d = (int)((word >> (4 * k)) & 15u);
+                if (d & 8) d -= 16;
+                if (d != 0) {
+                    int mag = d < 0 ? -d : d;
+                    ge_cached e = T[(size_t)(mag - 1) * stride];
+                    acc = d < 0 ? ge_sub(acc, e) : ge_add(acc, e);
+                    started = true;
+                }
+            }
+        }
+        ge lo = P[(size_t)j * B + b];
+        P[(size_t)j * B + b] = ge_add_ge(lo, acc);
         if (j == 0) {  // lam' = lam * f  ->  linv' = linv * f^-1
             sc finv = uk[(size_t)(side ? 0 : 1) * B + b];
             linv[(size_t)side * B + b] = sc_mul(linv[(size_t)side * B + b], finv);

@@ -412,3 +412,136 @@ __global__ void __launch_bounds__(64) k_rng_dpp(const strobe* rng_in, uint64_t* 
         }
     }
 }
+
+// ---------------------------------------------------------------- TranscriptRng chain, one ROW of the state per lane
+// k_rng_rows (rng mode 5): a Keccak state is spread over 5 lanes of an 8-lane group - lane y holds row y, i.e. the five
+// words A[0..4][y] - and a wavefront carries EIGHT proofs.  What each step costs per round:
+//   theta   column parities = XOR over the 5 row-lanes: a 3-step DPP all-reduce inside the 8-lane group (quad_perm
+//           1032, quad_perm 2301, row_half_mirror; the three spare lanes hold zeros) - no LDS, no barrier;
+//   rho     per-lane rotation amounts (5 constants per lane, two funnel shifts per word);
+//   pi      the only step that moves words between lanes: word (x, y) goes to lane Y = 2x + 3y as its word X = y -
+//           one LDS transpose per round (5 ds_write_b64 + 5 ds_read_b64 per lane for eight states);
+//   chi     entirely inside a lane (a row), iota on lane 0.
+// ~85 VALU + 10 DS instructions per round for EIGHT states against ~45 + 15 for two in k_rng_stream: the chain takes
+// 2.5x fewer issue slots from the MSM / IPA kernels of the batch it runs next to, at about the same latency per draw.
+#define K_DPP_XOR(v, ctrl) ((v) ^ (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), (ctrl), 0xf, 0xf, true))
+__global__ void __launch_bounds__(64) k_rng_rows(const strobe* rng_in, uint64_t* raw_out, int* err, uint32_t B, uint32_t draws) {
+    __builtin_amdgcn_s_setprio(3);
+    __shared__ uint64_t xch[8][33];  // per group: [0..24] the 5 x 5 state being transposed, [25] scratch of the spare lanes, [26..30] zeros
+    const uint32_t lane = threadIdx.x, y = lane & 7u, grp = lane >> 3;
+    uint32_t b = blockIdx.x * 8u + grp;
+    const bool valid = b < B;
+    if (!valid) b = B - 1;
+    const bool row = y < 5u;
+    if (rng_in[b].pos != 64 || rng_in[b].pos_begin != 0) {  // not the steady state: refuse (host reports an error)
+        if (lane == 0) atomicExch(err, 1);
+        return;
+    }
+    const int ROT[25] = {0, 1, 62, 28, 27, 36, 44, 6, 55, 20, 3, 10, 43, 25, 39, 41, 45, 15, 21, 8, 18, 2, 61, 56, 14};  // [x + 5y]
+    uint32_t L[5], H[5], rot_k[5], waddr[5];
+    bool rot_swap[5];
+#pragma unroll
+    for (int x = 0; x < 5; x++) {
+        uint64_t v = row ? rng_in[b].st[x + 5 * y] : 0ull;
+        L[x] = (uint32_t)v;
+        H[x] = (uint32_t)(v >> 32);
+        const int r = row ? ROT[x + 5 * y] : 0;
+        rot_swap[x] = r >= 32 || r == 0;          // rotl64 by r = (swap halves if r >= 32) then alignbit by 32 - (r & 31); r = 0: swap, shift 0
+        rot_k[x] = (32u - ((uint32_t)r & 31u)) & 31u;
+        waddr[x] = row ? ((2u * x + 3u * y) % 5u) * 5u + y : 25u;   // B[X = y][Y = 2x + 3y]; spare lanes write the pad word
+    }
+    uint64_t* buf = xch[grp];
+    if (y < 5u) buf[26 + y] = 0;   // the spare lanes gather zeros: their state stays zero and never disturbs the column parities
+    const uint32_t raddr = row ? y * 5u : 26u;
+    lds_order();
+    const uint32_t m0 = (row && y == 0u) ? 0xffffffffu : 0u, m1 = y == 1u ? 0xffffffffu : 0u, m4 = y == 4u ? 0xffffffffu : 0u;
+    for (uint32_t d = 0; d < draws; d++) {
+        // STROBE framing of fill_bytes(64) in the steady state (see merlin_rng_scalar): words 8, 9 (row 1), 20 (row 4)
+        L[3] ^= 0x00401200u & m1; H[3] ^= 0x07410000u & m1;
+        L[4] ^= 0x00000447u & m1;
+        H[0] ^= 0x80000000u & m4;
+#pragma unroll
+        for (int r = 0; r < 24; r++) {
+            uint32_t cl[5], ch[5];
+#pragma unroll
+            for (int x = 0; x < 5; x++) {  // theta: column parities over the row-lanes of the group
+                uint32_t a = L[x], c = H[x];
+                a = K_DPP_XOR(a, 0xB1); c = K_DPP_XOR(c, 0xB1);      // quad_perm [1,0,3,2]
+                a = K_DPP_XOR(a, 0x4E); c = K_DPP_XOR(c, 0x4E);      // quad_perm [2,3,0,1]
+                a = K_DPP_XOR(a, 0x141); c = K_DPP_XOR(c, 0x141);    // row_half_mirror
+                cl[x] = a; ch[x] = c;
+            }
+#pragma unroll
+            for (int x = 0; x < 5; x++) {
+                const int xm = (x + 4) % 5, xp = (x + 1) % 5;
+                uint32_t tl = K_XOR3(L[x], cl[xm], __builtin_amdgcn_alignbit(cl[xp], ch[xp], 31));   // a ^ C[x-1] ^ rol(C[x+1], 1)
+                uint32_t th = K_XOR3(H[x], ch[xm], __builtin_amdgcn_alignbit(ch[xp], cl[xp], 31));
+                uint32_t ul = rot_swap[x] ? th : tl, uh = rot_swap[x] ? tl : th;                        // rho
+                uint32_t nl = __builtin_amdgcn_alignbit(ul, uh, rot_k[x]), nh = __builtin_amdgcn_alignbit(uh, ul, rot_k[x]);
+                buf[waddr[x]] = ((uint64_t)nh << 32) | nl;                                               // pi (scatter)
+            }
+            lds_order();
+            uint32_t bl[5], bh[5];
+#pragma unroll
+            for (int x = 0; x < 5; x++) {
+                uint64_t v = buf[raddr + x];
+                bl[x] = (uint32_t)v;
+                bh[x] = (uint32_t)(v >> 32);
+            }
+#pragma unroll
+            for (int x = 0; x < 5; x++) {  // chi inside the row
+                L[x] = K_CHI(bl[x], bl[(x + 1) % 5], bl[(x + 2) % 5]);
+                H[x] = K_CHI(bh[x], bh[(x + 1) % 5], bh[(x + 2) % 5]);
+            }
+            L[0] = __builtin_amdgcn_bitop3_b32(L[0], (uint32_t)KECCAK_RC[r], m0, 0x78);          // iota: a ^ (RC & lane-0 mask)
+            H[0] = __builtin_amdgcn_bitop3_b32(H[0], (uint32_t)(KECCAK_RC[r] >> 32), m0, 0x78);
+            lds_order();  // the next round's scatter must not overtake this round's gather
+        }
+        // prf squeeze: the first 8 words (row 0: all five, row 1: three) are the output and are zeroed
+#pragma unroll
+        for (int x = 0; x < 5; x++) {
+            const bool out = row && (y == 0u || (y == 1u && x < 3));
+            if (out) {
+                if (valid) raw_out[((size_t)d * B + b) * 8 + x + 5u * y] = ((uint64_t)H[x] << 32) | L[x];
+                L[x] = 0; H[x] = 0;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------- on-device rate probes (bpr1cs_device_rates)
+// The ceilings bench.py prices the dominant kernel against, measured on the chip it runs on and for long enough
+// (tens of ms) that the clock has settled to its power budget: (a) the issue rate of v_mad_i64_i32 - 8 independent
+// chains per lane, every SIMD busy; (b) a chain of table additions (ge_madd_t) on register operands: the dominant
+// kernel's inner loop without its table gathers.
+__global__ void __launch_bounds__(256) k_probe_mad(uint32_t* out, uint32_t iters) {
+    uint32_t t = threadIdx.x + blockIdx.x * 256u;
+    int64_t a0 = t * 3 + 1, a1 = t * 5 + 1, a2 = t * 7 + 2, a3 = t * 11 + 3, a4 = t + 9, a5 = t + 17, a6 = t ^ 0x55, a7 = t ^ 0x99;
+    int32_t x = (int32_t)(t | 1), y = (int32_t)((t * 2654435761u) | 1);
+    for (uint32_t i = 0; i < iters; i++) {
+        asm volatile("v_mad_i64_i32 %0, vcc, %8, %9, %0\n\tv_mad_i64_i32 %1, vcc, %8, %9, %1\n\tv_mad_i64_i32 %2, vcc, %8, %9, %2\n\tv_mad_i64_i32 %3, vcc, %8, %9, %3\n\t"
+                     "v_mad_i64_i32 %4, vcc, %8, %9, %4\n\tv_mad_i64_i32 %5, vcc, %8, %9, %5\n\tv_mad_i64_i32 %6, vcc, %8, %9, %6\n\tv_mad_i64_i32 %7, vcc, %8, %9, %7"
+                     : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)
+                     : "v"(x), "v"(y)
+                     : "vcc");
+    }
+    out[t] = (uint32_t)(a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7);
+}
+__global__ void __launch_bounds__(256) k_probe_madd(uint32_t* out, uint32_t iters) {
+    uint32_t t = threadIdx.x + blockIdx.x * 256u;
+    ge p = ge_basepoint();
+    ge_niels q = ge_table_niels_identity();
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        p.X.v[i] += (int32_t)((t * 2654435761u) >> 5 & 0xfffffu);
+        q.yplusx.v[i] = (int32_t)((t + 77u * i) & 0x1fffffffu);
+        q.yminusx.v[i] = (int32_t)((t * 31u + i) & 0x1fffffffu);
+        q.xy2d.v[i] = (int32_t)((t ^ (0x9e3779b9u * (i + 1))) & 0x1fffffffu);
+    }
+    for (uint32_t i = 0; i < iters; i++) p = ge_madd_t(p, q, (int)(i & 1u));
+    fe a = fe_add(fe_add(p.X, p.Y), fe_add(p.Z, p.T));
+    uint32_t o = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) o ^= (uint32_t)a.v[i];
+    out[t] = o;
+}

@@ -23,6 +23,8 @@ struct MsmJob {
     const uint8_t* tab;  // table the job's base indices refer to
     ge* partial;         // [nchunks][B] chunk sums (ordinary class)
     uint32_t chunk, nchunks;
+    uint32_t interleave; // 0: chunk c = ordinals [c*chunk, (c+1)*chunk) ; 1: chunk c = ordinals c, c + nchunks, c + 2 nchunks, ...
+                         // (the IPA's folded generators: output j sums the terms i = j mod M, see enqueue_ipa)
 };
 struct MsmLaunch {
     MsmJob job[MSM_MAX_JOBS];
@@ -133,12 +135,14 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) k_msm_fixed2(const MsmLaun
     const bool active = b < B;
     if (!active) b = B - 1;  // ragged batch: the spare lanes repeat the last proof and do not store
     const uint32_t total = J.seg[0].count + J.seg[1].count;
-    const uint32_t lo = c * J.chunk, hi = lo + J.chunk < total ? lo + J.chunk : total;
+    const uint32_t step = J.interleave ? J.nchunks : 1u;
+    const uint32_t lo = J.interleave ? c : c * J.chunk;
+    const uint32_t hi = J.interleave ? total : (lo + J.chunk < total ? lo + J.chunk : total);
     const uint32_t dig_buf = tc.windows * 64u;  // digits of term parity p start at msm_dig[p * dig_buf + lane]
 
     // fetch the next term whose scalars are not all zero (IPA round 0: the l-vector is zero beyond n)
     auto fetch = [&](uint32_t& o, sc& x, MsmTerm& t) -> bool {
-        for (; o < hi; o++) {
+        for (; o < hi; o += step) {
             t = msm_term(J, o, B, tc);
             x = t.scal[b];
             if (__ballot(!sc_is_zero(x)) != 0ull) return true;
@@ -158,7 +162,7 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) k_msm_fixed2(const MsmLaun
         msm_entry_load(E, T.tab + (size_t)(d & 0x7fffu) * tc.stride);
     }
     while (have) {
-        uint32_t o2 = o + 1;
+        uint32_t o2 = o + step;
         sc x2;
         MsmTerm T2;
         bool have2 = fetch(o2, x2, T2);

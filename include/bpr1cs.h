@@ -286,6 +286,9 @@ void bpr1cs_set_witness_team(int t);
  *     measured alternative, never chosen automatically;
  * 4 = one state per wavefront, lane = 8y + x, theta by DPP row shifts and the gfx950 v_permlane16/32_swap row
  *     all-reduce, pi/chi by ds_bpermute: no LDS memory or barriers, but more VALU instructions - 8 % slower than 1;
+ * 5 = one ROW of the state per lane, eight proofs per wavefront: column parities by a DPP all-reduce inside 8-lane groups, one
+ *     LDS transpose per round (pi), chi inside the lane - 2.5x fewer instructions per draw than 1, but 1.5x its latency
+ *     (246 vs 160 ms per 1024-proof batch) and 5 % slower end to end with two batches in flight: measured alternative;
  * 0 = automatic: 1 (2 if CUs are reserved for it and another batch is in flight). */
 void bpr1cs_set_rng_mode(int mode);
 
@@ -309,6 +312,11 @@ int bpr1cs_last_timings(float* out, int cap);
  * summed launch durations (ms, events recorded on the kernel's own stream), number of launches and
  * number of scalar*point terms processed (summed over the batch). */
 int bpr1cs_last_msm_stats(double* ms_total, uint64_t* launches, uint64_t* terms);
+
+/* diagnostic: sustained rates of the device (each probe runs for about `seconds_each`, long enough for the clock to settle
+ * to its power budget): lane-operations per second of v_mad_i64_i32 with every SIMD busy, and table additions (ge_madd_t
+ * chains on register operands) per second - the integer ceilings bench.py prices the fixed-base MSM kernel against. */
+int bpr1cs_device_rates(double seconds_each, double* mad_lane_ops_per_s, double* table_adds_per_s);
 
 #ifdef __cplusplus
 }

@@ -59,7 +59,7 @@ def test_poseidon_hash_2_cube(hip_lib):
     common.check_against_oracle(hip_lib, lambda j: S.poseidon_hash_2(S.synth_scalar(b"xl", j), S.synth_scalar(b"xr", j), g.CUBE), 512, 2, 4)
 
 
-@pytest.mark.parametrize("mode", [1, 2, 3, 4])
+@pytest.mark.parametrize("mode", [1, 2, 3, 4, 5])
 def test_rng_chain_mappings_agree(hip_lib, mode):
     """TranscriptRng chain: one Keccak state over 25 lanes (k_rng_stream), one state per thread (k_rng_thread) and one
     state per wavefront on the scalar unit (k_rng_scalar) must all reproduce the oracle's blinding factors, i.e. its proof bytes; ragged batch (not a multiple of 64)."""

@@ -109,8 +109,8 @@ int main(int argc, char** argv) {
         auto run2 = [&](bool merged, int occ) {
             MsmLaunch L{};
             L.B = B; L.nbk = nbk; L.tc = tc;
-            L.job[0] = MsmJob{{gL, hL}, tab, partL.p, chunk, nchunks};
-            L.job[1] = MsmJob{{gR, hR}, tab, partR.p, chunk, nchunks};
+            L.job[0] = MsmJob{{gL, hL}, tab, partL.p, chunk, nchunks, 0};
+            L.job[1] = MsmJob{{gR, hR}, tab, partR.p, chunk, nchunks, 0};
             size_t lds = (size_t)2 * tc.windows * 64 * sizeof(uint16_t);
             auto go = [&](MsmLaunch LL) {
                 uint32_t wgs = LL.wg_end[LL.njobs - 1];

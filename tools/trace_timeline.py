@@ -15,6 +15,8 @@ def short(n):
     n = n.split("(")[0]
     for k in ("k_rng_stream", "k_witness_team"):
         if k in n: return k
+    if "k_msm_fixed2" in n: return "k_msm_fixed2"
+    if "k_functor_wave<" in n: return n.split("k_functor_wave<")[1].split(">")[0]
     if "k_functor<" in n: return n.split("k_functor<")[1].split(">")[0]
     return n[:40]
 print("# front kernels: name queue start_ms end_ms dur_ms")
