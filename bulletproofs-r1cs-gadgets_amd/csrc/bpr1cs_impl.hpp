@@ -209,7 +209,7 @@ void bpr1cs_set_witness_team(int t) { g_witness_team = (t == 4 || t == 8) ? t : 
 void bpr1cs_set_witness_macro(int enable) { g_witness_macro = enable ? 1 : 0; }
 void bpr1cs_set_rng_mode(int mode) { g_rng_mode = (mode >= 1 && mode <= 5) ? mode : 0; }
 int bpr1cs_circuit_macro_perms(const bpr1cs_circuit* c) { return c ? (int)c->n_perms : 0; }
-void bpr1cs_set_window_bits(int w) { g_window_bits = w < 4 ? 4 : (w > 12 ? 12 : w); }
+void bpr1cs_set_window_bits(int w) { g_window_bits = w <= 0 ? 0 : (w < 4 ? 4 : (w > 12 ? 12 : w)); }  // 0 = choose from the free memory
 void bpr1cs_set_table_format(int f) { g_table_format = (f == 0 || f == 1) ? f : -1; }
 int bpr1cs_gens_set_option(bpr1cs_gens* g, int option, int value) {
     if (!g) return BPR1CS_ERR_INVALID_ARGUMENT;
@@ -248,7 +248,19 @@ int bpr1cs_gens_create(uint32_t cap, bpr1cs_gens** out) {
     API_TRY
     g = new bpr1cs_gens();
     g->cap = cap;
-    const int window_bits = g_window_bits.load(), latency_cus = g_latency_cus.load();
+    int window_bits = g_window_bits.load();
+    const int latency_cus = g_latency_cus.load();
+    if (window_bits == 0) {  // automatic: the widest window (<= 11) whose packed tables leave 45 % of the free memory to the workspaces
+        window_bits = 8;
+#if !defined(BPR1CS_HOSTSIM)
+        size_t mfree = 0, mtotal = 0;
+        if (hipMemGetInfo(&mfree, &mtotal) == hipSuccess)
+            for (int w = 11; w >= 4; w--) {
+                TabCfg t = tab_cfg((uint32_t)w, TAB_FMT_PACKED, 96);
+                if ((double)(2 + 2 * (size_t)cap) * (double)t.base_bytes() <= 0.55 * (double)mfree) { window_bits = w; break; }
+            }
+#endif
+    }
     {   // table entry format: the limb form (no unpacking in the inner loop, 128-byte aligned slots) costs a third more
         // HBM than the packed one - take it when the device keeps >= 100 GB free for circuits' merged tables and the
         // per-batch workspace (two 1024-proof jobs of the depth-32 circuit in flight need ~55 GB)
@@ -1273,7 +1285,13 @@ static void verify_front(VerifyCtx& v, const bpr1cs_gens* g, const bpr1cs_circui
     run_flatten(c, nslots, v.plo.p, v.phi.p, v.wvec.p, B, v.H, st);
     v.gh.alloc((size_t)2 * N * B); v.dpart.alloc((size_t)N * B); v.delta.alloc(B); v.bsc.alloc((size_t)2 * B);
     launch((uint64_t)N * B, K_verify_gh{v.wvec.p, v.plo.p, v.phi.p, v.chal.p, v.uk.p, v.gh.p, v.gh.p + (size_t)N * B, v.dpart.p, B, v.H, n, N, lgN}, st);
-    launch(B, K_sum_partials{v.dpart.p, v.delta.p, B, N}, st);
+    if (N >= 1024) {  // delta = sum_i y^-i wR_i wL_i in two levels (one thread per proof walking N values alone takes ~12 ms)
+        DevBuf<sc> dsum((size_t)(N / 256) * B);
+        launch((uint64_t)(N / 256) * B, K_sum_partials{v.dpart.p, dsum.p, B, 256}, st);
+        launch(B, K_sum_partials{dsum.p, v.delta.p, B, N / 256}, st);
+    } else {
+        launch(B, K_sum_partials{v.dpart.p, v.delta.p, B, N}, st);
+    }
     launch(B, K_verify_bscalars{v.chal.p, v.wvec.p + (size_t)(3 * n + m) * B, v.delta.p, v.bsc.p, B}, st);
     v.P = 8 + m + 2 * lgN;
 }
@@ -1318,7 +1336,10 @@ static void verify_combine(CombinedCtx& k, VerifyCtx& v, const uint8_t* batch_se
     const uint32_t B = v.B, N = v.N;
     k.d_bseed.alloc(32); k.digest.alloc(32); k.rho.alloc(B);
     dev_h2d(k.d_bseed.p, batch_seed, 32, st);
-    launch(1, K_batch_digest{k.d_bseed.p, v.bind.p, k.digest.p, index_base, B}, st);
+    const uint32_t leaves = (B + BATCH_LEAF - 1) / BATCH_LEAF;
+    DevBuf<uint8_t> leaf((size_t)leaves * 32);
+    launch(leaves, K_batch_leaf{v.bind.p, leaf.p, B}, st);
+    launch(1, K_batch_digest{k.d_bseed.p, leaf.p, k.digest.p, index_base, B}, st);
     launch(B, K_batch_weights{k.digest.p, k.rho.p, index_base}, st);
     k.cgh.alloc((size_t)2 * N); k.cb.alloc(2);
     launch((uint64_t)2 * N, K_combine_scalars{v.gh.p, k.rho.p, k.cgh.p, B}, st);

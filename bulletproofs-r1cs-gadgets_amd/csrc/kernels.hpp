@@ -1401,9 +1401,24 @@ struct K_verify_points {  // gid = p*B + b, p < 8 + m + 2 lgN
 // The weights must be unpredictable to whoever chose the proofs: they are drawn from a transcript that absorbs the
 // caller's seed (fresh randomness) AND a binding value of every proof and commitment of the batch, so no proof can be
 // crafted against weights known in advance (a forger would need sum_j rho_j * defect_j = 0).
-struct K_batch_digest {  // single thread: D = challenge("digest") of Merlin("bpr1cs batch verify") <- seed, index_base, B, bind[0..B)
-    const uint8_t* seed;  // 32 bytes
+#define BATCH_LEAF 32u  // proofs per leaf of the two-level digest (a single thread absorbing thousands of values would take ~10 ms)
+struct K_batch_leaf {  // gid = leaf : leaf[gid] = challenge("leaf") of Merlin("bpr1cs batch leaf") <- leaf index, bind[32 gid .. 32 gid + 32)
     const uint8_t* bind;  // [B][32]
+    uint8_t* leaf;        // [ceil(B / 32)][32]
+    uint32_t B;
+    HD void operator()(uint32_t g) const {
+        strobe t;
+        const char lab[] = "bpr1cs batch leaf";
+        merlin_new(t, (const uint8_t*)lab, sizeof(lab) - 1);
+        merlin_append_u64(t, "leaf", 4, g);
+        uint32_t lo = g * BATCH_LEAF, hi = lo + BATCH_LEAF < B ? lo + BATCH_LEAF : B;
+        for (uint32_t b = lo; b < hi; b++) merlin_append(t, "proof", 5, bind + 32 * (size_t)b, 32);
+        merlin_challenge_bytes(t, "leaf", 4, leaf + 32 * (size_t)g, 32);
+    }
+};
+struct K_batch_digest {  // single thread: D = challenge("digest") of Merlin("bpr1cs batch verify") <- seed, index_base, B, leaf[0..)
+    const uint8_t* seed;  // 32 bytes
+    const uint8_t* leaf;  // [ceil(B / 32)][32]
     uint8_t* digest;      // 32 bytes
     uint64_t index_base;
     uint32_t B;
@@ -1414,7 +1429,8 @@ struct K_batch_digest {  // single thread: D = challenge("digest") of Merlin("bp
         merlin_append(t, "seed", 4, seed, 32);
         merlin_append_u64(t, "base", 4, index_base);
         merlin_append_u64(t, "count", 5, B);
-        for (uint32_t b = 0; b < B; b++) merlin_append(t, "proof", 5, bind + 32 * (size_t)b, 32);
+        const uint32_t leaves = (B + BATCH_LEAF - 1) / BATCH_LEAF;
+        for (uint32_t g = 0; g < leaves; g++) merlin_append(t, "leaf", 4, leaf + 32 * (size_t)g, 32);
         merlin_challenge_bytes(t, "digest", 6, digest, 32);
     }
 };

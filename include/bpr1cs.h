@@ -264,7 +264,8 @@ void bpr1cs_set_unfold_rounds(int r);
 /* tuning knob, read by bpr1cs_gens_create: signed window width W (4..12) of the fixed-base tables.
  * A term costs ceil(253/W) mixed additions (the top window of a canonical scalar never carries out); table bytes =
  * (2+2*cap) * ceil(253/W) * (2^(W-1) + 1) * 96 (packed) or 128 (limb form)  (W=8: 26 / 35 GB, W=11: 148 / 198 GB at
- * capacity 32768).  Default 8.  Capacity limit: W=11 serves N <= 32768 on a 288 GB device; the reference's as-shipped
+ * capacity 32768).  Default 8; 0 = automatic (the widest W <= 11 whose packed tables fit in 55 % of the free device memory).
+ * Capacity limit: W=11 serves N <= 32768 on a 288 GB device; the reference's as-shipped
  * tree depths (N = 131072 / 262144, gadget_vsmt_4.rs:25, gadget_vsmt_2.rs:23) need W <= 8. */
 void bpr1cs_set_window_bits(int w);
 
