@@ -50,18 +50,29 @@ def verify_sharded(bp, gens, circuit, label, proofs, commitments, batch, rank, w
       4. all_gather of (slice point, own-points sum, well-formed flag): 65 bytes per rank; accept iff the sum of all
          points is the identity and every rank was well-formed.
     Every rank returns the same verdict."""
-    vec, own, wf = bp.verify_batch_scalars(gens, circuit, label, proofs, commitments, batch, batch_seed=batch_seed, index_base=index_base)
-    total = bp.scalars_sum(_all_gather_bytes(vec, group, device), lib=gens.lib)
-    nb = len(total) // 32
-    lo, hi = shard_range(nb, rank, world)
-    if hi > lo:
-        # base order of the vector == base indices of bpr1cs_msm_fixed (0 = B, 1 = B~, 2+i = G[i], 2+cap+i = H[i]) when N == capacity;
-        # for N < capacity the H block starts at 2 + capacity
-        N = (nb - 2) // 2
-        bases = [i if i < 2 + N else i - N + gens.capacity for i in range(lo, hi)]
-        slice_pt = gens.msm_fixed(bases, total[32 * lo:32 * hi], 1)[0]
-    else:
-        slice_pt = bytes(32)
+    # a rank that fails locally still takes part in both collectives (with a zero vector and a "not well-formed" flag):
+    # the other ranks must never be left waiting in an all_gather
+    N = 1 << max(0, (circuit.n - 1).bit_length())
+    nb = 2 * N + 2
+    try:
+        vec, own, wf = bp.verify_batch_scalars(gens, circuit, label, proofs, commitments, batch, batch_seed=batch_seed, index_base=index_base)
+    except Exception:
+        vec, own, wf = bytes(32 * nb), bytes(32), False
+    gathered = _all_gather_bytes(vec, group, device)
+    slice_pt = bytes(32)
+    try:
+        total = bp.scalars_sum(gathered, lib=gens.lib)
+        lo, hi = shard_range(nb, rank, world)
+        if hi > lo:
+            # base order of the vector == base indices of bpr1cs_msm_fixed (0 = B, 1 = B~, 2+i = G[i], 2+cap+i = H[i]) when N == capacity;
+            # for N < capacity the H block starts at 2 + capacity
+            bases = [i if i < 2 + N else i - N + gens.capacity for i in range(lo, hi)]
+            slice_pt = gens.msm_fixed(bases, total[32 * lo:32 * hi], 1)[0]
+    except Exception:
+        wf = False
     parts = _all_gather_bytes(slice_pt + own + bytes([1 if wf else 0]), group, device)
     pts = [p[:32] for p in parts] + [p[32:64] for p in parts]
-    return all(p[64] == 1 for p in parts) and bp.points_sum_is_identity(pts, lib=gens.lib)
+    try:
+        return all(p[64] == 1 for p in parts) and bp.points_sum_is_identity(pts, lib=gens.lib)
+    except Exception:
+        return False
