@@ -144,6 +144,11 @@ def check_validation(lib):
     assert lib.bpr1cs_msm_fixed(gens.h, bp._u32arr([0, 1]), 2, bytes(32) + bigL, 1, out) == -17
     assert lib.bpr1cs_msm(bigL, gens.point(0), 1, out) == -17
     assert lib.bpr1cs_msm_fixed(gens.h, bp._u32arr([0, 2 + 2 * cap]), 2, bytes(64), 1, out) == -17   # base index out of range
+    # a batch whose largest launch would not fit 2^32 threads is refused up front (no abort, nothing allocated)
+    job = ctypes.c_void_p()
+    assert lib.bpr1cs_prove_batch_begin(gens.h, circ.h, b"x", 1, ob["values"], ob["blindings"], ob["seeds"], ob["wires"], (1 << 20) + 1, ctypes.byref(job)) == -17
+    okbuf = (ctypes.c_int * 1)()
+    assert lib.bpr1cs_verify_batch(gens.h, circ.h, b"x", 1, bytes(circ.proof_len), bytes(32 * ob["m"]), None, 1 << 31, okbuf) == -17
 
 
 def check_split_verifier(lib, glib, batch=4):

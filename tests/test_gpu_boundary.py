@@ -27,3 +27,18 @@ def test_split_shared_base_verifier(hip_lib, hip_glib):
 
 def test_two_threads_two_handles(hip_lib, hip_glib):
     bc.check_two_threads_two_handles(hip_lib, hip_glib, rounds=4)
+
+
+def test_out_of_memory_is_an_error_code_not_an_abort(hip_lib):
+    """Generator tables that cannot fit (capacity 2^22 at W = 11: ~25 TB) make bpr1cs_gens_create return
+    BPR1CS_ERR_OUT_OF_MEMORY; the process and the device stay usable."""
+    import ctypes
+    bp = bc.bp
+    hip_lib.bpr1cs_set_window_bits(11)
+    try:
+        h = ctypes.c_void_p()
+        assert hip_lib.bpr1cs_gens_create(1 << 22, ctypes.byref(h)) == -19
+    finally:
+        hip_lib.bpr1cs_set_window_bits(8)
+    g = bp.Gens(16, lib=hip_lib)   # still works
+    assert len(g.point(2, 3)) == 32
