@@ -30,13 +30,19 @@ def test_pipeline_factors(sim_lib):
 
 
 def test_pipeline_other_window_widths(sim_lib):
-    """fixed-base tables with 5- and 10-bit signed windows give the same proofs"""
+    """fixed-base tables with 5-, 10- and 11-bit signed windows (11: 23 windows, the top one keeps its digit), packed and
+    limb-form storage, give the same proofs"""
     try:
-        for w in (5, 10):
+        for w, fmt in ((5, 0), (10, 0), (11, 0), (11, 1), (4, 1)):
             sim_lib.bpr1cs_set_window_bits(w)
-            common.check_against_oracle(sim_lib, lambda j: S.bound_check(39 + j, 10, 100, 7), 16, 2, 2)
+            sim_lib.bpr1cs_set_table_format(fmt)
+            g = common.bp.Gens(16, lib=sim_lib)
+            info = g.table_info()
+            assert (info["window_bits"], info["format"], info["windows"]) == (w, fmt, -(-253 // w))
+            common.check_against_oracle(sim_lib, lambda j: S.bound_check(39 + j, 10, 100, 7), 16, 2, 2, gens=g)
     finally:
         sim_lib.bpr1cs_set_window_bits(8)
+        sim_lib.bpr1cs_set_table_format(-1)
 
 
 def test_two_jobs_in_flight(sim_lib):
