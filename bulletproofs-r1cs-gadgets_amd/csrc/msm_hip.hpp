@@ -14,6 +14,7 @@
 //     The entry registers are dead between the layers: the prefetch costs no extra VGPRs.
 //   * Digit 0 selects slot 0 of the row (the identity, see TabCfg): no divergent branch inside the pipeline.
 //   * Accumulator in the "table class" (ge_madd_t): five of seven products use the cheaper floor-carry multiplier.
+//   * Signed digits without selects: a per-lane polarity of the accumulator (see the loop body).
 #pragma once
 #include <hip/hip_runtime.h>
 #include "kernels.hpp"
@@ -150,6 +151,7 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) k_msm_fixed2(const MsmLaun
         return false;
     };
     ge acc = ge_identity();
+    int32_t pol = 0;  // 0: acc = +S, -1: acc = -S
     uint32_t o = lo, cur = 0;
     sc x;
     MsmTerm T;
@@ -169,11 +171,21 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) k_msm_fixed2(const MsmLaun
         if (have2) msm_recode(T2.mont ? sc_from_mont(x2) : x2, msm_dig + (cur ^ 1u) * dig_buf + lane, tc);
         for (uint32_t k = 0; k < tc.windows; k++) {
             // ---- layer 1: the three products that read the table entry
-            const int neg = (int)(d >> 15);
+            // Sign of the digit without a single select: the accumulator holds pol * S (pol = +-1 per lane).  S + s q with
+            // s = pol is acc + q; with s = -pol it is -((-acc) + q): so acc is negated first whenever the signs differ
+            // ((x ^ m) - m on X and T, one v_xad_u32 per limb) and the polarity becomes s - the addition itself is
+            // always the plain one (no swap of y+x / y-x, no swap of cZ / cT).
+            const int32_t sgn = -(int32_t)(d >> 15);   // -1: negative digit
+            const int32_t flip = sgn ^ pol;
+            pol = sgn;
+#pragma unroll
+            for (int i = 0; i < 9; i++) {
+                acc.X.v[i] = (acc.X.v[i] ^ flip) - flip;
+                acc.T.v[i] = (acc.T.v[i] ^ flip) - flip;
+            }
             ge_niels q = msm_entry_unpack(E);
-            fe a = fe_select(q.yplusx, q.yminusx, neg), bq = fe_select(q.yminusx, q.yplusx, neg);
-            fe PP = fe_mul_f(fe_add(acc.Y, acc.X), a);
-            fe MM = fe_mul_f(fe_sub(acc.Y, acc.X), bq);
+            fe PP = fe_mul_f(fe_add(acc.Y, acc.X), q.yplusx);
+            fe MM = fe_mul_f(fe_sub(acc.Y, acc.X), q.yminusx);
             fe Txy2d = fe_mul(acc.T, q.xy2d);
             // ---- request the next entry: it lands while layer 2 runs
             __builtin_amdgcn_sched_barrier(0);
@@ -187,11 +199,15 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) k_msm_fixed2(const MsmLaun
             __builtin_amdgcn_sched_barrier(0);
             // ---- layer 2
             fe cX = fe_sub(PP, MM), cY = fe_add(PP, MM);
-            fe zp = fe_add(acc.Z, Txy2d), zm = fe_sub(acc.Z, Txy2d);  // halved table operands: Z, not 2Z (ge_madd_t)
-            fe cZ = fe_select(zp, zm, neg), cT = fe_select(zm, zp, neg);
+            fe cZ = fe_add(acc.Z, Txy2d), cT = fe_sub(acc.Z, Txy2d);  // halved table operands: Z, not 2Z (ge_madd_t)
             acc.X = fe_mul_f(cX, cT); acc.Y = fe_mul_f(cY, cZ); acc.Z = fe_mul(cZ, cT); acc.T = fe_mul_f(cX, cY);
         }
         o = o2; T = T2; have = have2; cur ^= 1u;
+    }
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        acc.X.v[i] = (acc.X.v[i] ^ pol) - pol;
+        acc.T.v[i] = (acc.T.v[i] ^ pol) - pol;
     }
     if (active) J.partial[(size_t)c * B + b] = ge_from_table_class(acc);
 }
