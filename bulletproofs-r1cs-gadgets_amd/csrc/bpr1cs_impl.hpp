@@ -1,6 +1,7 @@
-// Host orchestration of the batched prover + the C ABI of include/bpr1cs.h.
-// One HIP stream per call; all per-batch state lives in HBM for the whole
-// prove (inputs are uploaded once, only proofs/commitments come back).
+// Host orchestration of the batched prover / verifier + the C ABI of include/bpr1cs.h.
+// A prove job runs its latency-bound front on its own HIP streams and its VALU-bound back on the handle's one heavy
+// stream (two jobs in flight overlap); all per-batch state lives in HBM for the whole prove (inputs are uploaded
+// once, only proofs/commitments come back).  No mutable process-global state on the call path (see BpOpts, LastStats).
 #pragma once
 #include <vector>
 #include <map>

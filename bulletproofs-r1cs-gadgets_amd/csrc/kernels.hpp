@@ -3,12 +3,14 @@
 // Data layout in HBM: every per-proof vector is stored element-major /
 // proof-minor, X[i*B + b], 32-byte scalars in Montgomery form -> the 64 lanes of
 // a wavefront are 64 consecutive proofs touching one contiguous 2 KiB run.
-// Fixed-base tables: for each base P (B, B~, G_i, H_i) and each of the 32 byte
-// windows k, the 128 affine-Niels multiples j*2^(8k)*P, j=1..128 (96 B each):
-//     tab[(base*32 + k)*128 + (j-1)]
-// Signed radix-2^W digits turn s*P into <= ceil(254/W) mixed additions, no doublings
-// (W = 8: 32 additions, 25.8 GB of tables at capacity 32768; W = 10: 26 additions, 84 GB).
+// Fixed-base tables: for each base P (B, B~, G_i, H_i) and each W-bit window k a row of 2^(W-1) + 1 slots - slot 0 the
+// identity, slot j the multiple j * 2^(W k) * P in halved affine Niels form (TabCfg below, ge.hpp):
+//     tab + ((base * windows + k) * row + j) * stride
+// Signed radix-2^W digits turn s*P into ceil(253/W) table additions, no doublings
+// (W = 8: 32 additions, 26 / 35 GB of tables at capacity 32768; W = 11: 23 additions, 148 / 198 GB).
 //
+// The functors below are what the CPU simulator of the tests runs kernel by kernel; on the device the dominant one
+// (K_msm_fixed) is replaced by csrc/msm_hip.hpp and the cooperative ones by csrc/kernels_hip.hpp.
 // Each functor is one kernel; `gid` enumerates (index, proof) pairs with the
 // proof index fastest.
 #pragma once
