@@ -136,11 +136,12 @@ struct bpr1cs_circuit {
     // S-box triples covered by the permutations (a_L = x,x,x ; a_R = 1/x,0,1/x) and the multipliers outside them:
     // the A_I commitment uses one merged table per triple and side (K_merge_points)
     std::vector<uint32_t> h_trip, h_rest;
-    DevBuf<uint32_t> trip, rest;
+    DevBuf<uint32_t> trip, rest, ones;  // ones: the multipliers m, m+2 of every triple (a_O = 1 by construction)
     // merged tables, one set per generator handle that has proved this circuit (built on first use, under mt_mu)
     struct MergedTab {
         uint32_t W = 0, cap = 0, fmt = 0;
         DevBuf<uint8_t> tab;
+        DevBuf<ge> ones_pt;  // sum over the triples of G_m + G_m+2: the constant part of A_O (K_triple_ones_point)
     };
     mutable std::mutex mt_mu;
     mutable std::map<const bpr1cs_gens*, MergedTab*> mt;
@@ -543,6 +544,9 @@ int bpr1cs_circuit_create(const bpr1cs_circuit_desc* d, bpr1cs_circuit** out) {
                         if (!covered[mi]) c->h_rest.push_back(mi);
                     upload(c->trip, c->h_trip, s);
                     upload(c->rest, c->h_rest, s);
+                    std::vector<uint32_t> ones;
+                    for (uint32_t mi : c->h_trip) { ones.push_back(mi); ones.push_back(mi + 2); }
+                    upload(c->ones, ones, s);
                 }
                 ops.swap(patched);
                 c->n_perms = (uint32_t)pms.size();
@@ -657,6 +661,8 @@ struct MsmReq {
     DevBuf<ge>* partial;  // out: the reduced partial sums sit at the front, [plan->nchunks][B]
     MsmPlan* plan;
     const uint8_t* table;  // nullptr = the generator tables of `g`
+    uint32_t chunk_hint = 0;  // terms per chunk (0: from the launch geometry).  Sums whose terms are skipped in all but exceptional
+                              // proofs (MSM_MINUS_ONE) take few, long chunks: an empty workgroup still costs its dispatch
 };
 static void run_msm_multi(const bpr1cs_gens* g, MsmReq* reqs, uint32_t nreq, uint32_t B, dev_stream_t st, MsmStats* stats) {
     if (B < 32) {  // a wavefront per (chunk, 64 proofs) would be mostly idle: lanes take different chunks instead
@@ -689,6 +695,15 @@ static void run_msm_multi(const bpr1cs_gens* g, MsmReq* reqs, uint32_t nreq, uin
         MsmReq& q = reqs[r];
         uint32_t total = q.s0.count + q.s1.count;
         uint32_t nchunks = pick_chunks(total, B, g_msm_target_threads, q.plan->chunk);
+        if (q.chunk_hint) {
+            q.plan->chunk = q.chunk_hint;
+            nchunks = total ? (total + q.chunk_hint - 1) / q.chunk_hint : 1;
+        } else if (q.plan->chunk < 8 && total >= 8) {
+            // short sums that share a launch with long ones: a workgroup needs several terms for its pipeline (the first
+            // term's scalar load, conversion, recoding and first gather are exposed): 1 term per workgroup costs 1.7x per term
+            q.plan->chunk = 8;
+            nchunks = (total + 7) / 8;
+        }
         uint32_t l1 = nchunks > MSM_REDUCE_GROUP ? (nchunks + MSM_REDUCE_GROUP - 1) / MSM_REDUCE_GROUP : 0;
         uint32_t l2 = l1 > MSM_REDUCE_GROUP ? (l1 + MSM_REDUCE_GROUP - 1) / MSM_REDUCE_GROUP : 0;
         size_t need = ((size_t)nchunks + l1 + l2) * B;
@@ -797,6 +812,9 @@ static void enqueue_ipa(const IpaIO& io, dev_stream_t st, MsmStats* stats) {
             // L: G-terms with pos >= m, H-terms with pos < m ; R: the complement
             MsmSeg gL{sG.p, half, mk, Nk, mk, baseG, 0}, hL{sH.p, half, mk, Nk, 0, baseH, 0};
             MsmSeg gR{sG.p, half, mk, Nk, 0, baseG, 0}, hR{sH.p, half, mk, Nk, mk, baseH, 0};
+            // (round 0: the prover's l(x) is zero beyond n, so 14 112 of the 65 536 scalars vanish in every proof; the kernel skips
+            // terms whose scalars are zero in a whole wavefront.  Leaving them out of the segments instead measured 5 % SLOWER
+            // for that launch - smaller, differently sized chunks - and was dropped.)
             MsmPlan planR;
             MsmReq rq[2] = {{gL, hL, &partial, &plan, nullptr}, {gR, hR, &partialR, &planR, nullptr}};
             run_msm_multi(g, rq, 2, B, st, stats);  // L_k and R_k share one launch
@@ -1097,8 +1115,9 @@ extern "C" int bpr1cs_prove_batch_begin(const bpr1cs_gens* g, const bpr1cs_circu
         MsmSeg none{nullptr, 0, 1, 1, 0, 0, 0};
         auto seg = [&](const sc* p, uint32_t base0) { return MsmSeg{p, n, n ? n : 1, n ? n : 1, 0, base0, 1}; };
         const uint32_t T3 = (uint32_t)c->h_trip.size();
-        DevBuf<ge> partial2;
-        MsmPlan planO;
+        DevBuf<ge> partial2, partialO1;
+        MsmPlan planO, planO1{0, 0};
+        const ge* ones_pt = nullptr;
         K_msm_finish finI{g->tab.p, g->tc, nullptr, blind.p + 0 * (size_t)B, nullptr, AOS.p + 0 * (size_t)B * 32, B, 0, 1};
         if (!wires && T3 && o_merge) {
             // A_I1 with the repeated S-box wires merged: 2 terms per S-box instead of 5 (see K_merge_points).  The merged
@@ -1113,16 +1132,33 @@ extern "C" int bpr1cs_prove_batch_begin(const bpr1cs_gens* g, const bpr1cs_circu
                     launch(T3, K_merge_points{g->pts.p, c->trip.p, mp.p, T3, baseG, baseH}, st);
                     mt->tab.alloc((size_t)2 * T3 * g->tc.base_bytes());
                     launch((uint64_t)2 * T3 * g->tc.windows, K_build_table{mp.p, mt->tab.p, g->tc}, st);
+                    DevBuf<ge> part64(64);
+                    mt->ones_pt.alloc(1);
+                    launch(64, K_triple_ones_point{g->pts.p, c->trip.p, part64.p, T3, baseG}, st);
+                    launch(1, K_ge_reduce{part64.p, mt->ones_pt.p, 1, 64, 64}, st);
                     mt->W = g->tc.W; mt->cap = g->cap; mt->fmt = g->tc.fmt;
                 }
                 mtab = mt->tab.p;
+                ones_pt = mt->ones_pt.p;
             }
             const uint32_t nr = (uint32_t)c->h_rest.size();
             MsmSeg rG{aL, nr, 1, 1, 0, baseG, 1, c->rest.p, 0}, rH{aR, nr, 1, 1, 0, baseH, 1, c->rest.p, 0};
             MsmSeg mG{aL, T3, 1, 1, 0, 0, 1, c->trip.p, 1}, mH{aR, T3, 1, 1, 0, T3, 1, c->trip.p, 1};
             MsmPlan plan2;
-            MsmReq rq[3] = {{rG, rH, &partial, &plan, nullptr}, {mG, mH, &partial2, &plan2, mtab}, {seg(aO, baseG), none, &partialO, &planO, nullptr}};
-            run_msm_multi(g, rq, 3, B, st, stats);  // the three sums that need the wires only share one launch
+            // A_O: the a_O wires of an S-box triple are (1, 0, 1) unless the S-box input was 0, so their generators enter as ONE
+            // constant point of the circuit and the sum only carries (a_O - 1) for them - zero, and skipped by the kernel, in all
+            // but exceptional proofs: 608 real terms instead of 18 656 for the depth-32 circuit
+            MsmSeg oRest{aO, nr, 1, 1, 0, baseG, MSM_MONT, c->rest.p, 0}, oOnes{aO, 2 * T3, 1, 1, 0, baseG, MSM_MINUS_ONE, c->ones.p, 0};
+            static const bool ao_plain = getenv("BPR1CS_AO_PLAIN") != nullptr;  // measurement knob: the full n-term sum
+            if (ao_plain) {
+                MsmReq rq[3] = {{rG, rH, &partial, &plan, nullptr}, {mG, mH, &partial2, &plan2, mtab}, {seg(aO, baseG), none, &partialO, &planO, nullptr}};
+                run_msm_multi(g, rq, 3, B, st, stats);
+                ones_pt = nullptr;
+            } else {
+                MsmReq rq[4] = {{rG, rH, &partial, &plan, nullptr}, {mG, mH, &partial2, &plan2, mtab}, {oRest, none, &partialO, &planO, nullptr},
+                                {oOnes, none, &partialO1, &planO1, nullptr, 256}};
+                run_msm_multi(g, rq, 4, B, st, stats);  // the sums that need the wires only share one launch
+            }
             finI.partial = partial.p;
             finI.nchunks = plan.nchunks;
             finI.partial_b = partial2.p;
@@ -1138,7 +1174,9 @@ extern "C" int bpr1cs_prove_batch_begin(const bpr1cs_gens* g, const bpr1cs_circu
 #endif
         pt.mark(st);
         launch(B, finI, st);
-        launch(B, K_msm_finish{g->tab.p, g->tc, partialO.p, blind.p + 1 * (size_t)B, nullptr, AOS.p + 1 * (size_t)B * 32, B, planO.nchunks, 1}, st);
+        K_msm_finish finO{g->tab.p, g->tc, partialO.p, blind.p + 1 * (size_t)B, nullptr, AOS.p + 1 * (size_t)B * 32, B, planO.nchunks, 1};
+        if (ones_pt) { finO.shared_pt = ones_pt; finO.partial_b = partialO1.p; finO.nchunks_b = planO1.nchunks; }
+        launch(B, finO, st);
         run_msm(g, seg(sL, baseG), seg(sR, baseH), B, partial, plan, st, stats);
         launch(B, K_msm_finish{g->tab.p, g->tc, partial.p, blind.p + 2 * (size_t)B, nullptr, AOS.p + 2 * (size_t)B * 32, B, plan.nchunks, 1}, st);
     }

@@ -190,6 +190,22 @@ struct K_merge_points {  // gid = s (< T): out[s] = G-sum ; out[T + s] = H-sum o
     }
 };
 
+// constant part of A_O for a circuit with Inverse-S-box triples: sum over the triples of G_m + G_m+2 (their a_O wires are 1)
+struct K_triple_ones_point {  // gid = chunk c (< 64): out[c] = sum over triples s = c, c + 64, ... of pts[baseG + m0] + pts[baseG + m0 + 2]
+    const ge* pts;
+    const uint32_t* trip;
+    ge* out;
+    uint32_t T, baseG;
+    HD void operator()(uint32_t c) const {
+        ge acc = ge_identity();
+        for (uint32_t s = c; s < T; s += 64) {
+            uint32_t m0 = trip[s];
+            acc = ge_add_ge(ge_add_ge(acc, pts[baseG + m0]), pts[baseG + m0 + 2]);
+        }
+        out[c] = acc;
+    }
+};
+
 // ------------------------------------------------------- inputs / V commitments
 struct K_load_inputs {  // canonical v, vbl [m][B] -> Montgomery copies
     const sc* v_raw;
@@ -652,11 +668,23 @@ struct K_load_wires {  // host-synthesised a_L a_R a_O (canonical) -> Montgomery
 // scalar = scal[i*B + b], base = base0 + i.
 struct MsmSeg {
     const sc* scal;
-    uint32_t count, run, period, off, base0, mont;
+    uint32_t count, run, period, off, base0, mont;  // mont: 0 canonical scalars, 1 Montgomery form, 2 Montgomery form of (s + 1): the term is (s) * Base
+                                                    // with s = scal - 1 (wires that are 1 by construction, see MSM_MINUS_ONE below)
     // optional gather form: element index = sidx[o]; base = base0 + (bdense ? o : sidx[o])
     const uint32_t* sidx = nullptr;
     uint32_t bdense = 0;
 };
+// canonical scalar of a term from its stored form.  MSM_MINUS_ONE: the stored wire is 1 by construction in all but
+// exceptional proofs (the a_O wires of an Inverse S-box, x * 1/x), so its generator is added ONCE, as part of a
+// constant point of the circuit, and the sum only carries (wire - 1) - zero, and skipped, unless the S-box input was 0.
+#define MSM_CANONICAL 0u
+#define MSM_MONT 1u
+#define MSM_MINUS_ONE 2u
+HD inline sc msm_scalar(const sc& x, uint32_t form) {
+    if (form == MSM_CANONICAL) return x;
+    if (form == MSM_MONT) return sc_from_mont(x);
+    return sc_from_mont(sc_sub(x, sc_one_mont()));
+}
 #define MSM_MAX_JOBS 4  // independent sums that may share one launch of the shipped kernel (csrc/msm_hip.hpp)
 // One thread = (chunk c of the term list, proof b); a workgroup = ONE wavefront = 64 consecutive proofs of one
 // chunk, so its lanes walk the same table rows.  Workgroups are dealt round-robin to the 8 XCDs (each with a
@@ -684,7 +712,7 @@ struct K_msm_fixed {  // gid = wg*64 + lane -> partial[c*B + b]   (launch_wave)
             uint32_t i = s.sidx ? s.sidx[oo] : (oo / s.run) * s.period + s.off + (oo % s.run);
             uint32_t base = s.base0 + (s.bdense ? oo : i);
             sc x = s.scal[(size_t)i * B + b];
-            if (s.mont) x = sc_from_mont(x);
+            x = msm_scalar(x, s.mont);
             acc = table_mul_acc_raw(acc, tab + (size_t)base * tc.base_bytes(), x, tc);
         }
         partial[(size_t)c * B + b] = ge_from_table_class(acc);
@@ -710,7 +738,7 @@ struct K_msm_fixed_small {  // gid = c*B + b -> partial[c*B + b]
             uint32_t i = s.sidx ? s.sidx[oo] : (oo / s.run) * s.period + s.off + (oo % s.run);
             uint32_t base = s.base0 + (s.bdense ? oo : i);
             sc x = s.scal[(size_t)i * B + b];
-            if (s.mont) x = sc_from_mont(x);
+            x = msm_scalar(x, s.mont);
             acc = table_mul_acc_raw(acc, tab + (size_t)base * tc.base_bytes(), x, tc);
         }
         partial[g] = ge_from_table_class(acc);
@@ -741,8 +769,9 @@ struct K_msm_finish {  // gid = b
     const ge* partial_b = nullptr;  // optional second list of partial sums (a second launch's)
     uint32_t nchunks_b = 0;
     const ge* extra_pt = nullptr;   // optional: the extra term is extra * extra_pt[b] (an arbitrary point: Q of bpr1cs_ipa_create)
+    const ge* shared_pt = nullptr;  // optional: ONE point added to every proof's sum (the constant part of A_O, see MSM_MINUS_ONE)
     HD void operator()(uint32_t b) const {
-        ge acc = ge_identity();
+        ge acc = shared_pt ? shared_pt[0] : ge_identity();
         for (uint32_t c = 0; c < nchunks; c++) acc = ge_add_ge(acc, partial[(size_t)c * B + b]);
         for (uint32_t c = 0; c < nchunks_b; c++) acc = ge_add_ge(acc, partial_b[(size_t)c * B + b]);
         if (extra) {

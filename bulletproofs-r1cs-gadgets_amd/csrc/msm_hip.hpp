@@ -146,6 +146,10 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) k_msm_fixed2(const MsmLaun
         for (; o < hi; o += step) {
             t = msm_term(J, o, B, tc);
             x = t.scal[b];
+            if (t.mont == MSM_MINUS_ONE) {  // wires that are 1 by construction: the term is (wire - 1) * Base, zero in all but exceptional proofs
+                x = sc_sub(x, sc_one_mont());
+                t.mont = MSM_MONT;
+            }
             if (__ballot(!sc_is_zero(x)) != 0ull) return true;
         }
         return false;
