@@ -142,6 +142,8 @@ struct bpr1cs_circuit {
         uint32_t W = 0, cap = 0, fmt = 0;
         DevBuf<uint8_t> tab;
         DevBuf<ge> ones_pt;  // sum over the triples of G_m + G_m+2: the constant part of A_O (K_triple_ones_point)
+        DevBuf<uint8_t> hs_tab;  // table of the single point sum_{n - N/2 <= i < N/2} H_i (K_range_sum_points), when n > N/2
+        uint32_t hs_W = 0, hs_cap = 0, hs_fmt = 0;
     };
     mutable std::mutex mt_mu;
     mutable std::map<const bpr1cs_gens*, MergedTab*> mt;
@@ -776,6 +778,11 @@ struct IpaIO {
     const ge* qpt;   // ... [B] arbitrary points Q (bpr1cs_ipa_create)
     uint8_t* LR;     // out [lgN][2][B][32]
     sc* uk;          // out [lgN][2][B]: u_k, u_k^-1
+    // optional (the R1CS prover's padding, see K_range_sum_points): in round 0 the H-terms hs_from <= i < N/2 of L_0 all carry
+    // the scalar hs_scal[b]; their generators' sum has its own one-base table
+    const uint8_t* hs_tab = nullptr;
+    const sc* hs_scal = nullptr;  // [B] Montgomery
+    uint32_t hs_from = 0;
 };
 static void enqueue_ipa(const IpaIO& io, dev_stream_t st, MsmStats* stats) {
     const bpr1cs_gens* g = io.g;
@@ -815,9 +822,17 @@ static void enqueue_ipa(const IpaIO& io, dev_stream_t st, MsmStats* stats) {
             // (round 0: the prover's l(x) is zero beyond n, so 14 112 of the 65 536 scalars vanish in every proof; the kernel skips
             // terms whose scalars are zero in a whole wavefront.  Leaving them out of the segments instead measured 5 % SLOWER
             // for that launch - smaller, differently sized chunks - and was dropped.)
+            const bool hs = k == 0 && io.hs_tab && io.hs_from < mk;
+            if (hs) hL.count = io.hs_from;  // the block hs_from <= i < N/2 enters through its summed generator
             MsmPlan planR;
             MsmReq rq[2] = {{gL, hL, &partial, &plan, nullptr}, {gR, hR, &partialR, &planR, nullptr}};
             run_msm_multi(g, rq, 2, B, st, stats);  // L_k and R_k share one launch
+            if (hs) {
+                K_msm_finish f{g->tab.p, g->tc, partial.p, cross.p, io.qw, Lout, B, plan.nchunks, 0};
+                if (io.qpt) { f.extra2 = nullptr; f.extra_pt = io.qpt; }
+                f.tab2 = io.hs_tab; f.extra_b = io.hs_scal;
+                launch(B, f, st);
+            } else
             finish(partial.p, plan.nchunks, cross.p, Lout);
             finish(partialR.p, planR.nchunks, cross.p + B, Rout);
         } else {
@@ -1207,6 +1222,27 @@ extern "C" int bpr1cs_prove_batch_begin(const bpr1cs_gens* g, const bpr1cs_circu
     DevBuf<uint8_t> LR((size_t)(lgN ? lgN : 1) * 2 * B * 32);
     DevBuf<sc> uk((size_t)(lgN ? lgN : 1) * 2 * B);
     IpaIO io{g, B, N, lgN, (uint32_t)o_unfold, tr.p, a.p, bb.p, cG.p, cH.p, chal.p + (size_t)CH_W * B, nullptr, LR.p, uk.p};
+    DevBuf<sc> hs_scal;
+    if (lgN >= 1 && n > N / 2 && n < N && o_unfold >= 1) {
+        // padding structure of round 0 (K_range_sum_points): the table of sum_{n - N/2 <= i < N/2} H_i belongs to
+        // (circuit shape, generator handle) and is built by the first job that needs it
+        std::lock_guard<std::mutex> lk(c->mt_mu);
+        bpr1cs_circuit::MergedTab*& mt = c->mt[g];
+        if (!mt) mt = new bpr1cs_circuit::MergedTab();
+        if (!mt->hs_tab.p || mt->hs_W != g->tc.W || mt->hs_cap != g->cap || mt->hs_fmt != g->tc.fmt) {
+            mt->hs_W = g->tc.W; mt->hs_cap = g->cap; mt->hs_fmt = g->tc.fmt;
+            DevBuf<ge> part64(64), hsum(1);
+            launch(64, K_range_sum_points{g->pts.p, part64.p, baseH + (n - N / 2), baseH + N / 2}, st);
+            launch(1, K_ge_reduce{part64.p, hsum.p, 1, 64, 64}, st);
+            mt->hs_tab.alloc(g->tc.base_bytes());
+            launch(g->tc.windows, K_build_table{hsum.p, mt->hs_tab.p, g->tc}, st);
+        }
+        hs_scal.alloc(B);
+        launch(B, K_neg_ypow{plo.p, phi.p, hs_scal.p, B, H, N / 2}, st);
+        io.hs_tab = mt->hs_tab.p;
+        io.hs_scal = hs_scal.p;
+        io.hs_from = n - N / 2;
+    }
     enqueue_ipa(io, st, stats);
     size_t plen = bpr1cs_proof_len(c);
     job->plen = plen;

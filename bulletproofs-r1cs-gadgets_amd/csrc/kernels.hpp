@@ -206,6 +206,20 @@ struct K_triple_ones_point {  // gid = chunk c (< 64): out[c] = sum over triples
     }
 };
 
+// The padding of l(x), r(x) gives IPA round 0 a block of H-terms with ONE scalar: for n - N/2 <= i < N/2 the scalar of H_i in
+// L_0 is r[i + N/2] * H_factors[i] = (-y^(i+N/2)) * y^-i = -y^(N/2), the same for every i.  Their generators are summed once
+// per (circuit shape, generator set) and the block enters L_0 as a single table term.
+struct K_range_sum_points {  // gid = c (< 64): out[c] = sum of pts[lo + c], pts[lo + c + 64], ... below hi
+    const ge* pts;
+    ge* out;
+    uint32_t lo, hi;
+    HD void operator()(uint32_t c) const {
+        ge acc = ge_identity();
+        for (uint32_t i = lo + c; i < hi; i += 64) acc = ge_add_ge(acc, pts[i]);
+        out[c] = acc;
+    }
+};
+
 // ------------------------------------------------------- inputs / V commitments
 struct K_load_inputs {  // canonical v, vbl [m][B] -> Montgomery copies
     const sc* v_raw;
@@ -351,6 +365,13 @@ HD inline sc pow_lookup(const sc* lo, const sc* hi, uint32_t which, uint32_t H, 
     const sc* h = hi + (size_t)which * H * B;
     return sc_mul(l[(size_t)(e & 255u) * B + b], h[(size_t)(e >> 8) * B + b]);
 }
+struct K_neg_ypow {  // gid = b : out[b] = -y^e (Montgomery), y from the power tables
+    const sc* plo;
+    const sc* phi;
+    sc* out;
+    uint32_t B, H, e;
+    HD void operator()(uint32_t b) const { out[b] = sc_neg(pow_lookup(plo, phi, 0, H, B, e, b)); }
+};
 
 // --------------------------------------------------------------- witness VM
 // One multiplier per op: left/right operands by recipe, out = left*right.
@@ -770,8 +791,11 @@ struct K_msm_finish {  // gid = b
     uint32_t nchunks_b = 0;
     const ge* extra_pt = nullptr;   // optional: the extra term is extra * extra_pt[b] (an arbitrary point: Q of bpr1cs_ipa_create)
     const ge* shared_pt = nullptr;  // optional: ONE point added to every proof's sum (the constant part of A_O, see MSM_MINUS_ONE)
+    const uint8_t* tab2 = nullptr;  // optional: one more table term extra_b[b] * (the single base of tab2)  (K_range_sum_points)
+    const sc* extra_b = nullptr;    // [B] Montgomery
     HD void operator()(uint32_t b) const {
         ge acc = shared_pt ? shared_pt[0] : ge_identity();
+        if (tab2) acc = table_mul_acc(acc, tab2, sc_from_mont(extra_b[b]), tc);
         for (uint32_t c = 0; c < nchunks; c++) acc = ge_add_ge(acc, partial[(size_t)c * B + b]);
         for (uint32_t c = 0; c < nchunks_b; c++) acc = ge_add_ge(acc, partial_b[(size_t)c * B + b]);
         if (extra) {
