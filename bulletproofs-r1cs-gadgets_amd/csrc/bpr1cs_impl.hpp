@@ -870,7 +870,8 @@ static void enqueue_ipa(const IpaIO& io, dev_stream_t st, MsmStats* stats) {
             }
             const uint32_t vc = 2 * mk < VC ? 2 * mk : VC;  // chunks of the 2*mk terms of one output
             launch((uint64_t)4 * mk * B, K_ipa_vb_tab{a, bb, GH.p, linv.p, vtab.p, vdig.p, B, mk, M}, st);
-            launch_wave((uint64_t)2 * 64 * vc * B, K_ipa_vb_win{vtab.p, vdig.p, vwin.p, B, mk, vc}, st);
+            static const bool vbwin_plain = getenv("BPR1CS_VBWIN_PLAIN") != nullptr;  // measurement knob: window-major order
+            launch_wave((uint64_t)2 * 64 * vc * B, K_ipa_vb_win{vtab.p, vdig.p, vwin.p, B, mk, vc, vbwin_plain ? 0u : 1u}, st);
             launch((uint64_t)2 * 64 * B, K_ge_reduce{vwin.p, vsum.p, B, 2 * 64 * vc, vc}, st);  // chunk sums -> window sums
             launch((uint64_t)2 * B, K_ipa_vb_horner{vsum.p, vout.p, B, 1}, st);
             finish(vout.p, 1, cross.p, Lout);

@@ -1140,13 +1140,38 @@ struct K_ipa_vb_tab {  // gid = (w*m + j)*B + b, w<4 (0 = a_lo*G_hi, 1 = b_hi*H_
         for (int i = 0; i < 8; i++) vdig[(size_t)i * stride + g] = dig[i];
     }
 };
-struct K_ipa_vb_win {  // gid = ((out*64 + win)*VC + c)*B + b : sum over the chunk's terms of digit_win(term) * P_term
+// Workgroup order of K_ipa_vb_win.  One wavefront per workgroup (launch_wave), workgroups dealt round-robin to the 8 XCDs:
+// ordered (output, chunk, proof block, WINDOW) with a contiguous range per XCD, the 64 wavefronts that read the multiples
+// of the same terms for the same proofs run on one XCD at the same time, and a multiple is pulled from HBM once instead of
+// once per window that selects it.  Returns the index into `part` ([2][64][VC][B]) and the decomposition.
+HD inline uint32_t vb_win_index(uint32_t g0, uint32_t B, uint32_t VC, uint32_t remap, uint32_t& out, uint32_t& win, uint32_t& c, uint32_t& b) {
+    b = g0 % B;
+    uint32_t r0 = g0 / B;
+    c = r0 % VC;
+    uint32_t ow = r0 / VC;
+    win = ow & 63u;
+    out = ow >> 6;
+    if (remap && (B & 63u) == 0) {
+        const uint32_t nbk = B >> 6, nwg = 2u * 64u * VC * nbk;
+        uint32_t wg = g0 >> 6;
+        wg = (wg & 7u) * (nwg >> 3) + (wg >> 3);
+        win = wg & 63u;
+        uint32_t r1 = wg >> 6, bk = r1 % nbk;
+        r1 /= nbk;
+        c = r1 % VC;
+        out = r1 / VC;
+        b = (bk << 6) | (g0 & 63u);
+    }
+    return ((out * 64u + win) * VC + c) * B + b;
+}
+struct K_ipa_vb_win {  // one thread per (output, window, chunk, proof): sum over the chunk's terms of digit_win(term) * P_term
     const ge_cached* vtab;
     const uint32_t* vdig;
     ge* part;  // [2][64][VC][B]
-    uint32_t B, m, VC;
-    HD void operator()(uint32_t g) const {
-        uint32_t b = g % B, r0 = g / B, c = r0 % VC, ow = r0 / VC, win = ow & 63u, out = ow >> 6;
+    uint32_t B, m, VC, remap;
+    HD void operator()(uint32_t g0) const {
+        uint32_t out, win, c, b;
+        const uint32_t g = vb_win_index(g0, B, VC, remap, out, win, c, b);
         uint32_t total = 2 * m, per = (total + VC - 1) / VC;
         uint32_t lo = c * per, hi = lo + per < total ? lo + per : total;
         size_t stride = (size_t)4 * m * B;

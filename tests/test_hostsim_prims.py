@@ -201,3 +201,8 @@ def test_table_msm_formats_and_windows(prim_lib):
             for p, s in zip(pts, ss):
                 want = want + p * s
             assert ok and out.raw == want.compress(), (W, fmt, stride)
+
+
+def test_vb_win_workgroup_order_is_a_permutation(prim_lib):
+    for B, VC in [(64, 1), (64, 16), (128, 4), (1024, 16), (1000, 16), (3, 2), (192, 2)]:
+        assert prim_lib.hs_vb_win_index_is_permutation(B, VC) == 1, (B, VC)

@@ -47,10 +47,30 @@ int main(int argc, char** argv) {
         for (uint32_t k = 0; k * W < 253; k++) one.v[(k * W) >> 5] |= 1u << ((k * W) & 31);
         for (auto& s : hs) s = one;
     }
-    for (uint32_t bb = 0; bb < B; bb++) { memset(&hs[(size_t)5 * B + bb], 0, sizeof(sc)); }
-    hs[0] = sc_zero(); hs[1] = sc_zero(); hs[1].v[0] = 1;
-    for (int i = 0; i < 8; i++) hs[2].v[i] = SC_L[i];
-    hs[2].v[0] -= 1;
+    // 2: digit = 1 + proof index in every window of every term (the 16 wavefronts of a chunk stream each row once, 8 KB per wavefront)
+    // 3: a random digit per (term, proof) inside the wavefront's own 64-slot (8 KB) block of the row, same in every window
+    // 4: a random digit per (term, proof) anywhere in the row, same in every window (control for 2 and 3)
+    if (pattern >= 2 && pattern <= 4) {
+        const uint32_t slots = 1u << (W - 1);
+        for (size_t i = 0; i < hs.size(); i++) {
+            uint32_t b = (uint32_t)(i % B), r = (uint32_t)rnd64();
+            uint32_t d = pattern == 2 ? (b % slots) : pattern == 3 ? ((b / 64 * 64) % slots + r % 64) : r % slots;
+            sc v = sc_zero();
+            for (uint32_t k = 0; k * W < 253; k++) {
+                uint64_t dk = 1 + ((k + 1) * W >= 253 ? d % (slots / 2) : d);
+                uint32_t bit = k * W;
+                v.v[bit >> 5] |= (uint32_t)(dk << (bit & 31));
+                if ((bit & 31) + W + 1 > 32 && (bit >> 5) + 1 < 8) v.v[(bit >> 5) + 1] |= (uint32_t)(dk >> (32 - (bit & 31)));
+            }
+            hs[i] = v;
+        }
+    }
+    if (pattern == 0) for (uint32_t bb = 0; bb < B; bb++) { memset(&hs[(size_t)5 * B + bb], 0, sizeof(sc)); }
+    if (pattern == 0) {
+        hs[0] = sc_zero(); hs[1] = sc_zero(); hs[1].v[0] = 1;
+        for (int i = 0; i < 8; i++) hs[2].v[i] = SC_L[i];
+        hs[2].v[0] -= 1;
+    }
     DevBuf<sc> d_s(hs.size());
     dev_h2d(d_s.p, hs.data(), hs.size() * sizeof(sc), st);
     const sc* sG = d_s.p;
