@@ -800,6 +800,10 @@ static void enqueue_ipa(const IpaIO& io, dev_stream_t st, MsmStats* stats) {
     const uint32_t M = N >> r;  // size of the materialised folded generator vectors
     if (r > 0) { sG.alloc((size_t)N * B); sH.alloc((size_t)N * B); }
     const uint32_t VC = 16;
+    // variable-base rounds come in pairs on one set of multiples, generators folded two levels at a time (K_ipa_vb_dig2 / _fold2)
+    static const bool fold_single = getenv("BPR1CS_FOLD_SINGLE") != nullptr;  // measurement knob: one fold per round
+    const bool two_level = !fold_single;
+    bool vb_reuse = false;
     auto finish = [&](const ge* part, uint32_t nch, const sc* c, uint8_t* out) {
         K_msm_finish f{g->tab.p, g->tc, part, c, io.qw, out, B, nch, 0};
         if (io.qpt) { f.extra2 = nullptr; f.extra_pt = io.qpt; }
@@ -868,11 +872,21 @@ static void enqueue_ipa(const IpaIO& io, dev_stream_t st, MsmStats* stats) {
                 linv.alloc((size_t)2 * B);
                 launch((uint64_t)2 * B, K_set_one{linv.p}, st);
             }
-            const uint32_t vc = 2 * mk < VC ? 2 * mk : VC;  // chunks of the 2*mk terms of one output
-            launch((uint64_t)4 * mk * B, K_ipa_vb_tab{a, bb, GH.p, linv.p, vtab.p, vdig.p, B, mk, M}, st);
             static const bool vbwin_plain = getenv("BPR1CS_VBWIN_PLAIN") != nullptr;  // measurement knob: window-major order
-            launch_wave((uint64_t)2 * 64 * vc * B, K_ipa_vb_win{vtab.p, vdig.p, vwin.p, B, mk, vc, vbwin_plain ? 0u : 1u}, st);
-            launch((uint64_t)2 * 64 * B, K_ge_reduce{vwin.p, vsum.p, B, 2 * 64 * vc, vc}, st);  // chunk sums -> window sums
+            const uint32_t remap = vbwin_plain ? 0u : 1u;
+            if (!vb_reuse) {
+                // multiples 1P..8P and digits of every term of this round
+                const uint32_t vc = 2 * mk < VC ? 2 * mk : VC;  // chunks of the 2*mk terms of one output
+                launch((uint64_t)4 * mk * B, K_ipa_vb_tab{a, bb, GH.p, linv.p, vtab.p, vdig.p, B, mk, M}, st);
+                launch_wave((uint64_t)2 * 64 * vc * B, K_ipa_vb_win{vtab.p, vdig.p, vwin.p, B, mk, vc, remap, 0}, st);
+                launch((uint64_t)2 * 64 * B, K_ge_reduce{vwin.p, vsum.p, B, 2 * 64 * vc, vc}, st);  // chunk sums -> window sums
+            } else {
+                // the round after: same multiples (the generators were not folded), product scalars
+                const uint32_t m0 = 2 * mk, vc = 2 * m0 < VC ? 2 * m0 : VC;
+                launch((uint64_t)4 * m0 * B, K_ipa_vb_dig2{a, bb, linv.p, io.uk + (size_t)(k - 1) * 2 * B, vdig.p, B, m0}, st);
+                launch_wave((uint64_t)2 * 64 * vc * B, K_ipa_vb_win{vtab.p, vdig.p, vwin.p, B, m0, vc, remap, 1}, st);
+                launch((uint64_t)2 * 64 * B, K_ge_reduce{vwin.p, vsum.p, B, 2 * 64 * vc, vc}, st);
+            }
             launch((uint64_t)2 * B, K_ipa_vb_horner{vsum.p, vout.p, B, 1}, st);
             finish(vout.p, 1, cross.p, Lout);
             finish(vout.p + (size_t)B, 1, cross.p + B, Rout);
@@ -881,7 +895,14 @@ static void enqueue_ipa(const IpaIO& io, dev_stream_t st, MsmStats* stats) {
         launch(B, K_transcript_LR{io.tr, Lout, ukk, B}, st);
         launch((uint64_t)mk * B, K_ipa_fold_ab{a, bb, ukk, B, mk}, st);
         if (k < r) launch((uint64_t)N * B, K_ipa_update_c{cG, cH, ukk, B, Nk}, st);
-        else if (mk > 0 && k + 1 < lgN) launch_wave((uint64_t)2 * mk * B, K_ipa_vb_fold{GH.p, ukk, linv.p, vtab.p, B, mk, M}, st);
+        else if (!two_level) {
+            if (k + 1 < lgN) launch_wave((uint64_t)2 * mk * B, K_ipa_vb_fold{GH.p, ukk, linv.p, vtab.p, B, mk, M}, st);
+        } else if (!vb_reuse) {
+            vb_reuse = k + 1 < lgN;  // the next round works on this round's multiples
+        } else {
+            if (k + 1 < lgN) launch_wave((uint64_t)2 * mk * B, K_ipa_vb_fold2{GH.p, io.uk + (size_t)(k - 1) * 2 * B, ukk, linv.p, vtab.p, B, 2 * mk, M}, st);
+            vb_reuse = false;
+        }
     }
     if (sG.p) dev_zero(sG.p, sG.bytes(), st);  // products of the secret l / r vectors
     if (sH.p) dev_zero(sH.p, sH.bytes(), st);

@@ -1169,6 +1169,8 @@ struct K_ipa_vb_win {  // one thread per (output, window, chunk, proof): sum ove
     const uint32_t* vdig;
     ge* part;  // [2][64][VC][B]
     uint32_t B, m, VC, remap;
+    uint32_t skip;  // 0: the round the multiples were built for (terms of output `out`: w = 2*out, 2*out + 1);
+                    // 1: the round after it, on the same multiples (K_ipa_vb_dig2): quarter q of the 4h terms, h = m/2
     HD void operator()(uint32_t g0) const {
         uint32_t out, win, c, b;
         const uint32_t g = vb_win_index(g0, B, VC, remap, out, win, c, b);
@@ -1177,7 +1179,15 @@ struct K_ipa_vb_win {  // one thread per (output, window, chunk, proof): sum ove
         size_t stride = (size_t)4 * m * B;
         ge acc = ge_identity();
         for (uint32_t o = lo; o < hi; o++) {
-            size_t t = ((size_t)(2 * out) * m + o) * B + b;  // terms of output `out` are w = 2*out and 2*out + 1
+            size_t t;
+            if (!skip) t = ((size_t)(2 * out) * m + o) * B + b;
+            else {
+                // L (out 0): G points at positions >= h, H points at positions < h, in the "lo" and the "hi" tables; R: the complement
+                const uint32_t h = m >> 1, q = o / h, jj = o - q * h;
+                const uint32_t w = q == 0 ? 2u : q == 1 ? 0u : q == 2 ? 1u : 3u;
+                const uint32_t up = (q < 2) ? (out == 0) : (out != 0);
+                t = ((size_t)w * m + jj + up * h) * B + b;
+            }
             int d = (int)((vdig[(size_t)(win >> 3) * stride + t] >> (4 * (win & 7u))) & 15u);
             if (d & 8) d -= 16;
             if (d != 0) {
@@ -1257,6 +1267,108 @@ struct K_ipa_vb_fold {  // gid = (b*2 + side)*m + j : Ghat'[j] = Ghat[j] + u^2 G
         if (j == 0) {  // lam' = lam * f  ->  linv' = linv * f^-1
             sc finv = uk[(size_t)(side ? 0 : 1) * B + b];
             linv[(size_t)side * B + b] = sc_mul(linv[(size_t)side * B + b], finv);
+        }
+    }
+};
+// Two rounds on one set of multiples.  After round k (vector length 2m, multiples 1P..8P of all 4m per-proof points in
+// vtab) the generators are NOT folded: round k+1's L/R are sums over the same 4m points with product scalars
+//   Ghat'_i = Ghat_i + u^2 Ghat_{i+m}  =>  a'_j Ghat'_{j+h} = a'_j Ghat_{j+h} + (a'_j u^2) Ghat_{j+h+m}      (h = m/2)
+// (K_ipa_vb_dig2 only writes new digits), and the generators of round k+2 come from ONE Straus pass per output over four
+// ready sets of multiples (K_ipa_vb_fold2): 63 x 4 doublings per output of level k+2 instead of per output of levels k+1
+// AND k+2 - a third of the doublings, which are what a fold costs.
+struct K_ipa_vb_dig2 {  // gid = (w*m + j)*B + b over round k's layout (w: 0 G_hi, 1 H_lo, 2 G_lo, 3 H_hi)
+    const sc* a;      // vectors AFTER round k's fold (length m)
+    const sc* bb;
+    const sc* linv;   // [2][B] as of round k (no generator fold has happened since)
+    const sc* uk;     // [2][B] u_k, u_k^-1
+    uint32_t* vdig;   // [8][4*m*B]
+    uint32_t B, m;
+    HD void operator()(uint32_t g) const {
+        uint32_t b = g % B, wj = g / B, w = wj / m, j = wj % m, h = m >> 1;
+        uint32_t side = w & 1u, hi = (w == 0u) | (w == 3u);
+        const sc* sv = side ? bb : a;
+        // the point at position j of a half meets a'[j-h] (in L) if j >= h, a'[j+h] (in R) otherwise; H: b'[j+h] (L) / b'[j-h] (R)
+        uint32_t idx = j >= h ? j - h : j + h;
+        // scale of the level-(k+1) generators: linv' = linv * f^-1 (G: f = u, H: f = u^-1); "hi" points carry f^2 on top
+        sc fac = sc_mul(linv[(size_t)side * B + b], uk[(size_t)((side ^ hi) ? 0u : 1u) * B + b]);
+        sc s = sc_from_mont(sc_mul(sv[(size_t)idx * B + b], fac));
+        uint32_t dig[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) dig[i] = 0;
+        int carry = 0;
+        for (int i = 0; i < 64; i++) {
+            int d = (int)((s.v[i >> 3] >> (4 * (i & 7))) & 15u) + carry;
+            carry = d >= 8;
+            d -= carry << 4;
+            dig[i >> 3] |= ((uint32_t)d & 15u) << (4 * (i & 7));
+        }
+        const size_t stride = (size_t)4 * m * B;
+#pragma unroll
+        for (int i = 0; i < 8; i++) vdig[(size_t)i * stride + g] = dig[i];
+    }
+};
+HD inline void vb_pack_digits(const sc& w, uint32_t pk[8]) {  // 64 signed radix-16 digits, 4-bit two's complement, 8 per word
+    int carry = 0;
+#pragma unroll
+    for (int wi = 0; wi < 8; wi++) {
+        uint32_t o = 0;
+        for (int k = 0; k < 8; k++) {
+            int d = (int)((w.v[wi] >> (4 * k)) & 15u) + carry;
+            carry = d >= 8;
+            o |= ((uint32_t)(d - (carry << 4)) & 15u) << (4 * k);
+        }
+        pk[wi] = o;
+    }
+}
+HD inline ge vb_add_digit(const ge& acc, uint32_t word, int k, const ge_cached* T, size_t stride, bool& started) {
+    int d = (int)((word >> (4 * k)) & 15u);
+    if (d & 8) d -= 16;
+    if (d == 0) return acc;
+    int mag = d < 0 ? -d : d;
+    ge_cached e = T[(size_t)(mag - 1) * stride];
+    started = true;
+    return d < 0 ? ge_sub(acc, e) : ge_add(acc, e);
+}
+struct K_ipa_vb_fold2 {  // gid = (b*2 + side)*h + j : Ghat''[j] = Ghat[j] + w0 Ghat[j+m] + w1 Ghat[j+h] + w0 w1 Ghat[j+h+m]
+    ge* GH;
+    const sc* uk0;  // [2][B] u_k, u_k^-1 of the round the multiples were built in
+    const sc* uk1;  // [2][B] of the round after it
+    sc* linv;       // [2][B]
+    const ge_cached* vtab;  // [8][4*m*B]
+    uint32_t B, m, M;
+    HD void operator()(uint32_t g) const {
+        const uint32_t h = m >> 1;
+        uint32_t j = g % h, bs = g / h, side = bs & 1u, b = bs >> 1;
+        ge* P = GH + (size_t)side * M * B;
+        const uint32_t fi = side ? 1u : 0u;  // G: f = u ; H: f = u^-1
+        sc f0 = uk0[(size_t)fi * B + b], f1 = uk1[(size_t)fi * B + b];
+        sc w0m = sc_mul(f0, f0), w1m = sc_mul(f1, f1);
+        uint32_t p0[8], p1[8], p01[8];
+        vb_pack_digits(sc_from_mont(w0m), p0);
+        vb_pack_digits(sc_from_mont(w1m), p1);
+        vb_pack_digits(sc_from_mont(sc_mul(w0m, w1m)), p01);
+        const size_t stride = (size_t)4 * m * B;
+        const uint32_t w_lo = side ? 1u : 2u, w_hi = side ? 3u : 0u;
+        const ge_cached* T0 = vtab + ((size_t)w_hi * m + j) * B + b;        // Ghat[j+m]
+        const ge_cached* T1 = vtab + ((size_t)w_lo * m + j + h) * B + b;    // Ghat[j+h]
+        const ge_cached* T01 = vtab + ((size_t)w_hi * m + j + h) * B + b;   // Ghat[j+h+m]
+        ge acc = ge_identity();
+        bool started = false;
+#pragma unroll
+        for (int wi = 7; wi >= 0; wi--) {
+            const uint32_t d0 = p0[wi], d1 = p1[wi], d01 = p01[wi];
+            for (int k = 7; k >= 0; k--) {
+                if (started) acc = ge_dbl4(acc);
+                acc = vb_add_digit(acc, d0, k, T0, stride, started);
+                acc = vb_add_digit(acc, d1, k, T1, stride, started);
+                acc = vb_add_digit(acc, d01, k, T01, stride, started);
+            }
+        }
+        ge lo = P[(size_t)j * B + b];
+        P[(size_t)j * B + b] = ge_add_ge(lo, acc);
+        if (j == 0) {  // lam'' = lam f0 f1  ->  linv'' = linv f0^-1 f1^-1
+            const uint32_t gi = side ? 0u : 1u;
+            linv[(size_t)side * B + b] = sc_mul(linv[(size_t)side * B + b], sc_mul(uk0[(size_t)gi * B + b], uk1[(size_t)gi * B + b]));
         }
     }
 };

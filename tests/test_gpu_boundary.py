@@ -9,6 +9,8 @@ pytestmark = pytest.mark.gpu
 def test_ipa_create_matches_oracle(hip_lib):
     bc.check_ipa_create(hip_lib, n=64, unfold=2)   # two rounds from the tables, then variable-base
     bc.check_ipa_create(hip_lib, n=16, unfold=0)
+    bc.check_ipa_create(hip_lib, n=128, unfold=0)  # seven variable-base rounds (pairs on one set of multiples, two-level folds)
+    bc.check_ipa_create(hip_lib, n=64, unfold=1)
     bc.check_ipa_create(hip_lib, n=8, unfold=9)
     bc.check_ipa_create(hip_lib, n=1, unfold=2)
 
