@@ -799,10 +799,9 @@ static void enqueue_ipa(const IpaIO& io, dev_stream_t st, MsmStats* stats) {
     MsmPlan plan;
     const uint32_t M = N >> r;  // size of the materialised folded generator vectors
     if (r > 0) { sG.alloc((size_t)N * B); sH.alloc((size_t)N * B); }
-    const uint32_t VC = 16;
+    static const uint32_t vc_env = getenv("BPR1CS_VB_CHUNKS") ? (uint32_t)atoi(getenv("BPR1CS_VB_CHUNKS")) : 0;  // measurement knob
+    const uint32_t VC = vc_env ? vc_env : 16;
     // variable-base rounds come in pairs on one set of multiples, generators folded two levels at a time (K_ipa_vb_dig2 / _fold2)
-    static const bool fold_single = getenv("BPR1CS_FOLD_SINGLE") != nullptr;  // measurement knob: one fold per round
-    const bool two_level = !fold_single;
     bool vb_reuse = false;
     auto finish = [&](const ge* part, uint32_t nch, const sc* c, uint8_t* out) {
         K_msm_finish f{g->tab.p, g->tc, part, c, io.qw, out, B, nch, 0};
@@ -864,10 +863,10 @@ static void enqueue_ipa(const IpaIO& io, dev_stream_t st, MsmStats* stats) {
                     HIPCHK(hipGetLastError());
                 }
 #endif
-                vtab.alloc((size_t)8 * 4 * (M / 2 ? M / 2 : 1) * B);
-                vdig.alloc((size_t)8 * 4 * (M / 2 ? M / 2 : 1) * B);
-                vwin.alloc((size_t)2 * 64 * VC * B);
-                vsum.alloc((size_t)2 * 64 * B);
+                vtab.alloc((size_t)VB_MULT * 4 * (M / 2 ? M / 2 : 1) * B);
+                vdig.alloc((size_t)VB_WORDS * 4 * (M / 2 ? M / 2 : 1) * B);
+                vwin.alloc((size_t)2 * VB_WINDOWS * VC * B);
+                vsum.alloc((size_t)2 * VB_WINDOWS * B);
                 vout.alloc((size_t)2 * B);
                 linv.alloc((size_t)2 * B);
                 launch((uint64_t)2 * B, K_set_one{linv.p}, st);
@@ -878,14 +877,14 @@ static void enqueue_ipa(const IpaIO& io, dev_stream_t st, MsmStats* stats) {
                 // multiples 1P..8P and digits of every term of this round
                 const uint32_t vc = 2 * mk < VC ? 2 * mk : VC;  // chunks of the 2*mk terms of one output
                 launch((uint64_t)4 * mk * B, K_ipa_vb_tab{a, bb, GH.p, linv.p, vtab.p, vdig.p, B, mk, M}, st);
-                launch_wave((uint64_t)2 * 64 * vc * B, K_ipa_vb_win{vtab.p, vdig.p, vwin.p, B, mk, vc, remap, 0}, st);
-                launch((uint64_t)2 * 64 * B, K_ge_reduce{vwin.p, vsum.p, B, 2 * 64 * vc, vc}, st);  // chunk sums -> window sums
+                launch_wave((uint64_t)2 * VB_WINDOWS * vc * B, K_ipa_vb_win{vtab.p, vdig.p, vwin.p, B, mk, vc, remap, 0}, st);
+                launch((uint64_t)2 * VB_WINDOWS * B, K_ge_reduce{vwin.p, vsum.p, B, 2 * VB_WINDOWS * vc, vc}, st);  // chunk sums -> window sums
             } else {
                 // the round after: same multiples (the generators were not folded), product scalars
                 const uint32_t m0 = 2 * mk, vc = 2 * m0 < VC ? 2 * m0 : VC;
                 launch((uint64_t)4 * m0 * B, K_ipa_vb_dig2{a, bb, linv.p, io.uk + (size_t)(k - 1) * 2 * B, vdig.p, B, m0}, st);
-                launch_wave((uint64_t)2 * 64 * vc * B, K_ipa_vb_win{vtab.p, vdig.p, vwin.p, B, m0, vc, remap, 1}, st);
-                launch((uint64_t)2 * 64 * B, K_ge_reduce{vwin.p, vsum.p, B, 2 * 64 * vc, vc}, st);
+                launch_wave((uint64_t)2 * VB_WINDOWS * vc * B, K_ipa_vb_win{vtab.p, vdig.p, vwin.p, B, m0, vc, remap, 1}, st);
+                launch((uint64_t)2 * VB_WINDOWS * B, K_ge_reduce{vwin.p, vsum.p, B, 2 * VB_WINDOWS * vc, vc}, st);
             }
             launch((uint64_t)2 * B, K_ipa_vb_horner{vsum.p, vout.p, B, 1}, st);
             finish(vout.p, 1, cross.p, Lout);
@@ -895,9 +894,7 @@ static void enqueue_ipa(const IpaIO& io, dev_stream_t st, MsmStats* stats) {
         launch(B, K_transcript_LR{io.tr, Lout, ukk, B}, st);
         launch((uint64_t)mk * B, K_ipa_fold_ab{a, bb, ukk, B, mk}, st);
         if (k < r) launch((uint64_t)N * B, K_ipa_update_c{cG, cH, ukk, B, Nk}, st);
-        else if (!two_level) {
-            if (k + 1 < lgN) launch_wave((uint64_t)2 * mk * B, K_ipa_vb_fold{GH.p, ukk, linv.p, vtab.p, B, mk, M}, st);
-        } else if (!vb_reuse) {
+        else if (!vb_reuse) {
             vb_reuse = k + 1 < lgN;  // the next round works on this round's multiples
         } else {
             if (k + 1 < lgN) launch_wave((uint64_t)2 * mk * B, K_ipa_vb_fold2{GH.p, io.uk + (size_t)(k - 1) * 2 * B, ukk, linv.p, vtab.p, B, 2 * mk, M}, st);
@@ -1668,16 +1665,16 @@ extern "C" int bpr1cs_msm(const uint8_t* scalars, const uint8_t* points, size_t 
     CallScope scope(st);
     const uint32_t N = (uint32_t)n, VC = N < 4096 ? (N + 63) / 64 : 64;
     DevBuf<uint8_t> d_s(32 * n), d_p(32 * n), d_out(32);
-    DevBuf<ge_cached> vtab((size_t)8 * n);
-    DevBuf<uint32_t> vdig((size_t)8 * n);
-    DevBuf<ge> part((size_t)64 * VC), sum(64), res(1);
+    DevBuf<ge_cached> vtab((size_t)VB_MULT * n);
+    DevBuf<uint32_t> vdig((size_t)VB_WORDS * n);
+    DevBuf<ge> part((size_t)VB_WINDOWS * VC), sum(VB_WINDOWS), res(1);
     DevBuf<int> fail(1);
     dev_h2d(d_s.p, scalars, 32 * n, st);
     dev_h2d(d_p.p, points, 32 * n, st);
     dev_zero(fail.p, sizeof(int), st);
     launch(N, K_msm_var_tab{d_s.p, d_p.p, vtab.p, vdig.p, fail.p, N}, st);
-    launch((uint64_t)64 * VC, K_msm_var_win{vtab.p, vdig.p, part.p, N, VC}, st);
-    launch(64, K_ge_reduce{part.p, sum.p, 1, 64 * VC, VC}, st);
+    launch((uint64_t)VB_WINDOWS * VC, K_msm_var_win{vtab.p, vdig.p, part.p, N, VC}, st);
+    launch(VB_WINDOWS, K_ge_reduce{part.p, sum.p, 1, VB_WINDOWS * VC, VC}, st);
     launch(1, K_ipa_vb_horner{sum.p, res.p, 1, 1}, st);
     launch(1, K_compress_one{res.p, d_out.p}, st);
     int f = 0;

@@ -201,13 +201,6 @@ HD inline ge ge_p1p1_to_p2(const ge_p1p1& c) {  // T is NOT computed: only a dou
 }
 // 2p: 4S + 4M
 HD inline ge ge_dbl(const ge& p) { return ge_p1p1_to_p3(ge_dbl_c(p)); }
-// 16p: the three inner doublings skip T (4 x 4S + 15M instead of 16M)
-HD inline ge ge_dbl4(const ge& p) {
-    ge q = ge_p1p1_to_p2(ge_dbl_c(p));
-    q = ge_p1p1_to_p2(ge_dbl_c(q));
-    q = ge_p1p1_to_p2(ge_dbl_c(q));
-    return ge_p1p1_to_p3(ge_dbl_c(q));
-}
 HD inline ge ge_add_ge(const ge& p, const ge& q) { return ge_add(p, ge_to_cached(q)); }
 
 // extended -> affine Niels (one inversion)

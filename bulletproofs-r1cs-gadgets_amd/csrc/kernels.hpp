@@ -1098,16 +1098,57 @@ struct K_ipa_fold_from_tables {  // gid = (side*M + j)*B + b
 // instead of upstream's two (u^-1*G_lo + u*G_hi); the scale is divided out of the L/R scalars
 // (linv = lam^-1).  Group elements are exact, so L_k / R_k are bit-identical.
 // L_k / R_k of a variable-base round are multiscalar multiplications over 2m per-proof points each.  Straus with the
-// doublings SHARED by all terms: (1) per term, the multiples 1P..8P and the 64 signed radix-16 digits of its scalar;
+// doublings SHARED by all terms: (1) per term, the multiples 1P..16P and the 51 signed radix-32 digits of its scalar;
 // (2) per (output, window, chunk of terms) the sum of the selected multiples - no doublings at all; (3) per output
-// one Horner pass over the 64 window sums (252 doublings in total instead of 253 per term).
+// one Horner pass over the 51 window sums (250 doublings in total instead of 253 per term).
+// The multiples are built once per PAIR of rounds and read by three passes (this round's sums, the next round's sums,
+// the two-level fold), which is what pays for 16 of them instead of 8.
+#define VB_W 5u            // digit width
+#define VB_WINDOWS 51u     // ceil(253 / 5): a canonical scalar's top digit is <= 8, no carry out
+#define VB_MULT 16u        // multiples 1P..16P (digits in [-16, 15])
+#define VB_PER_WORD 6u     // 5-bit two's-complement digits per 32-bit word
+#define VB_WORDS 9u
+HD inline void vb_recode(const sc& s, uint32_t dig[VB_WORDS]) {  // least significant digit first
+#pragma unroll
+    for (uint32_t i = 0; i < VB_WORDS; i++) dig[i] = 0;
+    int carry = 0;
+#pragma unroll
+    for (uint32_t wi = 0; wi < VB_WORDS; wi++) {
+        uint32_t o = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < VB_PER_WORD; k++) {
+            const uint32_t i = wi * VB_PER_WORD + k;
+            if (i < VB_WINDOWS) {
+                const uint32_t bit = i * VB_W, w0 = bit >> 5, sh = bit & 31u;
+                uint32_t v = s.v[w0] >> sh;
+                if (sh + VB_W > 32u && w0 + 1u < 8u) v |= s.v[w0 + 1u] << (32u - sh);
+                int d = (int)(v & (VB_MULT * 2u - 1u)) + carry;
+                carry = d >= (int)VB_MULT;
+                d -= carry << (VB_W);
+                o |= ((uint32_t)d & (VB_MULT * 2u - 1u)) << (VB_W * k);
+            }
+        }
+        dig[wi] = o;
+    }
+}
+HD inline int vb_digit(uint32_t word, uint32_t k) {  // digit k of a packed word, sign-extended
+    int d = (int)((word >> (VB_W * k)) & (VB_MULT * 2u - 1u));
+    return d - ((d & (int)VB_MULT) << 1);
+}
+template <int N>
+HD inline ge ge_dbln(const ge& p) {  // 2^N p: the inner doublings skip T
+    ge q = p;
+#pragma unroll
+    for (int i = 0; i + 1 < N; i++) q = ge_p1p1_to_p2(ge_dbl_c(q));
+    return ge_p1p1_to_p3(ge_dbl_c(q));
+}
 struct K_ipa_vb_tab {  // gid = (w*m + j)*B + b, w<4 (0 = a_lo*G_hi, 1 = b_hi*H_lo, 2 = a_hi*G_lo, 3 = b_lo*H_hi)
     const sc* a;
     const sc* bb;
     const ge* GH;       // [2][M][B]
     const sc* linv;     // [2][B] Montgomery: lamG^-1, lamH^-1
-    ge_cached* vtab;    // [8][4*m*B] multiples 1P..8P
-    uint32_t* vdig;     // [8][4*m*B] 64 x 4-bit two's-complement digits, least significant first
+    ge_cached* vtab;    // [VB_MULT][4*m*B] multiples 1P..16P
+    uint32_t* vdig;     // [VB_WORDS][4*m*B] packed signed digits, least significant first
     uint32_t B, m, M;
     HD void operator()(uint32_t g) const {
         uint32_t b = g % B, wj = g / B, w = wj / m, j = wj % m;
@@ -1122,52 +1163,44 @@ struct K_ipa_vb_tab {  // gid = (w*m + j)*B + b, w<4 (0 = a_lo*G_hi, 1 = b_hi*H_
         ge_cached* T = vtab + g;
         T[0] = c1;
         ge q = P;
-        for (int e = 1; e < 8; e++) {
+        for (uint32_t e = 1; e < VB_MULT; e++) {
             q = ge_add(q, c1);
             T[(size_t)e * stride] = ge_to_cached(q);
         }
-        uint32_t dig[8];
+        uint32_t dig[VB_WORDS];
+        vb_recode(s, dig);
 #pragma unroll
-        for (int i = 0; i < 8; i++) dig[i] = 0;
-        int carry = 0;
-        for (int i = 0; i < 64; i++) {
-            int d = (int)((s.v[i >> 3] >> (4 * (i & 7))) & 15u) + carry;
-            carry = d >= 8;
-            d -= carry << 4;  // d in [-8, 7]: fits a 4-bit two's-complement digit (s < 2^253: no carry out of digit 63)
-            dig[i >> 3] |= ((uint32_t)d & 15u) << (4 * (i & 7));
-        }
-#pragma unroll
-        for (int i = 0; i < 8; i++) vdig[(size_t)i * stride + g] = dig[i];
+        for (uint32_t i = 0; i < VB_WORDS; i++) vdig[(size_t)i * stride + g] = dig[i];
     }
 };
 // Workgroup order of K_ipa_vb_win.  One wavefront per workgroup (launch_wave), workgroups dealt round-robin to the 8 XCDs:
-// ordered (output, chunk, proof block, WINDOW) with a contiguous range per XCD, the 64 wavefronts that read the multiples
+// ordered (output, chunk, proof block, WINDOW) with a contiguous range per XCD, the wavefronts that read the multiples
 // of the same terms for the same proofs run on one XCD at the same time, and a multiple is pulled from HBM once instead of
-// once per window that selects it.  Returns the index into `part` ([2][64][VC][B]) and the decomposition.
+// once per window that selects it.  Returns the index into `part` ([2][VB_WINDOWS][VC][B]) and the decomposition.
 HD inline uint32_t vb_win_index(uint32_t g0, uint32_t B, uint32_t VC, uint32_t remap, uint32_t& out, uint32_t& win, uint32_t& c, uint32_t& b) {
     b = g0 % B;
     uint32_t r0 = g0 / B;
     c = r0 % VC;
     uint32_t ow = r0 / VC;
-    win = ow & 63u;
-    out = ow >> 6;
-    if (remap && (B & 63u) == 0) {
-        const uint32_t nbk = B >> 6, nwg = 2u * 64u * VC * nbk;
+    win = ow % VB_WINDOWS;
+    out = ow / VB_WINDOWS;
+    const uint32_t nbk = B >> 6, nwg = 2u * VB_WINDOWS * VC * nbk;
+    if (remap && (B & 63u) == 0 && (nwg & 7u) == 0) {
         uint32_t wg = g0 >> 6;
         wg = (wg & 7u) * (nwg >> 3) + (wg >> 3);
-        win = wg & 63u;
-        uint32_t r1 = wg >> 6, bk = r1 % nbk;
+        win = wg % VB_WINDOWS;
+        uint32_t r1 = wg / VB_WINDOWS, bk = r1 % nbk;
         r1 /= nbk;
         c = r1 % VC;
         out = r1 / VC;
         b = (bk << 6) | (g0 & 63u);
     }
-    return ((out * 64u + win) * VC + c) * B + b;
+    return ((out * VB_WINDOWS + win) * VC + c) * B + b;
 }
 struct K_ipa_vb_win {  // one thread per (output, window, chunk, proof): sum over the chunk's terms of digit_win(term) * P_term
     const ge_cached* vtab;
     const uint32_t* vdig;
-    ge* part;  // [2][64][VC][B]
+    ge* part;  // [2][VB_WINDOWS][VC][B]
     uint32_t B, m, VC, remap;
     uint32_t skip;  // 0: the round the multiples were built for (terms of output `out`: w = 2*out, 2*out + 1);
                     // 1: the round after it, on the same multiples (K_ipa_vb_dig2): quarter q of the 4h terms, h = m/2
@@ -1177,6 +1210,7 @@ struct K_ipa_vb_win {  // one thread per (output, window, chunk, proof): sum ove
         uint32_t total = 2 * m, per = (total + VC - 1) / VC;
         uint32_t lo = c * per, hi = lo + per < total ? lo + per : total;
         size_t stride = (size_t)4 * m * B;
+        const uint32_t dw = win / VB_PER_WORD, dk = win - dw * VB_PER_WORD;
         ge acc = ge_identity();
         for (uint32_t o = lo; o < hi; o++) {
             size_t t;
@@ -1188,8 +1222,7 @@ struct K_ipa_vb_win {  // one thread per (output, window, chunk, proof): sum ove
                 const uint32_t up = (q < 2) ? (out == 0) : (out != 0);
                 t = ((size_t)w * m + jj + up * h) * B + b;
             }
-            int d = (int)((vdig[(size_t)(win >> 3) * stride + t] >> (4 * (win & 7u))) & 15u);
-            if (d & 8) d -= 16;
+            int d = vb_digit(vdig[(size_t)dw * stride + t], dk);
             if (d != 0) {
                 int mag = d < 0 ? -d : d;
                 ge_cached e = vtab[(size_t)(mag - 1) * stride + t];
@@ -1199,89 +1232,33 @@ struct K_ipa_vb_win {  // one thread per (output, window, chunk, proof): sum ove
         part[g] = acc;
     }
 };
-struct K_ipa_vb_horner {  // gid = out*B + b : sum_w 16^w * S_w, S_w = sum of the VC chunk sums of window w
-    const ge* part;  // [2][64][VC][B]
+struct K_ipa_vb_horner {  // gid = out*B + b : sum_w 32^w * S_w, S_w = sum of the VC chunk sums of window w
+    const ge* part;  // [2][VB_WINDOWS][VC][B]
     ge* out;         // [2][B]
     uint32_t B, VC;
     HD void operator()(uint32_t g) const {
         uint32_t b = g % B, o = g / B;
         ge acc = ge_identity();
-        for (int w = 63; w >= 0; w--) {
-            if (w != 63) acc = ge_dbl4(acc);
-            const ge* p = part + (((size_t)o * 64 + (uint32_t)w) * VC) * B + b;
+        for (int w = (int)VB_WINDOWS - 1; w >= 0; w--) {
+            if (w != (int)VB_WINDOWS - 1) acc = ge_dbln<(int)VB_W>(acc);
+            const ge* p = part + (((size_t)o * VB_WINDOWS + (uint32_t)w) * VC) * B + b;
             for (uint32_t c = 0; c < VC; c++) acc = ge_add_ge(acc, p[(size_t)c * B]);
         }
         out[g] = acc;
     }
 };
-struct K_ipa_vb_fold {  // gid = (b*2 + side)*m + j : Ghat'[j] = Ghat[j] + u^2 Ghat[j+m] ; Hhat' = Hhat[j] + u^-2 Hhat[j+m]
-    ge* GH;
-    const sc* uk;   // [2][B]: u, u^-1 (Montgomery)
-    sc* linv;       // [2][B]
-    // the multiples 1P..8P of every "hi" generator were built for this round's L/R sums (K_ipa_vb_tab: w = 0 holds
-    // G_hi, w = 3 holds H_hi): the fold reuses them - signed radix-16 digits of the shared scalar, 63 x 4 doublings of
-    // which three in four skip the T coordinate, <= 64 additions of a ready multiple (instead of 253 full doublings +
-    // ~84 additions of the NAF ladder)
-    const ge_cached* vtab;  // [8][4*m*B]
-    uint32_t B, m, M;
-    HD void operator()(uint32_t g) const {
-        uint32_t j = g % m, bs = g / m, side = bs & 1u, b = bs >> 1;
-        ge* P = GH + (size_t)side * M * B;
-        sc f = uk[(size_t)(side ? 1 : 0) * B + b];   // G: u ; H: u^-1
-        sc w = sc_from_mont(sc_mul(f, f));
-        const size_t stride = (size_t)4 * m * B;
-        const ge_cached* T = vtab + ((size_t)(side ? 3u : 0u) * m + j) * B + b;
-        ge acc = ge_identity();
-        // signed digits d_i in [-8, 7] as 4-bit two's complement, 8 per word (w < l < 2^253: digit 63 <= 1, no carry out);
-        // consumed most significant first with the word index a compile-time constant (no scratch-memory array)
-        uint32_t pk[8];
-        int carry = 0;
-#pragma unroll
-        for (int wi = 0; wi < 8; wi++) {
-            uint32_t o = 0;
-            for (int k = 0; k < 8; k++) {
-                int d = (int)((w.v[wi] >> (4 * k)) & 15u) + carry;
-                carry = d >= 8;
-                o |= ((uint32_t)(d - (carry << 4)) & 15u) << (4 * k);
-            }
-            pk[wi] = o;
-        }
-        bool started = false;
-#pragma unroll
-        for (int wi = 7; wi >= 0; wi--) {
-            const uint32_t word = pk[wi];
-            for (int k = 7; k >= 0; k--) {
-                if (started) acc = ge_dbl4(acc);
-                int d = (int)((word >> (4 * k)) & 15u);
-                if (d & 8) d -= 16;
-                if (d != 0) {
-                    int mag = d < 0 ? -d : d;
-                    ge_cached e = T[(size_t)(mag - 1) * stride];
-                    acc = d < 0 ? ge_sub(acc, e) : ge_add(acc, e);
-                    started = true;
-                }
-            }
-        }
-        ge lo = P[(size_t)j * B + b];
-        P[(size_t)j * B + b] = ge_add_ge(lo, acc);
-        if (j == 0) {  // lam' = lam * f  ->  linv' = linv * f^-1
-            sc finv = uk[(size_t)(side ? 0 : 1) * B + b];
-            linv[(size_t)side * B + b] = sc_mul(linv[(size_t)side * B + b], finv);
-        }
-    }
-};
-// Two rounds on one set of multiples.  After round k (vector length 2m, multiples 1P..8P of all 4m per-proof points in
-// vtab) the generators are NOT folded: round k+1's L/R are sums over the same 4m points with product scalars
+// Two rounds on one set of multiples.  After round k (vector length 2m, multiples of all 4m per-proof points in vtab)
+// the generators are NOT folded: round k+1's L/R are sums over the same 4m points with product scalars
 //   Ghat'_i = Ghat_i + u^2 Ghat_{i+m}  =>  a'_j Ghat'_{j+h} = a'_j Ghat_{j+h} + (a'_j u^2) Ghat_{j+h+m}      (h = m/2)
-// (K_ipa_vb_dig2 only writes new digits), and the generators of round k+2 come from ONE Straus pass per output over four
-// ready sets of multiples (K_ipa_vb_fold2): 63 x 4 doublings per output of level k+2 instead of per output of levels k+1
+// (K_ipa_vb_dig2 only writes new digits), and the generators of round k+2 come from ONE Straus pass per output over three
+// ready sets of multiples (K_ipa_vb_fold2): 250 doublings per output of level k+2 instead of per output of levels k+1
 // AND k+2 - a third of the doublings, which are what a fold costs.
 struct K_ipa_vb_dig2 {  // gid = (w*m + j)*B + b over round k's layout (w: 0 G_hi, 1 H_lo, 2 G_lo, 3 H_hi)
     const sc* a;      // vectors AFTER round k's fold (length m)
     const sc* bb;
     const sc* linv;   // [2][B] as of round k (no generator fold has happened since)
     const sc* uk;     // [2][B] u_k, u_k^-1
-    uint32_t* vdig;   // [8][4*m*B]
+    uint32_t* vdig;   // [VB_WORDS][4*m*B]
     uint32_t B, m;
     HD void operator()(uint32_t g) const {
         uint32_t b = g % B, wj = g / B, w = wj / m, j = wj % m, h = m >> 1;
@@ -1292,37 +1269,15 @@ struct K_ipa_vb_dig2 {  // gid = (w*m + j)*B + b over round k's layout (w: 0 G_h
         // scale of the level-(k+1) generators: linv' = linv * f^-1 (G: f = u, H: f = u^-1); "hi" points carry f^2 on top
         sc fac = sc_mul(linv[(size_t)side * B + b], uk[(size_t)((side ^ hi) ? 0u : 1u) * B + b]);
         sc s = sc_from_mont(sc_mul(sv[(size_t)idx * B + b], fac));
-        uint32_t dig[8];
-#pragma unroll
-        for (int i = 0; i < 8; i++) dig[i] = 0;
-        int carry = 0;
-        for (int i = 0; i < 64; i++) {
-            int d = (int)((s.v[i >> 3] >> (4 * (i & 7))) & 15u) + carry;
-            carry = d >= 8;
-            d -= carry << 4;
-            dig[i >> 3] |= ((uint32_t)d & 15u) << (4 * (i & 7));
-        }
+        uint32_t dig[VB_WORDS];
+        vb_recode(s, dig);
         const size_t stride = (size_t)4 * m * B;
 #pragma unroll
-        for (int i = 0; i < 8; i++) vdig[(size_t)i * stride + g] = dig[i];
+        for (uint32_t i = 0; i < VB_WORDS; i++) vdig[(size_t)i * stride + g] = dig[i];
     }
 };
-HD inline void vb_pack_digits(const sc& w, uint32_t pk[8]) {  // 64 signed radix-16 digits, 4-bit two's complement, 8 per word
-    int carry = 0;
-#pragma unroll
-    for (int wi = 0; wi < 8; wi++) {
-        uint32_t o = 0;
-        for (int k = 0; k < 8; k++) {
-            int d = (int)((w.v[wi] >> (4 * k)) & 15u) + carry;
-            carry = d >= 8;
-            o |= ((uint32_t)(d - (carry << 4)) & 15u) << (4 * k);
-        }
-        pk[wi] = o;
-    }
-}
-HD inline ge vb_add_digit(const ge& acc, uint32_t word, int k, const ge_cached* T, size_t stride, bool& started) {
-    int d = (int)((word >> (4 * k)) & 15u);
-    if (d & 8) d -= 16;
+HD inline ge vb_add_digit(const ge& acc, uint32_t word, uint32_t k, const ge_cached* T, size_t stride, bool& started) {
+    int d = vb_digit(word, k);
     if (d == 0) return acc;
     int mag = d < 0 ? -d : d;
     ge_cached e = T[(size_t)(mag - 1) * stride];
@@ -1334,19 +1289,20 @@ struct K_ipa_vb_fold2 {  // gid = (b*2 + side)*h + j : Ghat''[j] = Ghat[j] + w0 
     const sc* uk0;  // [2][B] u_k, u_k^-1 of the round the multiples were built in
     const sc* uk1;  // [2][B] of the round after it
     sc* linv;       // [2][B]
-    const ge_cached* vtab;  // [8][4*m*B]
+    const ge_cached* vtab;  // [VB_MULT][4*m*B]
     uint32_t B, m, M;
     HD void operator()(uint32_t g) const {
+        // lanes of a wavefront = consecutive outputs of ONE proof: the three digit streams are wave-uniform (no divergence)
         const uint32_t h = m >> 1;
         uint32_t j = g % h, bs = g / h, side = bs & 1u, b = bs >> 1;
         ge* P = GH + (size_t)side * M * B;
         const uint32_t fi = side ? 1u : 0u;  // G: f = u ; H: f = u^-1
         sc f0 = uk0[(size_t)fi * B + b], f1 = uk1[(size_t)fi * B + b];
         sc w0m = sc_mul(f0, f0), w1m = sc_mul(f1, f1);
-        uint32_t p0[8], p1[8], p01[8];
-        vb_pack_digits(sc_from_mont(w0m), p0);
-        vb_pack_digits(sc_from_mont(w1m), p1);
-        vb_pack_digits(sc_from_mont(sc_mul(w0m, w1m)), p01);
+        uint32_t p0[VB_WORDS], p1[VB_WORDS], p01[VB_WORDS];
+        vb_recode(sc_from_mont(w0m), p0);
+        vb_recode(sc_from_mont(w1m), p1);
+        vb_recode(sc_from_mont(sc_mul(w0m, w1m)), p01);
         const size_t stride = (size_t)4 * m * B;
         const uint32_t w_lo = side ? 1u : 2u, w_hi = side ? 3u : 0u;
         const ge_cached* T0 = vtab + ((size_t)w_hi * m + j) * B + b;        // Ghat[j+m]
@@ -1355,13 +1311,14 @@ struct K_ipa_vb_fold2 {  // gid = (b*2 + side)*h + j : Ghat''[j] = Ghat[j] + w0 
         ge acc = ge_identity();
         bool started = false;
 #pragma unroll
-        for (int wi = 7; wi >= 0; wi--) {
+        for (int wi = (int)VB_WORDS - 1; wi >= 0; wi--) {  // word index a compile-time constant: no scratch-memory array
             const uint32_t d0 = p0[wi], d1 = p1[wi], d01 = p01[wi];
-            for (int k = 7; k >= 0; k--) {
-                if (started) acc = ge_dbl4(acc);
-                acc = vb_add_digit(acc, d0, k, T0, stride, started);
-                acc = vb_add_digit(acc, d1, k, T1, stride, started);
-                acc = vb_add_digit(acc, d01, k, T01, stride, started);
+            for (int k = (int)VB_PER_WORD - 1; k >= 0; k--) {
+                if ((uint32_t)wi * VB_PER_WORD + (uint32_t)k >= VB_WINDOWS) continue;
+                if (started) acc = ge_dbln<(int)VB_W>(acc);
+                acc = vb_add_digit(acc, d0, (uint32_t)k, T0, stride, started);
+                acc = vb_add_digit(acc, d1, (uint32_t)k, T1, stride, started);
+                acc = vb_add_digit(acc, d01, (uint32_t)k, T01, stride, started);
             }
         }
         ge lo = P[(size_t)j * B + b];
@@ -1673,12 +1630,12 @@ struct K_batch_finish {  // single thread: sum of the partial sums -> compressed
         *wellformed = ok;
     }
 };
-// general variable-base MSM (bpr1cs_msm): per term the multiples 1P..8P and the signed radix-16 digits ...
+// general variable-base MSM (bpr1cs_msm): per term the multiples 1P..16P and the signed radix-32 digits ...
 struct K_msm_var_tab {  // gid = i < n
     const uint8_t* scalars;  // [n][32] canonical
     const uint8_t* points;   // [n][32] compressed
-    ge_cached* vtab;         // [8][n]
-    uint32_t* vdig;          // [8][n]
+    ge_cached* vtab;         // [VB_MULT][n]
+    uint32_t* vdig;          // [VB_WORDS][n]
     int* fail;
     uint32_t n;
     HD void operator()(uint32_t g) const {
@@ -1688,35 +1645,29 @@ struct K_msm_var_tab {  // gid = i < n
         ge_cached c1 = ge_to_cached(P);
         vtab[g] = c1;
         ge q = P;
-        for (int e = 1; e < 8; e++) {
+        for (uint32_t e = 1; e < VB_MULT; e++) {
             q = ge_add(q, c1);
             vtab[(size_t)e * n + g] = ge_to_cached(q);
         }
-        uint32_t dig[8];
-        for (int i = 0; i < 8; i++) dig[i] = 0;
-        int carry = 0;
-        for (int i = 0; i < 64; i++) {
-            int d = (int)((s.v[i >> 3] >> (4 * (i & 7))) & 15u) + carry;
-            carry = d >= 8;
-            d -= carry << 4;
-            dig[i >> 3] |= ((uint32_t)d & 15u) << (4 * (i & 7));
-        }
-        for (int i = 0; i < 8; i++) vdig[(size_t)i * n + g] = dig[i];
+        uint32_t dig[VB_WORDS];
+        vb_recode(s, dig);
+#pragma unroll
+        for (uint32_t i = 0; i < VB_WORDS; i++) vdig[(size_t)i * n + g] = dig[i];
     }
 };
 // ... per (window, chunk) the sum of the selected multiples, then K_ge_reduce over the chunks and K_ipa_vb_horner
 struct K_msm_var_win {  // gid = win*VC + c
     const ge_cached* vtab;
     const uint32_t* vdig;
-    ge* part;  // [64][VC]
+    ge* part;  // [VB_WINDOWS][VC]
     uint32_t n, VC;
     HD void operator()(uint32_t g) const {
         uint32_t c = g % VC, win = g / VC;
         uint32_t per = (n + VC - 1) / VC, lo = c * per, hi = lo + per < n ? lo + per : n;
+        const uint32_t dw = win / VB_PER_WORD, dk = win - dw * VB_PER_WORD;
         ge acc = ge_identity();
         for (uint32_t o = lo; o < hi; o++) {
-            int d = (int)((vdig[(size_t)(win >> 3) * n + o] >> (4 * (win & 7u))) & 15u);
-            if (d & 8) d -= 16;
+            int d = vb_digit(vdig[(size_t)dw * n + o], dk);
             if (d != 0) {
                 int mag = d < 0 ? -d : d;
                 ge_cached e = vtab[(size_t)(mag - 1) * n + o];

@@ -131,13 +131,13 @@ extern "C" int hs_table_msm(const uint8_t* pts, const uint8_t* scalars, uint32_t
 
 // K_ipa_vb_win's XCD-aware workgroup order is a permutation of the (output, window, chunk, proof) space
 extern "C" int hs_vb_win_index_is_permutation(uint32_t B, uint32_t VC) {
-    const uint32_t n = 2u * 64u * VC * B;
+    const uint32_t n = 2u * VB_WINDOWS * VC * B;
     std::vector<uint8_t> seen(n, 0);
     for (uint32_t g0 = 0; g0 < n; g0++) {
         uint32_t out, win, c, b;
         uint32_t g = vb_win_index(g0, B, VC, 1, out, win, c, b);
-        if (g >= n || seen[g] || out > 1 || win > 63 || c >= VC || b >= B) return 0;
-        if (g != ((out * 64u + win) * VC + c) * B + b) return 0;
+        if (g >= n || seen[g] || out > 1 || win >= VB_WINDOWS || c >= VC || b >= B) return 0;
+        if (g != ((out * VB_WINDOWS + win) * VC + c) * B + b) return 0;
         // the 64 lanes of a wavefront are 64 consecutive proofs of one (output, window, chunk)
         if ((B & 63u) == 0 && (g0 & 63u) != (b & 63u)) return 0;
         seen[g] = 1;

@@ -34,3 +34,19 @@ for n, s, e, q in rows:
 print("# heavy kernels: name | alone: launches avg_ms | with a front kernel running: launches avg_ms")
 for k, a in sorted(agg.items(), key=lambda kv: -(kv[1][1] + kv[1][3]))[:14]:
     print("%-24s %5d %9.3f | %5d %9.3f" % (k, a[0], a[1] / max(a[0], 1), a[2], a[3] / max(a[2], 1)))
+# busy / idle time of the queue the MSM kernel runs on (the shared "back" stream), between the first and the last MSM launch
+msm = [(s, e, q) for n, s, e, q in rows if "k_msm_fixed2" in n]
+if msm:
+    hq = collections.Counter(q for _, _, q in msm).most_common(1)[0][0]
+    lo, hi = msm[len(msm) // 4][0], msm[-1][1]   # skip the setup / warm-up quarter
+    on = sorted((s, e, short(n)) for n, s, e, q in rows if q == hq and s >= lo and e <= hi)
+    busy = sum(e - s for s, e, _ in on)
+    gaps = collections.defaultdict(lambda: [0, 0.0])
+    for (s0, e0, n0), (s1, e1, n1) in zip(on, on[1:]):
+        g = (s1 - e0) / 1e6
+        if g > 0.02:
+            a = gaps[n0 + " -> " + n1]; a[0] += 1; a[1] += g
+    print("# back stream q%d over %.1f ms: busy %.1f ms (%.1f %%), %d launches" % (hq, (hi - lo) / 1e6, busy / 1e6, 100.0 * busy / (hi - lo), len(on)))
+    print("# gaps > 20 us on it, by neighbour pair: count total_ms")
+    for k, a in sorted(gaps.items(), key=lambda kv: -kv[1][1])[:12]:
+        print("%-60s %4d %8.2f" % (k, a[0], a[1]))
