@@ -190,7 +190,7 @@ def cpu_baseline(levels, root, values, blindings, seeds, m, n_proofs, max_thread
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=24, help="timed batches; the pipeline is empty at both ends of the timed region, so the first batch's front phase (~0.19 s, nothing to overlap with) is paid once per run: +190/K ms per step")
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=1024, help="proofs per GPU per step")
     ap.add_argument("--depth", type=int, default=32, help="4-ary tree levels (BASELINE: 32)")

@@ -115,6 +115,21 @@ HD inline ge ge_sub(const ge& p, const ge_cached& q) {
     r.X = fe_mul(cX, cT); r.Y = fe_mul(cY, cZ); r.Z = fe_mul(cZ, cT); r.T = fe_mul(cX, cY);
     return r;
 }
+// p + q or p - q by a per-lane flag, without branching (a divergent `neg ? ge_sub : ge_add` makes a wavefront run both bodies)
+HD inline ge ge_addsub(const ge& p, const ge_cached& q, int negate) {
+    fe a = fe_select(q.YplusX, q.YminusX, negate);
+    fe b = fe_select(q.YminusX, q.YplusX, negate);
+    fe PP = fe_mul(fe_add(p.Y, p.X), a);
+    fe MM = fe_mul(fe_sub(p.Y, p.X), b);
+    fe TT2d = fe_mul(p.T, q.T2d);
+    fe ZZ = fe_mul(p.Z, q.Z);
+    fe ZZ2 = fe_add(ZZ, ZZ);
+    fe zp = fe_add(ZZ2, TT2d), zm = fe_sub(ZZ2, TT2d);
+    fe cX = fe_sub(PP, MM), cY = fe_add(PP, MM), cZ = fe_select(zp, zm, negate), cT = fe_select(zm, zp, negate);
+    ge r;
+    r.X = fe_mul(cX, cT); r.Y = fe_mul(cY, cZ); r.Z = fe_mul(cZ, cT); r.T = fe_mul(cX, cY);
+    return r;
+}
 // p + q (q affine Niels): 7M.  `negate` selects p - q without branching.
 HD inline ge ge_madd(const ge& p, const ge_niels& q, int negate) {
     fe a = fe_select(q.yplusx, q.yminusx, negate);

@@ -1226,7 +1226,7 @@ struct K_ipa_vb_win {  // one thread per (output, window, chunk, proof): sum ove
             if (d != 0) {
                 int mag = d < 0 ? -d : d;
                 ge_cached e = vtab[(size_t)(mag - 1) * stride + t];
-                acc = d < 0 ? ge_sub(acc, e) : ge_add(acc, e);
+                acc = ge_addsub(acc, e, d < 0);
             }
         }
         part[g] = acc;
@@ -1282,7 +1282,7 @@ HD inline ge vb_add_digit(const ge& acc, uint32_t word, uint32_t k, const ge_cac
     int mag = d < 0 ? -d : d;
     ge_cached e = T[(size_t)(mag - 1) * stride];
     started = true;
-    return d < 0 ? ge_sub(acc, e) : ge_add(acc, e);
+    return ge_addsub(acc, e, d < 0);
 }
 struct K_ipa_vb_fold2 {  // gid = (b*2 + side)*h + j : Ghat''[j] = Ghat[j] + w0 Ghat[j+m] + w1 Ghat[j+h] + w0 w1 Ghat[j+h+m]
     ge* GH;
@@ -1671,7 +1671,7 @@ struct K_msm_var_win {  // gid = win*VC + c
             if (d != 0) {
                 int mag = d < 0 ? -d : d;
                 ge_cached e = vtab[(size_t)(mag - 1) * n + o];
-                acc = d < 0 ? ge_sub(acc, e) : ge_add(acc, e);
+                acc = ge_addsub(acc, e, d < 0);
             }
         }
         part[g] = acc;
