@@ -803,10 +803,10 @@ static void enqueue_ipa(const IpaIO& io, dev_stream_t st, MsmStats* stats) {
     const uint32_t VC = vc_env ? vc_env : 16;
     // variable-base rounds come in pairs on one set of multiples, generators folded two levels at a time (K_ipa_vb_dig2 / _fold2)
     bool vb_reuse = false;
-    auto finish = [&](const ge* part, uint32_t nch, const sc* c, uint8_t* out) {
+    auto finisher = [&](const ge* part, uint32_t nch, const sc* c, uint8_t* out) {
         K_msm_finish f{g->tab.p, g->tc, part, c, io.qw, out, B, nch, 0};
         if (io.qpt) { f.extra2 = nullptr; f.extra_pt = io.qpt; }
-        launch(B, f, st);
+        return f;
     };
     for (uint32_t k = 0; k < lgN; k++) {
         uint32_t Nk = N >> k, mk = Nk >> 1;
@@ -830,14 +830,9 @@ static void enqueue_ipa(const IpaIO& io, dev_stream_t st, MsmStats* stats) {
             MsmPlan planR;
             MsmReq rq[2] = {{gL, hL, &partial, &plan, nullptr}, {gR, hR, &partialR, &planR, nullptr}};
             run_msm_multi(g, rq, 2, B, st, stats);  // L_k and R_k share one launch
-            if (hs) {
-                K_msm_finish f{g->tab.p, g->tc, partial.p, cross.p, io.qw, Lout, B, plan.nchunks, 0};
-                if (io.qpt) { f.extra2 = nullptr; f.extra_pt = io.qpt; }
-                f.tab2 = io.hs_tab; f.extra_b = io.hs_scal;
-                launch(B, f, st);
-            } else
-            finish(partial.p, plan.nchunks, cross.p, Lout);
-            finish(partialR.p, planR.nchunks, cross.p + B, Rout);
+            K_msm_finish fL = finisher(partial.p, plan.nchunks, cross.p, Lout);
+            if (hs) { fL.tab2 = io.hs_tab; fL.extra_b = io.hs_scal; }
+            launch((uint64_t)2 * B, K_pair<K_msm_finish>{fL, finisher(partialR.p, planR.nchunks, cross.p + B, Rout), B}, st);
         } else {
             if (k == r) {
                 GH.alloc((size_t)2 * M * B);
@@ -887,8 +882,7 @@ static void enqueue_ipa(const IpaIO& io, dev_stream_t st, MsmStats* stats) {
                 launch((uint64_t)2 * VB_WINDOWS * B, K_ge_reduce{vwin.p, vsum.p, B, 2 * VB_WINDOWS * vc, vc}, st);
             }
             launch((uint64_t)2 * B, K_ipa_vb_horner{vsum.p, vout.p, B, 1}, st);
-            finish(vout.p, 1, cross.p, Lout);
-            finish(vout.p + (size_t)B, 1, cross.p + B, Rout);
+            launch((uint64_t)2 * B, K_pair<K_msm_finish>{finisher(vout.p, 1, cross.p, Lout), finisher(vout.p + (size_t)B, 1, cross.p + B, Rout), B}, st);
         }
         sc* ukk = io.uk + (size_t)k * 2 * B;
         launch(B, K_transcript_LR{io.tr, Lout, ukk, B}, st);

@@ -807,6 +807,16 @@ struct K_msm_finish {  // gid = b
         ge_compress(acc, out + 32 * (size_t)b);
     }
 };
+// two instances of one per-proof kernel in a single launch (gid < B: the first): L_k and R_k of an IPA round are finished and
+// compressed together - each is a 16-wavefront, latency-bound launch on the critical path of the round
+template <class F>
+struct K_pair {
+    F a, b;
+    uint32_t B;
+    HD void operator()(uint32_t g) const {
+        if (g < B) a(g); else b(g - B);
+    }
+};
 
 // ------------------------------------------------------ constraints / polys
 // wvec[s][b] = sum over entries (j, c) of slot s : z^(j+1) * c   (slots 3n.. are wV, negated)
