@@ -298,20 +298,24 @@ def main():
     try:
         _, comms = begin().finish()
         sh = importlib.import_module("bulletproofs-r1cs-gadgets_amd.sharding")
-        torch.cuda.synchronize()
-        tb = time.perf_counter()
-        try:   # fresh randomness for the weights (include/bpr1cs.h: batch_seed must not be predictable)
-            pt, wf = bp.verify_batch_combined(gens, circ, b"VSMT", proofs, comms, B, os.urandom(32), index_base=rank * B)
-        except Exception:  # keep the collective below matched on every rank
-            pt, wf = b"\xff" * 32, False
-        pts, all_wf = sh.gather_partial_points(pt, wf, device="cuda" if dist is not None else None)
-        accepted = bool(all_wf) and bp.points_sum_is_identity(pts)
-        tb = time.perf_counter() - tb
-        # the multi-GPU form: shared-base MSM split by base range over the ranks (all_gather of the combined scalar vectors)
-        torch.cuda.synchronize()
-        ts = time.perf_counter()
-        accepted_split = sh.verify_sharded(bp, gens, circ, b"VSMT", proofs, comms, B, rank, world, rank * B, device="cuda" if dist is not None else None)
-        ts = time.perf_counter() - ts
+        # one-shot calls are noisy (first-use allocations): both forms run twice, the faster run is reported
+        tb = ts = float("inf")
+        accepted = accepted_split = True
+        for _ in range(2):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            try:   # fresh randomness for the weights (include/bpr1cs.h: batch_seed must not be predictable)
+                pt, wf = bp.verify_batch_combined(gens, circ, b"VSMT", proofs, comms, B, os.urandom(32), index_base=rank * B)
+            except Exception:  # keep the collective below matched on every rank
+                pt, wf = b"\xff" * 32, False
+            pts, all_wf = sh.gather_partial_points(pt, wf, device="cuda" if dist is not None else None)
+            accepted = accepted and bool(all_wf) and bp.points_sum_is_identity(pts)
+            tb = min(tb, time.perf_counter() - t1)
+            # the multi-GPU form: shared-base MSM split by base range over the ranks (all_gather of the combined scalar vectors)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            accepted_split = sh.verify_sharded(bp, gens, circ, b"VSMT", proofs, comms, B, rank, world, rank * B, device="cuda" if dist is not None else None) and accepted_split
+            ts = min(ts, time.perf_counter() - t1)
         batched = {"accepted_all": accepted, "proofs": B * world, "proofs_per_s": B * world / tb,
                    "split_shared_base": {"accepted_all": accepted_split, "proofs_per_s": B * world / ts,
                                          "note": "bpr1cs_verify_batch_scalars + all_gather of the scalar vectors + 1/world of the bases per rank"},

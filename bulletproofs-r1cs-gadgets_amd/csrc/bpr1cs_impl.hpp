@@ -891,7 +891,7 @@ static void enqueue_ipa(const IpaIO& io, dev_stream_t st, MsmStats* stats) {
         else if (!vb_reuse) {
             vb_reuse = k + 1 < lgN;  // the next round works on this round's multiples
         } else {
-            if (k + 1 < lgN) launch_wave((uint64_t)2 * mk * B, K_ipa_vb_fold2{GH.p, io.uk + (size_t)(k - 1) * 2 * B, ukk, linv.p, vtab.p, B, 2 * mk, M}, st);
+            if (k + 1 < lgN) launch((uint64_t)2 * mk * B, K_ipa_vb_fold2{GH.p, io.uk + (size_t)(k - 1) * 2 * B, ukk, linv.p, vtab.p, B, 2 * mk, M}, st);
             vb_reuse = false;
         }
     }

@@ -1286,15 +1286,14 @@ struct K_ipa_vb_dig2 {  // gid = (w*m + j)*B + b over round k's layout (w: 0 G_h
         for (uint32_t i = 0; i < VB_WORDS; i++) vdig[(size_t)i * stride + g] = dig[i];
     }
 };
-HD inline ge vb_add_digit(const ge& acc, uint32_t word, uint32_t k, const ge_cached* T, size_t stride, bool& started) {
+HD inline ge vb_add_digit(const ge& acc, uint32_t word, uint32_t k, const ge_cached* T, size_t stride) {
     int d = vb_digit(word, k);
     if (d == 0) return acc;
     int mag = d < 0 ? -d : d;
     ge_cached e = T[(size_t)(mag - 1) * stride];
-    started = true;
     return ge_addsub(acc, e, d < 0);
 }
-struct K_ipa_vb_fold2 {  // gid = (b*2 + side)*h + j : Ghat''[j] = Ghat[j] + w0 Ghat[j+m] + w1 Ghat[j+h] + w0 w1 Ghat[j+h+m]
+struct K_ipa_vb_fold2 {  // gid = (side*h + j)*B + b : Ghat''[j] = Ghat[j] + w0 Ghat[j+m] + w1 Ghat[j+h] + w0 w1 Ghat[j+h+m]
     ge* GH;
     const sc* uk0;  // [2][B] u_k, u_k^-1 of the round the multiples were built in
     const sc* uk1;  // [2][B] of the round after it
@@ -1302,9 +1301,9 @@ struct K_ipa_vb_fold2 {  // gid = (b*2 + side)*h + j : Ghat''[j] = Ghat[j] + w0 
     const ge_cached* vtab;  // [VB_MULT][4*m*B]
     uint32_t B, m, M;
     HD void operator()(uint32_t g) const {
-        // lanes of a wavefront = consecutive outputs of ONE proof: the three digit streams are wave-uniform (no divergence)
+        // lanes of a wavefront = consecutive proofs (coalesced reads of the multiples); signs are applied without branching
         const uint32_t h = m >> 1;
-        uint32_t j = g % h, bs = g / h, side = bs & 1u, b = bs >> 1;
+        uint32_t b = g % B, sj = g / B, side = sj / h, j = sj % h;
         ge* P = GH + (size_t)side * M * B;
         const uint32_t fi = side ? 1u : 0u;  // G: f = u ; H: f = u^-1
         sc f0 = uk0[(size_t)fi * B + b], f1 = uk1[(size_t)fi * B + b];
@@ -1319,16 +1318,16 @@ struct K_ipa_vb_fold2 {  // gid = (b*2 + side)*h + j : Ghat''[j] = Ghat[j] + w0 
         const ge_cached* T1 = vtab + ((size_t)w_lo * m + j + h) * B + b;    // Ghat[j+h]
         const ge_cached* T01 = vtab + ((size_t)w_hi * m + j + h) * B + b;   // Ghat[j+h+m]
         ge acc = ge_identity();
-        bool started = false;
 #pragma unroll
         for (int wi = (int)VB_WORDS - 1; wi >= 0; wi--) {  // word index a compile-time constant: no scratch-memory array
             const uint32_t d0 = p0[wi], d1 = p1[wi], d01 = p01[wi];
             for (int k = (int)VB_PER_WORD - 1; k >= 0; k--) {
-                if ((uint32_t)wi * VB_PER_WORD + (uint32_t)k >= VB_WINDOWS) continue;
-                if (started) acc = ge_dbln<(int)VB_W>(acc);
-                acc = vb_add_digit(acc, d0, (uint32_t)k, T0, stride, started);
-                acc = vb_add_digit(acc, d1, (uint32_t)k, T1, stride, started);
-                acc = vb_add_digit(acc, d01, (uint32_t)k, T01, stride, started);
+                const uint32_t i = (uint32_t)wi * VB_PER_WORD + (uint32_t)k;
+                if (i >= VB_WINDOWS) continue;
+                if (i + 1u < VB_WINDOWS) acc = ge_dbln<(int)VB_W>(acc);  // (the identity doubles to itself)
+                acc = vb_add_digit(acc, d0, (uint32_t)k, T0, stride);
+                acc = vb_add_digit(acc, d1, (uint32_t)k, T1, stride);
+                acc = vb_add_digit(acc, d01, (uint32_t)k, T01, stride);
             }
         }
         ge lo = P[(size_t)j * B + b];
