@@ -50,7 +50,7 @@ def build_workload(bp, levels, batch, n_leaves, seed_base):
     proof j proves membership of leaf j mod n_leaves with its own blindings and rng seed."""
     tree = bp.SparseMerkleTree(4, levels, 140)
     leaves = [(i, i) for i in range(1, 11)]
-    mask = (1 << (2 * levels)) - 1
+    mask = (1 << min(2 * levels, 250)) - 1   # an index is a Scalar (reference gadget_vsmt_4.rs:226-238): below 2^252
     for k in range(max(0, n_leaves - 10)):
         leaves.append((synth_scalar(b"leaf-idx", k) & mask, synth_scalar(b"leaf-val", k)))
     leaves = leaves[:max(1, n_leaves)]

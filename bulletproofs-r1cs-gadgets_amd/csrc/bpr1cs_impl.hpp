@@ -400,7 +400,7 @@ int bpr1cs_circuit_create(const bpr1cs_circuit_desc* d, bpr1cs_circuit** out) {
                 return true;
             }
             if (kind == WK_INV_LEFT) return right;
-            if (kind == WK_BIT || kind == WK_NOTBIT) return (arg >> 8) < d->m && (arg & 0xffu) < 253u;
+            if (kind == WK_BIT || kind == WK_NOTBIT) return (arg >> 8) < d->m;  // any of the 256 bits of the canonical value (the as-shipped depth-128 tree takes 2 x 128)
             return false;
         };
         for (uint32_t i = 0; i < d->n; i++)

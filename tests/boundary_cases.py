@@ -115,7 +115,6 @@ def check_validation(lib):
         "wop: unknown operand kind": _raw_desc(2, 1, 2, [0, 1], [V(1, 0)], [(9, 0, 0, 1), (0, 2, 1, 0)], ok_off, ok_var),
         "wop: INV_LEFT as a left operand": _raw_desc(2, 1, 2, [0, 1], [V(1, 0)], [(1, 0, 0, 1), (0, 2, 1, 0)], ok_off, ok_var),
         "wop: bit of committed value >= m": _raw_desc(2, 1, 2, [0, 1], [V(1, 0)], [(2, (2 << 8) | 3, 0, 1), (0, 2, 1, 0)], ok_off, ok_var),
-        "wop: bit index >= 253": _raw_desc(2, 1, 2, [0, 1], [V(1, 0)], [(2, 253, 0, 1), (0, 2, 1, 0)], ok_off, ok_var),
         "lc: forward wire reference": _raw_desc(2, 1, 2, [0, 1], [V(1, 0)], [(0, 2, 0, 1), (0, 0, 1, 0)], ok_off, ok_var),
         "lc: reference to its own multiplier": _raw_desc(2, 1, 2, [0, 1], [V(1, 0)], ok_wops, ok_off, [V(0, 0), V(0, 1), V(1, 1)]),
         "lc: committed index >= m": _raw_desc(2, 1, 2, [0, 1], [V(1, 0)], ok_wops, ok_off, [V(0, 5), V(0, 1), V(1, 0)]),

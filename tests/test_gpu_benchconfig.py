@@ -188,3 +188,101 @@ def test_mimc_set_membership_batch_8192_config_c5(hip_lib, hip_glib):
     sh = importlib.import_module("bulletproofs-r1cs-gadgets_amd.sharding")
     assert sh.verify_sharded(bp, gens, circ, b"MiMC+SetMembership", P, C, B, 0, 1, 0) is True
     assert sh.verify_sharded(bp, gens, circ, b"MiMC+SetMembership", bad, C, B, 0, 1, 0) is False
+
+
+def test_vsmt4_as_shipped_depth_128(hip_lib, hip_glib):
+    """The depth the reference ships (TreeDepth = 128, src/gadget_vsmt_4.rs:25,28): n = 74 624, N = 131 072, 388 committed
+    values.  Window width chosen by the library from the free memory (W = 11 cannot hold 262 146 bases), a ragged batch of 70:
+    first and last proof equal the C oracle's byte for byte, all pass both device verifiers."""
+    sys.path.insert(0, ROOT)
+    import bench
+    bp = importlib.import_module("bulletproofs-r1cs-gadgets_amd")
+    o = _oracle()
+    levels, B = 128, 70
+    root, values, blindings, seeds, m = bench.build_workload(bp, levels, B, 70, 11)
+    assert m == 388
+    circ = bp.CompiledGadget("vsmt_4", [levels, 140], [root], lib=hip_lib, glib=hip_glib)
+    assert circ.n == 583 * levels and circ.has_witness_program
+    bp.release_cached_memory(hip_lib)
+    hip_lib.bpr1cs_set_window_bits(0)
+    hip_lib.bpr1cs_set_table_format(-1)
+    try:
+        gens = bp.Gens(131072, lib=hip_lib)
+    finally:
+        hip_lib.bpr1cs_set_window_bits(8)
+    try:
+        info = gens.table_info()
+        assert info["window_bits"] < 11 and info["bytes"] < 250e9, info
+        hip_lib.bpr1cs_set_unfold_rounds(4)
+        P, C = bp.prove_batch(gens, circ, b"VSMT", values, blindings, seeds, B)
+        assert len(P[0]) == 1 + 32 * (13 + 2 * 17)
+        oc = o.compile_vsmt4(levels, 140, root)
+        for j in (0, B - 1):
+            ref = o.prove_vsmt4(oc, values[j * m * 32:(j + 1) * m * 32], blindings[j * m * 32:(j + 1) * m * 32], seeds[32 * j:32 * j + 32])
+            assert P[j] == ref, "proof %d differs from the C oracle" % j
+        assert bp.verify_batch(gens, circ, b"VSMT", P, C, B) == [True] * B
+        pt, wf = bp.verify_batch_combined(gens, circ, b"VSMT", P, C, B)
+        assert wf and pt == bytes(32)
+        bad = bytearray(P[3]); bad[40] ^= 1
+        assert bp.verify_batch(gens, circ, b"VSMT", [P[0], bytes(bad)], [C[0], C[3]], 2) == [True, False]
+    finally:
+        gens.close()
+        bp.release_cached_memory(hip_lib)
+
+
+
+def test_vsmt2_as_shipped_depth_253(hip_lib, hip_glib):
+    """The binary tree at the depth the reference ships (TreeDepth = 253, src/gadget_vsmt_2.rs:23): n = 143 704, N = 262 144,
+    511 committed values, 524 290 generator bases (window width from the free memory), a ragged batch of 66: the first proof
+    equals the C oracle's byte for byte, all pass the device verifier, a tampered one is named."""
+    sys.path.insert(0, ROOT)
+    import bench
+    bp = importlib.import_module("bulletproofs-r1cs-gadgets_amd")
+    from cref import VSMT_2
+    o = _oracle()
+    depth, B = 253, 66
+    tree = bp.SparseMerkleTree(2, depth, 140, glib=hip_glib)
+    leaves, seen, k = [(i, i) for i in range(1, 11)], set(range(1, 11)), 0
+    while len(leaves) < 10 + B:
+        idx = bench.synth_scalar(b"l253-idx", k) & ((1 << 250) - 1)
+        k += 1
+        if idx not in seen:
+            seen.add(idx)
+            leaves.append((idx, bench.synth_scalar(b"l253-val", k)))
+    tree.update_many(leaves)
+    sel = leaves[10:10 + B]
+    lv, paths = tree.get_many([i for i, _ in sel])
+    sc = bench.sc
+    m = 2 * depth + 5
+    vals, bls = [], []
+    for k, (idx, val) in enumerate(sel):
+        nodes = [paths[32 * (depth * k + t):32 * (depth * k + t) + 32] for t in range(depth)]   # root level first
+        vals.append(sc(val) + b"".join(sc((idx >> t) & 1) for t in range(depth)) + b"".join(reversed(nodes)) + sc(0) + sc(101) + sc(0) + sc(0))
+        bls.append(b"".join(sc(bench.synth_scalar(b"bl253", k * 1024 + t)) for t in range(m - 4)) + bytes(128))   # statics: blinding 0
+    seeds = b"".join(bench.synth_rng_seed(2 * 10**6 + k) for k in range(B))
+    root = tree.root()
+    circ = bp.CompiledGadget("vsmt_2", [depth, 140], [root], lib=hip_lib, glib=hip_glib)
+    assert (circ.n, circ.m) == (568 * depth, m)
+    bp.release_cached_memory(hip_lib)
+    hip_lib.bpr1cs_set_window_bits(0)
+    hip_lib.bpr1cs_set_table_format(-1)
+    try:
+        gens = bp.Gens(262144, lib=hip_lib)
+    finally:
+        hip_lib.bpr1cs_set_window_bits(8)
+    try:
+        info = gens.table_info()
+        assert info["window_bits"] < 11 and info["bytes"] < 260e9, info
+        hip_lib.bpr1cs_set_unfold_rounds(4)
+        P, C = bp.prove_batch(gens, circ, b"VSMT", b"".join(vals), b"".join(bls), seeds, B)
+        assert len(P[0]) == 1 + 32 * (13 + 2 * 18)
+        o.lib.oracle_warm_gens(262144)
+        r = o.prove(VSMT_2, [depth, 140], root, b"VSMT", vals[0], bls[0], seeds[:32])
+        assert (r["n"], r["m"]) == (568 * depth, m)
+        assert P[0] == r["proof"] and C[0] == r["comms"], "proof 0 differs from the C oracle"
+        assert bp.verify_batch(gens, circ, b"VSMT", P, C, B) == [True] * B
+        bad = bytearray(P[65]); bad[1 + 32 * 9 + 1] ^= 2
+        assert bp.verify_batch(gens, circ, b"VSMT", P[:65] + [bytes(bad)], C, B) == [True] * 65 + [False]
+    finally:
+        gens.close()
+        bp.release_cached_memory(hip_lib)
