@@ -799,8 +799,7 @@ static void enqueue_ipa(const IpaIO& io, dev_stream_t st, MsmStats* stats) {
     MsmPlan plan;
     const uint32_t M = N >> r;  // size of the materialised folded generator vectors
     if (r > 0) { sG.alloc((size_t)N * B); sH.alloc((size_t)N * B); }
-    static const uint32_t vc_env = getenv("BPR1CS_VB_CHUNKS") ? (uint32_t)atoi(getenv("BPR1CS_VB_CHUNKS")) : 0;  // measurement knob
-    const uint32_t VC = vc_env ? vc_env : 16;
+    const uint32_t VC = 16;  // chunks per Straus output (8 / 32 / 64 measured within 0.3 %)
     // variable-base rounds come in pairs on one set of multiples, generators folded two levels at a time (K_ipa_vb_dig2 / _fold2)
     bool vb_reuse = false;
     auto finisher = [&](const ge* part, uint32_t nch, const sc* c, uint8_t* out) {
@@ -839,8 +838,7 @@ static void enqueue_ipa(const IpaIO& io, dev_stream_t st, MsmStats* stats) {
 #if defined(BPR1CS_HOSTSIM)
                 launch_wave((uint64_t)2 * M * B, K_ipa_fold_from_tables{g->tab.p, g->tc, cG, cH, GH.p, B, M, N, baseG, baseH}, st);
 #else
-                static const bool fold_functor = getenv("BPR1CS_FOLD_FUNCTOR") != nullptr;  // measurement knob
-                if (B < 32 || fold_functor) {
+                if (B < 32) {
                     launch_wave((uint64_t)2 * M * B, K_ipa_fold_from_tables{g->tab.p, g->tc, cG, cH, GH.p, B, M, N, baseG, baseH}, st);
                 } else {
                     // the folded generators through the MSM kernel: output j of a side = the "chunk" of terms i = j (mod M), two
@@ -866,8 +864,7 @@ static void enqueue_ipa(const IpaIO& io, dev_stream_t st, MsmStats* stats) {
                 linv.alloc((size_t)2 * B);
                 launch((uint64_t)2 * B, K_set_one{linv.p}, st);
             }
-            static const bool vbwin_plain = getenv("BPR1CS_VBWIN_PLAIN") != nullptr;  // measurement knob: window-major order
-            const uint32_t remap = vbwin_plain ? 0u : 1u;
+            const uint32_t remap = 1u;  // XCD-aware workgroup order of the window sums (vb_win_index; +1 % end to end)
             if (!vb_reuse) {
                 // multiples 1P..8P and digits of every term of this round
                 const uint32_t vc = 2 * mk < VC ? 2 * mk : VC;  // chunks of the 2*mk terms of one output
@@ -1177,16 +1174,10 @@ extern "C" int bpr1cs_prove_batch_begin(const bpr1cs_gens* g, const bpr1cs_circu
             // constant point of the circuit and the sum only carries (a_O - 1) for them - zero, and skipped by the kernel, in all
             // but exceptional proofs: 608 real terms instead of 18 656 for the depth-32 circuit
             MsmSeg oRest{aO, nr, 1, 1, 0, baseG, MSM_MONT, c->rest.p, 0}, oOnes{aO, 2 * T3, 1, 1, 0, baseG, MSM_MINUS_ONE, c->ones.p, 0};
-            static const bool ao_plain = getenv("BPR1CS_AO_PLAIN") != nullptr;  // measurement knob: the full n-term sum
-            if (ao_plain) {
-                MsmReq rq[3] = {{rG, rH, &partial, &plan, nullptr}, {mG, mH, &partial2, &plan2, mtab}, {seg(aO, baseG), none, &partialO, &planO, nullptr}};
-                run_msm_multi(g, rq, 3, B, st, stats);
-                ones_pt = nullptr;
-            } else {
-                MsmReq rq[4] = {{rG, rH, &partial, &plan, nullptr}, {mG, mH, &partial2, &plan2, mtab}, {oRest, none, &partialO, &planO, nullptr},
-                                {oOnes, none, &partialO1, &planO1, nullptr, 256}};
-                run_msm_multi(g, rq, 4, B, st, stats);  // the sums that need the wires only share one launch
-            }
+            // (measured against the plain n-term sum on one box: first launch of a batch 27 -> 13.5 ms)
+            MsmReq rq[4] = {{rG, rH, &partial, &plan, nullptr}, {mG, mH, &partial2, &plan2, mtab}, {oRest, none, &partialO, &planO, nullptr},
+                            {oOnes, none, &partialO1, &planO1, nullptr, 256}};
+            run_msm_multi(g, rq, 4, B, st, stats);  // the sums that need the wires only share one launch
             finI.partial = partial.p;
             finI.nchunks = plan.nchunks;
             finI.partial_b = partial2.p;
