@@ -134,7 +134,8 @@ __global__ void __launch_bounds__(64) k_poseidon_team(K_poseidon_batch p, uint32
 __device__ inline void lds_order() { __syncthreads(); }  // one wavefront per workgroup: lgkmcnt(0) + s_barrier
 __global__ void __launch_bounds__(64) k_rng_stream(const strobe* rng_in, uint64_t* raw_out, int* err, uint32_t B, uint32_t draws) {
     __builtin_amdgcn_s_setprio(3);  // one long dependent chain per state: take every issue slot it can use
-    __shared__ uint64_t xch[2][2][32];  // [buffer][half][lane]
+    __shared__ uint64_t xch[2][32];      // [half][lane]: rho(theta(A)) for the pi/chi gather
+    __shared__ uint64_t colp[2][8];      // [half][x]: column parities, accumulated by LDS atomics
     const uint32_t lane = threadIdx.x, i = lane & 31u, half = lane >> 5;
     uint32_t b = blockIdx.x * 2u + half;
     const bool valid = b < B;
@@ -157,8 +158,11 @@ __global__ void __launch_bounds__(64) k_rng_stream(const strobe* rng_in, uint64_
     const uint32_t s0 = (x + 3u * y) % 5u + 5u * x;
     const uint32_t x1 = (x + 1u) % 5u, x2 = (x + 2u) % 5u;
     const uint32_t s1 = (x1 + 3u * y) % 5u + 5u * x1, s2 = (x2 + 3u * y) % 5u + 5u * x2;
-    uint64_t* A0 = xch[0][half];
-    uint64_t* A1 = xch[1][half];
+    uint64_t* A1 = xch[half];
+    uint64_t* C = colp[half];
+    // lanes 25..31 of a half mirror lanes 0..6 (j = i % 25): they must not add their copy to the parities
+    const bool real = i < 25u;
+    if (i < 8u) C[i] = 0;
 #define LO(v) ((uint32_t)(v))
 #define HI(v) ((uint32_t)((v) >> 32))
     for (uint32_t d = 0; d < draws; d++) {
@@ -168,14 +172,16 @@ __global__ void __launch_bounds__(64) k_rng_stream(const strobe* rng_in, uint64_
         if (j == 20) a ^= 0x8000000000000000ull;
 #pragma unroll
         for (int r = 0; r < 24; r++) {  // fully unrolled: the round constants become immediates (no s_load per round)
-            A0[i] = a;
-            lds_order();
-            uint64_t m0 = A0[xm], m1 = A0[xm + 5], m2 = A0[xm + 10], m3 = A0[xm + 15], m4 = A0[xm + 20];
-            uint64_t p0 = A0[xp], p1 = A0[xp + 5], p2 = A0[xp + 10], p3 = A0[xp + 15], p4 = A0[xp + 20];
-            uint32_t ml = K_XOR3(K_XOR3(LO(m0), LO(m1), LO(m2)), LO(m3), LO(m4)), mh = K_XOR3(K_XOR3(HI(m0), HI(m1), HI(m2)), HI(m3), HI(m4));
-            uint32_t pl = K_XOR3(K_XOR3(LO(p0), LO(p1), LO(p2)), LO(p3), LO(p4)), ph = K_XOR3(K_XOR3(HI(p0), HI(p1), HI(p2)), HI(p3), HI(p4));
-            uint32_t tl = K_XOR3(LO(a), ml, __builtin_amdgcn_alignbit(pl, ph, 31));   // theta: a ^ C[x-1] ^ rol(C[x+1], 1)
-            uint32_t th = K_XOR3(HI(a), mh, __builtin_amdgcn_alignbit(ph, pl, 31));
+            // theta's column parities by the LDS atomic unit (ds_xor_b64, no return value): no VALU work at all, and two reads
+            // instead of ten.  One wavefront per workgroup: its LDS operations execute in issue order, so the reads see every
+            // lane's contribution and the clearing store lands before the next round's atomics.
+            if (real) __hip_atomic_fetch_xor(&C[x], a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            uint64_t m = C[xm], p = C[xp];
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            if (y == 0u) C[x] = 0;
+            uint32_t tl = K_XOR3(LO(a), LO(m), __builtin_amdgcn_alignbit(LO(p), HI(p), 31));   // theta: a ^ C[x-1] ^ rol(C[x+1], 1)
+            uint32_t th = K_XOR3(HI(a), HI(m), __builtin_amdgcn_alignbit(HI(p), LO(p), 31));
             uint32_t ul = rot_swap ? th : tl, uh = rot_swap ? tl : th;             // rho
             uint32_t nl = __builtin_amdgcn_alignbit(ul, uh, rot_k), nh = __builtin_amdgcn_alignbit(uh, ul, rot_k);
             A1[i] = ((uint64_t)nh << 32) | nl;
@@ -185,6 +191,7 @@ __global__ void __launch_bounds__(64) k_rng_stream(const strobe* rng_in, uint64_
             cl = __builtin_amdgcn_bitop3_b32(cl, (uint32_t)KECCAK_RC[r], iota_mask, 0x78);          // iota: a ^ (RC & lane-0 mask)
             ch = __builtin_amdgcn_bitop3_b32(ch, (uint32_t)(KECCAK_RC[r] >> 32), iota_mask, 0x78);
             a = ((uint64_t)ch << 32) | cl;
+            lds_order();   // every lane has gathered before A1 is overwritten
         }
         if (i < 8) {
             if (valid) raw_out[((size_t)d * B + b) * 8 + i] = a;
