@@ -176,22 +176,20 @@ __global__ void __launch_bounds__(64) k_rng_stream(const strobe* rng_in, uint64_
             // instead of ten.  One wavefront per workgroup: its LDS operations execute in issue order, so the reads see every
             // lane's contribution and the clearing store lands before the next round's atomics.
             if (real) __hip_atomic_fetch_xor(&C[x], a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            uint64_t m = C[xm], p = C[xp];
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            uint64_t m = C[xm], p = C[xp];   // (may alias the atomic's address: the compiler keeps the order too)
             if (y == 0u) C[x] = 0;
             uint32_t tl = K_XOR3(LO(a), LO(m), __builtin_amdgcn_alignbit(LO(p), HI(p), 31));   // theta: a ^ C[x-1] ^ rol(C[x+1], 1)
             uint32_t th = K_XOR3(HI(a), HI(m), __builtin_amdgcn_alignbit(HI(p), LO(p), 31));
             uint32_t ul = rot_swap ? th : tl, uh = rot_swap ? tl : th;             // rho
             uint32_t nl = __builtin_amdgcn_alignbit(ul, uh, rot_k), nh = __builtin_amdgcn_alignbit(uh, ul, rot_k);
             A1[i] = ((uint64_t)nh << 32) | nl;
-            lds_order();
+            __builtin_amdgcn_wave_barrier();   // one wavefront, LDS operations complete in issue order: no wait between the store and the gathers
             uint64_t b0 = A1[s0], b1 = A1[s1], b2 = A1[s2];                         // pi
             uint32_t cl = K_CHI(LO(b0), LO(b1), LO(b2)), ch = K_CHI(HI(b0), HI(b1), HI(b2));  // chi
             cl = __builtin_amdgcn_bitop3_b32(cl, (uint32_t)KECCAK_RC[r], iota_mask, 0x78);          // iota: a ^ (RC & lane-0 mask)
             ch = __builtin_amdgcn_bitop3_b32(ch, (uint32_t)(KECCAK_RC[r] >> 32), iota_mask, 0x78);
             a = ((uint64_t)ch << 32) | cl;
-            lds_order();   // every lane has gathered before A1 is overwritten
+            __builtin_amdgcn_wave_barrier();   // (the gathers were issued before the next round's store: in-order LDS)
         }
         if (i < 8) {
             if (valid) raw_out[((size_t)d * B + b) * 8 + i] = a;
