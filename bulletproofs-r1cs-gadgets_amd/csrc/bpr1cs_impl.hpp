@@ -779,7 +779,8 @@ struct IpaIO {
     uint8_t* LR;     // out [lgN][2][B][32]
     sc* uk;          // out [lgN][2][B]: u_k, u_k^-1
     // optional (the R1CS prover's padding, see K_range_sum_points): in round 0 the H-terms hs_from <= i < N/2 of L_0 all carry
-    // the scalar hs_scal[b]; their generators' sum has its own one-base table
+    // the scalar hs_scal[b]; their generators' sum has its own one-base table.  Setting it also promises a[i] = 0 for
+    // i >= N/2 + hs_from (the same padding on the l side): R_0's G-terms there are not visited
     const uint8_t* hs_tab = nullptr;
     const sc* hs_scal = nullptr;  // [B] Montgomery
     uint32_t hs_from = 0;
@@ -821,11 +822,13 @@ static void enqueue_ipa(const IpaIO& io, dev_stream_t st, MsmStats* stats) {
             // L: G-terms with pos >= m, H-terms with pos < m ; R: the complement
             MsmSeg gL{sG.p, half, mk, Nk, mk, baseG, 0}, hL{sH.p, half, mk, Nk, 0, baseH, 0};
             MsmSeg gR{sG.p, half, mk, Nk, 0, baseG, 0}, hR{sH.p, half, mk, Nk, mk, baseH, 0};
-            // (round 0: the prover's l(x) is zero beyond n, so 14 112 of the 65 536 scalars vanish in every proof; the kernel skips
-            // terms whose scalars are zero in a whole wavefront.  Leaving them out of the segments instead measured 5 % SLOWER
-            // for that launch - smaller, differently sized chunks - and was dropped.)
+            // (round 0 of the R1CS prover: l(x) is zero and r(x) is -y^i beyond n, so of the 65 536 terms 14 112 G-terms of R_0
+            // vanish and 14 112 H-terms of L_0 share one scalar: both blocks are left out of the segments - 50 -> 36 ms for the launch)
             const bool hs = k == 0 && io.hs_tab && io.hs_from < mk;
-            if (hs) hL.count = io.hs_from;  // the block hs_from <= i < N/2 enters through its summed generator
+            if (hs) {
+                hL.count = io.hs_from;  // the block hs_from <= i < N/2 enters through its summed generator
+                gR.count = io.hs_from;  // a is zero beyond N/2 + hs_from (the same padding): R_0 has no G-terms there
+            }
             MsmPlan planR;
             MsmReq rq[2] = {{gL, hL, &partial, &plan, nullptr}, {gR, hR, &partialR, &planR, nullptr}};
             run_msm_multi(g, rq, 2, B, st, stats);  // L_k and R_k share one launch
