@@ -20,7 +20,7 @@ VAR_COMMITTED, VAR_MUL_LEFT, VAR_MUL_RIGHT, VAR_MUL_OUT, VAR_ONE = 0, 1, 2, 3, 4
 W_LC, W_INV_LEFT, W_BIT, W_NOTBIT = 0, 1, 2, 3
 
 ERRORS = {0: "OK", -1: "InvalidGeneratorsLength", -2: "FormatError", -3: "VerificationError",
-          -4: "MissingAssignment", -5: "GadgetError", -16: "NoDevice", -17: "InvalidArgument"}
+          -4: "MissingAssignment", -5: "GadgetError", -16: "NoDevice", -17: "InvalidArgument", -18: "DeviceError", -19: "OutOfMemory"}
 
 
 class R1CSError(RuntimeError):

@@ -1011,7 +1011,7 @@ extern "C" int bpr1cs_prove_batch_begin(const bpr1cs_gens* g, const bpr1cs_circu
     job = new bpr1cs_job();
     job->g = g;
     uint32_t slot = g->next_job++ & 1u;
-    job->st = g->jstream[0][0];  // ONE heavy stream: MSM/IPA phases of successive jobs run back to back (FIFO)
+    job->st = g->jstream[0][0];  // ONE heavy stream: MSM/IPA phases of successive jobs run back to back (FIFO; a heavy stream per job measured 3.4 % slower)
     job->st2 = g->jstream[slot][1];
     job->st3 = g->jstream[slot][2];
     Scope scope(job);
