@@ -810,7 +810,7 @@ static void enqueue_ipa(const IpaIO& io, dev_stream_t st, MsmStats* stats) {
     };
     for (uint32_t k = 0; k < lgN; k++) {
         uint32_t Nk = N >> k, mk = Nk >> 1;
-        uint32_t cchunk, CC = pick_chunks(mk, B, 1u << 16, cchunk);
+        uint32_t cchunk, CC = pick_chunks(mk, B, 1u << 18, cchunk);
         if (cpart.n < (size_t)2 * CC * B) cpart.alloc((size_t)2 * CC * B);
         launch((uint64_t)CC * B, K_ipa_cross{a, bb, cpart.p, B, mk, cchunk, CC}, st);
         launch((uint64_t)2 * B, K_sum_partials{cpart.p, cross.p, B, CC}, st);
@@ -1213,7 +1213,8 @@ extern "C" int bpr1cs_prove_batch_begin(const bpr1cs_gens* g, const bpr1cs_circu
     launch((uint64_t)3 * B, K_pow_tables{chal.p, plo.p, phi.p, B, H}, st);
     DevBuf<sc> wvec((size_t)(3 * n + m) * B + 1);
     run_flatten(c, 3 * n + m, plo.p, phi.p, wvec.p, B, H, st);
-    uint32_t tchunk, TC = pick_chunks(n, B, 1u << 16, tchunk);
+    // 4 wavefronts per SIMD: with one (2^16 threads) the kernel is latency bound and a co-running front kernel doubles its time (9 -> 4 ms)
+    uint32_t tchunk, TC = pick_chunks(n, B, 1u << 18, tchunk);
     DevBuf<sc> tpart((size_t)6 * TC * B), tco((size_t)6 * B);
     launch((uint64_t)TC * B, K_tcoef_partial{W.p, wvec.p, plo.p, phi.p, tpart.p, B, H, n, tchunk, TC}, st);
     launch((uint64_t)6 * B, K_sum_partials{tpart.p, tco.p, B, TC}, st);
