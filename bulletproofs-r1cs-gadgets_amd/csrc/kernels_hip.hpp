@@ -119,14 +119,16 @@ __global__ void __launch_bounds__(64) k_poseidon_team(K_poseidon_batch p, uint32
 // The 2n+8 blinding draws of a proof are a strictly sequential chain of Keccak-f[1600]
 // permutations (STROBE prf, one permutation per 64-byte draw: SURVEY §8a P6), 37k of them for
 // the depth-32 VSMT circuit.  One Keccak state is spread over 25 lanes of a half-wavefront
-// (lane = x + 5y holds A[x][y]); theta/pi/chi become cross-lane pulls, two dependent exchange
-// stages per round.  Two proofs per wavefront, one wavefront per workgroup.
-// Raw 64-byte outputs go to HBM; the wide reduction mod l is done afterwards by K_rng_reduce
-// for all draws in parallel (it is not part of the sequential chain).
+// (lane = x + 5y holds A[x][y]); two dependent LDS stages per round: (1) theta's column parities are
+// accumulated by the LDS atomic unit (ds_xor_b64 without return: no VALU work, each lane then reads the
+// two parities it needs), (2) pi/chi gather the rotated lanes.  Two proofs per wavefront, one wavefront
+// per workgroup.  Raw 64-byte outputs go to HBM; the wide reduction mod l is done afterwards by
+// K_rng_reduce for all draws in parallel (it is not part of the sequential chain).
 // Cross-lane exchange goes through LDS (ds_write_b64 / ds_read_b64: 8 bytes per lane per
 // instruction, 256 B/clk) instead of ds_bpermute_b32 (4 bytes, crossbar): measured 3.3x faster per round.
-// A wavefront's DS operations are executed in order, so a lane's read issued after the wave's write sees
-// the new data; the fences below only stop the compiler from reordering.
+// A wavefront's DS operations are executed in order, so a lane's read issued after the wave's write (or
+// atomic) sees the new data WITHOUT waiting in between: the kernel has two s_waitcnt per round, for the
+// two values-needed-now points, and wave barriers that only stop the compiler from reordering.
 // ---- Keccak-f[1600] on 32-bit halves with the gfx950 three-input logic op (v_bitop3_b32: one instruction for
 // a^b^c and for a^(~b&c)) and v_alignbit_b32 funnel shifts: 180 VALU instructions per round instead of ~330.
 #define K_XOR3(a, b, c) __builtin_amdgcn_bitop3_b32((a), (b), (c), 0x96)
