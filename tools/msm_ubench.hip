@@ -50,11 +50,13 @@ int main(int argc, char** argv) {
     // 2: digit = 1 + proof index in every window of every term (the 16 wavefronts of a chunk stream each row once, 8 KB per wavefront)
     // 3: a random digit per (term, proof) inside the wavefront's own 64-slot (8 KB) block of the row, same in every window
     // 4: a random digit per (term, proof) anywhere in the row, same in every window (control for 2 and 3)
-    if (pattern >= 2 && pattern <= 4) {
+    // 6: a random digit in [1, 64] per (term, proof), same in every window: the 16 wavefronts sharing a row all gather from its first
+    //    8 KB - a tenth of the HBM traffic of pattern 4 with the SAME number of distinct cache lines per load instruction
+    if ((pattern >= 2 && pattern <= 4) || pattern == 6) {
         const uint32_t slots = 1u << (W - 1);
         for (size_t i = 0; i < hs.size(); i++) {
             uint32_t b = (uint32_t)(i % B), r = (uint32_t)rnd64();
-            uint32_t d = pattern == 2 ? (b % slots) : pattern == 3 ? ((b / 64 * 64) % slots + r % 64) : r % slots;
+            uint32_t d = pattern == 2 ? (b % slots) : pattern == 3 ? ((b / 64 * 64) % slots + r % 64) : pattern == 6 ? r % 64 : r % slots;
             sc v = sc_zero();
             for (uint32_t k = 0; k * W < 253; k++) {
                 uint64_t dk = 1 + ((k + 1) * W >= 253 ? d % (slots / 2) : d);
