@@ -105,6 +105,10 @@ def check_validation(lib):
     h = ctypes.c_void_p()
     assert lib.bpr1cs_circuit_create(ctypes.byref(good), ctypes.byref(h)) == 0
     lib.bpr1cs_circuit_destroy(h)
+    # a witness program may read any of the 256 bits of a committed value (the depth-128 tree of the reference takes 2 x 128)
+    top_bit, _k2 = _raw_desc(2, 1, 2, [0, 1], [V(1, 0)], [(2, 255, 0, 1), (0, 2, 1, 0)], ok_off, ok_var)
+    assert lib.bpr1cs_circuit_create(ctypes.byref(top_bit), ctypes.byref(h)) == 0
+    lib.bpr1cs_circuit_destroy(h)
     cases = {
         "constraint term: wire index >= n": _raw_desc(2, 1, 2, [0, 1], [V(1, 2)]),
         "constraint term: committed index >= m": _raw_desc(2, 1, 2, [0, 1], [V(0, 2)]),
