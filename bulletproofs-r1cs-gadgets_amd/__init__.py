@@ -488,6 +488,7 @@ def load_gadgets_library(path=None):
     g.bpr1cs_mimc.argtypes = [cp, cp, cp, sz, cp]
     for nm in ("vsmt4", "vsmt2"):
         getattr(g, "bpr1cs_%s_new" % nm).argtypes = [u32, u32, cp, sz, ctypes.POINTER(vp)]
+        getattr(g, "bpr1cs_%s_new_sbox" % nm).argtypes = [u32, u32, ctypes.c_int, cp, sz, ctypes.POINTER(vp)]
         getattr(g, "bpr1cs_%s_free" % nm).argtypes = [vp]
         getattr(g, "bpr1cs_%s_root" % nm).argtypes = [vp, cp]
         getattr(g, "bpr1cs_%s_update" % nm).argtypes = [vp, cp, cp]
@@ -571,13 +572,14 @@ def poseidon_hash(arity, inverse, partial_rounds, inputs, glib=None):
 class SparseMerkleTree:
     """VanillaSparseMerkleTree_4 (arity 4) / VanillaSparseMerkleTree (arity 2) of the reference."""
 
-    def __init__(self, arity, levels, partial_rounds=140, glib=None):
+    def __init__(self, arity, levels, partial_rounds=140, glib=None, inverse=True):
+        """inverse=False: the tree over Poseidon with the Cube S-box (the reference hard-wires Inverse)"""
         self.g = glib or load_gadgets_library()
         self.nm = "vsmt4" if arity == 4 else "vsmt2"
         self.arity, self.levels = arity, levels
         blob = poseidon_blob()
         h = ctypes.c_void_p()
-        _chk(getattr(self.g, "bpr1cs_%s_new" % self.nm)(levels, partial_rounds, blob, len(blob), ctypes.byref(h)))
+        _chk(getattr(self.g, "bpr1cs_%s_new_sbox" % self.nm)(levels, partial_rounds, 1 if inverse else 0, blob, len(blob), ctypes.byref(h)))
         self.h = h
 
     def root(self):

@@ -509,10 +509,10 @@ int bpr1cs_circuit_create(const bpr1cs_circuit_desc* d, bpr1cs_circuit** out) {
                 for (uint32_t i = 0; i < t.width && ok; i++) {
                     pm.in_lc[i] = pp.in_lc[i];
                     if (pp.in_lc[i] >= d->n_lc) { ok = false; break; }
-                    for (uint32_t tt = lo[pp.in_lc[i]]; tt < lo[pp.in_lc[i] + 1]; tt++) {  // inputs must be known by then
-                        uint32_t vk = lv[tt] >> 28, vi = lv[tt] & 0x0fffffffu;
-                        if (vk >= VK_LEFT && vk <= VK_OUT && vi >= pm.first_mul) ok = false;
-                    }
+                    // every term of an input combination is checked like a wop operand (kind, committed index < m, wires of
+                    // multipliers BEFORE the permutation's first one): an annotation no wop refers to must not reach the device unchecked
+                    for (uint32_t tt = lo[pp.in_lc[i]]; tt < lo[pp.in_lc[i] + 1]; tt++)
+                        if (!var_ok(lv[tt], std::min(pm.first_mul, d->n))) { delete c; return BPR1CS_ERR_INVALID_ARGUMENT; }
                 }
                 for (uint32_t sidx = 0; sidx < S && ok; sidx++) {
                     uint32_t mi = pp.sbox_mul[sidx];
@@ -658,6 +658,29 @@ struct MsmStats {
 // sums share one launch (k_msm_fixed2).  The chunk partials are folded `MSM_REDUCE_GROUP` at a time (twice when
 // there are many) before the per-proof finish kernel, which then adds at most MSM_REDUCE_GROUP points.
 static const uint32_t MSM_REDUCE_GROUP = 16;
+#if !defined(BPR1CS_HOSTSIM)
+// one launch of the dominant kernel, HIP-event timed on its own stream when `stats` is given; `terms` = scalar*point
+// products of the launch summed over the batch (every launch of k_msm_fixed2 goes through here, so that bench.py's roofline
+// object describes the whole kernel: the commit sums, L_k / R_k of the un-folded rounds AND the folded generators)
+static void launch_msm_kernel(const bpr1cs_gens* g, MsmLaunch& L, dev_stream_t st, MsmStats* stats, uint64_t terms) {
+    hipEvent_t e0{}, e1{};
+    if (stats) {
+        e0 = stats->get(); e1 = stats->get();
+        stats->ev.push_back({e0, e1});
+        HIPCHK(hipEventRecord(e0, st));
+    }
+    L.nwg = (L.wg_end[L.njobs - 1] + 7u) & ~7u;  // a multiple of 8 keeps the XCD-aware remap on
+    const size_t lds = (size_t)2 * g->tc.windows * 64 * sizeof(uint16_t);
+    if (g->tc.fmt == TAB_FMT_PACKED) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_msm_fixed2<(int)TAB_FMT_PACKED, 3>), dim3(L.nwg), dim3(64), lds, st, L);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_msm_fixed2<(int)TAB_FMT_LIMB, 3>), dim3(L.nwg), dim3(64), lds, st, L);
+    HIPCHK(hipGetLastError());
+    if (stats) {
+        HIPCHK(hipEventRecord(e1, st));
+        stats->launches++;
+        stats->terms += terms;
+    }
+}
+#endif
 struct MsmReq {
     MsmSeg s0, s1;
     DevBuf<ge>* partial;  // out: the reduced partial sums sit at the front, [plan->nchunks][B]
@@ -725,27 +748,14 @@ static void run_msm_multi(const bpr1cs_gens* g, MsmReq* reqs, uint32_t nreq, uin
         K_msm_fixed k{q.table ? q.table : g->tab.p, g->tc, {q.s0, q.s1}, lay[r].raw, B, q.plan->chunk, nbk, lay[r].nchunks * nbk};
         launch_wave((uint64_t)lay[r].nchunks * nbk * 64u, k, st);
     }
+    if (stats) { stats->launches++; stats->terms += terms; }
+    (void)wg;
 #else
-    hipEvent_t e0{}, e1{};
-    if (stats) {
-        e0 = stats->get(); e1 = stats->get();
-        stats->ev.push_back({e0, e1});
-        HIPCHK(hipEventRecord(e0, st));
-    }
-    L.nwg = (wg + 7u) & ~7u;  // a multiple of 8 keeps the XCD-aware remap on
-    const size_t lds = (size_t)2 * g->tc.windows * 64 * sizeof(uint16_t);
-    if (g->tc.fmt == TAB_FMT_PACKED) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_msm_fixed2<(int)TAB_FMT_PACKED, 3>), dim3(L.nwg), dim3(64), lds, st, L);
-    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_msm_fixed2<(int)TAB_FMT_LIMB, 3>), dim3(L.nwg), dim3(64), lds, st, L);
-    HIPCHK(hipGetLastError());
-    if (stats) HIPCHK(hipEventRecord(e1, st));
+    launch_msm_kernel(g, L, st, stats, terms);
 #endif
     for (uint32_t r = 0; r < nreq; r++) {
         if (lay[r].l1) launch((uint64_t)lay[r].l1 * B, K_ge_reduce{lay[r].raw, lay[r].p1, B, lay[r].nchunks, MSM_REDUCE_GROUP}, st);
         if (lay[r].l2) launch((uint64_t)lay[r].l2 * B, K_ge_reduce{lay[r].p1, lay[r].p2, B, lay[r].l1, MSM_REDUCE_GROUP}, st);
-    }
-    if (stats) {
-        stats->launches++;
-        stats->terms += terms;
     }
 }
 static void run_msm(const bpr1cs_gens* g, MsmSeg s0, MsmSeg s1, uint32_t B, DevBuf<ge>& partial, MsmPlan& plan, dev_stream_t st,
@@ -852,11 +862,7 @@ static void enqueue_ipa(const IpaIO& io, dev_stream_t st, MsmStats* stats) {
                     L.job[0] = MsmJob{{MsmSeg{cG, N, N, N, 0, baseG, 1}, none}, g->tab.p, GH.p, N / M, M, 1};
                     L.job[1] = MsmJob{{MsmSeg{cH, N, N, N, 0, baseH, 1}, none}, g->tab.p, GH.p + (size_t)M * B, N / M, M, 1};
                     L.wg_end[0] = M * L.nbk; L.wg_end[1] = 2 * M * L.nbk;
-                    L.nwg = (L.wg_end[1] + 7u) & ~7u;
-                    const size_t lds = (size_t)2 * g->tc.windows * 64 * sizeof(uint16_t);
-                    if (g->tc.fmt == TAB_FMT_PACKED) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_msm_fixed2<(int)TAB_FMT_PACKED, 3>), dim3(L.nwg), dim3(64), lds, st, L);
-                    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_msm_fixed2<(int)TAB_FMT_LIMB, 3>), dim3(L.nwg), dim3(64), lds, st, L);
-                    HIPCHK(hipGetLastError());
+                    launch_msm_kernel(g, L, st, stats, (uint64_t)2 * N * B);
                 }
 #endif
                 vtab.alloc((size_t)VB_MULT * 4 * (M / 2 ? M / 2 : 1) * B);
@@ -1238,12 +1244,12 @@ extern "C" int bpr1cs_prove_batch_begin(const bpr1cs_gens* g, const bpr1cs_circu
         bpr1cs_circuit::MergedTab*& mt = c->mt[g];
         if (!mt) mt = new bpr1cs_circuit::MergedTab();
         if (!mt->hs_tab.p || mt->hs_W != g->tc.W || mt->hs_cap != g->cap || mt->hs_fmt != g->tc.fmt) {
-            mt->hs_W = g->tc.W; mt->hs_cap = g->cap; mt->hs_fmt = g->tc.fmt;
             DevBuf<ge> part64(64), hsum(1);
             launch(64, K_range_sum_points{g->pts.p, part64.p, baseH + (n - N / 2), baseH + N / 2}, st);
             launch(1, K_ge_reduce{part64.p, hsum.p, 1, 64, 64}, st);
             mt->hs_tab.alloc(g->tc.base_bytes());
             launch(g->tc.windows, K_build_table{hsum.p, mt->hs_tab.p, g->tc}, st);
+            mt->hs_W = g->tc.W; mt->hs_cap = g->cap; mt->hs_fmt = g->tc.fmt;  // only once allocation and launches went through
         }
         hs_scal.alloc(B);
         launch(B, K_neg_ypow{plo.p, phi.p, hs_scal.p, B, H, N / 2}, st);

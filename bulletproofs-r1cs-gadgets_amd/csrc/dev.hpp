@@ -179,9 +179,12 @@ struct DevBuf {
     DevBuf& operator=(const DevBuf&) = delete;
     ~DevBuf() { dev_free(p); }
     void alloc(size_t count) {
-        dev_free(p);
-        n = count;
+        T* old = p;  // dev_alloc may throw (out of memory): never keep a pointer that has already gone back to the pool
+        p = nullptr;
+        n = 0;
+        dev_free(old);
         p = (T*)dev_alloc(count * sizeof(T));
+        n = count;
     }
     size_t bytes() const { return n * sizeof(T); }
 };

@@ -1436,7 +1436,9 @@ struct K_verify_transcript {  // gid = b
             uk[((size_t)k * 2 + 1) * B + b] = sc_invert(uu);
         }
         if (bind) {  // 32 bytes that depend on every byte of this proof and of its commitments (cross-proof batching)
-            strobe t = s;
+            strobe t = s;  // the proof's own transcript never absorbs the two final IPA scalars: the clone does, so the weights bind them too
+            merlin_append(t, "ipp_a", 5, el + (11 + 2 * lgN) * 32, 32);
+            merlin_append(t, "ipp_b", 5, el + (12 + 2 * lgN) * 32, 32);
             merlin_challenge_bytes(t, "bpr1cs-bind", 11, bind + 32 * (size_t)b, 32);
         }
         // verifier's TranscriptRng: no witness, external 32 bytes made explicit

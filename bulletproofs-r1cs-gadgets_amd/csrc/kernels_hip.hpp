@@ -134,6 +134,13 @@ __global__ void __launch_bounds__(64) k_poseidon_team(K_poseidon_batch p, uint32
 #define K_XOR3(a, b, c) __builtin_amdgcn_bitop3_b32((a), (b), (c), 0x96)
 #define K_CHI(a, b, c) __builtin_amdgcn_bitop3_b32((a), (b), (c), 0xd2)  // a ^ (~b & c)
 __device__ inline void lds_order() { __syncthreads(); }  // one wavefront per workgroup: lgkmcnt(0) + s_barrier
+// Hand-off of LDS data between the lanes of ONE wavefront (one wavefront per workgroup).  The hardware executes a
+// wavefront's DS operations in issue order, so no s_waitcnt is needed between a lane's store / atomic and another
+// lane's load of the same address; what the language still needs is that the COMPILER keeps that order: a
+// sequentially consistent signal fence (no instruction) forbids moving any memory access across it, the wave
+// barrier pins the convergence point.  tests/test_gpu_parity.py::test_rng_chain_mappings_agree stays the gate that the
+// blinding stream is byte-identical for every compiler version.
+#define LDS_HANDOFF() do { __atomic_signal_fence(__ATOMIC_SEQ_CST); __builtin_amdgcn_wave_barrier(); __atomic_signal_fence(__ATOMIC_SEQ_CST); } while (0)
 __global__ void __launch_bounds__(64) k_rng_stream(const strobe* rng_in, uint64_t* raw_out, int* err, uint32_t B, uint32_t draws) {
     __builtin_amdgcn_s_setprio(3);  // one long dependent chain per state: take every issue slot it can use
     __shared__ uint64_t xch[2][32];      // [half][lane]: rho(theta(A)) for the pi/chi gather
@@ -178,20 +185,22 @@ __global__ void __launch_bounds__(64) k_rng_stream(const strobe* rng_in, uint64_
             // instead of ten.  One wavefront per workgroup: its LDS operations execute in issue order, so the reads see every
             // lane's contribution and the clearing store lands before the next round's atomics.
             if (real) __hip_atomic_fetch_xor(&C[x], a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            uint64_t m = C[xm], p = C[xp];   // (may alias the atomic's address: the compiler keeps the order too)
+            LDS_HANDOFF();   // the other lanes' atomics are read next: compiler-level fence, no wait (in-order LDS)
+            uint64_t m = C[xm], p = C[xp];
+            LDS_HANDOFF();   // ... and cleared only after every lane has read them
             if (y == 0u) C[x] = 0;
             uint32_t tl = K_XOR3(LO(a), LO(m), __builtin_amdgcn_alignbit(LO(p), HI(p), 31));   // theta: a ^ C[x-1] ^ rol(C[x+1], 1)
             uint32_t th = K_XOR3(HI(a), HI(m), __builtin_amdgcn_alignbit(HI(p), LO(p), 31));
             uint32_t ul = rot_swap ? th : tl, uh = rot_swap ? tl : th;             // rho
             uint32_t nl = __builtin_amdgcn_alignbit(ul, uh, rot_k), nh = __builtin_amdgcn_alignbit(uh, ul, rot_k);
             A1[i] = ((uint64_t)nh << 32) | nl;
-            __builtin_amdgcn_wave_barrier();   // one wavefront, LDS operations complete in issue order: no wait between the store and the gathers
+            LDS_HANDOFF();   // one wavefront, LDS operations complete in issue order: no wait between the store and the gathers
             uint64_t b0 = A1[s0], b1 = A1[s1], b2 = A1[s2];                         // pi
             uint32_t cl = K_CHI(LO(b0), LO(b1), LO(b2)), ch = K_CHI(HI(b0), HI(b1), HI(b2));  // chi
             cl = __builtin_amdgcn_bitop3_b32(cl, (uint32_t)KECCAK_RC[r], iota_mask, 0x78);          // iota: a ^ (RC & lane-0 mask)
             ch = __builtin_amdgcn_bitop3_b32(ch, (uint32_t)(KECCAK_RC[r] >> 32), iota_mask, 0x78);
             a = ((uint64_t)ch << 32) | cl;
-            __builtin_amdgcn_wave_barrier();   // (the gathers were issued before the next round's store: in-order LDS)
+            LDS_HANDOFF();   // (the gathers were issued before the next round's store: in-order LDS)
         }
         if (i < 8) {
             if (valid) raw_out[((size_t)d * B + b) * 8 + i] = a;

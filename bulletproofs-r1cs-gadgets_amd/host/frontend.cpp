@@ -302,17 +302,20 @@ static size_t run_gadget(const GadgetSpec& g, Harness& h) {
         Poseidon_permutation_gadget(h.cs, in, params, sbox, out);
         return 6;
     }
-    if (g.name == "vsmt_4") {  // src/gadget_vsmt_4.rs:363-440 ; ip = [levels, partial_rounds], sp = [root]
+    // trees: optional third ip = S-box of the tree's Poseidon (1 / absent: Inverse as the reference hard-wires it,
+    // gadget_vsmt_4.rs:301, gadget_vsmt_2.rs:203; 0: Cube)
+    auto tree_sbox = [&]() { return (g.ip.size() > 2 && g.ip[2] == 0) ? SboxType::Cube : SboxType::Inverse; };
+    if (g.name == "vsmt_4") {  // src/gadget_vsmt_4.rs:363-440 ; ip = [levels, partial_rounds(, sbox)], sp = [root]
         size_t levels = g.ip.at(0);
         PoseidonParams params(6, 4, 4, g.ip.at(1), g.blob, g.blob_len);
         auto leaf = AS(0), idx = AS(1);
         std::vector<AllocatedScalar> nodes;
         for (size_t i = 0; i < 3 * levels; i++) nodes.push_back(AS(2 + i));
         auto st = statics_from(2 + 3 * levels, 2);
-        vanilla_merkle_merkle_tree_4_verif_gadget(h.cs, levels, g.sp.at(0), leaf, idx, nodes, st, params, levels / 4);
+        vanilla_merkle_merkle_tree_4_verif_gadget(h.cs, levels, g.sp.at(0), leaf, idx, nodes, st, params, levels / 4, tree_sbox());
         return 4 + 3 * levels;
     }
-    if (g.name == "vsmt_2") {  // src/gadget_vsmt_2.rs:262-352 ; ip = [depth, partial_rounds], sp = [root]
+    if (g.name == "vsmt_2") {  // src/gadget_vsmt_2.rs:262-352 ; ip = [depth, partial_rounds(, sbox)], sp = [root]
         size_t depth = g.ip.at(0);
         PoseidonParams params(6, 4, 4, g.ip.at(1), g.blob, g.blob_len);
         auto leaf = AS(0);
@@ -320,7 +323,7 @@ static size_t run_gadget(const GadgetSpec& g, Harness& h) {
         for (size_t i = 0; i < depth; i++) bits.push_back(AS(1 + i));
         for (size_t i = 0; i < depth; i++) nodes.push_back(AS(1 + depth + i));
         auto st = statics_from(1 + 2 * depth, 4);
-        vanilla_merkle_merkle_tree_verif_gadget(h.cs, depth, g.sp.at(0), leaf, bits, nodes, st, params);
+        vanilla_merkle_merkle_tree_verif_gadget(h.cs, depth, g.sp.at(0), leaf, bits, nodes, st, params, tree_sbox());
         return 5 + 2 * depth;
     }
     throw R1CSError::GadgetError("unknown gadget " + g.name);
@@ -482,16 +485,19 @@ int bpr1cs_mimc(const uint8_t* xl, const uint8_t* xr, const uint8_t* constants, 
     return BPR1CS_OK;
 }
 
-int bpr1cs_vsmt4_new(uint32_t levels, uint32_t partial_rounds, const uint8_t* blob, size_t blob_len, bpr1cs_vsmt4** out) {
+int bpr1cs_vsmt4_new_sbox(uint32_t levels, uint32_t partial_rounds, int sbox_inverse, const uint8_t* blob, size_t blob_len, bpr1cs_vsmt4** out) {
     try {
         auto t = new bpr1cs_vsmt4();
         t->params.reset(new PoseidonParams(6, 4, 4, partial_rounds, blob, blob_len));
-        t->tree.reset(new VanillaSparseMerkleTree_4(*t->params, levels));
+        t->tree.reset(new VanillaSparseMerkleTree_4(*t->params, levels, sbox_inverse ? SboxType::Inverse : SboxType::Cube));
         *out = t;
         return BPR1CS_OK;
     } catch (const R1CSError& e) {
         return e.code;
     }
+}
+int bpr1cs_vsmt4_new(uint32_t levels, uint32_t partial_rounds, const uint8_t* blob, size_t blob_len, bpr1cs_vsmt4** out) {
+    return bpr1cs_vsmt4_new_sbox(levels, partial_rounds, 1, blob, blob_len, out);
 }
 void bpr1cs_vsmt4_free(bpr1cs_vsmt4* t) { delete t; }
 void bpr1cs_vsmt4_root(const bpr1cs_vsmt4* t, uint8_t out[32]) { memcpy(out, t->tree->root.to_bytes().data(), 32); }
@@ -499,7 +505,7 @@ void bpr1cs_vsmt4_update(bpr1cs_vsmt4* t, const uint8_t idx[32], const uint8_t v
     t->tree->update(Scalar::from_bytes_mod_order(idx), Scalar::from_bytes_mod_order(val));
 }
 // many Poseidon permutations of width-6 states through the device; returns element [1] of every output (the hash)
-static std::vector<Scalar> device_perm_batch_elem1(const PoseidonParams& p, const std::vector<std::array<Scalar, 6>>& states) {
+static std::vector<Scalar> device_perm_batch_elem1(const PoseidonParams& p, const std::vector<std::array<Scalar, 6>>& states, SboxType sbox) {
     std::vector<uint8_t> mds, rk, in(states.size() * 6 * 32), out(states.size() * 6 * 32);
     for (size_t i = 0; i < p.width; i++)
         for (size_t j = 0; j < p.width; j++) { auto b = p.MDS_matrix[i][j].to_bytes(); mds.insert(mds.end(), b.begin(), b.end()); }
@@ -513,22 +519,22 @@ static std::vector<Scalar> device_perm_batch_elem1(const PoseidonParams& p, cons
         for (size_t i = 0; i < 6; i++) { auto b = states[h][i].to_bytes(); memcpy(&in[32 * (6 * h + i)], b.data(), 32); }
     std::vector<Scalar> res;
     if (states.empty()) return res;
-    int rc = bpr1cs_poseidon_permutation_batch(&pp, 1, in.data(), states.size(), out.data());
+    int rc = bpr1cs_poseidon_permutation_batch(&pp, sbox == SboxType::Inverse ? 1 : 0, in.data(), states.size(), out.data());
     if (rc) throw R1CSError::Backend(rc);
     for (size_t h = 0; h < states.size(); h++) res.push_back(Scalar::from_bytes_mod_order(&out[32 * (6 * h + 1)]));
     return res;
 }
 // Poseidon_hash_2 (gadget_poseidon.rs:428-443) of many pairs
-static std::vector<Scalar> device_hash2_batch(const PoseidonParams& p, const std::vector<std::pair<Scalar, Scalar>>& inputs) {
+static std::vector<Scalar> device_hash2_batch(const PoseidonParams& p, const std::vector<std::pair<Scalar, Scalar>>& inputs, SboxType sbox) {
     std::vector<std::array<Scalar, 6>> st;
     for (auto& in : inputs) st.push_back({Scalar(ZERO_CONST), in.first, in.second, Scalar(PADDING_CONST), Scalar(ZERO_CONST), Scalar(ZERO_CONST)});
-    return device_perm_batch_elem1(p, st);
+    return device_perm_batch_elem1(p, st, sbox);
 }
 // Poseidon_hash_4 (gadget_poseidon.rs:488-503) of many inputs through the device's bulk permutation
-static std::vector<Scalar> device_hash4_batch(const PoseidonParams& p, const std::vector<std::array<Scalar, 4>>& inputs) {
+static std::vector<Scalar> device_hash4_batch(const PoseidonParams& p, const std::vector<std::array<Scalar, 4>>& inputs, SboxType sbox) {
     std::vector<std::array<Scalar, 6>> st;
     for (auto& in : inputs) st.push_back({Scalar(ZERO_CONST), in[0], in[1], in[2], in[3], Scalar(PADDING_CONST)});
-    return device_perm_batch_elem1(p, st);
+    return device_perm_batch_elem1(p, st, sbox);
 }
 // bulk insert of `count` DISTINCT leaves; every tree level is hashed by one device launch
 int bpr1cs_vsmt4_update_many(bpr1cs_vsmt4* t, const uint8_t* idx, const uint8_t* vals, size_t count) {
@@ -536,7 +542,7 @@ int bpr1cs_vsmt4_update_many(bpr1cs_vsmt4* t, const uint8_t* idx, const uint8_t*
         std::vector<std::pair<Scalar, Scalar>> leaves;
         for (size_t i = 0; i < count; i++) leaves.push_back({Scalar::from_bytes_mod_order(idx + 32 * i), Scalar::from_bytes_mod_order(vals + 32 * i)});
         const PoseidonParams& p = *t->params;
-        t->tree->update_many(leaves, [&](const std::vector<std::array<Scalar, 4>>& in) { return device_hash4_batch(p, in); });
+        t->tree->update_many(leaves, [&](const std::vector<std::array<Scalar, 4>>& in) { return device_hash4_batch(p, in, t->tree->sbox); });
         return BPR1CS_OK;
     } catch (const R1CSError& e) {
         return e.code;
@@ -575,16 +581,19 @@ int bpr1cs_vsmt4_get(const bpr1cs_vsmt4* t, const uint8_t idx[32], uint8_t* leaf
         return BPR1CS_ERR_INVALID_ARGUMENT;
     }
 }
-int bpr1cs_vsmt2_new(uint32_t depth, uint32_t partial_rounds, const uint8_t* blob, size_t blob_len, bpr1cs_vsmt2** out) {
+int bpr1cs_vsmt2_new_sbox(uint32_t depth, uint32_t partial_rounds, int sbox_inverse, const uint8_t* blob, size_t blob_len, bpr1cs_vsmt2** out) {
     try {
         auto t = new bpr1cs_vsmt2();
         t->params.reset(new PoseidonParams(6, 4, 4, partial_rounds, blob, blob_len));
-        t->tree.reset(new VanillaSparseMerkleTree(*t->params, depth));
+        t->tree.reset(new VanillaSparseMerkleTree(*t->params, depth, sbox_inverse ? SboxType::Inverse : SboxType::Cube));
         *out = t;
         return BPR1CS_OK;
     } catch (const R1CSError& e) {
         return e.code;
     }
+}
+int bpr1cs_vsmt2_new(uint32_t depth, uint32_t partial_rounds, const uint8_t* blob, size_t blob_len, bpr1cs_vsmt2** out) {
+    return bpr1cs_vsmt2_new_sbox(depth, partial_rounds, 1, blob, blob_len, out);
 }
 void bpr1cs_vsmt2_free(bpr1cs_vsmt2* t) { delete t; }
 void bpr1cs_vsmt2_root(const bpr1cs_vsmt2* t, uint8_t out[32]) { memcpy(out, t->tree->root.to_bytes().data(), 32); }
@@ -608,7 +617,7 @@ int bpr1cs_vsmt2_update_many(bpr1cs_vsmt2* t, const uint8_t* idx, const uint8_t*
         std::vector<std::pair<Scalar, Scalar>> leaves;
         for (size_t i = 0; i < count; i++) leaves.push_back({Scalar::from_bytes_mod_order(idx + 32 * i), Scalar::from_bytes_mod_order(vals + 32 * i)});
         const PoseidonParams& p = *t->params;
-        t->tree->update_many(leaves, [&](const std::vector<std::pair<Scalar, Scalar>>& in) { return device_hash2_batch(p, in); });
+        t->tree->update_many(leaves, [&](const std::vector<std::pair<Scalar, Scalar>>& in) { return device_hash2_batch(p, in, t->tree->sbox); });
         return BPR1CS_OK;
     } catch (const R1CSError& e) {
         return e.code;

@@ -389,16 +389,18 @@ class VanillaSparseMerkleTree_4 {
 public:
     size_t depth, leaf_index_bytes;
     const PoseidonParams& hash_params;
+    SboxType sbox;  // the reference hard-wires SboxType::Inverse (gadget_vsmt_4.rs:53,301); Cube is SURVEY §8f N4's variant
     std::vector<Scalar> empty_tree_hashes;
     std::map<ScalarKey, std::array<Scalar, 4>> db;
     Scalar root;
-    VanillaSparseMerkleTree_4(const PoseidonParams& p, size_t tree_depth = 128) : depth(tree_depth), leaf_index_bytes(tree_depth / 4), hash_params(p) {
+    VanillaSparseMerkleTree_4(const PoseidonParams& p, size_t tree_depth = 128, SboxType sbox_type = SboxType::Inverse)
+        : depth(tree_depth), leaf_index_bytes(tree_depth / 4), hash_params(p), sbox(sbox_type) {
         if (tree_depth % 4 != 0) throw R1CSError::GadgetError("Tree depth should be a multiple of 4");
         empty_tree_hashes.push_back(Scalar::zero());
         for (size_t i = 1; i <= depth; i++) {
             Scalar prev = empty_tree_hashes[i - 1];
             std::array<Scalar, 4> input{prev, prev, prev, prev};
-            Scalar nw = Poseidon_hash_4(input, hash_params, SboxType::Inverse);
+            Scalar nw = Poseidon_hash_4(input, hash_params, sbox);
             db[ScalarKey{nw.to_bytes()}] = input;
             empty_tree_hashes.push_back(nw);
         }
@@ -415,7 +417,7 @@ public:
             sidenodes.pop_back();
             std::array<Scalar, 4> input;
             for (size_t i = 0, j = 0; i < 4; i++) input[i] = (i == d) ? cur_val : pn[j++];
-            Scalar h = Poseidon_hash_4(input, hash_params, SboxType::Inverse);
+            Scalar h = Poseidon_hash_4(input, hash_params, sbox);
             db[ScalarKey{h.to_bytes()}] = input;
             cur_val = h;
         }
@@ -496,7 +498,7 @@ public:
             const ProofNode& pn = proof[depth - 1 - i];
             std::array<Scalar, 4> input;
             for (size_t t = 0, j = 0; t < 4; t++) input[t] = (t == d) ? cur_val : pn[j++];
-            cur_val = Poseidon_hash_4(input, hash_params, SboxType::Inverse);
+            cur_val = Poseidon_hash_4(input, hash_params, sbox);
         }
         return cur_val == (root_opt ? *root_opt : root);
     }
@@ -507,7 +509,7 @@ public:
 inline void vanilla_merkle_merkle_tree_4_verif_gadget(ConstraintSystem& cs, size_t depth, const Scalar& root, const AllocatedScalar& leaf_val,
                                                       const AllocatedScalar& leaf_index, std::vector<AllocatedScalar> proof_nodes,
                                                       const std::vector<AllocatedScalar>& statics_, const PoseidonParams& poseidon_params,
-                                                      size_t leaf_index_bytes) {
+                                                      size_t leaf_index_bytes, SboxType sbox_type = SboxType::Inverse) {
     (void)depth;
     LinearCombination prev_hash(leaf_val.variable);
     std::vector<LinearCombination> statics;
@@ -560,7 +562,7 @@ inline void vanilla_merkle_merkle_tree_4_verif_gadget(ConstraintSystem& cs, size
             Variable c3_2 = cs.multiply(LC(b0_1_b1), N3).out;
             Variable c3_3 = cs.multiply(LC(b0_b1), prev_hash).out;
             LinearCombination c3 = c3_1 + c3_2 + LC(c3_3);
-            prev_hash = Poseidon_hash_4_constraints(cs, {c0, c1, c2, c3}, statics, poseidon_params, SboxType::Inverse);
+            prev_hash = Poseidon_hash_4_constraints(cs, {c0, c1, c2, c3}, statics, poseidon_params, sbox_type);
             exp_4 = exp_4 * four;
         }
     }
@@ -574,14 +576,15 @@ class VanillaSparseMerkleTree {
 public:
     size_t depth;
     const PoseidonParams& hash_params;
+    SboxType sbox;  // the reference hard-wires SboxType::Inverse (gadget_vsmt_2.rs:203); Cube is SURVEY §8f N4's variant
     std::vector<Scalar> empty_tree_hashes;
     std::map<ScalarKey, std::pair<Scalar, Scalar>> db;
     Scalar root;
-    VanillaSparseMerkleTree(const PoseidonParams& p, size_t tree_depth = 253) : depth(tree_depth), hash_params(p) {
+    VanillaSparseMerkleTree(const PoseidonParams& p, size_t tree_depth = 253, SboxType sbox_type = SboxType::Inverse) : depth(tree_depth), hash_params(p), sbox(sbox_type) {
         empty_tree_hashes.push_back(Scalar::zero());
         for (size_t i = 1; i <= depth; i++) {
             Scalar prev = empty_tree_hashes[i - 1];
-            Scalar nw = Poseidon_hash_2(prev, prev, hash_params, SboxType::Inverse);
+            Scalar nw = Poseidon_hash_2(prev, prev, hash_params, sbox);
             db[ScalarKey{nw.to_bytes()}] = {prev, prev};
             empty_tree_hashes.push_back(nw);
         }
@@ -596,8 +599,8 @@ public:
             Scalar side = sidenodes.back();
             sidenodes.pop_back();
             Scalar h;
-            if (bits[i]) { h = Poseidon_hash_2(side, cur_val, hash_params, SboxType::Inverse); db[ScalarKey{h.to_bytes()}] = {side, cur_val}; }
-            else { h = Poseidon_hash_2(cur_val, side, hash_params, SboxType::Inverse); db[ScalarKey{h.to_bytes()}] = {cur_val, side}; }
+            if (bits[i]) { h = Poseidon_hash_2(side, cur_val, hash_params, sbox); db[ScalarKey{h.to_bytes()}] = {side, cur_val}; }
+            else { h = Poseidon_hash_2(cur_val, side, hash_params, sbox); db[ScalarKey{h.to_bytes()}] = {cur_val, side}; }
             cur_val = h;
         }
         root = cur_val;
@@ -666,7 +669,7 @@ public:
         Scalar cur = val;
         for (size_t i = 0; i < depth; i++) {
             const Scalar& p = proof[depth - 1 - i];
-            cur = bits[i] ? Poseidon_hash_2(p, cur, hash_params, SboxType::Inverse) : Poseidon_hash_2(cur, p, hash_params, SboxType::Inverse);
+            cur = bits[i] ? Poseidon_hash_2(p, cur, hash_params, sbox) : Poseidon_hash_2(cur, p, hash_params, sbox);
         }
         return cur == (root_opt ? *root_opt : root);
     }
@@ -675,7 +678,8 @@ public:
 // vanilla_merkle_merkle_tree_verif_gadget (gadget_vsmt_2.rs:171-209)
 inline void vanilla_merkle_merkle_tree_verif_gadget(ConstraintSystem& cs, size_t depth, const Scalar& root, const AllocatedScalar& leaf_val,
                                                     const std::vector<AllocatedScalar>& leaf_index_bits, const std::vector<AllocatedScalar>& proof_nodes,
-                                                    const std::vector<AllocatedScalar>& statics_, const PoseidonParams& poseidon_params) {
+                                                    const std::vector<AllocatedScalar>& statics_, const PoseidonParams& poseidon_params,
+                                                    SboxType sbox_type = SboxType::Inverse) {
     LinearCombination prev_hash;
     std::vector<LinearCombination> statics;
     for (auto& s : statics_) statics.push_back(LinearCombination(s.variable));
@@ -688,7 +692,7 @@ inline void vanilla_merkle_merkle_tree_verif_gadget(ConstraintSystem& cs, size_t
         Variable right_1 = cs.multiply(LinearCombination(leaf_index_bits[i].variable), leaf_val_lc).out;
         Variable right_2 = cs.multiply(one_minus_leaf_side, LinearCombination(proof_nodes[i].variable)).out;
         LinearCombination right = right_1 + right_2;
-        prev_hash = Poseidon_hash_2_constraints(cs, left, right, statics, poseidon_params, SboxType::Inverse);
+        prev_hash = Poseidon_hash_2_constraints(cs, left, right, statics, poseidon_params, sbox_type);
     }
     constrain_lc_with_scalar(cs, prev_hash, root);
 }

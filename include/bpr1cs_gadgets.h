@@ -22,8 +22,9 @@
  *   "poseidon_hash_2"  ip=[sbox(0 cube,1 inverse), partial_rounds] sp=[output]  values: xl, xr, 0,101,0,0       (src/gadget_poseidon.rs:692-790)
  *   "poseidon_hash_4"  ip=[sbox, partial_rounds] sp=[output]    values: x0..x3, 0,101                (:792-875)
  *   "poseidon_perm"    ip=[sbox, partial_rounds] sp=[out0..5]   values: x0..x5                       (:624-690)
- *   "vsmt_4"           ip=[levels, partial_rounds] sp=[root]    values: leaf, index, 3*levels nodes (root level first), 0,101   (src/gadget_vsmt_4.rs:363-440)
- *   "vsmt_2"           ip=[depth, partial_rounds]  sp=[root]    values: leaf, depth index bits (LSB first), depth nodes (leaf level first), 0,101,0,0   (src/gadget_vsmt_2.rs:262-352)
+ *   "vsmt_4"           ip=[levels, partial_rounds(, sbox)] sp=[root]  values: leaf, index, 3*levels nodes (root level first), 0,101   (src/gadget_vsmt_4.rs:363-440)
+ *   "vsmt_2"           ip=[depth, partial_rounds(, sbox)]  sp=[root]  values: leaf, depth index bits (LSB first), depth nodes (leaf level first), 0,101,0,0   (src/gadget_vsmt_2.rs:262-352)
+ *                      sbox: 1 or absent = SboxType::Inverse as the reference hard-wires it (gadget_vsmt_4.rs:301, gadget_vsmt_2.rs:203), 0 = Cube
  * The statics (0 / 101 / 0...) are committed with blinding 0 (reference gadget_poseidon.rs:554-578).
  * `poseidon_blob` = bulletproofs-r1cs-gadgets_amd/data/poseidon_params_ristretto.bin (may be NULL for non-Poseidon gadgets).
  */
@@ -58,6 +59,8 @@ int bpr1cs_mimc(const uint8_t* xl, const uint8_t* xr, const uint8_t* constants, 
 
 typedef struct bpr1cs_vsmt4 bpr1cs_vsmt4; /* VanillaSparseMerkleTree_4, src/gadget_vsmt_4.rs:32-165 */
 int bpr1cs_vsmt4_new(uint32_t levels, uint32_t partial_rounds, const uint8_t* blob, size_t blob_len, bpr1cs_vsmt4** out);
+/* the tree over Poseidon with the Cube S-box (sbox_inverse = 0); bpr1cs_vsmt4_new = sbox_inverse 1, the reference's choice (:53) */
+int bpr1cs_vsmt4_new_sbox(uint32_t levels, uint32_t partial_rounds, int sbox_inverse, const uint8_t* blob, size_t blob_len, bpr1cs_vsmt4** out);
 void bpr1cs_vsmt4_free(bpr1cs_vsmt4* t);
 void bpr1cs_vsmt4_root(const bpr1cs_vsmt4* t, uint8_t out[32]);
 void bpr1cs_vsmt4_update(bpr1cs_vsmt4* t, const uint8_t idx[32], const uint8_t val[32]);
@@ -71,6 +74,7 @@ int bpr1cs_vsmt4_get_many(const bpr1cs_vsmt4* t, const uint8_t* idx, size_t coun
 
 typedef struct bpr1cs_vsmt2 bpr1cs_vsmt2; /* VanillaSparseMerkleTree, src/gadget_vsmt_2.rs:27-166 */
 int bpr1cs_vsmt2_new(uint32_t depth, uint32_t partial_rounds, const uint8_t* blob, size_t blob_len, bpr1cs_vsmt2** out);
+int bpr1cs_vsmt2_new_sbox(uint32_t depth, uint32_t partial_rounds, int sbox_inverse, const uint8_t* blob, size_t blob_len, bpr1cs_vsmt2** out);
 void bpr1cs_vsmt2_free(bpr1cs_vsmt2* t);
 void bpr1cs_vsmt2_root(const bpr1cs_vsmt2* t, uint8_t out[32]);
 void bpr1cs_vsmt2_update(bpr1cs_vsmt2* t, const uint8_t idx[32], const uint8_t val[32]);

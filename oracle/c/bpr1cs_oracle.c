@@ -20,6 +20,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <stdio.h>
+#include <time.h>
 
 typedef unsigned __int128 u128;
 typedef uint64_t u64;
@@ -75,7 +76,23 @@ static fe fe_mul(fe a, fe b) {
     r.v[0] += c * 19; c = r.v[0] >> 51; r.v[0] &= M51; r.v[1] += c;
     return r;
 }
-static fe fe_sq(fe a) { return fe_mul(a, a); }
+static fe fe_sq(fe a) { /* dedicated squaring: 15 limb products instead of 25 (as dalek's FieldElement51::square) */
+    u64 a0 = a.v[0], a1 = a.v[1], a2 = a.v[2], a3 = a.v[3], a4 = a.v[4];
+    u64 a3_19 = a3 * 19, a4_19 = a4 * 19;
+    u128 t0 = (u128)a0*a0 + 2 * ((u128)a1*a4_19 + (u128)a2*a3_19);
+    u128 t1 = 2 * ((u128)a0*a1 + (u128)a2*a4_19) + (u128)a3*a3_19;
+    u128 t2 = 2 * ((u128)a0*a2 + (u128)a3*a4_19) + (u128)a1*a1;
+    u128 t3 = 2 * ((u128)a0*a3 + (u128)a1*a2) + (u128)a4*a4_19;
+    u128 t4 = 2 * ((u128)a0*a4 + (u128)a1*a3) + (u128)a2*a2;
+    fe r; u64 c;
+    t1 += (u64)(t0 >> 51); r.v[0] = (u64)t0 & M51;
+    t2 += (u64)(t1 >> 51); r.v[1] = (u64)t1 & M51;
+    t3 += (u64)(t2 >> 51); r.v[2] = (u64)t2 & M51;
+    t4 += (u64)(t3 >> 51); r.v[3] = (u64)t3 & M51;
+    c = (u64)(t4 >> 51); r.v[4] = (u64)t4 & M51;
+    r.v[0] += c * 19; c = r.v[0] >> 51; r.v[0] &= M51; r.v[1] += c;
+    return r;
+}
 static fe fe_sqn(fe a, int n) { while (n--) a = fe_sq(a); return a; }
 static void fe_pow22501(fe z, fe* t19, fe* t3) {
     fe t0 = fe_sq(z), t1 = fe_sqn(t0, 2), t2 = fe_mul(z, t1);
@@ -315,20 +332,66 @@ static ge msm(const sc* s, const ge* P, size_t n) {
     free(sb); free(bucket); free(used);
     return acc;
 }
-/* a*P + b*Q (vartime Straus, 4-bit windows) — the per-element generator fold of the IPA */
-static ge mul2(sc a, ge P, sc b, ge Q) {
-    u8 ab[32], bb[32]; sc_tobytes(a, ab); sc_tobytes(b, bb);
-    ge tp[16], tq[16];
-    tp[1] = P; tq[1] = Q;
-    for (int i = 2; i < 16; i++) { tp[i] = ge_add(tp[i-1], P); tq[i] = ge_add(tq[i-1], Q); }
-    ge acc = ge_identity(); int started = 0;
-    for (int w = 63; w >= 0; w--) {
-        if (started) { acc = ge_dbl(ge_dbl(ge_dbl(ge_dbl(acc)))); }
-        u32 da = (ab[w >> 1] >> (4 * (w & 1))) & 15, db = (bb[w >> 1] >> (4 * (w & 1))) & 15;
-        if (da) { acc = ge_add(acc, tp[da]); started = 1; }
-        if (db) { acc = ge_add(acc, tq[db]); started = 1; }
+/* a*P + b*Q as curve25519-dalek's vartime Straus for small inputs (RistrettoPoint::vartime_multiscalar_mul, what the
+   IPA's per-element generator fold calls): width-5 non-adjacent forms, 8 odd multiples per point in cached (projective
+   Niels) form, doublings on (X:Y:Z) without T.  Same group element as any other evaluation order. */
+typedef struct { fe YpX, YmX, Z, T2d; } ge_cached;
+typedef struct { fe X, Y, Z, T; } ge_p1p1;
+typedef struct { fe X, Y, Z; } ge_p2;
+static ge_cached ge_to_cached(ge p) { ge_cached c = {fe_add(p.Y, p.X), fe_sub(p.Y, p.X), p.Z, fe_mul(p.T, FE_D2)}; return c; }
+static ge_p1p1 ge_add_cached(ge p, const ge_cached* q, int neg) {
+    fe A = fe_mul(fe_add(p.Y, p.X), neg ? q->YmX : q->YpX), B = fe_mul(fe_sub(p.Y, p.X), neg ? q->YpX : q->YmX);
+    fe C = fe_mul(p.T, q->T2d), D = fe_mul(p.Z, q->Z); D = fe_add(D, D);
+    ge_p1p1 r = {fe_sub(A, B), fe_add(A, B), neg ? fe_sub(D, C) : fe_add(D, C), neg ? fe_add(D, C) : fe_sub(D, C)};
+    return r;
+}
+static ge_p2 p1p1_to_p2(ge_p1p1 r) { ge_p2 p = {fe_mul(r.X, r.T), fe_mul(r.Y, r.Z), fe_mul(r.Z, r.T)}; return p; }
+static ge p1p1_to_p3(ge_p1p1 r) { ge p = {fe_mul(r.X, r.T), fe_mul(r.Y, r.Z), fe_mul(r.Z, r.T), fe_mul(r.X, r.Y)}; return p; }
+static ge_p1p1 p2_dbl(ge_p2 p) {
+    fe XX = fe_sq(p.X), YY = fe_sq(p.Y), ZZ2 = fe_sq(p.Z); ZZ2 = fe_add(ZZ2, ZZ2);
+    fe XpY2 = fe_sq(fe_add(p.X, p.Y)), Y3 = fe_add(YY, XX), Z3 = fe_sub(YY, XX);
+    ge_p1p1 r = {fe_sub(XpY2, Y3), Y3, Z3, fe_sub(ZZ2, Z3)};
+    return r;
+}
+static void sc_naf5(sc a, int8_t naf[257]) { /* canonical scalar -> width-5 NAF (odd digits in [-15, 15]) */
+    u8 b[32]; u64 x[5] = {0, 0, 0, 0, 0};
+    sc_tobytes(a, b); memcpy(x, b, 32);
+    memset(naf, 0, 257);
+    u32 pos = 0; u64 carry = 0;
+    while (pos < 257) {
+        u32 wi = pos >> 6, bi = pos & 63;
+        u64 buf = bi < 64 - 5 ? x[wi] >> bi : (x[wi] >> bi) | (wi + 1 < 5 ? x[wi + 1] << (64 - bi) : 0);
+        u64 window = carry + (buf & 31);
+        if ((window & 1) == 0) { pos++; continue; }
+        if (window < 16) { carry = 0; naf[pos] = (int8_t)window; } else { carry = 1; naf[pos] = (int8_t)((int)window - 32); }
+        pos += 5;
     }
-    return acc;
+}
+static void odd_multiples(ge P, ge_cached t[8]) { /* P, 3P, ..., 15P */
+    ge P2 = p1p1_to_p3(p2_dbl((ge_p2){P.X, P.Y, P.Z})), cur = P;
+    ge_cached c2 = ge_to_cached(P2);
+    t[0] = ge_to_cached(P);
+    for (int i = 1; i < 8; i++) { cur = p1p1_to_p3(ge_add_cached(cur, &c2, 0)); t[i] = ge_to_cached(cur); }
+}
+static ge mul2(sc a, ge P, sc b, ge Q) {
+    int8_t na[257], nb[257];
+    sc_naf5(a, na); sc_naf5(b, nb);
+    ge_cached tp[8], tq[8];
+    odd_multiples(P, tp); odd_multiples(Q, tq);
+    int i = 256;
+    while (i >= 0 && !na[i] && !nb[i]) i--;
+    ge_p2 acc = {FE_ZERO, FE_ONE, FE_ONE};
+    for (; i >= 0; i--) {
+        ge_p1p1 r = p2_dbl(acc);
+        if (na[i] > 0) r = ge_add_cached(p1p1_to_p3(r), &tp[na[i] >> 1], 0);
+        else if (na[i] < 0) r = ge_add_cached(p1p1_to_p3(r), &tp[(-na[i]) >> 1], 1);
+        if (nb[i] > 0) r = ge_add_cached(p1p1_to_p3(r), &tq[nb[i] >> 1], 0);
+        else if (nb[i] < 0) r = ge_add_cached(p1p1_to_p3(r), &tq[(-nb[i]) >> 1], 1);
+        acc = p1p1_to_p2(r);
+    }
+    ge out = {acc.X, acc.Y, acc.Z, FE_ZERO};  /* T = XY/Z: rebuilt by one more (trivial) conversion */
+    { fe zi = acc.Z; out.X = fe_mul(acc.X, zi); out.Y = fe_mul(acc.Y, zi); out.Z = fe_sq(zi); out.T = fe_mul(acc.X, acc.Y); }
+    return out;
 }
 
 /* ============================================================ generators */
@@ -601,11 +664,20 @@ static void set_membership_gadget(prover* p, u32 c0, u32 k, const u64* items) {
 }
 
 /* ============================================================ Prover::prove */
+/* wall seconds of the last oracle_prove on this thread, for bench.py's cpu_baseline: [0] gadget synthesis (LC algebra, S-box
+   inversions)  [1] V commitments + TranscriptRng draws  [2] A_I/A_O/S multiscalar multiplications  [3] constraint flattening,
+   l/r/t polynomials, T commitments  [4] IPA: L/R multiscalar multiplications  [5] IPA: generator folds (two-term double-scalar
+   multiplications) + scalar folds */
+static __thread double g_phase[6];
+static double now_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
+void oracle_last_phase_seconds(double* out) { for (int i = 0; i < 6; i++) out[i] = g_phase[i]; }
 static sc ip(const sc* a, const sc* b, u32 n) { sc acc = SC_ZERO; for (u32 i = 0; i < n; i++) acc = sc_add(acc, sc_mul(a[i], b[i])); return acc; }
 static size_t prove_core(prover* p, const u8* label, u32 label_len, const u8* seed, u8* out, u8* comm_out) {
     u32 n = p->n, m = p->m, N = 1, lgN = 0;
     while (N < n) { N <<= 1; lgN++; }
     gens_t* g = get_gens(N);
+    double tp = now_s(), tq;
+#define PHASE(k) do { tq = now_s(); g_phase[k] += tq - tp; tp = tq; } while (0)
     strobe T; t_new(&T, label, label_len);
     t_append(&T, "dom-sep", "r1cs v1", 7);
     for (u32 j = 0; j < m; j++) {
@@ -621,6 +693,7 @@ static size_t prove_core(prover* p, const u8* label, u32 label_len, const u8* se
     sc* sL = malloc(32 * (size_t)n); sc* sR = malloc(32 * (size_t)n);
     for (u32 i = 0; i < n; i++) sL[i] = rng_scalar(&R);
     for (u32 i = 0; i < n; i++) sR[i] = rng_scalar(&R);
+    PHASE(1);
     /* A_I1, A_O1, S1 */
     sc* ms = malloc(32 * (size_t)(2 * n + 1)); ge* mp = malloc(sizeof(ge) * (size_t)(2 * n + 1));
     u8 AI[32], AO[32], S1[32];
@@ -629,6 +702,7 @@ static size_t prove_core(prover* p, const u8* label, u32 label_len, const u8* se
     ge_compress(msm(ms, mp, 2 * n + 1), AI);
     ms[0] = o_bl; memcpy(ms + 1, p->aO, 32 * (size_t)n); ge_compress(msm(ms, mp, n + 1), AO);
     ms[0] = s_bl; memcpy(ms + 1, sL, 32 * (size_t)n); memcpy(ms + 1 + n, sR, 32 * (size_t)n); ge_compress(msm(ms, mp, 2 * n + 1), S1);
+    PHASE(2);
     t_append(&T, "A_I1", AI, 32); t_append(&T, "A_O1", AO, 32); t_append(&T, "S1", S1, 32);
     t_append(&T, "dom-sep", "r1cs-1phase", 11);
     u8 id[32]; memset(id, 0, 32);
@@ -681,6 +755,7 @@ static size_t prove_core(prover* p, const u8* label, u32 label_len, const u8* se
     memcpy(G, g->G, sizeof(ge) * (size_t)N); memcpy(H, g->H, sizeof(ge) * (size_t)N);
     sc* gf = malloc(32 * (size_t)N); sc* hf = malloc(32 * (size_t)N);
     for (u32 i = 0; i < N; i++) { gf[i] = i < n ? SC_R : u; hf[i] = sc_mul(eyi[i], gf[i]); }
+    PHASE(3);
     u8* o = out; *o++ = 0;
     memcpy(o, AI, 32); memcpy(o + 32, AO, 32); memcpy(o + 64, S1, 32); o += 96;
     for (int k = 0; k < 5; k++) { memcpy(o, Tc[k], 32); o += 32; }
@@ -694,6 +769,7 @@ static size_t prove_core(prover* p, const u8* label, u32 label_len, const u8* se
         ss[2 * nn] = cL; pp[2 * nn] = Q; ge_compress(msm(ss, pp, 2 * nn + 1), o);
         for (u32 i = 0; i < nn; i++) { ss[i] = first ? sc_mul(lv[nn + i], gf[i]) : lv[nn + i]; pp[i] = G[i]; ss[nn + i] = first ? sc_mul(rv[i], hf[nn + i]) : rv[i]; pp[nn + i] = H[nn + i]; }
         ss[2 * nn] = cR; ge_compress(msm(ss, pp, 2 * nn + 1), o + 32);
+        PHASE(4);
         t_append(&T, "L", o, 32); t_append(&T, "R", o + 32, 32); o += 64;
         sc uu = t_challenge(&T, "u"), ui = sc_invert(uu);
         for (u32 i = 0; i < nn; i++) {
@@ -703,6 +779,7 @@ static size_t prove_core(prover* p, const u8* label, u32 label_len, const u8* se
             else { G[i] = mul2(ui, G[i], uu, G[nn + i]); H[i] = mul2(uu, H[i], ui, H[nn + i]); }
         }
         first = 0;
+        PHASE(5);
     }
     sc_tobytes(lv[0], o); sc_tobytes(rv[0], o + 32); o += 64;
     free(sL); free(sR); free(ms); free(mp); free(wL); free(wR); free(wO); free(wV); free(eyi); free(l1); free(r0); free(r1); free(r3);
@@ -739,6 +816,8 @@ static void load_params(poseidon_params* pp, const u8* blob, u32 partial_rounds)
 size_t oracle_prove(int gadget, const u32* ip, const u8* sp, const u8* poseidon_blob, const u8* label, u32 label_len,
                     const u8* values, const u8* blindings, u32 m, const u8* seed, u8* proof_out, u8* comm_out, u32* stats,
                     u8* wires_out /* optional: n_max*3*32, a_L|a_R|a_O */, u32 wires_cap) {
+    for (int i = 0; i < 6; i++) g_phase[i] = 0;
+    double t_syn = now_s();
     prover* p = pr_new(values, blindings, m);
     poseidon_params pp;
     if (gadget <= 2 || gadget == 4) load_params(&pp, poseidon_blob, ip[1]);
@@ -767,6 +846,7 @@ size_t oracle_prove(int gadget, const u32* ip, const u8* sp, const u8* poseidon_
         set_membership_gadget(p, 0, k, items);
         free(items);
     }
+    g_phase[0] = now_s() - t_syn;
     if (stats) { stats[0] = p->n; stats[1] = p->q; stats[2] = p->m; }
     if (wires_out && wires_cap >= p->n)
         for (u32 i = 0; i < p->n; i++) { sc_tobytes(p->aL[i], wires_out + 32 * (size_t)i); sc_tobytes(p->aR[i], wires_out + 32 * ((size_t)p->n + i)); sc_tobytes(p->aO[i], wires_out + 32 * (2 * (size_t)p->n + i)); }

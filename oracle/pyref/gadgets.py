@@ -360,14 +360,15 @@ class VanillaSparseMerkleTree_4:
     """gadget_vsmt_4.rs:32-165, TreeDepth re-parameterised (trap T3):
     depth = number of 4-ary levels, LeafIndexBytes = depth/4."""
 
-    def __init__(self, hash_params, depth=128):
+    def __init__(self, hash_params, depth=128, sbox=INVERSE):
+        """sbox: the reference hard-wires INVERSE (gadget_vsmt_4.rs:53); CUBE is the variant of SURVEY §8f N4"""
         assert depth % 4 == 0
-        self.depth, self.leaf_index_bytes, self.hash_params = depth, depth // 4, hash_params
+        self.depth, self.leaf_index_bytes, self.hash_params, self.sbox = depth, depth // 4, hash_params, sbox
         self.db = {}
         self.empty_tree_hashes = [0]
         for i in range(1, depth + 1):
             prev = self.empty_tree_hashes[i - 1]
-            new = Poseidon_hash_4([prev] * 4, hash_params, INVERSE)
+            new = Poseidon_hash_4([prev] * 4, hash_params, self.sbox)
             self.db[new] = [prev] * 4
             self.empty_tree_hashes.append(new)
         self.root = self.empty_tree_hashes[depth]
@@ -379,7 +380,7 @@ class VanillaSparseMerkleTree_4:
         for d in cur_idx:
             side = list(sidenodes.pop())
             side.insert(d, cur_val)
-            h = Poseidon_hash_4(side, self.hash_params, INVERSE)
+            h = Poseidon_hash_4(side, self.hash_params, self.sbox)
             self.db[h] = side
             cur_val = h
         self.root = cur_val
@@ -400,12 +401,12 @@ class VanillaSparseMerkleTree_4:
         for i, d in enumerate(get_base_4_repr(idx, self.leaf_index_bytes)[::-1]):
             p = list(proof[self.depth - 1 - i])
             p.insert(d, cur)
-            cur = Poseidon_hash_4(p, self.hash_params, INVERSE)
+            cur = Poseidon_hash_4(p, self.hash_params, self.sbox)
         return cur == (self.root if root is None else root)
 
 
 def vanilla_merkle_merkle_tree_4_verif_gadget(cs, depth, root, leaf_val, leaf_index, proof_nodes, statics,
-                                              poseidon_params, leaf_index_bytes):
+                                              poseidon_params, leaf_index_bytes, sbox=INVERSE):
     """gadget_vsmt_4.rs:199-312; `depth` is unused as in the reference (T3),
     the loop bound is LeafIndexBytes (passed explicitly here)."""
     prev_hash = LinearCombination.of(leaf_val.variable)
@@ -457,7 +458,7 @@ def vanilla_merkle_merkle_tree_4_verif_gadget(cs, depth, root, leaf_val, leaf_in
             _, _, c3_2 = cs.multiply(V(b0_1_b1), N3)
             _, _, c3_3 = cs.multiply(V(b0_b1), prev_hash)
             c3 = c3_1 + c3_2 + c3_3
-            prev_hash = Poseidon_hash_4_constraints(cs, [c0, c1, c2, c3], statics, poseidon_params, INVERSE)
+            prev_hash = Poseidon_hash_4_constraints(cs, [c0, c1, c2, c3], statics, poseidon_params, sbox)
             exp_4 = exp_4 * 4 % L
     cs.constrain(LinearCombination(constraint_leaf_index))
     constrain_lc_with_scalar(cs, prev_hash, root)
@@ -467,13 +468,14 @@ def vanilla_merkle_merkle_tree_4_verif_gadget(cs, depth, root, leaf_val, leaf_in
 class VanillaSparseMerkleTree:
     """gadget_vsmt_2.rs:27-166, TreeDepth re-parameterised (trap T3)."""
 
-    def __init__(self, hash_params, depth=253):
-        self.depth, self.hash_params = depth, hash_params
+    def __init__(self, hash_params, depth=253, sbox=INVERSE):
+        """sbox: the reference hard-wires INVERSE (gadget_vsmt_2.rs:203); CUBE is the variant of SURVEY §8f N4"""
+        self.depth, self.hash_params, self.sbox = depth, hash_params, sbox
         self.db = {}
         self.empty_tree_hashes = [0]
         for i in range(1, depth + 1):
             prev = self.empty_tree_hashes[i - 1]
-            new = Poseidon_hash_2(prev, prev, hash_params, INVERSE)
+            new = Poseidon_hash_2(prev, prev, hash_params, self.sbox)
             self.db[new] = (prev, prev)
             self.empty_tree_hashes.append(new)
         self.root = self.empty_tree_hashes[depth]
@@ -485,10 +487,10 @@ class VanillaSparseMerkleTree:
         for i in range(self.depth):
             side = sidenodes.pop()
             if bits[i]:
-                h = Poseidon_hash_2(side, cur_val, self.hash_params, INVERSE)
+                h = Poseidon_hash_2(side, cur_val, self.hash_params, self.sbox)
                 self.db[h] = (side, cur_val)
             else:
-                h = Poseidon_hash_2(cur_val, side, self.hash_params, INVERSE)
+                h = Poseidon_hash_2(cur_val, side, self.hash_params, self.sbox)
                 self.db[h] = (cur_val, side)
             cur_val = h
         self.root = cur_val
@@ -511,13 +513,13 @@ class VanillaSparseMerkleTree:
         cur = val % L
         for i in range(self.depth):
             p = proof[self.depth - 1 - i]
-            cur = Poseidon_hash_2(p, cur, self.hash_params, INVERSE) if bits[i] else \
-                Poseidon_hash_2(cur, p, self.hash_params, INVERSE)
+            cur = Poseidon_hash_2(p, cur, self.hash_params, self.sbox) if bits[i] else \
+                Poseidon_hash_2(cur, p, self.hash_params, self.sbox)
         return cur == (self.root if root is None else root)
 
 
 def vanilla_merkle_merkle_tree_verif_gadget(cs, depth, root, leaf_val, leaf_index_bits, proof_nodes, statics,
-                                            poseidon_params):
+                                            poseidon_params, sbox=INVERSE):
     """gadget_vsmt_2.rs:171-209."""
     prev_hash = LinearCombination()
     statics = [LinearCombination.of(s.variable) for s in statics]
@@ -531,5 +533,5 @@ def vanilla_merkle_merkle_tree_verif_gadget(cs, depth, root, leaf_val, leaf_inde
         _, _, right_1 = cs.multiply(V(leaf_index_bits[i].variable), leaf_val_lc)
         _, _, right_2 = cs.multiply(one_minus_leaf_side, V(proof_nodes[i].variable))
         right = right_1 + right_2
-        prev_hash = Poseidon_hash_2_constraints(cs, left, right, statics, poseidon_params, INVERSE)
+        prev_hash = Poseidon_hash_2_constraints(cs, left, right, statics, poseidon_params, sbox)
     constrain_lc_with_scalar(cs, prev_hash, root)

@@ -165,7 +165,7 @@ def vsmt_4(tree, leaf_idx):
             c, v = pr.commit(x, bl[2 + k]); comms.append(c); allocs.append(Alloc(v, x))
         st = g.allocate_statics_for_prover(pr, 2)
         g.vanilla_merkle_merkle_tree_4_verif_gadget(pr, depth, root, Alloc(vl, leaf_val), Alloc(vi, leaf_idx),
-                                                    allocs, st, params, lib)
+                                                    allocs, st, params, lib, tree.sbox)
         return comms
 
     def bv(vr, comms, pc):
@@ -173,7 +173,7 @@ def vsmt_4(tree, leaf_idx):
         allocs = [Alloc(vr.commit(c), None) for c in comms[2:]]
         st = g.allocate_statics_for_verifier(vr, 2, pc)
         g.vanilla_merkle_merkle_tree_4_verif_gadget(vr, depth, root, Alloc(vl, None), Alloc(vi, None),
-                                                    allocs, st, params, lib)
+                                                    allocs, st, params, lib, tree.sbox)
     s = Scenario(b"VSMT", [leaf_val, leaf_idx] + flat, bp, bv)
     s.root = root
     return s
@@ -196,7 +196,7 @@ def vsmt_2(tree, leaf_idx):
         for x in rev:
             c, v = pr.commit(x, bl[k]); k += 1; comms.append(c); pn.append(Alloc(v, x))
         st = g.allocate_statics_for_prover(pr, 4)
-        g.vanilla_merkle_merkle_tree_verif_gadget(pr, depth, root, Alloc(vl, leaf_val), ib, pn, st, params)
+        g.vanilla_merkle_merkle_tree_verif_gadget(pr, depth, root, Alloc(vl, leaf_val), ib, pn, st, params, tree.sbox)
         return comms
 
     def bv(vr, comms, pc):
@@ -204,7 +204,7 @@ def vsmt_2(tree, leaf_idx):
         ib = [Alloc(vr.commit(c), None) for c in comms[1:1 + depth]]
         pn = [Alloc(vr.commit(c), None) for c in comms[1 + depth:]]
         st = g.allocate_statics_for_verifier(vr, 4, pc)
-        g.vanilla_merkle_merkle_tree_verif_gadget(vr, depth, root, Alloc(vl, None), ib, pn, st, params)
+        g.vanilla_merkle_merkle_tree_verif_gadget(vr, depth, root, Alloc(vl, None), ib, pn, st, params, tree.sbox)
     return Scenario(b"VSMT", [leaf_val] + bits + rev, bp, bv)
 
 

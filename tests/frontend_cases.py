@@ -63,11 +63,12 @@ def case(name, j=0):
         sc = S.poseidon_hash_4([S.synth_scalar(b"x4", 4 * j + i) for i in range(4)], sbox, params)
         return "poseidon_hash_4", [0 if sbox == g.CUBE else 1, 140], [sc.output], sc, 512 if sbox == g.CUBE else 1024
     if name.startswith("vsmt_4"):
-        levels, pr = (4, 140) if name == "vsmt_4_l4" else (4, 2)
-        tree = _tree4(levels, pr)
+        levels, pr = (4, 140) if name in ("vsmt_4_l4", "vsmt_4_cube") else (4, 2)
+        cube = name.endswith("_cube")   # the tree over the Cube S-box (the reference hard-wires Inverse, gadget_vsmt_4.rs:301)
+        tree = _tree4(levels, pr, g.CUBE if cube else g.INVERSE)
         sc = S.vsmt_4(tree, 1 + (j % 10))
-        n = 583 * levels if pr == 140 else None
-        return "vsmt_4", [levels, pr], [tree.root], sc, 4096 if pr == 140 else 512
+        cap = 512 if pr != 140 else (2048 if cube else 4096)   # n = levels * (19 + 188 * (2 | 3))
+        return "vsmt_4", [levels, pr] + ([0] if cube else []), [tree.root], sc, cap
     if name == "mimc":
         consts = [S.synth_scalar(b"mimc-const", i) for i in range(g.MIMC_ROUNDS)]   # gadget_mimc.rs:93-96 draws them from the seeded rng
         sc = S.mimc(S.synth_scalar(b"ml", j), S.synth_scalar(b"mr", j), consts)
@@ -85,29 +86,30 @@ def case(name, j=0):
         return "mimc_set_membership", ip, consts + [g.mimc(xl, xr, consts)], sc, 1 << (n - 1).bit_length()
     if name.startswith("vsmt_2"):
         depth, pr = 3, 2
-        tree = _tree2(depth, pr)
+        cube = name.endswith("_cube")   # gadget_vsmt_2.rs:203 hard-wires Inverse; Cube is the N4 variant
+        tree = _tree2(depth, pr, g.CUBE if cube else g.INVERSE)
         sc = S.vsmt_2(tree, 1 + (j % 7))
-        return "vsmt_2", [depth, pr], [tree.root], sc, 512
+        return "vsmt_2", [depth, pr] + ([0] if cube else []), [tree.root], sc, 512
     raise KeyError(name)
 
 
 _T = {}
 
 
-def _tree4(levels, pr):
-    k = (4, levels, pr)
+def _tree4(levels, pr, sbox=g.INVERSE):
+    k = (4, levels, pr, sbox)
     if k not in _T:
-        t = g.VanillaSparseMerkleTree_4(S.poseidon_params(pr), depth=levels)
+        t = g.VanillaSparseMerkleTree_4(S.poseidon_params(pr), depth=levels, sbox=sbox)
         for i in range(1, 11):
             t.update(i, i)
         _T[k] = t
     return _T[k]
 
 
-def _tree2(depth, pr):
-    k = (2, depth, pr)
+def _tree2(depth, pr, sbox=g.INVERSE):
+    k = (2, depth, pr, sbox)
     if k not in _T:
-        t = g.VanillaSparseMerkleTree(S.poseidon_params(pr), depth=depth)
+        t = g.VanillaSparseMerkleTree(S.poseidon_params(pr), depth=depth, sbox=sbox)
         for i in range(1, 8):
             t.update(i, i)
         _T[k] = t
@@ -196,6 +198,21 @@ def check_trees(glib, levels4, depth2, partial_rounds):
     leaf, nodes = t2.get(3)
     oleaf, oproof = o2.get(3, True)
     assert leaf == sc_to_bytes(oleaf) and nodes == [sc_to_bytes(x) for x in oproof]
+    # the Cube-S-box variants of both trees (the reference hard-wires Inverse): sequential and bulk inserts
+    c4 = bp.SparseMerkleTree(4, levels4, partial_rounds, glib=glib, inverse=False)
+    oc4 = g.VanillaSparseMerkleTree_4(S.poseidon_params(partial_rounds), depth=levels4, sbox=g.CUBE)
+    assert c4.root() == sc_to_bytes(oc4.root) and c4.root() != sc_to_bytes(o4.empty_tree_hashes[levels4])
+    c4.update(2, 9); oc4.update(2, 9)
+    c4.update_many([(5, 50), (77, 7)]); oc4.update(5, 50); oc4.update(77, 7)
+    assert c4.root() == sc_to_bytes(oc4.root)
+    leaf, nodes = c4.get(77)
+    oleaf, oproof = oc4.get(77, True)
+    assert leaf == sc_to_bytes(oleaf) and nodes == [sc_to_bytes(x) for node in oproof for x in node]
+    c2 = bp.SparseMerkleTree(2, depth2, partial_rounds, glib=glib, inverse=False)
+    oc2 = g.VanillaSparseMerkleTree(S.poseidon_params(partial_rounds), depth=depth2, sbox=g.CUBE)
+    c2.update(1, 11); oc2.update(1, 11)
+    c2.update_many([(2, 22), (6, 66)]); oc2.update(2, 22); oc2.update(6, 66)
+    assert c2.root() == sc_to_bytes(oc2.root)
 
 
 def check_bulk_tree(lib, glib, levels=4, partial_rounds=2, count=9):

@@ -57,3 +57,10 @@ def test_bulk_poseidon_and_tree_construction(sim_lib, sim_glib):
 def test_compiled_mimc_plus_set_membership_small(sim_lib, sim_glib):
     """SURVEY §8d config C5 at 8 MiMC rounds (the 322-round circuit runs in the GPU suite)"""
     fc.check_compiled(sim_lib, sim_glib, "mimc_set_membership_r8", batch=2)
+
+
+@pytest.mark.parametrize("case", ["vsmt_4_pr2_cube", "vsmt_2_cube"])
+def test_compiled_tree_gadgets_with_the_cube_sbox(sim_lib, sim_glib, case):
+    """the sparse-Merkle gadgets over Poseidon with the Cube S-box (`sbox` iparam; the reference hard-wires
+    Inverse at src/gadget_vsmt_4.rs:301, src/gadget_vsmt_2.rs:203): proof bytes equal the oracle's"""
+    fc.check_compiled(sim_lib, sim_glib, case, batch=2)

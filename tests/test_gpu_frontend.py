@@ -32,6 +32,13 @@ def test_compiled_vsmt_4_four_levels(hip_lib, hip_glib):
     fc.check_compiled(hip_lib, hip_glib, "vsmt_4_l4", batch=2, unfold=4)
 
 
+@pytest.mark.parametrize("case", ["vsmt_4_cube", "vsmt_2_cube"])
+def test_compiled_tree_gadgets_with_the_cube_sbox(hip_lib, hip_glib, case):
+    """Cube-S-box variants of both tree gadgets (4 levels x 148 rounds: n = 1580, N = 2048; depth 3)"""
+    fc.check_compiled(hip_lib, hip_glib, case, batch=2, unfold=4)
+    fc.check_prove_verify_roundtrip(hip_lib, hip_glib, case)
+
+
 def test_compiled_mimc_322_rounds(hip_lib, hip_glib):
     # config 5's preimage half: MiMC-322, n = 644, N = 1024 (per-proof image => one circuit, batch of 1)
     fc.check_compiled(hip_lib, hip_glib, "mimc", batch=1, unfold=4)
