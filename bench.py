@@ -203,6 +203,9 @@ def main():
     ap.add_argument("--team", type=int, default=0, help="witness team size 4/8/16 (0 = library default)")
     ap.add_argument("--rng-mode", type=int, default=-1, help="TranscriptRng chain mapping: 0 auto, 1 lane-parallel, 2 state per thread (-1 = library default)")
     ap.add_argument("--unfold", type=int, default=4, help="IPA rounds computed from the un-folded generator tables")
+    ap.add_argument("--fuse", type=int, default=1, help="steps (batches of --batch proofs) handed to the device as ONE prove job: every table row fetched serves F x batch proofs")
+    ap.add_argument("--shared-back", type=int, default=-1, help="jobs in flight share the scratch of their back phases (-1 = library default)")
+    ap.add_argument("--tail-rounds", type=int, default=-1, help="final IPA rounds enqueued on the job's own tail stream (-1 = library default, 0 = all on the heavy stream)")
     ap.add_argument("--window", type=int, default=11, help="fixed-base table window bits (11: 23 adds/term, 148 / 198 GB of tables at capacity 32768)")
     args = ap.parse_args()
 
@@ -233,11 +236,18 @@ def main():
         lib.bpr1cs_set_rng_mode(args.rng_mode)
     if args.latency_cus >= 0:
         lib.bpr1cs_set_latency_cus(args.latency_cus)
+    if args.tail_rounds >= 0:
+        lib.bpr1cs_set_tail_rounds(args.tail_rounds)
+    if args.shared_back >= 0:
+        lib.bpr1cs_set_shared_back(args.shared_back)
 
     levels, B = args.depth, args.batch
+    F = max(1, args.fuse)
+    Bj = B * F                                      # proofs per device job
+    args.steps = ((max(1, args.steps) + F - 1) // F) * F
     t0 = time.time()
-    n_leaves = args.leaves if args.leaves > 0 else B
-    root, values, blindings, seeds, m = build_workload(bp, levels, B, n_leaves, rank * B)
+    n_leaves = args.leaves if args.leaves > 0 else Bj
+    root, values, blindings, seeds, m = build_workload(bp, levels, Bj, n_leaves, rank * Bj)
     t_witness = time.time() - t0
     t0 = time.time()
     circ = bp.CompiledGadget("vsmt_4", [levels, 140], [root])
@@ -255,7 +265,7 @@ def main():
         torch.cuda.synchronize()
 
     def begin():
-        return bp.ProveJob(gens, circ, b"VSMT", values, blindings, seeds, B)
+        return bp.ProveJob(gens, circ, b"VSMT", values, blindings, seeds, Bj)
 
     def stats():
         a, b, c = bp.last_msm_stats(lib)
@@ -272,7 +282,7 @@ def main():
     t0 = time.perf_counter()
     msm_ms, msm_launches, msm_terms, phases = 0.0, 0, 0, [0.0] * 6
     inflight = []
-    for k in range(args.steps):
+    for k in range(args.steps // F):
         inflight.append(begin())
         if len(inflight) >= depth:
             proofs, _ = inflight.pop(0).finish()
@@ -305,7 +315,7 @@ def main():
             torch.cuda.synchronize()
             t1 = time.perf_counter()
             try:   # fresh randomness for the weights (include/bpr1cs.h: batch_seed must not be predictable)
-                pt, wf = bp.verify_batch_combined(gens, circ, b"VSMT", proofs, comms, B, os.urandom(32), index_base=rank * B)
+                pt, wf = bp.verify_batch_combined(gens, circ, b"VSMT", proofs, comms, Bj, os.urandom(32), index_base=rank * Bj)
             except Exception:  # keep the collective below matched on every rank
                 pt, wf = b"\xff" * 32, False
             pts, all_wf = sh.gather_partial_points(pt, wf, device="cuda" if dist is not None else None)
@@ -314,10 +324,10 @@ def main():
             # the multi-GPU form: shared-base MSM split by base range over the ranks (all_gather of the combined scalar vectors)
             torch.cuda.synchronize()
             t1 = time.perf_counter()
-            accepted_split = sh.verify_sharded(bp, gens, circ, b"VSMT", proofs, comms, B, rank, world, rank * B, device="cuda" if dist is not None else None) and accepted_split
+            accepted_split = sh.verify_sharded(bp, gens, circ, b"VSMT", proofs, comms, Bj, rank, world, rank * Bj, device="cuda" if dist is not None else None) and accepted_split
             ts = min(ts, time.perf_counter() - t1)
-        batched = {"accepted_all": accepted, "proofs": B * world, "proofs_per_s": B * world / tb,
-                   "split_shared_base": {"accepted_all": accepted_split, "proofs_per_s": B * world / ts,
+        batched = {"accepted_all": accepted, "proofs": Bj * world, "proofs_per_s": Bj * world / tb,
+                   "split_shared_base": {"accepted_all": accepted_split, "proofs_per_s": Bj * world / ts,
                                          "note": "bpr1cs_verify_batch_scalars + all_gather of the scalar vectors + 1/world of the bases per rank"},
                    "note": "bpr1cs_verify_batch_combined + all_gather of one point per rank; not part of `value`"}
     except Exception as e:  # pragma: no cover
@@ -330,10 +340,10 @@ def main():
         lgN = N.bit_length() - 1
         alg_bytes_per_proof = 576 * n + 448 * N + 64 * lgN - 96
         # dominant kernel: algorithmic bytes = 64 B per scalar*point term + 32 B per output (MSM_BYTES(t) = 64 t + 32)
-        msm_alg_bytes = 64.0 * msm_terms + 32.0 * msm_launches * B
+        msm_alg_bytes = 64.0 * msm_terms + 32.0 * msm_launches * Bj
         achieved = (msm_alg_bytes / 1e9) / (msm_ms / 1e3) if msm_ms > 0 else None
         tinfo = gens.table_info()
-        traffic, traffic_lps, traffic_src = pmc_traffic(tinfo["format"]) if (B == 1024 and levels == 32 and args.window == 11) else (None, None, None)
+        traffic, traffic_lps, traffic_src = pmc_traffic(tinfo["format"]) if (Bj == 1024 and levels == 32 and args.window == 11) else (None, None, None)
         launches_per_step = msm_launches / steps
         # integer ceilings, measured NOW on this device by the library's probes (bpr1cs_device_rates, ~80 ms each)
         mad_rate, madd_chain_rate = bp.device_rates(0.08, lib)
@@ -346,7 +356,7 @@ def main():
             "config": {"workload": "gadget_vsmt_4 sparse-Merkle depth-%d membership (Poseidon 4:1 inverse S-box, 148 rounds)" % levels,
                        "batch_per_gpu": B, "global_batch": B * world, "n_multipliers": n, "padded_n": N, "constraints": circ.q,
                        "commitments": m, "proof_bytes": circ.proof_len, "sharding": "independent proofs per rank, no collective",
-                       "synthetic_leaves": n_leaves, "batches_in_flight": depth, "ipa_unfold_rounds": args.unfold,
+                       "synthetic_leaves": n_leaves, "steps_per_device_job": F, "proofs_per_device_job": Bj, "jobs_in_flight": depth, "ipa_unfold_rounds": args.unfold,
                        "table_window_bits": tinfo["window_bits"], "table_windows": tinfo["windows"], "table_format": tinfo["format"],
                        "table_bytes": tinfo["bytes"]},
             "roofline": {"bound": "hbm", "kernel": "k_msm_fixed2 (batched fixed-base MSM over the generator tables; a launch carries 1-3 sums)",
@@ -381,9 +391,9 @@ def main():
         # outside the timed region: the device verifier (Verifier::verify, one mega-check MSM per proof) on the last batch
         try:
             tv = time.perf_counter()
-            oks = bp.verify_batch(gens, circ, b"VSMT", proofs, comms, B)
+            oks = bp.verify_batch(gens, circ, b"VSMT", proofs, comms, Bj)
             tv = time.perf_counter() - tv
-            out["verify"] = {"accepted": sum(oks), "of": B, "proofs_per_s": B / tv, "note": "bpr1cs_verify_batch, not part of `value`"}
+            out["verify"] = {"accepted": sum(oks), "of": Bj, "proofs_per_s": Bj / tv, "note": "bpr1cs_verify_batch, not part of `value`"}
         except Exception as e:  # pragma: no cover
             out["verify"] = {"error": repr(e)}
         out["verify_batched"] = batched

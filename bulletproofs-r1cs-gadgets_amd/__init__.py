@@ -57,7 +57,7 @@ class ProofStruct(ctypes.Structure):
                [("lg_n", ctypes.c_uint32), ("L", _B32 * 32), ("R", _B32 * 32), ("ipp_a", _B32), ("ipp_b", _B32)]
 
 
-OPT_UNFOLD_ROUNDS, OPT_RNG_MODE, OPT_WITNESS_TEAM = 0, 1, 2
+OPT_UNFOLD_ROUNDS, OPT_RNG_MODE, OPT_WITNESS_TEAM, OPT_TAIL_ROUNDS = 0, 1, 2, 3
 
 
 def load_library(path=None):
@@ -102,6 +102,8 @@ def load_library(path=None):
     lib.bpr1cs_set_witness_team.argtypes = [ctypes.c_int]
     lib.bpr1cs_set_witness_macro.argtypes = [ctypes.c_int]
     lib.bpr1cs_set_rng_mode.argtypes = [ctypes.c_int]
+    lib.bpr1cs_set_tail_rounds.argtypes = [ctypes.c_int]
+    lib.bpr1cs_set_shared_back.argtypes = [ctypes.c_int]
     lib.bpr1cs_circuit_macro_perms.argtypes = [ctypes.c_void_p]
     lib.bpr1cs_circuit_macro_perms.restype = ctypes.c_int
     lib.bpr1cs_set_latency_cus.argtypes = [ctypes.c_int]

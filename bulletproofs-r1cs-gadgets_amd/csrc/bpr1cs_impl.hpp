@@ -50,9 +50,11 @@ static std::atomic<int> g_rng_mode{0};       // 0 auto, 1 lane-parallel via LDS 
 static std::atomic<int> g_merge_triples{1};  // A_I1: one merged table per Inverse-S-box wire triple (needs the annotated witness program)
 static std::atomic<int> g_witness_macro{1};  // use the Poseidon annotations of a circuit description (poseidon_team)
 static std::atomic<int> g_witness_team{8};   // lanes cooperating on one proof in k_witness_team (4, 8 or 16)
+static std::atomic<int> g_shared_back{1};    // the jobs in flight on a handle share the scratch of their back phases (DevArena)
+static std::atomic<int> g_tail_rounds{7};    // final IPA rounds (m_k <= 64 at 7) enqueued on the job's own tail stream instead of the shared heavy one
 static const uint32_t g_msm_target_threads = 1u << 21;  // (chunk, proof) threads per MSM launch
 struct BpOpts {  // per-handle overrides; -1 = process default
-    std::atomic<int> unfold{-1}, rng_mode{-1}, witness_team{-1};
+    std::atomic<int> unfold{-1}, rng_mode{-1}, witness_team{-1}, tail_rounds{-1};
 };
 // statistics of the last prove job that ENDED ON THIS THREAD (bpr1cs_last_timings / bpr1cs_last_msm_stats)
 struct LastStats {
@@ -112,8 +114,9 @@ struct bpr1cs_gens {
     // HIGH-priority streams: their kernels are latency bound (one wave per proof group, few hundred
     // waves in total) and must get wave slots as soon as any short MSM workgroup retires, so that they
     // co-run with the other in-flight job's MSM/IPA kernels instead of queueing behind them.
-    dev_stream_t jstream[2][4]{};  // [slot][heavy, front, witness, isolated RNG chain]
+    dev_stream_t jstream[2][4]{};  // [slot][heavy, front, witness (later: the job's IPA tail), isolated RNG chain]
     bool rng_isolated = false;
+    mutable DevArena arena;           // back-phase scratch shared by the handle's jobs (one thread at a time uses a handle)
     mutable std::atomic<uint32_t> next_job{0};
     mutable std::atomic<int> in_flight{0};  // jobs begun and not yet ended
     mutable BpOpts opts;
@@ -211,6 +214,8 @@ void bpr1cs_set_unfold_rounds(int r) { g_unfold_rounds = r < 0 ? 0 : r; }
 void bpr1cs_set_latency_cus(int n) { g_latency_cus = n < 0 ? 0 : n; }
 void bpr1cs_set_witness_team(int t) { g_witness_team = (t == 4 || t == 8) ? t : 16; }
 void bpr1cs_set_witness_macro(int enable) { g_witness_macro = enable ? 1 : 0; }
+void bpr1cs_set_tail_rounds(int r) { g_tail_rounds = r < 0 ? 0 : r; }
+void bpr1cs_set_shared_back(int enable) { g_shared_back = enable ? 1 : 0; }
 void bpr1cs_set_rng_mode(int mode) { g_rng_mode = (mode >= 1 && mode <= 5) ? mode : 0; }
 int bpr1cs_circuit_macro_perms(const bpr1cs_circuit* c) { return c ? (int)c->n_perms : 0; }
 void bpr1cs_set_window_bits(int w) { g_window_bits = w <= 0 ? 0 : (w < 4 ? 4 : (w > 12 ? 12 : w)); }  // 0 = choose from the free memory
@@ -220,6 +225,7 @@ int bpr1cs_gens_set_option(bpr1cs_gens* g, int option, int value) {
     if (option == BPR1CS_OPT_UNFOLD_ROUNDS) g->opts.unfold = value < 0 ? -1 : value;
     else if (option == BPR1CS_OPT_RNG_MODE) g->opts.rng_mode = (value >= 0 && value <= 5) ? value : -1;
     else if (option == BPR1CS_OPT_WITNESS_TEAM) g->opts.witness_team = (value == 4 || value == 8 || value == 16) ? value : -1;
+    else if (option == BPR1CS_OPT_TAIL_ROUNDS) g->opts.tail_rounds = value < 0 ? -1 : value;
     else return BPR1CS_ERR_INVALID_ARGUMENT;
     return BPR1CS_OK;
 }
@@ -345,6 +351,7 @@ int bpr1cs_gens_create(uint32_t cap, bpr1cs_gens** out) {
 }
 void bpr1cs_gens_destroy(bpr1cs_gens* g) {
     if (!g) return;
+    g->arena.release();
 #if !defined(BPR1CS_HOSTSIM)
     if (g->stream) (void)hipStreamDestroy(g->stream);
     for (int a = 0; a < 2; a++)
@@ -794,8 +801,28 @@ struct IpaIO {
     const uint8_t* hs_tab = nullptr;
     const sc* hs_scal = nullptr;  // [B] Montgomery
     uint32_t hs_from = 0;
+    // optional: the last `tail_rounds` rounds (latency bound: a few wavefronts per proof, ~10 dependent launches per round)
+    // go to `tail_stream`, which waits for the heavy stream at the hand-off; the heavy stream is then free for the next
+    // job's sums while this job's tail finishes next to them.  At the hand-off the live state (the 2 m_k scalars of a and b,
+    // the 2 m_k generators per side, lambda^-1) is COPIED into buffers of the job's own (`tail_keep`) and the shared arena is
+    // left: the tail never touches memory the next job's back phase may already be writing, so that job does not wait for it.
+    dev_stream_t tail_stream{};
+    uint32_t tail_rounds = 0;
+    struct TailKeep {  // owned by the job: lives until it is released
+        DevBuf<sc> a, bb, linv, cross, cpart;
+        DevBuf<ge> GH, vwin, vsum, vout;
+        DevBuf<ge_cached> vtab;
+        DevBuf<uint32_t> vdig;
+    }* tail_keep = nullptr;
+#if !defined(BPR1CS_HOSTSIM)
+    hipEvent_t* tail_event = nullptr;
+#endif
 };
-static void enqueue_ipa(const IpaIO& io, dev_stream_t st, MsmStats* stats) {
+struct IpaEnd {
+    dev_stream_t st;  // the stream the caller continues on
+    sc* a; sc* bb;    // where the final a, b are (element 0)
+};
+static IpaEnd enqueue_ipa(const IpaIO& io, dev_stream_t st, MsmStats* stats) {
     const bpr1cs_gens* g = io.g;
     const uint32_t B = io.B, N = io.N, lgN = io.lgN;
     const uint32_t baseG = 2, baseH = 2 + g->cap;
@@ -808,7 +835,9 @@ static void enqueue_ipa(const IpaIO& io, dev_stream_t st, MsmStats* stats) {
     DevBuf<uint32_t> vdig;
     DevBuf<sc> linv;
     MsmPlan plan;
-    const uint32_t M = N >> r;  // size of the materialised folded generator vectors
+    uint32_t M = N >> r;  // size of the materialised folded generator vectors (= stride between the two sides in GH)
+    ge* GHp = nullptr; ge* vwinp = nullptr; ge* vsump = nullptr; ge* voutp = nullptr;
+    ge_cached* vtabp = nullptr; uint32_t* vdigp = nullptr; sc* linvp = nullptr; sc* crossp = cross.p;
     if (r > 0) { sG.alloc((size_t)N * B); sH.alloc((size_t)N * B); }
     const uint32_t VC = 16;  // chunks per Straus output (8 / 32 / 64 measured within 0.3 %)
     // variable-base rounds come in pairs on one set of multiples, generators folded two levels at a time (K_ipa_vb_dig2 / _fold2)
@@ -818,12 +847,66 @@ static void enqueue_ipa(const IpaIO& io, dev_stream_t st, MsmStats* stats) {
         if (io.qpt) { f.extra2 = nullptr; f.extra_pt = io.qpt; }
         return f;
     };
+    // hand-off round: among the variable-base rounds, at the start of a pair (the second round of a pair reads the first one's multiples)
+    uint32_t tail_from = lgN;
+    if (io.tail_rounds && io.tail_keep && io.tail_rounds < lgN) {
+        tail_from = std::max(lgN - io.tail_rounds, r + 2);
+        if ((tail_from - r) & 1u) tail_from++;
+    }
+    sc* cpartp = nullptr; size_t cpart_n = 0;
+    bool handed_off = false;
     for (uint32_t k = 0; k < lgN; k++) {
         uint32_t Nk = N >> k, mk = Nk >> 1;
+        if (k == tail_from && k + 1 < lgN) {
+            // ---- leave the shared arena: copy the live state into the job's own buffers (on the heavy stream, before the event)
+            IpaIO::TailKeep& T = *io.tail_keep;
+            DevArena* saved = dev_arena();
+            dev_arena() = nullptr;
+            try {
+                T.a.alloc((size_t)Nk * B); T.bb.alloc((size_t)Nk * B); T.linv.alloc((size_t)2 * B); T.cross.alloc((size_t)2 * B);
+                T.GH.alloc((size_t)2 * Nk * B);
+                T.vtab.alloc((size_t)VB_MULT * 4 * mk * B); T.vdig.alloc((size_t)VB_WORDS * 4 * mk * B);
+                T.vwin.alloc((size_t)2 * VB_WINDOWS * VC * B); T.vsum.alloc((size_t)2 * VB_WINDOWS * B); T.vout.alloc((size_t)2 * B);
+            } catch (...) { dev_arena() = saved; throw; }
+            dev_arena() = saved;
+            dev_d2d(T.a.p, a, (size_t)Nk * B * sizeof(sc), st);
+            dev_d2d(T.bb.p, bb, (size_t)Nk * B * sizeof(sc), st);
+            dev_d2d(T.linv.p, linvp, (size_t)2 * B * sizeof(sc), st);
+            dev_d2d(T.GH.p, GHp, (size_t)Nk * B * sizeof(ge), st);
+            dev_d2d(T.GH.p + (size_t)Nk * B, GHp + (size_t)M * B, (size_t)Nk * B * sizeof(ge), st);
+            dev_zero(io.a, (size_t)N * B * sizeof(sc), st);  // the arena's copies of the secret vectors die here
+            dev_zero(io.bb, (size_t)N * B * sizeof(sc), st);
+            if (sG.p) dev_zero(sG.p, sG.bytes(), st);
+            if (sH.p) dev_zero(sH.p, sH.bytes(), st);
+            handed_off = true;
+            a = T.a.p; bb = T.bb.p; linvp = T.linv.p; crossp = T.cross.p; GHp = T.GH.p; M = Nk;
+            vtabp = T.vtab.p; vdigp = T.vdig.p; vwinp = T.vwin.p; vsump = T.vsum.p; voutp = T.vout.p;
+            cpartp = nullptr; cpart_n = 0;
+#if !defined(BPR1CS_HOSTSIM)
+            if (io.tail_stream && io.tail_event) {  // ... and hand over to the job's tail stream
+                HIPCHK(hipEventCreateWithFlags(io.tail_event, hipEventDisableTiming));  // owned (and destroyed) by the job
+                HIPCHK(hipEventRecord(*io.tail_event, st));
+                HIPCHK(hipStreamWaitEvent(io.tail_stream, *io.tail_event, 0));
+                st = io.tail_stream;
+            }
+#endif
+        }
         uint32_t cchunk, CC = pick_chunks(mk, B, 1u << 18, cchunk);
-        if (cpart.n < (size_t)2 * CC * B) cpart.alloc((size_t)2 * CC * B);
-        launch((uint64_t)CC * B, K_ipa_cross{a, bb, cpart.p, B, mk, cchunk, CC}, st);
-        launch((uint64_t)2 * B, K_sum_partials{cpart.p, cross.p, B, CC}, st);
+        if (cpart_n < (size_t)2 * CC * B) {
+            if (k >= tail_from && io.tail_keep) {
+                DevArena* saved = dev_arena();
+                dev_arena() = nullptr;
+                try { io.tail_keep->cpart.alloc((size_t)2 * CC * B); } catch (...) { dev_arena() = saved; throw; }
+                dev_arena() = saved;
+                cpartp = io.tail_keep->cpart.p;
+            } else {
+                cpart.alloc((size_t)2 * CC * B);
+                cpartp = cpart.p;
+            }
+            cpart_n = (size_t)2 * CC * B;
+        }
+        launch((uint64_t)CC * B, K_ipa_cross{a, bb, cpartp, B, mk, cchunk, CC}, st);
+        launch((uint64_t)2 * B, K_sum_partials{cpartp, crossp, B, CC}, st);
         uint8_t* Lout = io.LR + ((size_t)k * 2 + 0) * B * 32;
         uint8_t* Rout = io.LR + ((size_t)k * 2 + 1) * B * 32;
         if (k < r) {
@@ -842,9 +925,9 @@ static void enqueue_ipa(const IpaIO& io, dev_stream_t st, MsmStats* stats) {
             MsmPlan planR;
             MsmReq rq[2] = {{gL, hL, &partial, &plan, nullptr}, {gR, hR, &partialR, &planR, nullptr}};
             run_msm_multi(g, rq, 2, B, st, stats);  // L_k and R_k share one launch
-            K_msm_finish fL = finisher(partial.p, plan.nchunks, cross.p, Lout);
+            K_msm_finish fL = finisher(partial.p, plan.nchunks, crossp, Lout);
             if (hs) { fL.tab2 = io.hs_tab; fL.extra_b = io.hs_scal; }
-            launch((uint64_t)2 * B, K_pair<K_msm_finish>{fL, finisher(partialR.p, planR.nchunks, cross.p + B, Rout), B}, st);
+            launch((uint64_t)2 * B, K_pair<K_msm_finish>{fL, finisher(partialR.p, planR.nchunks, crossp + B, Rout), B}, st);
         } else {
             if (k == r) {
                 GH.alloc((size_t)2 * M * B);
@@ -872,23 +955,24 @@ static void enqueue_ipa(const IpaIO& io, dev_stream_t st, MsmStats* stats) {
                 vout.alloc((size_t)2 * B);
                 linv.alloc((size_t)2 * B);
                 launch((uint64_t)2 * B, K_set_one{linv.p}, st);
+                GHp = GH.p; vtabp = vtab.p; vdigp = vdig.p; vwinp = vwin.p; vsump = vsum.p; voutp = vout.p; linvp = linv.p;
             }
             const uint32_t remap = 1u;  // XCD-aware workgroup order of the window sums (vb_win_index; +1 % end to end)
             if (!vb_reuse) {
                 // multiples 1P..8P and digits of every term of this round
                 const uint32_t vc = 2 * mk < VC ? 2 * mk : VC;  // chunks of the 2*mk terms of one output
-                launch((uint64_t)4 * mk * B, K_ipa_vb_tab{a, bb, GH.p, linv.p, vtab.p, vdig.p, B, mk, M}, st);
-                launch_wave((uint64_t)2 * VB_WINDOWS * vc * B, K_ipa_vb_win{vtab.p, vdig.p, vwin.p, B, mk, vc, remap, 0}, st);
-                launch((uint64_t)2 * VB_WINDOWS * B, K_ge_reduce{vwin.p, vsum.p, B, 2 * VB_WINDOWS * vc, vc}, st);  // chunk sums -> window sums
+                launch((uint64_t)4 * mk * B, K_ipa_vb_tab{a, bb, GHp, linvp, vtabp, vdigp, B, mk, M}, st);
+                launch_wave((uint64_t)2 * VB_WINDOWS * vc * B, K_ipa_vb_win{vtabp, vdigp, vwinp, B, mk, vc, remap, 0}, st);
+                launch((uint64_t)2 * VB_WINDOWS * B, K_ge_reduce{vwinp, vsump, B, 2 * VB_WINDOWS * vc, vc}, st);  // chunk sums -> window sums
             } else {
                 // the round after: same multiples (the generators were not folded), product scalars
                 const uint32_t m0 = 2 * mk, vc = 2 * m0 < VC ? 2 * m0 : VC;
-                launch((uint64_t)4 * m0 * B, K_ipa_vb_dig2{a, bb, linv.p, io.uk + (size_t)(k - 1) * 2 * B, vdig.p, B, m0}, st);
-                launch_wave((uint64_t)2 * VB_WINDOWS * vc * B, K_ipa_vb_win{vtab.p, vdig.p, vwin.p, B, m0, vc, remap, 1}, st);
-                launch((uint64_t)2 * VB_WINDOWS * B, K_ge_reduce{vwin.p, vsum.p, B, 2 * VB_WINDOWS * vc, vc}, st);
+                launch((uint64_t)4 * m0 * B, K_ipa_vb_dig2{a, bb, linvp, io.uk + (size_t)(k - 1) * 2 * B, vdigp, B, m0}, st);
+                launch_wave((uint64_t)2 * VB_WINDOWS * vc * B, K_ipa_vb_win{vtabp, vdigp, vwinp, B, m0, vc, remap, 1}, st);
+                launch((uint64_t)2 * VB_WINDOWS * B, K_ge_reduce{vwinp, vsump, B, 2 * VB_WINDOWS * vc, vc}, st);
             }
-            launch((uint64_t)2 * B, K_ipa_vb_horner{vsum.p, vout.p, B, 1}, st);
-            launch((uint64_t)2 * B, K_pair<K_msm_finish>{finisher(vout.p, 1, cross.p, Lout), finisher(vout.p + (size_t)B, 1, cross.p + B, Rout), B}, st);
+            launch((uint64_t)2 * B, K_ipa_vb_horner{vsump, voutp, B, 1}, st);
+            launch((uint64_t)2 * B, K_pair<K_msm_finish>{finisher(voutp, 1, crossp, Lout), finisher(voutp + (size_t)B, 1, crossp + B, Rout), B}, st);
         }
         sc* ukk = io.uk + (size_t)k * 2 * B;
         launch(B, K_transcript_LR{io.tr, Lout, ukk, B}, st);
@@ -897,17 +981,20 @@ static void enqueue_ipa(const IpaIO& io, dev_stream_t st, MsmStats* stats) {
         else if (!vb_reuse) {
             vb_reuse = k + 1 < lgN;  // the next round works on this round's multiples
         } else {
-            if (k + 1 < lgN) launch((uint64_t)2 * mk * B, K_ipa_vb_fold2{GH.p, io.uk + (size_t)(k - 1) * 2 * B, ukk, linv.p, vtab.p, B, 2 * mk, M}, st);
+            if (k + 1 < lgN) launch((uint64_t)2 * mk * B, K_ipa_vb_fold2{GHp, io.uk + (size_t)(k - 1) * 2 * B, ukk, linvp, vtabp, B, 2 * mk, M}, st);
             vb_reuse = false;
         }
     }
-    if (sG.p) dev_zero(sG.p, sG.bytes(), st);  // products of the secret l / r vectors
-    if (sH.p) dev_zero(sH.p, sH.bytes(), st);
+    if (!handed_off) {
+        if (sG.p) dev_zero(sG.p, sG.bytes(), st);  // products of the secret l / r vectors
+        if (sH.p) dev_zero(sH.p, sH.bytes(), st);
+    }
+    return IpaEnd{st, a, bb};
 }
 
 struct bpr1cs_job {
     const bpr1cs_gens* g = nullptr;
-    dev_stream_t st{}, st2{}, st3{};
+    dev_stream_t st{}, st2{}, st3{}, st4{};
     std::vector<void*> deferred;
     PhaseTimer pt;
     MsmStats msm;
@@ -917,8 +1004,9 @@ struct bpr1cs_job {
     uint8_t* h_comms = nullptr;
     int* h_err = nullptr;
     bool counted = false;         // contributes to g->in_flight
+    IpaIO::TailKeep tail;         // the IPA tail's own buffers (outside the handle's shared arena)
 #if !defined(BPR1CS_HOSTSIM)
-    hipEvent_t ev_in{}, ev_rng{}, ev_wit{}, ev_done{}, ev_rng0{}, ev_rng1{};
+    hipEvent_t ev_in{}, ev_rng{}, ev_wit{}, ev_done{}, ev_rng0{}, ev_rng1{}, ev_tail{};
 #endif
 };
 // pinned staging buffers are cached: hipHostFree (like hipFree) synchronises the whole device, which
@@ -979,7 +1067,8 @@ static void job_release(bpr1cs_job* job) {
     else if (job->st) (void)hipStreamSynchronize(job->st);
     if (job->st2) (void)hipStreamSynchronize(job->st2);
     if (job->st3) (void)hipStreamSynchronize(job->st3);
-    hipEvent_t* evs[6] = {&job->ev_in, &job->ev_rng, &job->ev_wit, &job->ev_done, &job->ev_rng0, &job->ev_rng1};
+    if (job->st4) (void)hipStreamSynchronize(job->st4);
+    hipEvent_t* evs[7] = {&job->ev_in, &job->ev_rng, &job->ev_wit, &job->ev_done, &job->ev_rng0, &job->ev_rng1, &job->ev_tail};
     for (auto e : evs)
         if (*e) { (void)hipEventDestroy(*e); *e = nullptr; }
     for (auto e : job->pt.ev) (void)hipEventDestroy(e);
@@ -1020,12 +1109,17 @@ extern "C" int bpr1cs_prove_batch_begin(const bpr1cs_gens* g, const bpr1cs_circu
     job->st = g->jstream[0][0];  // ONE heavy stream: MSM/IPA phases of successive jobs run back to back (FIFO; a heavy stream per job measured 3.4 % slower)
     job->st2 = g->jstream[slot][1];
     job->st3 = g->jstream[slot][2];
+    // the tail runs on the job's own witness stream: idle since the witness kernel ended (before the job's first sum), high
+    // priority, and never used by the other job in flight (that one has the other slot).  A stream of its own would change the
+    // streams' mapping onto the few hardware queues (measured: two more streams serialised the jobs, 2540 -> 2040 proofs/s)
+    job->st4 = g->jstream[slot][2];
     Scope scope(job);
     // per-call knobs: the handle's own setting, else the process default
     const int o_unfold = g->opts.unfold.load() >= 0 ? g->opts.unfold.load() : g_unfold_rounds.load();
     const int o_rng = g->opts.rng_mode.load() >= 0 ? g->opts.rng_mode.load() : g_rng_mode.load();
     const int o_team = g->opts.witness_team.load() >= 0 ? g->opts.witness_team.load() : g_witness_team.load();
     const int o_merge = g_merge_triples.load();
+    const int o_tail = g->opts.tail_rounds.load() >= 0 ? g->opts.tail_rounds.load() : g_tail_rounds.load();
     const uint32_t B = (uint32_t)batch, n = c->n, m = c->m, N = c->N, lgN = c->lgN;
     const uint32_t baseG = 2, baseH = 2 + g->cap;
     dev_stream_t st = job->st;
@@ -1210,8 +1304,21 @@ extern "C" int bpr1cs_prove_batch_begin(const bpr1cs_gens* g, const bpr1cs_circu
     }
     pt.mark(st);
 
+    // ---- from here on the job's scratch comes from the handle's arena, shared with the other job in flight: that job's
+    // back phase is AHEAD of this one on the heavy stream (FIFO), and its tail - the only part that runs on another stream -
+    // works on copies of its own (IpaIO::TailKeep), so stream order alone keeps the two jobs apart: no event, no wait.
+    struct ArenaHook {
+        DevArena* prev;
+        explicit ArenaHook(DevArena* a) : prev(dev_arena()) { if (a) { a->next = 0; dev_arena() = a; } }
+        ~ArenaHook() { dev_arena() = prev; }
+    };
+    // what the IPA tail and the proof assembly read stays the job's own: challenges, T commitments, t_x.., L/R, u_k
+    DevBuf<sc> chal((size_t)CH_COUNT * B), txs((size_t)3 * B), uk((size_t)(lgN ? lgN : 1) * 2 * B);
+    DevBuf<uint8_t> Tc((size_t)5 * B * 32), LR((size_t)(lgN ? lgN : 1) * 2 * B * 32);
+    const bool shared_back = g_shared_back.load() != 0;
+    ArenaHook arena_hook(shared_back ? &g->arena : nullptr);
+
     // ---- P3/P4: challenges, flatten, t(x), T commitments, l(x), r(x)
-    DevBuf<sc> chal((size_t)CH_COUNT * B);
     launch(B, K_transcript_A{tr.p, AOS.p, chal.p, B}, st);
     uint32_t maxe = std::max<uint32_t>(N, c->q + 1);
     uint32_t H = (maxe >> 8) + 1;
@@ -1224,17 +1331,13 @@ extern "C" int bpr1cs_prove_batch_begin(const bpr1cs_gens* g, const bpr1cs_circu
     DevBuf<sc> tpart((size_t)6 * TC * B), tco((size_t)6 * B);
     launch((uint64_t)TC * B, K_tcoef_partial{W.p, wvec.p, plo.p, phi.p, tpart.p, B, H, n, tchunk, TC}, st);
     launch((uint64_t)6 * B, K_sum_partials{tpart.p, tco.p, B, TC}, st);
-    DevBuf<uint8_t> Tc((size_t)5 * B * 32);
     launch((uint64_t)5 * B, K_commit_T{g->tab.p, g->tc, tco.p, blind.p, Tc.p, B}, st);
-    DevBuf<sc> txs((size_t)3 * B);
     launch(B, K_transcript_T{tr.p, Tc.p, tco.p, blind.p, wvec.p + (size_t)3 * n * B, vbl_m.p, chal.p, txs.p, B, m, (uint64_t)N}, st);
     DevBuf<sc> a((size_t)N * B), bb((size_t)N * B), cG((size_t)N * B), cH((size_t)N * B);
     launch((uint64_t)N * B, K_lr_eval{W.p, wvec.p, plo.p, phi.p, chal.p, a.p, bb.p, cG.p, cH.p, B, H, n}, st);
     pt.mark(st);
 
     // ---- P5: inner-product argument
-    DevBuf<uint8_t> LR((size_t)(lgN ? lgN : 1) * 2 * B * 32);
-    DevBuf<sc> uk((size_t)(lgN ? lgN : 1) * 2 * B);
     IpaIO io{g, B, N, lgN, (uint32_t)o_unfold, tr.p, a.p, bb.p, cG.p, cH.p, chal.p + (size_t)CH_W * B, nullptr, LR.p, uk.p};
     DevBuf<sc> hs_scal;
     if (lgN >= 1 && n > N / 2 && n < N && o_unfold >= 1) {
@@ -1244,6 +1347,11 @@ extern "C" int bpr1cs_prove_batch_begin(const bpr1cs_gens* g, const bpr1cs_circu
         bpr1cs_circuit::MergedTab*& mt = c->mt[g];
         if (!mt) mt = new bpr1cs_circuit::MergedTab();
         if (!mt->hs_tab.p || mt->hs_W != g->tc.W || mt->hs_cap != g->cap || mt->hs_fmt != g->tc.fmt) {
+            struct ArenaPause {  // the table outlives the job: it must not come from the jobs' shared arena
+                DevArena* saved;
+                ArenaPause() : saved(dev_arena()) { dev_arena() = nullptr; }
+                ~ArenaPause() { dev_arena() = saved; }
+            } pause;
             DevBuf<ge> part64(64), hsum(1);
             launch(64, K_range_sum_points{g->pts.p, part64.p, baseH + (n - N / 2), baseH + N / 2}, st);
             launch(1, K_ge_reduce{part64.p, hsum.p, 1, 64, 64}, st);
@@ -1257,11 +1365,18 @@ extern "C" int bpr1cs_prove_batch_begin(const bpr1cs_gens* g, const bpr1cs_circu
         io.hs_scal = hs_scal.p;
         io.hs_from = n - N / 2;
     }
-    enqueue_ipa(io, st, stats);
+    io.tail_stream = job->st4;
+    io.tail_rounds = (uint32_t)o_tail;
+#if !defined(BPR1CS_HOSTSIM)
+    io.tail_event = &job->ev_tail;
+#endif
+    io.tail_keep = &job->tail;
+    const IpaEnd ipa_end = enqueue_ipa(io, st, stats);
+    st = ipa_end.st;  // from here on `st` may be the job's tail stream: only the job's own buffers are touched below
     size_t plen = bpr1cs_proof_len(c);
     job->plen = plen;
     DevBuf<uint8_t> d_out((size_t)B * plen);
-    launch(B, K_assemble{AOS.p, Tc.p, txs.p, LR.p, a.p, bb.p, d_out.p, B, lgN, (uint32_t)plen}, st);
+    launch(B, K_assemble{AOS.p, Tc.p, txs.p, LR.p, ipa_end.a, ipa_end.bb, d_out.p, B, lgN, (uint32_t)plen}, st);
     pt.mark(st);
     job->h_proofs = (uint8_t*)host_stage_alloc((size_t)B * plen);
     job->h_comms = (uint8_t*)host_stage_alloc((size_t)B * m * 32);
@@ -1275,7 +1390,8 @@ extern "C" int bpr1cs_prove_batch_begin(const bpr1cs_gens* g, const bpr1cs_circu
     dev_zero(blind.p, blind.bytes(), st);
     dev_zero(v_raw.p, v_raw.bytes(), st); dev_zero(vbl_raw.p, vbl_raw.bytes(), st);
     dev_zero(v_m.p, v_m.bytes(), st); dev_zero(vbl_m.p, vbl_m.bytes(), st);
-    dev_zero(a.p, a.bytes(), st); dev_zero(bb.p, bb.bytes(), st);
+    if (ipa_end.a == a.p) { dev_zero(a.p, a.bytes(), st); dev_zero(bb.p, bb.bytes(), st); }  // (else: zeroed at the hand-off, on the heavy stream)
+    else { dev_zero(job->tail.a.p, job->tail.a.bytes(), st); dev_zero(job->tail.bb.p, job->tail.bb.bytes(), st); }
     if (px.p) dev_zero(px.p, px.bytes(), st);
     dev_zero(d_seeds.p, d_seeds.bytes(), st);
 #if !defined(BPR1CS_HOSTSIM)
@@ -1631,7 +1747,7 @@ extern "C" int bpr1cs_ipa_create(const bpr1cs_gens* g, bpr1cs_transcript* t, con
     DevBuf<sc> uk((size_t)(lgN ? lgN : 1) * 2);
     const int unfold = g->opts.unfold.load() >= 0 ? g->opts.unfold.load() : g_unfold_rounds.load();
     IpaIO io{g, 1, N, lgN, (uint32_t)unfold, tr.p, vec.p, vec.p + N, vec.p + (size_t)2 * N, vec.p + (size_t)3 * N, nullptr, dq.p, LR.p, uk.p};
-    enqueue_ipa(io, st, &stats);
+    (void)enqueue_ipa(io, st, &stats);
     std::vector<sc> fin(N + 1);
     dev_d2h(fin.data(), vec.p, (size_t)(N + 1) * sizeof(sc), st);  // a' = vec[0], b' = vec[N]
     sc_mont_tobytes(fin[0], a_out);

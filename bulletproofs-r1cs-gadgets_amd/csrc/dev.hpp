@@ -41,6 +41,7 @@ inline void dev_free(void* p) {
 inline void dev_h2d(void* d, const void* h, size_t n, dev_stream_t) { memcpy(d, h, n); }
 inline void dev_d2h(void* h, const void* d, size_t n, dev_stream_t) { memcpy(h, d, n); }
 inline void dev_zero(void* d, size_t n, dev_stream_t) { memset(d, 0, n); }
+inline void dev_d2d(void* d, const void* s, size_t n, dev_stream_t) { memcpy(d, s, n); }
 inline void dev_sync(dev_stream_t) {}
 template <class F>
 inline void launch(uint64_t n, const F& f, dev_stream_t) {
@@ -127,6 +128,7 @@ inline void dev_d2h(void* h, const void* d, size_t n, dev_stream_t s) {
     HIPCHK(hipStreamSynchronize(s));
 }
 inline void dev_zero(void* d, size_t n, dev_stream_t s) { HIPCHK(hipMemsetAsync(d, 0, n, s)); }
+inline void dev_d2d(void* d, const void* src, size_t n, dev_stream_t s) { HIPCHK(hipMemcpyAsync(d, src, n, hipMemcpyDeviceToDevice, s)); }
 inline void dev_sync(dev_stream_t s) { HIPCHK(hipStreamSynchronize(s)); }
 
 template <class F>
@@ -169,21 +171,60 @@ inline void launch_wave(uint64_t n, const F& f, dev_stream_t s) {
 }
 #endif
 
+// Arena of device blocks that successive prove jobs of one generator handle REUSE for the buffers of their "back" phase
+// (everything after the commitment sums): the backs of the jobs in flight run one after the other on the handle's heavy
+// stream, so their scratch can be the same memory - a job only has to wait for its predecessor's tail before its first
+// write (bpr1cs_prove_batch_begin).  While a job's enqueue code has the arena installed (dev_arena()), every
+// DevBuf::alloc takes the next slot instead of asking the allocator: jobs of the same shape issue the same sequence of
+// requests and get the same addresses.  A slot that is too small (or much too large) is replaced; the old block goes to
+// the current job's deferred frees, i.e. it returns to the pool only after this job - and with it every earlier job -
+// has drained.
+struct DevArena {
+    std::vector<std::pair<void*, size_t>> slots;
+    size_t next = 0;
+    void* take(size_t bytes) {
+        if (bytes == 0) bytes = 1;
+        if (next < slots.size() && slots[next].second >= bytes && slots[next].second <= 4 * bytes + (1u << 20)) return slots[next++].first;
+        void* np = dev_alloc(bytes);
+        if (next < slots.size()) {
+            dev_free(slots[next].first);
+            slots[next] = {np, bytes};
+        } else slots.push_back({np, bytes});
+        next++;
+        return np;
+    }
+    void release() {  // only when no job of the handle is in flight
+        for (auto& s : slots) dev_free_now(s.first);
+        slots.clear();
+        next = 0;
+    }
+};
+inline DevArena*& dev_arena() {
+    static thread_local DevArena* a = nullptr;
+    return a;
+}
+
 template <class T>
 struct DevBuf {
     T* p = nullptr;
     size_t n = 0;
+    bool owned = true;  // false: the block belongs to the installed DevArena
     DevBuf() {}
     explicit DevBuf(size_t count) { alloc(count); }
     DevBuf(const DevBuf&) = delete;
     DevBuf& operator=(const DevBuf&) = delete;
-    ~DevBuf() { dev_free(p); }
+    ~DevBuf() { if (owned) dev_free(p); }
     void alloc(size_t count) {
         T* old = p;  // dev_alloc may throw (out of memory): never keep a pointer that has already gone back to the pool
+        const bool was_owned = owned;
         p = nullptr;
         n = 0;
-        dev_free(old);
-        p = (T*)dev_alloc(count * sizeof(T));
+        owned = true;
+        if (was_owned) dev_free(old);
+        if (DevArena* a = dev_arena()) {
+            p = (T*)a->take(count * sizeof(T));
+            owned = false;
+        } else p = (T*)dev_alloc(count * sizeof(T));
         n = count;
     }
     size_t bytes() const { return n * sizeof(T); }

@@ -121,6 +121,7 @@ int bpr1cs_gens_table_info(const bpr1cs_gens* g, uint32_t* window_bits, uint32_t
 #define BPR1CS_OPT_UNFOLD_ROUNDS 0 /* bpr1cs_set_unfold_rounds */
 #define BPR1CS_OPT_RNG_MODE 1      /* bpr1cs_set_rng_mode      */
 #define BPR1CS_OPT_WITNESS_TEAM 2  /* bpr1cs_set_witness_team  */
+#define BPR1CS_OPT_TAIL_ROUNDS 3   /* bpr1cs_set_tail_rounds   */
 int bpr1cs_gens_set_option(bpr1cs_gens* g, int option, int value);
 /* give the device memory cached by the library's allocator (freed tables, workspaces) back to the driver */
 int bpr1cs_release_cached_memory(void);
@@ -260,6 +261,18 @@ int bpr1cs_proof_serialize(const bpr1cs_proof* p, uint8_t* out, size_t cap, size
 /* tuning knob: IPA rounds computed from the un-folded generator tables before the
  * folded generators are materialised (default 4; clamped to lg N) */
 void bpr1cs_set_unfold_rounds(int r);
+
+/* tuning knob: how many of the LAST inner-product rounds (latency bound: a few wavefronts per proof) a prove job enqueues
+ * on its own tail stream instead of the handle's shared heavy stream, so that the next job's multiscalar multiplications
+ * start while this job's tail finishes (default 7 = the rounds with m_k <= 64; 0 = everything on the heavy stream;
+ * never earlier than the round after the folded generators are materialised).  Results do not depend on it. */
+void bpr1cs_set_tail_rounds(int r);
+
+/* tuning knob: 1 (default) = the prove jobs in flight on a handle share the device scratch of their back phases (they run one
+ * after the other on the handle's heavy stream; a job waits for its predecessor's tail before its first write): a
+ * 1024-proof job of the depth-32 circuit then holds ~7 GB of its own plus ~15 GB shared instead of 22 GB.  0 = every job
+ * allocates its own scratch.  Results do not depend on it. */
+void bpr1cs_set_shared_back(int enable);
 
 /* tuning knob, read by bpr1cs_gens_create: signed window width W (4..12) of the fixed-base tables.
  * A term costs ceil(253/W) mixed additions (the top window of a canonical scalar never carries out); table bytes =

@@ -135,14 +135,18 @@ def proof_digest(proof):
     return hashlib.sha256(proof).hexdigest()[:32]
 
 
-def check_digests(name, case, proofs, comms=None):
-    """GPU side: every proof of the batch against the committed fixture (tests/golden/fullsize_digests.json)"""
+def check_digests(name, case, proofs, comms=None, first=None):
+    """GPU side: every proof of the batch (or its first `first` proofs) against the committed fixture
+    (tests/golden/fullsize_digests.json, written by tests/golden/make_fullsize_digests.py from the C oracle)"""
     import json
     fx = json.load(open(os.path.join(ROOT, "tests", "golden", "fullsize_digests.json")))[name]
-    assert fx["inputs_sha256"] == input_digest(case), "%s: the inputs built here differ from the fixture's (tree builder / workload changed)" % name
-    assert len(proofs) == fx["B"] == len(fx["proofs"])
+    if first is None:
+        assert fx["inputs_sha256"] == input_digest(case), "%s: the inputs built here differ from the fixture's (tree builder / workload changed)" % name
+        assert len(proofs) == fx["B"] == len(fx["proofs"])
+    else:
+        assert len(proofs) == first <= fx["B"]
     bad = [j for j, p in enumerate(proofs) if proof_digest(p) != fx["proofs"][j]]
     assert not bad, "%s: %d proofs differ from the oracle's digests, first: %s" % (name, len(bad), bad[:8])
-    if comms is not None:
+    if comms is not None and first is None:
         per = b"".join(hashlib.sha256(b"".join(c)).digest() for c in comms)
         assert hashlib.sha256(per).hexdigest() == fx["commitments_sha256"], "%s: commitments differ" % name

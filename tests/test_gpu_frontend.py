@@ -73,3 +73,39 @@ def test_config_c5_mimc_plus_set_membership(hip_lib, hip_glib):
     ob, P, C = fc.check_compiled(hip_lib, hip_glib, "mimc_set_membership", batch=2, unfold=4)
     assert (ob["n"], ob["m"]) == (665, 10)
     fc.check_prove_verify_roundtrip(hip_lib, hip_glib, "mimc_set_membership", batch=1)
+
+
+def test_zero_sbox_input_inside_a_full_wavefront_batch(hip_lib, hip_glib):
+    """A batch of 96 proofs (k_msm_fixed2's wavefront-per-64-proofs path, not the small-batch kernel) in which ONE proof has an
+    Inverse-S-box input of 0 (upstream's invert(0) = 0: its a_O wire is 0 where every other proof has 1): the `a_O - 1` form
+    of the A_O sum (MSM_MINUS_ONE) must take its non-skipped branch for that wavefront.  All 96 proofs equal the C oracle's
+    (95 of them prove a false statement - the public output belongs to proof 40 - which does not matter for the bytes)."""
+    import subprocess, os, importlib
+    from pyref import scenarios as S, gadgets as g
+    from pyref.ed import sc_to_bytes, L
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle", "c")])
+    from cref import COracle, POSEIDON_HASH_2
+    bp = importlib.import_module("bulletproofs-r1cs-gadgets_amd")
+    o = COracle()
+    pr, B, special = 1, 96, 40
+    params = S.poseidon_params(pr)
+    xz = (-params.round_keys[1]) % L            # first-round S-box input of element 1 = xl + round_key[1] = 0
+    xs = [(xz if j == special else S.synth_scalar(b"zx", j), S.synth_scalar(b"zy", j)) for j in range(B)]
+    out = g.Poseidon_hash_2(xs[special][0], xs[special][1], params, g.INVERSE)
+    vals = [b"".join(sc_to_bytes(x) for x in (a, b, 0, 101, 0, 0)) for a, b in xs]
+    bls = [sc_to_bytes(S.synth_scalar(b"zb", 2 * j)) + sc_to_bytes(S.synth_scalar(b"zb", 2 * j + 1)) + bytes(128) for j in range(B)]
+    seeds = [S.synth_seed(7 * 10**6 + j) for j in range(B)]
+    circ = bp.CompiledGadget("poseidon_hash_2", [1, pr], [out], lib=hip_lib, glib=hip_glib)
+    assert circ.n == 147 and hip_lib.bpr1cs_circuit_macro_perms(circ.h) == 1
+    hip_lib.bpr1cs_set_unfold_rounds(4)
+    gens = bp.Gens(256, lib=hip_lib)
+    P, C = bp.prove_batch(gens, circ, b"Poseidon_hash_2", b"".join(vals), b"".join(bls), b"".join(seeds), B)
+    for j in range(B):
+        r = o.prove(POSEIDON_HASH_2, [1, pr], sc_to_bytes(out), b"Poseidon_hash_2", vals[j], bls[j], seeds[j], want_wires=(j == special))
+        assert P[j] == r["proof"], "proof %d differs from the C oracle" % j
+        if j == special:   # the exceptional wires are really there: a_L = 0 and a_O = 0 at the first S-box triple of element 1
+            n = r["n"]
+            aO = [r["wires"][32 * (2 * n + i):32 * (2 * n + i) + 32] for i in range(n)]
+            assert sum(1 for w in aO if w == sc_to_bytes(1)) == 2 * 49 - 2   # two of the 98 "always 1" output wires are 0 in this proof
+    assert bp.verify_batch(gens, circ, b"Poseidon_hash_2", [P[special]], [C[special]], 1) == [True]

@@ -3,7 +3,6 @@ ragged batch: GPU proofs equal the C oracle's byte for byte; every GPU proof pas
 (size-independent property); tampering and a wrong root are rejected."""
 import importlib
 import os
-import subprocess
 import sys
 
 import pytest
@@ -13,13 +12,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_vsmt4_depth32_ragged_batch(hip_lib, hip_glib):
-    sys.path.insert(0, ROOT)
-    import bench
+    import fullsize_cases as fc
     bp = importlib.import_module("bulletproofs-r1cs-gadgets_amd")
-    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle", "c")])
-    from cref import COracle
-    B, levels = 70, 32           # not a multiple of the wavefront size
-    root, values, blindings, seeds, m = bench.build_workload(bp, levels, B, 12, 0)
+    B, levels = 70, 32           # not a multiple of the wavefront size: the first 70 proofs of the C4 digest fixture
+    case = fc.vsmt4(bp, hip_glib, levels, B, 64, 0)
+    root, values, blindings, seeds, m = case["sp"][0], case["values"], case["blindings"], case["seeds"], case["m"]
     circ = bp.CompiledGadget("vsmt_4", [levels, 140], [root], lib=hip_lib, glib=hip_glib)
     assert (circ.n, circ.q, circ.m, circ.proof_len) == (18656, 43330, 100, 1377)
     hip_lib.bpr1cs_set_window_bits(8)
@@ -29,11 +26,7 @@ def test_vsmt4_depth32_ragged_batch(hip_lib, hip_glib):
     finally:
         hip_lib.bpr1cs_set_window_bits(8)
     P, C = bp.prove_batch(gens, circ, b"VSMT", values, blindings, seeds, B)
-    o = COracle()
-    oc = o.compile_vsmt4(levels, 140, root)
-    for j in (0, B - 1):
-        ref = o.prove_vsmt4(oc, values[j * m * 32:(j + 1) * m * 32], blindings[j * m * 32:(j + 1) * m * 32], seeds[32 * j:32 * j + 32])
-        assert P[j] == ref, "proof %d differs from the C oracle" % j
+    fc.check_digests("c4_vsmt4_d32_x2024", case, P, first=B)   # W = 8 tables, IPA switch round 5: the same bytes as the W = 11 / round 4 run
     assert bp.verify_batch(gens, circ, b"VSMT", P, C, B) == [True] * B
     # negative: tampered IPA element, swapped commitments, wrong public root
     bad = [bytearray(p) for p in P]
@@ -103,32 +96,19 @@ def test_vsmt2_depth32_config_c3(hip_lib, hip_glib):
 
 
 def test_poseidon_2to1_cube_batch_4096_config_c2(hip_lib, hip_glib):
-    """Poseidon 2:1 Cube preimage (n = 376, N = 512, m = 6), 4096 proofs in one batch: sampled
-    proofs equal the C oracle's byte for byte, all of them pass the per-proof and the batched device verifier."""
-    import json
+    """Poseidon 2:1 Cube preimage (n = 376, N = 512, m = 6), 4096 proofs in one batch: ALL proofs equal
+    the C oracle's (digest fixture), all of them pass the per-proof and the batched device verifier."""
+    import fullsize_cases as fc
     bp = importlib.import_module("bulletproofs-r1cs-gadgets_amd")
-    sys.path.insert(0, ROOT)
-    import bench
-    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle", "c")])
-    from cref import COracle
-    gd = json.load(open(os.path.join(ROOT, "tests", "golden", "proofs.json")))["poseidon_hash_2_cube"]
-    B, m = 4096, gd["m"]
-    vals1 = bytes.fromhex(gd["values"])[:m * 32]
-    image = bytes.fromhex(gd["sparams"][0])
-    label = gd["label"].encode()
-    values = vals1 * B
-    bl = b"".join(b"".join(bench.sc(bench.synth_scalar(b"c2bl", j * 8 + t)) for t in range(2)) + bytes(128) for j in range(B))
-    seeds = b"".join(bench.synth_scalar(b"c2seed", j).to_bytes(32, "little") for j in range(B))
-    circ = bp.CompiledGadget("poseidon_hash_2", gd["iparams"], [image], lib=hip_lib, glib=hip_glib)
+    case = fc.CASES["c2_poseidon2_cube_x4096"](bp, hip_glib)
+    B, label = case["B"], case["label"]
+    circ = bp.CompiledGadget("poseidon_hash_2", case["ip"], case["sp"], lib=hip_lib, glib=hip_glib)
     assert (circ.n, circ.m) == (376, 6)
     hip_lib.bpr1cs_set_window_bits(8)
     hip_lib.bpr1cs_set_unfold_rounds(4)
     gens = bp.Gens(512, lib=hip_lib)
-    P, C = bp.prove_batch(gens, circ, label, values, bl, seeds, B)
-    o = COracle()
-    for j in (0, 1777, B - 1):
-        r = o.prove(1, gd["iparams"], image, label, vals1, bl[j * m * 32:(j + 1) * m * 32], seeds[32 * j:32 * j + 32])
-        assert P[j] == r["proof"], "proof %d differs from the C oracle" % j
+    P, C = bp.prove_batch(gens, circ, label, case["values"], case["blindings"], case["seeds"], B)
+    fc.check_digests("c2_poseidon2_cube_x4096", case, P, C)
     assert bp.verify_batch(gens, circ, label, P, C, B) == [True] * B
     pt, wf = bp.verify_batch_combined(gens, circ, label, P, C, B, bytes(range(32)))
     assert wf and pt == bytes(32)

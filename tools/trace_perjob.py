@@ -19,7 +19,7 @@ rows = [(short(n), s, e, q) for n, s, e, q in con.execute("select name, start, e
 msm = [r for r in rows if r[0] == "k_msm_fixed2"]
 hq = collections.Counter(r[3] for r in msm).most_common(1)[0][0]
 on = [r for r in rows if r[3] == hq]
-asm = [r for r in on if r[0] == "K_assemble"]
+asm = [r for r in rows if r[0] == "K_assemble"]   # (on the job's tail stream when the last IPA rounds are handed off)
 if len(asm) < 4:
     sys.exit("need at least 4 batches in the trace")
 lo, hi, nb = asm[1][2], asm[-2][2], len(asm) - 3
@@ -32,6 +32,15 @@ print("# steady state over %d batches: period %.1f ms per batch, back stream bus
 print("# kernel | launches per batch | ms per batch | share of the back stream")
 for k, a in sorted(agg.items(), key=lambda kv: -kv[1][1])[: int(sys.argv[2]) if len(sys.argv) > 2 else 16]:
     print("%-28s | %5.1f | %8.2f | %5.1f %%" % (k, a[0] / nb, a[1] / nb, 100 * a[1] / tot))
+tail = [r for r in rows if r[3] != hq and r[0].startswith("K_") and r[0] not in ("K_rng_reduce", "K_transcript_init", "K_commit_v", "K_load_inputs") and r[1] >= lo and r[2] <= hi]
+if tail:
+    first = {}
+    spans = []
+    for a0, a1 in zip(asm[1:-2], asm[2:-1]):
+        t = [r for r in tail if a0[2] < r[2] <= a1[2]]
+        if t: spans.append((t[-1][2] - t[0][1]) / 1e6)
+    print("# IPA tail on the jobs' own streams: %d launches per batch, %.2f ms of kernel time per batch, %.1f ms from its first launch to K_assemble's end" %
+          (len(tail) // nb, sum(r[2] - r[1] for r in tail) / 1e6 / nb, sum(spans) / max(1, len(spans))))
 front = [r for r in rows if r[0] in ("k_rng_stream", "k_rng_rows", "k_witness_team") and r[1] >= lo and r[2] <= hi]
 fa = collections.defaultdict(lambda: [0, 0.0])
 for r in front:
