@@ -1,17 +1,21 @@
 #!/usr/bin/env python3
-"""bench.py — R1CS proofs/s for Poseidon-VSMT-4 depth-32 membership (BASELINE.json config[3]:
-batch 8192 sharded over 8 MI355X = 1024 proofs per GPU, weak scaling).
+"""bench.py — R1CS proofs/s of the batched prover on MI355X, for every BASELINE.json configuration.
 
-One "step" = one pass of the whole hot path over one batch of synthetic membership witnesses:
-V commitments -> Merlin transcript + TranscriptRng -> constraint synthesis (device witness
-program: Poseidon S-box inversions + MDS, 4-ary selection logic) -> A_I/A_O/S MSMs ->
-polynomial phase -> inner-product argument -> proof bytes.
+Default (`--config c4`): Poseidon-VSMT-4 depth-32 membership (BASELINE.json configs[3]: batch 8192 sharded over
+8 MI355X = 1024 proofs per GPU per step, weak scaling) — the metric BASELINE.json is quoted on.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--depth D]
+One "step" = one pass of the whole hot path over one batch of synthetic witnesses:
+V commitments -> Merlin transcript + TranscriptRng -> constraint synthesis (device witness program: Poseidon S-box
+inversions + MDS, tree selection logic) -> A_I/A_O/S MSMs -> polynomial phase -> inner-product argument -> proof bytes.
+`--fuse F` hands F consecutive steps (F x batch distinct proofs) to the device as ONE prove job: every table row a
+multiscalar multiplication fetches then serves F x batch proofs (config key `proofs_per_device_job`); all K steps are
+proved inside the timed region either way.
+
+    python bench.py [--config c2|c3|c4|c5|vsmt4_d128|vsmt2_d253] [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
-Prints ONE JSON line on rank 0 (contract in the task prompt), with `roofline` for the dominant
-kernel (batched fixed-base MSM, HIP-event timed on its own stream inside the library) and
+Prints ONE JSON line on rank 0 (contract in the task prompt), with `roofline` for the dominant kernel (batched fixed-base
+MSM, HIP-event timed on its own stream inside the library), `roofline_valu` (the integer ceiling that really binds it) and
 `cpu_baseline` (the oracle's C restatement timed on the host cores, rank 0, N=1 only).
 """
 import argparse
@@ -24,78 +28,66 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+wl = importlib.import_module("bulletproofs-r1cs-gadgets_amd.workloads")
 
-L = 2**252 + 27742317777372353535851937790883648493
+# names the tests and tools import from here
+L, synth_scalar, sc, synth_rng_seed = wl.L, wl.synth_scalar, wl.sc, wl.synth_rng_seed
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
-
-
-def synth_scalar(tag, i):
-    return int.from_bytes(hashlib.sha512(tag + i.to_bytes(8, "little")).digest(), "little") % L
-
-
-def sc(x):
-    return int(x).to_bytes(32, "little")
-
-
-def synth_rng_seed(global_index):
-    """SYNTHETIC stand-in for the 32 bytes upstream draws from thread_rng() in TranscriptRng::finalize: SHA-256("seed" ||
-    LE64(j)) of the global proof index - reproducible proofs for the parity check; a deployment passes
-    fresh randomness."""
-    return hashlib.sha256(b"seed" + int(global_index).to_bytes(8, "little")).digest()
-
-
-def build_workload(bp, levels, batch, n_leaves, seed_base):
-    """Synthetic leaves in a depth-`levels` 4-ary sparse Merkle tree (reference
-    src/gadget_vsmt_4.rs:363-419): leaves i->i for i in 1..=10 plus synthetic (idx, val) pairs;
-    proof j proves membership of leaf j mod n_leaves with its own blindings and rng seed."""
-    tree = bp.SparseMerkleTree(4, levels, 140)
-    leaves = [(i, i) for i in range(1, 11)]
-    mask = (1 << min(2 * levels, 250)) - 1   # an index is a Scalar (reference gadget_vsmt_4.rs:226-238): below 2^252
-    for k in range(max(0, n_leaves - 10)):
-        leaves.append((synth_scalar(b"leaf-idx", k) & mask, synth_scalar(b"leaf-val", k)))
-    leaves = leaves[:max(1, n_leaves)]
-    seen = set()
-    leaves = [(i, v) for i, v in leaves if not (i in seen or seen.add(i))]
-    # tree built on the device: every level of the affected nodes is ONE bulk Poseidon launch (bpr1cs_vsmt4_update_many)
-    tree.update_many(leaves)
-    lv, pp = tree.get_many([i for i, _ in leaves])
-    per = 32 * 3 * levels
-    paths = []
-    for k, (idx, val) in enumerate(leaves):
-        assert lv[32 * k:32 * k + 32] == sc(val)
-        paths.append(sc(val) + sc(idx) + pp[per * k:per * (k + 1)] + sc(0) + sc(101))
-    m = 4 + 3 * levels
-    values = b"".join(paths[j % len(paths)] for j in range(batch))
-    bl = bytearray()
-    for j in range(batch):
-        for k in range(m - 2):
-            bl += sc(synth_scalar(b"blind", (seed_base + j) * 1024 + k))
-        bl += bytes(64)  # statics are committed with blinding 0 (gadget_poseidon.rs:554-578)
-    seeds = b"".join(synth_rng_seed(seed_base + j) for j in range(batch))
-    return tree.root(), values, bytes(bl), seeds, m
-
-
 MADS_PER_TABLE_ADD = 7 * 99   # 7 field multiplications (ge_madd_t) x (81 limb products + 9 fold + 9 carry re-entries) v_mad_i64_i32 / v_mad_u64_u32
 
 
-def pmc_traffic(table_format):
-    """HBM bytes per k_msm_fixed2 launch from the committed rocprofv3 PMC passes of THIS kernel build (FETCH_SIZE and
-    WRITE_SIZE in separate runs of `bench.py --steps 3`, profiles/r02*_pmc_hbm_traffic.txt): -> (bytes, launches per step of
-    the profiled run, source) or (None, None, None).  Counter values are taken as reported (KB * 1024); MI355X_MICROARCH.md:
-    on gfx950 FETCH_SIZE under-reports wide coalesced streams 2x and is uncalibrated for the 128-byte gathers this kernel
-    issues, so the figure is a lower bound."""
+def build_workload(bp, levels, batch, n_leaves, seed_base):
+    """VSMT-4 membership workload through the default (device) front-end -> (root, values, blindings, seeds, m)"""
+    return wl.build_vsmt4(lambda a, l, pr: bp.SparseMerkleTree(a, l, pr), levels, batch, n_leaves, seed_base)
+
+
+# ---- the reference's benchmark configurations (BASELINE.json `configs`, SURVEY §8d) and the depths it ships.
+# batch = proofs per GPU per step; fuse = steps per device job; window = table window bits (0: from the free memory)
+CONFIGS = {
+    "c2": dict(metric="R1CS proofs/sec (Poseidon 2:1 cube-S-box preimage)", batch=4096, fuse=1, window=11, cpu_proofs=48,
+               workload="gadget_poseidon 2:1 Cube-S-box preimage proof (148 rounds; reference src/gadget_poseidon.rs:692-790)",
+               build=lambda bp, B, base, a: wl.poseidon_2to1_cube(bp, None, B, index_base=base)),
+    "c3": dict(metric="R1CS proofs/sec (Poseidon VSMT-2 depth-32)", batch=1024, fuse=2, window=11, cpu_proofs=2,
+               workload="gadget_vsmt_2 sparse-Merkle depth-32 membership (Poseidon 2:1 inverse S-box; reference src/gadget_vsmt_2.rs:262-352)",
+               build=lambda bp, B, base, a: wl.vsmt2(bp, None, 32, B, b"l2", 0xffffffff, 10**6 + base)),
+    "c4": dict(metric=None, batch=1024, fuse=2, window=11, cpu_proofs=2,
+               workload=None,
+               build=lambda bp, B, base, a: wl.vsmt4(bp, None, a.depth, B, a.leaves if a.leaves > 0 else B, base)),
+    "c5": dict(metric="R1CS proofs/sec (MiMC-322 preimage + set membership)", batch=8192, fuse=1, window=11, cpu_proofs=32,
+               workload="gadget_mimc preimage + gadget_set_membership (k = 7) on one prover (reference src/gadget_mimc.rs:92-175, src/gadget_set_membership.rs:93-171)",
+               build=lambda bp, B, base, a: wl.mimc_set_membership(B, index_base=base)),
+    "vsmt4_d128": dict(metric="R1CS proofs/sec (Poseidon VSMT-4 depth-128, as shipped)", batch=128, fuse=1, window=0, cpu_proofs=1,
+                       workload="gadget_vsmt_4 at the depth the reference ships (TreeDepth = 128, src/gadget_vsmt_4.rs:25): n = 74 624, N = 131 072",
+                       build=lambda bp, B, base, a: wl.vsmt4(bp, None, 128, B, B, base)),
+    "vsmt2_d253": dict(metric="R1CS proofs/sec (Poseidon VSMT-2 depth-253, as shipped)", batch=64, fuse=1, window=0, cpu_proofs=1,
+                       workload="gadget_vsmt_2 at the depth the reference ships (TreeDepth = 253, src/gadget_vsmt_2.rs:23): n = 143 704, N = 262 144",
+                       build=lambda bp, B, base, a: wl.vsmt2(bp, None, 253, B, b"l253", (1 << 250) - 1, 2 * 10**6 + base)),
+}
+
+
+def pmc_profile(kind, table_format):
+    """Figures of the dominant kernel from the committed rocprofv3 PMC passes of THIS kernel build (separate --pmc runs of
+    `bench.py --steps 3`, profiles/r0*_pmc_*.txt), newest round first.
+    kind "traffic": FETCH_SIZE + WRITE_SIZE per launch -> (bytes, proofs per launch of the profiled run, source).  Counter
+    values are taken as reported (KB * 1024); MI355X_MICROARCH.md: on gfx950 FETCH_SIZE under-reports wide coalesced streams
+    2x and is uncalibrated for the 128-byte gathers this kernel issues, so the figure is a lower bound.
+    kind "clock": GRBM_GUI_ACTIVE / 8 XCDs / duration -> (GHz, source)."""
     import glob
     import re
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r02*_pmc_hbm_traffic.txt")), reverse=True):
+    name = "pmc_hbm_traffic" if kind == "traffic" else "pmc_clock"
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r0*_%s.txt" % name)), reverse=True):
         text = open(path).read()
-        lps = re.search(r"launches_per_step=(\d+)", text)
-        if ("table_format=%d" % table_format) not in text or not lps:
-            continue
         for line in text.split("\n"):
-            if line.startswith("k_msm_fixed2"):
-                f = [x.strip() for x in line.split("|")]
-                return (float(f[2]) + float(f[3])) * 1024.0, float(lps.group(1)), os.path.relpath(path, ROOT)
-    return None, None, None
+            if not line.startswith("k_msm_fixed2"):
+                continue
+            f = [x.strip() for x in line.split("|")]
+            if kind == "traffic":
+                ppl = re.search(r"proofs_per_launch=(\d+)", text)
+                if ("table_format=%d" % table_format) not in text or not ppl:
+                    break
+                return (float(f[2]) + float(f[3])) * 1024.0, float(ppl.group(1)), os.path.relpath(path, ROOT)
+            return float(f[2]) / 8.0 / (float(f[3]) * 1e-3) / 1e9, os.path.relpath(path, ROOT)
+    return (None, None, None) if kind == "traffic" else (None, None)
 
 
 def cpu_info():
@@ -128,47 +120,65 @@ def cpu_info():
     return model, os.cpu_count() or 1, usable, quota
 
 
-def cpu_baseline(levels, root, values, blindings, seeds, m, n_proofs, max_threads):
+PHASES = ["gadget synthesis", "V commitments + TranscriptRng", "A_I/A_O/S multiscalar mults", "flatten + polynomials + T commitments",
+          "IPA: L/R multiscalar mults", "IPA: generator folds (two-point Straus per element) + scalar folds"]
+
+
+def cpu_baseline(w, n_proofs, max_threads):
     """Oracle leg, same run, same inputs, host cores of this box: the C restatement (oracle/c) proves witnesses of the batch
-    (gadget synthesis + prove, as reference src/gadget_vsmt_4.rs:421-435; generator setup excluded) (i) on ONE thread (the
-    reference is single-threaded) and (ii) on all usable cores, one proof per thread.  -> (dict, proofs of (i))."""
+    (gadget synthesis + prove, the reference's timed region, e.g. src/gadget_vsmt_4.rs:421-435; generator setup excluded)
+    (i) `n_proofs` on ONE thread (the reference is single-threaded), with the seconds per phase, and (ii) a few proofs per
+    worker process on every CPU this process is entitled to.  -> (dict, proofs of (i))."""
+    import ctypes
+    import math
     try:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         from cref import COracle  # noqa
     except Exception as e:  # pragma: no cover
         return {"value": None, "unit": "proofs/s", "cores": 0, "kind": "port", "sample": "oracle/c not built: %r" % (e,)}, None
     o = COracle()
-    t0 = time.time()
-    circ = o.compile_vsmt4(levels, 140, root)
-    t_setup = time.time() - t0
 
-    def one(j):
-        return o.prove_vsmt4(circ, values[j * m * 32:(j + 1) * m * 32], blindings[j * m * 32:(j + 1) * m * 32], seeds[32 * j:32 * j + 32])
+    def one(j, **kw):
+        return o.prove_case(w["gadget"], w["ip"], w["sp"], w["label"], *wl.slice_proof(w, j), **kw)
     t0 = time.time()
-    proofs = [one(j) for j in range(n_proofs)]
+    shape = one(0, prove=False)
+    N = 1 << max(0, shape["n"] - 1).bit_length()
+    o.lib.oracle_warm_gens(N)      # generator setup is outside the timed region (reference :386-387)
+    t_setup = time.time() - t0
+    n_proofs = max(1, min(n_proofs, w["B"]))
+    phase = [0.0] * 6
+    ph = (ctypes.c_double * 6)()
+    proofs = []
+    t0 = time.time()
+    for j in range(n_proofs):
+        proofs.append(one(j)["proof"])
+        o.lib.oracle_last_phase_seconds(ph)
+        phase = [a + b for a, b in zip(phase, ph)]
     dt1 = time.time() - t0
     model, logical, usable, quota = cpu_info()
-    import math
-    threads = max(1, min(usable, max_threads, len(seeds) // 32, math.ceil(quota) if quota else usable))
-    # all cores this process is entitled to (affinity mask and cgroup CPU quota): one proof per WORKER PROCESS (forked after the generators are warm; the children only run the C oracle and
-    # leave through os._exit).  Threads of one process would serialise on the kernel's mmap lock: the oracle allocates and frees
-    # hundreds of MB per proof (256 threads: 30x slower per proof than one thread alone).
+    threads = max(1, min(usable, max_threads, w["B"], math.ceil(quota) if quota else usable))
+    per_worker = max(1, min(w["B"] // threads, int(math.ceil(4.0 / max(dt1 / n_proofs, 1e-3)))))   # ~4 s of work per worker
+    # one WORKER PROCESS per CPU (forked after the generators are warm; the children only run the C oracle and leave through
+    # os._exit).  Threads of one process would serialise on the kernel's mmap lock: the oracle allocates and frees hundreds
+    # of MB per proof (256 threads: 30x slower per proof than one thread alone).
     sys.stdout.flush()
     t0 = time.time()
     kids = []
     for k in range(threads):
-        r, w = os.pipe()
+        r, wr = os.pipe()
         pid = os.fork()
         if pid == 0:
             code = 1
             try:
                 os.close(r)
-                pf = one(k)
-                os.write(w, hashlib.sha256(pf).digest())
+                h = hashlib.sha256()
+                for i in range(per_worker):
+                    h.update(one(k * per_worker + i)["proof"])
+                os.write(wr, h.digest())
                 code = 0
             finally:
                 os._exit(code)
-        os.close(w)
+        os.close(wr)
         kids.append((pid, r))
     digests = []
     for pid, r in kids:
@@ -177,37 +187,42 @@ def cpu_baseline(levels, root, values, blindings, seeds, m, n_proofs, max_thread
         os.waitpid(pid, 0)
     dtn = time.time() - t0
     assert all(len(d) == 32 for d in digests), "a CPU worker failed"
-    assert digests[:n_proofs] == [hashlib.sha256(p).digest() for p in proofs[:min(n_proofs, threads)]]
-    return ({"value": threads / dtn, "unit": "proofs/s", "cores": threads, "kind": "port",
-             "single_thread": {"value": n_proofs / dt1, "proofs": n_proofs, "seconds": dt1},
+    tot = sum(phase) or 1.0
+    return ({"value": threads * per_worker / dtn, "unit": "proofs/s", "cores": threads, "kind": "port",
+             "single_thread": {"value": n_proofs / dt1, "proofs": n_proofs, "seconds": dt1,
+                               "phase_seconds_per_proof": {k: v / n_proofs for k, v in zip(PHASES, phase)}},
              "cpu_model": model, "logical_cpus": logical, "usable_cpus": usable, "cgroup_cpu_quota": quota,
-             "sample": "%d proofs of the same workload (VSMT-4 depth %d, gadget synthesis + prove), one per worker process on %d CPUs, %.1f s wall "
-                       "(%.0f core-seconds); single thread: %d proof(s) in %.1f s; C restatement (oracle/c: 5x51-bit field, Pippenger / Straus), "
-                       "not dalek-AVX2; generator setup (%.1f s) excluded"
-                       % (threads, levels, threads, dtn, threads * dtn, n_proofs, dt1, t_setup)}, proofs)
+             "sample": "%d proofs of the same workload (gadget synthesis + prove), %d per worker process on %d CPUs, %.1f s wall (%.0f core-seconds); "
+                       "single thread: %d proof(s) in %.1f s = %s; C restatement of the reference's algorithm (oracle/c: 5x51-bit field, Pippenger "
+                       "multiscalar mults, per-element width-5-NAF Straus generator folds as curve25519-dalek's serial backend does them), not "
+                       "dalek-AVX2; generator setup (%.1f s) excluded"
+                       % (threads * per_worker, per_worker, threads, dtn, threads * dtn, n_proofs, dt1,
+                          ", ".join("%s %.0f %%" % (k, 100 * v / tot) for k, v in zip(PHASES, phase)), t_setup)}, proofs)
 
 
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--config", default="c4", choices=sorted(CONFIGS), help="BASELINE.json configuration (c4 = the headline metric)")
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=24, help="timed batches; the pipeline is empty at both ends of the timed region, so the first batch's front phase (~0.19 s, nothing to overlap with) is paid once per run: +190/K ms per step")
+    ap.add_argument("--steps", type=int, default=24, help="timed batches; the pipeline is empty at both ends of the timed region, so the first job's front phase (nothing to overlap with) is paid once per run")
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=1024, help="proofs per GPU per step")
-    ap.add_argument("--depth", type=int, default=32, help="4-ary tree levels (BASELINE: 32)")
-    ap.add_argument("--leaves", type=int, default=0, help="distinct synthetic leaves cycled over the batch (0 = one per proof of the batch)")
-    ap.add_argument("--cpu-proofs", type=int, default=2, help="proofs timed on ONE thread of the CPU oracle (0 = skip the CPU leg)")
-    ap.add_argument("--cpu-threads", type=int, default=128, help="upper bound of the all-cores CPU run (one proof per thread)")
+    ap.add_argument("--batch", type=int, default=0, help="proofs per GPU per step (0 = the configuration's)")
+    ap.add_argument("--fuse", type=int, default=0, help="steps handed to the device as ONE prove job (0 = the configuration's; c4: 2)")
+    ap.add_argument("--depth", type=int, default=32, help="c4 only: 4-ary tree levels (BASELINE: 32)")
+    ap.add_argument("--leaves", type=int, default=0, help="c4 only: distinct synthetic leaves cycled over the batch (0 = one per proof of a device job)")
+    ap.add_argument("--cpu-proofs", type=int, default=-1, help="proofs timed on ONE thread of the CPU oracle (0 = skip the CPU leg, -1 = the configuration's)")
+    ap.add_argument("--cpu-threads", type=int, default=128, help="upper bound of the all-cores CPU run")
     ap.add_argument("--table-format", type=int, default=-1, help="fixed-base table storage: 0 packed 96 B, 1 limb form in 128-B slots, -1 automatic")
-    ap.add_argument("--pipeline", type=int, default=2, help="batches in flight (1 = synchronous)")
+    ap.add_argument("--pipeline", type=int, default=2, help="device jobs in flight (1 = synchronous)")
     ap.add_argument("--latency-cus", type=int, default=-1, help="CUs reserved for the latency-bound kernels (-1 = library default)")
     ap.add_argument("--team", type=int, default=0, help="witness team size 4/8/16 (0 = library default)")
     ap.add_argument("--rng-mode", type=int, default=-1, help="TranscriptRng chain mapping: 0 auto, 1 lane-parallel, 2 state per thread (-1 = library default)")
     ap.add_argument("--unfold", type=int, default=4, help="IPA rounds computed from the un-folded generator tables")
-    ap.add_argument("--fuse", type=int, default=1, help="steps (batches of --batch proofs) handed to the device as ONE prove job: every table row fetched serves F x batch proofs")
     ap.add_argument("--shared-back", type=int, default=-1, help="jobs in flight share the scratch of their back phases (-1 = library default)")
     ap.add_argument("--tail-rounds", type=int, default=-1, help="final IPA rounds enqueued on the job's own tail stream (-1 = library default, 0 = all on the heavy stream)")
-    ap.add_argument("--window", type=int, default=11, help="fixed-base table window bits (11: 23 adds/term, 148 / 198 GB of tables at capacity 32768)")
+    ap.add_argument("--window", type=int, default=-1, help="fixed-base table window bits (-1 = the configuration's; 11: 23 adds/term, 198 GB of tables at capacity 32768; 0 = from the free memory)")
     args = ap.parse_args()
+    cfg = CONFIGS[args.config]
 
     import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -225,10 +240,10 @@ def main():
     lib = bp.load_library()
     lib.bpr1cs_set_device(local_rank)
     bp.load_gadgets_library()
+    window = cfg["window"] if args.window < 0 else args.window
     if args.unfold >= 0:
         lib.bpr1cs_set_unfold_rounds(args.unfold)
-    if args.window > 0:
-        lib.bpr1cs_set_window_bits(args.window)
+    lib.bpr1cs_set_window_bits(window)
     lib.bpr1cs_set_table_format(args.table_format)
     if args.team > 0:
         lib.bpr1cs_set_witness_team(args.team)
@@ -241,16 +256,16 @@ def main():
     if args.shared_back >= 0:
         lib.bpr1cs_set_shared_back(args.shared_back)
 
-    levels, B = args.depth, args.batch
-    F = max(1, args.fuse)
+    B = args.batch if args.batch > 0 else cfg["batch"]
+    F = max(1, args.fuse if args.fuse > 0 else cfg["fuse"])
     Bj = B * F                                      # proofs per device job
-    args.steps = ((max(1, args.steps) + F - 1) // F) * F
+    steps = max(1, args.steps)
     t0 = time.time()
-    n_leaves = args.leaves if args.leaves > 0 else Bj
-    root, values, blindings, seeds, m = build_workload(bp, levels, Bj, n_leaves, rank * Bj)
+    w = cfg["build"](bp, Bj, rank * Bj, args)      # inputs of one device job: F steps' worth of distinct proofs (own leaves, blindings, seeds)
     t_witness = time.time() - t0
+    m, label = w["m"], w["label"]
     t0 = time.time()
-    circ = bp.CompiledGadget("vsmt_4", [levels, 140], [root])
+    circ = bp.CompiledGadget(w["gadget"], w["ip"], w["sp"])
     t_compile = time.time() - t0
     N = 1 << (circ.n - 1).bit_length()
     t0 = time.time()
@@ -264,49 +279,53 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def begin():
-        return bp.ProveJob(gens, circ, b"VSMT", values, blindings, seeds, Bj)
+    def begin(nsteps=F):
+        nb = B * nsteps
+        return bp.ProveJob(gens, circ, label, w["values"][:nb * m * 32], w["blindings"][:nb * m * 32], w["seeds"][:nb * 32], nb)
 
     def stats():
         a, b, c = bp.last_msm_stats(lib)
         return a, b, c, bp.last_timings(lib)
 
-    # Software pipeline of depth `--pipeline` over the K steps: the next batch is enqueued (on its own
-    # HIP stream pair) before the previous one is collected, so its latency-bound RNG / witness phase
-    # overlaps the VALU-bound MSM / IPA phase.  All K batches start and finish inside the timed region.
+    # Software pipeline of depth `--pipeline` over the device jobs: the next job is enqueued (on its own HIP streams) before
+    # the previous one is collected, so its latency-bound RNG / witness phase overlaps the VALU-bound MSM / IPA phase.  EXACTLY
+    # `steps` steps are proved inside the timed region: steps // F jobs of F steps and one shorter job for the remainder.
     depth = max(1, args.pipeline)
     proofs = None
     for _ in range(args.warmup):
         proofs, _ = begin().finish()
+    plan = [F] * (steps // F) + ([steps % F] if steps % F else [])
     barrier()
     t0 = time.perf_counter()
-    msm_ms, msm_launches, msm_terms, phases = 0.0, 0, 0, [0.0] * 6
+    acc = {"ms": 0.0, "launches": 0, "terms": 0, "phases": [0.0] * 6}
     inflight = []
-    for k in range(args.steps // F):
-        inflight.append(begin())
-        if len(inflight) >= depth:
-            proofs, _ = inflight.pop(0).finish()
-            a, b, c, ph = stats()
-            msm_ms += a; msm_launches += b; msm_terms += c
-            phases = [x + y for x, y in zip(phases, ph)]
-    while inflight:
-        proofs, _ = inflight.pop(0).finish()
+
+    def collect():
+        pf, _ = inflight.pop(0).finish()
         a, b, c, ph = stats()
-        msm_ms += a; msm_launches += b; msm_terms += c
-        phases = [x + y for x, y in zip(phases, ph)]
+        acc["ms"] += a; acc["launches"] += b; acc["terms"] += c
+        acc["phases"] = [x + y for x, y in zip(acc["phases"], ph)]
+        return pf
+    for ns in plan:
+        inflight.append(begin(ns))
+        if len(inflight) >= depth:
+            proofs = collect()
+    while inflight:
+        proofs = collect()
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
         t = torch.tensor([dt], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    msm_ms, msm_launches, msm_terms, phases = acc["ms"], acc["launches"], acc["terms"], acc["phases"]
 
-    # Outside the timed region, on every rank: cross-proof batched verification of the last batch
+    # Outside the timed region, on every rank: cross-proof batched verification of one job's proofs
     # (bpr1cs_verify_batch_combined) and the path's only exchange step, an all_gather of one 32-byte point per rank.
     batched = None
     comms = None
     try:
-        _, comms = begin().finish()
+        proofs, comms = begin().finish()
         sh = importlib.import_module("bulletproofs-r1cs-gadgets_amd.sharding")
         # one-shot calls are noisy (first-use allocations): both forms run twice, the faster run is reported
         tb = ts = float("inf")
@@ -315,7 +334,7 @@ def main():
             torch.cuda.synchronize()
             t1 = time.perf_counter()
             try:   # fresh randomness for the weights (include/bpr1cs.h: batch_seed must not be predictable)
-                pt, wf = bp.verify_batch_combined(gens, circ, b"VSMT", proofs, comms, Bj, os.urandom(32), index_base=rank * Bj)
+                pt, wf = bp.verify_batch_combined(gens, circ, label, proofs, comms, Bj, os.urandom(32), index_base=rank * Bj)
             except Exception:  # keep the collective below matched on every rank
                 pt, wf = b"\xff" * 32, False
             pts, all_wf = sh.gather_partial_points(pt, wf, device="cuda" if dist is not None else None)
@@ -324,7 +343,7 @@ def main():
             # the multi-GPU form: shared-base MSM split by base range over the ranks (all_gather of the combined scalar vectors)
             torch.cuda.synchronize()
             t1 = time.perf_counter()
-            accepted_split = sh.verify_sharded(bp, gens, circ, b"VSMT", proofs, comms, Bj, rank, world, rank * Bj, device="cuda" if dist is not None else None) and accepted_split
+            accepted_split = sh.verify_sharded(bp, gens, circ, label, proofs, comms, Bj, rank, world, rank * Bj, device="cuda" if dist is not None else None) and accepted_split
             ts = min(ts, time.perf_counter() - t1)
         batched = {"accepted_all": accepted, "proofs": Bj * world, "proofs_per_s": Bj * world / tb,
                    "split_shared_base": {"accepted_all": accepted_split, "proofs_per_s": Bj * world / ts,
@@ -334,40 +353,46 @@ def main():
         batched = {"error": repr(e)}
 
     if rank == 0:
-        steps = max(1, args.steps)
         value = world * B * steps / dt
         n = circ.n
         lgN = N.bit_length() - 1
         alg_bytes_per_proof = 576 * n + 448 * N + 64 * lgN - 96
-        # dominant kernel: algorithmic bytes = 64 B per scalar*point term + 32 B per output (MSM_BYTES(t) = 64 t + 32)
-        msm_alg_bytes = 64.0 * msm_terms + 32.0 * msm_launches * Bj
+        # dominant kernel: algorithmic bytes = 64 B per scalar*point term + 32 B per output (MSM_BYTES(t) = 64 t + 32);
+        # every launch of the kernel is counted (commit sums, L/R of the un-folded rounds, the folded generators)
+        launches_per_job = msm_launches / max(1, len(plan))
+        msm_alg_bytes = 64.0 * msm_terms + 32.0 * launches_per_job * B * steps
         achieved = (msm_alg_bytes / 1e9) / (msm_ms / 1e3) if msm_ms > 0 else None
         tinfo = gens.table_info()
-        traffic, traffic_lps, traffic_src = pmc_traffic(tinfo["format"]) if (Bj == 1024 and levels == 32 and args.window == 11) else (None, None, None)
-        launches_per_step = msm_launches / steps
+        default_knobs = args.config == "c4" and args.depth == 32 and tinfo["window_bits"] == 11 and args.unfold == 4
+        traffic, traffic_ppl, traffic_src = pmc_profile("traffic", tinfo["format"]) if default_knobs else (None, None, None)
+        clock_ghz, clock_src = pmc_profile("clock", tinfo["format"]) if default_knobs else (None, None)
         # integer ceilings, measured NOW on this device by the library's probes (bpr1cs_device_rates, ~80 ms each)
         mad_rate, madd_chain_rate = bp.device_rates(0.08, lib)
         adds = msm_terms * tinfo["windows"]
         adds_per_s = adds / (msm_ms / 1e3) if msm_ms > 0 else None
+        metric = cfg["metric"] or "R1CS proofs/sec (Poseidon VSMT-4 depth-%d)" % args.depth
+        workload = cfg["workload"] or "gadget_vsmt_4 sparse-Merkle depth-%d membership (Poseidon 4:1 inverse S-box, 148 rounds)" % args.depth
         out = {
-            "metric": "R1CS proofs/sec (Poseidon VSMT-4 depth-%d)" % levels, "value": value, "unit": "proofs/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / steps,
+            "metric": metric, "value": value, "unit": "proofs/s",
+            "n_gpus": world, "steps": steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
-            "config": {"workload": "gadget_vsmt_4 sparse-Merkle depth-%d membership (Poseidon 4:1 inverse S-box, 148 rounds)" % levels,
+            "config": {"workload": workload, "name": args.config,
                        "batch_per_gpu": B, "global_batch": B * world, "n_multipliers": n, "padded_n": N, "constraints": circ.q,
                        "commitments": m, "proof_bytes": circ.proof_len, "sharding": "independent proofs per rank, no collective",
-                       "synthetic_leaves": n_leaves, "steps_per_device_job": F, "proofs_per_device_job": Bj, "jobs_in_flight": depth, "ipa_unfold_rounds": args.unfold,
+                       "steps_per_device_job": F, "proofs_per_device_job": Bj, "device_jobs": len(plan), "jobs_in_flight": depth,
+                       "ipa_unfold_rounds": args.unfold,
                        "table_window_bits": tinfo["window_bits"], "table_windows": tinfo["windows"], "table_format": tinfo["format"],
                        "table_bytes": tinfo["bytes"]},
-            "roofline": {"bound": "hbm", "kernel": "k_msm_fixed2 (batched fixed-base MSM over the generator tables; a launch carries 1-3 sums)",
+            "roofline": {"bound": "hbm", "kernel": "k_msm_fixed2 (batched fixed-base MSM over the generator tables; a launch carries 1-4 sums)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
-                         "traffic": (traffic * traffic_lps / launches_per_step) if (traffic and launches_per_step) else None,
+                         "traffic": (traffic * Bj / traffic_ppl) if traffic else None,
                          "traffic_source": traffic_src,
                          "traffic_note": "PMC FETCH_SIZE + WRITE_SIZE per launch of the same kernel build and configuration, from the named profile (separate "
-                                         "rocprofv3 --pmc passes; rescaled by launches per step if the profiled run grouped the sums differently); as reported by the counters: "
-                                         "on gfx950 FETCH_SIZE under-reports wide reads 2x and is uncalibrated for 128-byte gathers - a lower bound",
-                         "avg_launch_ms": (msm_ms / msm_launches) if msm_launches else None, "launches_per_step": launches_per_step,
+                                         "rocprofv3 --pmc passes; scaled by proofs per launch if the profiled run fused fewer steps); as reported by the "
+                                         "counters: on gfx950 FETCH_SIZE under-reports wide reads 2x and is uncalibrated for 128-byte gathers - a lower bound",
+                         "avg_launch_ms": (msm_ms / msm_launches) if msm_launches else None, "launches_per_step": msm_launches / steps,
+                         "launches_per_device_job": launches_per_job,
                          "alg_bytes_per_launch": (msm_alg_bytes / msm_launches) if msm_launches else None,
                          "note": "achieved/frac use ALGORITHMIC bytes (64 B per scalar*point term); the kernel is bound by integer multiply-add issue "
                                  "and by the power its table gathers cost (DVFS), not by HBM bandwidth - see roofline_valu and DESIGN.md"},
@@ -381,24 +406,27 @@ def main():
                               "mad_lane_ops_per_s": mad_rate, "mads_per_table_add": MADS_PER_TABLE_ADD,
                               "ge_madd_t_chain_G_per_s": madd_chain_rate / 1e9,
                               "frac_of_madd_chain": (adds_per_s / madd_chain_rate) if adds_per_s else None,
+                              "effective_clock_ghz": clock_ghz, "effective_clock_source": clock_src,
                               "note": "peak = sustained v_mad_i64_i32 lane-ops/s measured in this run (bpr1cs_device_rates) / 693 multiply-adds per "
-                                      "table addition; ge_madd_t chain = the same additions on register operands (no gathers); zero scalars / zero "
-                                      "digits are counted in `achieved`"},
+                                      "table addition; ge_madd_t chain = the same additions on register operands (no gathers); effective clock of the "
+                                      "kernel = GRBM_GUI_ACTIVE / 8 XCDs / duration from the named profile of this build; zero scalars / zero digits "
+                                      "are counted in `achieved`"},
             "hbm_frac_whole_path": value / world * alg_bytes_per_proof / (HBM_PEAK_GBS * 1e9),
-            "phase_ms_per_step": {k: v / steps for k, v in zip(["total", "inputs+commitV", "rng||witness", "commit_msm", "poly", "ipa"], phases)},
+            "phase_ms_per_device_job": {k: v / len(plan) for k, v in zip(["total", "inputs+commitV", "rng||witness", "commit_msm", "poly", "ipa"], phases)},
             "setup_s": {"witness_trees": t_witness, "circuit_compile": t_compile, "generator_tables": t_gens},
         }
-        # outside the timed region: the device verifier (Verifier::verify, one mega-check MSM per proof) on the last batch
+        # outside the timed region: the device verifier (Verifier::verify, one mega-check MSM per proof) on one job's proofs
         try:
             tv = time.perf_counter()
-            oks = bp.verify_batch(gens, circ, b"VSMT", proofs, comms, Bj)
+            oks = bp.verify_batch(gens, circ, label, proofs, comms, Bj)
             tv = time.perf_counter() - tv
             out["verify"] = {"accepted": sum(oks), "of": Bj, "proofs_per_s": Bj / tv, "note": "bpr1cs_verify_batch, not part of `value`"}
         except Exception as e:  # pragma: no cover
             out["verify"] = {"error": repr(e)}
         out["verify_batched"] = batched
-        if world == 1 and args.cpu_proofs > 0:
-            cb, cproofs = cpu_baseline(levels, root, values, blindings, seeds, m, args.cpu_proofs, args.cpu_threads)
+        n_cpu = cfg["cpu_proofs"] if args.cpu_proofs < 0 else args.cpu_proofs
+        if world == 1 and n_cpu > 0:
+            cb, cproofs = cpu_baseline(w, n_cpu, args.cpu_threads)
             out["cpu_baseline"] = cb
             if cproofs is not None:
                 out["parity_vs_cpu_oracle"] = all(cproofs[j] == proofs[j] for j in range(len(cproofs)))

@@ -195,7 +195,7 @@ def check_two_threads_two_handles(lib, glib, rounds=3):
     name = "bound_check"
     gname, ip, sp, _, cap = fc.case(name, 0)
     batch = 3
-    ob = common.oracle_batch(lambda j: fc.case(name, j)[3], cap, 2 * batch)
+    ob = common.oracle_batch(lambda j: fc.case(name, j)[3], cap, 2 * batch, key=name)
     circ = bp.CompiledGadget(gname, ip, sp, lib=lib, glib=glib)
     m = ob["m"]
     errors = []

@@ -17,10 +17,23 @@ def oracle_gens(cap):
     return _BP[cap]
 
 
-def oracle_batch(scenario_fn, cap, batch, nbl=512, satisfiable=True):
+_OB_CACHE = {}
+
+
+def oracle_batch(scenario_fn, cap, batch, nbl=512, satisfiable=True, key=None):
     """Prove `batch` scenarios with the oracle; returns dict with everything the library needs.
     `satisfiable=False`: the witness violates the circuit on purpose (the proof bytes are still deterministic and
-    must match; the oracle's verifier must reject them)."""
+    must match; the oracle's verifier must reject them).  `key`: the oracle's work is a pure function of the named case -
+    computed once per test session (the 4-level tree circuits take half a minute per proof in pure Python)."""
+    if key is not None and (key, cap, batch) in _OB_CACHE:
+        return _OB_CACHE[(key, cap, batch)]
+    out = _oracle_batch(scenario_fn, cap, batch, nbl, satisfiable)
+    if key is not None:
+        _OB_CACHE[(key, cap, batch)] = out
+    return out
+
+
+def _oracle_batch(scenario_fn, cap, batch, nbl, satisfiable):
     obp = oracle_gens(cap)
     out = dict(values=b"", blindings=b"", seeds=b"", wires=b"", proofs=[], comms=[], traces=[])
     for j in range(batch):

@@ -120,7 +120,7 @@ def check_compiled(lib, glib, name, batch, unfold=4, gens_cache={}):
     """compile the gadget with the C++ front-end, prove a batch with the DEVICE witness program,
     compare proof bytes with the oracle (which synthesises on its own)."""
     gname, ip, sp, _, cap = case(name, 0)
-    ob = common.oracle_batch(lambda j: case(name, j)[3], cap, batch, satisfiable=not (name.endswith("pr1_zero") or name.endswith("_violated")))
+    ob = common.oracle_batch(lambda j: case(name, j)[3], cap, batch, satisfiable=not (name.endswith("pr1_zero") or name.endswith("_violated")), key=name)
     circ = bp.CompiledGadget(gname, ip, sp, lib=lib, glib=glib)
     assert (circ.n, circ.q, circ.m) == (ob["n"], ob["q"], ob["m"]), (circ.n, circ.q, circ.m, ob["n"], ob["q"], ob["m"])
     assert circ.has_witness_program
@@ -153,7 +153,7 @@ def check_macro_vs_plain(lib, glib, name, batch):
 
 def check_prove_single(glib, name):
     gname, ip, sp, sc, cap = case(name, 0)
-    ob = common.oracle_batch(lambda j: case(name, 0)[3], cap, 1)
+    ob = common.oracle_batch(lambda j: case(name, 0)[3], cap, 1, key=name)
     m = ob["m"]
     vals = [ob["values"][32 * i:32 * i + 32] for i in range(m)]
     bls = [ob["blindings"][32 * i:32 * i + 32] for i in range(m)]
@@ -267,7 +267,7 @@ def check_prove_verify_roundtrip(lib, glib, name, batch=2):
     """the reference's own test assertion: prove -> verify accepts (device prover AND device verifier),
     plus rejection of a tampered proof / wrong commitment through both verifier entry points."""
     gname, ip, sp, _, cap = case(name, 0)
-    ob = common.oracle_batch(lambda j: case(name, j)[3], cap, batch)
+    ob = common.oracle_batch(lambda j: case(name, j)[3], cap, batch, key=name)
     circ = bp.CompiledGadget(gname, ip, sp, lib=lib, glib=glib)
     gens = bp.Gens(cap, lib=lib)
     P, C = bp.prove_batch(gens, circ, ob["label"], ob["values"], ob["blindings"], ob["seeds"], batch, wires=None)

@@ -62,7 +62,8 @@ def test_pyref_agrees_on_a_sample_of_the_fixture():
     blind = [int.from_bytes(bl[32 * i:32 * i + 32], "little") for i in range(case["m"])]
     pf, _ = sc.prove(common.PC, common.oracle_gens(1024), blind, seed)
     assert fc.proof_digest(pf) == FX["c5_mimc_set_x8192"]["proofs"][5]
-    case = fc.poseidon_2to1_cube(4)
+    import make_fullsize_digests as mk
+    case = fc.poseidon_2to1_cube(*mk.host_frontend(), 4)
     v, bl, seed = fc.slice_proof(case, 3)
     xl, xr = int.from_bytes(v[:32], "little"), int.from_bytes(v[32:64], "little")
     sc = S.poseidon_hash_2(xl, xr, g.CUBE, S.poseidon_params(140))

@@ -108,4 +108,6 @@ def test_zero_sbox_input_inside_a_full_wavefront_batch(hip_lib, hip_glib):
             n = r["n"]
             aO = [r["wires"][32 * (2 * n + i):32 * (2 * n + i) + 32] for i in range(n)]
             assert sum(1 for w in aO if w == sc_to_bytes(1)) == 2 * 49 - 2   # two of the 98 "always 1" output wires are 0 in this proof
-    assert bp.verify_batch(gens, circ, b"Poseidon_hash_2", [P[special]], [C[special]], 1) == [True]
+    # (no proof of this batch verifies: is_nonzero_gadget, src/gadget_zero_nonzero.rs:46-66, demands x * x^-1 = 1, which an S-box
+    # input of 0 cannot satisfy, and the other 95 claim proof 40's output - byte parity is the point here)
+    assert bp.verify_batch(gens, circ, b"Poseidon_hash_2", [P[special], P[0]], [C[special], C[0]], 2) == [False, False]
