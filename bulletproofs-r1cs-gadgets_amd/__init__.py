@@ -111,6 +111,11 @@ def load_library(path=None):
     lib.bpr1cs_gens_table_info.argtypes = [vp, ctypes.POINTER(u32), ctypes.POINTER(u32), ctypes.POINTER(u32), ctypes.POINTER(ctypes.c_uint64)]
     lib.bpr1cs_verify_batch_scalars.argtypes = [vp, vp, cp, sz, cp, cp, cp, cp, ctypes.c_uint64, sz, cp, cp, ctypes.POINTER(ctypes.c_int)]
     lib.bpr1cs_scalars_sum.argtypes = [cp, sz, sz, cp]
+    lib.bpr1cs_comm_unique_id.argtypes = [cp]
+    lib.bpr1cs_comm_create.argtypes = [cp, ctypes.c_int, ctypes.c_int, ctypes.POINTER(vp)]
+    lib.bpr1cs_comm_wrap.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.POINTER(vp)]
+    lib.bpr1cs_comm_destroy.argtypes = [vp]
+    lib.bpr1cs_verify_batch_sharded.argtypes = [vp, vp, cp, sz, cp, cp, cp, cp, ctypes.c_uint64, sz, vp, ctypes.POINTER(ctypes.c_int)]
     lib.bpr1cs_ipa_create.argtypes = [vp, vp, cp, cp, cp, cp, cp, sz, cp, cp, cp, cp]
     lib.bpr1cs_proof_parse.argtypes = [cp, sz, ctypes.POINTER(ProofStruct)]
     lib.bpr1cs_proof_serialize.argtypes = [ctypes.POINTER(ProofStruct), cp, sz, ctypes.POINTER(sz)]
@@ -298,6 +303,51 @@ def verify_batch_scalars(gens, circuit, label, proofs, commitments, batch, batch
     _chk(gens.lib.bpr1cs_verify_batch_scalars(gens.h, circuit.h, label, len(label), pf, cm or b"\0", seeds, batch_seed, index_base, batch,
                                               out, own, ctypes.byref(wf)))
     return out.raw, own.raw, bool(wf.value)
+
+
+class Comm:
+    """An RCCL communicator owned by the library (include/bpr1cs.h: bpr1cs_comm).  `unique_id()` on rank 0, hand the 128
+    bytes to the other ranks (any side channel, e.g. a torch.distributed broadcast), `Comm(id, rank, world)` on every rank."""
+
+    def __init__(self, uid, rank, world, lib=None):
+        self.lib = lib or load_library()
+        self.rank, self.world = rank, world
+        h = ctypes.c_void_p()
+        _chk(self.lib.bpr1cs_comm_create(uid, rank, world, ctypes.byref(h)))
+        self.h = h
+
+    @staticmethod
+    def unique_id(lib=None):
+        lib = lib or load_library()
+        buf = ctypes.create_string_buffer(128)
+        _chk(lib.bpr1cs_comm_unique_id(buf))
+        return buf.raw
+
+    def close(self):
+        if self.h:
+            self.lib.bpr1cs_comm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def verify_batch_sharded(gens, circuit, label, proofs, commitments, batch, comm=None, batch_seed=None, index_base=0, seeds=None):
+    """The multi-GPU batched verifier in one call per rank (bpr1cs_verify_batch_sharded: RCCL all_gathers inside the library)
+    -> True / False, the same on every rank.  comm = None: a job of one rank."""
+    if batch_seed is None:
+        batch_seed = os.urandom(32)
+    if seeds is None:
+        seeds = os.urandom(32 * batch)
+    pf = proofs if isinstance(proofs, (bytes, bytearray)) else b"".join(proofs)
+    cm = commitments if isinstance(commitments, (bytes, bytearray)) else b"".join(b"".join(c) for c in commitments)
+    ok = ctypes.c_int()
+    _chk(gens.lib.bpr1cs_verify_batch_sharded(gens.h, circuit.h, label, len(label), pf, cm or b"\0", seeds, batch_seed, index_base, batch,
+                                              comm.h if comm is not None else None, ctypes.byref(ok)))
+    return bool(ok.value)
 
 
 def scalars_sum(vectors, lib=None):

@@ -41,8 +41,25 @@ def _all_gather_bytes(payload, group=None, device=None):
     return [bytes(o.cpu().numpy().tobytes()) for o in outs]
 
 
-def verify_sharded(bp, gens, circuit, label, proofs, commitments, batch, rank, world, index_base, batch_seed=None, group=None, device=None):
-    """Batched verification of a job sharded over `world` ranks with the shared-base MSM computed ONCE per job:
+def make_comm(bp, rank, world, group=None, device=None, lib=None):
+    """An RCCL communicator owned by the library (bp.Comm) for the ranks of a torch.distributed job (or a single process):
+    rank 0 draws the unique id, the others receive it by a broadcast of 128 bytes."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or world == 1:
+        return bp.Comm(bp.Comm.unique_id(lib), 0, 1, lib=lib)
+    t = torch.frombuffer(bytearray(bp.Comm.unique_id(lib) if rank == 0 else bytes(128)), dtype=torch.uint8)
+    if device is not None:
+        t = t.to(device)
+    dist.broadcast(t, src=0, group=group)
+    return bp.Comm(bytes(t.cpu().numpy().tobytes()), rank, world, lib=lib)
+
+
+def verify_sharded(bp, gens, circuit, label, proofs, commitments, batch, rank, world, index_base, batch_seed=None, group=None, device=None, comm=None):
+    """Batched verification of a job sharded over `world` ranks with the shared-base MSM computed ONCE per job.
+    With `comm` (bp.Comm, an RCCL communicator) this is ONE call into the library: bpr1cs_verify_batch_sharded does the
+    steps below with ncclAllGather over xGMI.  Without it the same steps run here with torch.distributed collectives - the
+    form the CPU tests use (gloo has no RCCL):
       1. every rank: bpr1cs_verify_batch_scalars -> its combined scalar vector over B, B~, G.., H.. and the weighted sum of
          its proofs' own points;
       2. all_gather of the scalar vectors ((2N+2)*32 bytes per rank, ~2 MB at N = 32768), summed mod l (bpr1cs_scalars_sum);
@@ -50,6 +67,11 @@ def verify_sharded(bp, gens, circuit, label, proofs, commitments, batch, rank, w
       4. all_gather of (slice point, own-points sum, well-formed flag): 65 bytes per rank; accept iff the sum of all
          points is the identity and every rank was well-formed.
     Every rank returns the same verdict."""
+    if comm is not None:
+        try:
+            return bp.verify_batch_sharded(gens, circuit, label, proofs, commitments, batch, comm, batch_seed, index_base)
+        except Exception:
+            return False
     # a rank that fails locally still takes part in both collectives (with a zero vector and a "not well-formed" flag):
     # the other ranks must never be left waiting in an all_gather
     N = 1 << max(0, (circuit.n - 1).bit_length())

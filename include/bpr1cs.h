@@ -203,6 +203,27 @@ int bpr1cs_verify_batch_scalars(const bpr1cs_gens* gens, const bpr1cs_circuit* c
 /* out[i] = sum_r vectors[r*len + i] mod l   (count vectors of len canonical scalars; host side) */
 int bpr1cs_scalars_sum(const uint8_t* vectors, size_t count, size_t len, uint8_t* out);
 
+/* ---- the path's only exchange step behind the C ABI (north star: "RCCL over xGMI only for the batched-verifier
+ * final MSM").  One process per GPU; a bpr1cs_comm is an RCCL communicator: either created here from the 128-byte unique id
+ * that rank 0 draws and hands to the others out of band (exactly ncclGetUniqueId / ncclCommInitRank), or an ncclComm_t the
+ * host already has (passed as void*; the header needs no rccl.h, the library loads librccl on first use).
+ * bpr1cs_verify_batch_sharded = the whole multi-GPU batched verifier in one call per rank, every rank with its own proofs:
+ * bpr1cs_verify_batch_scalars -> ncclAllGather of the scalar vectors ((2N+2)*32 bytes per rank) -> sum mod l -> this rank's
+ * 1/world slice of the shared bases (bpr1cs_msm_fixed) -> ncclAllGather of 65 bytes per rank -> *accepted_out = 1 iff the sum
+ * of all points is the identity and every rank was well-formed (the same verdict on every rank).  `index_base`: disjoint
+ * per rank (e.g. rank * batch).  comm = NULL: a job of one rank (no RCCL involved).  Collective: every rank of the
+ * communicator must call it; a rank whose local part fails still takes part in both all_gathers and makes the job fail.
+ * The reference verifies one proof at a time on one core (src/gadget_vsmt_4.rs:479). */
+typedef struct bpr1cs_comm bpr1cs_comm;
+int bpr1cs_comm_unique_id(uint8_t id_out[128]);
+int bpr1cs_comm_create(const uint8_t id[128], int rank, int world, bpr1cs_comm** out);
+int bpr1cs_comm_wrap(void* nccl_comm, int rank, int world, bpr1cs_comm** out); /* not destroyed by bpr1cs_comm_destroy */
+void bpr1cs_comm_destroy(bpr1cs_comm* comm);
+int bpr1cs_verify_batch_sharded(const bpr1cs_gens* gens, const bpr1cs_circuit* circuit, const uint8_t* label, size_t label_len,
+                                const uint8_t* proofs, const uint8_t* commitments, const uint8_t* verifier_rng_seeds,
+                                const uint8_t* batch_seed /* 32 */, uint64_t index_base, size_t batch, const bpr1cs_comm* comm,
+                                int* accepted_out);
+
 /* `count` native Poseidon permutations (reference Poseidon_permutation, gadget_poseidon.rs:189-280; sbox_inverse
  * selects SboxType::Inverse / Cube): inputs/outputs are count*width canonical scalars.  With the Inverse S-box each
  * permutation costs ONE inversion (state carried as fractions, as in the witness program).  Used by the sparse

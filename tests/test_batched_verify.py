@@ -61,6 +61,11 @@ def check_batched_verify(lib, glib, batch=4):
     # wrong commitment
     cm2 = [list(c) for c in cm]; cm2[0][0] = cm[1][0]
     assert bp.verify_batch_combined(gens, circ, ob["label"], P, cm2, batch, SEED)[0] != bytes(32)
+    # the whole multi-GPU verifier behind ONE C entry point (bpr1cs_verify_batch_sharded), here as a job of one rank
+    assert bp.verify_batch_sharded(gens, circ, label, P, cm, batch, None, SEED) is True
+    assert bp.verify_batch_sharded(gens, circ, label, Pb, cm, batch, None, SEED) is False
+    assert bp.verify_batch_sharded(gens, circ, label, [bytes(bad3)] + P[1:], cm, batch, None, SEED) is False
+    assert bp.verify_batch_sharded(gens, circ, label, P, cm2, batch, None, SEED) is False
     return True
 
 
