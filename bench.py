@@ -326,6 +326,7 @@ def main():
     # (bpr1cs_verify_batch_combined) and the path's only exchange step, an all_gather of one 32-byte point per rank.
     batched = None
     comms = None
+    comm = None
     try:
         proofs, comms = begin().finish()
         sh = importlib.import_module("bulletproofs-r1cs-gadgets_amd.sharding")
@@ -435,9 +436,21 @@ def main():
                 out["parity_vs_cpu_oracle"] = all(cproofs[j] == proofs[j] for j in range(len(cproofs)))
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out), flush=True)
+        result_line = json.dumps(out)
+    else:
+        result_line = None
     if dist is not None:
         dist.destroy_process_group()
+    try:
+        comm.close()
+    except Exception:
+        pass
+    # the ONE JSON line is the last thing on stdout: RCCL prints a version banner through C stdio, whose buffer (a pipe is
+    # block-buffered) would otherwise be flushed at exit, after Python's line
+    import ctypes
+    ctypes.CDLL(None).fflush(None)
+    if result_line is not None:
+        print(result_line, flush=True)
 
 
 if __name__ == "__main__":

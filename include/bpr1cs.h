@@ -22,6 +22,18 @@
  * out of memory) are reported as BPR1CS_ERR_DEVICE / BPR1CS_ERR_OUT_OF_MEMORY; the
  * library never aborts the process.  All scalar inputs must be canonical (< l);
  * non-canonical scalars are refused with BPR1CS_ERR_INVALID_ARGUMENT.
+ *
+ * TIMING SIDE CHANNELS - this library is NOT constant time, the reference's prover is.  Upstream computes A_I, A_O, S
+ * (sums over the secret wires and blindings) with curve25519-dalek's constant-time `multiscalar_mul` and the L_k / R_k of
+ * the inner-product argument with `vartime_multiscalar_mul` (public after the fact).  Here every multiscalar
+ * multiplication runs through k_msm_fixed2, which (i) gathers table entries at addresses that are the signed digits of
+ * the secret scalars (memory-access pattern = secret), (ii) skips a term when the scalars of all 64 proofs of a
+ * wavefront are zero, and (iii) takes the a_O wires of Inverse-S-box triples in the form a_O - 1, so that a proof whose
+ * S-box input is 0 (an unsatisfiable witness: is_nonzero fails) makes its wavefront do work the others skip.  The witness
+ * kernel branches on committed bits.  Results are identical; only the time and the memory traffic depend on secrets.
+ * This is the usual posture of a throughput prover on a device the prover owns (nobody else can observe its caches or
+ * timing); do not run it where an untrusted party shares the GPU or can time individual batches of a victim's witnesses.
+ * Secrets are wiped from device memory before their blocks return to the allocator (upstream: clear_on_drop).
  */
 #ifndef BPR1CS_H
 #define BPR1CS_H

@@ -93,6 +93,54 @@ __global__ void __launch_bounds__(256) k_inst(uint32_t* out, uint32_t seed) {
     out[t] = (uint32_t)(a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7) ^ (uint32_t)(d0 + d1 + d2 + d3 + d4 + d5 + d6 + d7);
 }
 
+// Kill-test of a 3x3-block Karatsuba field multiplication: 9 signed 29-bit limbs as three blocks of
+// three, six 3x3 block products (54 multiply-adds) instead of nine (81), against the same routine with the schoolbook
+// product - both in plain C++ with the same fold (2^261 = 1216) and the same carry chain, so the only difference is
+// 27 v_mad_i64_i32 less against 18 32-bit and ~43 64-bit additions more.
+__device__ inline void mul3(const int32_t* a, const int32_t* b, int64_t* c) {  // c[0..4] = a[0..2] * b[0..2]
+    c[0] = (int64_t)a[0] * b[0];
+    c[1] = (int64_t)a[0] * b[1] + (int64_t)a[1] * b[0];
+    c[2] = (int64_t)a[0] * b[2] + (int64_t)a[1] * b[1] + (int64_t)a[2] * b[0];
+    c[3] = (int64_t)a[1] * b[2] + (int64_t)a[2] * b[1];
+    c[4] = (int64_t)a[2] * b[2];
+}
+__device__ inline fe fold_carry(int64_t* c) {  // 17 columns -> 9 limbs
+    for (int k = 0; k < 8; k++) c[k] += 1216 * (c[k + 9] >> 0);
+    fe r; int64_t cy = 0;
+    for (int k = 0; k < 9; k++) { int64_t v = c[k] + cy; r.v[k] = (int32_t)(v & 0x1fffffff); cy = v >> 29; }
+    r.v[0] += (int32_t)(cy * 1216);
+    return r;
+}
+template <int KARATSUBA>
+__device__ inline fe fe_mul_cpp(const fe& a, const fe& b) {
+    int64_t c[17];
+    if (!KARATSUBA) {
+        for (int k = 0; k < 17; k++) c[k] = 0;
+#pragma unroll
+        for (int i = 0; i < 9; i++)
+#pragma unroll
+            for (int j = 0; j < 9; j++) c[i + j] += (int64_t)a.v[i] * b.v[j];
+    } else {
+        int32_t a01[3], a02[3], a12[3], b01[3], b02[3], b12[3];
+        for (int i = 0; i < 3; i++) {
+            a01[i] = a.v[i] + a.v[3 + i]; a02[i] = a.v[i] + a.v[6 + i]; a12[i] = a.v[3 + i] + a.v[6 + i];
+            b01[i] = b.v[i] + b.v[3 + i]; b02[i] = b.v[i] + b.v[6 + i]; b12[i] = b.v[3 + i] + b.v[6 + i];
+        }
+        int64_t p00[5], p11[5], p22[5], p01[5], p02[5], p12[5];
+        mul3(a.v, b.v, p00); mul3(a.v + 3, b.v + 3, p11); mul3(a.v + 6, b.v + 6, p22);
+        mul3(a01, b01, p01); mul3(a02, b02, p02); mul3(a12, b12, p12);
+        for (int k = 0; k < 17; k++) c[k] = 0;
+        for (int k = 0; k < 5; k++) {
+            c[k] += p00[k];
+            c[3 + k] += p01[k] - p00[k] - p11[k];
+            c[6 + k] += p02[k] - p00[k] - p22[k] + p11[k];
+            c[9 + k] += p12[k] - p11[k] - p22[k];
+            c[12 + k] += p22[k];
+        }
+    }
+    return fold_carry(c);
+}
+
 template <int OP>
 __global__ void __launch_bounds__(256) k_prim(uint32_t* out, const uint32_t* in, int iters) {
     uint32_t t = threadIdx.x + blockIdx.x * 256;
@@ -103,6 +151,8 @@ __global__ void __launch_bounds__(256) k_prim(uint32_t* out, const uint32_t* in,
     if (OP == 2) { for (int i = 0; i < iters; i++) a = fe_sub(a, b); }
     if (OP == 7) { for (int i = 0; i < iters; i++) a = fe_sq(a); }
     if (OP == 9) { for (int i = 0; i < iters; i++) a = fe_mul_f(a, b); }
+    if (OP == 11) { for (int i = 0; i < iters; i++) a = fe_mul_cpp<0>(a, b); }
+    if (OP == 12) { for (int i = 0; i < iters; i++) a = fe_mul_cpp<1>(a, b); }
     if (OP == 10) {
         ge p = ge_basepoint();
         p.X = fe_add(p.X, a);
@@ -185,13 +235,15 @@ int main() {
     CHK(hipEventElapsedTime(&ms, e0, e1)); double n = (double)blocks * threads * (ITER / 4) * 16; \
     printf("%-36s %8.3f ms  (%.2f cyc/wave-inst/SIMD @2.4GHz)\n", cn[M], ms, 1024.0 * 2.4e9 * 64 / (n / (ms * 1e-3))); }
     RUN_CHAIN(0) RUN_CHAIN(1) RUN_CHAIN(2)
-    const char* pn[] = {"fe_mul", "fe_add", "fe_sub", "sc_mul", "ge_madd", "ge_dbl", "ge_add", "fe_sq", "sc_invert", "fe_mul_f", "ge_madd_t"};
+    const char* pn[] = {"fe_mul", "fe_add", "fe_sub", "sc_mul", "ge_madd", "ge_dbl", "ge_add", "fe_sq", "sc_invert", "fe_mul_f", "ge_madd_t", "fe_mul C++ 9x9", "fe_mul C++ Karatsuba 3x3 blocks"};
 #define RUN_PRIM(OP, IT) { hipLaunchKernelGGL(k_prim<OP>, dim3(blocks), dim3(threads), 0, 0, out, in, 8); CHK(hipDeviceSynchronize()); \
     CHK(hipEventRecord(e0)); hipLaunchKernelGGL(k_prim<OP>, dim3(blocks), dim3(threads), 0, 0, out, in, IT); CHK(hipEventRecord(e1)); CHK(hipEventSynchronize(e1)); \
     CHK(hipEventElapsedTime(&ms, e0, e1)); double n = (double)blocks * threads * IT; \
-    printf("%-18s %8.3f ms  %8.2f Gop/s  (%.0f cyc/wave-op/SIMD @2.4GHz)\n", pn[OP], ms, n / ms / 1e6, 1024.0 * 2.4e9 * 64 / (n / (ms * 1e-3))); }
+    printf("%-32s %8.3f ms  %8.2f Gop/s  (%.0f cyc/wave-op/SIMD @2.4GHz)\n", pn[OP], ms, n / ms / 1e6, 1024.0 * 2.4e9 * 64 / (n / (ms * 1e-3))); }
     RUN_PRIM(0, 2048) RUN_PRIM(1, 2048) RUN_PRIM(2, 2048) RUN_PRIM(3, 2048) RUN_PRIM(4, 256) RUN_PRIM(5, 256) RUN_PRIM(6, 256) RUN_PRIM(7, 2048) RUN_PRIM(8, 16) RUN_PRIM(9, 2048) RUN_PRIM(10, 256)
     // the same primitives under sustained load (DVFS: the chip clocks to its power budget)
     RUN_PRIM(0, 65536) RUN_PRIM(10, 16384)
+    // Karatsuba kill-test: schoolbook against 3x3-block Karatsuba, identical fold / carry code, sustained
+    RUN_PRIM(11, 65536) RUN_PRIM(12, 65536)
     return 0;
 }
