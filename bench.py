@@ -44,7 +44,7 @@ def build_workload(bp, levels, batch, n_leaves, seed_base):
 # ---- the reference's benchmark configurations (BASELINE.json `configs`) and the depths it ships.
 # batch = proofs per GPU per step; fuse = steps per device job; window = table window bits (0: from the free memory)
 CONFIGS = {
-    "c2": dict(metric="R1CS proofs/sec (Poseidon 2:1 cube-S-box preimage)", batch=4096, fuse=1, window=11, cpu_proofs=48,
+    "c2": dict(metric="R1CS proofs/sec (Poseidon 2:1 cube-S-box preimage)", batch=4096, fuse=2, window=11, cpu_proofs=48,
                workload="gadget_poseidon 2:1 Cube-S-box preimage proof (148 rounds; reference src/gadget_poseidon.rs:692-790)",
                build=lambda bp, B, base, a: wl.poseidon_2to1_cube(bp, None, B, index_base=base)),
     "c3": dict(metric="R1CS proofs/sec (Poseidon VSMT-2 depth-32)", batch=1024, fuse=2, window=11, cpu_proofs=2,

@@ -521,7 +521,7 @@ static void poseidon_perm_constraints(prover* p, lc st[6], const poseidon_params
 }
 /* vanilla_merkle_merkle_tree_4_verif_gadget (gadget_vsmt_4.rs:199-312).
    committed layout: 0 leaf, 1 index, 2..2+3L nodes, then statics [0, 101] */
-static void vsmt4_gadget(prover* p, u32 levels, sc root, const poseidon_params* pp) {
+static void vsmt4_gadget(prover* p, u32 levels, sc root, const poseidon_params* pp, int inverse /* reference: 1, gadget_vsmt_4.rs:301 */) {
     lc prev = lc_var(VAR(VK_COMMITTED, 0));
     u32 st0 = VAR(VK_COMMITTED, 2 + 3 * levels), st1 = VAR(VK_COMMITTED, 3 + 3 * levels);
     lc cli = lc_new(); lc_push(&cli, VAR(VK_COMMITTED, 1), sc_neg(SC_R));
@@ -554,7 +554,7 @@ static void vsmt4_gadget(prover* p, u32 levels, sc root, const poseidon_params* 
         st[4] = lc_var(c3_1); lc_push(&st[4], c3_2, one); lc_push(&st[4], c3_3, one);
         st[5] = lc_var(st1);
         lc_free(&prev);
-        poseidon_perm_constraints(p, st, pp, 1);
+        poseidon_perm_constraints(p, st, pp, inverse);
         prev = st[1];
         for (int k = 0; k < 6; k++) if (k != 1) lc_free(&st[k]);
         exp4 = sc_mul(exp4, four);
@@ -600,7 +600,7 @@ static void lc_append(lc* dst, const lc* src) { for (u32 i = 0; i < src->n; i++)
 /* vanilla_merkle_merkle_tree_verif_gadget (gadget_vsmt_2.rs:171-209) with Poseidon_hash_2_constraints
    (gadget_poseidon.rs:445-468: inputs [statics[0], xl, xr, statics[1], statics[2], statics[3]]).
    committed layout: 0 leaf, 1..d index bits (LSB first), d+1..2d proof nodes (leaf level first), then 4 statics */
-static void vsmt2_gadget(prover* p, u32 depth, sc root, const poseidon_params* pp) {
+static void vsmt2_gadget(prover* p, u32 depth, sc root, const poseidon_params* pp, int inverse /* reference: 1, gadget_vsmt_2.rs:203 */) {
     lc prev = lc_new();
     u32 sb = 1 + 2 * depth;
     sc one = SC_R;
@@ -617,7 +617,7 @@ static void vsmt2_gadget(prover* p, u32 depth, sc root, const poseidon_params* p
         st[1] = lc_var(VAR(VK_OUT, l1)); lc_push(&st[1], VAR(VK_OUT, l2), one);
         st[2] = lc_var(VAR(VK_OUT, r1)); lc_push(&st[2], VAR(VK_OUT, r2), one);
         st[3] = lc_var(VAR(VK_COMMITTED, sb + 1)); st[4] = lc_var(VAR(VK_COMMITTED, sb + 2)); st[5] = lc_var(VAR(VK_COMMITTED, sb + 3));
-        poseidon_perm_constraints(p, st, pp, 1);
+        poseidon_perm_constraints(p, st, pp, inverse);
         prev = st[1];
         for (int k = 0; k < 6; k++) if (k != 1) lc_free(&st[k]);
     }
@@ -804,10 +804,10 @@ static void load_params(poseidon_params* pp, const u8* blob, u32 partial_rounds)
 }
 
 /* ============================================================ exported entry points (ctypes) */
-/* gadget: 0 = vsmt_4 (ip0 = levels, ip1 = partial rounds, sp = root)
+/* gadget: 0 = vsmt_4 (ip0 = levels, ip1 = partial rounds, ip2 = S-box of the tree: 1 inverse (the reference) / 0 cube, sp = root)
            1 = poseidon_hash_2, 2 = poseidon_hash_4 (ip0 = sbox 0 cube/1 inverse, ip1 = partial rounds, sp = output)
            3 = bound_check (ip0 = bits, min = ip1|ip2<<32, max = ip3|ip4<<32)
-           4 = vsmt_2 (ip0 = depth, ip1 = partial rounds, sp = root)
+           4 = vsmt_2 (ip0 = depth, ip1 = partial rounds, ip2 = S-box as for vsmt_4, sp = root)
            5 = mimc (ip0 = rounds, sp = image; aux blob = the round constants, rounds * 32 bytes)
            6 = set_membership (ip0 = k, then k items as lo,hi words)
            7 = mimc preimage + set_membership on one prover (ip0 = rounds, ip1 = k, items; sp = image; aux blob = constants)
@@ -821,13 +821,13 @@ size_t oracle_prove(int gadget, const u32* ip, const u8* sp, const u8* poseidon_
     prover* p = pr_new(values, blindings, m);
     poseidon_params pp;
     if (gadget <= 2 || gadget == 4) load_params(&pp, poseidon_blob, ip[1]);
-    if (gadget == 0) vsmt4_gadget(p, ip[0], sc_from_bytes(sp), &pp);
+    if (gadget == 0) vsmt4_gadget(p, ip[0], sc_from_bytes(sp), &pp, ip[2] != 0);
     else if (gadget == 1) poseidon_hash_gadget(p, 2, (int)ip[0], sc_from_bytes(sp), &pp);
     else if (gadget == 2) poseidon_hash_gadget(p, 4, (int)ip[0], sc_from_bytes(sp), &pp);
     else if (gadget == 3) {
         u8 ab[32], bb[32]; sc_tobytes(p->v[1], ab); sc_tobytes(p->v[2], bb); u64 a, b; memcpy(&a, ab, 8); memcpy(&b, bb, 8);
         bound_check_gadget(p, a, b, (u64)ip[3] | ((u64)ip[4] << 32), (u64)ip[1] | ((u64)ip[2] << 32), ip[0]);
-    } else if (gadget == 4) vsmt2_gadget(p, ip[0], sc_from_bytes(sp), &pp);
+    } else if (gadget == 4) vsmt2_gadget(p, ip[0], sc_from_bytes(sp), &pp, ip[2] != 0);
     else if (gadget == 5 || gadget == 7) {
         u32 rounds = ip[0];
         sc* consts = malloc(32 * (size_t)(rounds ? rounds : 1));

@@ -33,6 +33,8 @@ class COracle:
         """-> dict(proof, comms, n, q, m[, wires]).  `aux`: the gadget's auxiliary table when it is not the Poseidon
         constants (MiMC round constants, rounds * 32 bytes)."""
         m = len(values) // 32
+        if gadget in (VSMT_4, VSMT_2) and len(ip) == 2:
+            ip = list(ip) + [1]   # S-box of the tree's Poseidon: Inverse unless the caller asks for Cube (ip[2] = 0)
         blob = self.blob if aux is None else aux
         ipa = (ctypes.c_uint32 * max(1, len(ip)))(*ip)
         proof = ctypes.create_string_buffer(1 + 32 * (13 + 64)) if prove else None

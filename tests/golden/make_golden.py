@@ -12,9 +12,12 @@ import common
 import frontend_cases as fc
 
 CASES = ["factors", "bound_check", "bound_check_64", "set_membership", "poseidon_hash_2_cube", "poseidon_hash_2_inverse",
-         "poseidon_hash_4_inverse", "vsmt_2_d3", "vsmt_4_l4"]
-out = {}
+         "poseidon_hash_4_inverse", "vsmt_2_d3", "vsmt_4_l4", "vsmt_2_cube", "vsmt_4_cube"]   # the last two: SURVEY §8f N4 (Cube-S-box trees)
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "proofs.json")
+out = json.load(open(OUT)) if os.path.exists(OUT) and "--all" not in sys.argv else {}   # existing vectors are kept as they are
 for name in CASES:
+    if name in out:
+        continue
     gname, ip, sp, _, cap = fc.case(name, 0)
     ob = common.oracle_batch(lambda j: fc.case(name, j)[3], cap, 2)
     out[name] = {"gadget": gname, "iparams": ip, "sparams": [int(s).to_bytes(32, "little").hex() if not isinstance(s, bytes) else s.hex() for s in sp],
@@ -23,4 +26,4 @@ for name in CASES:
                  "proofs": [p.hex() for p in ob["proofs"]], "commitments": [[c.hex() for c in cs] for cs in ob["comms"]],
                  "wires_sha256": hashlib.sha256(ob["wires"]).hexdigest()}
     print(name, ob["n"], ob["q"], ob["m"], len(ob["proofs"][0]))
-json.dump(out, open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "proofs.json"), "w"), indent=1)
+json.dump(out, open(OUT, "w"), indent=1)

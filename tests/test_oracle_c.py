@@ -17,7 +17,7 @@ def corc():
 
 
 CASES = {"bound_check_64": 3, "poseidon_hash_2_cube": 1, "poseidon_hash_2_inverse": 1, "poseidon_hash_4_inverse": 2, "vsmt_4_l4": 0,
-         "vsmt_2_d3": 4, "set_membership": 6}
+         "vsmt_2_d3": 4, "set_membership": 6, "vsmt_4_cube": 0, "vsmt_2_cube": 4}
 
 
 @pytest.mark.parametrize("name", list(CASES))
