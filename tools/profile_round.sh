@@ -4,9 +4,9 @@
 tag=${1:-rXX}; out=gpurun_out/$tag; mkdir -p $out
 export TMPDIR=/tmp
 B="--steps 12 --warmup 1 --cpu-proofs 0"
-timeout 900 python bench.py > $out/bench_default.log 2>&1; tail -1 $out/bench_default.log > $out/bench_default.json; cut -c1-200 $out/bench_default.json
-timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 8 --warmup 1 --cpu-proofs 0 > $out/bench_torchrun.log 2>&1; tail -1 $out/bench_torchrun.log > $out/bench_torchrun_1rank.json
-timeout 600 python bench.py --pipeline 1 --steps 6 --cpu-proofs 0 2>&1 | tail -1 > $out/bench_sync.json
+timeout 900 python bench.py 2> $out/bench_default.err | grep -a "^{" | tail -1 > $out/bench_default.json; cut -c1-200 $out/bench_default.json
+timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 8 --warmup 1 --cpu-proofs 0 2> $out/bench_torchrun.err | grep -a "^{" | tail -1 > $out/bench_torchrun_1rank.json
+timeout 600 python bench.py --pipeline 1 --steps 6 --cpu-proofs 0 2>/dev/null | grep -a "^{" | tail -1 > $out/bench_sync.json
 for c in c2 c3 c5 vsmt4_d128 vsmt2_d253; do
   s=12; [ $c = vsmt4_d128 ] && s=6; [ $c = vsmt2_d253 ] && s=4
   timeout 900 python bench.py --config $c --steps $s 2>&1 | grep -a "^{" | tail -1 > $out/bench_$c.json
