@@ -445,13 +445,16 @@ int bpr1cs_circuit_create(const bpr1cs_circuit_desc* d, bpr1cs_circuit** out) {
     for (uint32_t i = 0; i < nslots; i++) cnt[i + 1] += cnt[i];
     std::vector<uint32_t> fill(cnt.begin(), cnt.end() - 1), ent_row(cnt[nslots]);
     std::vector<sc> ent_coeff(cnt[nslots]);
+    const sc one_m = sc_one_mont(), minus_one_m = sc_neg(sc_one_mont());
     for (uint32_t j = 0; j < d->q; j++)
         for (uint32_t t = d->row_off[j]; t < d->row_off[j + 1]; t++) {
             uint32_t slot;
             if (slot_of(d->term_var[t], slot) == 1) {
                 uint32_t p = fill[slot]++;
-                ent_row[p] = j;
                 ent_coeff[p] = host_mont(d->term_coeff + 32 * (size_t)t);
+                // (q <= 2^26 was checked above: the two top bits of the row word are free for the +-1 flags of K_flatten_chunks)
+                ent_row[p] = j | (memcmp(&ent_coeff[p], &one_m, sizeof(sc)) == 0 ? 0x80000000u : 0u) |
+                             (memcmp(&ent_coeff[p], &minus_one_m, sizeof(sc)) == 0 ? 0x40000000u : 0u);
             }
         }
     upload(c->slot_off, cnt, s);

@@ -826,7 +826,8 @@ struct K_pair {
 #define FLATTEN_CHUNK 256u
 struct K_flatten_chunks {  // gid = c*B + b -> part[c][b]
     const uint32_t* chunk_lo;  // [nchunks + 1] entry ranges (chunks of one slot are consecutive)
-    const uint32_t* ent_row;
+    const uint32_t* ent_row;   // bit 31 / bit 30: the coefficient is +1 / -1 (most coefficients of the reference's gadgets are:
+                               // sums of wires - MiMC's linear combinations grow to ~160 such terms) - no multiplication then
     const sc* ent_coeff;  // Montgomery
     const sc* plo;
     const sc* phi;
@@ -835,8 +836,13 @@ struct K_flatten_chunks {  // gid = c*B + b -> part[c][b]
     HD void operator()(uint32_t g) const {
         uint32_t c = g / B, b = g % B;
         sc acc = sc_zero();
-        for (uint32_t t = chunk_lo[c]; t < chunk_lo[c + 1]; t++)
-            acc = sc_add(acc, sc_mul(pow_lookup(plo, phi, 2, H, B, ent_row[t] + 1, b), ent_coeff[t]));
+        for (uint32_t t = chunk_lo[c]; t < chunk_lo[c + 1]; t++) {
+            const uint32_t rw = ent_row[t];   // the same for every proof of a wavefront: the branches below do not diverge
+            sc zp = pow_lookup(plo, phi, 2, H, B, (rw & 0x3fffffffu) + 1, b);
+            if (rw & 0x80000000u) acc = sc_add(acc, zp);
+            else if (rw & 0x40000000u) acc = sc_sub(acc, zp);
+            else acc = sc_add(acc, sc_mul(zp, ent_coeff[t]));
+        }
         part[g] = acc;
     }
 };
