@@ -313,7 +313,7 @@ def main():
                 raise
             fused_fallback = "out of device memory with %d steps per device job: fell back to 1" % F
             F, Bj = 1, B
-            bp.release_cached_memory(lib)
+            gens.release_scratch()
             warm = [begin() for _ in range(depth)]
             for j in warm:
                 proofs, _ = j.finish()

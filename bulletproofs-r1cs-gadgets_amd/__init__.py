@@ -108,6 +108,7 @@ def load_library(path=None):
     lib.bpr1cs_circuit_macro_perms.restype = ctypes.c_int
     lib.bpr1cs_set_latency_cus.argtypes = [ctypes.c_int]
     lib.bpr1cs_gens_set_option.argtypes = [vp, ctypes.c_int, ctypes.c_int]
+    lib.bpr1cs_gens_release_scratch.argtypes = [vp]
     lib.bpr1cs_gens_table_info.argtypes = [vp, ctypes.POINTER(u32), ctypes.POINTER(u32), ctypes.POINTER(u32), ctypes.POINTER(ctypes.c_uint64)]
     lib.bpr1cs_verify_batch_scalars.argtypes = [vp, vp, cp, sz, cp, cp, cp, cp, ctypes.c_uint64, sz, cp, cp, ctypes.POINTER(ctypes.c_int)]
     lib.bpr1cs_scalars_sum.argtypes = [cp, sz, sz, cp]
@@ -162,6 +163,11 @@ class Gens:
     def set_option(self, option, value):
         """per-handle override of a per-call knob (OPT_UNFOLD_ROUNDS / OPT_RNG_MODE / OPT_WITNESS_TEAM; value < 0: process default)"""
         _chk(self.lib.bpr1cs_gens_set_option(self.h, option, value))
+
+    def release_scratch(self):
+        """drop the handle's back-phase arena and the allocator's cache (before a job of a very different shape)"""
+        _chk(self.lib.bpr1cs_gens_release_scratch(self.h))
+        self.lib.bpr1cs_release_cached_memory()
 
     def table_info(self):
         """-> dict(window_bits, windows, format, bytes) of the fixed-base tables"""

@@ -237,6 +237,12 @@ int bpr1cs_gens_table_info(const bpr1cs_gens* g, uint32_t* window_bits, uint32_t
     if (bytes) *bytes = (uint64_t)(2 + 2 * (size_t)g->cap) * g->tc.base_bytes();
     return BPR1CS_OK;
 }
+int bpr1cs_gens_release_scratch(bpr1cs_gens* g) {
+    if (!g) return BPR1CS_ERR_INVALID_ARGUMENT;
+    if (g->in_flight.load() > 0) return BPR1CS_ERR_INVALID_ARGUMENT;  // the jobs in flight are working in it
+    g->arena.release();
+    return BPR1CS_OK;
+}
 int bpr1cs_release_cached_memory(void) {
 #if !defined(BPR1CS_HOSTSIM)
     dev_pool().release_all();

@@ -135,6 +135,9 @@ int bpr1cs_gens_table_info(const bpr1cs_gens* g, uint32_t* window_bits, uint32_t
 #define BPR1CS_OPT_WITNESS_TEAM 2  /* bpr1cs_set_witness_team  */
 #define BPR1CS_OPT_TAIL_ROUNDS 3   /* bpr1cs_set_tail_rounds   */
 int bpr1cs_gens_set_option(bpr1cs_gens* g, int option, int value);
+/* hand the back-phase scratch arena of a handle (bpr1cs_set_shared_back; ~15 GB per 1024 proofs of the depth-32 circuit, kept
+ * between jobs) to the allocator's cache; BPR1CS_ERR_INVALID_ARGUMENT while a job of the handle is in flight */
+int bpr1cs_gens_release_scratch(bpr1cs_gens* g);
 /* give the device memory cached by the library's allocator (freed tables, workspaces) back to the driver */
 int bpr1cs_release_cached_memory(void);
 

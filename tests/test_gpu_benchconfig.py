@@ -56,6 +56,7 @@ def test_vsmt4_depth32_bench_configuration_two_jobs_in_flight(hip_lib, hip_glib,
     # ONE device job of 2024 proofs (bench.py --fuse 2 hands two steps to the device at once), the last IPA rounds on the
     # heavy stream instead of the job's tail stream: the same bytes
     hip_lib.bpr1cs_set_tail_rounds(0)
+    w11_gens.release_scratch()   # the arena is sized for 1024-proof jobs: growing it next to 234 GB of tables would hold both sizes for a moment
     try:
         P2, C2 = bp.prove_batch(w11_gens, circ, b"VSMT", values, blindings, seeds, BA + BB)
     finally:
