@@ -126,6 +126,20 @@ def check_validation(lib):
     }
     for what, (d, _keep) in cases.items():
         assert create(d) == -17, what
+    # Poseidon annotations: the input combinations of a permutation are checked like wop operands even when NO wop
+    # refers to them - a committed index >= m or an unknown kind there used to reach the device unchecked
+    class _Perm(ctypes.Structure):
+        _fields_ = [("params", ctypes.c_uint32), ("in_lc", ctypes.c_uint32 * 8), ("sbox_mul", ctypes.POINTER(ctypes.c_uint32))]
+    for what, bad_var in (("annotation: committed index >= m in an input combination", V(0, 7)),
+                          ("annotation: unknown variable kind in an input combination", V(9, 0)),
+                          ("annotation: input combination reads a wire of the permutation itself", V(1, 0))):
+        d, keep = _raw_desc(2, 1, 2, [0, 2], [V(1, 0), V(3, 1)], ok_wops, [0, 1, 2, 3, 4], ok_var + [bad_var])
+        pp = bp._PoseidonParams(2, 1, 0, 0, bytes(4 * 32), bytes(2 * 32))
+        sm = bp._u32arr([0])
+        perm = _Perm(0, (ctypes.c_uint32 * 8)(0, 3, 0, 0, 0, 0, 0, 0), sm)
+        d.n_poseidon_params, d.poseidon_params = 1, ctypes.cast(ctypes.pointer(pp), ctypes.c_void_p)
+        d.n_poseidon_perms, d.poseidon_perms = 1, ctypes.cast(ctypes.pointer(perm), ctypes.c_void_p)
+        assert create(d) == -17, what
     # non-canonical scalars: committed value, blinding, host wires, msm_fixed scalar, bpr1cs_msm scalar
     gname, ip, sp, sc0, cap = __import__("frontend_cases").case("bound_check", 0)
     ob = common.oracle_batch(lambda j: __import__("frontend_cases").case("bound_check", j)[3], cap, 1)
