@@ -1785,6 +1785,30 @@ extern "C" int bpr1cs_msm(const uint8_t* scalars, const uint8_t* points, size_t 
     CallScope scope(st);
     const uint32_t N = (uint32_t)n, VC = N < 4096 ? (N + 63) / 64 : 64;
     DevBuf<uint8_t> d_s(32 * n), d_p(32 * n), d_out(32);
+#if !defined(BPR1CS_HOSTSIM)
+    if (N >= 4096) {  // LDS-staged Pippenger buckets (kernels_hip.hpp): 26 windows x chunks workgroups, 512 buckets each in LDS
+        const uint32_t chunks = std::max<uint32_t>(1u, std::min<uint32_t>(64u, N / 2048u));
+        DevBuf<ge_cached> pc(n);
+        DevBuf<int16_t> dig((size_t)PIP_WINDOWS * n);
+        DevBuf<ge> part((size_t)PIP_WINDOWS * chunks), wsum(PIP_WINDOWS), res(1);
+        DevBuf<int> fail(1);
+        dev_h2d(d_s.p, scalars, 32 * n, st);
+        dev_h2d(d_p.p, points, 32 * n, st);
+        dev_zero(fail.p, sizeof(int), st);
+        launch(N, K_pip_prepare{d_s.p, d_p.p, pc.p, dig.p, fail.p, N}, st);
+        hipLaunchKernelGGL(k_pip_buckets, dim3(chunks, PIP_WINDOWS), dim3(256), 0, st, pc.p, dig.p, part.p, N, chunks);
+        HIPCHK(hipGetLastError());
+        launch(PIP_WINDOWS, K_ge_reduce{part.p, wsum.p, 1, PIP_WINDOWS * chunks, chunks}, st);
+        launch(1, K_pip_horner{wsum.p, res.p}, st);
+        launch(1, K_compress_one{res.p, d_out.p}, st);
+        int f = 0;
+        dev_d2h(out, d_out.p, 32, st);
+        dev_d2h(&f, fail.p, sizeof(int), st);
+        dev_zero(d_s.p, 32 * n, st);   // the scalars may be secret
+        dev_zero(dig.p, dig.bytes(), st);
+        return f ? BPR1CS_ERR_FORMAT : BPR1CS_OK;
+    }
+#endif
     DevBuf<ge_cached> vtab((size_t)VB_MULT * n);
     DevBuf<uint32_t> vdig((size_t)VB_WORDS * n);
     DevBuf<ge> part((size_t)VB_WINDOWS * VC), sum(VB_WINDOWS), res(1);

@@ -561,3 +561,98 @@ __global__ void __launch_bounds__(256) k_probe_madd(uint32_t* out, uint32_t iter
     for (int i = 0; i < 9; i++) o ^= (uint32_t)a.v[i];
     out[t] = o;
 }
+
+
+// ---------------------------------------------------------------- Pippenger for ONE large variable-base MSM (bpr1cs_msm, n >= 4096)
+// out = sum_i s_i P_i over arbitrary points: signed 10-bit windows, 26 windows, 512 buckets per window.  A workgroup owns one
+// (window, chunk of points) and keeps that window's 512 buckets in LDS (72 KB of the CU's 160: two workgroups per CU):
+//   1. bucket accumulation: every lane takes one point of the chunk per step and adds it to bucket |digit| - lanes of the
+//      workgroup that meet in a bucket are serialised by an ownership vote in LDS (the last writer of owner[bucket] goes first,
+//      the others retry: with 256 lanes on 512 buckets 1.3 rounds per step on average); __syncthreads_or tells when all are done;
+//   2. bucket reduction sum_m m * bucket[m] as a parallel suffix scan (9 steps) and a tree sum (9 steps) in LDS.
+// The chunk sums of a window are added by K_ge_reduce, the windows combined by k_pip_horner.  Straus (K_msm_var_*) stays for
+// small n, where 16 multiples per point cost less than 26 * 512 bucket operations.
+#define PIP_C 10
+#define PIP_WINDOWS 26u            // ceil(253 / 10); the top window holds 3 bits + a carry
+#define PIP_BUCKETS (1u << (PIP_C - 1))
+struct K_pip_prepare {  // gid = i < n : decompress, cached form, signed digits
+    const uint8_t* scalars;  // [n][32] canonical
+    const uint8_t* points;   // [n][32] compressed
+    ge_cached* pc;           // [n]
+    int16_t* dig;            // [PIP_WINDOWS][n]
+    int* fail;
+    uint32_t n;
+    HD void operator()(uint32_t g) const {
+        ge P;
+        if (!ge_decompress(points + 32 * (size_t)g, P)) { *fail = 1; P = ge_identity(); }
+        pc[g] = ge_to_cached(P);
+        sc s = sc_load_raw(scalars + 32 * (size_t)g);
+        int carry = 0;
+        for (uint32_t w = 0; w < PIP_WINDOWS; w++) {
+            uint32_t bit = w * PIP_C, wi = bit >> 5, sh = bit & 31u;
+            uint64_t v = s.v[wi];
+            if (wi + 1 < 8) v |= (uint64_t)s.v[wi + 1] << 32;
+            int d = (int)((v >> sh) & ((1u << PIP_C) - 1u)) + carry;
+            carry = d > (int)PIP_BUCKETS;
+            d -= carry << PIP_C;
+            dig[(size_t)w * n + g] = (int16_t)d;
+        }
+    }
+};
+__global__ void __launch_bounds__(256) k_pip_buckets(const ge_cached* pc, const int16_t* dig, ge* part, uint32_t n, uint32_t chunks) {
+    __shared__ ge bucket[PIP_BUCKETS];
+    __shared__ uint16_t owner[PIP_BUCKETS];
+    const uint32_t tid = threadIdx.x, c = blockIdx.x, w = blockIdx.y;
+    const uint32_t per = (n + chunks - 1) / chunks, lo = c * per, hi = lo + per < n ? lo + per : n;
+    for (uint32_t k = tid; k < PIP_BUCKETS; k += 256) bucket[k] = ge_identity();
+    __syncthreads();
+    const int16_t* dw = dig + (size_t)w * n;
+    for (uint32_t base = lo; base < hi; base += 256) {
+        const uint32_t i = base + tid;
+        const int d = i < hi ? (int)dw[i] : 0;
+        const uint32_t mag = (uint32_t)(d < 0 ? -d : d);
+        int pending = mag != 0;
+        ge_cached P;
+        if (pending) P = pc[i];
+        while (__syncthreads_or(pending)) {      // every lane that still has a point votes for its bucket; the last vote wins it
+            if (pending) owner[mag - 1] = (uint16_t)tid;
+            __syncthreads();
+            if (pending && owner[mag - 1] == tid) {
+                bucket[mag - 1] = ge_addsub(bucket[mag - 1], P, d < 0);
+                pending = 0;
+            }
+            __syncthreads();
+        }
+    }
+    // sum_m m * bucket[m-1] = sum_k suffix_k,  suffix_k = sum_{m >= k} bucket[m-1]: in-place scan, two buckets per lane
+    for (uint32_t off = 1; off < PIP_BUCKETS; off <<= 1) {
+        ge t[2];
+        bool have[2];
+        for (int r = 0; r < 2; r++) {
+            uint32_t k = tid + 256u * r;
+            have[r] = k + off < PIP_BUCKETS;
+            if (have[r]) t[r] = ge_add_ge(bucket[k], bucket[k + off]);
+        }
+        __syncthreads();
+        for (int r = 0; r < 2; r++)
+            if (have[r]) bucket[tid + 256u * r] = t[r];
+        __syncthreads();
+    }
+    for (uint32_t off = PIP_BUCKETS >> 1; off >= 1; off >>= 1) {
+        if (tid < off) bucket[tid] = ge_add_ge(bucket[tid], bucket[tid + off]);
+        __syncthreads();
+    }
+    if (tid == 0) part[(size_t)w * chunks + c] = bucket[0];
+}
+struct K_pip_horner {  // single thread: sum_w 2^(10 w) * wsum[w]
+    const ge* wsum;  // [PIP_WINDOWS]
+    ge* out;
+    HD void operator()(uint32_t) const {
+        ge acc = wsum[PIP_WINDOWS - 1];
+        for (int w = (int)PIP_WINDOWS - 2; w >= 0; w--) {
+            acc = ge_dbln<PIP_C>(acc);
+            acc = ge_add_ge(acc, wsum[w]);
+        }
+        out[0] = acc;
+    }
+};

@@ -261,7 +261,9 @@ int bpr1cs_ipa_create(const bpr1cs_gens* g, bpr1cs_transcript* t, const uint8_t*
                       const uint8_t* H_factors /* n*32 */, const uint8_t* a /* n*32 */, const uint8_t* b /* n*32 */, size_t n,
                       uint8_t* L_out /* lg n * 32 */, uint8_t* R_out /* lg n * 32 */, uint8_t* a_out /* 32 */, uint8_t* b_out /* 32 */);
 /* RistrettoPoint::vartime_multiscalar_mul over arbitrary (compressed) points: out = sum_i scalars[i] * points[i], on the
- * device (Straus with shared doublings, as the variable-base IPA rounds).  BPR1CS_ERR_FORMAT if a point does not decode. */
+ * device: Straus with shared doublings (as the variable-base IPA rounds) below 4096 terms, from there on Pippenger with the
+ * 512 signed-digit buckets of a window staged in LDS (26 windows x chunks workgroups; lanes that meet in a bucket take turns).
+ * BPR1CS_ERR_FORMAT if a point does not decode. */
 int bpr1cs_msm(const uint8_t* scalars /* n*32 canonical */, const uint8_t* points /* n*32 compressed */, size_t n, uint8_t* out /* 32 */);
 
 /* out = compress(sum of `count` compressed ristretto points); BPR1CS_ERR_FORMAT if one of them does not decode */

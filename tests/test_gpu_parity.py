@@ -98,3 +98,31 @@ def test_low_level_abi_on_device(hip_lib):
     pts = o.G[:64] + o.H[:37]                      # more terms than one chunk
     sc = [S.synth_scalar(b"lowmsm2", i) for i in range(len(pts))]
     assert common.bp.msm(sc, [p.compress() for p in pts], lib=hip_lib) == msm(sc, pts).compress()
+
+
+def test_large_variable_base_msm_pippenger_buckets(hip_lib):
+    """bpr1cs_msm with n >= 4096 takes the LDS-staged Pippenger path (kernels_hip.hpp: 26 windows x 512 buckets per
+    workgroup, bucket collisions inside a workgroup resolved by an ownership vote): against the C oracle's Pippenger on
+    4096, 5000 and 20 011 terms with random scalars, edge scalars (0, 1, 2^252, l - 1, every digit +-512), the SAME point many
+    times with the same scalar (every lane of a step votes for one bucket) and P next to -P."""
+    import subprocess, os
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle", "c")])
+    from cref import COracle
+    from pyref.ed import L
+    o = COracle()
+    bp = common.bp
+    gens = bp.Gens(4096, lib=hip_lib)
+    base = [gens.point(2, i) for i in range(4096)] + [gens.point(3, i) for i in range(4096)]
+    for n in (4096, 5000, 20011):
+        pts = [base[(7 * i) % len(base)] for i in range(n)]
+        sc = [S.synth_scalar(b"pip%d" % n, i) for i in range(n)]
+        edge = [0, 1, 2**252, L - 1, sum(512 << (10 * k) for k in range(25)), L - sum(512 << (10 * k) for k in range(25))]
+        sc[:len(edge)] = edge
+        for i in range(300, 700):            # one point, one scalar, 400 times in a row: a bucket with 256 voters per step
+            pts[i], sc[i] = base[5], sc[300]
+        sc[1000], sc[1001], pts[1001] = 12345, L - 12345, pts[1000]   # s * P + (-s) * P
+        got = bp.msm(sc, pts, lib=hip_lib)
+        assert got == o.msm(sc, pts), "n = %d" % n
+    with pytest.raises(bp.R1CSError):
+        bp.msm([1] * 4096, [b"\xff" * 32] + base[:4095], lib=hip_lib)   # a point that does not decode: FormatError on the Pippenger path too
