@@ -51,6 +51,8 @@ static std::atomic<int> g_merge_triples{1};  // A_I1: one merged table per Inver
 static std::atomic<int> g_witness_macro{1};  // use the Poseidon annotations of a circuit description (poseidon_team)
 static std::atomic<int> g_witness_team{8};   // lanes cooperating on one proof in k_witness_team (4, 8 or 16)
 static std::atomic<int> g_shared_back{1};    // the jobs in flight on a handle share the scratch of their back phases (DevArena)
+static std::atomic<int> g_tail_fused{0};     // 1: the IPA tail as ONE kernel (a wavefront per proof executes the recorded per-round steps) - measured
+                                             // alternative, slower: the steps are 1 to 1632 items wide per proof, separate launches pack 64 proofs per wavefront
 static std::atomic<int> g_tail_rounds{7};    // final IPA rounds (m_k <= 64 at 7) enqueued on the job's own tail stream instead of the shared heavy one
 static const uint32_t g_msm_target_threads = 1u << 21;  // (chunk, proof) threads per MSM launch
 struct BpOpts {  // per-handle overrides; -1 = process default
@@ -216,6 +218,7 @@ void bpr1cs_set_witness_team(int t) { g_witness_team = (t == 4 || t == 8) ? t : 
 void bpr1cs_set_witness_macro(int enable) { g_witness_macro = enable ? 1 : 0; }
 void bpr1cs_set_tail_rounds(int r) { g_tail_rounds = r < 0 ? 0 : r; }
 void bpr1cs_set_shared_back(int enable) { g_shared_back = enable ? 1 : 0; }
+void bpr1cs_set_tail_fused(int enable) { g_tail_fused = enable ? 1 : 0; }
 void bpr1cs_set_rng_mode(int mode) { g_rng_mode = (mode >= 1 && mode <= 5) ? mode : 0; }
 int bpr1cs_circuit_macro_perms(const bpr1cs_circuit* c) { return c ? (int)c->n_perms : 0; }
 void bpr1cs_set_window_bits(int w) { g_window_bits = w <= 0 ? 0 : (w < 4 ? 4 : (w > 12 ? 12 : w)); }  // 0 = choose from the free memory
@@ -792,6 +795,62 @@ static void run_flatten(const bpr1cs_circuit* c, uint32_t nslots, const sc* plo,
 // InnerProductProof::create for B independent proofs whose transcripts already hold ("dom-sep","ipp v1"), ("n", N).
 // Rounds 0..unfold-1 take L_k, R_k from the UN-folded generator tables with product scalars; at round `unfold` the
 // folded generators are materialised once and the remaining rounds are variable-base.
+// ---- the IPA tail as ONE launch (round 3): every kernel of the last rounds is per proof (gid = index * B + proof), so a
+// workgroup per proof can run them all back to back with a barrier in between - the functors are the ones the separate launches
+// use, recorded here as a list of steps instead of being launched (k_tail_program, kernels_hip.hpp).
+enum TailKind : uint32_t { TK_CROSS, TK_SUMP, TK_VBTAB, TK_VBDIG2, TK_VBWIN, TK_GERED, TK_HORNER, TK_FINISH2, TK_TLR, TK_FOLDAB, TK_FOLD2 };
+#define TAIL_F_BYTES 384
+struct TailStep {
+    uint32_t kind, count;   // count = work items per proof: the step runs functor(t * B + proof) for t < count
+    alignas(8) unsigned char f[TAIL_F_BYTES];
+};
+template <class F> struct tail_kind;
+template <> struct tail_kind<K_ipa_cross> { static const uint32_t v = TK_CROSS; };
+template <> struct tail_kind<K_sum_partials> { static const uint32_t v = TK_SUMP; };
+template <> struct tail_kind<K_ipa_vb_tab> { static const uint32_t v = TK_VBTAB; };
+template <> struct tail_kind<K_ipa_vb_dig2> { static const uint32_t v = TK_VBDIG2; };
+template <> struct tail_kind<K_ipa_vb_win> { static const uint32_t v = TK_VBWIN; };
+template <> struct tail_kind<K_ge_reduce> { static const uint32_t v = TK_GERED; };
+template <> struct tail_kind<K_ipa_vb_horner> { static const uint32_t v = TK_HORNER; };
+template <> struct tail_kind<K_pair<K_msm_finish>> { static const uint32_t v = TK_FINISH2; };
+template <> struct tail_kind<K_transcript_LR> { static const uint32_t v = TK_TLR; };
+template <> struct tail_kind<K_ipa_fold_ab> { static const uint32_t v = TK_FOLDAB; };
+template <> struct tail_kind<K_ipa_vb_fold2> { static const uint32_t v = TK_FOLD2; };
+#if !defined(BPR1CS_HOSTSIM)
+template <class F>
+__device__ inline void tail_run(const TailStep& st, uint32_t b, uint32_t tid, uint32_t B) {
+    const F& f = *reinterpret_cast<const F*>(st.f);
+    for (uint32_t t = tid; t < st.count; t += blockDim.x) f(t * B + b);
+}
+// one workgroup (= ONE wavefront: with four, 192 of the 256 lanes sat at barriers most of the time and their registers and wave
+// slots were taken from the co-running sums: measured 2476 against 2760 proofs/s) per proof; a step's work items are spread
+// over its lanes, steps are separated by a workgroup barrier (release / acquire at workgroup scope: what one lane wrote to
+// HBM for this proof the others read in the next step)
+__global__ void __launch_bounds__(64) k_tail_program(const TailStep* prog, uint32_t nsteps, uint32_t B) {
+    const uint32_t b = blockIdx.x, tid = threadIdx.x;
+    for (uint32_t s = 0; s < nsteps; s++) {
+        const TailStep& st = prog[s];
+        switch (st.kind) {   // uniform over the workgroup
+            case TK_CROSS: tail_run<K_ipa_cross>(st, b, tid, B); break;
+            case TK_SUMP: tail_run<K_sum_partials>(st, b, tid, B); break;
+            case TK_VBTAB: tail_run<K_ipa_vb_tab>(st, b, tid, B); break;
+            case TK_VBDIG2: tail_run<K_ipa_vb_dig2>(st, b, tid, B); break;
+            case TK_VBWIN: tail_run<K_ipa_vb_win>(st, b, tid, B); break;
+            case TK_GERED: tail_run<K_ge_reduce>(st, b, tid, B); break;
+            case TK_HORNER: tail_run<K_ipa_vb_horner>(st, b, tid, B); break;
+            case TK_FINISH2: tail_run<K_pair<K_msm_finish>>(st, b, tid, B); break;
+            case TK_TLR: tail_run<K_transcript_LR>(st, b, tid, B); break;
+            case TK_FOLDAB: tail_run<K_ipa_fold_ab>(st, b, tid, B); break;
+            case TK_FOLD2: tail_run<K_ipa_vb_fold2>(st, b, tid, B); break;
+            default: break;
+        }
+        __syncthreads();
+    }
+}
+#endif
+static void* host_stage_alloc(size_t n);
+static void host_stage_free(void* p);
+
 struct IpaIO {
     const bpr1cs_gens* g;
     uint32_t B, N, lgN, unfold;
@@ -822,7 +881,10 @@ struct IpaIO {
         DevBuf<ge> GH, vwin, vsum, vout;
         DevBuf<ge_cached> vtab;
         DevBuf<uint32_t> vdig;
+        DevBuf<TailStep> prog;          // the fused tail's step list on the device ...
+        TailStep* h_prog = nullptr;     // ... and its pinned staging copy (host_stage_alloc; released with the job)
     }* tail_keep = nullptr;
+    int tail_fused = 0;                 // 1: record the tail's launches as a step list and run them as ONE kernel
 #if !defined(BPR1CS_HOSTSIM)
     hipEvent_t* tail_event = nullptr;
 #endif
@@ -864,6 +926,22 @@ static IpaEnd enqueue_ipa(const IpaIO& io, dev_stream_t st, MsmStats* stats) {
     }
     sc* cpartp = nullptr; size_t cpart_n = 0;
     bool handed_off = false;
+    // launches that can belong to the tail go through `emit`: launched as they come, or - once the tail is being fused -
+    // recorded as steps of the tail program (same functor, same arguments)
+    std::vector<TailStep> steps;
+    bool fusing = false;
+    auto emit = [&](uint64_t total, const auto& f, bool wave) {
+        using F = typename std::decay<decltype(f)>::type;
+        static_assert(sizeof(F) <= TAIL_F_BYTES && std::is_trivially_copyable<F>::value, "tail step functor");
+        if (fusing) {
+            TailStep ts{};
+            ts.kind = tail_kind<F>::v;
+            ts.count = (uint32_t)(total / B);
+            memcpy(ts.f, &f, sizeof(F));
+            steps.push_back(ts);
+        } else if (wave) launch_wave(total, f, st);
+        else launch(total, f, st);
+    };
     for (uint32_t k = 0; k < lgN; k++) {
         uint32_t Nk = N >> k, mk = Nk >> 1;
         if (k == tail_from && k + 1 < lgN) {
@@ -898,6 +976,7 @@ static IpaEnd enqueue_ipa(const IpaIO& io, dev_stream_t st, MsmStats* stats) {
                 HIPCHK(hipStreamWaitEvent(io.tail_stream, *io.tail_event, 0));
                 st = io.tail_stream;
             }
+            fusing = io.tail_fused != 0;
 #endif
         }
         uint32_t cchunk, CC = pick_chunks(mk, B, 1u << 18, cchunk);
@@ -914,8 +993,8 @@ static IpaEnd enqueue_ipa(const IpaIO& io, dev_stream_t st, MsmStats* stats) {
             }
             cpart_n = (size_t)2 * CC * B;
         }
-        launch((uint64_t)CC * B, K_ipa_cross{a, bb, cpartp, B, mk, cchunk, CC}, st);
-        launch((uint64_t)2 * B, K_sum_partials{cpartp, crossp, B, CC}, st);
+        emit((uint64_t)CC * B, K_ipa_cross{a, bb, cpartp, B, mk, cchunk, CC}, false);
+        emit((uint64_t)2 * B, K_sum_partials{cpartp, crossp, B, CC}, false);
         uint8_t* Lout = io.LR + ((size_t)k * 2 + 0) * B * 32;
         uint8_t* Rout = io.LR + ((size_t)k * 2 + 1) * B * 32;
         if (k < r) {
@@ -966,34 +1045,48 @@ static IpaEnd enqueue_ipa(const IpaIO& io, dev_stream_t st, MsmStats* stats) {
                 launch((uint64_t)2 * B, K_set_one{linv.p}, st);
                 GHp = GH.p; vtabp = vtab.p; vdigp = vdig.p; vwinp = vwin.p; vsump = vsum.p; voutp = vout.p; linvp = linv.p;
             }
-            const uint32_t remap = 1u;  // XCD-aware workgroup order of the window sums (vb_win_index; +1 % end to end)
+            const uint32_t remap = fusing ? 0u : 1u;  // XCD-aware workgroup order of the window sums (vb_win_index; +1 % end to end); plain order inside the fused tail
             if (!vb_reuse) {
                 // multiples 1P..8P and digits of every term of this round
                 const uint32_t vc = 2 * mk < VC ? 2 * mk : VC;  // chunks of the 2*mk terms of one output
-                launch((uint64_t)4 * mk * B, K_ipa_vb_tab{a, bb, GHp, linvp, vtabp, vdigp, B, mk, M}, st);
-                launch_wave((uint64_t)2 * VB_WINDOWS * vc * B, K_ipa_vb_win{vtabp, vdigp, vwinp, B, mk, vc, remap, 0}, st);
-                launch((uint64_t)2 * VB_WINDOWS * B, K_ge_reduce{vwinp, vsump, B, 2 * VB_WINDOWS * vc, vc}, st);  // chunk sums -> window sums
+                emit((uint64_t)4 * mk * B, K_ipa_vb_tab{a, bb, GHp, linvp, vtabp, vdigp, B, mk, M}, false);
+                emit((uint64_t)2 * VB_WINDOWS * vc * B, K_ipa_vb_win{vtabp, vdigp, vwinp, B, mk, vc, remap, 0}, true);
+                emit((uint64_t)2 * VB_WINDOWS * B, K_ge_reduce{vwinp, vsump, B, 2 * VB_WINDOWS * vc, vc}, false);  // chunk sums -> window sums
             } else {
                 // the round after: same multiples (the generators were not folded), product scalars
                 const uint32_t m0 = 2 * mk, vc = 2 * m0 < VC ? 2 * m0 : VC;
-                launch((uint64_t)4 * m0 * B, K_ipa_vb_dig2{a, bb, linvp, io.uk + (size_t)(k - 1) * 2 * B, vdigp, B, m0}, st);
-                launch_wave((uint64_t)2 * VB_WINDOWS * vc * B, K_ipa_vb_win{vtabp, vdigp, vwinp, B, m0, vc, remap, 1}, st);
-                launch((uint64_t)2 * VB_WINDOWS * B, K_ge_reduce{vwinp, vsump, B, 2 * VB_WINDOWS * vc, vc}, st);
+                emit((uint64_t)4 * m0 * B, K_ipa_vb_dig2{a, bb, linvp, io.uk + (size_t)(k - 1) * 2 * B, vdigp, B, m0}, false);
+                emit((uint64_t)2 * VB_WINDOWS * vc * B, K_ipa_vb_win{vtabp, vdigp, vwinp, B, m0, vc, remap, 1}, true);
+                emit((uint64_t)2 * VB_WINDOWS * B, K_ge_reduce{vwinp, vsump, B, 2 * VB_WINDOWS * vc, vc}, false);
             }
-            launch((uint64_t)2 * B, K_ipa_vb_horner{vsump, voutp, B, 1}, st);
-            launch((uint64_t)2 * B, K_pair<K_msm_finish>{finisher(voutp, 1, crossp, Lout), finisher(voutp + (size_t)B, 1, crossp + B, Rout), B}, st);
+            emit((uint64_t)2 * B, K_ipa_vb_horner{vsump, voutp, B, 1}, false);
+            emit((uint64_t)2 * B, K_pair<K_msm_finish>{finisher(voutp, 1, crossp, Lout), finisher(voutp + (size_t)B, 1, crossp + B, Rout), B}, false);
         }
         sc* ukk = io.uk + (size_t)k * 2 * B;
-        launch(B, K_transcript_LR{io.tr, Lout, ukk, B}, st);
-        launch((uint64_t)mk * B, K_ipa_fold_ab{a, bb, ukk, B, mk}, st);
+        emit(B, K_transcript_LR{io.tr, Lout, ukk, B}, false);
+        emit((uint64_t)mk * B, K_ipa_fold_ab{a, bb, ukk, B, mk}, false);
         if (k < r) launch((uint64_t)N * B, K_ipa_update_c{cG, cH, ukk, B, Nk}, st);
         else if (!vb_reuse) {
             vb_reuse = k + 1 < lgN;  // the next round works on this round's multiples
         } else {
-            if (k + 1 < lgN) launch((uint64_t)2 * mk * B, K_ipa_vb_fold2{GHp, io.uk + (size_t)(k - 1) * 2 * B, ukk, linvp, vtabp, B, 2 * mk, M}, st);
+            if (k + 1 < lgN) emit((uint64_t)2 * mk * B, K_ipa_vb_fold2{GHp, io.uk + (size_t)(k - 1) * 2 * B, ukk, linvp, vtabp, B, 2 * mk, M}, false);
             vb_reuse = false;
         }
     }
+#if !defined(BPR1CS_HOSTSIM)
+    if (fusing && !steps.empty()) {   // the whole tail in ONE launch: a workgroup per proof runs the recorded steps
+        IpaIO::TailKeep& T = *io.tail_keep;
+        DevArena* saved = dev_arena();
+        dev_arena() = nullptr;
+        try { T.prog.alloc(steps.size()); } catch (...) { dev_arena() = saved; throw; }
+        dev_arena() = saved;
+        T.h_prog = (TailStep*)host_stage_alloc(steps.size() * sizeof(TailStep));
+        memcpy(T.h_prog, steps.data(), steps.size() * sizeof(TailStep));
+        HIPCHK(hipMemcpyAsync(T.prog.p, T.h_prog, steps.size() * sizeof(TailStep), hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(k_tail_program, dim3(B), dim3(64), 0, st, T.prog.p, (uint32_t)steps.size(), B);
+        HIPCHK(hipGetLastError());
+    }
+#endif
     if (!handed_off) {
         if (sG.p) dev_zero(sG.p, sG.bytes(), st);  // products of the secret l / r vectors
         if (sH.p) dev_zero(sH.p, sH.bytes(), st);
@@ -1088,6 +1181,8 @@ static void job_release(bpr1cs_job* job) {
     host_stage_free(job->h_proofs);
     host_stage_free(job->h_comms);
     host_stage_free(job->h_err);
+    host_stage_free(job->tail.h_prog);
+    job->tail.h_prog = nullptr;
     if (job->counted) job->g->in_flight--;
     delete job;
 }
@@ -1380,6 +1475,7 @@ extern "C" int bpr1cs_prove_batch_begin(const bpr1cs_gens* g, const bpr1cs_circu
     io.tail_event = &job->ev_tail;
 #endif
     io.tail_keep = &job->tail;
+    io.tail_fused = g_tail_fused.load();
     const IpaEnd ipa_end = enqueue_ipa(io, st, stats);
     st = ipa_end.st;  // from here on `st` may be the job's tail stream: only the job's own buffers are touched below
     size_t plen = bpr1cs_proof_len(c);

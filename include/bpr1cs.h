@@ -305,6 +305,12 @@ void bpr1cs_set_unfold_rounds(int r);
  * start while this job's tail finishes (default 7 = the rounds with m_k <= 64; 0 = everything on the heavy stream;
  * never earlier than the round after the folded generators are materialised).  Results do not depend on it. */
 void bpr1cs_set_tail_rounds(int r);
+/* tuning knob, measured alternative (default 0): 1 = those rounds run as ONE kernel - every kernel of an IPA round is per
+ * proof, so a wavefront per proof executes the recorded per-round steps (cross terms, Straus tables / digits, window sums,
+ * Horner, compression, transcript, folds) back to back with barriers in between: ~60 launches per job become one.  Slower
+ * (-4 % on the depth-32 trees, -30 % on the small circuits): the steps are between 1 and 1632 items wide per proof, so most
+ * lanes idle in the narrow ones, while separate launches pack 64 proofs into every wavefront.  Same bytes either way. */
+void bpr1cs_set_tail_fused(int enable);
 
 /* tuning knob: 1 (default) = the prove jobs in flight on a handle share the device scratch of their back phases (they run one
  * after the other on the handle's heavy stream; a job waits for its predecessor's tail before its first write): a

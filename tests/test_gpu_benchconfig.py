@@ -83,6 +83,13 @@ def test_vsmt4_8_levels_w11_every_proof_of_a_ragged_batch(hip_lib, hip_glib):
     P, C = bp.prove_batch(gens, circ, b"VSMT", case["values"], case["blindings"], case["seeds"], B)
     fc.check_digests("vsmt4_l8_x70", case, P, C)
     assert bp.verify_batch(gens, circ, b"VSMT", P, C, B) == [True] * B
+    # the measured alternative for the IPA tail (one kernel, a wavefront per proof runs the recorded steps): the same bytes
+    hip_lib.bpr1cs_set_tail_fused(1)
+    try:
+        P1, C1 = bp.prove_batch(gens, circ, b"VSMT", case["values"], case["blindings"], case["seeds"], B)
+    finally:
+        hip_lib.bpr1cs_set_tail_fused(0)
+    assert P1 == P and C1 == C
     gens.close()
 
 
