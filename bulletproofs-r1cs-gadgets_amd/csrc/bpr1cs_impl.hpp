@@ -998,7 +998,9 @@ static IpaEnd enqueue_ipa(const IpaIO& io, dev_stream_t st, MsmStats* stats) {
         uint8_t* Lout = io.LR + ((size_t)k * 2 + 0) * B * 32;
         uint8_t* Rout = io.LR + ((size_t)k * 2 + 1) * B * 32;
         if (k < r) {
-            launch((uint64_t)N * B, K_ipa_scalars{a, bb, cG, cH, sG.p, sH.p, B, Nk}, st);
+            K_ipa_scalars ks{a, bb, cG, cH, sG.p, sH.p, B, Nk};
+            if (k > 0) ks.uk_prev = io.uk + (size_t)(k - 1) * 2 * B;   // round k-1's fold of the generator factors rides along
+            launch((uint64_t)N * B, ks, st);
             uint32_t half = N / 2;
             // L: G-terms with pos >= m, H-terms with pos < m ; R: the complement
             MsmSeg gL{sG.p, half, mk, Nk, mk, baseG, 0}, hL{sH.p, half, mk, Nk, 0, baseH, 0};
@@ -1065,7 +1067,8 @@ static IpaEnd enqueue_ipa(const IpaIO& io, dev_stream_t st, MsmStats* stats) {
         sc* ukk = io.uk + (size_t)k * 2 * B;
         emit(B, K_transcript_LR{io.tr, Lout, ukk, B}, false);
         emit((uint64_t)mk * B, K_ipa_fold_ab{a, bb, ukk, B, mk}, false);
-        if (k < r) launch((uint64_t)N * B, K_ipa_update_c{cG, cH, ukk, B, Nk}, st);
+        if (k + 1 == r) launch((uint64_t)N * B, K_ipa_update_c{cG, cH, ukk, B, Nk}, st);   // (earlier rounds: inside the next K_ipa_scalars)
+        else if (k < r) {}
         else if (!vb_reuse) {
             vb_reuse = k + 1 < lgN;  // the next round works on this round's multiples
         } else {

@@ -1026,18 +1026,29 @@ struct K_ipa_cross {  // gid = c*B + b -> part[0][c][b] = <a_lo,b_hi>, part[1][c
 struct K_ipa_scalars {  // gid = i*B + b, i<N
     const sc* a;
     const sc* bb;
-    const sc* cG;
-    const sc* cH;
+    sc* cG;
+    sc* cH;
     sc* sG;
     sc* sH;
     uint32_t B, Nk;
+    // the fold factors of the PREVIOUS round (K_ipa_update_c) applied on the way: one pass over cG / cH per round instead of two
+    const sc* uk_prev = nullptr;  // [2][B] u, u^-1 of round k-1, or null (round 0)
     HD void operator()(uint32_t g) const {
         uint32_t i = g / B, b = g % B, m = Nk >> 1;
         uint32_t pos = i & (Nk - 1);
         uint32_t partner = pos >= m ? pos - m : pos + m;
         size_t pb = (size_t)partner * B + b;
-        sG[g] = sc_from_mont(sc_mul(a[pb], cG[g]));
-        sH[g] = sc_from_mont(sc_mul(bb[pb], cH[g]));
+        sc cg = cG[g], ch = cH[g];
+        if (uk_prev) {
+            int hi = (i & (2u * Nk - 1u)) >= Nk;   // position inside the previous round's vector of length 2 Nk
+            sc u = uk_prev[b], ui = uk_prev[(size_t)B + b];
+            cg = sc_mul(cg, hi ? u : ui);
+            ch = sc_mul(ch, hi ? ui : u);
+            cG[g] = cg;
+            cH[g] = ch;
+        }
+        sG[g] = sc_from_mont(sc_mul(a[pb], cg));
+        sH[g] = sc_from_mont(sc_mul(bb[pb], ch));
     }
 };
 struct K_transcript_LR {  // append L,R -> u_k, u_k^-1
