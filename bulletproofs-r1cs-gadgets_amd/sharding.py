@@ -43,16 +43,26 @@ def _all_gather_bytes(payload, group=None, device=None):
 
 def make_comm(bp, rank, world, group=None, device=None, lib=None):
     """An RCCL communicator owned by the library (bp.Comm) for the ranks of a torch.distributed job (or a single process):
-    rank 0 draws the unique id, the others receive it by a broadcast of 128 bytes."""
+    rank 0 draws the unique id, the others receive it by a broadcast of 128 bytes.  -> bp.Comm, or None when rank 0 could not
+    draw an id (every rank then learns that from the broadcast and none enters ncclCommInitRank)."""
     import torch
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or world == 1:
         return bp.Comm(bp.Comm.unique_id(lib), 0, 1, lib=lib)
-    t = torch.frombuffer(bytearray(bp.Comm.unique_id(lib) if rank == 0 else bytes(128)), dtype=torch.uint8)
+    uid = bytes(128)
+    if rank == 0:
+        try:
+            uid = bp.Comm.unique_id(lib)
+        except Exception:
+            uid = bytes(128)
+    t = torch.frombuffer(bytearray(uid), dtype=torch.uint8)
     if device is not None:
         t = t.to(device)
     dist.broadcast(t, src=0, group=group)
-    return bp.Comm(bytes(t.cpu().numpy().tobytes()), rank, world, lib=lib)
+    uid = bytes(t.cpu().numpy().tobytes())
+    if uid == bytes(128):
+        return None
+    return bp.Comm(uid, rank, world, lib=lib)
 
 
 def verify_sharded(bp, gens, circuit, label, proofs, commitments, batch, rank, world, index_base, batch_seed=None, group=None, device=None, comm=None):
