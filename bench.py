@@ -56,7 +56,7 @@ CONFIGS = {
     "c5": dict(metric="R1CS proofs/sec (MiMC-322 preimage + set membership)", batch=8192, fuse=1, window=11, cpu_proofs=32,
                workload="gadget_mimc preimage + gadget_set_membership (k = 7) on one prover (reference src/gadget_mimc.rs:92-175, src/gadget_set_membership.rs:93-171)",
                build=lambda bp, B, base, a: wl.mimc_set_membership(B, index_base=base)),
-    "vsmt4_d128": dict(metric="R1CS proofs/sec (Poseidon VSMT-4 depth-128, as shipped)", batch=512, fuse=1, window=0, cpu_proofs=1,
+    "vsmt4_d128": dict(metric="R1CS proofs/sec (Poseidon VSMT-4 depth-128, as shipped)", batch=1024, fuse=1, window=0, cpu_proofs=1,
                        workload="gadget_vsmt_4 at the depth the reference ships (TreeDepth = 128, src/gadget_vsmt_4.rs:25): n = 74 624, N = 131 072",
                        build=lambda bp, B, base, a: wl.vsmt4(bp, None, 128, B, B, base)),
     "vsmt2_d253": dict(metric="R1CS proofs/sec (Poseidon VSMT-2 depth-253, as shipped)", batch=256, fuse=1, window=0, cpu_proofs=1,
