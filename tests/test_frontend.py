@@ -64,3 +64,16 @@ def test_compiled_tree_gadgets_with_the_cube_sbox(sim_lib, sim_glib, case):
     """the sparse-Merkle gadgets over Poseidon with the Cube S-box (`sbox` iparam; the reference hard-wires
     Inverse at src/gadget_vsmt_4.rs:301, src/gadget_vsmt_2.rs:203): proof bytes equal the oracle's"""
     fc.check_compiled(sim_lib, sim_glib, case, batch=2)
+
+
+def test_job_memory_knobs_do_not_change_a_byte(sim_lib, sim_glib):
+    """N = 512 (9 IPA rounds, folded generators at round 4, tail hand-off at round 6): private scratch instead of the shared
+    back-phase arena, no tail hand-off, a different hand-off round - the oracle's proof bytes every time"""
+    try:
+        for shared, tail in ((0, 7), (1, 0), (1, 3), (0, 0)):
+            sim_lib.bpr1cs_set_shared_back(shared)
+            sim_lib.bpr1cs_set_tail_rounds(tail)
+            fc.check_compiled(sim_lib, sim_glib, "vsmt_2_cube", batch=2)
+    finally:
+        sim_lib.bpr1cs_set_shared_back(1)
+        sim_lib.bpr1cs_set_tail_rounds(7)
