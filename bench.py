@@ -221,6 +221,7 @@ def main():
     ap.add_argument("--shared-back", type=int, default=-1, help="jobs in flight share the scratch of their back phases (-1 = library default)")
     ap.add_argument("--tail-rounds", type=int, default=-1, help="final IPA rounds enqueued on the job's own tail stream (-1 = library default, 0 = all on the heavy stream)")
     ap.add_argument("--tail-fused", type=int, default=-1, help="1: the IPA tail as one kernel, 0: one launch per step (-1 = library default)")
+    ap.add_argument("--msm-threads-log2", type=int, default=-1, help="measuring knob: log2 of the (chunk, proof) threads per MSM launch (-1 = library default 21)")
     ap.add_argument("--window", type=int, default=-1, help="fixed-base table window bits (-1 = the configuration's; 11: 23 adds/term, 198 GB of tables at capacity 32768; 0 = from the free memory)")
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
@@ -258,6 +259,8 @@ def main():
         lib.bpr1cs_set_shared_back(args.shared_back)
     if args.tail_fused >= 0:
         lib.bpr1cs_set_tail_fused(args.tail_fused)
+    if args.msm_threads_log2 >= 0:
+        lib.bpr1cs_set_msm_threads_log2(args.msm_threads_log2)
 
     B = args.batch if args.batch > 0 else cfg["batch"]
     F = max(1, args.fuse if args.fuse > 0 else cfg["fuse"])

@@ -105,6 +105,7 @@ def load_library(path=None):
     lib.bpr1cs_set_tail_rounds.argtypes = [ctypes.c_int]
     lib.bpr1cs_set_shared_back.argtypes = [ctypes.c_int]
     lib.bpr1cs_set_tail_fused.argtypes = [ctypes.c_int]
+    lib.bpr1cs_set_msm_threads_log2.argtypes = [ctypes.c_int]
     lib.bpr1cs_circuit_macro_perms.argtypes = [ctypes.c_void_p]
     lib.bpr1cs_circuit_macro_perms.restype = ctypes.c_int
     lib.bpr1cs_set_latency_cus.argtypes = [ctypes.c_int]

@@ -54,7 +54,7 @@ static std::atomic<int> g_shared_back{1};    // the jobs in flight on a handle s
 static std::atomic<int> g_tail_fused{0};     // 1: the IPA tail as ONE kernel (a wavefront per proof executes the recorded per-round steps) - measured
                                              // alternative, slower: the steps are 1 to 1632 items wide per proof, separate launches pack 64 proofs per wavefront
 static std::atomic<int> g_tail_rounds{7};    // final IPA rounds (m_k <= 64 at 7) enqueued on the job's own tail stream instead of the shared heavy one
-static const uint32_t g_msm_target_threads = 1u << 21;  // (chunk, proof) threads per MSM launch
+static std::atomic<uint32_t> g_msm_target_threads{1u << 21};  // (chunk, proof) threads per MSM launch (bpr1cs_set_msm_threads_log2: a measuring knob)
 struct BpOpts {  // per-handle overrides; -1 = process default
     std::atomic<int> unfold{-1}, rng_mode{-1}, witness_team{-1}, tail_rounds{-1};
 };
@@ -219,6 +219,7 @@ void bpr1cs_set_witness_macro(int enable) { g_witness_macro = enable ? 1 : 0; }
 void bpr1cs_set_tail_rounds(int r) { g_tail_rounds = r < 0 ? 0 : r; }
 void bpr1cs_set_shared_back(int enable) { g_shared_back = enable ? 1 : 0; }
 void bpr1cs_set_tail_fused(int enable) { g_tail_fused = enable ? 1 : 0; }
+void bpr1cs_set_msm_threads_log2(int lg) { g_msm_target_threads = 1u << (lg < 16 ? 16 : (lg > 26 ? 26 : lg)); }
 void bpr1cs_set_rng_mode(int mode) { g_rng_mode = (mode >= 1 && mode <= 5) ? mode : 0; }
 int bpr1cs_circuit_macro_perms(const bpr1cs_circuit* c) { return c ? (int)c->n_perms : 0; }
 void bpr1cs_set_window_bits(int w) { g_window_bits = w <= 0 ? 0 : (w < 4 ? 4 : (w > 12 ? 12 : w)); }  // 0 = choose from the free memory
@@ -738,7 +739,7 @@ static void run_msm_multi(const bpr1cs_gens* g, MsmReq* reqs, uint32_t nreq, uin
     for (uint32_t r = 0; r < nreq; r++) {
         MsmReq& q = reqs[r];
         uint32_t total = q.s0.count + q.s1.count;
-        uint32_t nchunks = pick_chunks(total, B, g_msm_target_threads, q.plan->chunk);
+        uint32_t nchunks = pick_chunks(total, B, g_msm_target_threads.load(), q.plan->chunk);
         if (q.chunk_hint) {
             q.plan->chunk = q.chunk_hint;
             nchunks = total ? (total + q.chunk_hint - 1) / q.chunk_hint : 1;

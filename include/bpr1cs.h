@@ -318,6 +318,10 @@ void bpr1cs_set_tail_fused(int enable);
  * allocates its own scratch.  Results do not depend on it. */
 void bpr1cs_set_shared_back(int enable);
 
+/* measuring knob: log2 of the (chunk, proof) threads a launch of the fixed-base MSM kernel is cut into (default 21: ~32 k
+ * wavefronts per launch; fewer = longer chunks and a longer launch tail, more = more first-term overhead and partial sums) */
+void bpr1cs_set_msm_threads_log2(int lg);
+
 /* tuning knob, read by bpr1cs_gens_create: signed window width W (4..12) of the fixed-base tables.
  * A term costs ceil(253/W) mixed additions (the top window of a canonical scalar never carries out); table bytes =
  * (2+2*cap) * ceil(253/W) * (2^(W-1) + 1) * 96 (packed) or 128 (limb form)  (W=8: 26 / 35 GB, W=11: 148 / 198 GB at
