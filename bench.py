@@ -262,6 +262,21 @@ def main():
     if args.msm_threads_log2 >= 0:
         lib.bpr1cs_set_msm_threads_log2(args.msm_threads_log2)
 
+    # the library's own RCCL communicator for the sharded verifier (bpr1cs_verify_batch_sharded), created at start-up: RCCL brings
+    # up its view of the runtime best in a young process, and every rank meets here before any of them holds 280 GB
+    comm = None
+    try:
+        sh0 = importlib.import_module("bulletproofs-r1cs-gadgets_amd.sharding")
+        comm = sh0.make_comm(bp, rank, world, device="cuda" if dist is not None else None)
+    except Exception as e:  # pragma: no cover
+        print("bench.py: no RCCL communicator for the verification leg (%r): the torch collectives are used instead" % (e,), file=sys.stderr)
+    if dist is not None:   # all ranks use the same form
+        flag = torch.tensor([1 if comm is not None else 0], device="cuda", dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0 and comm is not None:
+            comm.close()
+            comm = None
+
     B = args.batch if args.batch > 0 else cfg["batch"]
     F = max(1, args.fuse if args.fuse > 0 else cfg["fuse"])
     Bj = B * F                                      # proofs per device job
@@ -353,7 +368,6 @@ def main():
     # (bpr1cs_verify_batch_combined) and the path's only exchange step, an all_gather of one 32-byte point per rank.
     batched = None
     comms = None
-    comm = None
     have_job = 1
     try:
         proofs, comms = begin().finish()
@@ -367,7 +381,6 @@ def main():
         if not have_job:
             raise RuntimeError("a rank could not produce the batch to verify")
         sh = importlib.import_module("bulletproofs-r1cs-gadgets_amd.sharding")
-        comm = sh.make_comm(bp, rank, world, device="cuda" if dist is not None else None)   # RCCL communicator owned by the library
         # one-shot calls are noisy (first-use allocations): both forms run twice, the faster run is reported
         tb = ts = float("inf")
         accepted = accepted_split = True

@@ -785,11 +785,13 @@ static void run_msm(const bpr1cs_gens* g, MsmSeg s0, MsmSeg s1, uint32_t B, DevB
 }
 
 // constraint columns weighted by powers of z: wvec[slot][b] (first `nslots` slots of the circuit)
-static void run_flatten(const bpr1cs_circuit* c, uint32_t nslots, const sc* plo, const sc* phi, sc* wvec, uint32_t B, uint32_t H, dev_stream_t st) {
+static void run_flatten(const bpr1cs_circuit* c, uint32_t nslots, const sc* plo, const sc* phi, sc* wvec, uint32_t B, uint32_t H, dev_stream_t st,
+                        sc* part_buf = nullptr /* optional room for the chunk sums: h_slot_chunk[nslots] * B scalars */) {
     uint32_t nch = c->h_slot_chunk[nslots];
-    DevBuf<sc> part((size_t)(nch ? nch : 1) * B);
-    launch((uint64_t)nch * B, K_flatten_chunks{c->chunk_lo.p, c->ent_row.p, c->ent_coeff.p, plo, phi, part.p, B, H}, st);
-    launch((uint64_t)nslots * B, K_flatten{c->slot_chunk.p, part.p, wvec, B, 3 * c->n}, st);
+    DevBuf<sc> part;
+    if (!part_buf) { part.alloc((size_t)(nch ? nch : 1) * B); part_buf = part.p; }
+    launch((uint64_t)nch * B, K_flatten_chunks{c->chunk_lo.p, c->ent_row.p, c->ent_coeff.p, plo, phi, part_buf, B, H}, st);
+    launch((uint64_t)nslots * B, K_flatten{c->slot_chunk.p, part_buf, wvec, B, 3 * c->n}, st);
 }
 
 // ---------------------------------------------------------------- inner-product argument
@@ -886,6 +888,10 @@ struct IpaIO {
         TailStep* h_prog = nullptr;     // ... and its pinned staging copy (host_stage_alloc; released with the job)
     }* tail_keep = nullptr;
     int tail_fused = 0;                 // 1: record the tail's launches as a step list and run them as ONE kernel
+    // optional: room provided by the caller for the product scalars of the un-folded rounds (2 x N*B) and for the Straus
+    // multiples of the first variable-base pair - the prover lets them SHARE one block with buffers that are dead by then
+    sc* sG_pre = nullptr; sc* sH_pre = nullptr;
+    ge_cached* vtab_pre = nullptr; size_t vtab_pre_count = 0;
 #if !defined(BPR1CS_HOSTSIM)
     hipEvent_t* tail_event = nullptr;
 #endif
@@ -910,7 +916,9 @@ static IpaEnd enqueue_ipa(const IpaIO& io, dev_stream_t st, MsmStats* stats) {
     uint32_t M = N >> r;  // size of the materialised folded generator vectors (= stride between the two sides in GH)
     ge* GHp = nullptr; ge* vwinp = nullptr; ge* vsump = nullptr; ge* voutp = nullptr;
     ge_cached* vtabp = nullptr; uint32_t* vdigp = nullptr; sc* linvp = nullptr; sc* crossp = cross.p;
-    if (r > 0) { sG.alloc((size_t)N * B); sH.alloc((size_t)N * B); }
+    sc* sGp = io.sG_pre; sc* sHp = io.sH_pre;
+    if (r > 0 && !(sGp && sHp)) { sG.alloc((size_t)N * B); sH.alloc((size_t)N * B); sGp = sG.p; sHp = sH.p; }
+    const size_t s_bytes = r > 0 ? (size_t)N * B * sizeof(sc) : 0;
     const uint32_t VC = 16;  // chunks per Straus output (8 / 32 / 64 measured within 0.3 %)
     // variable-base rounds come in pairs on one set of multiples, generators folded two levels at a time (K_ipa_vb_dig2 / _fold2)
     bool vb_reuse = false;
@@ -964,8 +972,7 @@ static IpaEnd enqueue_ipa(const IpaIO& io, dev_stream_t st, MsmStats* stats) {
             dev_d2d(T.GH.p + (size_t)Nk * B, GHp + (size_t)M * B, (size_t)Nk * B * sizeof(ge), st);
             dev_zero(io.a, (size_t)N * B * sizeof(sc), st);  // the arena's copies of the secret vectors die here
             dev_zero(io.bb, (size_t)N * B * sizeof(sc), st);
-            if (sG.p) dev_zero(sG.p, sG.bytes(), st);
-            if (sH.p) dev_zero(sH.p, sH.bytes(), st);
+            if (s_bytes) { dev_zero(sGp, s_bytes, st); dev_zero(sHp, s_bytes, st); }
             handed_off = true;
             a = T.a.p; bb = T.bb.p; linvp = T.linv.p; crossp = T.cross.p; GHp = T.GH.p; M = Nk;
             vtabp = T.vtab.p; vdigp = T.vdig.p; vwinp = T.vwin.p; vsump = T.vsum.p; voutp = T.vout.p;
@@ -999,13 +1006,13 @@ static IpaEnd enqueue_ipa(const IpaIO& io, dev_stream_t st, MsmStats* stats) {
         uint8_t* Lout = io.LR + ((size_t)k * 2 + 0) * B * 32;
         uint8_t* Rout = io.LR + ((size_t)k * 2 + 1) * B * 32;
         if (k < r) {
-            K_ipa_scalars ks{a, bb, cG, cH, sG.p, sH.p, B, Nk};
+            K_ipa_scalars ks{a, bb, cG, cH, sGp, sHp, B, Nk};
             if (k > 0) ks.uk_prev = io.uk + (size_t)(k - 1) * 2 * B;   // round k-1's fold of the generator factors rides along
             launch((uint64_t)N * B, ks, st);
             uint32_t half = N / 2;
             // L: G-terms with pos >= m, H-terms with pos < m ; R: the complement
-            MsmSeg gL{sG.p, half, mk, Nk, mk, baseG, 0}, hL{sH.p, half, mk, Nk, 0, baseH, 0};
-            MsmSeg gR{sG.p, half, mk, Nk, 0, baseG, 0}, hR{sH.p, half, mk, Nk, mk, baseH, 0};
+            MsmSeg gL{sGp, half, mk, Nk, mk, baseG, 0}, hL{sHp, half, mk, Nk, 0, baseH, 0};
+            MsmSeg gR{sGp, half, mk, Nk, 0, baseG, 0}, hR{sHp, half, mk, Nk, mk, baseH, 0};
             // (round 0 of the R1CS prover: l(x) is zero and r(x) is -y^i beyond n, so of the 65 536 terms 14 112 G-terms of R_0
             // vanish and 14 112 H-terms of L_0 share one scalar: both blocks are left out of the segments - 50 -> 36 ms for the launch)
             const bool hs = k == 0 && io.hs_tab && io.hs_from < mk;
@@ -1039,14 +1046,15 @@ static IpaEnd enqueue_ipa(const IpaIO& io, dev_stream_t st, MsmStats* stats) {
                     launch_msm_kernel(g, L, st, stats, (uint64_t)2 * N * B);
                 }
 #endif
-                vtab.alloc((size_t)VB_MULT * 4 * (M / 2 ? M / 2 : 1) * B);
+                const size_t vtab_need = (size_t)VB_MULT * 4 * (M / 2 ? M / 2 : 1) * B;
+                if (!(io.vtab_pre && io.vtab_pre_count >= vtab_need)) vtab.alloc(vtab_need);
                 vdig.alloc((size_t)VB_WORDS * 4 * (M / 2 ? M / 2 : 1) * B);
                 vwin.alloc((size_t)2 * VB_WINDOWS * VC * B);
                 vsum.alloc((size_t)2 * VB_WINDOWS * B);
                 vout.alloc((size_t)2 * B);
                 linv.alloc((size_t)2 * B);
                 launch((uint64_t)2 * B, K_set_one{linv.p}, st);
-                GHp = GH.p; vtabp = vtab.p; vdigp = vdig.p; vwinp = vwin.p; vsump = vsum.p; voutp = vout.p; linvp = linv.p;
+                GHp = GH.p; vtabp = vtab.p ? vtab.p : io.vtab_pre; vdigp = vdig.p; vwinp = vwin.p; vsump = vsum.p; voutp = vout.p; linvp = linv.p;
             }
             const uint32_t remap = fusing ? 0u : 1u;  // XCD-aware workgroup order of the window sums (vb_win_index; +1 % end to end); plain order inside the fused tail
             if (!vb_reuse) {
@@ -1091,9 +1099,9 @@ static IpaEnd enqueue_ipa(const IpaIO& io, dev_stream_t st, MsmStats* stats) {
         HIPCHK(hipGetLastError());
     }
 #endif
-    if (!handed_off) {
-        if (sG.p) dev_zero(sG.p, sG.bytes(), st);  // products of the secret l / r vectors
-        if (sH.p) dev_zero(sH.p, sH.bytes(), st);
+    if (!handed_off && s_bytes) {
+        dev_zero(sGp, s_bytes, st);  // products of the secret l / r vectors
+        dev_zero(sHp, s_bytes, st);
     }
     return IpaEnd{st, a, bb};
 }
@@ -1432,8 +1440,26 @@ extern "C" int bpr1cs_prove_batch_begin(const bpr1cs_gens* g, const bpr1cs_circu
     uint32_t H = (maxe >> 8) + 1;
     DevBuf<sc> plo((size_t)3 * 256 * B), phi((size_t)3 * H * B);
     launch((uint64_t)3 * B, K_pow_tables{chal.p, plo.p, phi.p, B, H}, st);
-    DevBuf<sc> wvec((size_t)(3 * n + m) * B + 1);
-    run_flatten(c, 3 * n + m, plo.p, phi.p, wvec.p, B, H, st);
+    // ONE block for buffers whose lives do not overlap: the flattened constraints and their chunk sums (dead after l(x), r(x)),
+    // the generator factors cG / cH (dead once the folded generators exist) and the product scalars of the un-folded rounds
+    // (dead after round r-1) share their memory with the Straus multiples of the first variable-base pair, which K_ipa_vb_tab
+    // writes at round r, after the launch that materialises the folded generators: 15 of 40 GiB of a 2048-proof job's back phase.
+    const uint32_t r_eff = std::min<uint32_t>((uint32_t)o_unfold, lgN);
+    const uint32_t nfl = c->h_slot_chunk[3 * n + m];
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t w_bytes = al(((size_t)(3 * n + m) * B + 1) * sizeof(sc)), p_bytes = al((size_t)(nfl ? nfl : 1) * B * sizeof(sc)),
+                 v_bytes = al((size_t)N * B * sizeof(sc));
+    const size_t vt_count = r_eff < lgN ? (size_t)VB_MULT * 4 * ((N >> r_eff) / 2 ? (N >> r_eff) / 2 : 1) * B : 0;
+    const size_t others = w_bytes + p_bytes + 2 * v_bytes + (r_eff ? 2 * v_bytes : 0);
+    DevBuf<uint8_t> shared_blk(std::max(others, vt_count * sizeof(ge_cached)));
+    sc* wvec_p = (sc*)shared_blk.p;
+    sc* fpart_p = (sc*)(shared_blk.p + w_bytes);
+    sc* cG_p = (sc*)(shared_blk.p + w_bytes + p_bytes);
+    sc* cH_p = (sc*)(shared_blk.p + w_bytes + p_bytes + v_bytes);
+    sc* sG_p = r_eff ? (sc*)(shared_blk.p + w_bytes + p_bytes + 2 * v_bytes) : nullptr;
+    sc* sH_p = r_eff ? (sc*)(shared_blk.p + w_bytes + p_bytes + 3 * v_bytes) : nullptr;
+    struct { sc* p; } wvec{wvec_p}, cG{cG_p}, cH{cH_p};
+    run_flatten(c, 3 * n + m, plo.p, phi.p, wvec.p, B, H, st, fpart_p);
     // 4 wavefronts per SIMD: with one (2^16 threads) the kernel is latency bound and a co-running front kernel doubles its time (9 -> 4 ms)
     uint32_t tchunk, TC = pick_chunks(n, B, 1u << 18, tchunk);
     DevBuf<sc> tpart((size_t)6 * TC * B), tco((size_t)6 * B);
@@ -1441,7 +1467,7 @@ extern "C" int bpr1cs_prove_batch_begin(const bpr1cs_gens* g, const bpr1cs_circu
     launch((uint64_t)6 * B, K_sum_partials{tpart.p, tco.p, B, TC}, st);
     launch((uint64_t)5 * B, K_commit_T{g->tab.p, g->tc, tco.p, blind.p, Tc.p, B}, st);
     launch(B, K_transcript_T{tr.p, Tc.p, tco.p, blind.p, wvec.p + (size_t)3 * n * B, vbl_m.p, chal.p, txs.p, B, m, (uint64_t)N}, st);
-    DevBuf<sc> a((size_t)N * B), bb((size_t)N * B), cG((size_t)N * B), cH((size_t)N * B);
+    DevBuf<sc> a((size_t)N * B), bb((size_t)N * B);
     launch((uint64_t)N * B, K_lr_eval{W.p, wvec.p, plo.p, phi.p, chal.p, a.p, bb.p, cG.p, cH.p, B, H, n}, st);
     pt.mark(st);
 
@@ -1478,6 +1504,8 @@ extern "C" int bpr1cs_prove_batch_begin(const bpr1cs_gens* g, const bpr1cs_circu
 #if !defined(BPR1CS_HOSTSIM)
     io.tail_event = &job->ev_tail;
 #endif
+    io.sG_pre = sG_p; io.sH_pre = sH_p;
+    io.vtab_pre = (ge_cached*)shared_blk.p; io.vtab_pre_count = shared_blk.n / sizeof(ge_cached);
     io.tail_keep = &job->tail;
     io.tail_fused = g_tail_fused.load();
     const IpaEnd ipa_end = enqueue_ipa(io, st, stats);
@@ -2068,7 +2096,18 @@ extern "C" int bpr1cs_comm_create(const uint8_t id[128], int rank, int world, bp
     bpr1cs_comm* c = new (std::nothrow) bpr1cs_comm();
     if (!c) return BPR1CS_ERR_OUT_OF_MEMORY;
     c->rank = rank; c->world = world; c->owned = true;
-    if (rccl_api().comm_init_rank(&c->comm, world, uid, rank) != ncclSuccess) { delete c; return BPR1CS_ERR_DEVICE; }
+    if (world == 1) {
+        // RCCL allocates its own device buffers: when this library's allocator cache holds the rest of the device, give it back
+        // and try once more (only where no other rank is waiting inside the same collective initialisation)
+        if (rccl_api().comm_init_rank(&c->comm, world, uid, rank) != ncclSuccess) {
+            dev_pool().release_all();
+            ncclUniqueId uid2;
+            if (rccl_api().get_unique_id(&uid2) != ncclSuccess || rccl_api().comm_init_rank(&c->comm, 1, uid2, 0) != ncclSuccess) { delete c; return BPR1CS_ERR_DEVICE; }
+        }
+    } else {
+        dev_pool().release_all();   // before the ranks meet: cached blocks are of no use to RCCL
+        if (rccl_api().comm_init_rank(&c->comm, world, uid, rank) != ncclSuccess) { delete c; return BPR1CS_ERR_DEVICE; }
+    }
     *out = c;
     return BPR1CS_OK;
 #endif

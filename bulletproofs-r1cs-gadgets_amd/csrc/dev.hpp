@@ -84,13 +84,29 @@ struct DevPool {
             free_blocks.erase(it);
             return p;
         }
+        // The HIP / HSA runtime needs device memory of its own (scratch, queues, kernel arguments) and ABORTS the process when
+        // it finds none ("HSA_STATUS_ERROR_OUT_OF_RESOURCES ... Available Free mem : 0 MB"): a large block that would leave less
+        // than RESERVE free is refused like a failed allocation, so that running out of memory stays a return code.
+        static const size_t RESERVE = (size_t)2 << 30;
+        auto try_alloc = [&](void** out) -> bool {
+            if (hipMalloc(out, n) != hipSuccess) { (void)hipGetLastError(); *out = nullptr; return false; }
+            if (n >= ((size_t)64 << 20)) {
+                size_t mfree = 0, mtotal = 0;
+                static const bool dbg = getenv("BPR1CS_DEBUG_MEM") != nullptr;
+                hipError_t ei = hipMemGetInfo(&mfree, &mtotal);
+                if (dbg) fprintf(stderr, "bpr1cs: hipMalloc %zu MB -> free %zu MB of %zu MB\n", n >> 20, mfree >> 20, mtotal >> 20);
+                if (ei == hipSuccess && mfree < RESERVE) { (void)hipFree(*out); *out = nullptr; return false; }
+            }
+            return true;
+        };
         void* p = nullptr;
-        hipError_t e = hipMalloc(&p, n);
-        if (e != hipSuccess) {  // out of memory: drop the cache and retry once
-            (void)hipGetLastError();
+        if (!try_alloc(&p)) {  // out of memory: drop the cache and retry once
             for (auto& kv : free_blocks) (void)hipFree(kv.second);
             free_blocks.clear();
-            HIPCHK(hipMalloc(&p, n));
+            if (!try_alloc(&p)) {
+                fprintf(stderr, "bpr1cs: out of device memory (%zu bytes requested)\n", n);
+                throw DevError{DEV_ERR_OUT_OF_MEMORY};
+            }
         }
         live[p] = n;
         return p;
