@@ -218,6 +218,7 @@ def main():
     ap.add_argument("--team", type=int, default=0, help="witness team size 4/8/16 (0 = library default)")
     ap.add_argument("--rng-mode", type=int, default=-1, help="TranscriptRng chain mapping: 0 auto, 1 lane-parallel, 2 state per thread (-1 = library default)")
     ap.add_argument("--unfold", type=int, default=4, help="IPA rounds computed from the un-folded generator tables")
+    ap.add_argument("--factor-vectors", type=int, default=-1, help="1: IPA factor vectors as N x B arrays instead of their closed form (-1 = library default)")
     ap.add_argument("--shared-back", type=int, default=-1, help="jobs in flight share the scratch of their back phases (-1 = library default)")
     ap.add_argument("--tail-rounds", type=int, default=-1, help="final IPA rounds enqueued on the job's own tail stream (-1 = library default, 0 = all on the heavy stream)")
     ap.add_argument("--tail-fused", type=int, default=-1, help="1: the IPA tail as one kernel, 0: one launch per step (-1 = library default)")
@@ -257,6 +258,8 @@ def main():
         lib.bpr1cs_set_tail_rounds(args.tail_rounds)
     if args.shared_back >= 0:
         lib.bpr1cs_set_shared_back(args.shared_back)
+    if args.factor_vectors >= 0:
+        lib.bpr1cs_set_factor_vectors(args.factor_vectors)
     if args.tail_fused >= 0:
         lib.bpr1cs_set_tail_fused(args.tail_fused)
     if args.msm_threads_log2 >= 0:

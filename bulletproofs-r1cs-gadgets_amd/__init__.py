@@ -104,6 +104,7 @@ def load_library(path=None):
     lib.bpr1cs_set_rng_mode.argtypes = [ctypes.c_int]
     lib.bpr1cs_set_tail_rounds.argtypes = [ctypes.c_int]
     lib.bpr1cs_set_shared_back.argtypes = [ctypes.c_int]
+    lib.bpr1cs_set_factor_vectors.argtypes = [ctypes.c_int]
     lib.bpr1cs_set_tail_fused.argtypes = [ctypes.c_int]
     lib.bpr1cs_set_msm_threads_log2.argtypes = [ctypes.c_int]
     lib.bpr1cs_circuit_macro_perms.argtypes = [ctypes.c_void_p]

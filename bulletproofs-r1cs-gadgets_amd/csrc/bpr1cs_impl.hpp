@@ -50,6 +50,7 @@ static std::atomic<int> g_rng_mode{0};       // 0 auto, 1 lane-parallel via LDS 
 static std::atomic<int> g_merge_triples{1};  // A_I1: one merged table per Inverse-S-box wire triple (needs the annotated witness program)
 static std::atomic<int> g_witness_macro{1};  // use the Poseidon annotations of a circuit description (poseidon_team)
 static std::atomic<int> g_witness_team{8};   // lanes cooperating on one proof in k_witness_team (4, 8 or 16)
+static std::atomic<int> g_factor_vectors{0}; // 1: the prover hands the IPA its factor vectors as N x B arrays (the general form), 0: in closed form (IpaGeo)
 static std::atomic<int> g_shared_back{1};    // the jobs in flight on a handle share the scratch of their back phases (DevArena)
 static std::atomic<int> g_tail_fused{0};     // 1: the IPA tail as ONE kernel (a wavefront per proof executes the recorded per-round steps) - measured
                                              // alternative, slower: the steps are 1 to 1632 items wide per proof, separate launches pack 64 proofs per wavefront
@@ -218,6 +219,7 @@ void bpr1cs_set_witness_team(int t) { g_witness_team = (t == 4 || t == 8) ? t : 
 void bpr1cs_set_witness_macro(int enable) { g_witness_macro = enable ? 1 : 0; }
 void bpr1cs_set_tail_rounds(int r) { g_tail_rounds = r < 0 ? 0 : r; }
 void bpr1cs_set_shared_back(int enable) { g_shared_back = enable ? 1 : 0; }
+void bpr1cs_set_factor_vectors(int enable) { g_factor_vectors = enable ? 1 : 0; }
 void bpr1cs_set_tail_fused(int enable) { g_tail_fused = enable ? 1 : 0; }
 void bpr1cs_set_msm_threads_log2(int lg) { g_msm_target_threads = 1u << (lg < 16 ? 16 : (lg > 26 ? 26 : lg)); }
 void bpr1cs_set_rng_mode(int mode) { g_rng_mode = (mode >= 1 && mode <= 5) ? mode : 0; }
@@ -860,7 +862,7 @@ struct IpaIO {
     strobe* tr;      // [B] transcript states (updated)
     sc* a;           // [N][B] Montgomery, folded in place; a[0][b] = final a
     sc* bb;          // [N][B]
-    sc* cG;          // [N][B] G_factors (consumed)
+    sc* cG;          // [N][B] G_factors (consumed), or null with `geo` set
     sc* cH;          // [N][B] H_factors (consumed)
     const sc* qw;    // [B] Montgomery w with Q = w * B (the prover's case), or nullptr ...
     const ge* qpt;   // ... [B] arbitrary points Q (bpr1cs_ipa_create)
@@ -891,6 +893,7 @@ struct IpaIO {
     // optional: room provided by the caller for the product scalars of the un-folded rounds (2 x N*B) and for the Straus
     // multiples of the first variable-base pair - the prover lets them SHARE one block with buffers that are dead by then
     sc* sG_pre = nullptr; sc* sH_pre = nullptr;
+    IpaGeo geo;      // the R1CS prover's factor vectors in closed form (kernels.hpp) instead of cG / cH
     ge_cached* vtab_pre = nullptr; size_t vtab_pre_count = 0;
 #if !defined(BPR1CS_HOSTSIM)
     hipEvent_t* tail_event = nullptr;
@@ -917,8 +920,28 @@ static IpaEnd enqueue_ipa(const IpaIO& io, dev_stream_t st, MsmStats* stats) {
     ge* GHp = nullptr; ge* vwinp = nullptr; ge* vsump = nullptr; ge* voutp = nullptr;
     ge_cached* vtabp = nullptr; uint32_t* vdigp = nullptr; sc* linvp = nullptr; sc* crossp = cross.p;
     sc* sGp = io.sG_pre; sc* sHp = io.sH_pre;
-    if (r > 0 && !(sGp && sHp)) { sG.alloc((size_t)N * B); sH.alloc((size_t)N * B); sGp = sG.p; sHp = sH.p; }
-    const size_t s_bytes = r > 0 ? (size_t)N * B * sizeof(sc) : 0;
+    const bool geo = io.geo.plo != nullptr;
+    if ((r > 0 || (geo && lgN > 0)) && !(sGp && sHp)) { sG.alloc((size_t)N * B); sH.alloc((size_t)N * B); sGp = sG.p; sHp = sH.p; }
+    const size_t s_bytes = sGp ? (size_t)N * B * sizeof(sc) : 0;
+    const uint32_t facT = 1u << r;
+    DevBuf<sc> fac;
+    const uint32_t hfJ = N >> 8;
+    DevBuf<sc> hf;
+    if (geo && lgN > 0) {
+        fac.alloc((size_t)6 * facT * B);
+        if (hfJ) hf.alloc((size_t)2 * hfJ * B);
+    }
+    // closed-form factors of round k: the per-proof products (and, for blocks of >= 256 positions, their table by i >> 8), then the scalars
+    auto geo_scalars = [&](uint32_t k, const sc* va, const sc* vb) {
+        const uint32_t lgNk = lgN - k;
+        launch((uint64_t)2 * B, K_ipa_fac{fac.p, k ? io.uk + (size_t)(k - 1) * 2 * B : nullptr, io.geo.upad, B, k, facT}, st);
+        const sc* hfp = nullptr;
+        if (lgNk >= 8 && hfJ) {
+            launch((uint64_t)2 * hfJ * B, K_ipa_hf{fac.p, io.geo.phi + (size_t)io.geo.H * B, hf.p, B, hfJ, lgNk - 8, facT}, st);
+            hfp = hf.p;
+        }
+        launch((uint64_t)N * B, K_ipa_scalars_geo{va, vb, fac.p, hfp, io.geo, sGp, sHp, B, N >> k, lgNk, facT, hfJ}, st);
+    };
     const uint32_t VC = 16;  // chunks per Straus output (8 / 32 / 64 measured within 0.3 %)
     // variable-base rounds come in pairs on one set of multiples, generators folded two levels at a time (K_ipa_vb_dig2 / _fold2)
     bool vb_reuse = false;
@@ -1006,9 +1029,13 @@ static IpaEnd enqueue_ipa(const IpaIO& io, dev_stream_t st, MsmStats* stats) {
         uint8_t* Lout = io.LR + ((size_t)k * 2 + 0) * B * 32;
         uint8_t* Rout = io.LR + ((size_t)k * 2 + 1) * B * 32;
         if (k < r) {
-            K_ipa_scalars ks{a, bb, cG, cH, sGp, sHp, B, Nk};
-            if (k > 0) ks.uk_prev = io.uk + (size_t)(k - 1) * 2 * B;   // round k-1's fold of the generator factors rides along
-            launch((uint64_t)N * B, ks, st);
+            if (geo) {
+                geo_scalars(k, a, bb);
+            } else {
+                K_ipa_scalars ks{a, bb, cG, cH, sGp, sHp, B, Nk};
+                if (k > 0) ks.uk_prev = io.uk + (size_t)(k - 1) * 2 * B;   // round k-1's fold of the generator factors rides along
+                launch((uint64_t)N * B, ks, st);
+            }
             uint32_t half = N / 2;
             // L: G-terms with pos >= m, H-terms with pos < m ; R: the complement
             MsmSeg gL{sGp, half, mk, Nk, mk, baseG, 0}, hL{sHp, half, mk, Nk, 0, baseH, 0};
@@ -1029,19 +1056,26 @@ static IpaEnd enqueue_ipa(const IpaIO& io, dev_stream_t st, MsmStats* stats) {
         } else {
             if (k == r) {
                 GH.alloc((size_t)2 * M * B);
+                const sc* fG = cG; const sc* fH = cH;   // scalars of the folded generators: Montgomery factor vectors, or ...
+                if (geo) {  // ... their closed form, written out once (canonical) where the product scalars of the rounds before lived
+                    geo_scalars(k, nullptr, nullptr);
+                    fG = sGp; fH = sHp;
+                }
+                const uint32_t f_mont = geo ? 0u : 1u;
+                (void)f_mont;
 #if defined(BPR1CS_HOSTSIM)
-                launch_wave((uint64_t)2 * M * B, K_ipa_fold_from_tables{g->tab.p, g->tc, cG, cH, GH.p, B, M, N, baseG, baseH}, st);
+                launch_wave((uint64_t)2 * M * B, K_ipa_fold_from_tables{g->tab.p, g->tc, fG, fH, GH.p, B, M, N, baseG, baseH, geo ? 1u : 0u}, st);
 #else
                 if (B < 32) {
-                    launch_wave((uint64_t)2 * M * B, K_ipa_fold_from_tables{g->tab.p, g->tc, cG, cH, GH.p, B, M, N, baseG, baseH}, st);
+                    launch_wave((uint64_t)2 * M * B, K_ipa_fold_from_tables{g->tab.p, g->tc, fG, fH, GH.p, B, M, N, baseG, baseH, geo ? 1u : 0u}, st);
                 } else {
                     // the folded generators through the MSM kernel: output j of a side = the "chunk" of terms i = j (mod M), two
                     // sides = two jobs of one launch (prefetch pipeline, XCD-aware placement of the workgroups sharing a row)
                     MsmLaunch L{};
                     L.B = B; L.nbk = (B + 63u) / 64u; L.tc = g->tc; L.njobs = 2;
                     const MsmSeg none{nullptr, 0, 1, 1, 0, 0, 0};
-                    L.job[0] = MsmJob{{MsmSeg{cG, N, N, N, 0, baseG, 1}, none}, g->tab.p, GH.p, N / M, M, 1};
-                    L.job[1] = MsmJob{{MsmSeg{cH, N, N, N, 0, baseH, 1}, none}, g->tab.p, GH.p + (size_t)M * B, N / M, M, 1};
+                    L.job[0] = MsmJob{{MsmSeg{fG, N, N, N, 0, baseG, f_mont}, none}, g->tab.p, GH.p, N / M, M, 1};
+                    L.job[1] = MsmJob{{MsmSeg{fH, N, N, N, 0, baseH, f_mont}, none}, g->tab.p, GH.p + (size_t)M * B, N / M, M, 1};
                     L.wg_end[0] = M * L.nbk; L.wg_end[1] = 2 * M * L.nbk;
                     launch_msm_kernel(g, L, st, stats, (uint64_t)2 * N * B);
                 }
@@ -1076,7 +1110,7 @@ static IpaEnd enqueue_ipa(const IpaIO& io, dev_stream_t st, MsmStats* stats) {
         sc* ukk = io.uk + (size_t)k * 2 * B;
         emit(B, K_transcript_LR{io.tr, Lout, ukk, B}, false);
         emit((uint64_t)mk * B, K_ipa_fold_ab{a, bb, ukk, B, mk}, false);
-        if (k + 1 == r) launch((uint64_t)N * B, K_ipa_update_c{cG, cH, ukk, B, Nk}, st);   // (earlier rounds: inside the next K_ipa_scalars)
+        if (k + 1 == r && !geo) launch((uint64_t)N * B, K_ipa_update_c{cG, cH, ukk, B, Nk}, st);   // (earlier rounds: inside the next K_ipa_scalars)
         else if (k < r) {}
         else if (!vb_reuse) {
             vb_reuse = k + 1 < lgN;  // the next round works on this round's multiples
@@ -1445,19 +1479,21 @@ extern "C" int bpr1cs_prove_batch_begin(const bpr1cs_gens* g, const bpr1cs_circu
     // (dead after round r-1) share their memory with the Straus multiples of the first variable-base pair, which K_ipa_vb_tab
     // writes at round r, after the launch that materialises the folded generators: 15 of 40 GiB of a 2048-proof job's back phase.
     const uint32_t r_eff = std::min<uint32_t>((uint32_t)o_unfold, lgN);
+    const bool fvec = g_factor_vectors.load() != 0;   // factor vectors as arrays (measuring knob); default: closed form, no cG / cH
     const uint32_t nfl = c->h_slot_chunk[3 * n + m];
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     const size_t w_bytes = al(((size_t)(3 * n + m) * B + 1) * sizeof(sc)), p_bytes = al((size_t)(nfl ? nfl : 1) * B * sizeof(sc)),
                  v_bytes = al((size_t)N * B * sizeof(sc));
     const size_t vt_count = r_eff < lgN ? (size_t)VB_MULT * 4 * ((N >> r_eff) / 2 ? (N >> r_eff) / 2 : 1) * B : 0;
-    const size_t others = w_bytes + p_bytes + 2 * v_bytes + (r_eff ? 2 * v_bytes : 0);
+    const bool need_s = r_eff > 0 || (!fvec && lgN > 0);   // product scalars of the un-folded rounds / scalars of the folded generators
+    const size_t others = w_bytes + p_bytes + (fvec ? 2 * v_bytes : 0) + (need_s ? 2 * v_bytes : 0);
     DevBuf<uint8_t> shared_blk(std::max(others, vt_count * sizeof(ge_cached)));
     sc* wvec_p = (sc*)shared_blk.p;
     sc* fpart_p = (sc*)(shared_blk.p + w_bytes);
-    sc* cG_p = (sc*)(shared_blk.p + w_bytes + p_bytes);
-    sc* cH_p = (sc*)(shared_blk.p + w_bytes + p_bytes + v_bytes);
-    sc* sG_p = r_eff ? (sc*)(shared_blk.p + w_bytes + p_bytes + 2 * v_bytes) : nullptr;
-    sc* sH_p = r_eff ? (sc*)(shared_blk.p + w_bytes + p_bytes + 3 * v_bytes) : nullptr;
+    uint8_t* nxt = shared_blk.p + w_bytes + p_bytes;
+    sc* cG_p = nullptr; sc* cH_p = nullptr; sc* sG_p = nullptr; sc* sH_p = nullptr;
+    if (fvec) { cG_p = (sc*)nxt; cH_p = (sc*)(nxt + v_bytes); nxt += 2 * v_bytes; }
+    if (need_s) { sG_p = (sc*)nxt; sH_p = (sc*)(nxt + v_bytes); }
     struct { sc* p; } wvec{wvec_p}, cG{cG_p}, cH{cH_p};
     run_flatten(c, 3 * n + m, plo.p, phi.p, wvec.p, B, H, st, fpart_p);
     // 4 wavefronts per SIMD: with one (2^16 threads) the kernel is latency bound and a co-running front kernel doubles its time (9 -> 4 ms)
@@ -1473,6 +1509,7 @@ extern "C" int bpr1cs_prove_batch_begin(const bpr1cs_gens* g, const bpr1cs_circu
 
     // ---- P5: inner-product argument
     IpaIO io{g, B, N, lgN, (uint32_t)o_unfold, tr.p, a.p, bb.p, cG.p, cH.p, chal.p + (size_t)CH_W * B, nullptr, LR.p, uk.p};
+    if (!fvec) { io.geo.plo = plo.p; io.geo.phi = phi.p; io.geo.upad = chal.p + (size_t)CH_U * B; io.geo.H = H; io.geo.n1 = n; }
     DevBuf<sc> hs_scal;
     if (lgN >= 1 && n > N / 2 && n < N && o_unfold >= 1) {
         // padding structure of round 0 (K_range_sum_points): the table of sum_{n - N/2 <= i < N/2} H_i belongs to

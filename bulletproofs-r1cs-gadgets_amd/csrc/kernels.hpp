@@ -976,12 +976,12 @@ struct K_lr_eval {  // gid = i*B + b, i < N
     const sc* chal;
     sc* a;   // [N][B]
     sc* bb;  // [N][B]
-    sc* cG;  // [N][B]
+    sc* cG;  // [N][B], or null: the argument derives its factors from the power tables (IpaGeo)
     sc* cH;  // [N][B]
     uint32_t B, H, n;
     HD void operator()(uint32_t g) const {
         uint32_t i = g / B, b = g % B;
-        sc yi = pow_lookup(plo, phi, 0, H, B, i, b), yinv = pow_lookup(plo, phi, 1, H, B, i, b);
+        sc yi = pow_lookup(plo, phi, 0, H, B, i, b), yinv = (i < n || cG) ? pow_lookup(plo, phi, 1, H, B, i, b) : sc_zero();
         sc x = chal[(size_t)CH_X * B + b];
         if (i < n) {
             size_t ib = (size_t)i * B + b, nb = (size_t)n * B;
@@ -991,14 +991,18 @@ struct K_lr_eval {  // gid = i*B + b, i < N
             sc r0 = sc_sub(wO, yi), r1 = sc_add(sc_mul(yi, aR), wL), r3 = sc_mul(yi, sR);
             a[g] = sc_mul(x, sc_add(l1, sc_mul(x, sc_add(aO, sc_mul(x, sL)))));
             bb[g] = sc_add(r0, sc_mul(x, sc_add(r1, sc_mul(x, sc_mul(x, r3)))));
-            cG[g] = sc_one_mont();
-            cH[g] = yinv;
+            if (cG) {
+                cG[g] = sc_one_mont();
+                cH[g] = yinv;
+            }
         } else {
             a[g] = sc_zero();
             bb[g] = sc_neg(yi);
-            sc u = chal[(size_t)CH_U * B + b];
-            cG[g] = u;
-            cH[g] = sc_mul(yinv, u);
+            if (cG) {
+                sc u = chal[(size_t)CH_U * B + b];
+                cG[g] = u;
+                cH[g] = sc_mul(yinv, u);
+            }
         }
     }
 };
@@ -1051,6 +1055,82 @@ struct K_ipa_scalars {  // gid = i*B + b, i<N
         sH[g] = sc_from_mont(sc_mul(bb[pb], ch));
     }
 };
+// The R1CS prover's factor vectors have a closed form - G_factors[i] = e_i, H_factors[i] = y^-i e_i with e_i = 1 below n1 and the
+// padding challenge from n1 on (K_lr_eval) - and so do their folds: after k rounds the factor of generator i is e_i (y^-i) times a
+// product of k challenges chosen by the top k bits of i, i.e. one of 2^k values per proof and side.  With the description (IpaGeo)
+// instead of the vectors, a round's product scalars are a[partner] * fac[side][i >> lg N_k] * e_i (* y^-i from the power tables):
+// no N x B factor vectors are written by K_lr_eval, read and rewritten by every un-folded round, or folded by K_ipa_update_c.
+struct IpaGeo {
+    const sc* plo = nullptr;   // power tables of K_pow_tables (which = 1: y^-1)
+    const sc* phi = nullptr;
+    const sc* upad = nullptr;  // [B] Montgomery: the factor of the positions >= n1
+    uint32_t H = 0, n1 = 0;
+};
+// fac: [6][T][B] - 0 / 1: the G / H products in Montgomery form (the chain the next round extends); 2, 3: the G products and the
+// G products times the padding factor as CANONICAL integers; 4, 5: the same for H.  A Montgomery product of a Montgomery-form
+// scalar with a canonical one is the canonical product, so the product scalars come out table-ready without a conversion.
+struct K_ipa_fac {  // gid = side*B + b : the 2^k products of round k from the 2^(k-1) of the round before and its challenge
+    sc* fac;
+    const sc* uk;     // [2][B] u, u^-1 of round k-1 (unused for k = 0)
+    const sc* upad;   // [B]
+    uint32_t B, k, T;
+    HD void operator()(uint32_t g) const {
+        uint32_t side = g / B, b = g % B;
+        sc* f = fac + (size_t)side * T * B + b;
+        if (k == 0) f[0] = sc_one_mont();
+        else {
+            sc u = uk[b], ui = uk[(size_t)B + b];
+            sc fhi = side ? ui : u, flo = side ? u : ui;   // G: the upper half of a block takes u, the lower u^-1; H the other way round
+            for (uint32_t t = 1u << (k - 1); t-- > 0;) {
+                sc x = f[(size_t)t * B];
+                f[(size_t)(2 * t + 1) * B] = sc_mul(x, fhi);
+                f[(size_t)(2 * t) * B] = sc_mul(x, flo);
+            }
+        }
+        sc* c0 = fac + (size_t)(2 + 2 * side) * T * B + b;
+        sc* c1 = c0 + (size_t)T * B;
+        sc up = upad[b];
+        for (uint32_t t = 0; t < (1u << k); t++) {
+            sc x = f[(size_t)t * B];
+            c0[(size_t)t * B] = sc_from_mont(x);
+            c1[(size_t)t * B] = sc_from_mont(sc_mul(x, up));
+        }
+    }
+};
+// blocks of >= 256 positions: the H product and the upper power-table entry of y^-i depend on i >> 8 only - one combined table
+struct K_ipa_hf {  // gid = (e*J + j)*B + b : hf = y^-(256 j) * (H product of block j >> shift) [* padding factor], canonical
+    const sc* fac;
+    const sc* phi_yinv;  // [H][B] upper table of y^-1
+    sc* hf;              // [2][J][B]
+    uint32_t B, J, shift, T;
+    HD void operator()(uint32_t g) const {
+        uint32_t b = g % B, ej = g / B, e = ej / J, j = ej % J;
+        hf[g] = sc_mul(phi_yinv[(size_t)j * B + b], fac[((size_t)(4 + e) * T + (j >> shift)) * B + b]);
+    }
+};
+struct K_ipa_scalars_geo {  // gid = i*B + b, i<N
+    const sc* a;    // null: the factors themselves (scalars of the launch that materialises the folded generators)
+    const sc* bb;
+    const sc* fac;  // as of this round (K_ipa_fac)
+    const sc* hf;   // K_ipa_hf's table, or null (blocks shorter than 256)
+    IpaGeo geo;
+    sc* sG;
+    sc* sH;
+    uint32_t B, Nk, lgNk, T, J;
+    HD void operator()(uint32_t g) const {
+        uint32_t i = g / B, b = g % B, m = Nk >> 1;
+        uint32_t pos = i & (Nk - 1), t = i >> lgNk;
+        uint32_t partner = pos >= m ? pos - m : pos + m;
+        size_t pb = (size_t)partner * B + b;
+        const uint32_t e = i >= geo.n1 ? 1u : 0u;
+        sc cg = fac[((size_t)(2 + e) * T + t) * B + b];
+        sc ch;
+        if (hf) ch = sc_mul(geo.plo[((size_t)256 + (i & 255u)) * B + b], hf[((size_t)e * J + (i >> 8)) * B + b]);
+        else ch = sc_mul(pow_lookup(geo.plo, geo.phi, 1, geo.H, B, i, b), fac[((size_t)(4 + e) * T + t) * B + b]);
+        sG[g] = a ? sc_mul(a[pb], cg) : cg;
+        sH[g] = a ? sc_mul(bb[pb], ch) : ch;
+    }
+};
 struct K_transcript_LR {  // append L,R -> u_k, u_k^-1
     strobe* tr;
     const uint8_t* LR;  // [2][B][32] for this round
@@ -1100,6 +1180,7 @@ struct K_ipa_fold_from_tables {  // gid = (side*M + j)*B + b
     const sc* cH;
     ge* GH;  // [2][M][B]
     uint32_t B, M, N, baseG, baseH;
+    uint32_t canonical = 0;  // 1: cG / cH hold canonical scalars (K_ipa_scalars_geo), not Montgomery forms
     HD void operator()(uint32_t g0) const {
         // XCD-aware order (launch_wave: one wavefront per workgroup, workgroups dealt round-robin to the 8 XCDs): the
         // wavefronts of one output (same table rows, different proofs) run on the same XCD
@@ -1115,7 +1196,7 @@ struct K_ipa_fold_from_tables {  // gid = (side*M + j)*B + b
         uint32_t base0 = side ? baseH : baseG;
         ge acc = ge_identity();
         for (uint32_t i = j; i < N; i += M)
-            acc = table_mul_acc_raw(acc, tab + (size_t)(base0 + i) * tc.base_bytes(), sc_from_mont(c[(size_t)i * B + b]), tc);
+            acc = table_mul_acc_raw(acc, tab + (size_t)(base0 + i) * tc.base_bytes(), canonical ? c[(size_t)i * B + b] : sc_from_mont(c[(size_t)i * B + b]), tc);
         GH[g] = ge_from_table_class(acc);
     }
 };

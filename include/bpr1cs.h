@@ -318,6 +318,12 @@ void bpr1cs_set_tail_fused(int enable);
  * allocates its own scratch.  Results do not depend on it. */
 void bpr1cs_set_shared_back(int enable);
 
+/* measuring knob: 0 (default) = the prover describes the inner-product argument's factor vectors (G_factors = 1 / u,
+ * H_factors = y^-i times the same) in closed form and every un-folded round derives its product scalars from 2^k per-proof
+ * values and the power tables; 1 = it writes them out as two N x B arrays that every un-folded round reads, folds and
+ * rewrites (the form bpr1cs_ipa_create, whose factors are arbitrary, always uses).  Same bytes either way. */
+void bpr1cs_set_factor_vectors(int enable);
+
 /* measuring knob: log2 of the (chunk, proof) threads a launch of the fixed-base MSM kernel is cut into (default 21: ~32 k
  * wavefronts per launch; fewer = longer chunks and a longer launch tail, more = more first-term overhead and partial sums) */
 void bpr1cs_set_msm_threads_log2(int lg);

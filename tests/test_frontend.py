@@ -74,6 +74,13 @@ def test_job_memory_knobs_do_not_change_a_byte(sim_lib, sim_glib):
             sim_lib.bpr1cs_set_shared_back(shared)
             sim_lib.bpr1cs_set_tail_rounds(tail)
             fc.check_compiled(sim_lib, sim_glib, "vsmt_2_cube", batch=2)
+        sim_lib.bpr1cs_set_factor_vectors(1)   # the argument's factor vectors written out instead of their closed form
+        for unfold in (4, 0, 9):
+            fc.check_compiled(sim_lib, sim_glib, "vsmt_2_cube", batch=2, unfold=unfold)
+        sim_lib.bpr1cs_set_factor_vectors(0)
+        for unfold in (0, 1, 9):               # closed form: no un-folded round / one / every round from the tables
+            fc.check_compiled(sim_lib, sim_glib, "vsmt_2_cube", batch=2, unfold=unfold)
     finally:
+        sim_lib.bpr1cs_set_factor_vectors(0)
         sim_lib.bpr1cs_set_shared_back(1)
         sim_lib.bpr1cs_set_tail_rounds(7)

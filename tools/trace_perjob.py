@@ -34,6 +34,23 @@ print("# steady state over %d device jobs: period %.1f ms per job, back stream b
 print("# kernel | launches per job | ms per job | share of the back stream")
 for k, a in sorted(agg.items(), key=lambda kv: -kv[1][1])[: int(sys.argv[2]) if len(sys.argv) > 2 else 16]:
     print("%-28s | %5.1f | %8.2f | %5.1f %%" % (k, a[0] / nb, a[1] / nb, 100 * a[1] / tot))
+# idle time of the heavy stream inside the window, by the pair of launches it lies between
+gaps = collections.defaultdict(lambda: [0, 0.0])
+ws = sorted(w, key=lambda r: r[1])
+for r0, r1 in zip(ws, ws[1:]):
+    gp = (r1[1] - r0[2]) / 1e6
+    if gp > 0.004:
+        a = gaps[r0[0] + " -> " + r1[0]]; a[0] += 1; a[1] += gp
+print("# idle time of the back stream (gaps > 4 us), per job, by neighbour pair: count ms   [sum of all gaps %.2f ms per job]" % (sum(max(0, r1[1] - r0[2]) for r0, r1 in zip(ws, ws[1:])) / 1e6 / nb))
+for k, a in sorted(gaps.items(), key=lambda kv: -kv[1][1])[:10]:
+    print("  %-58s %5.1f %8.2f" % (k, a[0] / nb, a[1] / nb))
+for r0, r1 in zip(ws, ws[1:]):
+    gp = (r1[1] - r0[2]) / 1e6
+    if gp > 0.5:
+        ji = max(i for i, a in enumerate(asm) if a[1] <= r1[1] + 200e6)
+        fr = [f for f in rows if f[0] in ("k_rng_stream", "k_witness_team") and f[2] > r0[2] - 300e6 and f[1] < r1[1] + 50e6]
+        print("#   gap of %.2f ms between %s and %s, %.1f ms before K_transcript_A number %d; front kernels around it: %s" % (gp, r0[0], r1[0], (asm[ji][1] - r1[1]) / 1e6, ji,
+              ", ".join("%s [%.1f .. %.1f]" % (f[0], (f[1] - r1[1]) / 1e6, (f[2] - r1[1]) / 1e6) for f in fr)))
 tail = [r for r in rows if r[3] != hq and r[0].startswith("K_") and r[0] not in ("K_rng_reduce", "K_transcript_init", "K_commit_v", "K_load_inputs") and r[1] >= lo and r[2] <= hi]
 if tail:
     first = {}
