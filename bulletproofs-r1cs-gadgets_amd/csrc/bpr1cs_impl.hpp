@@ -1989,6 +1989,8 @@ extern "C" int bpr1cs_msm(const uint8_t* scalars, const uint8_t* points, size_t 
     int f = 0;
     dev_d2h(out, d_out.p, 32, st);
     dev_d2h(&f, fail.p, sizeof(int), st);
+    dev_zero(d_s.p, 32 * n, st);   // the scalars may be secret
+    dev_zero(vdig.p, vdig.bytes(), st);
     return f ? BPR1CS_ERR_FORMAT : BPR1CS_OK;
     API_CATCH
 }
