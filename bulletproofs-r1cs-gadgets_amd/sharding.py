@@ -43,25 +43,28 @@ def _all_gather_bytes(payload, group=None, device=None):
 
 def make_comm(bp, rank, world, group=None, device=None, lib=None):
     """An RCCL communicator owned by the library (bp.Comm) for the ranks of a torch.distributed job (or a single process):
-    rank 0 draws the unique id, the others receive it by a broadcast of 128 bytes.  -> bp.Comm, or None when rank 0 could not
-    draw an id (every rank then learns that from the broadcast and none enters ncclCommInitRank)."""
+    rank 0 draws the unique id, the others receive it by a broadcast of 128 bytes.  -> bp.Comm, or None when some rank cannot
+    load RCCL (the ranks agree on that first, and then none enters ncclCommInitRank)."""
     import torch
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or world == 1:
         return bp.Comm(bp.Comm.unique_id(lib), 0, 1, lib=lib)
-    uid = bytes(128)
-    if rank == 0:
-        try:
-            uid = bp.Comm.unique_id(lib)
-        except Exception:
-            uid = bytes(128)
-    t = torch.frombuffer(bytearray(uid), dtype=torch.uint8)
+    # ncclCommInitRank blocks until every rank has joined: a rank that cannot even load RCCL must be known BEFORE anybody enters
+    # it.  Every rank draws an id of its own as the test (rank 0's is the one that is used) and the ranks agree on the outcome.
+    uid, ok = bytes(128), 1
+    try:
+        uid = bp.Comm.unique_id(lib)
+    except Exception:
+        uid, ok = bytes(128), 0
+    t = torch.frombuffer(bytearray(uid) + bytearray([ok]), dtype=torch.uint8).clone()
+    flag = torch.tensor([ok], dtype=torch.int32)
     if device is not None:
-        t = t.to(device)
+        t, flag = t.to(device), flag.to(device)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
     dist.broadcast(t, src=0, group=group)
-    uid = bytes(t.cpu().numpy().tobytes())
-    if uid == bytes(128):
+    if int(flag.item()) == 0:
         return None
+    uid = bytes(t[:128].cpu().numpy().tobytes())
     return bp.Comm(uid, rank, world, lib=lib)
 
 

@@ -40,6 +40,9 @@ def _worker(rank, world, port, sim_path, global_batch, q):
     gens = bp.Gens(16, lib=lib)
     lib.bpr1cs_set_unfold_rounds(2)
     P, _ = bp.prove_batch(gens, circ, ob["label"], ob["values"], ob["blindings"], seeds, hi - lo, wires=ob["wires"])
+    # the library-owned RCCL communicator cannot exist on the simulator: every rank learns that from the agreement step of
+    # make_comm and none of them enters the (blocking) communicator creation
+    assert sh.make_comm(bp, rank, world, lib=lib) is None
     digest = hashlib.sha256(b"".join(P)).digest()
     t = torch.tensor(list(digest), dtype=torch.uint8)
     out = [torch.zeros(32, dtype=torch.uint8) for _ in range(world)]
