@@ -153,16 +153,19 @@ HD inline ge ge_madd(const ge& p, const ge_niels& q, int negate) {
 //      calls ("table class"): X, Y, T are fe_mul_f outputs (limbs in [-2^24, F'), F' = 2^29 + 2^24), Z is centred
 //      (|limb| <= N = 2^28 + 2^23); a point in the ordinary class (all coordinates N) is also accepted.  q: limbs in [0, 2^29).
 //   U = Y+X <= 2F', |V = Y-X| <= F' + 2^24 ;  A = U a, B = V b : 9 * 2F' * 2^29 = 2^62.2          (fe_mul_f)
-//   C = T q.dxy : F' * 2^29, centred output (N) ;  |cZ|, |cT| <= 2N ;  |cX| <= F' + 2^24 ;  cY <= 2F'
-//   X' = cX cT : 9 * 1.04F' * 2N = 2^61.3 ;  Y' = cY cZ : 9 * 2F' * 2N = 2^62.3 ;  T' = cX cY : 9 * 1.04F' * 2F' = 2^62.3  (fe_mul_f)
-//   Z' = cZ cT : 9 * 2N * 2N = 2^61.2                                                               (fe_mul, centred)
-// all below the 2^63 limit of the signed 64-bit column sums.  Five of the seven products use the floor-carry form.
+//   C = T q.dxy : 9 * F' * 2^29 = 2^61.2, floor-carry output too (limbs in [-2^24, F')) ;  |cZ|, |cT| <= N + F' = 3N ;
+//   |cX| <= F' + 2^24 ;  cY <= 2F'
+//   X' = cX cT : 9 * 1.04F' * 3N = 2^61.8 ;  Y' = cY cZ : 9 * 2F' * 3N = 2^62.8 ;  T' = cX cY : 9 * 1.04F' * 2F' = 2^62.3  (fe_mul_f)
+//   Z' = cZ cT : 9 * 3N * 3N = 2^62.4                                                               (fe_mul, centred)
+// all below the 2^63 limit of the signed 64-bit column sums (tests/test_hostsim_prims.py drives the worst-case limb patterns of
+// every class through the multipliers and through the whole addition).  Six of the seven products use the floor-carry form;
+// exactly one of C and Z' has to stay centred (with both in floor form cZ reaches 2^30 and Y' 2^63.2).
 HD inline ge ge_madd_t(const ge& p, const ge_niels& q, int negate) {
     fe a = fe_select(q.yplusx, q.yminusx, negate);
     fe b = fe_select(q.yminusx, q.yplusx, negate);
     fe PP = fe_mul_f(fe_add(p.Y, p.X), a);
     fe MM = fe_mul_f(fe_sub(p.Y, p.X), b);
-    fe Tdxy = fe_mul(p.T, q.xy2d);
+    fe Tdxy = fe_mul_f(p.T, q.xy2d);
     fe cX = fe_sub(PP, MM), cY = fe_add(PP, MM);
     fe zp = fe_add(p.Z, Tdxy), zm = fe_sub(p.Z, Tdxy);
     fe cZ = fe_select(zp, zm, negate), cT = fe_select(zm, zp, negate);

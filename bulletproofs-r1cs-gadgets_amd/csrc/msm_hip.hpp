@@ -13,7 +13,7 @@
 //     during the second layer (4 multiplications, ~2800 issue cycles), so the HBM gather latency never stalls a wave.
 //     The entry registers are dead between the layers: the prefetch costs no extra VGPRs.
 //   * Digit 0 selects slot 0 of the row (the identity, see TabCfg): no divergent branch inside the pipeline.
-//   * Accumulator in the "table class" (ge_madd_t): five of seven products use the cheaper floor-carry multiplier.
+//   * Accumulator in the "table class" (ge_madd_t): six of seven products use the cheaper floor-carry multiplier.
 //   * Signed digits without selects: a per-lane polarity of the accumulator (see the loop body).
 #pragma once
 #include <hip/hip_runtime.h>
@@ -140,6 +140,7 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) k_msm_fixed2(const MsmLaun
     const uint32_t lo = J.interleave ? c : c * J.chunk;
     const uint32_t hi = J.interleave ? total : (lo + J.chunk < total ? lo + J.chunk : total);
     const uint32_t dig_buf = tc.windows * 64u;  // digits of term parity p start at msm_dig[p * dig_buf + lane]
+    const size_t row_bytes = (size_t)tc.row * tc.stride;
 
     // fetch the next term whose scalars are not all zero (IPA round 0: the l-vector is zero beyond n)
     auto fetch = [&](uint32_t& o, sc& x, MsmTerm& t) -> bool {
@@ -181,24 +182,28 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) k_msm_fixed2(const MsmLaun
             // always the plain one (no swap of y+x / y-x, no swap of cZ / cT).
             const int32_t sgn = -(int32_t)(d >> 15);   // -1: negative digit
             const int32_t flip = sgn ^ pol;
-            pol = sgn;
+            const uint32_t fadd = (uint32_t)flip & 1u;   // (x ^ m) - m written as (x ^ m) + (m & 1): hipcc then emits ONE v_xad_u32 per limb
+            pol = sgn;                                   // (left as xor and subtract it emits two: 18 instructions more per addition, +0.7 %)
 #pragma unroll
             for (int i = 0; i < 9; i++) {
-                acc.X.v[i] = (acc.X.v[i] ^ flip) - flip;
-                acc.T.v[i] = (acc.T.v[i] ^ flip) - flip;
+                acc.X.v[i] = (int32_t)(((uint32_t)acc.X.v[i] ^ (uint32_t)flip) + fadd);
+                acc.T.v[i] = (int32_t)(((uint32_t)acc.T.v[i] ^ (uint32_t)flip) + fadd);
             }
             ge_niels q = msm_entry_unpack(E);
             fe PP = fe_mul_f(fe_add(acc.Y, acc.X), q.yplusx);
             fe MM = fe_mul_f(fe_sub(acc.Y, acc.X), q.yminusx);
-            fe Txy2d = fe_mul(acc.T, q.xy2d);
+            fe Txy2d = fe_mul_f(acc.T, q.xy2d);   // floor-carry form as well: six of the seven products (limb budget: ge_madd_t in ge.hpp)
             // ---- request the next entry: it lands while layer 2 runs
             __builtin_amdgcn_sched_barrier(0);
+            // address = wave-uniform row pointer (scalar registers) + 32-bit per-lane offset: the loads take the scalar base
+            // directly (global_load ... saddr) instead of a 64-bit per-lane multiply-add
             if (k + 1 < tc.windows) {
                 d = msm_dig[cur * dig_buf + (k + 1) * 64u + lane];
-                msm_entry_load(E, T.tab + ((size_t)(k + 1) * tc.row + (d & 0x7fffu)) * tc.stride);
+                const uint8_t* rowp = T.tab + (size_t)(k + 1) * row_bytes;
+                msm_entry_load(E, rowp + (uint32_t)((d & 0x7fffu) * tc.stride));
             } else if (have2) {
                 d = msm_dig[(cur ^ 1u) * dig_buf + lane];
-                msm_entry_load(E, T2.tab + (size_t)(d & 0x7fffu) * tc.stride);
+                msm_entry_load(E, T2.tab + (uint32_t)((d & 0x7fffu) * tc.stride));
             }
             __builtin_amdgcn_sched_barrier(0);
             // ---- layer 2

@@ -156,7 +156,7 @@ def test_table_class_limb_bounds(prim_lib):
     for a in floor_pat():
         for b in floor_pat():
             a2 = [2 * x for x in a]                      # cY <= 2F'
-            b3 = [min(3 * N, max(-3 * N, 3 * x)) for x in b]  # |cZ| <= 2N in ge_madd_t; 3N leaves margin
+            b3 = [min(3 * N, max(-3 * N, 3 * x)) for x in b]  # |cZ|, |cT| <= N + F' = 3N in ge_madd_t (T*dxy in floor-carry form)
             prim_lib.hs_fe_mul_f_limbs(I9(*a2), I9(*b3), out, ol)
             assert int.from_bytes(bytes(out), "little") == val(a2) * val(b3) % P
             assert min(ol) >= -2**24 and max(ol) < FP
