@@ -150,7 +150,9 @@ inline void dev_sync(dev_stream_t s) { HIPCHK(hipStreamSynchronize(s)); }
 template <class F>
 __global__ void __launch_bounds__(256) k_functor(F f, uint32_t n) {
     uint32_t g = blockIdx.x * 256u + threadIdx.x;
-    if (g < n) f(g);
+    // always inlined HERE: a functor that is also a step of k_tail_program (or simply large) is otherwise compiled once as an
+    // out-of-line function for the worst case of all its callers (227-248 VGPRs, scratch, flat loads) and CALLED from its own kernel
+    if (g < n) INLINE_CALL f(g);
 }
 template <class F>
 inline void launch(uint64_t n, const F& f, dev_stream_t s) {
@@ -170,7 +172,7 @@ inline void launch(uint64_t n, const F& f, dev_stream_t s) {
 template <class F>
 __global__ void __launch_bounds__(64) k_functor_wave(F f, uint32_t n) {
     uint32_t g = blockIdx.x * 64u + threadIdx.x;
-    if (g < n) f(g);
+    if (g < n) INLINE_CALL f(g);
 }
 template <class F>
 inline void launch_wave(uint64_t n, const F& f, dev_stream_t s) {

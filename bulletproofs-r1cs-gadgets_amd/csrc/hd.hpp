@@ -7,9 +7,11 @@
 #define HD
 #define HD_CONST static constexpr
 #define DEV_ONLY
+#define INLINE_CALL
 #else
 #include <hip/hip_runtime.h>
 #define HD __host__ __device__
 #define HD_CONST static constexpr
 #define DEV_ONLY __device__
+#define INLINE_CALL [[clang::always_inline]]   // statement attribute: inline THIS call (a kernel's call of its functor body)
 #endif

@@ -814,7 +814,7 @@ struct K_pair {
     F a, b;
     uint32_t B;
     HD void operator()(uint32_t g) const {
-        if (g < B) a(g); else b(g - B);
+        if (g < B) INLINE_CALL a(g); else INLINE_CALL b(g - B);
     }
 };
 
