@@ -1,0 +1,174 @@
+// C ABI: the path's only exchange step: RCCL all_gathers of the sharded batched verifier.
+#pragma once
+#include "api_verify.hpp"
+#include "api_lowlevel.hpp"
+// ---------------------------------------------------------------- the exchange step behind the C ABI
+// The batched verifier of a job sharded over several GPUs is the path's only inter-GPU step.  A host in any language gets
+// it here: RCCL (librccl, loaded on first use: the library carries no link-time dependency on it) all_gathers the ranks'
+// combined scalar vectors and their 65 result bytes over xGMI; everything else is the entry points above.
+#if !defined(BPR1CS_HOSTSIM)
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+struct RcclApi {
+    decltype(&ncclGetUniqueId) get_unique_id = nullptr;
+    decltype(&ncclCommInitRank) comm_init_rank = nullptr;
+    decltype(&ncclCommDestroy) comm_destroy = nullptr;
+    decltype(&ncclAllGather) all_gather = nullptr;
+    bool ok = false;
+};
+static RcclApi& rccl_api() {
+    static RcclApi api = [] {
+        RcclApi a;
+        void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) return a;
+        a.get_unique_id = (decltype(a.get_unique_id))dlsym(h, "ncclGetUniqueId");
+        a.comm_init_rank = (decltype(a.comm_init_rank))dlsym(h, "ncclCommInitRank");
+        a.comm_destroy = (decltype(a.comm_destroy))dlsym(h, "ncclCommDestroy");
+        a.all_gather = (decltype(a.all_gather))dlsym(h, "ncclAllGather");
+        a.ok = a.get_unique_id && a.comm_init_rank && a.comm_destroy && a.all_gather;
+        return a;
+    }();
+    return api;
+}
+#endif
+struct bpr1cs_comm {
+    int rank = 0, world = 1;
+    bool owned = false;
+#if !defined(BPR1CS_HOSTSIM)
+    ncclComm_t comm = nullptr;
+#endif
+};
+extern "C" int bpr1cs_comm_unique_id(uint8_t id_out[128]) {
+    if (!id_out) return BPR1CS_ERR_INVALID_ARGUMENT;
+#if defined(BPR1CS_HOSTSIM)
+    return BPR1CS_ERR_NO_DEVICE;
+#else
+    if (!have_device()) return BPR1CS_ERR_NO_DEVICE;
+    if (!rccl_api().ok) return BPR1CS_ERR_DEVICE;
+    ncclUniqueId id;
+    static_assert(sizeof(id) == 128, "ncclUniqueId is 128 bytes");
+    if (rccl_api().get_unique_id(&id) != ncclSuccess) return BPR1CS_ERR_DEVICE;
+    memcpy(id_out, &id, 128);
+    return BPR1CS_OK;
+#endif
+}
+extern "C" int bpr1cs_comm_create(const uint8_t id[128], int rank, int world, bpr1cs_comm** out) {
+    if (!id || !out || world < 1 || rank < 0 || rank >= world) return BPR1CS_ERR_INVALID_ARGUMENT;
+#if defined(BPR1CS_HOSTSIM)
+    return BPR1CS_ERR_NO_DEVICE;
+#else
+    if (!have_device()) return BPR1CS_ERR_NO_DEVICE;
+    if (!rccl_api().ok) return BPR1CS_ERR_DEVICE;
+    ncclUniqueId uid;
+    memcpy(&uid, id, 128);
+    bpr1cs_comm* c = new (std::nothrow) bpr1cs_comm();
+    if (!c) return BPR1CS_ERR_OUT_OF_MEMORY;
+    c->rank = rank; c->world = world; c->owned = true;
+    if (world == 1) {
+        // RCCL allocates its own device buffers: when this library's allocator cache holds the rest of the device, give it back
+        // and try once more (only where no other rank is waiting inside the same collective initialisation)
+        if (rccl_api().comm_init_rank(&c->comm, world, uid, rank) != ncclSuccess) {
+            dev_pool().release_all();
+            ncclUniqueId uid2;
+            if (rccl_api().get_unique_id(&uid2) != ncclSuccess || rccl_api().comm_init_rank(&c->comm, 1, uid2, 0) != ncclSuccess) { delete c; return BPR1CS_ERR_DEVICE; }
+        }
+    } else {
+        dev_pool().release_all();   // before the ranks meet: cached blocks are of no use to RCCL
+        if (rccl_api().comm_init_rank(&c->comm, world, uid, rank) != ncclSuccess) { delete c; return BPR1CS_ERR_DEVICE; }
+    }
+    *out = c;
+    return BPR1CS_OK;
+#endif
+}
+extern "C" int bpr1cs_comm_wrap(void* nccl_comm, int rank, int world, bpr1cs_comm** out) {
+    if (!nccl_comm || !out || world < 1 || rank < 0 || rank >= world) return BPR1CS_ERR_INVALID_ARGUMENT;
+#if defined(BPR1CS_HOSTSIM)
+    return BPR1CS_ERR_NO_DEVICE;
+#else
+    if (!rccl_api().ok) return BPR1CS_ERR_DEVICE;
+    bpr1cs_comm* c = new (std::nothrow) bpr1cs_comm();
+    if (!c) return BPR1CS_ERR_OUT_OF_MEMORY;
+    c->rank = rank; c->world = world; c->owned = false; c->comm = (ncclComm_t)nccl_comm;
+    *out = c;
+    return BPR1CS_OK;
+#endif
+}
+extern "C" void bpr1cs_comm_destroy(bpr1cs_comm* c) {
+    if (!c) return;
+#if !defined(BPR1CS_HOSTSIM)
+    if (c->owned && c->comm && rccl_api().ok) (void)rccl_api().comm_destroy(c->comm);
+#endif
+    delete c;
+}
+// all_gather of `len` bytes per rank through device buffers on the handle's stream (no communicator: a copy)
+static int comm_all_gather(const bpr1cs_gens* g, const bpr1cs_comm* c, const uint8_t* mine, size_t len, std::vector<uint8_t>& all) {
+    const int world = c ? c->world : 1;
+    all.assign((size_t)world * len, 0);
+    if (!c) { memcpy(all.data(), mine, len); return BPR1CS_OK; }   // (a communicator of ONE rank still goes through RCCL)
+#if defined(BPR1CS_HOSTSIM)
+    (void)g;
+    return BPR1CS_ERR_NO_DEVICE;
+#else
+    API_TRY
+    dev_stream_t st = g->stream;
+    CallScope scope(st);
+    DevBuf<uint8_t> d_in(len), d_out((size_t)world * len);
+    dev_h2d(d_in.p, mine, len, st);
+    if (rccl_api().all_gather(d_in.p, d_out.p, len, ncclUint8, c->comm, st) != ncclSuccess) return BPR1CS_ERR_DEVICE;
+    dev_d2h(all.data(), d_out.p, (size_t)world * len, st);
+    return BPR1CS_OK;
+    API_CATCH
+#endif
+}
+extern "C" int bpr1cs_verify_batch_sharded(const bpr1cs_gens* g, const bpr1cs_circuit* c, const uint8_t* label, size_t label_len,
+                                           const uint8_t* proofs, const uint8_t* commitments, const uint8_t* verifier_rng_seeds,
+                                           const uint8_t* batch_seed, uint64_t index_base, size_t batch, const bpr1cs_comm* comm,
+                                           int* accepted_out) {
+    if (!accepted_out || !g || !c) return BPR1CS_ERR_INVALID_ARGUMENT;
+    *accepted_out = 0;
+    const int rank = comm ? comm->rank : 0, world = comm ? comm->world : 1;
+    const size_t N = c->N, nb = 2 * N + 2, vlen = 32 * nb;
+    // 1. this rank's combined scalar vector and the weighted sum of its proofs' own points.  A rank that fails locally still
+    //    takes part in both collectives (zero vector, "not well-formed"): the others must never be left waiting.
+    std::vector<uint8_t> vec(vlen, 0), all;
+    uint8_t own[32] = {0}, slice_pt[32] = {0};
+    int wf = 0;
+    int rc_local = bpr1cs_verify_batch_scalars(g, c, label, label_len, proofs, commitments, verifier_rng_seeds, batch_seed, index_base, batch,
+                                               vec.data(), own, &wf);
+    if (rc_local != BPR1CS_OK) { std::fill(vec.begin(), vec.end(), 0); memset(own, 0, 32); wf = 0; }
+    // 2. all_gather of the scalar vectors ((2N+2)*32 bytes per rank, ~2 MB at N = 32768), summed mod l
+    int rc = comm_all_gather(g, comm, vec.data(), vlen, all);
+    if (rc != BPR1CS_OK) return rc;
+    std::vector<uint8_t> total(vlen);
+    if (bpr1cs_scalars_sum(all.data(), (size_t)world, nb, total.data()) != BPR1CS_OK) wf = 0;
+    else {
+        // 3. this rank's 1/world slice of the shared bases (base order of the vector == base indices of bpr1cs_msm_fixed when
+        //    N == capacity; for N < capacity the H block starts at 2 + capacity)
+        const size_t base = nb / (size_t)world, rem = nb % (size_t)world;
+        const size_t lo = (size_t)rank * base + std::min<size_t>((size_t)rank, rem), hi = lo + base + ((size_t)rank < rem ? 1 : 0);
+        if (hi > lo) {
+            std::vector<uint32_t> bases(hi - lo);
+            for (size_t i = lo; i < hi; i++) bases[i - lo] = (uint32_t)(i < 2 + N ? i : i - N + g->cap);
+            if (bpr1cs_msm_fixed(g, bases.data(), hi - lo, total.data() + 32 * lo, 1, slice_pt) != BPR1CS_OK) wf = 0;
+        }
+    }
+    // 4. all_gather of (slice point, own-points sum, well-formed flag): 65 bytes per rank, padded to 72
+    uint8_t mine[72] = {0};
+    memcpy(mine, slice_pt, 32); memcpy(mine + 32, own, 32); mine[64] = wf ? 1 : 0;
+    rc = comm_all_gather(g, comm, mine, sizeof mine, all);
+    if (rc != BPR1CS_OK) return rc;
+    std::vector<uint8_t> pts((size_t)2 * world * 32);
+    bool all_wf = true;
+    for (int r = 0; r < world; r++) {
+        memcpy(&pts[(size_t)r * 32], &all[(size_t)r * 72], 32);
+        memcpy(&pts[((size_t)world + r) * 32], &all[(size_t)r * 72 + 32], 32);
+        all_wf = all_wf && all[(size_t)r * 72 + 64] == 1;
+    }
+    uint8_t sum[32];
+    if (!all_wf || bpr1cs_points_sum(pts.data(), (size_t)2 * world, sum) != BPR1CS_OK) return BPR1CS_OK;   // rejected
+    uint8_t acc = 0;
+    for (int i = 0; i < 32; i++) acc |= sum[i];
+    *accepted_out = acc == 0;
+    return BPR1CS_OK;
+}

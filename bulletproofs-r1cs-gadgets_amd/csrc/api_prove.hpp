@@ -1,0 +1,484 @@
+// C ABI: the batched prover (Prover::commit x m + gadget synthesis + Prover::prove), asynchronous jobs.
+#pragma once
+#include "ipa.hpp"
+struct bpr1cs_job {
+    const bpr1cs_gens* g = nullptr;
+    dev_stream_t st{}, st2{}, st3{}, st4{};
+    std::vector<void*> deferred;
+    PhaseTimer pt;
+    MsmStats msm;
+    uint32_t B = 0, m = 0;
+    size_t plen = 0;
+    uint8_t* h_proofs = nullptr;  // pinned staging
+    uint8_t* h_comms = nullptr;
+    int* h_err = nullptr;
+    bool counted = false;         // contributes to g->in_flight
+    IpaIO::TailKeep tail;         // the IPA tail's own buffers (outside the handle's shared arena)
+#if !defined(BPR1CS_HOSTSIM)
+    hipEvent_t ev_in{}, ev_rng{}, ev_wit{}, ev_done{}, ev_rng0{}, ev_rng1{}, ev_tail{};
+#endif
+};
+// pinned staging buffers are cached: hipHostFree (like hipFree) synchronises the whole device, which
+// would serialise the in-flight jobs
+struct HostStage {
+    std::mutex mu;
+    std::multimap<size_t, void*> cache;
+    std::map<void*, size_t> live;
+};
+static HostStage& host_stage() {
+    static HostStage* h = new HostStage();  // intentionally leaked: must outlive static destructors
+    return *h;
+}
+static void* host_stage_alloc(size_t n) {
+    if (n == 0) n = 1;
+#if defined(BPR1CS_HOSTSIM)
+    return malloc(n);
+#else
+    HostStage& hs = host_stage();
+    std::lock_guard<std::mutex> lk(hs.mu);
+    auto it = hs.cache.lower_bound(n);
+    void* p = nullptr;
+    size_t sz = n;
+    if (it != hs.cache.end() && it->first <= 2 * n + 4096) { p = it->second; sz = it->first; hs.cache.erase(it); }
+    else HIPCHK(hipHostMalloc(&p, n, hipHostMallocDefault));
+    hs.live[p] = sz;
+    return p;
+#endif
+}
+static void host_stage_free(void* p) {
+#if defined(BPR1CS_HOSTSIM)
+    free(p);
+#else
+    if (!p) return;
+    HostStage& hs = host_stage();
+    std::lock_guard<std::mutex> lk(hs.mu);
+    auto it = hs.live.find(p);
+    if (it == hs.live.end()) return;
+    hs.cache.insert({it->second, p});
+    hs.live.erase(it);
+#endif
+}
+static void dev_d2h_async(void* h, const void* d, size_t n, dev_stream_t s) {
+#if defined(BPR1CS_HOSTSIM)
+    memcpy(h, d, n);
+#else
+    HIPCHK(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, s));
+#endif
+    (void)s;
+}
+// wait for everything a job has enqueued and release what it holds (normal end and error paths)
+static void job_release(bpr1cs_job* job) {
+    if (!job) return;
+#if !defined(BPR1CS_HOSTSIM)
+    // the heavy stream is shared with the NEXT job in flight: wait for this job's own completion event, and for the
+    // whole stream only when the job failed before recording it
+    if (job->ev_done) (void)hipEventSynchronize(job->ev_done);
+    else if (job->st) (void)hipStreamSynchronize(job->st);
+    if (job->st2) (void)hipStreamSynchronize(job->st2);
+    if (job->st3) (void)hipStreamSynchronize(job->st3);
+    if (job->st4) (void)hipStreamSynchronize(job->st4);
+    hipEvent_t* evs[7] = {&job->ev_in, &job->ev_rng, &job->ev_wit, &job->ev_done, &job->ev_rng0, &job->ev_rng1, &job->ev_tail};
+    for (auto e : evs)
+        if (*e) { (void)hipEventDestroy(*e); *e = nullptr; }
+    for (auto e : job->pt.ev) (void)hipEventDestroy(e);
+    job->pt.ev.clear();
+#endif
+    for (void* p : job->deferred) dev_free_now(p);
+    job->deferred.clear();
+    host_stage_free(job->h_proofs);
+    host_stage_free(job->h_comms);
+    host_stage_free(job->h_err);
+    host_stage_free(job->tail.h_prog);
+    job->tail.h_prog = nullptr;
+    if (job->counted) job->g->in_flight--;
+    delete job;
+}
+
+extern "C" int bpr1cs_prove_batch_begin(const bpr1cs_gens* g, const bpr1cs_circuit* c, const uint8_t* label, size_t label_len,
+                                        const uint8_t* values, const uint8_t* v_blindings, const uint8_t* rng_seeds,
+                                        const uint8_t* wires, size_t batch, bpr1cs_job** job_out) {
+    if (!g || !c || !label || !rng_seeds || !job_out || batch == 0) return BPR1CS_ERR_INVALID_ARGUMENT;
+    if (c->m && (!values || !v_blindings)) return BPR1CS_ERR_INVALID_ARGUMENT;
+    if (!have_device()) return BPR1CS_ERR_NO_DEVICE;
+    if (g->cap < c->N) return BPR1CS_ERR_INVALID_GENERATORS_LENGTH;
+    if (!wires && !c->has_program) return BPR1CS_ERR_MISSING_ASSIGNMENT;
+    // the largest grid of the call must fit 2^32 threads (N = 32768: batch <= 26 000; serve larger jobs in several calls)
+    if (batch > (1u << 20) || ((uint64_t)4 * c->N + 3ull * c->n + c->m + 64) * batch > 0xffffffffull) return BPR1CS_ERR_INVALID_ARGUMENT;
+    // Scalar inputs are canonical encodings (Scalar::to_bytes); anything else is refused here
+    if (c->m && (!host_scalars_canonical(values, batch * c->m) || !host_scalars_canonical(v_blindings, batch * c->m))) return BPR1CS_ERR_INVALID_ARGUMENT;
+    if (wires && !host_scalars_canonical(wires, batch * 3 * (size_t)c->n)) return BPR1CS_ERR_INVALID_ARGUMENT;
+    bpr1cs_job* job = nullptr;
+    struct Scope {  // every buffer released while enqueuing stays alive until the job has drained
+        std::vector<void*>* prev;
+        explicit Scope(bpr1cs_job* j) : prev(dev_deferred_frees()) { dev_deferred_frees() = &j->deferred; }
+        ~Scope() { dev_deferred_frees() = prev; }
+    };
+    try {
+    job = new bpr1cs_job();
+    job->g = g;
+    uint32_t slot = g->next_job++ & 1u;
+    job->st = g->jstream[0][0];  // ONE heavy stream: MSM/IPA phases of successive jobs run back to back (FIFO; a heavy stream per job measured 3.4 % slower)
+    job->st2 = g->jstream[slot][1];
+    job->st3 = g->jstream[slot][2];
+    // the tail runs on the job's own witness stream: idle since the witness kernel ended (before the job's first sum), high
+    // priority, and never used by the other job in flight (that one has the other slot).  A stream of its own would change the
+    // streams' mapping onto the few hardware queues (measured: two more streams serialised the jobs, 2540 -> 2040 proofs/s)
+    job->st4 = g->jstream[slot][2];
+    Scope scope(job);
+    // per-call knobs: the handle's own setting, else the process default
+    const int o_unfold = g->opts.unfold.load() >= 0 ? g->opts.unfold.load() : g_unfold_rounds.load();
+    const int o_rng = g->opts.rng_mode.load() >= 0 ? g->opts.rng_mode.load() : g_rng_mode.load();
+    const int o_team = g->opts.witness_team.load() >= 0 ? g->opts.witness_team.load() : g_witness_team.load();
+    const int o_merge = g_merge_triples.load();
+    const int o_tail = g->opts.tail_rounds.load() >= 0 ? g->opts.tail_rounds.load() : g_tail_rounds.load();
+    const uint32_t B = (uint32_t)batch, n = c->n, m = c->m, N = c->N, lgN = c->lgN;
+    const uint32_t baseG = 2, baseH = 2 + g->cap;
+    dev_stream_t st = job->st;
+    PhaseTimer& pt = job->pt;
+    MsmStats* stats = &job->msm;
+    job->B = B; job->m = m;
+#if defined(BPR1CS_HOSTSIM)
+    dev_stream_t sl = st;
+#else
+    dev_stream_t sl = job->st2;  // the latency-bound front of the job never touches the heavy stream
+#endif
+    pt.mark(sl);
+
+    // ---- inputs
+    DevBuf<sc> v_raw, vbl_raw, v_m((size_t)m * B), vbl_m((size_t)m * B);
+    upload_transposed(v_raw, values, B, m, sl);
+    upload_transposed(vbl_raw, v_blindings, B, m, sl);
+    DevBuf<uint8_t> d_seeds((size_t)B * 32), d_label(label_len ? label_len : 1);
+    dev_h2d(d_seeds.p, rng_seeds, (size_t)B * 32, sl);
+    if (label_len) dev_h2d(d_label.p, label, label_len, sl);
+    launch((uint64_t)m * B, K_load_inputs{v_raw.p, vbl_raw.p, v_m.p, vbl_m.p}, sl);
+
+    // ---- P1: V commitments, transcript, RNG stream
+    DevBuf<uint8_t> Vcomp((size_t)B * m * 32 + 1);
+    launch((uint64_t)m * B, K_commit_v{g->tab.p, g->tc, v_raw.p, vbl_raw.p, Vcomp.p, B, m}, sl);
+    DevBuf<strobe> tr(B);
+    DevBuf<sc> blind((size_t)8 * B), W((size_t)5 * n * B + 1);
+    sc* sL = W.p + (size_t)3 * n * B;
+    sc* sR = W.p + (size_t)4 * n * B;
+    pt.mark(sl);
+#if defined(BPR1CS_HOSTSIM)
+    (void)o_rng; (void)o_team;
+    launch(B, K_transcript_init{d_label.p, (uint32_t)label_len, Vcomp.p, vbl_raw.p, d_seeds.p, tr.p, blind.p, sL, sR, nullptr, B, m, n}, st);
+#else
+    hipEvent_t& ev_in = job->ev_in;
+    hipEvent_t& ev_rng = job->ev_rng;
+    HIPCHK(hipEventCreateWithFlags(&ev_in, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&ev_rng, hipEventDisableTiming));
+    HIPCHK(hipEventRecord(ev_in, sl));
+    const uint32_t draws = 2 * n + 7;
+    DevBuf<strobe> rng(B);
+    DevBuf<uint64_t> rng_raw((size_t)draws * B * 8);
+    DevBuf<int> rng_err(1);
+    dev_zero(rng_err.p, sizeof(int), sl);
+    launch(B, K_transcript_init{d_label.p, (uint32_t)label_len, Vcomp.p, vbl_raw.p, d_seeds.p, tr.p, blind.p, sL, sR, rng.p, B, m, n}, sl);
+    // a batch already in flight hides this chain's latency: then take the variant with the smallest VALU footprint
+    // (only with CUs reserved for it - see bpr1cs_gens_create)
+    const bool rng_per_thread = o_rng == 2 || (o_rng == 0 && g->rng_isolated && g->in_flight.load() > 0);
+    // ... or (explicit request only) the variant on the scalar unit: it takes no VALU issue slots, but a wavefront
+    // issues one scalar instruction per ~9 cycles, so the chain is 3.7x slower (717 ms per batch) and its 1024 resident
+    // wavefronts still slow the co-running MSM launches by 40 % - measured 1000 proofs/s against 1590
+    const bool rng_scalar = o_rng == 3;
+    if (o_rng == 5) {
+        hipLaunchKernelGGL(k_rng_rows, dim3((B + 7) / 8), dim3(64), 0, sl, rng.p, rng_raw.p, rng_err.p, B, draws);
+    } else if (o_rng == 4) {
+        hipLaunchKernelGGL(k_rng_dpp, dim3(B), dim3(64), 0, sl, rng.p, rng_raw.p, rng_err.p, B, draws);
+    } else if (rng_scalar) {
+        hipLaunchKernelGGL(k_rng_scalar, dim3(B), dim3(64), 0, sl, rng.p, rng_raw.p, rng_err.p, B, draws);
+    } else if (rng_per_thread && !g->rng_isolated) {
+        hipLaunchKernelGGL(k_rng_thread, dim3((B + 63) / 64), dim3(64), 0, sl, rng.p, rng_raw.p, rng_err.p, B, draws);
+    } else if (rng_per_thread) {
+        dev_stream_t sr = g->jstream[slot][3];
+        hipEvent_t& e0 = job->ev_rng0;
+        hipEvent_t& e1 = job->ev_rng1;
+        HIPCHK(hipEventCreateWithFlags(&e0, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&e1, hipEventDisableTiming));
+        HIPCHK(hipEventRecord(e0, sl));
+        HIPCHK(hipStreamWaitEvent(sr, e0, 0));
+        hipLaunchKernelGGL(k_rng_thread, dim3((B + 63) / 64), dim3(64), 0, sr, rng.p, rng_raw.p, rng_err.p, B, draws);
+        HIPCHK(hipEventRecord(e1, sr));
+        HIPCHK(hipStreamWaitEvent(sl, e1, 0));
+    } else hipLaunchKernelGGL(k_rng_stream, dim3((B + 1) / 2), dim3(64), 0, sl, rng.p, rng_raw.p, rng_err.p, B, draws);
+    HIPCHK(hipGetLastError());
+    launch((uint64_t)draws * B, K_rng_reduce{rng_raw.p, blind.p, sL, sR, B, n}, sl);
+    dev_zero(rng_raw.p, rng_raw.bytes(), sl);  // raw blinding material
+    dev_zero(rng.p, rng.bytes(), sl);
+    HIPCHK(hipEventRecord(ev_rng, sl));
+#endif
+
+    // ---- P7/P8: witness (device program) or host-synthesised wires
+    DevBuf<sc> px;
+    if (wires) {
+        DevBuf<sc> raw;
+        upload_transposed(raw, wires, B, (size_t)3 * n, sl);
+        launch((uint64_t)3 * n * B, K_load_wires{raw.p, W.p}, sl);
+        dev_zero(raw.p, raw.bytes(), sl);
+        dev_sync(sl);
+    } else {
+        K_witness kw{c->wops.p, c->lc_off.p, c->lc_var.p, c->lc_coeff.p, v_raw.p, v_m.p, W.p, B, n};
+        DevBuf<uint8_t> pzf;
+        if (c->n_perms) {
+            px.alloc((size_t)4 * c->px_stride * B);
+            pzf.alloc((size_t)c->px_stride * B);
+            kw.ptab = c->ptab.p; kw.perms = c->perms.p; kw.n_perms = c->n_perms; kw.pconst = c->pconst.p;
+            kw.px = px.p; kw.pzf = pzf.p; kw.px_stride = c->px_stride;
+        }
+#if defined(BPR1CS_HOSTSIM)
+        launch(B, kw, st);
+#else
+        int T = o_team;
+        if (c->n_perms && (uint32_t)T < c->macro_width + 2) T = 16;  // poseidon_team needs width + 2 lanes
+        kw.prio = 2;  // above the co-resident MSM waves (default 0), below the RNG chain (3)
+        uint32_t blocks = (uint32_t)(((uint64_t)B * T + 63) / 64);
+        HIPCHK(hipStreamWaitEvent(job->st3, ev_in, 0));
+        if (T == 4) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_witness_team<4>), dim3(blocks), dim3(64), 0, job->st3, kw);
+        else if (T == 8) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_witness_team<8>), dim3(blocks), dim3(64), 0, job->st3, kw);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_witness_team<16>), dim3(blocks), dim3(64), 0, job->st3, kw);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipEventCreateWithFlags(&job->ev_wit, hipEventDisableTiming));
+        HIPCHK(hipEventRecord(job->ev_wit, job->st3));
+        HIPCHK(hipStreamWaitEvent(st, job->ev_wit, 0));
+#endif
+    }
+    // ---- P2: A_I1, A_O1, S1.  The sums of A_I1 and A_O1 need the wires only, so they are enqueued BEFORE the heavy stream
+    // waits for the TranscriptRng chain (the longer of the two front kernels); their blinding terms and all of S1 follow it.
+    DevBuf<ge> partial, partialO;
+    DevBuf<uint8_t> AOS((size_t)3 * B * 32);
+    MsmPlan plan;
+    {
+        sc* aL = W.p; sc* aR = W.p + (size_t)n * B; sc* aO = W.p + (size_t)2 * n * B;
+        MsmSeg none{nullptr, 0, 1, 1, 0, 0, 0};
+        auto seg = [&](const sc* p, uint32_t base0) { return MsmSeg{p, n, n ? n : 1, n ? n : 1, 0, base0, 1}; };
+        const uint32_t T3 = (uint32_t)c->h_trip.size();
+        DevBuf<ge> partial2, partialO1;
+        MsmPlan planO, planO1{0, 0};
+        const ge* ones_pt = nullptr;
+        K_msm_finish finI{g->tab.p, g->tc, nullptr, blind.p + 0 * (size_t)B, nullptr, AOS.p + 0 * (size_t)B * 32, B, 0, 1};
+        if (!wires && T3 && o_merge) {
+            // A_I1 with the repeated S-box wires merged: 2 terms per S-box instead of 5 (see K_merge_points).  The merged
+            // tables belong to (circuit, generator handle); the first job that needs them builds them on the heavy stream.
+            const uint8_t* mtab = nullptr;
+            {
+                std::lock_guard<std::mutex> lk(c->mt_mu);
+                bpr1cs_circuit::MergedTab*& mt = c->mt[g];
+                if (!mt) mt = new bpr1cs_circuit::MergedTab();
+                if (mt->W != g->tc.W || mt->cap != g->cap || mt->fmt != g->tc.fmt || !mt->tab.p) {
+                    DevBuf<ge> mp((size_t)2 * T3);
+                    launch(T3, K_merge_points{g->pts.p, c->trip.p, mp.p, T3, baseG, baseH}, st);
+                    mt->tab.alloc((size_t)2 * T3 * g->tc.base_bytes());
+                    launch((uint64_t)2 * T3 * g->tc.windows, K_build_table{mp.p, mt->tab.p, g->tc}, st);
+                    DevBuf<ge> part64(64);
+                    mt->ones_pt.alloc(1);
+                    launch(64, K_triple_ones_point{g->pts.p, c->trip.p, part64.p, T3, baseG}, st);
+                    launch(1, K_ge_reduce{part64.p, mt->ones_pt.p, 1, 64, 64}, st);
+                    mt->W = g->tc.W; mt->cap = g->cap; mt->fmt = g->tc.fmt;
+                }
+                mtab = mt->tab.p;
+                ones_pt = mt->ones_pt.p;
+            }
+            const uint32_t nr = (uint32_t)c->h_rest.size();
+            MsmSeg rG{aL, nr, 1, 1, 0, baseG, 1, c->rest.p, 0}, rH{aR, nr, 1, 1, 0, baseH, 1, c->rest.p, 0};
+            MsmSeg mG{aL, T3, 1, 1, 0, 0, 1, c->trip.p, 1}, mH{aR, T3, 1, 1, 0, T3, 1, c->trip.p, 1};
+            MsmPlan plan2;
+            // A_O: the a_O wires of an S-box triple are (1, 0, 1) unless the S-box input was 0, so their generators enter as ONE
+            // constant point of the circuit and the sum only carries (a_O - 1) for them - zero, and skipped by the kernel, in all
+            // but exceptional proofs: 608 real terms instead of 18 656 for the depth-32 circuit
+            MsmSeg oRest{aO, nr, 1, 1, 0, baseG, MSM_MONT, c->rest.p, 0}, oOnes{aO, 2 * T3, 1, 1, 0, baseG, MSM_MINUS_ONE, c->ones.p, 0};
+            // (measured against the plain n-term sum on one box: first launch of a batch 27 -> 13.5 ms)
+            MsmReq rq[4] = {{rG, rH, &partial, &plan, nullptr}, {mG, mH, &partial2, &plan2, mtab}, {oRest, none, &partialO, &planO, nullptr},
+                            {oOnes, none, &partialO1, &planO1, nullptr, 256}};
+            run_msm_multi(g, rq, 4, B, st, stats);  // the sums that need the wires only share one launch
+            finI.partial = partial.p;
+            finI.nchunks = plan.nchunks;
+            finI.partial_b = partial2.p;
+            finI.nchunks_b = plan2.nchunks;
+        } else {
+            MsmReq rq[2] = {{seg(aL, baseG), seg(aR, baseH), &partial, &plan, nullptr}, {seg(aO, baseG), none, &partialO, &planO, nullptr}};
+            run_msm_multi(g, rq, 2, B, st, stats);
+            finI.partial = partial.p;
+            finI.nchunks = plan.nchunks;
+        }
+#if !defined(BPR1CS_HOSTSIM)
+        HIPCHK(hipStreamWaitEvent(st, ev_rng, 0));  // (in the wires path everything on `sl` was synchronised above)
+#endif
+        pt.mark(st);
+        launch(B, finI, st);
+        K_msm_finish finO{g->tab.p, g->tc, partialO.p, blind.p + 1 * (size_t)B, nullptr, AOS.p + 1 * (size_t)B * 32, B, planO.nchunks, 1};
+        if (ones_pt) { finO.shared_pt = ones_pt; finO.partial_b = partialO1.p; finO.nchunks_b = planO1.nchunks; }
+        launch(B, finO, st);
+        run_msm(g, seg(sL, baseG), seg(sR, baseH), B, partial, plan, st, stats);
+        launch(B, K_msm_finish{g->tab.p, g->tc, partial.p, blind.p + 2 * (size_t)B, nullptr, AOS.p + 2 * (size_t)B * 32, B, plan.nchunks, 1}, st);
+    }
+    pt.mark(st);
+
+    // ---- from here on the job's scratch comes from the handle's arena, shared with the other job in flight: that job's
+    // back phase is AHEAD of this one on the heavy stream (FIFO), and its tail - the only part that runs on another stream -
+    // works on copies of its own (IpaIO::TailKeep), so stream order alone keeps the two jobs apart: no event, no wait.
+    struct ArenaHook {
+        DevArena* prev;
+        explicit ArenaHook(DevArena* a) : prev(dev_arena()) { if (a) { a->next = 0; dev_arena() = a; } }
+        ~ArenaHook() { dev_arena() = prev; }
+    };
+    // what the IPA tail and the proof assembly read stays the job's own: challenges, T commitments, t_x.., L/R, u_k
+    DevBuf<sc> chal((size_t)CH_COUNT * B), txs((size_t)3 * B), uk((size_t)(lgN ? lgN : 1) * 2 * B);
+    DevBuf<uint8_t> Tc((size_t)5 * B * 32), LR((size_t)(lgN ? lgN : 1) * 2 * B * 32);
+    const bool shared_back = g_shared_back.load() != 0;
+    ArenaHook arena_hook(shared_back ? &g->arena : nullptr);
+
+    // ---- P3/P4: challenges, flatten, t(x), T commitments, l(x), r(x)
+    launch(B, K_transcript_A{tr.p, AOS.p, chal.p, B}, st);
+    uint32_t maxe = std::max<uint32_t>(N, c->q + 1);
+    uint32_t H = (maxe >> 8) + 1;
+    DevBuf<sc> plo((size_t)3 * 256 * B), phi((size_t)3 * H * B);
+    launch((uint64_t)3 * B, K_pow_tables{chal.p, plo.p, phi.p, B, H}, st);
+    // ONE block for buffers whose lives do not overlap: the flattened constraints and their chunk sums (dead after l(x), r(x)),
+    // the generator factors cG / cH (dead once the folded generators exist) and the product scalars of the un-folded rounds
+    // (dead after round r-1) share their memory with the Straus multiples of the first variable-base pair, which K_ipa_vb_tab
+    // writes at round r, after the launch that materialises the folded generators: 15 of 40 GiB of a 2048-proof job's back phase.
+    const uint32_t r_eff = std::min<uint32_t>((uint32_t)o_unfold, lgN);
+    const bool fvec = g_factor_vectors.load() != 0;   // factor vectors as arrays (measuring knob); default: closed form, no cG / cH
+    const uint32_t nfl = c->h_slot_chunk[3 * n + m];
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t w_bytes = al(((size_t)(3 * n + m) * B + 1) * sizeof(sc)), p_bytes = al((size_t)(nfl ? nfl : 1) * B * sizeof(sc)),
+                 v_bytes = al((size_t)N * B * sizeof(sc));
+    const size_t vt_count = r_eff < lgN ? (size_t)VB_MULT * 4 * ((N >> r_eff) / 2 ? (N >> r_eff) / 2 : 1) * B : 0;
+    const bool need_s = r_eff > 0 || (!fvec && lgN > 0);   // product scalars of the un-folded rounds / scalars of the folded generators
+    const size_t others = w_bytes + p_bytes + (fvec ? 2 * v_bytes : 0) + (need_s ? 2 * v_bytes : 0);
+    DevBuf<uint8_t> shared_blk(std::max(others, vt_count * sizeof(ge_cached)));
+    sc* wvec_p = (sc*)shared_blk.p;
+    sc* fpart_p = (sc*)(shared_blk.p + w_bytes);
+    uint8_t* nxt = shared_blk.p + w_bytes + p_bytes;
+    sc* cG_p = nullptr; sc* cH_p = nullptr; sc* sG_p = nullptr; sc* sH_p = nullptr;
+    if (fvec) { cG_p = (sc*)nxt; cH_p = (sc*)(nxt + v_bytes); nxt += 2 * v_bytes; }
+    if (need_s) { sG_p = (sc*)nxt; sH_p = (sc*)(nxt + v_bytes); }
+    struct { sc* p; } wvec{wvec_p}, cG{cG_p}, cH{cH_p};
+    run_flatten(c, 3 * n + m, plo.p, phi.p, wvec.p, B, H, st, fpart_p);
+    // 4 wavefronts per SIMD: with one (2^16 threads) the kernel is latency bound and a co-running front kernel doubles its time (9 -> 4 ms)
+    uint32_t tchunk, TC = pick_chunks(n, B, 1u << 18, tchunk);
+    DevBuf<sc> tpart((size_t)6 * TC * B), tco((size_t)6 * B);
+    launch((uint64_t)TC * B, K_tcoef_partial{W.p, wvec.p, plo.p, phi.p, tpart.p, B, H, n, tchunk, TC}, st);
+    launch((uint64_t)6 * B, K_sum_partials{tpart.p, tco.p, B, TC}, st);
+    launch((uint64_t)5 * B, K_commit_T{g->tab.p, g->tc, tco.p, blind.p, Tc.p, B}, st);
+    launch(B, K_transcript_T{tr.p, Tc.p, tco.p, blind.p, wvec.p + (size_t)3 * n * B, vbl_m.p, chal.p, txs.p, B, m, (uint64_t)N}, st);
+    DevBuf<sc> a((size_t)N * B), bb((size_t)N * B);
+    launch((uint64_t)N * B, K_lr_eval{W.p, wvec.p, plo.p, phi.p, chal.p, a.p, bb.p, cG.p, cH.p, B, H, n}, st);
+    pt.mark(st);
+
+    // ---- P5: inner-product argument
+    IpaIO io{g, B, N, lgN, (uint32_t)o_unfold, tr.p, a.p, bb.p, cG.p, cH.p, chal.p + (size_t)CH_W * B, nullptr, LR.p, uk.p};
+    if (!fvec) { io.geo.plo = plo.p; io.geo.phi = phi.p; io.geo.upad = chal.p + (size_t)CH_U * B; io.geo.H = H; io.geo.n1 = n; }
+    DevBuf<sc> hs_scal;
+    if (lgN >= 1 && n > N / 2 && n < N && o_unfold >= 1) {
+        // padding structure of round 0 (K_range_sum_points): the table of sum_{n - N/2 <= i < N/2} H_i belongs to
+        // (circuit shape, generator handle) and is built by the first job that needs it
+        std::lock_guard<std::mutex> lk(c->mt_mu);
+        bpr1cs_circuit::MergedTab*& mt = c->mt[g];
+        if (!mt) mt = new bpr1cs_circuit::MergedTab();
+        if (!mt->hs_tab.p || mt->hs_W != g->tc.W || mt->hs_cap != g->cap || mt->hs_fmt != g->tc.fmt) {
+            struct ArenaPause {  // the table outlives the job: it must not come from the jobs' shared arena
+                DevArena* saved;
+                ArenaPause() : saved(dev_arena()) { dev_arena() = nullptr; }
+                ~ArenaPause() { dev_arena() = saved; }
+            } pause;
+            DevBuf<ge> part64(64), hsum(1);
+            launch(64, K_range_sum_points{g->pts.p, part64.p, baseH + (n - N / 2), baseH + N / 2}, st);
+            launch(1, K_ge_reduce{part64.p, hsum.p, 1, 64, 64}, st);
+            mt->hs_tab.alloc(g->tc.base_bytes());
+            launch(g->tc.windows, K_build_table{hsum.p, mt->hs_tab.p, g->tc}, st);
+            mt->hs_W = g->tc.W; mt->hs_cap = g->cap; mt->hs_fmt = g->tc.fmt;  // only once allocation and launches went through
+        }
+        hs_scal.alloc(B);
+        launch(B, K_neg_ypow{plo.p, phi.p, hs_scal.p, B, H, N / 2}, st);
+        io.hs_tab = mt->hs_tab.p;
+        io.hs_scal = hs_scal.p;
+        io.hs_from = n - N / 2;
+    }
+    io.tail_stream = job->st4;
+    io.tail_rounds = (uint32_t)o_tail;
+#if !defined(BPR1CS_HOSTSIM)
+    io.tail_event = &job->ev_tail;
+#endif
+    io.sG_pre = sG_p; io.sH_pre = sH_p;
+    io.vtab_pre = (ge_cached*)shared_blk.p; io.vtab_pre_count = shared_blk.n / sizeof(ge_cached);
+    io.tail_keep = &job->tail;
+    io.tail_fused = g_tail_fused.load();
+    const IpaEnd ipa_end = enqueue_ipa(io, st, stats);
+    st = ipa_end.st;  // from here on `st` may be the job's tail stream: only the job's own buffers are touched below
+    size_t plen = bpr1cs_proof_len(c);
+    job->plen = plen;
+    DevBuf<uint8_t> d_out((size_t)B * plen);
+    launch(B, K_assemble{AOS.p, Tc.p, txs.p, LR.p, ipa_end.a, ipa_end.bb, d_out.p, B, lgN, (uint32_t)plen}, st);
+    pt.mark(st);
+    job->h_proofs = (uint8_t*)host_stage_alloc((size_t)B * plen);
+    job->h_comms = (uint8_t*)host_stage_alloc((size_t)B * m * 32);
+    job->h_err = (int*)host_stage_alloc(sizeof(int));
+    *job->h_err = 0;
+    dev_d2h_async(job->h_proofs, d_out.p, (size_t)B * plen, st);
+    if (m) dev_d2h_async(job->h_comms, Vcomp.p, (size_t)B * m * 32, st);
+    // secrets do not stay in the allocator's cache (upstream wipes them with clear_on_drop): witness, blindings, the
+    // blinding vectors s_L / s_R, the l / r vectors and the Poseidon scratch are zeroed before their blocks are released
+    dev_zero(W.p, W.bytes(), st);
+    dev_zero(blind.p, blind.bytes(), st);
+    dev_zero(v_raw.p, v_raw.bytes(), st); dev_zero(vbl_raw.p, vbl_raw.bytes(), st);
+    dev_zero(v_m.p, v_m.bytes(), st); dev_zero(vbl_m.p, vbl_m.bytes(), st);
+    if (ipa_end.a == a.p) { dev_zero(a.p, a.bytes(), st); dev_zero(bb.p, bb.bytes(), st); }  // (else: zeroed at the hand-off, on the heavy stream)
+    else { dev_zero(job->tail.a.p, job->tail.a.bytes(), st); dev_zero(job->tail.bb.p, job->tail.bb.bytes(), st); }
+    if (px.p) dev_zero(px.p, px.bytes(), st);
+    dev_zero(d_seeds.p, d_seeds.bytes(), st);
+#if !defined(BPR1CS_HOSTSIM)
+    dev_d2h_async(job->h_err, rng_err.p, sizeof(int), st);
+    HIPCHK(hipEventCreateWithFlags(&job->ev_done, hipEventDisableTiming));
+    HIPCHK(hipEventRecord(job->ev_done, st));
+#endif
+    g->in_flight++;
+    job->counted = true;
+    *job_out = job;
+    return BPR1CS_OK;
+    }
+    catch (const DevError& e_) { job_release(job); return e_.code; }
+    catch (const std::bad_alloc&) { job_release(job); return BPR1CS_ERR_OUT_OF_MEMORY; }
+    catch (...) { job_release(job); return BPR1CS_ERR_DEVICE; }
+}
+
+extern "C" int bpr1cs_prove_batch_end(bpr1cs_job* job, uint8_t* proofs_out, uint8_t* commitments_out) {
+    if (!job || !proofs_out) return BPR1CS_ERR_INVALID_ARGUMENT;
+    int rc = BPR1CS_OK;
+#if !defined(BPR1CS_HOSTSIM)
+    if (hipEventSynchronize(job->ev_done) != hipSuccess) rc = BPR1CS_ERR_DEVICE;
+    (void)hipStreamSynchronize(job->st2);
+    (void)hipStreamSynchronize(job->st3);
+#endif
+    if (rc == BPR1CS_OK) {
+        memcpy(proofs_out, job->h_proofs, (size_t)job->B * job->plen);
+        if (commitments_out && job->m) memcpy(commitments_out, job->h_comms, (size_t)job->B * job->m * 32);
+        if (*job->h_err) rc = BPR1CS_ERR_INVALID_ARGUMENT;  // RNG stream kernel found a non-steady STROBE state
+        try {
+            job->pt.finish(tl_last.timings);
+        } catch (...) {}
+        job->msm.collect();
+        tl_last.msm_ms = job->msm.ms; tl_last.msm_launches = job->msm.launches; tl_last.msm_terms = job->msm.terms;
+    }
+    job_release(job);
+    return rc;
+}
+
+extern "C" int bpr1cs_prove_batch(const bpr1cs_gens* g, const bpr1cs_circuit* c, const uint8_t* label, size_t label_len,
+                                  const uint8_t* values, const uint8_t* v_blindings, const uint8_t* rng_seeds,
+                                  const uint8_t* wires, size_t batch, uint8_t* proofs_out, uint8_t* commitments_out) {
+    if (!proofs_out) return BPR1CS_ERR_INVALID_ARGUMENT;
+    bpr1cs_job* job = nullptr;
+    int rc = bpr1cs_prove_batch_begin(g, c, label, label_len, values, v_blindings, rng_seeds, wires, batch, &job);
+    if (rc) return rc;
+    return bpr1cs_prove_batch_end(job, proofs_out, commitments_out);
+}
+
+extern "C" int bpr1cs_last_msm_stats(double* ms_total, uint64_t* launches, uint64_t* terms) {
+    if (ms_total) *ms_total = tl_last.msm_ms;
+    if (launches) *launches = tl_last.msm_launches;
+    if (terms) *terms = tl_last.msm_terms;
+    return BPR1CS_OK;
+}

@@ -1,0 +1,199 @@
+// Host side of the dominant kernel: launch geometry, HIP-event statistics, chunk-partial reduction; constraint flattening.
+#pragma once
+#include "api_common.hpp"
+// ---------------------------------------------------------------- timing
+struct PhaseTimer {
+#if defined(BPR1CS_HOSTSIM)
+    void mark(dev_stream_t) {}
+    void finish(float*) {}
+#else
+    std::vector<hipEvent_t> ev;
+    void mark(dev_stream_t s) {
+        hipEvent_t e;
+        HIPCHK(hipEventCreate(&e));
+        HIPCHK(hipEventRecord(e, s));
+        ev.push_back(e);
+    }
+    void finish(float* out) {  // out[0] total, out[1..] consecutive phases
+        if (ev.size() < 2) return;
+        HIPCHK(hipEventSynchronize(ev.back()));
+        HIPCHK(hipEventElapsedTime(&out[0], ev.front(), ev.back()));
+        for (size_t i = 1; i < ev.size() && i < 6; i++) HIPCHK(hipEventElapsedTime(&out[i], ev[i - 1], ev[i]));
+        for (auto e : ev) (void)hipEventDestroy(e);
+        ev.clear();
+    }
+#endif
+};
+
+static uint32_t pick_chunks(uint64_t items, uint32_t B, uint32_t target_threads, uint32_t& chunk) {
+    uint32_t want = (target_threads + B - 1) / B;
+    if (want < 1) want = 1;
+    if ((uint64_t)want > items) want = (uint32_t)(items ? items : 1);
+    chunk = (uint32_t)((items + want - 1) / want);
+    if (chunk == 0) chunk = 1;
+    return (uint32_t)((items + chunk - 1) / chunk);
+}
+
+// proof-major host array [B][cnt][32] -> element-major device array [cnt][B]
+static void upload_transposed(DevBuf<sc>& d, const uint8_t* h, size_t B, size_t cnt, dev_stream_t s) {
+    std::vector<sc> t(cnt * B);
+    for (size_t b = 0; b < B; b++)
+        for (size_t j = 0; j < cnt; j++) t[j * B + b] = sc_load_raw(h + (b * cnt + j) * 32);
+    d.alloc(cnt * B);
+    if (cnt * B) dev_h2d(d.p, t.data(), t.size() * sizeof(sc), s);
+}
+
+struct MsmPlan {
+    uint32_t nchunks, chunk;
+};
+
+// HIP-event timing of every launch of the dominant kernel (k_msm_fixed2) on its own stream, for bench.py's roofline
+// object.  One instance per prove job (or per synchronous call): nothing is shared between handles or threads.
+struct MsmStats {
+    double ms = 0;
+    uint64_t launches = 0, terms = 0;  // terms = scalar*point products (summed over the batch)
+#if !defined(BPR1CS_HOSTSIM)
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+    hipEvent_t get() {
+        hipEvent_t e;
+        HIPCHK(hipEventCreate(&e));
+        return e;
+    }
+    ~MsmStats() {
+        for (auto& p : ev) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
+    }
+#endif
+    void collect() {  // after the stream has drained
+#if !defined(BPR1CS_HOSTSIM)
+        for (auto& p : ev) {
+            float t = 0;
+            if (hipEventSynchronize(p.second) == hipSuccess && hipEventElapsedTime(&t, p.first, p.second) == hipSuccess) ms += t;
+            (void)hipEventDestroy(p.first);
+            (void)hipEventDestroy(p.second);
+        }
+        ev.clear();
+#endif
+    }
+};
+
+// Launch geometry: many more workgroups than the chip holds at once (g_msm_target_threads / 64 >> 16 per CU), so
+// that the hardware dispatcher load-balances them - a launch of exactly one resident set makes every workgroup
+// that shares a SIMD with a co-running front kernel a straggler for the whole launch.  Up to MSM_MAX_JOBS independent
+// sums share one launch (k_msm_fixed2).  The chunk partials are folded `MSM_REDUCE_GROUP` at a time (twice when
+// there are many) before the per-proof finish kernel, which then adds at most MSM_REDUCE_GROUP points.
+static const uint32_t MSM_REDUCE_GROUP = 16;
+#if !defined(BPR1CS_HOSTSIM)
+// one launch of the dominant kernel, HIP-event timed on its own stream when `stats` is given; `terms` = scalar*point
+// products of the launch summed over the batch (every launch of k_msm_fixed2 goes through here, so that bench.py's roofline
+// object describes the whole kernel: the commit sums, L_k / R_k of the un-folded rounds AND the folded generators)
+static void launch_msm_kernel(const bpr1cs_gens* g, MsmLaunch& L, dev_stream_t st, MsmStats* stats, uint64_t terms) {
+    hipEvent_t e0{}, e1{};
+    if (stats) {
+        e0 = stats->get(); e1 = stats->get();
+        stats->ev.push_back({e0, e1});
+        HIPCHK(hipEventRecord(e0, st));
+    }
+    L.nwg = (L.wg_end[L.njobs - 1] + 7u) & ~7u;  // a multiple of 8 keeps the XCD-aware remap on
+    const size_t lds = (size_t)2 * g->tc.windows * 64 * sizeof(uint16_t);
+    if (g->tc.fmt == TAB_FMT_PACKED) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_msm_fixed2<(int)TAB_FMT_PACKED, 3>), dim3(L.nwg), dim3(64), lds, st, L);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_msm_fixed2<(int)TAB_FMT_LIMB, 3>), dim3(L.nwg), dim3(64), lds, st, L);
+    HIPCHK(hipGetLastError());
+    if (stats) {
+        HIPCHK(hipEventRecord(e1, st));
+        stats->launches++;
+        stats->terms += terms;
+    }
+}
+#endif
+struct MsmReq {
+    MsmSeg s0, s1;
+    DevBuf<ge>* partial;  // out: the reduced partial sums sit at the front, [plan->nchunks][B]
+    MsmPlan* plan;
+    const uint8_t* table;  // nullptr = the generator tables of `g`
+    uint32_t chunk_hint = 0;  // terms per chunk (0: from the launch geometry).  Sums whose terms are skipped in all but exceptional
+                              // proofs (MSM_MINUS_ONE) take few, long chunks: an empty workgroup still costs its dispatch
+};
+static void run_msm_multi(const bpr1cs_gens* g, MsmReq* reqs, uint32_t nreq, uint32_t B, dev_stream_t st, MsmStats* stats) {
+    if (B < 32) {  // a wavefront per (chunk, 64 proofs) would be mostly idle: lanes take different chunks instead
+        for (uint32_t r = 0; r < nreq; r++) {
+            MsmReq& q = reqs[r];
+            uint32_t total = q.s0.count + q.s1.count;
+            uint32_t nchunks = pick_chunks(total, B, 1u << 16, q.plan->chunk);
+            uint32_t l1 = nchunks > MSM_REDUCE_GROUP ? (nchunks + MSM_REDUCE_GROUP - 1) / MSM_REDUCE_GROUP : 0;
+            size_t need = ((size_t)nchunks + l1) * B;
+            if (q.partial->n < need) q.partial->alloc(need);
+            ge* raw = q.partial->p + (size_t)l1 * B;
+            launch_wave((uint64_t)nchunks * B, K_msm_fixed_small{q.table ? q.table : g->tab.p, g->tc, {q.s0, q.s1}, raw, B, q.plan->chunk, nchunks}, st);
+            if (l1) launch((uint64_t)l1 * B, K_ge_reduce{raw, q.partial->p, B, nchunks, MSM_REDUCE_GROUP}, st);
+            q.plan->nchunks = l1 ? l1 : nchunks;
+            if (stats) { stats->launches++; stats->terms += (uint64_t)total * B; }
+        }
+        return;
+    }
+    const uint32_t nbk = (B + 63u) / 64u;
+    struct Lay { uint32_t nchunks, l1, l2; ge* raw; ge* p1; ge* p2; };
+    Lay lay[MSM_MAX_JOBS];
+#if !defined(BPR1CS_HOSTSIM)
+    MsmLaunch L{};
+    L.B = B; L.nbk = nbk; L.tc = g->tc;
+    L.njobs = nreq;
+#endif
+    uint32_t wg = 0;
+    uint64_t terms = 0;
+    for (uint32_t r = 0; r < nreq; r++) {
+        MsmReq& q = reqs[r];
+        uint32_t total = q.s0.count + q.s1.count;
+        uint32_t nchunks = pick_chunks(total, B, g_msm_target_threads.load(), q.plan->chunk);
+        if (q.chunk_hint) {
+            q.plan->chunk = q.chunk_hint;
+            nchunks = total ? (total + q.chunk_hint - 1) / q.chunk_hint : 1;
+        } else if (q.plan->chunk < 8 && total >= 8) {
+            // short sums that share a launch with long ones: a workgroup needs several terms for its pipeline (the first
+            // term's scalar load, conversion, recoding and first gather are exposed): 1 term per workgroup costs 1.7x per term
+            q.plan->chunk = 8;
+            nchunks = (total + 7) / 8;
+        }
+        uint32_t l1 = nchunks > MSM_REDUCE_GROUP ? (nchunks + MSM_REDUCE_GROUP - 1) / MSM_REDUCE_GROUP : 0;
+        uint32_t l2 = l1 > MSM_REDUCE_GROUP ? (l1 + MSM_REDUCE_GROUP - 1) / MSM_REDUCE_GROUP : 0;
+        size_t need = ((size_t)nchunks + l1 + l2) * B;
+        if (q.partial->n < need) q.partial->alloc(need);
+        lay[r] = Lay{nchunks, l1, l2, q.partial->p + (size_t)(l1 + l2) * B, q.partial->p + (size_t)l2 * B, q.partial->p};
+        q.plan->nchunks = l2 ? l2 : (l1 ? l1 : nchunks);
+        terms += (uint64_t)total * B;
+        wg += nchunks * nbk;
+#if !defined(BPR1CS_HOSTSIM)
+        L.job[r] = MsmJob{{q.s0, q.s1}, q.table ? q.table : g->tab.p, lay[r].raw, q.plan->chunk, nchunks, 0};
+        L.wg_end[r] = wg;
+#endif
+    }
+#if defined(BPR1CS_HOSTSIM)
+    for (uint32_t r = 0; r < nreq; r++) {
+        MsmReq& q = reqs[r];
+        K_msm_fixed k{q.table ? q.table : g->tab.p, g->tc, {q.s0, q.s1}, lay[r].raw, B, q.plan->chunk, nbk, lay[r].nchunks * nbk};
+        launch_wave((uint64_t)lay[r].nchunks * nbk * 64u, k, st);
+    }
+    if (stats) { stats->launches++; stats->terms += terms; }
+    (void)wg;
+#else
+    launch_msm_kernel(g, L, st, stats, terms);
+#endif
+    for (uint32_t r = 0; r < nreq; r++) {
+        if (lay[r].l1) launch((uint64_t)lay[r].l1 * B, K_ge_reduce{lay[r].raw, lay[r].p1, B, lay[r].nchunks, MSM_REDUCE_GROUP}, st);
+        if (lay[r].l2) launch((uint64_t)lay[r].l2 * B, K_ge_reduce{lay[r].p1, lay[r].p2, B, lay[r].l1, MSM_REDUCE_GROUP}, st);
+    }
+}
+static void run_msm(const bpr1cs_gens* g, MsmSeg s0, MsmSeg s1, uint32_t B, DevBuf<ge>& partial, MsmPlan& plan, dev_stream_t st,
+                    MsmStats* stats, const uint8_t* table = nullptr) {
+    MsmReq q{s0, s1, &partial, &plan, table};
+    run_msm_multi(g, &q, 1, B, st, stats);
+}
+
+// constraint columns weighted by powers of z: wvec[slot][b] (first `nslots` slots of the circuit)
+static void run_flatten(const bpr1cs_circuit* c, uint32_t nslots, const sc* plo, const sc* phi, sc* wvec, uint32_t B, uint32_t H, dev_stream_t st,
+                        sc* part_buf = nullptr /* optional room for the chunk sums: h_slot_chunk[nslots] * B scalars */) {
+    uint32_t nch = c->h_slot_chunk[nslots];
+    DevBuf<sc> part;
+    if (!part_buf) { part.alloc((size_t)(nch ? nch : 1) * B); part_buf = part.p; }
+    launch((uint64_t)nch * B, K_flatten_chunks{c->chunk_lo.p, c->ent_row.p, c->ent_coeff.p, plo, phi, part_buf, B, H}, st);
+    launch((uint64_t)nslots * B, K_flatten{c->slot_chunk.p, part_buf, wvec, B, 3 * c->n}, st);
+}
