@@ -7,12 +7,15 @@ Default (`--config c4`): Poseidon-VSMT-4 depth-32 membership (BASELINE.json conf
 One "step" = one pass of the whole hot path over one batch of synthetic witnesses:
 V commitments -> Merlin transcript + TranscriptRng -> constraint synthesis (device witness program: Poseidon S-box
 inversions + MDS, tree selection logic) -> A_I/A_O/S MSMs -> polynomial phase -> inner-product argument -> proof bytes.
-`--fuse F` hands F consecutive steps (F x batch distinct proofs) to the device as ONE prove job: every table row a
-multiscalar multiplication fetches then serves F x batch proofs (config key `proofs_per_device_job`); all K steps are
-proved inside the timed region either way.
+The timed region is ONE call of the library's plain entry point - bpr1cs_prove_batch over all K x batch proofs - on handles
+created with NO options: window width, proofs per device job and jobs in flight are the library's defaults, so what is
+measured is what any caller of the C ABI gets (config keys `proofs_per_device_job`, `device_jobs` report what it chose).
 
-    python bench.py [--config c2|c3|c4|c5|vsmt4_d128|vsmt2_d253] [--gpus N] [--steps K] [--warmup W]
-    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py [--config c2|c3|c4|c5|vsmt4_d128|vsmt2_d253] [--gpus N] [--steps K] [--warmup W] [--configs LIST]
+`--gpus N` with N > 1 launches N ranks by itself (python -m torch.distributed.run --nnodes=1 --nproc-per-node N, rendezvous on
+127.0.0.1) unless it already runs under a launcher (WORLD_SIZE set, which must then equal N); one rank per GPU over RCCL.
+After the headline the same run times the other BASELINE configurations (`configs` block of the JSON: c2, c3, c5 and the
+depths the reference ships, each with its proofs/s and a parity flag against the committed oracle digests).
 
 Prints ONE JSON line on rank 0 (contract in the task prompt), with `roofline` for the dominant kernel (batched fixed-base
 MSM, HIP-event timed on its own stream inside the library), `roofline_valu` (the integer ceiling that really binds it) and
@@ -33,6 +36,7 @@ wl = importlib.import_module("bulletproofs-r1cs-gadgets_amd.workloads")
 # names the tests and tools import from here
 L, synth_scalar, sc, synth_rng_seed = wl.L, wl.synth_scalar, wl.sc, wl.synth_rng_seed
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+NOMINAL_MAD_LANE_OPS = 256 * 4 * 16 * 2.4e9   # v_mad_i64_i32 at a quarter of the lane rate (MI355X_MICROARCH.md: 256 CUs x 4 SIMDs, 2.4 GHz peak engine clock)
 MADS_PER_TABLE_ADD = 7 * 99   # 7 field multiplications (ge_madd_t) x (81 limb products + 9 fold + 9 carry re-entries) v_mad_i64_i32 / v_mad_u64_u32
 
 
@@ -42,24 +46,28 @@ def build_workload(bp, levels, batch, n_leaves, seed_base):
 
 
 # ---- the reference's benchmark configurations (BASELINE.json `configs`) and the depths it ships.
-# batch = proofs per GPU per step; fuse = steps per device job; window = table window bits (0: from the free memory)
+# batch = proofs per GPU per step; short = (warm-up steps, timed steps) of the configuration's short run inside the headline run;
+# fixture = its batch in tests/golden/fullsize_digests.json (the C oracle's digest of every proof) when the inputs are the same
 CONFIGS = {
-    "c2": dict(metric="R1CS proofs/sec (Poseidon 2:1 cube-S-box preimage)", batch=4096, fuse=2, window=11, cpu_proofs=48,
+    "c2": dict(metric="R1CS proofs/sec (Poseidon 2:1 cube-S-box preimage)", batch=4096, cpu_proofs=48, short=(2, 8), fixture="c2_poseidon2_cube_x4096",
                workload="gadget_poseidon 2:1 Cube-S-box preimage proof (148 rounds; reference src/gadget_poseidon.rs:692-790)",
                build=lambda bp, B, base, a: wl.poseidon_2to1_cube(bp, None, B, index_base=base)),
-    "c3": dict(metric="R1CS proofs/sec (Poseidon VSMT-2 depth-32)", batch=1024, fuse=2, window=11, cpu_proofs=2,
+    "c3": dict(metric="R1CS proofs/sec (Poseidon VSMT-2 depth-32)", batch=1024, cpu_proofs=2, short=(4, 8), fixture="c3_vsmt2_d32_x1024",
                workload="gadget_vsmt_2 sparse-Merkle depth-32 membership (Poseidon 2:1 inverse S-box; reference src/gadget_vsmt_2.rs:262-352)",
                build=lambda bp, B, base, a: wl.vsmt2(bp, None, 32, B, b"l2", 0xffffffff, 10**6 + base)),
-    "c4": dict(metric=None, batch=1024, fuse=2, window=11, cpu_proofs=2,
+    "c4": dict(metric=None, batch=1024, cpu_proofs=2, short=(4, 8), fixture="c4_vsmt4_d32_x2024",
+               fixture_build=lambda bp: wl.vsmt4(bp, None, 32, 2024, 64, 0),
                workload=None,
                build=lambda bp, B, base, a: wl.vsmt4(bp, None, a.depth, B, a.leaves if a.leaves > 0 else B, base)),
-    "c5": dict(metric="R1CS proofs/sec (MiMC-322 preimage + set membership)", batch=8192, fuse=1, window=11, cpu_proofs=32,
+    "c5": dict(metric="R1CS proofs/sec (MiMC-322 preimage + set membership)", batch=8192, cpu_proofs=32, short=(2, 4), fixture="c5_mimc_set_x8192",
                workload="gadget_mimc preimage + gadget_set_membership (k = 7) on one prover (reference src/gadget_mimc.rs:92-175, src/gadget_set_membership.rs:93-171)",
                build=lambda bp, B, base, a: wl.mimc_set_membership(B, index_base=base)),
-    "vsmt4_d128": dict(metric="R1CS proofs/sec (Poseidon VSMT-4 depth-128, as shipped)", batch=1024, fuse=1, window=0, cpu_proofs=1,
+    "vsmt4_d128": dict(metric="R1CS proofs/sec (Poseidon VSMT-4 depth-128, as shipped)", batch=1024, cpu_proofs=1, short=(2, 3), fixture="vsmt4_d128_x70",
+                       fixture_build=lambda bp: wl.vsmt4(bp, None, 128, 70, 70, 11),
                        workload="gadget_vsmt_4 at the depth the reference ships (TreeDepth = 128, src/gadget_vsmt_4.rs:25): n = 74 624, N = 131 072",
                        build=lambda bp, B, base, a: wl.vsmt4(bp, None, 128, B, B, base)),
-    "vsmt2_d253": dict(metric="R1CS proofs/sec (Poseidon VSMT-2 depth-253, as shipped)", batch=256, fuse=1, window=0, cpu_proofs=1,
+    "vsmt2_d253": dict(metric="R1CS proofs/sec (Poseidon VSMT-2 depth-253, as shipped)", batch=256, cpu_proofs=1, short=(4, 6), fixture="vsmt2_d253_x66",
+                       fixture_build=lambda bp: wl.vsmt2(bp, None, 253, 66, b"l253", (1 << 250) - 1, 2 * 10**6),
                        workload="gadget_vsmt_2 at the depth the reference ships (TreeDepth = 253, src/gadget_vsmt_2.rs:23): n = 143 704, N = 262 144",
                        build=lambda bp, B, base, a: wl.vsmt2(bp, None, 253, B, b"l253", (1 << 250) - 1, 2 * 10**6 + base)),
 }
@@ -200,32 +208,163 @@ def cpu_baseline(w, n_proofs, max_threads):
                           ", ".join("%s %.0f %%" % (k, 100 * v / tot) for k, v in zip(PHASES, phase)), t_setup)}, proofs)
 
 
+def input_digest(case):
+    """SHA-256 over everything a proof depends on besides the library (as tests/fullsize_cases.py::input_digest)"""
+    h = hashlib.sha256()
+    h.update(case["gadget"].encode() + b"|" + ",".join(str(x) for x in case["ip"]).encode() + b"|")
+    for s in case["sp"]:
+        h.update(s if isinstance(s, (bytes, bytearray)) else int(s).to_bytes(32, "little"))
+    h.update(b"|" + case["label"] + b"|")
+    for k in ("values", "blindings", "seeds"):
+        h.update(hashlib.sha256(case[k]).digest())
+    return h.hexdigest()
+
+
+def fixture_parity(name, case, proofs_raw, plen):
+    """Every proof of the batch against the committed digests of the C oracle's proofs (tests/golden/fullsize_digests.json,
+    generated in the build container by tests/golden/make_fullsize_digests.py; data, not code: nothing under oracle/ runs here)
+    -> dict(ok, proofs, source)"""
+    fx = json.load(open(os.path.join(ROOT, "tests", "golden", "fullsize_digests.json")))[name]
+    if fx["inputs_sha256"] != input_digest(case):
+        return {"ok": False, "proofs": 0, "source": name, "error": "the inputs built here differ from the fixture's"}
+    n = min(fx["B"], len(proofs_raw) // plen)
+    bad = [j for j in range(n) if hashlib.sha256(proofs_raw[j * plen:(j + 1) * plen]).hexdigest()[:32] != fx["proofs"][j]]
+    return {"ok": not bad and n == fx["B"], "proofs": n, "mismatches": len(bad),
+            "source": "tests/golden/fullsize_digests.json[%s]: SHA-256 of every proof as the C oracle produces it" % name}
+
+
+def relaunch_under_torchrun(n):
+    """`python bench.py --gpus N` (N > 1) outside a launcher: start N ranks of this script, one per GPU, and pass their exit code on"""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(cmd, env=env)
+
+
+def dry_run(args):
+    """CPU rehearsal of the launch path (tests/test_bench_launch.py): rendezvous over gloo, the barrier-bracketed timed region with
+    the MAX over ranks, ONE JSON line from rank 0 - no prover, no GPU."""
+    import torch
+    import torch.distributed as dist
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    if world > 1:
+        dist.init_process_group(backend="gloo")
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit("bench.py: launched with %d ranks for --gpus %d" % (dist.get_world_size(), args.gpus))
+        dist.barrier()
+    t0 = time.perf_counter()
+    time.sleep(0.01 * args.steps * (1 + rank))
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    ranks = [rank]
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        got = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+        dist.all_gather(got, torch.tensor([rank], dtype=torch.int64))
+        ranks = [int(x.item()) for x in got]
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"metric": "dry run (no prover)", "value": None, "unit": "proofs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": 1e3 * dt / args.steps, "dry_run": True, "ranks": ranks}), flush=True)
+
+
+def measure(bp, lib, gens, circ, w, B, steps, warm_steps, barrier=None):
+    """warm-up call, then the timed region: ONE bpr1cs_prove_batch over steps * B proofs (the inputs of `w` repeated as often as
+    needed) -> (seconds, proof bytes of the timed call, commitment bytes, bpr1cs_prove_stats of it, proofs per warm-up call)"""
+    m, have = w["m"], w["B"]
+
+    def tiled(nproofs):
+        reps = -(-nproofs // have)
+        return ((w["values"] * reps)[:nproofs * m * 32], (w["blindings"] * reps)[:nproofs * m * 32], (w["seeds"] * reps)[:nproofs * 32])
+    if warm_steps > 0:   # untimed: sizes the shared arena and gives both job slots their buffers (and builds the circuit's merged tables)
+        v, b, s = tiled(warm_steps * B)
+        bp.prove_batch_raw(gens, circ, w["label"], v, b, s, warm_steps * B)
+    v, b, s = tiled(steps * B)
+    if barrier:
+        barrier()
+    t0 = time.perf_counter()
+    proofs, comms = bp.prove_batch_raw(gens, circ, w["label"], v, b, s, steps * B)
+    if barrier:
+        barrier()
+    dt = time.perf_counter() - t0
+    return dt, proofs, comms, bp.last_prove_stats(lib)
+
+
+def run_short_config(bp, lib, name, args, gens_by_cap):
+    """One of the other BASELINE configurations inside the headline run: fixture-sized batch, library defaults, a short timed
+    region -> dict for the `configs` block (throughput + parity of EVERY proof of one batch against the committed oracle digests)"""
+    import torch
+    cfg = CONFIGS[name]
+    B = cfg["batch"]
+    t0 = time.time()
+    w = cfg["build"](bp, B, 0, args)
+    circ = bp.CompiledGadget(w["gadget"], w["ip"], w["sp"])
+    N = 1 << (circ.n - 1).bit_length()
+    if N not in gens_by_cap:
+        for g in gens_by_cap.values():   # one set of generator tables at a time
+            g.close()
+        gens_by_cap.clear()
+        bp.release_cached_memory(lib)
+        gens_by_cap[N] = bp.Gens(N)
+    gens = gens_by_cap[N]
+    gens.release_scratch()   # the arena of the configuration before has another shape
+    t_setup = time.time() - t0
+    warm, steps = cfg["short"]
+    torch.cuda.synchronize()
+    dt, proofs, comms, st = measure(bp, lib, gens, circ, w, B, steps, warm)
+    out = {"metric": cfg["metric"] or "R1CS proofs/sec (Poseidon VSMT-4 depth-32)", "value": B * steps / dt, "unit": "proofs/s", "batch_per_gpu": B, "steps": steps, "warmup": warm,
+           "ms_per_step": 1e3 * dt / steps, "n_multipliers": circ.n, "padded_n": N, "commitments": circ.m, "proof_bytes": circ.proof_len,
+           "proofs_per_device_job": st["job_proofs"], "device_jobs": st["jobs"], "table_window_bits": gens.table_info()["window_bits"],
+           "msm_share_of_job_time": None, "setup_s": t_setup}
+    if st["msm_ms"] > 0 and st["msm_terms"]:
+        out["msm_table_adds_per_s"] = st["msm_terms"] * gens.table_info()["windows"] / (st["msm_ms"] / 1e3)
+    if "fixture_build" in cfg:   # the throughput inputs are not the fixture's: prove the fixture's batch as well
+        fw = cfg["fixture_build"](bp)
+        fcirc = bp.CompiledGadget(fw["gadget"], fw["ip"], fw["sp"])
+        fproofs, _ = bp.prove_batch_raw(gens, fcirc, fw["label"], fw["values"], fw["blindings"], fw["seeds"], fw["B"])
+        out["parity"] = fixture_parity(cfg["fixture"], fw, fproofs, fcirc.proof_len)
+        fcirc.close()
+    else:
+        out["parity"] = fixture_parity(cfg["fixture"], w, proofs, circ.proof_len)
+    circ.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--config", default="c4", choices=sorted(CONFIGS), help="BASELINE.json configuration (c4 = the headline metric)")
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=1, help="ranks = GPUs of this node; > 1 outside a launcher: bench.py starts them itself")
     ap.add_argument("--steps", type=int, default=24, help="timed batches; the pipeline is empty at both ends of the timed region, so the first job's front phase (nothing to overlap with) is paid once per run")
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--warmup", type=int, default=1, help="untimed steps before the timed region (at least 4 are run: two device jobs, so that both job slots own their buffers)")
     ap.add_argument("--batch", type=int, default=0, help="proofs per GPU per step (0 = the configuration's)")
-    ap.add_argument("--fuse", type=int, default=0, help="steps handed to the device as ONE prove job (0 = the configuration's; c4: 2)")
     ap.add_argument("--depth", type=int, default=32, help="c4 only: 4-ary tree levels (BASELINE: 32)")
-    ap.add_argument("--leaves", type=int, default=0, help="c4 only: distinct synthetic leaves cycled over the batch (0 = one per proof of a device job)")
+    ap.add_argument("--leaves", type=int, default=0, help="c4 only: distinct synthetic leaves cycled over the batch (0 = one per proof)")
     ap.add_argument("--cpu-proofs", type=int, default=-1, help="proofs timed on ONE thread of the CPU oracle (0 = skip the CPU leg, -1 = the configuration's)")
     ap.add_argument("--cpu-threads", type=int, default=128, help="upper bound of the all-cores CPU run")
-    ap.add_argument("--table-format", type=int, default=-1, help="fixed-base table storage: 0 packed 96 B, 1 limb form in 128-B slots, -1 automatic")
-    ap.add_argument("--pipeline", type=int, default=2, help="device jobs in flight (1 = synchronous)")
-    ap.add_argument("--latency-cus", type=int, default=-1, help="CUs reserved for the latency-bound kernels (-1 = library default)")
-    ap.add_argument("--team", type=int, default=0, help="witness team size 4/8/16 (0 = library default)")
-    ap.add_argument("--rng-mode", type=int, default=-1, help="TranscriptRng chain mapping: 0 auto, 1 lane-parallel, 2 state per thread (-1 = library default)")
-    ap.add_argument("--unfold", type=int, default=4, help="IPA rounds computed from the un-folded generator tables")
-    ap.add_argument("--factor-vectors", type=int, default=-1, help="1: IPA factor vectors as N x B arrays instead of their closed form (-1 = library default)")
-    ap.add_argument("--shared-back", type=int, default=-1, help="jobs in flight share the scratch of their back phases (-1 = library default)")
-    ap.add_argument("--tail-rounds", type=int, default=-1, help="final IPA rounds enqueued on the job's own tail stream (-1 = library default, 0 = all on the heavy stream)")
-    ap.add_argument("--tail-fused", type=int, default=-1, help="1: the IPA tail as one kernel, 0: one launch per step (-1 = library default)")
-    ap.add_argument("--msm-threads-log2", type=int, default=-1, help="measuring knob: log2 of the (chunk, proof) threads per MSM launch (-1 = library default 21)")
-    ap.add_argument("--window", type=int, default=-1, help="fixed-base table window bits (-1 = the configuration's; 11: 23 adds/term, 198 GB of tables at capacity 32768; 0 = from the free memory)")
+    ap.add_argument("--configs", default="default", help="other configurations timed after the headline (rank 0 of a 1-GPU run): 'default' = c2,c3,c4,c5,vsmt4_d128,vsmt2_d253 "
+                    "for the default c4 run, 'none', or a comma list")
+    ap.add_argument("--dry-run", action="store_true", help="CPU rehearsal of the launch / rendezvous / timing path (no prover)")
+    # measuring options: anything given here is an EXPLICIT option of the generator handle (the default run sets none)
+    ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE", help="option of the generator handle (bpr1cs_gens_create_opts), e.g. unfold=3, job_proofs=1024, "
+                    "jobs_in_flight=1, tail_rounds=0, window_bits=10, msm_threads_log2=22; may be repeated")
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
+    world_env = os.environ.get("WORLD_SIZE")
+    if args.gpus > 1 and world_env is None:
+        sys.exit(relaunch_under_torchrun(args.gpus))
+    if world_env is not None and int(world_env) != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started %s ranks" % (args.gpus, world_env))
+    if args.dry_run:
+        return dry_run(args)
 
     import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -238,32 +377,19 @@ def main():
     if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ:  # under torchrun the RCCL group is created even for one rank
         import torch.distributed as dist
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit("bench.py: %d ranks for --gpus %d" % (dist.get_world_size(), args.gpus))
 
     bp = importlib.import_module("bulletproofs-r1cs-gadgets_amd")
     lib = bp.load_library()
     lib.bpr1cs_set_device(local_rank)
     bp.load_gadgets_library()
-    window = cfg["window"] if args.window < 0 else args.window
-    if args.unfold >= 0:
-        lib.bpr1cs_set_unfold_rounds(args.unfold)
-    lib.bpr1cs_set_window_bits(window)
-    lib.bpr1cs_set_table_format(args.table_format)
-    if args.team > 0:
-        lib.bpr1cs_set_witness_team(args.team)
-    if args.rng_mode >= 0:
-        lib.bpr1cs_set_rng_mode(args.rng_mode)
-    if args.latency_cus >= 0:
-        lib.bpr1cs_set_latency_cus(args.latency_cus)
-    if args.tail_rounds >= 0:
-        lib.bpr1cs_set_tail_rounds(args.tail_rounds)
-    if args.shared_back >= 0:
-        lib.bpr1cs_set_shared_back(args.shared_back)
-    if args.factor_vectors >= 0:
-        lib.bpr1cs_set_factor_vectors(args.factor_vectors)
-    if args.tail_fused >= 0:
-        lib.bpr1cs_set_tail_fused(args.tail_fused)
-    if args.msm_threads_log2 >= 0:
-        lib.bpr1cs_set_msm_threads_log2(args.msm_threads_log2)
+    options = {}
+    for kv in args.opt:
+        k, v = kv.split("=")
+        if k not in bp.OPTIONS:
+            raise SystemExit("bench.py: unknown option %r (known: %s)" % (k, ", ".join(sorted(bp.OPTIONS))))
+        options[k] = int(v)
 
     # the library's own RCCL communicator for the sharded verifier (bpr1cs_verify_batch_sharded), created at start-up: RCCL brings
     # up its view of the runtime best in a young process, and every rank meets here before any of them holds 280 GB
@@ -279,13 +405,13 @@ def main():
         if int(flag.item()) == 0 and comm is not None:
             comm.close()
             comm = None
+    rccl_ranks = comm.world if comm is not None else None   # size of the library's own communicator (bpr1cs_comm_*)
 
     B = args.batch if args.batch > 0 else cfg["batch"]
-    F = max(1, args.fuse if args.fuse > 0 else cfg["fuse"])
-    Bj = B * F                                      # proofs per device job
     steps = max(1, args.steps)
+    Bw = B * min(2, steps)                          # distinct synthetic inputs: two steps' worth (own leaves, blindings, seeds), repeated over the steps
     t0 = time.time()
-    w = cfg["build"](bp, Bj, rank * Bj, args)      # inputs of one device job: F steps' worth of distinct proofs (own leaves, blindings, seeds)
+    w = cfg["build"](bp, Bw, rank * Bw, args)
     t_witness = time.time() - t0
     m, label = w["m"], w["label"]
     t0 = time.time()
@@ -293,7 +419,7 @@ def main():
     t_compile = time.time() - t0
     N = 1 << (circ.n - 1).bit_length()
     t0 = time.time()
-    gens = bp.Gens(N)
+    gens = bp.Gens(N, **options)
     t_gens = time.time() - t0
     assert circ.has_witness_program and circ.m == m
 
@@ -303,86 +429,25 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def begin(nsteps=None):
-        nb = B * (F if nsteps is None else nsteps)
-        return bp.ProveJob(gens, circ, label, w["values"][:nb * m * 32], w["blindings"][:nb * m * 32], w["seeds"][:nb * 32], nb)
-
-    def stats():
-        a, b, c = bp.last_msm_stats(lib)
-        return a, b, c, bp.last_timings(lib)
-
-    # Software pipeline of depth `--pipeline` over the device jobs: the next job is enqueued (on its own HIP streams) before
-    # the previous one is collected, so its latency-bound RNG / witness phase overlaps the VALU-bound MSM / IPA phase.  EXACTLY
-    # `steps` steps are proved inside the timed region: steps // F jobs of F steps and one shorter job for the remainder.
-    depth = max(1, args.pipeline)
-    proofs = None
-    fused_fallback = None
-    for it in range(args.warmup):   # untimed: `depth` jobs in flight, so that every job slot has its buffers before the clock starts
-        warm = []
-        try:
-            for _ in range(depth):
-                warm.append(begin())
-            for j in warm:
-                proofs, _ = j.finish()
-        except bp.R1CSError as e:
-            for j in warm:   # drain whatever did start
-                try:
-                    if j.h:
-                        j.finish()
-                except bp.R1CSError:
-                    pass
-            # a device with less free memory than the design point (198 GB of tables + two fused jobs): drop to one step per
-            # device job instead of failing the run; the JSON says so
-            if e.code != -19 or F == 1 or it > 0:
-                raise
-            fused_fallback = "out of device memory with %d steps per device job: fell back to 1" % F
-            F, Bj = 1, B
-            gens.release_scratch()
-            warm = [begin() for _ in range(depth)]
-            for j in warm:
-                proofs, _ = j.finish()
-    plan = [F] * (steps // F) + ([steps % F] if steps % F else [])
-    barrier()
-    t0 = time.perf_counter()
-    acc = {"ms": 0.0, "launches": 0, "terms": 0, "phases": [0.0] * 6}
-    inflight = []
-
-    def collect():
-        pf, _ = inflight.pop(0).finish()
-        a, b, c, ph = stats()
-        acc["ms"] += a; acc["launches"] += b; acc["terms"] += c
-        acc["phases"] = [x + y for x, y in zip(acc["phases"], ph)]
-        return pf
-    for ns in plan:
-        inflight.append(begin(ns))
-        if len(inflight) >= depth:
-            proofs = collect()
-    while inflight:
-        proofs = collect()
-    barrier()
-    dt = time.perf_counter() - t0
+    # Timed region = EXACTLY `steps` steps: one bpr1cs_prove_batch call over steps * B proofs, V commitments -> proof bytes.  The
+    # library cuts it into device jobs and keeps two in flight (the next job's latency-bound RNG / witness phase next to the
+    # VALU-bound MSM / IPA phase of the one before); the pipeline is empty at both ends of the region.
+    warm_steps = max(args.warmup, 4) if args.warmup > 0 else 0
+    dt, proofs_raw, comms_raw, st = measure(bp, lib, gens, circ, w, B, steps, warm_steps, barrier)
     if dist is not None:
         t = torch.tensor([dt], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    msm_ms, msm_launches, msm_terms, phases = acc["ms"], acc["launches"], acc["terms"], acc["phases"]
+    msm_ms, msm_launches, msm_terms, phases = st["msm_ms"], st["msm_launches"], st["msm_terms"], st["phase_ms"]
+    plen = circ.proof_len
+    Bj = min(st["job_proofs"], Bw)                  # one device job's worth of distinct proofs for the verification legs below
+    proofs = [proofs_raw[i * plen:(i + 1) * plen] for i in range(Bj)]
+    comms = [[comms_raw[(i * m + j) * 32:(i * m + j + 1) * 32] for j in range(m)] for i in range(Bj)]
 
     # Outside the timed region, on every rank: cross-proof batched verification of one job's proofs
     # (bpr1cs_verify_batch_combined) and the path's only exchange step, an all_gather of one 32-byte point per rank.
     batched = None
-    comms = None
-    have_job = 1
     try:
-        proofs, comms = begin().finish()
-    except Exception as e:  # pragma: no cover
-        have_job, batched = 0, {"error": repr(e)}
-    if dist is not None:   # every rank enters the collectives below, or none does
-        flag = torch.tensor([have_job], device="cuda", dtype=torch.int32)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        have_job = int(flag.item())
-    try:
-        if not have_job:
-            raise RuntimeError("a rank could not produce the batch to verify")
         sh = importlib.import_module("bulletproofs-r1cs-gadgets_amd.sharding")
         # one-shot calls are noisy (first-use allocations): both forms run twice, the faster run is reported
         tb = ts = float("inf")
@@ -407,7 +472,7 @@ def main():
                                          "note": "bpr1cs_verify_batch_sharded: ONE C-ABI call per rank (scalars, ncclAllGather of the scalar vectors, 1/world of the bases, ncclAllGather of 65 bytes)"},
                    "note": "bpr1cs_verify_batch_combined + all_gather of one point per rank; not part of `value`"}
     except Exception as e:  # pragma: no cover
-        batched = batched or {"error": repr(e)}
+        batched = {"error": repr(e)}
 
     if rank == 0:
         value = world * B * steps / dt
@@ -416,11 +481,12 @@ def main():
         alg_bytes_per_proof = 576 * n + 448 * N + 64 * lgN - 96
         # dominant kernel: algorithmic bytes = 64 B per scalar*point term + 32 B per output (MSM_BYTES(t) = 64 t + 32);
         # every launch of the kernel is counted (commit sums, L/R of the un-folded rounds, the folded generators)
-        launches_per_job = msm_launches / max(1, len(plan))
+        jobs = max(1, st["jobs"])
+        launches_per_job = msm_launches / jobs
         msm_alg_bytes = 64.0 * msm_terms + 32.0 * launches_per_job * B * steps
         achieved = (msm_alg_bytes / 1e9) / (msm_ms / 1e3) if msm_ms > 0 else None
         tinfo = gens.table_info()
-        default_knobs = args.config == "c4" and args.depth == 32 and tinfo["window_bits"] == 11 and args.unfold == 4
+        default_knobs = args.config == "c4" and args.depth == 32 and not options
         traffic, traffic_ppl, traffic_src = pmc_profile("traffic", tinfo["format"]) if default_knobs else (None, None, None)
         clock_ghz, clock_src = pmc_profile("clock", tinfo["format"]) if default_knobs else (None, None)
         # integer ceilings, measured NOW on this device by the library's probes (bpr1cs_device_rates, ~80 ms each)
@@ -436,17 +502,19 @@ def main():
             "config": {"workload": workload, "name": args.config,
                        "batch_per_gpu": B, "global_batch": B * world, "n_multipliers": n, "padded_n": N, "constraints": circ.q,
                        "commitments": m, "proof_bytes": circ.proof_len, "sharding": "independent proofs per rank, no collective",
-                       "steps_per_device_job": F, "proofs_per_device_job": Bj, "device_jobs": len(plan), "jobs_in_flight": depth,
-                       "ipa_unfold_rounds": args.unfold, "note": fused_fallback,
+                       "entry_point": "ONE bpr1cs_prove_batch call over steps x batch proofs per rank; handle created with %s" % ("no options (library defaults)" if not options else "options %r" % options),
+                       "proofs_per_device_job": st["job_proofs"], "device_jobs": st["jobs"], "jobs_in_flight": options.get("jobs_in_flight", 2),
+                       "steps_per_device_job": st["job_proofs"] / float(B), "warmup_steps_run": warm_steps,
+                       "ipa_unfold_rounds": options.get("unfold", 4), "options": options or None, "rccl_ranks": rccl_ranks,
                        "table_window_bits": tinfo["window_bits"], "table_windows": tinfo["windows"], "table_format": tinfo["format"],
                        "table_bytes": tinfo["bytes"]},
             "roofline": {"bound": "hbm", "kernel": "k_msm_fixed2 (batched fixed-base MSM over the generator tables; a launch carries 1-4 sums)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
-                         "traffic": (traffic * Bj / traffic_ppl) if traffic else None,
+                         "traffic": (traffic * st["job_proofs"] / traffic_ppl) if traffic else None,
                          "traffic_source": traffic_src,
                          "traffic_note": "PMC FETCH_SIZE + WRITE_SIZE per launch of the same kernel build and configuration, from the named profile (separate "
-                                         "rocprofv3 --pmc passes; scaled by proofs per launch if the profiled run fused fewer steps); as reported by the "
+                                         "rocprofv3 --pmc passes; scaled by proofs per launch if the profiled run used another job size); as reported by the "
                                          "counters: on gfx950 FETCH_SIZE under-reports wide reads 2x and is uncalibrated for 128-byte gathers - a lower bound",
                          "avg_launch_ms": (msm_ms / msm_launches) if msm_launches else None, "launches_per_step": msm_launches / steps,
                          "launches_per_device_job": launches_per_job,
@@ -454,22 +522,24 @@ def main():
                          "note": "achieved/frac use ALGORITHMIC bytes (64 B per scalar*point term); the kernel is bound by integer multiply-add issue "
                                  "and by the power its table gathers cost (DVFS), not by HBM bandwidth - see roofline_valu and DESIGN.md"},
             # second, honest ceiling: 32-bit integer multiply-add issue.  One table addition = 693 multiply-adds;
-            # peak = measured v_mad_i64_i32 rate of this device / 693.  The self-benchmarked ge_madd_t chain (the kernel's inner loop
-            # without its table gathers) is reported next to it.
+            # peak = measured v_mad_i64_i32 rate of this device / 693, and the NOMINAL quarter-rate ceiling beside it.
             "roofline_valu": {"bound": "valu-int32-mad", "unit": "G table-add/s",
                               "achieved": adds_per_s / 1e9 if adds_per_s else None,
                               "peak": mad_rate / MADS_PER_TABLE_ADD / 1e9,
                               "frac": (adds_per_s / (mad_rate / MADS_PER_TABLE_ADD)) if adds_per_s else None,
-                              "mad_lane_ops_per_s": mad_rate, "mads_per_table_add": MADS_PER_TABLE_ADD,
+                              "peak_nominal": NOMINAL_MAD_LANE_OPS / MADS_PER_TABLE_ADD / 1e9,
+                              "frac_nominal": (adds_per_s / (NOMINAL_MAD_LANE_OPS / MADS_PER_TABLE_ADD)) if adds_per_s else None,
+                              "mad_lane_ops_per_s": mad_rate, "mad_lane_ops_per_s_nominal": NOMINAL_MAD_LANE_OPS, "mads_per_table_add": MADS_PER_TABLE_ADD,
                               "ge_madd_t_chain_G_per_s": madd_chain_rate / 1e9,
                               "frac_of_madd_chain": (adds_per_s / madd_chain_rate) if adds_per_s else None,
                               "effective_clock_ghz": clock_ghz, "effective_clock_source": clock_src,
                               "note": "peak = sustained v_mad_i64_i32 lane-ops/s measured in this run (bpr1cs_device_rates) / 693 multiply-adds per "
-                                      "table addition; ge_madd_t chain = the same additions on register operands (no gathers); effective clock of the "
-                                      "kernel = GRBM_GUI_ACTIVE / 8 XCDs / duration from the named profile of this build; zero scalars / zero digits "
-                                      "are counted in `achieved`"},
+                                      "table addition; peak_nominal = 256 CUs x 4 SIMDs x 16 lanes per cycle (a 64-wide 64-bit multiply-add issues "
+                                      "over 4 cycles) x 2.4 GHz = 39.3 T lane-ops/s / 693; ge_madd_t chain = the same additions on register operands "
+                                      "(no gathers); effective clock of the kernel = GRBM_GUI_ACTIVE / 8 XCDs / duration from the named profile of this "
+                                      "build; zero scalars / zero digits are counted in `achieved`"},
             "hbm_frac_whole_path": value / world * alg_bytes_per_proof / (HBM_PEAK_GBS * 1e9),
-            "phase_ms_per_device_job": {k: v / len(plan) for k, v in zip(["total", "inputs+commitV", "rng||witness", "commit_msm", "poly", "ipa"], phases)},
+            "phase_ms_per_device_job": {k: v / jobs for k, v in zip(["total", "inputs+commitV", "rng||witness", "commit_msm", "poly", "ipa"], phases)},
             "setup_s": {"witness_trees": t_witness, "circuit_compile": t_compile, "generator_tables": t_gens},
         }
         # outside the timed region: the device verifier (Verifier::verify, one mega-check MSM per proof) on one job's proofs
@@ -489,6 +559,30 @@ def main():
                 out["parity_vs_cpu_oracle"] = all(cproofs[j] == proofs[j] for j in range(len(cproofs)))
         else:
             out["cpu_baseline"] = None
+        # the other BASELINE configurations, each a short run of its own with the library's defaults (1-GPU runs only)
+        which = args.configs
+        if which == "default":
+            which = "c2,c3,c4,c5,vsmt4_d128,vsmt2_d253" if (args.config == "c4" and args.depth == 32 and not options and world == 1) else "none"
+        if which != "none" and world == 1:
+            circ.close()
+            gens_by_cap = {N: gens}
+            blk = {}
+            for name in [x for x in which.split(",") if x]:
+                t1 = time.time()
+                try:
+                    if name == args.config and cfg.get("fixture") and "fixture_build" in cfg:
+                        # the headline itself: its throughput is `value`; here EVERY proof of the fixture batch against the oracle digests
+                        fw = cfg["fixture_build"](bp)
+                        fcirc = bp.CompiledGadget(fw["gadget"], fw["ip"], fw["sp"])
+                        fproofs, _ = bp.prove_batch_raw(gens, fcirc, fw["label"], fw["values"], fw["blindings"], fw["seeds"], fw["B"])
+                        blk[name] = {"metric": metric, "value": value, "unit": "proofs/s", "note": "the headline of this line", "parity": fixture_parity(cfg["fixture"], fw, fproofs, fcirc.proof_len)}
+                        fcirc.close()
+                    else:
+                        blk[name] = run_short_config(bp, lib, name, args, gens_by_cap)
+                except Exception as e:  # pragma: no cover
+                    blk[name] = {"error": repr(e)}
+                blk[name]["wall_s"] = time.time() - t1
+            out["configs"] = blk
         result_line = json.dumps(out)
     else:
         result_line = None

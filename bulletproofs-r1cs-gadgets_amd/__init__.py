@@ -57,7 +57,18 @@ class ProofStruct(ctypes.Structure):
                [("lg_n", ctypes.c_uint32), ("L", _B32 * 32), ("R", _B32 * 32), ("ipp_a", _B32), ("ipp_b", _B32)]
 
 
-OPT_UNFOLD_ROUNDS, OPT_RNG_MODE, OPT_WITNESS_TEAM, OPT_TAIL_ROUNDS = 0, 1, 2, 3
+# options of a generator handle (include/bpr1cs.h BPR1CS_OPT_*)
+OPT_UNFOLD_ROUNDS, OPT_WITNESS_TEAM, OPT_TAIL_ROUNDS, OPT_SHARED_BACK, OPT_FACTOR_VECTORS = 0, 2, 3, 4, 5
+OPT_MSM_THREADS_LOG2, OPT_JOB_PROOFS, OPT_JOBS_IN_FLIGHT, OPT_WINDOW_BITS = 6, 7, 8, 16
+OPTIONS = dict(unfold=OPT_UNFOLD_ROUNDS, witness_team=OPT_WITNESS_TEAM, tail_rounds=OPT_TAIL_ROUNDS, shared_back=OPT_SHARED_BACK,
+               factor_vectors=OPT_FACTOR_VECTORS, msm_threads_log2=OPT_MSM_THREADS_LOG2, job_proofs=OPT_JOB_PROOFS,
+               jobs_in_flight=OPT_JOBS_IN_FLIGHT, window_bits=OPT_WINDOW_BITS)
+
+
+class ProveStats(ctypes.Structure):
+    """bpr1cs_prove_stats (include/bpr1cs.h)"""
+    _fields_ = [("jobs", ctypes.c_uint32), ("job_proofs", ctypes.c_uint32), ("phase_ms", ctypes.c_float * 6), ("msm_ms", ctypes.c_double),
+                ("msm_launches", ctypes.c_uint64), ("msm_terms", ctypes.c_uint64)]
 
 
 def load_library(path=None):
@@ -96,20 +107,11 @@ def load_library(path=None):
     lib.bpr1cs_transcript_append_message.argtypes = [vp, cp, sz, cp, sz]
     lib.bpr1cs_transcript_challenge_bytes.argtypes = [vp, cp, sz, cp, sz]
     lib.bpr1cs_poseidon_permutation_batch.argtypes = [vp, ctypes.c_int, cp, sz, cp]
-    lib.bpr1cs_set_unfold_rounds.argtypes = [ctypes.c_int]
-    lib.bpr1cs_set_window_bits.argtypes = [ctypes.c_int]
-    lib.bpr1cs_set_table_format.argtypes = [ctypes.c_int]
-    lib.bpr1cs_set_witness_team.argtypes = [ctypes.c_int]
-    lib.bpr1cs_set_witness_macro.argtypes = [ctypes.c_int]
-    lib.bpr1cs_set_rng_mode.argtypes = [ctypes.c_int]
-    lib.bpr1cs_set_tail_rounds.argtypes = [ctypes.c_int]
-    lib.bpr1cs_set_shared_back.argtypes = [ctypes.c_int]
-    lib.bpr1cs_set_factor_vectors.argtypes = [ctypes.c_int]
-    lib.bpr1cs_set_tail_fused.argtypes = [ctypes.c_int]
-    lib.bpr1cs_set_msm_threads_log2.argtypes = [ctypes.c_int]
     lib.bpr1cs_circuit_macro_perms.argtypes = [ctypes.c_void_p]
     lib.bpr1cs_circuit_macro_perms.restype = ctypes.c_int
-    lib.bpr1cs_set_latency_cus.argtypes = [ctypes.c_int]
+    lib.bpr1cs_gens_create_opts.argtypes = [u32, ctypes.POINTER(ctypes.c_int32), sz, ctypes.POINTER(vp)]
+    lib.bpr1cs_prove_batch_transcripts.argtypes = [vp, vp, ctypes.POINTER(vp), sz, cp, cp, cp, cp, sz, cp, cp]
+    lib.bpr1cs_last_prove_stats.argtypes = [ctypes.POINTER(ProveStats)]
     lib.bpr1cs_gens_set_option.argtypes = [vp, ctypes.c_int, ctypes.c_int]
     lib.bpr1cs_gens_release_scratch.argtypes = [vp]
     lib.bpr1cs_gens_table_info.argtypes = [vp, ctypes.POINTER(u32), ctypes.POINTER(u32), ctypes.POINTER(u32), ctypes.POINTER(ctypes.c_uint64)]
@@ -126,8 +128,6 @@ def load_library(path=None):
     lib.bpr1cs_proof_serialized_len.argtypes = [ctypes.POINTER(ProofStruct)]
     lib.bpr1cs_proof_serialized_len.restype = sz
     lib.bpr1cs_device_rates.argtypes = [ctypes.c_double, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
-    lib.bpr1cs_last_timings.argtypes = [ctypes.POINTER(ctypes.c_float), ctypes.c_int]
-    lib.bpr1cs_last_msm_stats.argtypes = [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]
     if path is None:
         _lib = lib
     return lib
@@ -145,10 +145,15 @@ def _u32arr(xs):
 class Gens:
     """PedersenGens::default() + BulletproofGens::new(capacity, 1)."""
 
-    def __init__(self, capacity, lib=None):
+    def __init__(self, capacity, lib=None, **options):
+        """options: names of OPTIONS (unfold=4, window_bits=8, job_proofs=1024 ...); defaults = the benchmarked configuration"""
         self.lib = lib or load_library()
         h = ctypes.c_void_p()
-        _chk(self.lib.bpr1cs_gens_create(capacity, ctypes.byref(h)))
+        pairs = []
+        for k, v in options.items():
+            pairs += [OPTIONS[k], int(v)]
+        arr = (ctypes.c_int32 * max(1, len(pairs)))(*pairs)
+        _chk(self.lib.bpr1cs_gens_create_opts(capacity, arr, len(pairs) // 2, ctypes.byref(h)))
         self.h, self.capacity = h, capacity
 
     def point(self, which, i=0):
@@ -164,8 +169,8 @@ class Gens:
         return [raw[32 * i:32 * i + 32] for i in range(batch)]
 
     def set_option(self, option, value):
-        """per-handle override of a per-call knob (OPT_UNFOLD_ROUNDS / OPT_RNG_MODE / OPT_WITNESS_TEAM; value < 0: process default)"""
-        _chk(self.lib.bpr1cs_gens_set_option(self.h, option, value))
+        """option: an OPT_* constant or a name of OPTIONS; value < 0: back to the default"""
+        _chk(self.lib.bpr1cs_gens_set_option(self.h, OPTIONS.get(option, option) if isinstance(option, str) else option, value))
 
     def release_scratch(self):
         """drop the handle's back-phase arena and the allocator's cache (before a job of a very different shape)"""
@@ -506,19 +511,36 @@ class ProveJob:
                 [[craw[(i * m + j) * 32:(i * m + j + 1) * 32] for j in range(m)] for i in range(self.batch)])
 
 
-def last_msm_stats(lib=None):
-    """(summed K_msm_fixed launch time in ms, launches, scalar*point terms) of the last prove_batch."""
+def last_prove_stats(lib=None):
+    """bpr1cs_prove_stats of the last prove call that returned on this thread -> dict"""
     lib = lib or load_library()
-    ms, n, t = ctypes.c_double(), ctypes.c_uint64(), ctypes.c_uint64()
-    lib.bpr1cs_last_msm_stats(ctypes.byref(ms), ctypes.byref(n), ctypes.byref(t))
-    return ms.value, n.value, t.value
+    st = ProveStats()
+    _chk(lib.bpr1cs_last_prove_stats(ctypes.byref(st)))
+    return dict(jobs=st.jobs, job_proofs=st.job_proofs, phase_ms=list(st.phase_ms), msm_ms=st.msm_ms, msm_launches=st.msm_launches, msm_terms=st.msm_terms)
 
 
-def last_timings(lib=None):
-    lib = lib or load_library()
-    buf = (ctypes.c_float * 6)()
-    k = lib.bpr1cs_last_timings(buf, 6)
-    return list(buf)[:k]
+def prove_batch_transcripts(gens, circuit, transcripts, values, v_blindings, rng_seeds, batch, wires=None):
+    """bpr1cs_prove_batch_transcripts: `transcripts` = one Transcript (every proof starts from a copy) or `batch` of them (each is
+    advanced to the state upstream's `&mut transcript` has after prove()) -> (proofs, commitments) as prove_batch"""
+    lib = gens.lib
+    ts = transcripts if isinstance(transcripts, (list, tuple)) else [transcripts]
+    arr = (ctypes.c_void_p * len(ts))(*[t.h for t in ts])
+    m, plen = circuit.m, circuit.proof_len
+    proofs = ctypes.create_string_buffer(batch * plen)
+    comms = ctypes.create_string_buffer(max(1, batch * m * 32))
+    _chk(lib.bpr1cs_prove_batch_transcripts(gens.h, circuit.h, arr, len(ts), values or b"\0", v_blindings or b"\0", rng_seeds, wires, batch, proofs, comms))
+    praw, craw = proofs.raw, comms.raw
+    return ([praw[i * plen:(i + 1) * plen] for i in range(batch)],
+            [[craw[(i * m + j) * 32:(i * m + j + 1) * 32] for j in range(m)] for i in range(batch)])
+
+
+def prove_batch_raw(gens, circuit, label, values, v_blindings, rng_seeds, batch):
+    """ONE bpr1cs_prove_batch call over any batch (the library cuts it into device jobs) -> (proof bytes, commitment bytes), unsplit"""
+    m, plen = circuit.m, circuit.proof_len
+    proofs = ctypes.create_string_buffer(batch * plen)
+    comms = ctypes.create_string_buffer(max(1, batch * m * 32))
+    _chk(gens.lib.bpr1cs_prove_batch(gens.h, circuit.h, label, len(label), values or b"\0", v_blindings or b"\0", rng_seeds, None, batch, proofs, comms))
+    return proofs.raw, comms.raw
 
 
 # ---------------------------------------------------------------- host front-end (libbpr1cs_gadgets.so)

@@ -8,12 +8,20 @@
 // combined scalar vectors and their 65 result bytes over xGMI; everything else is the entry points above.
 #if !defined(BPR1CS_HOSTSIM)
 #include <dlfcn.h>
-#include <rccl/rccl.h>
+// The four RCCL entry points this file uses, declared HERE: building the library needs no RCCL headers, and its ABI does not
+// follow whichever rccl.h happens to be installed (the NCCL C ABI of these functions has been stable since NCCL 2.0).
+struct bp_nccl_unique_id { char internal[128]; };   // ncclUniqueId
+typedef void* bp_nccl_comm;                          // ncclComm_t
+enum { BP_NCCL_SUCCESS = 0, BP_NCCL_UINT8 = 1 };     // ncclSuccess, ncclUint8
+typedef int (*bp_nccl_get_unique_id_fn)(bp_nccl_unique_id*);
+typedef int (*bp_nccl_comm_init_rank_fn)(bp_nccl_comm*, int, bp_nccl_unique_id, int);
+typedef int (*bp_nccl_comm_destroy_fn)(bp_nccl_comm);
+typedef int (*bp_nccl_all_gather_fn)(const void*, void*, size_t, int, bp_nccl_comm, hipStream_t);
 struct RcclApi {
-    decltype(&ncclGetUniqueId) get_unique_id = nullptr;
-    decltype(&ncclCommInitRank) comm_init_rank = nullptr;
-    decltype(&ncclCommDestroy) comm_destroy = nullptr;
-    decltype(&ncclAllGather) all_gather = nullptr;
+    bp_nccl_get_unique_id_fn get_unique_id = nullptr;
+    bp_nccl_comm_init_rank_fn comm_init_rank = nullptr;
+    bp_nccl_comm_destroy_fn comm_destroy = nullptr;
+    bp_nccl_all_gather_fn all_gather = nullptr;
     bool ok = false;
 };
 static RcclApi& rccl_api() {
@@ -22,10 +30,10 @@ static RcclApi& rccl_api() {
         void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
         if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
         if (!h) return a;
-        a.get_unique_id = (decltype(a.get_unique_id))dlsym(h, "ncclGetUniqueId");
-        a.comm_init_rank = (decltype(a.comm_init_rank))dlsym(h, "ncclCommInitRank");
-        a.comm_destroy = (decltype(a.comm_destroy))dlsym(h, "ncclCommDestroy");
-        a.all_gather = (decltype(a.all_gather))dlsym(h, "ncclAllGather");
+        a.get_unique_id = (bp_nccl_get_unique_id_fn)dlsym(h, "ncclGetUniqueId");
+        a.comm_init_rank = (bp_nccl_comm_init_rank_fn)dlsym(h, "ncclCommInitRank");
+        a.comm_destroy = (bp_nccl_comm_destroy_fn)dlsym(h, "ncclCommDestroy");
+        a.all_gather = (bp_nccl_all_gather_fn)dlsym(h, "ncclAllGather");
         a.ok = a.get_unique_id && a.comm_init_rank && a.comm_destroy && a.all_gather;
         return a;
     }();
@@ -36,7 +44,7 @@ struct bpr1cs_comm {
     int rank = 0, world = 1;
     bool owned = false;
 #if !defined(BPR1CS_HOSTSIM)
-    ncclComm_t comm = nullptr;
+    bp_nccl_comm comm = nullptr;
 #endif
 };
 extern "C" int bpr1cs_comm_unique_id(uint8_t id_out[128]) {
@@ -46,9 +54,9 @@ extern "C" int bpr1cs_comm_unique_id(uint8_t id_out[128]) {
 #else
     if (!have_device()) return BPR1CS_ERR_NO_DEVICE;
     if (!rccl_api().ok) return BPR1CS_ERR_DEVICE;
-    ncclUniqueId id;
+    bp_nccl_unique_id id;
     static_assert(sizeof(id) == 128, "ncclUniqueId is 128 bytes");
-    if (rccl_api().get_unique_id(&id) != ncclSuccess) return BPR1CS_ERR_DEVICE;
+    if (rccl_api().get_unique_id(&id) != BP_NCCL_SUCCESS) return BPR1CS_ERR_DEVICE;
     memcpy(id_out, &id, 128);
     return BPR1CS_OK;
 #endif
@@ -60,7 +68,7 @@ extern "C" int bpr1cs_comm_create(const uint8_t id[128], int rank, int world, bp
 #else
     if (!have_device()) return BPR1CS_ERR_NO_DEVICE;
     if (!rccl_api().ok) return BPR1CS_ERR_DEVICE;
-    ncclUniqueId uid;
+    bp_nccl_unique_id uid;
     memcpy(&uid, id, 128);
     bpr1cs_comm* c = new (std::nothrow) bpr1cs_comm();
     if (!c) return BPR1CS_ERR_OUT_OF_MEMORY;
@@ -68,14 +76,14 @@ extern "C" int bpr1cs_comm_create(const uint8_t id[128], int rank, int world, bp
     if (world == 1) {
         // RCCL allocates its own device buffers: when this library's allocator cache holds the rest of the device, give it back
         // and try once more (only where no other rank is waiting inside the same collective initialisation)
-        if (rccl_api().comm_init_rank(&c->comm, world, uid, rank) != ncclSuccess) {
+        if (rccl_api().comm_init_rank(&c->comm, world, uid, rank) != BP_NCCL_SUCCESS) {
             dev_pool().release_all();
-            ncclUniqueId uid2;
-            if (rccl_api().get_unique_id(&uid2) != ncclSuccess || rccl_api().comm_init_rank(&c->comm, 1, uid2, 0) != ncclSuccess) { delete c; return BPR1CS_ERR_DEVICE; }
+            bp_nccl_unique_id uid2;
+            if (rccl_api().get_unique_id(&uid2) != BP_NCCL_SUCCESS || rccl_api().comm_init_rank(&c->comm, 1, uid2, 0) != BP_NCCL_SUCCESS) { delete c; return BPR1CS_ERR_DEVICE; }
         }
     } else {
         dev_pool().release_all();   // before the ranks meet: cached blocks are of no use to RCCL
-        if (rccl_api().comm_init_rank(&c->comm, world, uid, rank) != ncclSuccess) { delete c; return BPR1CS_ERR_DEVICE; }
+        if (rccl_api().comm_init_rank(&c->comm, world, uid, rank) != BP_NCCL_SUCCESS) { delete c; return BPR1CS_ERR_DEVICE; }
     }
     *out = c;
     return BPR1CS_OK;
@@ -89,7 +97,7 @@ extern "C" int bpr1cs_comm_wrap(void* nccl_comm, int rank, int world, bpr1cs_com
     if (!rccl_api().ok) return BPR1CS_ERR_DEVICE;
     bpr1cs_comm* c = new (std::nothrow) bpr1cs_comm();
     if (!c) return BPR1CS_ERR_OUT_OF_MEMORY;
-    c->rank = rank; c->world = world; c->owned = false; c->comm = (ncclComm_t)nccl_comm;
+    c->rank = rank; c->world = world; c->owned = false; c->comm = (bp_nccl_comm)nccl_comm;
     *out = c;
     return BPR1CS_OK;
 #endif
@@ -115,7 +123,7 @@ static int comm_all_gather(const bpr1cs_gens* g, const bpr1cs_comm* c, const uin
     CallScope scope(st);
     DevBuf<uint8_t> d_in(len), d_out((size_t)world * len);
     dev_h2d(d_in.p, mine, len, st);
-    if (rccl_api().all_gather(d_in.p, d_out.p, len, ncclUint8, c->comm, st) != ncclSuccess) return BPR1CS_ERR_DEVICE;
+    if (rccl_api().all_gather(d_in.p, d_out.p, len, BP_NCCL_UINT8, c->comm, st) != BP_NCCL_SUCCESS) return BPR1CS_ERR_DEVICE;
     dev_d2h(all.data(), d_out.p, (size_t)world * len, st);
     return BPR1CS_OK;
     API_CATCH
@@ -138,10 +146,12 @@ extern "C" int bpr1cs_verify_batch_sharded(const bpr1cs_gens* g, const bpr1cs_ci
                                                vec.data(), own, &wf);
     if (rc_local != BPR1CS_OK) { std::fill(vec.begin(), vec.end(), 0); memset(own, 0, 32); wf = 0; }
     // 2. all_gather of the scalar vectors ((2N+2)*32 bytes per rank, ~2 MB at N = 32768), summed mod l
+    //    A failure of the gather on THIS rank (allocation, HIP error) does not end the call either: the second collective below
+    //    is still entered - with "not well-formed" - so that no other rank is left blocked in it; the first error is what is returned.
     int rc = comm_all_gather(g, comm, vec.data(), vlen, all);
-    if (rc != BPR1CS_OK) return rc;
+    if (rc_local == BPR1CS_OK) rc_local = rc;
     std::vector<uint8_t> total(vlen);
-    if (bpr1cs_scalars_sum(all.data(), (size_t)world, nb, total.data()) != BPR1CS_OK) wf = 0;
+    if (rc != BPR1CS_OK || bpr1cs_scalars_sum(all.data(), (size_t)world, nb, total.data()) != BPR1CS_OK) wf = 0;
     else {
         // 3. this rank's 1/world slice of the shared bases (base order of the vector == base indices of bpr1cs_msm_fixed when
         //    N == capacity; for N < capacity the H block starts at 2 + capacity)
@@ -157,7 +167,8 @@ extern "C" int bpr1cs_verify_batch_sharded(const bpr1cs_gens* g, const bpr1cs_ci
     uint8_t mine[72] = {0};
     memcpy(mine, slice_pt, 32); memcpy(mine + 32, own, 32); mine[64] = wf ? 1 : 0;
     rc = comm_all_gather(g, comm, mine, sizeof mine, all);
-    if (rc != BPR1CS_OK) return rc;
+    if (rc_local == BPR1CS_OK) rc_local = rc;
+    if (rc_local != BPR1CS_OK) return rc_local;   // a local failure (out of memory, invalid argument ...) is an error, not a rejected proof
     std::vector<uint8_t> pts((size_t)2 * world * 32);
     bool all_wf = true;
     for (int r = 0; r < world; r++) {

@@ -10,9 +10,9 @@
 #include "../../include/bpr1cs.h"
 #include "dev.hpp"
 #include "kernels.hpp"
+#include "msm_kernel.hpp"
 #if !defined(BPR1CS_HOSTSIM)
 #include "kernels_hip.hpp"
-#include "msm_hip.hpp"
 #endif
 
 // ------------------------------------------------------------ host-side hashes
@@ -36,33 +36,43 @@ static void host_sponge(uint32_t rate, uint8_t suffix, const uint8_t* in, size_t
     }
 }
 
-// Process-wide DEFAULTS of the tuning knobs (the bpr1cs_set_* entry points).  They are read once - when a handle is
-// created (table geometry) or when a call starts (per-call knobs) - and a handle can override the per-call ones for
-// itself (bpr1cs_gens_set_option), so two threads working on distinct handles never depend on each other's settings.
-static std::atomic<int> g_unfold_rounds{4};
-static std::atomic<int> g_window_bits{8};
-static std::atomic<int> g_table_format{-1};  // -1 auto, 0 packed (96 B per entry), 1 limb form in 128-B slots (see bpr1cs_set_table_format)
-static std::atomic<int> g_latency_cus{0};    // >0: CUs reserved for the latency-bound kernels (see bpr1cs_gens_create)
-static std::atomic<int> g_rng_mode{0};       // 0 auto, 1 lane-parallel via LDS (k_rng_stream), 2 state per thread, 3 scalar unit, 4 lane-parallel via DPP (k_rng_dpp)
-static std::atomic<int> g_merge_triples{1};  // A_I1: one merged table per Inverse-S-box wire triple (needs the annotated witness program)
-static std::atomic<int> g_witness_macro{1};  // use the Poseidon annotations of a circuit description (poseidon_team)
-static std::atomic<int> g_witness_team{8};   // lanes cooperating on one proof in k_witness_team (4, 8 or 16)
-static std::atomic<int> g_factor_vectors{0}; // 1: the prover hands the IPA its factor vectors as N x B arrays (the general form), 0: in closed form (IpaGeo)
-static std::atomic<int> g_shared_back{1};    // the jobs in flight on a handle share the scratch of their back phases (DevArena)
-static std::atomic<int> g_tail_fused{0};     // 1: the IPA tail as ONE kernel (a wavefront per proof executes the recorded per-round steps) - measured
-                                             // alternative, slower: the steps are 1 to 1632 items wide per proof, separate launches pack 64 proofs per wavefront
-static std::atomic<int> g_tail_rounds{7};    // final IPA rounds (m_k <= 64 at 7) enqueued on the job's own tail stream instead of the shared heavy one
-static std::atomic<uint32_t> g_msm_target_threads{1u << 21};  // (chunk, proof) threads per MSM launch (bpr1cs_set_msm_threads_log2: a measuring knob)
-struct BpOpts {  // per-handle overrides; -1 = process default
-    std::atomic<int> unfold{-1}, rng_mode{-1}, witness_team{-1}, tail_rounds{-1};
+// Options of a generator handle (include/bpr1cs.h BPR1CS_OPT_*).  There are NO process-wide settings: an option is given at
+// creation (bpr1cs_gens_create_opts) or set on the handle later (bpr1cs_gens_set_option) and read once when a call starts.
+// Defaults = the configuration bench.py measures.
+struct BpOpts {
+    std::atomic<int> unfold{4};            // IPA rounds computed from the un-folded generator tables
+    std::atomic<int> witness_team{8};      // lanes cooperating on one proof in k_witness_team (4, 8 or 16)
+    std::atomic<int> tail_rounds{7};       // final IPA rounds (m_k <= 64 at 7) enqueued on the job's own tail stream
+    std::atomic<int> shared_back{1};       // the jobs in flight on a handle share the scratch of their back phases (DevArena)
+    std::atomic<int> factor_vectors{0};    // 1: the prover hands the IPA its factor vectors as N x B arrays, 0: closed form (IpaGeo)
+    std::atomic<int> msm_threads_log2{21}; // (chunk, proof) threads per MSM launch
+    std::atomic<int> job_proofs{0};        // proofs per device job of bpr1cs_prove_batch (0: from the free memory)
+    std::atomic<int> jobs_in_flight{2};
+    int window_bits = 0;                   // creation only (0: from the free memory)
 };
-// statistics of the last prove job that ENDED ON THIS THREAD (bpr1cs_last_timings / bpr1cs_last_msm_stats)
-struct LastStats {
-    float timings[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    double msm_ms = 0;
-    uint64_t msm_launches = 0, msm_terms = 0;
-};
-static thread_local LastStats tl_last;
+// -> false for an unknown option (or a creation-only one after creation)
+static bool opt_apply(BpOpts& o, int option, int value, bool creating) {
+    switch (option) {
+        case BPR1CS_OPT_UNFOLD_ROUNDS: o.unfold = value < 0 ? 4 : value; return true;
+        case BPR1CS_OPT_WITNESS_TEAM: o.witness_team = (value == 4 || value == 8 || value == 16) ? value : 8; return true;
+        case BPR1CS_OPT_TAIL_ROUNDS: o.tail_rounds = value < 0 ? 7 : value; return true;
+        case BPR1CS_OPT_SHARED_BACK: o.shared_back = value < 0 ? 1 : (value ? 1 : 0); return true;
+        case BPR1CS_OPT_FACTOR_VECTORS: o.factor_vectors = value < 0 ? 0 : (value ? 1 : 0); return true;
+        case BPR1CS_OPT_MSM_THREADS_LOG2: o.msm_threads_log2 = value < 0 ? 21 : (value < 16 ? 16 : (value > 26 ? 26 : value)); return true;
+        case BPR1CS_OPT_JOB_PROOFS: o.job_proofs = value < 0 ? 0 : value; return true;
+        case BPR1CS_OPT_JOBS_IN_FLIGHT: o.jobs_in_flight = (value == 1) ? 1 : 2; return true;
+        case BPR1CS_OPT_WINDOW_BITS:
+            if (!creating) return false;
+            o.window_bits = value <= 0 ? 0 : (value < 4 ? 4 : (value > 12 ? 12 : value));
+            return true;
+        default: return false;
+    }
+}
+// statistics of the last prove call that RETURNED ON THIS THREAD (bpr1cs_last_prove_stats)
+inline bpr1cs_prove_stats& tl_last_stats() {
+    static thread_local bpr1cs_prove_stats s{};
+    return s;
+}
 
 // ---- C ABI boundary: failures inside (HIP errors, allocation failures, oversized launches) become return codes
 #define API_TRY try {
@@ -102,6 +112,10 @@ static bool host_scalars_canonical(const uint8_t* p, size_t count) {
     return true;
 }
 
+struct bpr1cs_transcript {  // merlin::Transcript (host side)
+    strobe s;
+};
+
 struct bpr1cs_gens {
     uint32_t cap = 0;
     TabCfg tc{};             // fixed-base table geometry (window bits chosen at creation)
@@ -114,8 +128,7 @@ struct bpr1cs_gens {
     // HIGH-priority streams: their kernels are latency bound (one wave per proof group, few hundred
     // waves in total) and must get wave slots as soon as any short MSM workgroup retires, so that they
     // co-run with the other in-flight job's MSM/IPA kernels instead of queueing behind them.
-    dev_stream_t jstream[2][4]{};  // [slot][heavy, front, witness (later: the job's IPA tail), isolated RNG chain]
-    bool rng_isolated = false;
+    dev_stream_t jstream[2][3]{};  // [slot][heavy, front, witness (later: the job's IPA tail)]
     mutable DevArena arena;           // back-phase scratch shared by the handle's jobs (one thread at a time uses a handle)
     mutable std::atomic<uint32_t> next_job{0};
     mutable std::atomic<int> in_flight{0};  // jobs begun and not yet ended
@@ -142,11 +155,11 @@ struct bpr1cs_circuit {
     DevBuf<uint32_t> trip, rest, ones;  // ones: the multipliers m, m+2 of every triple (a_O = 1 by construction)
     // merged tables, one set per generator handle that has proved this circuit (built on first use, under mt_mu)
     struct MergedTab {
-        uint32_t W = 0, cap = 0, fmt = 0;
+        uint32_t W = 0, cap = 0;
         DevBuf<uint8_t> tab;
         DevBuf<ge> ones_pt;  // sum over the triples of G_m + G_m+2: the constant part of A_O (K_triple_ones_point)
         DevBuf<uint8_t> hs_tab;  // table of the single point sum_{n - N/2 <= i < N/2} H_i (K_range_sum_points), when n > N/2
-        uint32_t hs_W = 0, hs_cap = 0, hs_fmt = 0;
+        uint32_t hs_W = 0, hs_cap = 0;
     };
     mutable std::mutex mt_mu;
     mutable std::map<const bpr1cs_gens*, MergedTab*> mt;

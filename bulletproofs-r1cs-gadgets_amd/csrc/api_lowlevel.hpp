@@ -36,9 +36,6 @@ extern "C" int bpr1cs_poseidon_permutation_batch(const bpr1cs_poseidon_params* p
 }
 
 // ---- low-level entry points: Merlin transcript on the host, general variable-base MSM on the device
-struct bpr1cs_transcript {
-    strobe s;
-};
 extern "C" bpr1cs_transcript* bpr1cs_transcript_new(const uint8_t* label, size_t label_len) {
     bpr1cs_transcript* t = new (std::nothrow) bpr1cs_transcript();
     if (t) merlin_new(t->s, label, (uint32_t)label_len);
@@ -86,7 +83,7 @@ extern "C" int bpr1cs_ipa_create(const bpr1cs_gens* g, bpr1cs_transcript* t, con
     launch((uint64_t)4 * N, K_load_wires{raw.p, vec.p}, st);
     DevBuf<uint8_t> LR((size_t)(lgN ? lgN : 1) * 2 * 32), ab(64);
     DevBuf<sc> uk((size_t)(lgN ? lgN : 1) * 2);
-    const int unfold = g->opts.unfold.load() >= 0 ? g->opts.unfold.load() : g_unfold_rounds.load();
+    const int unfold = g->opts.unfold.load();
     IpaIO io{g, 1, N, lgN, (uint32_t)unfold, tr.p, vec.p, vec.p + N, vec.p + (size_t)2 * N, vec.p + (size_t)3 * N, nullptr, dq.p, LR.p, uk.p};
     (void)enqueue_ipa(io, st, &stats);
     std::vector<sc> fin(N + 1);

@@ -12,11 +12,10 @@ struct bpr1cs_job {
     uint8_t* h_proofs = nullptr;  // pinned staging
     uint8_t* h_comms = nullptr;
     int* h_err = nullptr;
+    strobe* h_tr = nullptr;       // final transcript states (only when the caller handed in its own transcripts)
     bool counted = false;         // contributes to g->in_flight
     IpaIO::TailKeep tail;         // the IPA tail's own buffers (outside the handle's shared arena)
-#if !defined(BPR1CS_HOSTSIM)
-    hipEvent_t ev_in{}, ev_rng{}, ev_wit{}, ev_done{}, ev_rng0{}, ev_rng1{}, ev_tail{};
-#endif
+    dev_event_t ev_in{}, ev_rng{}, ev_wit{}, ev_done{}, ev_tail{};
 };
 // pinned staging buffers are cached: hipHostFree (like hipFree) synchronises the whole device, which
 // would serialise the in-flight jobs
@@ -25,7 +24,7 @@ struct HostStage {
     std::multimap<size_t, void*> cache;
     std::map<void*, size_t> live;
 };
-static HostStage& host_stage() {
+inline HostStage& host_stage() {
     static HostStage* h = new HostStage();  // intentionally leaked: must outlive static destructors
     return *h;
 }
@@ -58,46 +57,37 @@ static void host_stage_free(void* p) {
     hs.live.erase(it);
 #endif
 }
-static void dev_d2h_async(void* h, const void* d, size_t n, dev_stream_t s) {
-#if defined(BPR1CS_HOSTSIM)
-    memcpy(h, d, n);
-#else
-    HIPCHK(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, s));
-#endif
-    (void)s;
-}
 // wait for everything a job has enqueued and release what it holds (normal end and error paths)
 static void job_release(bpr1cs_job* job) {
     if (!job) return;
-#if !defined(BPR1CS_HOSTSIM)
     // the heavy stream is shared with the NEXT job in flight: wait for this job's own completion event, and for the
     // whole stream only when the job failed before recording it
-    if (job->ev_done) (void)hipEventSynchronize(job->ev_done);
+    if (job->ev_done) (void)dev_event_sync(job->ev_done);
+#if !defined(BPR1CS_HOSTSIM)
     else if (job->st) (void)hipStreamSynchronize(job->st);
     if (job->st2) (void)hipStreamSynchronize(job->st2);
     if (job->st3) (void)hipStreamSynchronize(job->st3);
-    if (job->st4) (void)hipStreamSynchronize(job->st4);
-    hipEvent_t* evs[7] = {&job->ev_in, &job->ev_rng, &job->ev_wit, &job->ev_done, &job->ev_rng0, &job->ev_rng1, &job->ev_tail};
-    for (auto e : evs)
-        if (*e) { (void)hipEventDestroy(*e); *e = nullptr; }
     for (auto e : job->pt.ev) (void)hipEventDestroy(e);
     job->pt.ev.clear();
 #endif
+    dev_event_t* evs[5] = {&job->ev_in, &job->ev_rng, &job->ev_wit, &job->ev_done, &job->ev_tail};
+    for (auto e : evs) dev_event_destroy(e);
     for (void* p : job->deferred) dev_free_now(p);
     job->deferred.clear();
     host_stage_free(job->h_proofs);
     host_stage_free(job->h_comms);
     host_stage_free(job->h_err);
-    host_stage_free(job->tail.h_prog);
-    job->tail.h_prog = nullptr;
+    host_stage_free(job->h_tr);
     if (job->counted) job->g->in_flight--;
     delete job;
 }
 
-extern "C" int bpr1cs_prove_batch_begin(const bpr1cs_gens* g, const bpr1cs_circuit* c, const uint8_t* label, size_t label_len,
-                                        const uint8_t* values, const uint8_t* v_blindings, const uint8_t* rng_seeds,
-                                        const uint8_t* wires, size_t batch, bpr1cs_job** job_out) {
-    if (!g || !c || !label || !rng_seeds || !job_out || batch == 0) return BPR1CS_ERR_INVALID_ARGUMENT;
+// One device job.  `init`: the transcripts the proofs start from - n_init = 1 (every proof starts from a copy of init[0]: what
+// Transcript::new(label) gives) or n_init = batch (the caller's own); want_tr: read the final transcript states back.
+static int prove_job_begin(const bpr1cs_gens* g, const bpr1cs_circuit* c, const strobe* init, size_t n_init, bool want_tr,
+                           const uint8_t* values, const uint8_t* v_blindings, const uint8_t* rng_seeds,
+                           const uint8_t* wires, size_t batch, bpr1cs_job** job_out) {
+    if (!g || !c || !init || !rng_seeds || !job_out || batch == 0 || (n_init != 1 && n_init != batch)) return BPR1CS_ERR_INVALID_ARGUMENT;
     if (c->m && (!values || !v_blindings)) return BPR1CS_ERR_INVALID_ARGUMENT;
     if (!have_device()) return BPR1CS_ERR_NO_DEVICE;
     if (g->cap < c->N) return BPR1CS_ERR_INVALID_GENERATORS_LENGTH;
@@ -125,12 +115,8 @@ extern "C" int bpr1cs_prove_batch_begin(const bpr1cs_gens* g, const bpr1cs_circu
     // streams' mapping onto the few hardware queues (measured: two more streams serialised the jobs, 2540 -> 2040 proofs/s)
     job->st4 = g->jstream[slot][2];
     Scope scope(job);
-    // per-call knobs: the handle's own setting, else the process default
-    const int o_unfold = g->opts.unfold.load() >= 0 ? g->opts.unfold.load() : g_unfold_rounds.load();
-    const int o_rng = g->opts.rng_mode.load() >= 0 ? g->opts.rng_mode.load() : g_rng_mode.load();
-    const int o_team = g->opts.witness_team.load() >= 0 ? g->opts.witness_team.load() : g_witness_team.load();
-    const int o_merge = g_merge_triples.load();
-    const int o_tail = g->opts.tail_rounds.load() >= 0 ? g->opts.tail_rounds.load() : g_tail_rounds.load();
+    // the handle's options, read once per job
+    const int o_unfold = g->opts.unfold.load(), o_team = g->opts.witness_team.load(), o_tail = g->opts.tail_rounds.load();
     const uint32_t B = (uint32_t)batch, n = c->n, m = c->m, N = c->N, lgN = c->lgN;
     const uint32_t baseG = 2, baseH = 2 + g->cap;
     dev_stream_t st = job->st;
@@ -148,9 +134,11 @@ extern "C" int bpr1cs_prove_batch_begin(const bpr1cs_gens* g, const bpr1cs_circu
     DevBuf<sc> v_raw, vbl_raw, v_m((size_t)m * B), vbl_m((size_t)m * B);
     upload_transposed(v_raw, values, B, m, sl);
     upload_transposed(vbl_raw, v_blindings, B, m, sl);
-    DevBuf<uint8_t> d_seeds((size_t)B * 32), d_label(label_len ? label_len : 1);
+    DevBuf<uint8_t> d_seeds((size_t)B * 32);
     dev_h2d(d_seeds.p, rng_seeds, (size_t)B * 32, sl);
-    if (label_len) dev_h2d(d_label.p, label, label_len, sl);
+    DevBuf<strobe> d_init(n_init);
+    dev_h2d(d_init.p, init, n_init * sizeof(strobe), sl);
+    const uint32_t init_stride = n_init == 1 ? 0u : 1u;
     launch((uint64_t)m * B, K_load_inputs{v_raw.p, vbl_raw.p, v_m.p, vbl_m.p}, sl);
 
     // ---- P1: V commitments, transcript, RNG stream
@@ -161,54 +149,30 @@ extern "C" int bpr1cs_prove_batch_begin(const bpr1cs_gens* g, const bpr1cs_circu
     sc* sL = W.p + (size_t)3 * n * B;
     sc* sR = W.p + (size_t)4 * n * B;
     pt.mark(sl);
+    dev_event_create(&job->ev_in);
+    dev_event_create(&job->ev_rng);
+    dev_event_record(job->ev_in, sl);
 #if defined(BPR1CS_HOSTSIM)
-    (void)o_rng; (void)o_team;
-    launch(B, K_transcript_init{d_label.p, (uint32_t)label_len, Vcomp.p, vbl_raw.p, d_seeds.p, tr.p, blind.p, sL, sR, nullptr, B, m, n}, st);
+    (void)o_team;
+    launch(B, K_transcript_init{d_init.p, init_stride, Vcomp.p, vbl_raw.p, d_seeds.p, tr.p, blind.p, sL, sR, nullptr, B, m, n}, st);
+    DevBuf<int> rng_err(1);
+    dev_zero(rng_err.p, sizeof(int), sl);
 #else
-    hipEvent_t& ev_in = job->ev_in;
-    hipEvent_t& ev_rng = job->ev_rng;
-    HIPCHK(hipEventCreateWithFlags(&ev_in, hipEventDisableTiming));
-    HIPCHK(hipEventCreateWithFlags(&ev_rng, hipEventDisableTiming));
-    HIPCHK(hipEventRecord(ev_in, sl));
+    // TranscriptRng: the sequential STROBE chain of a proof (2n + 7 draws, one Keccak-f[1600] each) runs lane-parallel - one state
+    // on 25 lanes, two proofs per wavefront (k_rng_stream) -, the wide reductions mod l of its outputs afterwards in parallel
     const uint32_t draws = 2 * n + 7;
     DevBuf<strobe> rng(B);
     DevBuf<uint64_t> rng_raw((size_t)draws * B * 8);
     DevBuf<int> rng_err(1);
     dev_zero(rng_err.p, sizeof(int), sl);
-    launch(B, K_transcript_init{d_label.p, (uint32_t)label_len, Vcomp.p, vbl_raw.p, d_seeds.p, tr.p, blind.p, sL, sR, rng.p, B, m, n}, sl);
-    // a batch already in flight hides this chain's latency: then take the variant with the smallest VALU footprint
-    // (only with CUs reserved for it - see bpr1cs_gens_create)
-    const bool rng_per_thread = o_rng == 2 || (o_rng == 0 && g->rng_isolated && g->in_flight.load() > 0);
-    // ... or (explicit request only) the variant on the scalar unit: it takes no VALU issue slots, but a wavefront
-    // issues one scalar instruction per ~9 cycles, so the chain is 3.7x slower (717 ms per batch) and its 1024 resident
-    // wavefronts still slow the co-running MSM launches by 40 % - measured 1000 proofs/s against 1590
-    const bool rng_scalar = o_rng == 3;
-    if (o_rng == 5) {
-        hipLaunchKernelGGL(k_rng_rows, dim3((B + 7) / 8), dim3(64), 0, sl, rng.p, rng_raw.p, rng_err.p, B, draws);
-    } else if (o_rng == 4) {
-        hipLaunchKernelGGL(k_rng_dpp, dim3(B), dim3(64), 0, sl, rng.p, rng_raw.p, rng_err.p, B, draws);
-    } else if (rng_scalar) {
-        hipLaunchKernelGGL(k_rng_scalar, dim3(B), dim3(64), 0, sl, rng.p, rng_raw.p, rng_err.p, B, draws);
-    } else if (rng_per_thread && !g->rng_isolated) {
-        hipLaunchKernelGGL(k_rng_thread, dim3((B + 63) / 64), dim3(64), 0, sl, rng.p, rng_raw.p, rng_err.p, B, draws);
-    } else if (rng_per_thread) {
-        dev_stream_t sr = g->jstream[slot][3];
-        hipEvent_t& e0 = job->ev_rng0;
-        hipEvent_t& e1 = job->ev_rng1;
-        HIPCHK(hipEventCreateWithFlags(&e0, hipEventDisableTiming));
-        HIPCHK(hipEventCreateWithFlags(&e1, hipEventDisableTiming));
-        HIPCHK(hipEventRecord(e0, sl));
-        HIPCHK(hipStreamWaitEvent(sr, e0, 0));
-        hipLaunchKernelGGL(k_rng_thread, dim3((B + 63) / 64), dim3(64), 0, sr, rng.p, rng_raw.p, rng_err.p, B, draws);
-        HIPCHK(hipEventRecord(e1, sr));
-        HIPCHK(hipStreamWaitEvent(sl, e1, 0));
-    } else hipLaunchKernelGGL(k_rng_stream, dim3((B + 1) / 2), dim3(64), 0, sl, rng.p, rng_raw.p, rng_err.p, B, draws);
+    launch(B, K_transcript_init{d_init.p, init_stride, Vcomp.p, vbl_raw.p, d_seeds.p, tr.p, blind.p, sL, sR, rng.p, B, m, n}, sl);
+    hipLaunchKernelGGL(k_rng_stream, dim3((B + 1) / 2), dim3(64), 0, sl, rng.p, rng_raw.p, rng_err.p, B, draws);
     HIPCHK(hipGetLastError());
     launch((uint64_t)draws * B, K_rng_reduce{rng_raw.p, blind.p, sL, sR, B, n}, sl);
     dev_zero(rng_raw.p, rng_raw.bytes(), sl);  // raw blinding material
     dev_zero(rng.p, rng.bytes(), sl);
-    HIPCHK(hipEventRecord(ev_rng, sl));
 #endif
+    dev_event_record(job->ev_rng, sl);
 
     // ---- P7/P8: witness (device program) or host-synthesised wires
     DevBuf<sc> px;
@@ -234,14 +198,14 @@ extern "C" int bpr1cs_prove_batch_begin(const bpr1cs_gens* g, const bpr1cs_circu
         if (c->n_perms && (uint32_t)T < c->macro_width + 2) T = 16;  // poseidon_team needs width + 2 lanes
         kw.prio = 2;  // above the co-resident MSM waves (default 0), below the RNG chain (3)
         uint32_t blocks = (uint32_t)(((uint64_t)B * T + 63) / 64);
-        HIPCHK(hipStreamWaitEvent(job->st3, ev_in, 0));
+        dev_stream_wait(job->st3, job->ev_in);
         if (T == 4) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_witness_team<4>), dim3(blocks), dim3(64), 0, job->st3, kw);
         else if (T == 8) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_witness_team<8>), dim3(blocks), dim3(64), 0, job->st3, kw);
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_witness_team<16>), dim3(blocks), dim3(64), 0, job->st3, kw);
         HIPCHK(hipGetLastError());
-        HIPCHK(hipEventCreateWithFlags(&job->ev_wit, hipEventDisableTiming));
-        HIPCHK(hipEventRecord(job->ev_wit, job->st3));
-        HIPCHK(hipStreamWaitEvent(st, job->ev_wit, 0));
+        dev_event_create(&job->ev_wit);
+        dev_event_record(job->ev_wit, job->st3);
+        dev_stream_wait(st, job->ev_wit);
 #endif
     }
     // ---- P2: A_I1, A_O1, S1.  The sums of A_I1 and A_O1 need the wires only, so they are enqueued BEFORE the heavy stream
@@ -258,7 +222,7 @@ extern "C" int bpr1cs_prove_batch_begin(const bpr1cs_gens* g, const bpr1cs_circu
         MsmPlan planO, planO1{0, 0};
         const ge* ones_pt = nullptr;
         K_msm_finish finI{g->tab.p, g->tc, nullptr, blind.p + 0 * (size_t)B, nullptr, AOS.p + 0 * (size_t)B * 32, B, 0, 1};
-        if (!wires && T3 && o_merge) {
+        if (!wires && T3) {
             // A_I1 with the repeated S-box wires merged: 2 terms per S-box instead of 5 (see K_merge_points).  The merged
             // tables belong to (circuit, generator handle); the first job that needs them builds them on the heavy stream.
             const uint8_t* mtab = nullptr;
@@ -266,7 +230,7 @@ extern "C" int bpr1cs_prove_batch_begin(const bpr1cs_gens* g, const bpr1cs_circu
                 std::lock_guard<std::mutex> lk(c->mt_mu);
                 bpr1cs_circuit::MergedTab*& mt = c->mt[g];
                 if (!mt) mt = new bpr1cs_circuit::MergedTab();
-                if (mt->W != g->tc.W || mt->cap != g->cap || mt->fmt != g->tc.fmt || !mt->tab.p) {
+                if (mt->W != g->tc.W || mt->cap != g->cap || !mt->tab.p) {
                     DevBuf<ge> mp((size_t)2 * T3);
                     launch(T3, K_merge_points{g->pts.p, c->trip.p, mp.p, T3, baseG, baseH}, st);
                     mt->tab.alloc((size_t)2 * T3 * g->tc.base_bytes());
@@ -275,7 +239,7 @@ extern "C" int bpr1cs_prove_batch_begin(const bpr1cs_gens* g, const bpr1cs_circu
                     mt->ones_pt.alloc(1);
                     launch(64, K_triple_ones_point{g->pts.p, c->trip.p, part64.p, T3, baseG}, st);
                     launch(1, K_ge_reduce{part64.p, mt->ones_pt.p, 1, 64, 64}, st);
-                    mt->W = g->tc.W; mt->cap = g->cap; mt->fmt = g->tc.fmt;
+                    mt->W = g->tc.W; mt->cap = g->cap;
                 }
                 mtab = mt->tab.p;
                 ones_pt = mt->ones_pt.p;
@@ -302,9 +266,7 @@ extern "C" int bpr1cs_prove_batch_begin(const bpr1cs_gens* g, const bpr1cs_circu
             finI.partial = partial.p;
             finI.nchunks = plan.nchunks;
         }
-#if !defined(BPR1CS_HOSTSIM)
-        HIPCHK(hipStreamWaitEvent(st, ev_rng, 0));  // (in the wires path everything on `sl` was synchronised above)
-#endif
+        dev_stream_wait(st, job->ev_rng);  // (in the wires path everything on `sl` was synchronised above)
         pt.mark(st);
         launch(B, finI, st);
         K_msm_finish finO{g->tab.p, g->tc, partialO.p, blind.p + 1 * (size_t)B, nullptr, AOS.p + 1 * (size_t)B * 32, B, planO.nchunks, 1};
@@ -317,7 +279,8 @@ extern "C" int bpr1cs_prove_batch_begin(const bpr1cs_gens* g, const bpr1cs_circu
 
     // ---- from here on the job's scratch comes from the handle's arena, shared with the other job in flight: that job's
     // back phase is AHEAD of this one on the heavy stream (FIFO), and its tail - the only part that runs on another stream -
-    // works on copies of its own (IpaIO::TailKeep), so stream order alone keeps the two jobs apart: no event, no wait.
+    // works on copies of its own (IpaIO::TailKeep) and on buffers allocated BEFORE the arena is installed (the proof bytes
+    // `d_out` among them), so stream order alone keeps the two jobs apart: no event, no wait.
     struct ArenaHook {
         DevArena* prev;
         explicit ArenaHook(DevArena* a) : prev(dev_arena()) { if (a) { a->next = 0; dev_arena() = a; } }
@@ -326,7 +289,10 @@ extern "C" int bpr1cs_prove_batch_begin(const bpr1cs_gens* g, const bpr1cs_circu
     // what the IPA tail and the proof assembly read stays the job's own: challenges, T commitments, t_x.., L/R, u_k
     DevBuf<sc> chal((size_t)CH_COUNT * B), txs((size_t)3 * B), uk((size_t)(lgN ? lgN : 1) * 2 * B);
     DevBuf<uint8_t> Tc((size_t)5 * B * 32), LR((size_t)(lgN ? lgN : 1) * 2 * B * 32);
-    const bool shared_back = g_shared_back.load() != 0;
+    const size_t plen = bpr1cs_proof_len(c);
+    job->plen = plen;
+    DevBuf<uint8_t> d_out((size_t)B * plen);   // written by K_assemble and read back on the TAIL stream: never an arena block
+    const bool shared_back = g->opts.shared_back.load() != 0;
     ArenaHook arena_hook(shared_back ? &g->arena : nullptr);
 
     // ---- P3/P4: challenges, flatten, t(x), T commitments, l(x), r(x)
@@ -340,7 +306,7 @@ extern "C" int bpr1cs_prove_batch_begin(const bpr1cs_gens* g, const bpr1cs_circu
     // (dead after round r-1) share their memory with the Straus multiples of the first variable-base pair, which K_ipa_vb_tab
     // writes at round r, after the launch that materialises the folded generators: 15 of 40 GiB of a 2048-proof job's back phase.
     const uint32_t r_eff = std::min<uint32_t>((uint32_t)o_unfold, lgN);
-    const bool fvec = g_factor_vectors.load() != 0;   // factor vectors as arrays (measuring knob); default: closed form, no cG / cH
+    const bool fvec = g->opts.factor_vectors.load() != 0;   // factor vectors as arrays (measuring knob); default: closed form, no cG / cH
     const uint32_t nfl = c->h_slot_chunk[3 * n + m];
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     const size_t w_bytes = al(((size_t)(3 * n + m) * B + 1) * sizeof(sc)), p_bytes = al((size_t)(nfl ? nfl : 1) * B * sizeof(sc)),
@@ -378,7 +344,7 @@ extern "C" int bpr1cs_prove_batch_begin(const bpr1cs_gens* g, const bpr1cs_circu
         std::lock_guard<std::mutex> lk(c->mt_mu);
         bpr1cs_circuit::MergedTab*& mt = c->mt[g];
         if (!mt) mt = new bpr1cs_circuit::MergedTab();
-        if (!mt->hs_tab.p || mt->hs_W != g->tc.W || mt->hs_cap != g->cap || mt->hs_fmt != g->tc.fmt) {
+        if (!mt->hs_tab.p || mt->hs_W != g->tc.W || mt->hs_cap != g->cap) {
             struct ArenaPause {  // the table outlives the job: it must not come from the jobs' shared arena
                 DevArena* saved;
                 ArenaPause() : saved(dev_arena()) { dev_arena() = nullptr; }
@@ -389,7 +355,7 @@ extern "C" int bpr1cs_prove_batch_begin(const bpr1cs_gens* g, const bpr1cs_circu
             launch(1, K_ge_reduce{part64.p, hsum.p, 1, 64, 64}, st);
             mt->hs_tab.alloc(g->tc.base_bytes());
             launch(g->tc.windows, K_build_table{hsum.p, mt->hs_tab.p, g->tc}, st);
-            mt->hs_W = g->tc.W; mt->hs_cap = g->cap; mt->hs_fmt = g->tc.fmt;  // only once allocation and launches went through
+            mt->hs_W = g->tc.W; mt->hs_cap = g->cap;  // only once allocation and launches went through
         }
         hs_scal.alloc(B);
         launch(B, K_neg_ypow{plo.p, phi.p, hs_scal.p, B, H, N / 2}, st);
@@ -399,18 +365,12 @@ extern "C" int bpr1cs_prove_batch_begin(const bpr1cs_gens* g, const bpr1cs_circu
     }
     io.tail_stream = job->st4;
     io.tail_rounds = (uint32_t)o_tail;
-#if !defined(BPR1CS_HOSTSIM)
     io.tail_event = &job->ev_tail;
-#endif
     io.sG_pre = sG_p; io.sH_pre = sH_p;
     io.vtab_pre = (ge_cached*)shared_blk.p; io.vtab_pre_count = shared_blk.n / sizeof(ge_cached);
     io.tail_keep = &job->tail;
-    io.tail_fused = g_tail_fused.load();
     const IpaEnd ipa_end = enqueue_ipa(io, st, stats);
     st = ipa_end.st;  // from here on `st` may be the job's tail stream: only the job's own buffers are touched below
-    size_t plen = bpr1cs_proof_len(c);
-    job->plen = plen;
-    DevBuf<uint8_t> d_out((size_t)B * plen);
     launch(B, K_assemble{AOS.p, Tc.p, txs.p, LR.p, ipa_end.a, ipa_end.bb, d_out.p, B, lgN, (uint32_t)plen}, st);
     pt.mark(st);
     job->h_proofs = (uint8_t*)host_stage_alloc((size_t)B * plen);
@@ -419,6 +379,10 @@ extern "C" int bpr1cs_prove_batch_begin(const bpr1cs_gens* g, const bpr1cs_circu
     *job->h_err = 0;
     dev_d2h_async(job->h_proofs, d_out.p, (size_t)B * plen, st);
     if (m) dev_d2h_async(job->h_comms, Vcomp.p, (size_t)B * m * 32, st);
+    if (want_tr) {
+        job->h_tr = (strobe*)host_stage_alloc((size_t)B * sizeof(strobe));
+        dev_d2h_async(job->h_tr, tr.p, (size_t)B * sizeof(strobe), st);
+    }
     // secrets do not stay in the allocator's cache (upstream wipes them with clear_on_drop): witness, blindings, the
     // blinding vectors s_L / s_R, the l / r vectors and the Poseidon scratch are zeroed before their blocks are released
     dev_zero(W.p, W.bytes(), st);
@@ -429,11 +393,9 @@ extern "C" int bpr1cs_prove_batch_begin(const bpr1cs_gens* g, const bpr1cs_circu
     else { dev_zero(job->tail.a.p, job->tail.a.bytes(), st); dev_zero(job->tail.bb.p, job->tail.bb.bytes(), st); }
     if (px.p) dev_zero(px.p, px.bytes(), st);
     dev_zero(d_seeds.p, d_seeds.bytes(), st);
-#if !defined(BPR1CS_HOSTSIM)
     dev_d2h_async(job->h_err, rng_err.p, sizeof(int), st);
-    HIPCHK(hipEventCreateWithFlags(&job->ev_done, hipEventDisableTiming));
-    HIPCHK(hipEventRecord(job->ev_done, st));
-#endif
+    dev_event_create(&job->ev_done);
+    dev_event_record(job->ev_done, st);
     g->in_flight++;
     job->counted = true;
     *job_out = job;
@@ -444,41 +406,168 @@ extern "C" int bpr1cs_prove_batch_begin(const bpr1cs_gens* g, const bpr1cs_circu
     catch (...) { job_release(job); return BPR1CS_ERR_DEVICE; }
 }
 
-extern "C" int bpr1cs_prove_batch_end(bpr1cs_job* job, uint8_t* proofs_out, uint8_t* commitments_out) {
+// wait for a job, copy its results out and add its statistics to `acc` (nullptr: none)
+static int prove_job_end(bpr1cs_job* job, uint8_t* proofs_out, uint8_t* commitments_out, bpr1cs_transcript* const* tr_out, bpr1cs_prove_stats* acc) {
     if (!job || !proofs_out) return BPR1CS_ERR_INVALID_ARGUMENT;
     int rc = BPR1CS_OK;
+    if (!dev_event_sync(job->ev_done)) rc = BPR1CS_ERR_DEVICE;
 #if !defined(BPR1CS_HOSTSIM)
-    if (hipEventSynchronize(job->ev_done) != hipSuccess) rc = BPR1CS_ERR_DEVICE;
     (void)hipStreamSynchronize(job->st2);
     (void)hipStreamSynchronize(job->st3);
 #endif
     if (rc == BPR1CS_OK) {
         memcpy(proofs_out, job->h_proofs, (size_t)job->B * job->plen);
         if (commitments_out && job->m) memcpy(commitments_out, job->h_comms, (size_t)job->B * job->m * 32);
+        if (tr_out && job->h_tr)
+            for (uint32_t b = 0; b < job->B; b++) tr_out[b]->s = job->h_tr[b];
         if (*job->h_err) rc = BPR1CS_ERR_INVALID_ARGUMENT;  // RNG stream kernel found a non-steady STROBE state
+        float ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         try {
-            job->pt.finish(tl_last.timings);
+            job->pt.finish(ph);
         } catch (...) {}
         job->msm.collect();
-        tl_last.msm_ms = job->msm.ms; tl_last.msm_launches = job->msm.launches; tl_last.msm_terms = job->msm.terms;
+        if (acc) {
+            acc->jobs++;
+            if (job->B > acc->job_proofs) acc->job_proofs = job->B;
+            for (int i = 0; i < 6; i++) acc->phase_ms[i] += ph[i];
+            acc->msm_ms += job->msm.ms; acc->msm_launches += job->msm.launches; acc->msm_terms += job->msm.terms;
+        }
     }
     job_release(job);
     return rc;
 }
 
-extern "C" int bpr1cs_prove_batch(const bpr1cs_gens* g, const bpr1cs_circuit* c, const uint8_t* label, size_t label_len,
-                                  const uint8_t* values, const uint8_t* v_blindings, const uint8_t* rng_seeds,
-                                  const uint8_t* wires, size_t batch, uint8_t* proofs_out, uint8_t* commitments_out) {
-    if (!proofs_out) return BPR1CS_ERR_INVALID_ARGUMENT;
-    bpr1cs_job* job = nullptr;
-    int rc = bpr1cs_prove_batch_begin(g, c, label, label_len, values, v_blindings, rng_seeds, wires, batch, &job);
-    if (rc) return rc;
-    return bpr1cs_prove_batch_end(job, proofs_out, commitments_out);
+// Proofs per device job when a batch is cut into jobs (BPR1CS_OPT_JOB_PROOFS = 0): the largest of 4096, 2048, ... 64 whose working
+// set - the fronts of the jobs in flight, ONE shared back phase, the circuit's merged tables if they are still to be built - fits
+// into the memory the device has left next to the generator tables.  Per proof: the front holds the wires and blinding vectors
+// (5 n scalars), the raw TranscriptRng output (64 B x (2n + 7)) and the IPA tail's copies; the back holds l / r (2 N scalars),
+// the shared block (the larger of the flattened constraints + product scalars and the Straus multiples of the first
+// variable-base pair) and the folded generators.  2048 for the depth-32 tree circuits on a 288 GB device.
+static uint32_t auto_job_proofs(const bpr1cs_gens* g, const bpr1cs_circuit* c, bool have_program, int in_flight) {
+    const size_t n = c->n, m = c->m, N = c->N;
+    const uint32_t r = std::min<uint32_t>((uint32_t)std::max(0, g->opts.unfold.load()), c->lgN);
+    const size_t Mr = N >> r, nfl = c->h_slot_chunk.empty() ? 0 : c->h_slot_chunk[3 * n + m];
+    const size_t tail_m = std::min<size_t>(N, 128);
+    const size_t front = 160 * n + 64 * (2 * n + 7) + 200 * m + 4 * 32 * (size_t)c->px_stride + 512 + c->lgN * 128 +
+                         tail_m * (2 * 32 + 2 * sizeof(ge)) + (tail_m / 2) * (4 * VB_MULT * sizeof(ge_cached) + 4 * VB_WORDS * 4) + 2 * VB_WINDOWS * 17 * sizeof(ge);
+    const size_t others = 32 * (3 * n + m + nfl) + 64 * N, vt = r < c->lgN ? (size_t)VB_MULT * 4 * std::max<size_t>(1, Mr / 2) * sizeof(ge_cached) : 0;
+    const size_t back = std::max(others, vt) + 64 * N + 2 * Mr * sizeof(ge) + 4 * VB_WORDS * 4 * std::max<size_t>(1, Mr / 2) + 2 * VB_WINDOWS * 17 * sizeof(ge) + 30000;
+    size_t fixed = (size_t)3 << 30;   // chunk partial sums of the MSM launches (~2^21 points each, whatever the batch), transposition staging
+    if (have_program && !c->h_trip.empty()) {
+        std::lock_guard<std::mutex> lk(c->mt_mu);
+        auto it = c->mt.find(g);
+        if (it == c->mt.end() || !it->second->tab.p) fixed += 2 * c->h_trip.size() * g->tc.base_bytes();
+    }
+    const size_t avail = dev_free_memory() + g->arena.bytes();
+    const size_t reserve = (size_t)2 << 30;
+    const uint64_t grid_per_proof = (uint64_t)4 * c->N + 3ull * c->n + c->m + 64;
+    for (uint32_t J = 4096; J > 64; J >>= 1) {
+        if (grid_per_proof * J > 0xffffffffull) continue;
+        if ((double)J * ((double)front * in_flight + (double)back) + (double)fixed + (double)reserve <= (double)avail) return J;
+    }
+    return 64;
 }
 
-extern "C" int bpr1cs_last_msm_stats(double* ms_total, uint64_t* launches, uint64_t* terms) {
-    if (ms_total) *ms_total = tl_last.msm_ms;
-    if (launches) *launches = tl_last.msm_launches;
-    if (terms) *terms = tl_last.msm_terms;
+// The batched prover over any batch: device jobs of `job_proofs` proofs, `jobs_in_flight` of them in flight (the latency-bound
+// front of job k+1 - TranscriptRng chain, witness synthesis - next to the multiscalar multiplications of job k).
+static int prove_batch_impl(const bpr1cs_gens* g, const bpr1cs_circuit* c, const strobe* init, size_t n_init, bpr1cs_transcript* const* tr_out,
+                            const uint8_t* values, const uint8_t* v_blindings, const uint8_t* rng_seeds,
+                            const uint8_t* wires, size_t batch, uint8_t* proofs_out, uint8_t* commitments_out) {
+    if (!g || !c || !proofs_out || batch == 0) return BPR1CS_ERR_INVALID_ARGUMENT;
+    if (batch > ((size_t)1 << 28)) return BPR1CS_ERR_INVALID_ARGUMENT;
+    if (!have_device()) return BPR1CS_ERR_NO_DEVICE;
+    bpr1cs_prove_stats acc{};
+    const int depth = g->opts.jobs_in_flight.load() == 1 ? 1 : 2;
+    size_t J = (size_t)g->opts.job_proofs.load();
+    const uint64_t grid_per_proof = (uint64_t)4 * c->N + 3ull * c->n + c->m + 64;
+    const size_t grid_max = (size_t)std::min<uint64_t>(0xffffffffull / grid_per_proof, 1u << 20);
+    if (grid_max == 0) return BPR1CS_ERR_INVALID_ARGUMENT;
+    if (J == 0) J = batch <= 64 ? batch : auto_job_proofs(g, c, wires == nullptr, depth);
+    J = std::min(J, grid_max);
+    const size_t m = c->m, plen = bpr1cs_proof_len(c), wn = 3 * (size_t)c->n;
+    struct Pending { bpr1cs_job* job; size_t first; };
+    std::vector<Pending> fl;
+    int rc = BPR1CS_OK;
+    auto finish_oldest = [&]() {
+        Pending p = fl.front();
+        fl.erase(fl.begin());
+        int e = prove_job_end(p.job, proofs_out + p.first * plen, commitments_out ? commitments_out + p.first * m * 32 : nullptr,
+                              tr_out ? tr_out + p.first : nullptr, &acc);
+        if (e != BPR1CS_OK && rc == BPR1CS_OK) rc = e;
+    };
+    size_t done = 0;
+    while (done < batch && rc == BPR1CS_OK) {
+        // full jobs of J proofs; what is left once fewer than 2 J remain is cut into two equal jobs (no short straggler whose
+        // latency-bound front would have nothing to hide behind).  The first job is the largest: it sizes the shared arena.
+        const size_t rest = batch - done, take = (rest >= 2 * J || rest <= J) ? std::min(J, rest) : (rest + 1) / 2;
+        bpr1cs_job* job = nullptr;
+        int e = prove_job_begin(g, c, n_init == 1 ? init : init + done, n_init == 1 ? 1 : take, tr_out != nullptr,
+                                values ? values + done * m * 32 : nullptr, v_blindings ? v_blindings + done * m * 32 : nullptr,
+                                rng_seeds ? rng_seeds + done * 32 : nullptr, wires ? wires + done * wn * 32 : nullptr, take, &job);
+        if (e == BPR1CS_ERR_OUT_OF_MEMORY && take > 64) {
+            // less memory than estimated (another process, a second handle): let the jobs in flight finish, hand the scratch back
+            // and go on with jobs of half the size
+            while (!fl.empty()) finish_oldest();
+            g->arena.release();
+#if !defined(BPR1CS_HOSTSIM)
+            dev_pool().release_all();
+#endif
+            J = std::max<size_t>(64, take / 2);
+            continue;
+        }
+        if (e != BPR1CS_OK) { rc = e; break; }
+        fl.push_back({job, done});
+        done += take;
+        if ((int)fl.size() >= depth) finish_oldest();
+    }
+    while (!fl.empty()) finish_oldest();
+    tl_last_stats() = acc;
+    return rc;
+}
+
+static strobe label_state(const uint8_t* label, size_t label_len) {
+    strobe s;
+    merlin_new(s, label, (uint32_t)label_len);
+    return s;
+}
+
+extern "C" {
+int bpr1cs_prove_batch_begin(const bpr1cs_gens* g, const bpr1cs_circuit* c, const uint8_t* label, size_t label_len,
+                             const uint8_t* values, const uint8_t* v_blindings, const uint8_t* rng_seeds,
+                             const uint8_t* wires, size_t batch, bpr1cs_job** job_out) {
+    if (!label) return BPR1CS_ERR_INVALID_ARGUMENT;
+    const strobe s0 = label_state(label, label_len);
+    return prove_job_begin(g, c, &s0, 1, false, values, v_blindings, rng_seeds, wires, batch, job_out);
+}
+int bpr1cs_prove_batch_end(bpr1cs_job* job, uint8_t* proofs_out, uint8_t* commitments_out) {
+    bpr1cs_prove_stats acc{};
+    int rc = prove_job_end(job, proofs_out, commitments_out, nullptr, &acc);
+    if (job && proofs_out) tl_last_stats() = acc;
+    return rc;
+}
+int bpr1cs_prove_batch(const bpr1cs_gens* g, const bpr1cs_circuit* c, const uint8_t* label, size_t label_len,
+                       const uint8_t* values, const uint8_t* v_blindings, const uint8_t* rng_seeds,
+                       const uint8_t* wires, size_t batch, uint8_t* proofs_out, uint8_t* commitments_out) {
+    if (!label) return BPR1CS_ERR_INVALID_ARGUMENT;
+    const strobe s0 = label_state(label, label_len);
+    return prove_batch_impl(g, c, &s0, 1, nullptr, values, v_blindings, rng_seeds, wires, batch, proofs_out, commitments_out);
+}
+int bpr1cs_prove_batch_transcripts(const bpr1cs_gens* g, const bpr1cs_circuit* c, bpr1cs_transcript* const* transcripts, size_t n_transcripts,
+                                   const uint8_t* values, const uint8_t* v_blindings, const uint8_t* rng_seeds,
+                                   const uint8_t* wires, size_t batch, uint8_t* proofs_out, uint8_t* commitments_out) {
+    if (!transcripts || (n_transcripts != 1 && n_transcripts != batch)) return BPR1CS_ERR_INVALID_ARGUMENT;
+    for (size_t i = 0; i < n_transcripts; i++)
+        if (!transcripts[i]) return BPR1CS_ERR_INVALID_ARGUMENT;
+    try {
+        std::vector<strobe> init(n_transcripts);
+        for (size_t i = 0; i < n_transcripts; i++) init[i] = transcripts[i]->s;
+        return prove_batch_impl(g, c, init.data(), n_transcripts, n_transcripts == 1 ? nullptr : transcripts, values, v_blindings, rng_seeds, wires,
+                                batch, proofs_out, commitments_out);
+    } catch (const std::bad_alloc&) { return BPR1CS_ERR_OUT_OF_MEMORY; }
+}
+int bpr1cs_last_prove_stats(bpr1cs_prove_stats* out) {
+    if (!out) return BPR1CS_ERR_INVALID_ARGUMENT;
+    *out = tl_last_stats();
     return BPR1CS_OK;
 }
+}  // extern "C"

@@ -19,33 +19,16 @@ int bpr1cs_set_device(int ordinal) {
     (void)ordinal;
     return BPR1CS_OK;
 }
-void bpr1cs_set_unfold_rounds(int r) { g_unfold_rounds = r < 0 ? 0 : r; }
-void bpr1cs_set_latency_cus(int n) { g_latency_cus = n < 0 ? 0 : n; }
-void bpr1cs_set_witness_team(int t) { g_witness_team = (t == 4 || t == 8) ? t : 16; }
-void bpr1cs_set_witness_macro(int enable) { g_witness_macro = enable ? 1 : 0; }
-void bpr1cs_set_tail_rounds(int r) { g_tail_rounds = r < 0 ? 0 : r; }
-void bpr1cs_set_shared_back(int enable) { g_shared_back = enable ? 1 : 0; }
-void bpr1cs_set_factor_vectors(int enable) { g_factor_vectors = enable ? 1 : 0; }
-void bpr1cs_set_tail_fused(int enable) { g_tail_fused = enable ? 1 : 0; }
-void bpr1cs_set_msm_threads_log2(int lg) { g_msm_target_threads = 1u << (lg < 16 ? 16 : (lg > 26 ? 26 : lg)); }
-void bpr1cs_set_rng_mode(int mode) { g_rng_mode = (mode >= 1 && mode <= 5) ? mode : 0; }
 int bpr1cs_circuit_macro_perms(const bpr1cs_circuit* c) { return c ? (int)c->n_perms : 0; }
-void bpr1cs_set_window_bits(int w) { g_window_bits = w <= 0 ? 0 : (w < 4 ? 4 : (w > 12 ? 12 : w)); }  // 0 = choose from the free memory
-void bpr1cs_set_table_format(int f) { g_table_format = (f == 0 || f == 1) ? f : -1; }
 int bpr1cs_gens_set_option(bpr1cs_gens* g, int option, int value) {
     if (!g) return BPR1CS_ERR_INVALID_ARGUMENT;
-    if (option == BPR1CS_OPT_UNFOLD_ROUNDS) g->opts.unfold = value < 0 ? -1 : value;
-    else if (option == BPR1CS_OPT_RNG_MODE) g->opts.rng_mode = (value >= 0 && value <= 5) ? value : -1;
-    else if (option == BPR1CS_OPT_WITNESS_TEAM) g->opts.witness_team = (value == 4 || value == 8 || value == 16) ? value : -1;
-    else if (option == BPR1CS_OPT_TAIL_ROUNDS) g->opts.tail_rounds = value < 0 ? -1 : value;
-    else return BPR1CS_ERR_INVALID_ARGUMENT;
-    return BPR1CS_OK;
+    return opt_apply(g->opts, option, value, false) ? BPR1CS_OK : BPR1CS_ERR_INVALID_ARGUMENT;
 }
 int bpr1cs_gens_table_info(const bpr1cs_gens* g, uint32_t* window_bits, uint32_t* windows, uint32_t* format, uint64_t* bytes) {
     if (!g) return BPR1CS_ERR_INVALID_ARGUMENT;
     if (window_bits) *window_bits = g->tc.W;
     if (windows) *windows = g->tc.windows;
-    if (format) *format = g->tc.fmt;
+    if (format) *format = 1;
     if (bytes) *bytes = (uint64_t)(2 + 2 * (size_t)g->cap) * g->tc.base_bytes();
     return BPR1CS_OK;
 }
@@ -61,81 +44,38 @@ int bpr1cs_release_cached_memory(void) {
 #endif
     return BPR1CS_OK;
 }
-int bpr1cs_last_timings(float* out, int cap) {
-    int k = cap < 6 ? cap : 6;
-    for (int i = 0; i < k; i++) out[i] = tl_last.timings[i];
-    return k;
-}
-
 void bpr1cs_gens_destroy(bpr1cs_gens* g);
-int bpr1cs_gens_create(uint32_t cap, bpr1cs_gens** out) {
-    if (!out || cap == 0) return BPR1CS_ERR_INVALID_ARGUMENT;
+int bpr1cs_gens_create_opts(uint32_t cap, const int32_t* pairs, size_t n_pairs, bpr1cs_gens** out) {
+    if (!out || cap == 0 || (n_pairs && !pairs)) return BPR1CS_ERR_INVALID_ARGUMENT;
     if (!have_device()) return BPR1CS_ERR_NO_DEVICE;
     if (cap > (1u << 24)) return BPR1CS_ERR_INVALID_ARGUMENT;
     bpr1cs_gens* g = nullptr;
     API_TRY
     g = new bpr1cs_gens();
     g->cap = cap;
-    int window_bits = g_window_bits.load();
-    const int latency_cus = g_latency_cus.load();
-    if (window_bits == 0) {  // automatic: the widest window (<= 11) whose packed tables leave 45 % of the free memory to the workspaces
-        window_bits = 8;
-#if !defined(BPR1CS_HOSTSIM)
-        size_t mfree = 0, mtotal = 0;
-        if (hipMemGetInfo(&mfree, &mtotal) == hipSuccess)
-            for (int w = 11; w >= 4; w--) {
-                TabCfg t = tab_cfg((uint32_t)w, TAB_FMT_PACKED, 96);
-                if ((double)(2 + 2 * (size_t)cap) * (double)t.base_bytes() <= 0.55 * (double)mfree) { window_bits = w; break; }
-            }
+    for (size_t i = 0; i < n_pairs; i++)
+        if (!opt_apply(g->opts, pairs[2 * i], pairs[2 * i + 1], true)) { delete g; return BPR1CS_ERR_INVALID_ARGUMENT; }
+    int window_bits = g->opts.window_bits;
+    if (window_bits == 0) {
+        // automatic: the widest window (<= 11) whose tables take at most two thirds of the free device memory - W = 11 (198 GB) for
+        // capacity 32768 on a 288 GB device, 8 / 7 for the reference's as-shipped depths (capacity 131072 / 262144); what is left is
+        // for a circuit's merged tables and the prove jobs, whose size follows from it (BPR1CS_OPT_JOB_PROOFS)
+#if defined(BPR1CS_HOSTSIM)
+        window_bits = 8;   // (the simulator builds its tables on one CPU core)
+#else
+        window_bits = 4;
+        const double room = (double)dev_free_memory() * (2.0 / 3.0);
+        for (int w = 11; w >= 4; w--)
+            if ((double)(2 + 2 * (size_t)cap) * (double)tab_cfg((uint32_t)w).base_bytes() <= room) { window_bits = w; break; }
 #endif
     }
-    {   // table entry format: the limb form (no unpacking in the inner loop, 128-byte aligned slots) costs a third more
-        // HBM than the packed one - take it when the device keeps >= 100 GB free for circuits' merged tables and the
-        // per-batch workspace (two 1024-proof jobs of the depth-32 circuit in flight need ~55 GB)
-        int fmt = g_table_format.load();
-        if (fmt < 0) {
-            fmt = 0;
-#if !defined(BPR1CS_HOSTSIM)
-            size_t mfree = 0, mtotal = 0;
-            TabCfg lim = tab_cfg((uint32_t)window_bits, TAB_FMT_LIMB, 128);
-            if (hipMemGetInfo(&mfree, &mtotal) == hipSuccess && mfree > (size_t)(2 + 2 * (size_t)cap) * lim.base_bytes() + (100ull << 30)) fmt = 1;
-#endif
-        }
-        g->tc = fmt ? tab_cfg((uint32_t)window_bits, TAB_FMT_LIMB, 128) : tab_cfg((uint32_t)window_bits, TAB_FMT_PACKED, 96);
-    }
+    g->tc = tab_cfg((uint32_t)window_bits);
 #if !defined(BPR1CS_HOSTSIM)
     HIPCHK(hipStreamCreate(&g->stream));
     int prio_lo = 0, prio_hi = 0;
     HIPCHK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));  // numerically lower = higher priority
-    hipDeviceProp_t prop;
-    int dev = 0;
-    HIPCHK(hipGetDevice(&dev));
-    HIPCHK(hipGetDeviceProperties(&prop, dev));
-    const uint32_t ncu = (uint32_t)prop.multiProcessorCount;
-    if (latency_cus > 0 && (uint32_t)latency_cus < ncu) {
-        // Reserve `latency_cus` CUs (every k-th one, so they spread over the XCDs) for the per-thread
-        // TranscriptRng chain (k_rng_thread): a few wavefronts of pure VALU code on the critical path.  Sharing a
-        // SIMD with anything else hurts both ways - an equal-priority neighbour halves the chain's speed, and a
-        // chain wave with raised priority starves the neighbour, which then becomes the straggler of ITS launch
-        // (measured: witness 94 -> 500 ms, K_msm_fixed 31 -> 56 ms).  Every other stream is masked off those CUs.
-        const uint32_t words = (ncu + 31) / 32;
-        std::vector<uint32_t> lat(words, 0), rest(words, 0);
-        const uint32_t stride = ncu / (uint32_t)latency_cus;
-        uint32_t taken = 0;
-        for (uint32_t cu = 0; cu < ncu; cu++) {
-            bool is_lat = (cu % stride == 0) && taken < (uint32_t)latency_cus;
-            if (is_lat) { lat[cu / 32] |= 1u << (cu % 32); taken++; }
-            else rest[cu / 32] |= 1u << (cu % 32);
-        }
-        for (int a = 0; a < 2; a++) {
-            for (int b = 0; b < 3; b++) HIPCHK(hipExtStreamCreateWithCUMask(&g->jstream[a][b], words, rest.data()));
-            HIPCHK(hipExtStreamCreateWithCUMask(&g->jstream[a][3], words, lat.data()));
-        }
-        g->rng_isolated = true;
-    } else {
-        for (int a = 0; a < 2; a++)
-            for (int b = 0; b < 3; b++) HIPCHK(hipStreamCreateWithPriority(&g->jstream[a][b], hipStreamNonBlocking, b == 0 ? prio_lo : prio_hi));
-    }
+    for (int a = 0; a < 2; a++)
+        for (int b = 0; b < 3; b++) HIPCHK(hipStreamCreateWithPriority(&g->jstream[a][b], hipStreamNonBlocking, b == 0 ? prio_lo : prio_hi));
 #endif
     CallScope scope(g->stream);
     uint32_t nb = 2 + 2 * cap;
@@ -167,13 +107,14 @@ int bpr1cs_gens_create(uint32_t cap, bpr1cs_gens** out) {
     catch (const std::bad_alloc&) { bpr1cs_gens_destroy(g); return BPR1CS_ERR_OUT_OF_MEMORY; }
     catch (...) { bpr1cs_gens_destroy(g); return BPR1CS_ERR_DEVICE; }
 }
+int bpr1cs_gens_create(uint32_t cap, bpr1cs_gens** out) { return bpr1cs_gens_create_opts(cap, nullptr, 0, out); }
 void bpr1cs_gens_destroy(bpr1cs_gens* g) {
     if (!g) return;
     g->arena.release();
 #if !defined(BPR1CS_HOSTSIM)
     if (g->stream) (void)hipStreamDestroy(g->stream);
     for (int a = 0; a < 2; a++)
-        for (int b = 0; b < 4; b++) if (g->jstream[a][b]) (void)hipStreamDestroy(g->jstream[a][b]);
+        for (int b = 0; b < 3; b++) if (g->jstream[a][b]) (void)hipStreamDestroy(g->jstream[a][b]);
 #endif
     delete g;
 }
@@ -240,7 +181,8 @@ int bpr1cs_circuit_create(const bpr1cs_circuit_desc* d, bpr1cs_circuit** out) {
     while (c->N < d->n) { c->N <<= 1; c->lgN++; }
     dev_stream_t s{};
     CallScope scope(s);
-    const int witness_macro = g_witness_macro.load();
+    const char* wm_env = getenv("BPR1CS_WITNESS_MACRO");   // test knob: 0 = run every S-box op by op (one inversion each)
+    const int witness_macro = !(wm_env && wm_env[0] == '0');
     // CSR by row -> CSC by wire slot (LEFT i -> i, RIGHT -> n+i, OUT -> 2n+i, COMMITTED -> 3n+i, One -> 3n+m).
     // The prover flattens slots [0, 3n+m) (it ignores constant terms); the verifier also needs slot 3n+m (w_c).
     uint32_t nslots = 3 * d->n + d->m + 1;

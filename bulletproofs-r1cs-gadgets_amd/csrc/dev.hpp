@@ -43,6 +43,17 @@ inline void dev_d2h(void* h, const void* d, size_t n, dev_stream_t) { memcpy(h, 
 inline void dev_zero(void* d, size_t n, dev_stream_t) { memset(d, 0, n); }
 inline void dev_d2d(void* d, const void* s, size_t n, dev_stream_t) { memcpy(d, s, n); }
 inline void dev_sync(dev_stream_t) {}
+// events / cross-stream order: the simulator is synchronous, so these are no-ops
+typedef int dev_event_t;
+inline void dev_event_create(dev_event_t* e, bool = false) { *e = 1; }
+inline void dev_event_record(dev_event_t, dev_stream_t) {}
+inline void dev_stream_wait(dev_stream_t, dev_event_t) {}
+inline bool dev_event_sync(dev_event_t) { return true; }
+inline void dev_event_destroy(dev_event_t* e) { *e = 0; }
+inline float dev_event_ms(dev_event_t, dev_event_t) { return 0.f; }
+inline void dev_d2h_async(void* h, const void* d, size_t n, dev_stream_t) { memcpy(h, d, n); }
+inline void dev_h2d_async(void* d, const void* h, size_t n, dev_stream_t) { memcpy(d, h, n); }
+inline size_t dev_free_memory() { return (size_t)64 << 30; }
 template <class F>
 inline void launch(uint64_t n, const F& f, dev_stream_t) {
     if (n > 0xffffffffull) throw DevError{DEV_ERR_INVALID_ARGUMENT};
@@ -86,16 +97,25 @@ struct DevPool {
         }
         // The HIP / HSA runtime needs device memory of its own (scratch, queues, kernel arguments) and ABORTS the process when
         // it finds none ("HSA_STATUS_ERROR_OUT_OF_RESOURCES ... Available Free mem : 0 MB"): a large block that would leave less
-        // than RESERVE free is refused like a failed allocation, so that running out of memory stays a return code.
-        static const size_t RESERVE = (size_t)2 << 30;
+        // than the reserve free is refused like a failed allocation, so that running out of memory stays a return code.  Free
+        // memory is device-wide (another process, RCCL): the reserve is small by default and configurable (BPR1CS_MEM_RESERVE_MB),
+        // and it is checked BEFORE hipMalloc - no allocate-and-free round trip for a refused block.
+        static const size_t RESERVE = [] {
+            const char* e = getenv("BPR1CS_MEM_RESERVE_MB");
+            long mb = e ? atol(e) : 1024;
+            return (size_t)(mb < 0 ? 0 : mb) << 20;
+        }();
         auto try_alloc = [&](void** out) -> bool {
-            if (hipMalloc(out, n) != hipSuccess) { (void)hipGetLastError(); *out = nullptr; return false; }
+            static const bool dbg = getenv("BPR1CS_DEBUG_MEM") != nullptr;
             if (n >= ((size_t)64 << 20)) {
                 size_t mfree = 0, mtotal = 0;
-                static const bool dbg = getenv("BPR1CS_DEBUG_MEM") != nullptr;
-                hipError_t ei = hipMemGetInfo(&mfree, &mtotal);
-                if (dbg) fprintf(stderr, "bpr1cs: hipMalloc %zu MB -> free %zu MB of %zu MB\n", n >> 20, mfree >> 20, mtotal >> 20);
-                if (ei == hipSuccess && mfree < RESERVE) { (void)hipFree(*out); *out = nullptr; return false; }
+                if (hipMemGetInfo(&mfree, &mtotal) == hipSuccess && mfree < n + RESERVE) { *out = nullptr; return false; }
+            }
+            if (hipMalloc(out, n) != hipSuccess) { (void)hipGetLastError(); *out = nullptr; return false; }
+            if (dbg && n >= ((size_t)64 << 20)) {
+                size_t mfree = 0, mtotal = 0;
+                (void)hipMemGetInfo(&mfree, &mtotal);
+                fprintf(stderr, "bpr1cs: hipMalloc %zu MB -> free %zu MB of %zu MB\n", n >> 20, mfree >> 20, mtotal >> 20);
             }
             return true;
         };
@@ -124,6 +144,12 @@ struct DevPool {
         for (auto& kv : free_blocks) (void)hipFree(kv.second);
         free_blocks.clear();
     }
+    size_t cached_bytes() {
+        std::lock_guard<std::mutex> lk(mu);
+        size_t t = 0;
+        for (auto& kv : free_blocks) t += kv.first;
+        return t;
+    }
 };
 inline DevPool& dev_pool() {
     static DevPool* p = new DevPool();  // intentionally leaked: must outlive static destructors
@@ -146,11 +172,28 @@ inline void dev_d2h(void* h, const void* d, size_t n, dev_stream_t s) {
 inline void dev_zero(void* d, size_t n, dev_stream_t s) { HIPCHK(hipMemsetAsync(d, 0, n, s)); }
 inline void dev_d2d(void* d, const void* src, size_t n, dev_stream_t s) { HIPCHK(hipMemcpyAsync(d, src, n, hipMemcpyDeviceToDevice, s)); }
 inline void dev_sync(dev_stream_t s) { HIPCHK(hipStreamSynchronize(s)); }
+typedef hipEvent_t dev_event_t;
+inline void dev_event_create(dev_event_t* e, bool timing = false) {
+    if (timing) HIPCHK(hipEventCreate(e));
+    else HIPCHK(hipEventCreateWithFlags(e, hipEventDisableTiming));
+}
+inline void dev_event_record(dev_event_t e, dev_stream_t s) { HIPCHK(hipEventRecord(e, s)); }
+inline void dev_stream_wait(dev_stream_t s, dev_event_t e) { HIPCHK(hipStreamWaitEvent(s, e, 0)); }
+inline bool dev_event_sync(dev_event_t e) { return hipEventSynchronize(e) == hipSuccess; }
+inline void dev_event_destroy(dev_event_t* e) { if (*e) { (void)hipEventDestroy(*e); *e = nullptr; } }
+inline void dev_d2h_async(void* h, const void* d, size_t n, dev_stream_t s) { HIPCHK(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, s)); }
+inline void dev_h2d_async(void* d, const void* h, size_t n, dev_stream_t s) { HIPCHK(hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, s)); }
+// device memory a new allocation can draw on: what the driver reports free plus what the allocator's cache holds
+inline size_t dev_free_memory() {
+    size_t mfree = 0, mtotal = 0;
+    if (hipMemGetInfo(&mfree, &mtotal) != hipSuccess) { (void)hipGetLastError(); mfree = 0; }
+    return mfree + dev_pool().cached_bytes();
+}
 
 template <class F>
 __global__ void __launch_bounds__(256) k_functor(F f, uint32_t n) {
     uint32_t g = blockIdx.x * 256u + threadIdx.x;
-    // always inlined HERE: a functor that is also a step of k_tail_program (or simply large) is otherwise compiled once as an
+    // always inlined HERE: a functor that is also large is otherwise compiled once as an
     // out-of-line function for the worst case of all its callers (227-248 VGPRs, scratch, flat loads) and CALLED from its own kernel
     if (g < n) INLINE_CALL f(g);
 }
@@ -210,6 +253,11 @@ struct DevArena {
         } else slots.push_back({np, bytes});
         next++;
         return np;
+    }
+    size_t bytes() const {
+        size_t t = 0;
+        for (auto& sl : slots) t += sl.second;
+        return t;
     }
     void release() {  // only when no job of the handle is in flight
         for (auto& s : slots) dev_free_now(s.first);

@@ -5,59 +5,6 @@
 // InnerProductProof::create for B independent proofs whose transcripts already hold ("dom-sep","ipp v1"), ("n", N).
 // Rounds 0..unfold-1 take L_k, R_k from the UN-folded generator tables with product scalars; at round `unfold` the
 // folded generators are materialised once and the remaining rounds are variable-base.
-// ---- the IPA tail as ONE launch (round 3): every kernel of the last rounds is per proof (gid = index * B + proof), so a
-// workgroup per proof can run them all back to back with a barrier in between - the functors are the ones the separate launches
-// use, recorded here as a list of steps instead of being launched (k_tail_program, kernels_hip.hpp).
-enum TailKind : uint32_t { TK_CROSS, TK_SUMP, TK_VBTAB, TK_VBDIG2, TK_VBWIN, TK_GERED, TK_HORNER, TK_FINISH2, TK_TLR, TK_FOLDAB, TK_FOLD2 };
-#define TAIL_F_BYTES 384
-struct TailStep {
-    uint32_t kind, count;   // count = work items per proof: the step runs functor(t * B + proof) for t < count
-    alignas(8) unsigned char f[TAIL_F_BYTES];
-};
-template <class F> struct tail_kind;
-template <> struct tail_kind<K_ipa_cross> { static const uint32_t v = TK_CROSS; };
-template <> struct tail_kind<K_sum_partials> { static const uint32_t v = TK_SUMP; };
-template <> struct tail_kind<K_ipa_vb_tab> { static const uint32_t v = TK_VBTAB; };
-template <> struct tail_kind<K_ipa_vb_dig2> { static const uint32_t v = TK_VBDIG2; };
-template <> struct tail_kind<K_ipa_vb_win> { static const uint32_t v = TK_VBWIN; };
-template <> struct tail_kind<K_ge_reduce> { static const uint32_t v = TK_GERED; };
-template <> struct tail_kind<K_ipa_vb_horner> { static const uint32_t v = TK_HORNER; };
-template <> struct tail_kind<K_pair<K_msm_finish>> { static const uint32_t v = TK_FINISH2; };
-template <> struct tail_kind<K_transcript_LR> { static const uint32_t v = TK_TLR; };
-template <> struct tail_kind<K_ipa_fold_ab> { static const uint32_t v = TK_FOLDAB; };
-template <> struct tail_kind<K_ipa_vb_fold2> { static const uint32_t v = TK_FOLD2; };
-#if !defined(BPR1CS_HOSTSIM)
-template <class F>
-__device__ inline void tail_run(const TailStep& st, uint32_t b, uint32_t tid, uint32_t B) {
-    const F& f = *reinterpret_cast<const F*>(st.f);
-    for (uint32_t t = tid; t < st.count; t += blockDim.x) f(t * B + b);
-}
-// one workgroup (= ONE wavefront: with four, 192 of the 256 lanes sat at barriers most of the time and their registers and wave
-// slots were taken from the co-running sums: measured 2476 against 2760 proofs/s) per proof; a step's work items are spread
-// over its lanes, steps are separated by a workgroup barrier (release / acquire at workgroup scope: what one lane wrote to
-// HBM for this proof the others read in the next step)
-__global__ void __launch_bounds__(64) k_tail_program(const TailStep* prog, uint32_t nsteps, uint32_t B) {
-    const uint32_t b = blockIdx.x, tid = threadIdx.x;
-    for (uint32_t s = 0; s < nsteps; s++) {
-        const TailStep& st = prog[s];
-        switch (st.kind) {   // uniform over the workgroup
-            case TK_CROSS: tail_run<K_ipa_cross>(st, b, tid, B); break;
-            case TK_SUMP: tail_run<K_sum_partials>(st, b, tid, B); break;
-            case TK_VBTAB: tail_run<K_ipa_vb_tab>(st, b, tid, B); break;
-            case TK_VBDIG2: tail_run<K_ipa_vb_dig2>(st, b, tid, B); break;
-            case TK_VBWIN: tail_run<K_ipa_vb_win>(st, b, tid, B); break;
-            case TK_GERED: tail_run<K_ge_reduce>(st, b, tid, B); break;
-            case TK_HORNER: tail_run<K_ipa_vb_horner>(st, b, tid, B); break;
-            case TK_FINISH2: tail_run<K_pair<K_msm_finish>>(st, b, tid, B); break;
-            case TK_TLR: tail_run<K_transcript_LR>(st, b, tid, B); break;
-            case TK_FOLDAB: tail_run<K_ipa_fold_ab>(st, b, tid, B); break;
-            case TK_FOLD2: tail_run<K_ipa_vb_fold2>(st, b, tid, B); break;
-            default: break;
-        }
-        __syncthreads();
-    }
-}
-#endif
 static void* host_stage_alloc(size_t n);
 static void host_stage_free(void* p);
 
@@ -91,18 +38,13 @@ struct IpaIO {
         DevBuf<ge> GH, vwin, vsum, vout;
         DevBuf<ge_cached> vtab;
         DevBuf<uint32_t> vdig;
-        DevBuf<TailStep> prog;          // the fused tail's step list on the device ...
-        TailStep* h_prog = nullptr;     // ... and its pinned staging copy (host_stage_alloc; released with the job)
     }* tail_keep = nullptr;
-    int tail_fused = 0;                 // 1: record the tail's launches as a step list and run them as ONE kernel
     // optional: room provided by the caller for the product scalars of the un-folded rounds (2 x N*B) and for the Straus
     // multiples of the first variable-base pair - the prover lets them SHARE one block with buffers that are dead by then
     sc* sG_pre = nullptr; sc* sH_pre = nullptr;
     IpaGeo geo;      // the R1CS prover's factor vectors in closed form (kernels.hpp) instead of cG / cH
     ge_cached* vtab_pre = nullptr; size_t vtab_pre_count = 0;
-#if !defined(BPR1CS_HOSTSIM)
-    hipEvent_t* tail_event = nullptr;
-#endif
+    dev_event_t* tail_event = nullptr;
 };
 struct IpaEnd {
     dev_stream_t st;  // the stream the caller continues on
@@ -163,20 +105,8 @@ static IpaEnd enqueue_ipa(const IpaIO& io, dev_stream_t st, MsmStats* stats) {
     }
     sc* cpartp = nullptr; size_t cpart_n = 0;
     bool handed_off = false;
-    // launches that can belong to the tail go through `emit`: launched as they come, or - once the tail is being fused -
-    // recorded as steps of the tail program (same functor, same arguments)
-    std::vector<TailStep> steps;
-    bool fusing = false;
     auto emit = [&](uint64_t total, const auto& f, bool wave) {
-        using F = typename std::decay<decltype(f)>::type;
-        static_assert(sizeof(F) <= TAIL_F_BYTES && std::is_trivially_copyable<F>::value, "tail step functor");
-        if (fusing) {
-            TailStep ts{};
-            ts.kind = tail_kind<F>::v;
-            ts.count = (uint32_t)(total / B);
-            memcpy(ts.f, &f, sizeof(F));
-            steps.push_back(ts);
-        } else if (wave) launch_wave(total, f, st);
+        if (wave) launch_wave(total, f, st);
         else launch(total, f, st);
     };
     for (uint32_t k = 0; k < lgN; k++) {
@@ -201,19 +131,21 @@ static IpaEnd enqueue_ipa(const IpaIO& io, dev_stream_t st, MsmStats* stats) {
             dev_zero(io.a, (size_t)N * B * sizeof(sc), st);  // the arena's copies of the secret vectors die here
             dev_zero(io.bb, (size_t)N * B * sizeof(sc), st);
             if (s_bytes) { dev_zero(sGp, s_bytes, st); dev_zero(sHp, s_bytes, st); }
+            // ... and so does everything derived from them that lives in the arena: Straus digits of the products with a / b,
+            // the partial inner products
+            if (vdig.p) dev_zero(vdig.p, vdig.bytes(), st);
+            if (cpart.p) dev_zero(cpart.p, cpart.bytes(), st);
+            dev_zero(cross.p, cross.bytes(), st);
             handed_off = true;
             a = T.a.p; bb = T.bb.p; linvp = T.linv.p; crossp = T.cross.p; GHp = T.GH.p; M = Nk;
             vtabp = T.vtab.p; vdigp = T.vdig.p; vwinp = T.vwin.p; vsump = T.vsum.p; voutp = T.vout.p;
             cpartp = nullptr; cpart_n = 0;
-#if !defined(BPR1CS_HOSTSIM)
-            if (io.tail_stream && io.tail_event) {  // ... and hand over to the job's tail stream
-                HIPCHK(hipEventCreateWithFlags(io.tail_event, hipEventDisableTiming));  // owned (and destroyed) by the job
-                HIPCHK(hipEventRecord(*io.tail_event, st));
-                HIPCHK(hipStreamWaitEvent(io.tail_stream, *io.tail_event, 0));
+            if (io.tail_event) {  // ... and hand over to the job's tail stream
+                dev_event_create(io.tail_event);  // owned (and destroyed) by the job
+                dev_event_record(*io.tail_event, st);
+                dev_stream_wait(io.tail_stream, *io.tail_event);
                 st = io.tail_stream;
             }
-            fusing = io.tail_fused != 0;
-#endif
         }
         uint32_t cchunk, CC = pick_chunks(mk, B, 1u << 18, cchunk);
         if (cpart_n < (size_t)2 * CC * B) {
@@ -267,10 +199,6 @@ static IpaEnd enqueue_ipa(const IpaIO& io, dev_stream_t st, MsmStats* stats) {
                     fG = sGp; fH = sHp;
                 }
                 const uint32_t f_mont = geo ? 0u : 1u;
-                (void)f_mont;
-#if defined(BPR1CS_HOSTSIM)
-                launch_wave((uint64_t)2 * M * B, K_ipa_fold_from_tables{g->tab.p, g->tc, fG, fH, GH.p, B, M, N, baseG, baseH, geo ? 1u : 0u}, st);
-#else
                 if (B < 32) {
                     launch_wave((uint64_t)2 * M * B, K_ipa_fold_from_tables{g->tab.p, g->tc, fG, fH, GH.p, B, M, N, baseG, baseH, geo ? 1u : 0u}, st);
                 } else {
@@ -284,7 +212,6 @@ static IpaEnd enqueue_ipa(const IpaIO& io, dev_stream_t st, MsmStats* stats) {
                     L.wg_end[0] = M * L.nbk; L.wg_end[1] = 2 * M * L.nbk;
                     launch_msm_kernel(g, L, st, stats, (uint64_t)2 * N * B);
                 }
-#endif
                 const size_t vtab_need = (size_t)VB_MULT * 4 * (M / 2 ? M / 2 : 1) * B;
                 if (!(io.vtab_pre && io.vtab_pre_count >= vtab_need)) vtab.alloc(vtab_need);
                 vdig.alloc((size_t)VB_WORDS * 4 * (M / 2 ? M / 2 : 1) * B);
@@ -295,7 +222,7 @@ static IpaEnd enqueue_ipa(const IpaIO& io, dev_stream_t st, MsmStats* stats) {
                 launch((uint64_t)2 * B, K_set_one{linv.p}, st);
                 GHp = GH.p; vtabp = vtab.p ? vtab.p : io.vtab_pre; vdigp = vdig.p; vwinp = vwin.p; vsump = vsum.p; voutp = vout.p; linvp = linv.p;
             }
-            const uint32_t remap = fusing ? 0u : 1u;  // XCD-aware workgroup order of the window sums (vb_win_index; +1 % end to end); plain order inside the fused tail
+            const uint32_t remap = 1u;  // XCD-aware workgroup order of the window sums (vb_win_index; +1 % end to end)
             if (!vb_reuse) {
                 // multiples 1P..8P and digits of every term of this round
                 const uint32_t vc = 2 * mk < VC ? 2 * mk : VC;  // chunks of the 2*mk terms of one output
@@ -324,23 +251,20 @@ static IpaEnd enqueue_ipa(const IpaIO& io, dev_stream_t st, MsmStats* stats) {
             vb_reuse = false;
         }
     }
-#if !defined(BPR1CS_HOSTSIM)
-    if (fusing && !steps.empty()) {   // the whole tail in ONE launch: a workgroup per proof runs the recorded steps
-        IpaIO::TailKeep& T = *io.tail_keep;
-        DevArena* saved = dev_arena();
-        dev_arena() = nullptr;
-        try { T.prog.alloc(steps.size()); } catch (...) { dev_arena() = saved; throw; }
-        dev_arena() = saved;
-        T.h_prog = (TailStep*)host_stage_alloc(steps.size() * sizeof(TailStep));
-        memcpy(T.h_prog, steps.data(), steps.size() * sizeof(TailStep));
-        HIPCHK(hipMemcpyAsync(T.prog.p, T.h_prog, steps.size() * sizeof(TailStep), hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(k_tail_program, dim3(B), dim3(64), 0, st, T.prog.p, (uint32_t)steps.size(), B);
-        HIPCHK(hipGetLastError());
-    }
-#endif
     if (!handed_off && s_bytes) {
         dev_zero(sGp, s_bytes, st);  // products of the secret l / r vectors
         dev_zero(sHp, s_bytes, st);
+    }
+    // digits and partial inner products of the rounds that ran last (the job's own copies after a hand-off)
+    if (handed_off) {
+        IpaIO::TailKeep& T = *io.tail_keep;
+        if (T.vdig.p) dev_zero(T.vdig.p, T.vdig.bytes(), st);
+        if (T.cpart.p) dev_zero(T.cpart.p, T.cpart.bytes(), st);
+        if (T.cross.p) dev_zero(T.cross.p, T.cross.bytes(), st);
+    } else {
+        if (vdig.p) dev_zero(vdig.p, vdig.bytes(), st);
+        if (cpart.p) dev_zero(cpart.p, cpart.bytes(), st);
+        dev_zero(cross.p, cross.bytes(), st);
     }
     return IpaEnd{st, a, bb};
 }

@@ -26,18 +26,17 @@
 // s >= 2^252, whose lower windows are zero and send no carry) - 23 windows at W = 11, not 24.
 struct TabCfg {
     uint32_t W, windows, entries, row, per_base;  // per_base = windows * row slots
-    uint32_t fmt, stride;                         // entry format (ge.hpp) and byte stride of a slot
+    uint32_t stride;                              // byte stride of a slot (ge.hpp: 27 limbs in a 128-byte slot)
     HD size_t base_bytes() const { return (size_t)per_base * stride; }
 };
-HD inline TabCfg tab_cfg(uint32_t W, uint32_t fmt = TAB_FMT_PACKED, uint32_t stride = 96) {
+HD inline TabCfg tab_cfg(uint32_t W) {
     TabCfg t;
     t.W = W;
     t.windows = (252 + W) / W;
     t.entries = 1u << (W - 1);
     t.row = t.entries + 1;
     t.per_base = t.windows * t.row;
-    t.fmt = fmt;
-    t.stride = stride;
+    t.stride = 128;
     return t;
 }
 // signed digit of window k (carry in/out through `carry`); the top window keeps its value (see above)
@@ -78,7 +77,7 @@ HD inline ge table_mul_acc_raw(ge acc, const uint8_t* tbase, const sc& s, const 
         if (d != 0) {
             int neg = d < 0;
             int mag = neg ? -d : d;
-            acc = ge_madd_t(acc, ge_niels_load(tbase + ((size_t)k * tc.row + (uint32_t)mag) * tc.stride, tc.fmt), neg);
+            acc = ge_madd_t(acc, ge_niels_load(tbase + ((size_t)k * tc.row + (uint32_t)mag) * tc.stride), neg);
         }
     }
     return acc;
@@ -151,7 +150,7 @@ struct K_build_table {  // gid = base*windows + k
         ge_cached c = ge_to_cached(P);
         ge acc = P;
         uint8_t* out = tab + (size_t)g * tc.row * tc.stride;
-        ge_niels_store(ge_table_niels_identity(), out, tc.fmt);
+        ge_niels_store(ge_table_niels_identity(), out);
         out += tc.stride;
         // affine normalisation with Montgomery's trick, up to 16 entries per field inversion
         const int CH = 16;
@@ -169,7 +168,7 @@ struct K_build_table {  // gid = base*windows + k
                 fe zi = t ? fe_mul(inv, pre[t - 1]) : inv;
                 inv = fe_mul(inv, q[t].Z);
                 fe x = fe_mul(q[t].X, zi), y = fe_mul(q[t].Y, zi);
-                ge_niels_store(ge_to_table_niels(x, y), out + (size_t)(j0 + t) * tc.stride, tc.fmt);
+                ge_niels_store(ge_to_table_niels(x, y), out + (size_t)(j0 + t) * tc.stride);
             }
         }
     }
@@ -250,8 +249,8 @@ struct K_commit_v {  // gid = j*B + b : V = v*B + vbl*B~   (Prover::commit, P1)
 // --------------------------------------------------------------- transcript
 // Transcript::new(label); Prover::new; V appends; "m"; TranscriptRng; all draws.
 struct K_transcript_init {
-    const uint8_t* label;
-    uint32_t label_len;
+    const strobe* init;     // the transcript a proof starts from: Transcript::new(label), or the caller's own (advanced) one
+    uint32_t init_stride;   // 0: every proof starts from init[0]; 1: proof b from init[b]
     const uint8_t* Vcomp;   // [B][m][32]
     const sc* vbl_raw;      // [m][B]
     const uint8_t* seeds;   // [B][32]
@@ -262,8 +261,7 @@ struct K_transcript_init {
     strobe* rng_out;        // non-null: stop after the first draw and hand the RNG state over
     uint32_t B, m, n;
     HD void operator()(uint32_t b) const {
-        strobe s;
-        merlin_new(s, label, label_len);
+        strobe s = init[(size_t)b * init_stride];
         merlin_append(s, "dom-sep", 7, (const uint8_t*)"r1cs v1", 7);
         for (uint32_t j = 0; j < m; j++) merlin_append(s, "V", 1, Vcomp + ((size_t)b * m + j) * 32, 32);
         merlin_append_u64(s, "m", 1, m);
@@ -706,41 +704,9 @@ HD inline sc msm_scalar(const sc& x, uint32_t form) {
     if (form == MSM_MONT) return sc_from_mont(x);
     return sc_from_mont(sc_sub(x, sc_one_mont()));
 }
-#define MSM_MAX_JOBS 4  // independent sums that may share one launch of the shipped kernel (csrc/msm_hip.hpp)
-// One thread = (chunk c of the term list, proof b); a workgroup = ONE wavefront = 64 consecutive proofs of one
-// chunk, so its lanes walk the same table rows.  Workgroups are dealt round-robin to the 8 XCDs (each with a
-// private L2): the workgroup index is remapped so that the `nbk` workgroups sharing a chunk run on the SAME XCD
-// back to back and a table row is pulled from HBM once, not once per XCD.
-struct K_msm_fixed {  // gid = wg*64 + lane -> partial[c*B + b]   (launch_wave)
-    const uint8_t* tab;
-    TabCfg tc;
-    MsmSeg seg[2];
-    ge* partial;
-    uint32_t B, chunk;  // ordinals per chunk over the concatenated segments
-    uint32_t nbk;       // workgroups per chunk = ceil(B / 64)
-    uint32_t nwg;       // workgroups in the launch = nchunks * nbk
-    HD void operator()(uint32_t g) const {
-        uint32_t wg = g >> 6, lane = g & 63u;
-        if ((nwg & 7u) == 0) wg = (wg & 7u) * (nwg >> 3) + (wg >> 3);
-        uint32_t c = wg / nbk, b = (wg % nbk) * 64u + lane;
-        if (b >= B) return;
-        uint32_t total = seg[0].count + seg[1].count;
-        uint32_t lo = c * chunk, hi = lo + chunk < total ? lo + chunk : total;
-        ge acc = ge_identity();
-        for (uint32_t o = lo; o < hi; o++) {
-            const MsmSeg& s = o < seg[0].count ? seg[0] : seg[1];
-            uint32_t oo = o < seg[0].count ? o : o - seg[0].count;
-            uint32_t i = s.sidx ? s.sidx[oo] : (oo / s.run) * s.period + s.off + (oo % s.run);
-            uint32_t base = s.base0 + (s.bdense ? oo : i);
-            sc x = s.scal[(size_t)i * B + b];
-            x = msm_scalar(x, s.mont);
-            acc = table_mul_acc_raw(acc, tab + (size_t)base * tc.base_bytes(), x, tc);
-        }
-        partial[(size_t)c * B + b] = ge_from_table_class(acc);
-    }
-};
+#define MSM_MAX_JOBS 4  // independent sums that may share one launch of the shipped kernel (csrc/msm_kernel.hpp)
 // Small batches (B < 32: the cross-proof batched verifier evaluates ONE combined scalar vector): a wavefront of
-// K_msm_fixed / k_msm_fixed2 would carry B active lanes only, so here the lanes of a wave take different CHUNKS - thread
+// k_msm_fixed2 would carry B active lanes only, so here the lanes of a wave take different CHUNKS - thread
 // g = c * B + b sums chunk c for proof b; table rows differ per lane (gathers), scalar loads stay coalesced over b.
 struct K_msm_fixed_small {  // gid = c*B + b -> partial[c*B + b]
     const uint8_t* tab;

@@ -1,6 +1,7 @@
 // The dominant kernel: batched fixed-base multiscalar multiplication over the generator tables (SURVEY §8a P2, P5,
-// P10) as a hand-scheduled gfx950 kernel.  kernels.hpp's K_msm_fixed functor computes the same partial sums term by
-// term and is what the CPU simulator of the tests runs; this file is what ships.
+// P10) as a hand-scheduled gfx950 kernel.  ONE body (msm_fixed2_body) serves the shipped kernel and the CPU simulator of
+// the tests: the simulator runs it lane by lane (tests/hostsim), so the polarity flips, the two-layer order and the digit
+// recoding below are what `-m "not gpu"` executes, not a restatement of them.
 //
 //   * One wavefront per workgroup = 64 consecutive proofs of one chunk of the term list (they walk the same table
 //     rows); workgroups that share a chunk are remapped onto the same XCD so a row is pulled from HBM once per XCD.
@@ -16,7 +17,6 @@
 //   * Accumulator in the "table class" (ge_madd_t): six of seven products use the cheaper floor-carry multiplier.
 //   * Signed digits without selects: a per-lane polarity of the accumulator (see the loop body).
 #pragma once
-#include <hip/hip_runtime.h>
 #include "kernels.hpp"
 
 struct MsmJob {
@@ -34,51 +34,60 @@ struct MsmLaunch {
     TabCfg tc;
 };
 
-template <int FMT>
+// What the body needs from the wavefront it runs in.  Device: the hardware's vote and broadcast.  Simulator: lanes run one after
+// the other, so a vote evaluates the predicate for every lane of the wavefront.
+#if defined(BPR1CS_HOSTSIM)
+#define MSM_FN inline
+#define MSM_SCHED_FENCE() do { } while (0)
+struct MsmWave {
+    template <class F> static bool any(bool, F&& of_lane) {
+        for (uint32_t l = 0; l < 64; l++) if (of_lane(l)) return true;
+        return false;
+    }
+    static uint32_t uniform(uint32_t x) { return x; }
+};
+#else
+#include <hip/hip_runtime.h>
+#define MSM_FN __device__ inline
+#define MSM_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+struct MsmWave {
+    template <class F> __device__ static bool any(bool own, F&&) { return __ballot(own) != 0ull; }
+    __device__ static uint32_t uniform(uint32_t x) { return __builtin_amdgcn_readfirstlane(x); }
+};
+#endif
+
 struct MsmEntry {
-    static constexpr int WORDS = FMT == (int)TAB_FMT_PACKED ? 24 : 27;
-    uint32_t w[WORDS];
+    uint32_t w[27];
 };
 struct __attribute__((packed, aligned(4))) msm_u4 { uint32_t x, y, z, w; };
 struct __attribute__((packed, aligned(4))) msm_u3 { uint32_t x, y, z; };
 
-template <int FMT>
-__device__ inline void msm_entry_load(MsmEntry<FMT>& e, const uint8_t* p) {
+MSM_FN void msm_entry_load(MsmEntry& e, const uint8_t* p) {
 #pragma unroll
     for (int i = 0; i < 6; i++) {
         msm_u4 v = *(const msm_u4*)(p + 16 * i);
         e.w[4 * i] = v.x; e.w[4 * i + 1] = v.y; e.w[4 * i + 2] = v.z; e.w[4 * i + 3] = v.w;
     }
-    if (FMT != (int)TAB_FMT_PACKED) {
-        msm_u3 v = *(const msm_u3*)(p + 96);
-        e.w[24] = v.x; e.w[25] = v.y; e.w[26] = v.z;
-    }
+    msm_u3 v = *(const msm_u3*)(p + 96);
+    e.w[24] = v.x; e.w[25] = v.y; e.w[26] = v.z;
 }
-template <int FMT>
-__device__ inline ge_niels msm_entry_unpack(const MsmEntry<FMT>& e) {
+MSM_FN ge_niels msm_entry_unpack(const MsmEntry& e) {
     ge_niels n;
-    if (FMT == (int)TAB_FMT_PACKED) {
-        n.yplusx = fe_fromwords(e.w);
-        n.yminusx = fe_fromwords(e.w + 8);
-        n.xy2d = fe_fromwords(e.w + 16);
-    } else {
 #pragma unroll
-        for (int i = 0; i < 9; i++) {
-            n.yplusx.v[i] = (int32_t)e.w[i];
-            n.yminusx.v[i] = (int32_t)e.w[9 + i];
-            n.xy2d.v[i] = (int32_t)e.w[18 + i];
-        }
+    for (int i = 0; i < 9; i++) {
+        n.yplusx.v[i] = (int32_t)e.w[i];
+        n.yminusx.v[i] = (int32_t)e.w[9 + i];
+        n.xy2d.v[i] = (int32_t)e.w[18 + i];
     }
     return n;
 }
-
 // wave-uniform description of term ordinal o of a job: where its scalars live, which table rows it uses
 struct MsmTerm {
     const sc* scal;      // + b
     const uint8_t* tab;  // rows of its base
     uint32_t mont;
 };
-__device__ inline MsmTerm msm_term(const MsmJob& J, uint32_t o, uint32_t B, const TabCfg& tc) {
+MSM_FN MsmTerm msm_term(const MsmJob& J, uint32_t o, uint32_t B, const TabCfg& tc) {
     const bool first = o < J.seg[0].count;
     const MsmSeg& s = first ? J.seg[0] : J.seg[1];
     uint32_t oo = first ? o : o - J.seg[0].count;
@@ -93,7 +102,7 @@ __device__ inline MsmTerm msm_term(const MsmJob& J, uint32_t o, uint32_t B, cons
 // signed digits of a canonical scalar -> one uint16 per window: bit 15 = negative, low bits = magnitude (slot index).
 // Register-only bit stream (the word index is a compile-time constant in the unrolled outer loop; a run-time word
 // index would send the scalar through scratch memory).  Same digits as tab_digit.
-__device__ inline void msm_recode(const sc& x, uint16_t* dst, const TabCfg& tc) {
+MSM_FN void msm_recode(const sc& x, uint16_t* dst, const TabCfg& tc) {
     const uint32_t W = tc.W, mask = (1u << W) - 1u;
     uint64_t buf = 0;
     uint32_t bits = 0, k = 0;
@@ -116,23 +125,21 @@ __device__ inline void msm_recode(const sc& x, uint16_t* dst, const TabCfg& tc) 
     while (k < tc.windows) emit();  // the top window holds the remaining (< W) bits
 }
 
-template <int FMT, int WAVES_PER_SIMD>
-__global__ void __launch_bounds__(64, WAVES_PER_SIMD) k_msm_fixed2(const MsmLaunch L) {
-    extern __shared__ uint16_t msm_dig[];  // [2][windows][64]
+// the work of lane `lane` of logical workgroup `wg_raw` of a launch; msm_dig: [2][windows][64] uint16 (LDS on the device)
+MSM_FN void msm_fixed2_body(const MsmLaunch& L, uint32_t wg_raw, const uint32_t lane, uint16_t* msm_dig) {
     const TabCfg tc = L.tc;
-    const uint32_t lane = threadIdx.x;
-    uint32_t wg = blockIdx.x;
+    uint32_t wg = wg_raw;
     if ((L.nwg & 7u) == 0) wg = (wg & 7u) * (L.nwg >> 3) + (wg >> 3);  // XCD-aware: consecutive logical workgroups share an XCD
     uint32_t j = 0, w0 = 0;
 #pragma unroll
     for (uint32_t t = 0; t + 1 < MSM_MAX_JOBS; t++)
         if (t + 1 < L.njobs && wg >= L.wg_end[t]) { j = t + 1; w0 = L.wg_end[t]; }
     if (wg >= L.wg_end[L.njobs - 1]) return;  // padding up to a multiple of 8
-    j = __builtin_amdgcn_readfirstlane(j);
+    j = MsmWave::uniform(j);
     const MsmJob& J = L.job[j];
     wg -= w0;
-    const uint32_t B = L.B, c = wg / L.nbk;
-    uint32_t b = (wg % L.nbk) * 64u + lane;
+    const uint32_t B = L.B, c = wg / L.nbk, b0 = (wg % L.nbk) * 64u;
+    uint32_t b = b0 + lane;
     const bool active = b < B;
     if (!active) b = B - 1;  // ragged batch: the spare lanes repeat the last proof and do not store
     const uint32_t total = J.seg[0].count + J.seg[1].count;
@@ -146,12 +153,16 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) k_msm_fixed2(const MsmLaun
     auto fetch = [&](uint32_t& o, sc& x, MsmTerm& t) -> bool {
         for (; o < hi; o += step) {
             t = msm_term(J, o, B, tc);
-            x = t.scal[b];
-            if (t.mont == MSM_MINUS_ONE) {  // wires that are 1 by construction: the term is (wire - 1) * Base, zero in all but exceptional proofs
-                x = sc_sub(x, sc_one_mont());
-                t.mont = MSM_MONT;
-            }
-            if (__ballot(!sc_is_zero(x)) != 0ull) return true;
+            const uint32_t form = t.mont;
+            // wires that are 1 by construction (MSM_MINUS_ONE): the term is (wire - 1) * Base, zero in all but exceptional proofs
+            auto scalar_of = [&](uint32_t proof) {
+                sc v = t.scal[proof];
+                if (form == MSM_MINUS_ONE) v = sc_sub(v, sc_one_mont());
+                return v;
+            };
+            x = scalar_of(b);
+            if (form == MSM_MINUS_ONE) t.mont = MSM_MONT;
+            if (MsmWave::any(!sc_is_zero(x), [&](uint32_t l) { return !sc_is_zero(scalar_of(b0 + l < B ? b0 + l : B - 1)); })) return true;
         }
         return false;
     };
@@ -162,7 +173,7 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) k_msm_fixed2(const MsmLaun
     MsmTerm T;
     bool have = fetch(o, x, T);
     if (have) msm_recode(T.mont ? sc_from_mont(x) : x, msm_dig + lane, tc);
-    MsmEntry<FMT> E;
+    MsmEntry E;
     uint32_t d = 0;
     if (have) {
         d = msm_dig[lane];
@@ -194,7 +205,7 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) k_msm_fixed2(const MsmLaun
             fe MM = fe_mul_f(fe_sub(acc.Y, acc.X), q.yminusx);
             fe Txy2d = fe_mul_f(acc.T, q.xy2d);   // floor-carry form as well: six of the seven products (limb budget: ge_madd_t in ge.hpp)
             // ---- request the next entry: it lands while layer 2 runs
-            __builtin_amdgcn_sched_barrier(0);
+            MSM_SCHED_FENCE();
             // address = wave-uniform row pointer (scalar registers) + 32-bit per-lane offset: the loads take the scalar base
             // directly (global_load ... saddr) instead of a 64-bit per-lane multiply-add
             if (k + 1 < tc.windows) {
@@ -205,7 +216,7 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) k_msm_fixed2(const MsmLaun
                 d = msm_dig[(cur ^ 1u) * dig_buf + lane];
                 msm_entry_load(E, T2.tab + (uint32_t)((d & 0x7fffu) * tc.stride));
             }
-            __builtin_amdgcn_sched_barrier(0);
+            MSM_SCHED_FENCE();
             // ---- layer 2
             fe cX = fe_sub(PP, MM), cY = fe_add(PP, MM);
             fe cZ = fe_add(acc.Z, Txy2d), cT = fe_sub(acc.Z, Txy2d);  // halved table operands: Z, not 2Z (ge_madd_t)
@@ -220,3 +231,18 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) k_msm_fixed2(const MsmLaun
     }
     if (active) J.partial[(size_t)c * B + b] = ge_from_table_class(acc);
 }
+
+#if defined(BPR1CS_HOSTSIM)
+// the simulator's "launch": every lane of every workgroup runs the body, one after the other
+inline void msm_fixed2_sim(const MsmLaunch& L) {
+    std::vector<uint16_t> dig((size_t)2 * L.tc.windows * 64u);
+    for (uint32_t wg = 0; wg < L.nwg; wg++)
+        for (uint32_t lane = 0; lane < 64; lane++) msm_fixed2_body(L, wg, lane, dig.data());
+}
+#else
+template <int WAVES_PER_SIMD>
+__global__ void __launch_bounds__(64, WAVES_PER_SIMD) k_msm_fixed2(const MsmLaunch L) {
+    extern __shared__ uint16_t msm_dig[];  // [2][windows][64]
+    msm_fixed2_body(L, blockIdx.x, threadIdx.x, msm_dig);
+}
+#endif

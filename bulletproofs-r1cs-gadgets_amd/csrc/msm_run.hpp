@@ -82,29 +82,33 @@ struct MsmStats {
 // sums share one launch (k_msm_fixed2).  The chunk partials are folded `MSM_REDUCE_GROUP` at a time (twice when
 // there are many) before the per-proof finish kernel, which then adds at most MSM_REDUCE_GROUP points.
 static const uint32_t MSM_REDUCE_GROUP = 16;
-#if !defined(BPR1CS_HOSTSIM)
 // one launch of the dominant kernel, HIP-event timed on its own stream when `stats` is given; `terms` = scalar*point
 // products of the launch summed over the batch (every launch of k_msm_fixed2 goes through here, so that bench.py's roofline
-// object describes the whole kernel: the commit sums, L_k / R_k of the un-folded rounds AND the folded generators)
+// object describes the whole kernel: the commit sums, L_k / R_k of the un-folded rounds AND the folded generators).
+// The simulator runs the same body lane by lane (msm_fixed2_sim).
 static void launch_msm_kernel(const bpr1cs_gens* g, MsmLaunch& L, dev_stream_t st, MsmStats* stats, uint64_t terms) {
+    L.nwg = (L.wg_end[L.njobs - 1] + 7u) & ~7u;  // a multiple of 8 keeps the XCD-aware remap on
+#if defined(BPR1CS_HOSTSIM)
+    (void)g; (void)st;
+    msm_fixed2_sim(L);
+    if (stats) { stats->launches++; stats->terms += terms; }
+#else
     hipEvent_t e0{}, e1{};
     if (stats) {
         e0 = stats->get(); e1 = stats->get();
         stats->ev.push_back({e0, e1});
         HIPCHK(hipEventRecord(e0, st));
     }
-    L.nwg = (L.wg_end[L.njobs - 1] + 7u) & ~7u;  // a multiple of 8 keeps the XCD-aware remap on
     const size_t lds = (size_t)2 * g->tc.windows * 64 * sizeof(uint16_t);
-    if (g->tc.fmt == TAB_FMT_PACKED) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_msm_fixed2<(int)TAB_FMT_PACKED, 3>), dim3(L.nwg), dim3(64), lds, st, L);
-    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_msm_fixed2<(int)TAB_FMT_LIMB, 3>), dim3(L.nwg), dim3(64), lds, st, L);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_msm_fixed2<3>), dim3(L.nwg), dim3(64), lds, st, L);
     HIPCHK(hipGetLastError());
     if (stats) {
         HIPCHK(hipEventRecord(e1, st));
         stats->launches++;
         stats->terms += terms;
     }
-}
 #endif
+}
 struct MsmReq {
     MsmSeg s0, s1;
     DevBuf<ge>* partial;  // out: the reduced partial sums sit at the front, [plan->nchunks][B]
@@ -133,17 +137,15 @@ static void run_msm_multi(const bpr1cs_gens* g, MsmReq* reqs, uint32_t nreq, uin
     const uint32_t nbk = (B + 63u) / 64u;
     struct Lay { uint32_t nchunks, l1, l2; ge* raw; ge* p1; ge* p2; };
     Lay lay[MSM_MAX_JOBS];
-#if !defined(BPR1CS_HOSTSIM)
     MsmLaunch L{};
     L.B = B; L.nbk = nbk; L.tc = g->tc;
     L.njobs = nreq;
-#endif
     uint32_t wg = 0;
     uint64_t terms = 0;
     for (uint32_t r = 0; r < nreq; r++) {
         MsmReq& q = reqs[r];
         uint32_t total = q.s0.count + q.s1.count;
-        uint32_t nchunks = pick_chunks(total, B, g_msm_target_threads.load(), q.plan->chunk);
+        uint32_t nchunks = pick_chunks(total, B, 1u << g->opts.msm_threads_log2.load(), q.plan->chunk);
         if (q.chunk_hint) {
             q.plan->chunk = q.chunk_hint;
             nchunks = total ? (total + q.chunk_hint - 1) / q.chunk_hint : 1;
@@ -161,22 +163,10 @@ static void run_msm_multi(const bpr1cs_gens* g, MsmReq* reqs, uint32_t nreq, uin
         q.plan->nchunks = l2 ? l2 : (l1 ? l1 : nchunks);
         terms += (uint64_t)total * B;
         wg += nchunks * nbk;
-#if !defined(BPR1CS_HOSTSIM)
         L.job[r] = MsmJob{{q.s0, q.s1}, q.table ? q.table : g->tab.p, lay[r].raw, q.plan->chunk, nchunks, 0};
         L.wg_end[r] = wg;
-#endif
     }
-#if defined(BPR1CS_HOSTSIM)
-    for (uint32_t r = 0; r < nreq; r++) {
-        MsmReq& q = reqs[r];
-        K_msm_fixed k{q.table ? q.table : g->tab.p, g->tc, {q.s0, q.s1}, lay[r].raw, B, q.plan->chunk, nbk, lay[r].nchunks * nbk};
-        launch_wave((uint64_t)lay[r].nchunks * nbk * 64u, k, st);
-    }
-    if (stats) { stats->launches++; stats->terms += terms; }
-    (void)wg;
-#else
     launch_msm_kernel(g, L, st, stats, terms);
-#endif
     for (uint32_t r = 0; r < nreq; r++) {
         if (lay[r].l1) launch((uint64_t)lay[r].l1 * B, K_ge_reduce{lay[r].raw, lay[r].p1, B, lay[r].nchunks, MSM_REDUCE_GROUP}, st);
         if (lay[r].l2) launch((uint64_t)lay[r].l2 * B, K_ge_reduce{lay[r].p1, lay[r].p2, B, lay[r].l1, MSM_REDUCE_GROUP}, st);

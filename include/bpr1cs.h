@@ -14,10 +14,9 @@
  * negative = bpr1cs_error (mirrors R1CSError).  No exceptions cross the ABI.
  * Threading: a handle may be used from one thread at a time; distinct handles are
  * independent (two threads may prove / verify concurrently on two bpr1cs_gens handles,
- * sharing a bpr1cs_circuit); the bpr1cs_set_* knobs only set process-wide DEFAULTS that
- * are read when a handle is created or a call starts - per-handle overrides:
- * bpr1cs_gens_set_option.  bpr1cs_last_* report the last prove job that ended on the
- * calling thread.  There is NO CPU fallback: every compute entry point fails with
+ * sharing a bpr1cs_circuit); options belong to a handle (bpr1cs_gens_create_opts,
+ * bpr1cs_gens_set_option) - the library has no process-wide settings.  bpr1cs_last_prove_stats
+ * reports the last prove call that returned on the calling thread.  There is NO CPU fallback: every compute entry point fails with
  * BPR1CS_ERR_NO_DEVICE when no gfx950 device is visible.  Device failures (HIP errors,
  * out of memory) are reported as BPR1CS_ERR_DEVICE / BPR1CS_ERR_OUT_OF_MEMORY; the
  * library never aborts the process.  All scalar inputs must be canonical (< l);
@@ -33,7 +32,10 @@
  * kernel branches on committed bits.  Results are identical; only the time and the memory traffic depend on secrets.
  * This is the usual posture of a throughput prover on a device the prover owns (nobody else can observe its caches or
  * timing); do not run it where an untrusted party shares the GPU or can time individual batches of a victim's witnesses.
- * Secrets are wiped from device memory before their blocks return to the allocator (upstream: clear_on_drop).
+ * Secrets (wires, blindings, the blinding vectors, l / r and everything derived from them: product scalars, Straus digits,
+ * partial inner products) are wiped from device memory before their blocks return to the allocator (upstream: clear_on_drop).
+ * Memory: the allocator refuses a large block that would leave less than BPR1CS_MEM_RESERVE_MB (environment, default 1024) of
+ * device memory free - the HIP runtime aborts the process when IT finds none - and reports BPR1CS_ERR_OUT_OF_MEMORY instead.
  */
 #ifndef BPR1CS_H
 #define BPR1CS_H
@@ -127,15 +129,34 @@ uint32_t bpr1cs_gens_capacity(const bpr1cs_gens* g);
 /* which: 0 = B, 1 = B_blinding, 2 = G[i], 3 = H[i]; compressed encoding */
 int bpr1cs_gens_point(const bpr1cs_gens* g, int which, uint32_t i, uint8_t out[32]);
 
-/* geometry of the handle's fixed-base tables: window bits W, windows per scalar, storage format (bpr1cs_set_table_format), bytes */
+/* geometry of the handle's fixed-base tables: window bits W, windows per scalar, storage format (always 1: 27 limbs of 29 bits
+ * in 128-byte slots), bytes */
 int bpr1cs_gens_table_info(const bpr1cs_gens* g, uint32_t* window_bits, uint32_t* windows, uint32_t* format, uint64_t* bytes);
-/* per-handle override of a per-call knob (value < 0: back to the process default set by bpr1cs_set_*) */
-#define BPR1CS_OPT_UNFOLD_ROUNDS 0 /* bpr1cs_set_unfold_rounds */
-#define BPR1CS_OPT_RNG_MODE 1      /* bpr1cs_set_rng_mode      */
-#define BPR1CS_OPT_WITNESS_TEAM 2  /* bpr1cs_set_witness_team  */
-#define BPR1CS_OPT_TAIL_ROUNDS 3   /* bpr1cs_set_tail_rounds   */
+/* ---- options of a generator handle.  Every option has a default that is the measured optimum on MI355X (what bench.py runs);
+ * value < 0 = back to that default.  No process-wide knobs exist: two threads on two handles never see each other's settings.
+ * Results (proof bytes, verdicts) never depend on an option. */
+#define BPR1CS_OPT_UNFOLD_ROUNDS 0    /* IPA rounds computed from the UN-folded generator tables before the folded generators are
+                                         materialised (default 4: measured 2 / 3 / 4 / 5 = 2420 / 2748 / 2880 / 2678 proofs/s; clamped to lg N) */
+#define BPR1CS_OPT_WITNESS_TEAM 2     /* lanes of a wavefront cooperating on one proof during witness synthesis: 4, 8 (default) or 16 */
+#define BPR1CS_OPT_TAIL_ROUNDS 3      /* how many of the LAST inner-product rounds (latency bound) a job enqueues on its own tail stream
+                                         instead of the handle's heavy stream (default 7 = the rounds with m_k <= 64; 0 = none) */
+#define BPR1CS_OPT_SHARED_BACK 4      /* 1 (default): the jobs in flight on a handle share the device scratch of their back phases */
+#define BPR1CS_OPT_FACTOR_VECTORS 5   /* measuring option: 1 = the prover writes the argument's factor vectors out as N x B arrays
+                                         (the form bpr1cs_ipa_create always uses) instead of their closed form (default 0) */
+#define BPR1CS_OPT_MSM_THREADS_LOG2 6 /* measuring option: log2 of the (chunk, proof) threads per launch of the MSM kernel (default 21) */
+#define BPR1CS_OPT_JOB_PROOFS 7       /* proofs per device job when bpr1cs_prove_batch cuts a batch into jobs (default 0 = the largest of
+                                         4096, 2048, ... 64 whose working set fits next to the tables: 2048 for N = 32768 on 288 GB) */
+#define BPR1CS_OPT_JOBS_IN_FLIGHT 8   /* device jobs bpr1cs_prove_batch keeps in flight: 1 or 2 (default 2: the latency-bound front of
+                                         job k+1 runs next to the multiscalar multiplications of job k) */
+#define BPR1CS_OPT_WINDOW_BITS 16     /* creation only: signed window width W (4..12) of the fixed-base tables.  A term costs
+                                         ceil(253/W) mixed additions; table bytes = (2+2*cap) * ceil(253/W) * (2^(W-1)+1) * 128
+                                         (W=8: 35 GB, W=11: 198 GB at capacity 32768).  Default 0 = the widest W <= 11 whose tables fit in
+                                         two thirds of the free device memory: 11 for N <= 32768 on a 288 GB device, 8 / 7 for the
+                                         reference's as-shipped tree depths (N = 131072 / 262144, gadget_vsmt_4.rs:25, gadget_vsmt_2.rs:23) */
 int bpr1cs_gens_set_option(bpr1cs_gens* g, int option, int value);
-/* hand the back-phase scratch arena of a handle (bpr1cs_set_shared_back; ~15 GB per 1024 proofs of the depth-32 circuit, kept
+/* bpr1cs_gens_create with options: `pairs` = n_pairs x (option, value).  BPR1CS_ERR_INVALID_ARGUMENT for an unknown option. */
+int bpr1cs_gens_create_opts(uint32_t gens_capacity, const int32_t* pairs, size_t n_pairs, bpr1cs_gens** out);
+/* hand the back-phase scratch arena of a handle (BPR1CS_OPT_SHARED_BACK; ~13 GB per 1024 proofs of the depth-32 circuit, kept
  * between jobs) to the allocator's cache; BPR1CS_ERR_INVALID_ARGUMENT while a job of the handle is in flight */
 int bpr1cs_gens_release_scratch(bpr1cs_gens* g);
 /* give the device memory cached by the library's allocator (freed tables, workspaces) back to the driver */
@@ -160,10 +181,22 @@ size_t bpr1cs_proof_len(const bpr1cs_circuit* c);
  *                      batch * 3 * n * 32 : a_L | a_R | a_O per proof
  *   proofs_out         batch * bpr1cs_proof_len
  *   commitments_out    batch * m * 32 (may be NULL)
- */
+ * Any batch size: the call cuts the batch into device jobs of BPR1CS_OPT_JOB_PROOFS proofs (default: what fits next to the
+ * tables) and keeps BPR1CS_OPT_JOBS_IN_FLIGHT of them in flight, so ONE call with a large batch runs the device at the rate
+ * bench.py reports; if the device runs out of memory the job size is halved and the call goes on. */
 int bpr1cs_prove_batch(const bpr1cs_gens* g, const bpr1cs_circuit* c, const uint8_t* label, size_t label_len,
                        const uint8_t* values, const uint8_t* v_blindings, const uint8_t* rng_seeds,
                        const uint8_t* wires, size_t batch, uint8_t* proofs_out, uint8_t* commitments_out);
+
+/* The same with the caller's transcripts, for Prover::new(&pc_gens, &mut transcript) on a transcript that is not fresh
+ * (reference src/gadget_vsmt_4.rs:390-391: `let mut prover_transcript = Transcript::new(b"VSMT"); Prover::new(&pc_gens,
+ * &mut prover_transcript)` - any messages appended in between are part of the state).  `transcripts`: n_transcripts = batch
+ * handles (proof i starts from transcripts[i] and leaves it in the state upstream's `&mut` transcript has when prove() returns),
+ * or n_transcripts = 1: every proof starts from a copy of transcripts[0], which is left untouched. */
+typedef struct bpr1cs_transcript bpr1cs_transcript;
+int bpr1cs_prove_batch_transcripts(const bpr1cs_gens* g, const bpr1cs_circuit* c, bpr1cs_transcript* const* transcripts, size_t n_transcripts,
+                                   const uint8_t* values, const uint8_t* v_blindings, const uint8_t* rng_seeds,
+                                   const uint8_t* wires, size_t batch, uint8_t* proofs_out, uint8_t* commitments_out);
 
 /* Asynchronous form of bpr1cs_prove_batch: `begin` uploads the inputs and enqueues the whole prove on
  * one of two per-handle HIP stream pairs and returns without waiting; `end` waits for that job and
@@ -247,7 +280,6 @@ int bpr1cs_poseidon_permutation_batch(const bpr1cs_poseidon_params* params, int 
                                       uint8_t* outputs);
 /* ---- low-level entry points for parity tests and for a Rust shim -------------------------------------------
  * merlin::Transcript (merlin 2.0: STROBE-128 over Keccak-f[1600]) exactly as the prover kernels run it; host-side. */
-typedef struct bpr1cs_transcript bpr1cs_transcript;
 bpr1cs_transcript* bpr1cs_transcript_new(const uint8_t* label, size_t label_len);                 /* Transcript::new(label)      */
 void bpr1cs_transcript_free(bpr1cs_transcript* t);
 void bpr1cs_transcript_append_message(bpr1cs_transcript* t, const uint8_t* label, size_t label_len, const uint8_t* msg, size_t msg_len);
@@ -296,90 +328,21 @@ size_t bpr1cs_proof_serialized_len(const bpr1cs_proof* p);
 /* one-phase form when A_I2 = A_O2 = S2 = identity, two-phase form otherwise (as R1CSProof::to_bytes) */
 int bpr1cs_proof_serialize(const bpr1cs_proof* p, uint8_t* out, size_t cap, size_t* len_out);
 
-/* tuning knob: IPA rounds computed from the un-folded generator tables before the
- * folded generators are materialised (default 4; clamped to lg N) */
-void bpr1cs_set_unfold_rounds(int r);
-
-/* tuning knob: how many of the LAST inner-product rounds (latency bound: a few wavefronts per proof) a prove job enqueues
- * on its own tail stream instead of the handle's shared heavy stream, so that the next job's multiscalar multiplications
- * start while this job's tail finishes (default 7 = the rounds with m_k <= 64; 0 = everything on the heavy stream;
- * never earlier than the round after the folded generators are materialised).  Results do not depend on it. */
-void bpr1cs_set_tail_rounds(int r);
-/* tuning knob, measured alternative (default 0): 1 = those rounds run as ONE kernel - every kernel of an IPA round is per
- * proof, so a wavefront per proof executes the recorded per-round steps (cross terms, Straus tables / digits, window sums,
- * Horner, compression, transcript, folds) back to back with barriers in between: ~60 launches per job become one.  Slower
- * (-4 % on the depth-32 trees, -30 % on the small circuits): the steps are between 1 and 1632 items wide per proof, so most
- * lanes idle in the narrow ones, while separate launches pack 64 proofs into every wavefront.  Same bytes either way. */
-void bpr1cs_set_tail_fused(int enable);
-
-/* tuning knob: 1 (default) = the prove jobs in flight on a handle share the device scratch of their back phases (they run one
- * after the other on the handle's heavy stream; a job waits for its predecessor's tail before its first write): a
- * 1024-proof job of the depth-32 circuit then holds ~7 GB of its own plus ~15 GB shared instead of 22 GB.  0 = every job
- * allocates its own scratch.  Results do not depend on it. */
-void bpr1cs_set_shared_back(int enable);
-
-/* measuring knob: 0 (default) = the prover describes the inner-product argument's factor vectors (G_factors = 1 / u,
- * H_factors = y^-i times the same) in closed form and every un-folded round derives its product scalars from 2^k per-proof
- * values and the power tables; 1 = it writes them out as two N x B arrays that every un-folded round reads, folds and
- * rewrites (the form bpr1cs_ipa_create, whose factors are arbitrary, always uses).  Same bytes either way. */
-void bpr1cs_set_factor_vectors(int enable);
-
-/* measuring knob: log2 of the (chunk, proof) threads a launch of the fixed-base MSM kernel is cut into (default 21: ~32 k
- * wavefronts per launch; fewer = longer chunks and a longer launch tail, more = more first-term overhead and partial sums) */
-void bpr1cs_set_msm_threads_log2(int lg);
-
-/* tuning knob, read by bpr1cs_gens_create: signed window width W (4..12) of the fixed-base tables.
- * A term costs ceil(253/W) mixed additions (the top window of a canonical scalar never carries out); table bytes =
- * (2+2*cap) * ceil(253/W) * (2^(W-1) + 1) * 96 (packed) or 128 (limb form)  (W=8: 26 / 35 GB, W=11: 148 / 198 GB at
- * capacity 32768).  Default 8; 0 = automatic (the widest W <= 11 whose packed tables fit in 55 % of the free device memory).
- * Capacity limit: W=11 serves N <= 32768 on a 288 GB device; the reference's as-shipped
- * tree depths (N = 131072 / 262144, gadget_vsmt_4.rs:25, gadget_vsmt_2.rs:23) need W <= 8. */
-void bpr1cs_set_window_bits(int w);
-
-/* tuning knob, read by bpr1cs_gens_create: storage format of the fixed-base tables.  0 = packed (96 B per entry, unpacked
- * on load), 1 = limb form in 128-byte slots (no unpacking, one aligned slot per gather; a third more HBM), -1 (default) =
- * limb form when the device keeps >= 100 GB free after the tables, packed otherwise.  Results do not depend on it. */
-void bpr1cs_set_table_format(int fmt);
-
-/* tuning knob: lanes of a wavefront cooperating on one proof during witness synthesis (4, 8 or 16).
- * Fewer lanes = fewer wavefronts (less interference with a co-running batch), longer LC evaluation. */
-void bpr1cs_set_witness_team(int t);
-
-/* tuning knob: how the sequential TranscriptRng chain of a proof (one Keccak-f[1600] per blinding draw) is mapped.
- * 1 = one state over 25 lanes of a wavefront, cross-lane exchange through LDS (lowest latency);
- * 2 = one state per thread (fewest instructions, but its pure-VALU wavefronts only pay off on SIMDs of their own,
- *     see bpr1cs_set_latency_cus);
- * 3 = one state per wavefront on the SCALAR unit (all lanes in SGPRs, s_xor_b64 / s_andn2_b64 ...): no VALU issue
- *     slots, but 3.7x the latency of 1 (a wavefront issues one scalar instruction per ~9 cycles) - kept as a
- *     measured alternative, never chosen automatically;
- * 4 = one state per wavefront, lane = 8y + x, theta by DPP row shifts and the gfx950 v_permlane16/32_swap row
- *     all-reduce, pi/chi by ds_bpermute: no LDS memory or barriers, but more VALU instructions - 8 % slower than 1;
- * 5 = one ROW of the state per lane, eight proofs per wavefront: column parities by a DPP all-reduce inside 8-lane groups, one
- *     LDS transpose per round (pi), chi inside the lane - 2.5x fewer instructions per draw than 1, but 1.5x its latency
- *     (246 vs 160 ms per 1024-proof batch) and 5 % slower end to end with two batches in flight: measured alternative;
- * 0 = automatic: 1 (2 if CUs are reserved for it and another batch is in flight). */
-void bpr1cs_set_rng_mode(int mode);
-
-/* test knob, read by bpr1cs_circuit_create: 0 = ignore the Poseidon annotations of a circuit description and run
- * its witness program op by op (one inversion per S-box); default 1. */
-void bpr1cs_set_witness_macro(int enable);
-/* diagnostic: number of Poseidon permutations of this circuit's witness program that are evaluated jointly */
+/* diagnostic: number of Poseidon permutations of this circuit's witness program that are evaluated jointly
+ * (test knob, environment: BPR1CS_WITNESS_MACRO=0 makes bpr1cs_circuit_create ignore the annotations) */
 int bpr1cs_circuit_macro_perms(const bpr1cs_circuit* c);
 
-/* experimental knob, read by bpr1cs_gens_create: reserve n compute units (HIP CU masks) for the per-thread
- * TranscriptRng chain (rng mode 2) and mask every other stream off them; rng mode 0 then picks mode 2 while another
- * batch is in flight.  Default 0 = off: on ROCm 7.2 / MI355X CU-masked streams cost far more than they save
- * (measured 1270 -> 830 proofs/s synchronous), see DESIGN.md. */
-void bpr1cs_set_latency_cus(int n);
-
-/* phase timings in milliseconds (HIP events) of the last prove job that ended on the calling thread, for bench.py:
- * [0]=total [1]=inputs+V commitments [2]=RNG stream || witness synthesis [3]=commit MSMs [4]=polys [5]=IPA; returns count */
-int bpr1cs_last_timings(float* out, int cap);
-
-/* HIP-event statistics of the dominant kernel (batched fixed-base MSM) over the last prove job that ended on this thread:
- * summed launch durations (ms, events recorded on the kernel's own stream), number of launches and
- * number of scalar*point terms processed (summed over the batch). */
-int bpr1cs_last_msm_stats(double* ms_total, uint64_t* launches, uint64_t* terms);
+/* Statistics of the last bpr1cs_prove_batch / bpr1cs_prove_batch_end that returned on the calling thread (HIP events), summed over the
+ * device jobs of the call, for bench.py's roofline object. */
+typedef struct {
+    uint32_t jobs;          /* device jobs the call was cut into */
+    uint32_t job_proofs;    /* proofs of the largest job */
+    float phase_ms[6];      /* [0]=total [1]=inputs+V commitments [2]=RNG stream || witness synthesis [3]=commit MSMs [4]=polys [5]=IPA */
+    double msm_ms;          /* summed launch durations of the dominant kernel (k_msm_fixed2), events recorded on its own stream */
+    uint64_t msm_launches;
+    uint64_t msm_terms;     /* scalar*point terms it processed, summed over the batch */
+} bpr1cs_prove_stats;
+int bpr1cs_last_prove_stats(bpr1cs_prove_stats* out);
 
 /* diagnostic: sustained rates of the device (each probe runs for about `seconds_each`, long enough for the clock to settle
  * to its power budget): lane-operations per second of v_mad_i64_i32 with every SIMD busy, and table additions (ge_madd_t

@@ -69,7 +69,7 @@ def circuit_from_oracle(ob, lib):
 def check_against_oracle(lib, scenario_fn, cap, batch, unfold, gens=None):
     ob = oracle_batch(scenario_fn, cap, batch)
     g = gens or bp.Gens(cap, lib=lib)
-    lib.bpr1cs_set_unfold_rounds(unfold)
+    g.set_option("unfold", unfold)
     circ = circuit_from_oracle(ob, lib)
     P, C = bp.prove_batch(g, circ, ob["label"], ob["values"], ob["blindings"], ob["seeds"], batch, wires=ob["wires"])
     for j in range(batch):

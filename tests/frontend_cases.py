@@ -116,9 +116,9 @@ def _tree2(depth, pr, sbox=g.INVERSE):
     return _T[k]
 
 
-def check_compiled(lib, glib, name, batch, unfold=4, gens_cache={}):
+def check_compiled(lib, glib, name, batch, unfold=4, gens_cache={}, **opts):
     """compile the gadget with the C++ front-end, prove a batch with the DEVICE witness program,
-    compare proof bytes with the oracle (which synthesises on its own)."""
+    compare proof bytes with the oracle (which synthesises on its own).  opts: options of the generator handle for this call."""
     gname, ip, sp, _, cap = case(name, 0)
     ob = common.oracle_batch(lambda j: case(name, j)[3], cap, batch, satisfiable=not (name.endswith("pr1_zero") or name.endswith("_violated")), key=name)
     circ = bp.CompiledGadget(gname, ip, sp, lib=lib, glib=glib)
@@ -127,8 +127,15 @@ def check_compiled(lib, glib, name, batch, unfold=4, gens_cache={}):
     key = (id(lib), cap)
     if key not in gens_cache:
         gens_cache[key] = bp.Gens(cap, lib=lib)
-    lib.bpr1cs_set_unfold_rounds(unfold)
-    P, C = bp.prove_batch(gens_cache[key], circ, ob["label"], ob["values"], ob["blindings"], ob["seeds"], batch, wires=None)
+    gens = gens_cache[key]
+    opts = dict(opts, unfold=unfold)
+    try:
+        for k, v in opts.items():
+            gens.set_option(k, v)
+        P, C = bp.prove_batch(gens, circ, ob["label"], ob["values"], ob["blindings"], ob["seeds"], batch, wires=None)
+    finally:
+        for k in opts:
+            gens.set_option(k, -1)
     for j in range(batch):
         assert P[j] == ob["proofs"][j], "proof %d differs (%s)" % (j, name)
     return ob, P, C
@@ -136,19 +143,20 @@ def check_compiled(lib, glib, name, batch, unfold=4, gens_cache={}):
 
 def check_macro_vs_plain(lib, glib, name, batch):
     gname, ip, sp, _, cap = case(name, 0)
-    try:
-        lib.bpr1cs_set_witness_macro(1)
+    import os
+    try:   # the test knob of bpr1cs_circuit_create: BPR1CS_WITNESS_MACRO=0 ignores the Poseidon annotations
+        os.environ.pop("BPR1CS_WITNESS_MACRO", None)
         circ = bp.CompiledGadget(gname, ip, sp, lib=lib, glib=glib)
         assert lib.bpr1cs_circuit_macro_perms(circ.h) >= 1
         circ.close()
         check_compiled(lib, glib, name, batch)
-        lib.bpr1cs_set_witness_macro(0)
+        os.environ["BPR1CS_WITNESS_MACRO"] = "0"
         circ = bp.CompiledGadget(gname, ip, sp, lib=lib, glib=glib)
         assert lib.bpr1cs_circuit_macro_perms(circ.h) == 0
         circ.close()
         check_compiled(lib, glib, name, batch)
     finally:
-        lib.bpr1cs_set_witness_macro(1)
+        os.environ.pop("BPR1CS_WITNESS_MACRO", None)
 
 
 def check_prove_single(glib, name):

@@ -19,11 +19,10 @@ def make_batch(lib, glib, batch, first=0, cap=16):
     subject of the other tests): -> (gens, circuit, label, proofs, commitments)"""
     from pyref.ed import sc_to_bytes
     circ = bp.CompiledGadget("bound_check", [7, 10, 0, 100, 0], [], lib=lib, glib=glib)
-    gens = bp.Gens(cap, lib=lib)
+    gens = bp.Gens(cap, lib=lib, unfold=2)
     vals = b"".join(sc_to_bytes(x) for j in range(first, first + batch) for x in (37 + j, 27 + j, 63 - j))
     bls = b"".join(sc_to_bytes(S.synth_scalar(b"bvb%d" % j, i)) for j in range(first, first + batch) for i in range(3))
     seeds = b"".join(S.synth_seed(j) for j in range(first, first + batch))
-    lib.bpr1cs_set_unfold_rounds(2)
     P, C = bp.prove_batch(gens, circ, b"BoundsTest", vals, bls, seeds, batch, wires=None)
     return gens, circ, b"BoundsTest", P, C
 

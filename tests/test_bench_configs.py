@@ -18,8 +18,10 @@ def test_config_table_matches_baseline():
     assert "4096" in base["configs"][1] and "1024" in base["configs"][2] and "8192" in base["configs"][3] and "65536" in base["configs"][4]
     assert bench.CONFIGS["c4"]["metric"] is None   # the headline metric string is built from --depth: BASELINE's "Poseidon VSMT-4 depth-32"
     assert "VSMT-4 depth-32" in base["metric"]
+    fx = json.load(open(os.path.join(ROOT, "tests", "golden", "fullsize_digests.json")))
     for c in bench.CONFIGS.values():
-        assert c["fuse"] >= 1 and c["cpu_proofs"] >= 1 and callable(c["build"])
+        assert c["cpu_proofs"] >= 1 and callable(c["build"]) and c["short"][1] >= 1
+        assert c["fixture"] in fx      # every configuration of the `configs` block has its parity fixture
 
 
 def test_workloads_are_the_ones_the_digest_fixture_pins():

@@ -69,18 +69,9 @@ def test_compiled_tree_gadgets_with_the_cube_sbox(sim_lib, sim_glib, case):
 def test_job_memory_knobs_do_not_change_a_byte(sim_lib, sim_glib):
     """N = 512 (9 IPA rounds, folded generators at round 4, tail hand-off at round 6): private scratch instead of the shared
     back-phase arena, no tail hand-off, a different hand-off round - the oracle's proof bytes every time"""
-    try:
-        for shared, tail in ((0, 7), (1, 0), (1, 3), (0, 0)):
-            sim_lib.bpr1cs_set_shared_back(shared)
-            sim_lib.bpr1cs_set_tail_rounds(tail)
-            fc.check_compiled(sim_lib, sim_glib, "vsmt_2_cube", batch=2)
-        sim_lib.bpr1cs_set_factor_vectors(1)   # the argument's factor vectors written out instead of their closed form
-        for unfold in (4, 0, 9):
-            fc.check_compiled(sim_lib, sim_glib, "vsmt_2_cube", batch=2, unfold=unfold)
-        sim_lib.bpr1cs_set_factor_vectors(0)
-        for unfold in (0, 1, 9):               # closed form: no un-folded round / one / every round from the tables
-            fc.check_compiled(sim_lib, sim_glib, "vsmt_2_cube", batch=2, unfold=unfold)
-    finally:
-        sim_lib.bpr1cs_set_factor_vectors(0)
-        sim_lib.bpr1cs_set_shared_back(1)
-        sim_lib.bpr1cs_set_tail_rounds(7)
+    for shared, tail in ((0, 7), (1, 0), (1, 3), (0, 0)):
+        fc.check_compiled(sim_lib, sim_glib, "vsmt_2_cube", batch=2, shared_back=shared, tail_rounds=tail)
+    for unfold in (4, 0, 9):   # the argument's factor vectors written out instead of their closed form
+        fc.check_compiled(sim_lib, sim_glib, "vsmt_2_cube", batch=2, unfold=unfold, factor_vectors=1)
+    for unfold in (0, 1, 9):   # closed form: no un-folded round / one / every round from the tables
+        fc.check_compiled(sim_lib, sim_glib, "vsmt_2_cube", batch=2, unfold=unfold)

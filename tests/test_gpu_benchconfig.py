@@ -15,15 +15,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.fixture(scope="module")
 def w11_gens(hip_lib):
-    """32768-capacity generators with W = 11 tables exactly as bench.py creates them (format chosen automatically)."""
+    """32768-capacity generators exactly as bench.py and any plain caller get them: bpr1cs_gens_create with no options picks
+    W = 11 from the free memory of the device."""
     bp = importlib.import_module("bulletproofs-r1cs-gadgets_amd")
     bp.release_cached_memory(hip_lib)
-    hip_lib.bpr1cs_set_window_bits(11)
-    hip_lib.bpr1cs_set_table_format(-1)
-    try:
-        gens = bp.Gens(32768, lib=hip_lib)
-    finally:
-        hip_lib.bpr1cs_set_window_bits(8)
+    gens = bp.Gens(32768, lib=hip_lib)
     info = gens.table_info()
     assert info["window_bits"] == 11 and info["windows"] == 23
     yield gens
@@ -43,7 +39,6 @@ def test_vsmt4_depth32_bench_configuration_two_jobs_in_flight(hip_lib, hip_glib,
     circ = bp.CompiledGadget("vsmt_4", case["ip"], case["sp"], lib=hip_lib, glib=hip_glib)
     assert (circ.n, circ.q, circ.m, circ.proof_len) == (18656, 43330, 100, 1377) and circ.has_witness_program
     assert hip_lib.bpr1cs_circuit_macro_perms(circ.h) == 32
-    hip_lib.bpr1cs_set_unfold_rounds(4)
     cut = BA * m * 32
     jobA = bp.ProveJob(w11_gens, circ, b"VSMT", values[:cut], blindings[:cut], seeds[:32 * BA], BA)
     jobB = bp.ProveJob(w11_gens, circ, b"VSMT", values[cut:], blindings[cut:], seeds[32 * BA:], BB)   # begins while A is in flight
@@ -53,15 +48,28 @@ def test_vsmt4_depth32_bench_configuration_two_jobs_in_flight(hip_lib, hip_glib,
     assert bp.verify_batch(w11_gens, circ, b"VSMT", PB, CB, BB) == [True] * BB
     pt, wf = bp.verify_batch_combined(w11_gens, circ, b"VSMT", PA, CA, BA)
     assert wf and pt == bytes(32)
-    # ONE device job of 2024 proofs (bench.py --fuse 2 hands two steps to the device at once), the last IPA rounds on the
-    # heavy stream instead of the job's tail stream: the same bytes
-    hip_lib.bpr1cs_set_tail_rounds(0)
+    # ONE call over all 2024 proofs, as bench.py makes it: the library cuts the batch into device jobs by itself (2048 proofs fit
+    # next to the tables: one job here), the last IPA rounds on the heavy stream instead of the job's tail stream: the same bytes
     w11_gens.release_scratch()   # the arena is sized for 1024-proof jobs: growing it next to 234 GB of tables would hold both sizes for a moment
+    w11_gens.set_option("tail_rounds", 0)
     try:
         P2, C2 = bp.prove_batch(w11_gens, circ, b"VSMT", values, blindings, seeds, BA + BB)
     finally:
-        hip_lib.bpr1cs_set_tail_rounds(7)
+        w11_gens.set_option("tail_rounds", -1)
     assert P2 == PA + PB and C2 == CA + CB
+    st = bp.last_prove_stats(hip_lib)
+    assert st["jobs"] == 1 and st["job_proofs"] == 2024 and st["msm_launches"] == 7
+    # ... and cut into FOUR jobs (512, 512, 500, 500 proofs), two in flight (what a larger batch or a smaller device gets): the same bytes
+    w11_gens.release_scratch()
+    w11_gens.set_option("job_proofs", 512)
+    try:
+        P3, C3 = bp.prove_batch(w11_gens, circ, b"VSMT", values, blindings, seeds, BA + BB)
+    finally:
+        w11_gens.set_option("job_proofs", -1)
+    assert P3 == PA + PB and C3 == CA + CB
+    st = bp.last_prove_stats(hip_lib)
+    assert st["jobs"] == 4 and st["job_proofs"] == 512 and st["msm_launches"] == 28
+    w11_gens.release_scratch()
 
 
 def test_vsmt4_8_levels_w11_every_proof_of_a_ragged_batch(hip_lib, hip_glib):
@@ -74,22 +82,18 @@ def test_vsmt4_8_levels_w11_every_proof_of_a_ragged_batch(hip_lib, hip_glib):
     circ = bp.CompiledGadget("vsmt_4", case["ip"], case["sp"], lib=hip_lib, glib=hip_glib)
     assert circ.n == 583 * 8
     bp.release_cached_memory(hip_lib)
-    hip_lib.bpr1cs_set_window_bits(11)
-    try:
-        gens = bp.Gens(8192, lib=hip_lib)
-    finally:
-        hip_lib.bpr1cs_set_window_bits(8)
-    hip_lib.bpr1cs_set_unfold_rounds(4)
+    gens = bp.Gens(8192, lib=hip_lib, window_bits=11)
     P, C = bp.prove_batch(gens, circ, b"VSMT", case["values"], case["blindings"], case["seeds"], B)
     fc.check_digests("vsmt4_l8_x70", case, P, C)
     assert bp.verify_batch(gens, circ, b"VSMT", P, C, B) == [True] * B
-    # the measured alternative for the IPA tail (one kernel, a wavefront per proof runs the recorded steps): the same bytes
-    hip_lib.bpr1cs_set_tail_fused(1)
-    try:
-        P1, C1 = bp.prove_batch(gens, circ, b"VSMT", case["values"], case["blindings"], case["seeds"], B)
-    finally:
-        hip_lib.bpr1cs_set_tail_fused(0)
+    # every proof from its caller's own transcript (bpr1cs_prove_batch_transcripts, Prover::new(&pc_gens, &mut transcript)): the same
+    # bytes when the transcripts are fresh Transcript::new(b"VSMT"), and every transcript advances
+    ts = [bp.Transcript(b"VSMT", lib=hip_lib) for _ in range(B)]
+    P1, C1 = bp.prove_batch_transcripts(gens, circ, ts, case["values"], case["blindings"], case["seeds"], B)
     assert P1 == P and C1 == C
+    fresh = bp.Transcript(b"VSMT", lib=hip_lib).challenge_bytes(b"probe", 32)
+    after = [t.challenge_bytes(b"probe", 32) for t in ts]
+    assert len(set(after)) == B and fresh not in after
     gens.close()
 
 
@@ -103,7 +107,6 @@ def test_vsmt2_depth32_batch_1024_config_c3(hip_lib, hip_glib, w11_gens):
     B = case["B"]
     circ = bp.CompiledGadget("vsmt_2", case["ip"], case["sp"], lib=hip_lib, glib=hip_glib)
     assert (circ.n, circ.q, circ.m) == (18176, 42369, 69)
-    hip_lib.bpr1cs_set_unfold_rounds(4)
     P, C = bp.prove_batch(w11_gens, circ, b"VSMT", case["values"], case["blindings"], case["seeds"], B)
     fc.check_digests("c3_vsmt2_d32_x1024", case, P, C)
     assert bp.verify_batch(w11_gens, circ, b"VSMT", P, C, B) == [True] * B
@@ -125,9 +128,7 @@ def test_mimc_set_membership_batch_8192_config_c5(hip_lib, hip_glib):
     B, rounds = case["B"], fc.MIMC_ROUNDS
     circ = bp.CompiledGadget("mimc_set_membership", case["ip"], case["sp"], lib=hip_lib, glib=hip_glib)
     assert (circ.n, circ.q, circ.m) == (2 * rounds + 3 * len(fc.SET), 2 * 2 * rounds + 1 + 7 * len(fc.SET) + 2, 2 + len(fc.SET) + 1)
-    hip_lib.bpr1cs_set_window_bits(8)
-    hip_lib.bpr1cs_set_unfold_rounds(4)
-    gens = bp.Gens(1024, lib=hip_lib)
+    gens = bp.Gens(1024, lib=hip_lib, window_bits=8)
     P, C = bp.prove_batch(gens, circ, case["label"], case["values"], case["blindings"], case["seeds"], B)
     fc.check_digests("c5_mimc_set_x8192", case, P, C)
     pt, wf = bp.verify_batch_combined(gens, circ, b"MiMC+SetMembership", P, C, B)
@@ -156,16 +157,10 @@ def test_vsmt4_as_shipped_depth_128(hip_lib, hip_glib):
     circ = bp.CompiledGadget("vsmt_4", case["ip"], case["sp"], lib=hip_lib, glib=hip_glib)
     assert circ.n == 583 * 128 and circ.has_witness_program
     bp.release_cached_memory(hip_lib)
-    hip_lib.bpr1cs_set_window_bits(0)
-    hip_lib.bpr1cs_set_table_format(-1)
-    try:
-        gens = bp.Gens(131072, lib=hip_lib)
-    finally:
-        hip_lib.bpr1cs_set_window_bits(8)
+    gens = bp.Gens(131072, lib=hip_lib)
     try:
         info = gens.table_info()
         assert info["window_bits"] < 11 and info["bytes"] < 250e9, info
-        hip_lib.bpr1cs_set_unfold_rounds(4)
         P, C = bp.prove_batch(gens, circ, b"VSMT", case["values"], case["blindings"], case["seeds"], B)
         assert len(P[0]) == 1 + 32 * (13 + 2 * 17)
         fc.check_digests("vsmt4_d128_x70", case, P, C)
@@ -190,16 +185,10 @@ def test_vsmt2_as_shipped_depth_253(hip_lib, hip_glib):
     circ = bp.CompiledGadget("vsmt_2", case["ip"], case["sp"], lib=hip_lib, glib=hip_glib)
     assert (circ.n, circ.m) == (568 * depth, 2 * depth + 5)
     bp.release_cached_memory(hip_lib)
-    hip_lib.bpr1cs_set_window_bits(0)
-    hip_lib.bpr1cs_set_table_format(-1)
-    try:
-        gens = bp.Gens(262144, lib=hip_lib)
-    finally:
-        hip_lib.bpr1cs_set_window_bits(8)
+    gens = bp.Gens(262144, lib=hip_lib)
     try:
         info = gens.table_info()
         assert info["window_bits"] < 11 and info["bytes"] < 260e9, info
-        hip_lib.bpr1cs_set_unfold_rounds(4)
         P, C = bp.prove_batch(gens, circ, b"VSMT", case["values"], case["blindings"], case["seeds"], B)
         assert len(P[0]) == 1 + 32 * (13 + 2 * 18)
         fc.check_digests("vsmt2_d253_x66", case, P, C)

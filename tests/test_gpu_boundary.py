@@ -36,11 +36,8 @@ def test_out_of_memory_is_an_error_code_not_an_abort(hip_lib):
     BPR1CS_ERR_OUT_OF_MEMORY; the process and the device stay usable."""
     import ctypes
     bp = bc.bp
-    hip_lib.bpr1cs_set_window_bits(11)
-    try:
-        h = ctypes.c_void_p()
-        assert hip_lib.bpr1cs_gens_create(1 << 22, ctypes.byref(h)) == -19
-    finally:
-        hip_lib.bpr1cs_set_window_bits(8)
+    h = ctypes.c_void_p()
+    opts = (ctypes.c_int32 * 2)(bp.OPT_WINDOW_BITS, 11)
+    assert hip_lib.bpr1cs_gens_create_opts(1 << 22, opts, 1, ctypes.byref(h)) == -19
     g = bp.Gens(16, lib=hip_lib)   # still works
     assert len(g.point(2, 3)) == 32

@@ -98,7 +98,6 @@ def test_zero_sbox_input_inside_a_full_wavefront_batch(hip_lib, hip_glib):
     seeds = [S.synth_seed(7 * 10**6 + j) for j in range(B)]
     circ = bp.CompiledGadget("poseidon_hash_2", [1, pr], [out], lib=hip_lib, glib=hip_glib)
     assert circ.n == 147 and hip_lib.bpr1cs_circuit_macro_perms(circ.h) == 1
-    hip_lib.bpr1cs_set_unfold_rounds(4)
     gens = bp.Gens(256, lib=hip_lib)
     P, C = bp.prove_batch(gens, circ, b"Poseidon_hash_2", b"".join(vals), b"".join(bls), b"".join(seeds), B)
     for j in range(B):

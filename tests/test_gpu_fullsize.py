@@ -19,12 +19,7 @@ def test_vsmt4_depth32_ragged_batch(hip_lib, hip_glib):
     root, values, blindings, seeds, m = case["sp"][0], case["values"], case["blindings"], case["seeds"], case["m"]
     circ = bp.CompiledGadget("vsmt_4", [levels, 140], [root], lib=hip_lib, glib=hip_glib)
     assert (circ.n, circ.q, circ.m, circ.proof_len) == (18656, 43330, 100, 1377)
-    hip_lib.bpr1cs_set_window_bits(8)
-    hip_lib.bpr1cs_set_unfold_rounds(5)
-    try:
-        gens = bp.Gens(32768, lib=hip_lib)
-    finally:
-        hip_lib.bpr1cs_set_window_bits(8)
+    gens = bp.Gens(32768, lib=hip_lib, window_bits=8, unfold=5)
     P, C = bp.prove_batch(gens, circ, b"VSMT", values, blindings, seeds, B)
     fc.check_digests("c4_vsmt4_d32_x2024", case, P, first=B)   # W = 8 tables, IPA switch round 5: the same bytes as the W = 11 / round 4 run
     assert bp.verify_batch(gens, circ, b"VSMT", P, C, B) == [True] * B
@@ -41,9 +36,8 @@ def test_vsmt4_depth32_ragged_batch(hip_lib, hip_glib):
     circ2 = bp.CompiledGadget("vsmt_4", [levels, 140], [wrong_root], lib=hip_lib, glib=hip_glib)
     assert bp.verify_batch(gens, circ2, b"VSMT", P[:4], C[:4], 4) == [False] * 4
     # a different proving configuration (all IPA rounds from un-folded tables vs early fold) gives the same bytes
-    hip_lib.bpr1cs_set_unfold_rounds(2)
+    gens.set_option("unfold", 2)
     P2, _ = bp.prove_batch(gens, circ, b"VSMT", values[:3 * m * 32], blindings[:3 * m * 32], seeds[:96], 3)
-    hip_lib.bpr1cs_set_unfold_rounds(5)
     assert P2 == P[:3]
 
 
@@ -71,20 +65,18 @@ def test_vsmt2_depth32_config_c3(hip_lib, hip_glib):
         bl += b"".join(sc(bench.synth_scalar(b"bl2", k * 1024 + t)) for t in range(m - 4)) + bytes(128)  # statics: blinding 0
     seeds = b"".join(bytes([k + 1]) * 32 for k in range(B))
     root = tree.root()
-    hip_lib.bpr1cs_set_window_bits(8)
-    gens = bp.Gens(32768, lib=hip_lib)
+    gens = bp.Gens(32768, lib=hip_lib, window_bits=8)
     out = {}
     try:
         for macro, unfold in ((1, 4), (0, 2)):
-            hip_lib.bpr1cs_set_witness_macro(macro)
-            hip_lib.bpr1cs_set_unfold_rounds(unfold)
+            os.environ["BPR1CS_WITNESS_MACRO"] = str(macro)   # test knob of bpr1cs_circuit_create
+            gens.set_option("unfold", unfold)
             circ = bp.CompiledGadget("vsmt_2", [depth, 140], [root], lib=hip_lib, glib=hip_glib)
             assert (circ.n, circ.q, circ.m) == (18176, 42369, 69)
             assert (hip_lib.bpr1cs_circuit_macro_perms(circ.h) > 0) == bool(macro)
             out[macro] = bp.prove_batch(gens, circ, b"VSMT", values, bl, seeds, B)
     finally:
-        hip_lib.bpr1cs_set_witness_macro(1)
-        hip_lib.bpr1cs_set_unfold_rounds(4)
+        os.environ.pop("BPR1CS_WITNESS_MACRO", None)
     P, C = out[1]
     assert out[0][0] == P and out[0][1] == C
     assert bp.verify_batch(gens, circ, b"VSMT", P, C, B) == [True] * B
@@ -104,9 +96,7 @@ def test_poseidon_2to1_cube_batch_4096_config_c2(hip_lib, hip_glib):
     B, label = case["B"], case["label"]
     circ = bp.CompiledGadget("poseidon_hash_2", case["ip"], case["sp"], lib=hip_lib, glib=hip_glib)
     assert (circ.n, circ.m) == (376, 6)
-    hip_lib.bpr1cs_set_window_bits(8)
-    hip_lib.bpr1cs_set_unfold_rounds(4)
-    gens = bp.Gens(512, lib=hip_lib)
+    gens = bp.Gens(512, lib=hip_lib, window_bits=8)
     P, C = bp.prove_batch(gens, circ, label, case["values"], case["blindings"], case["seeds"], B)
     fc.check_digests("c2_poseidon2_cube_x4096", case, P, C)
     assert bp.verify_batch(gens, circ, label, P, C, B) == [True] * B

@@ -20,7 +20,7 @@ def test_gpu_reproduces_golden(hip_lib, hip_glib, name):
     assert (circ.n, circ.q, circ.m) == (gd["n"], gd["q"], gd["m"])
     gens = bp.Gens(gd["capacity"], lib=hip_lib)
     for unfold in (4, 1):
-        hip_lib.bpr1cs_set_unfold_rounds(unfold)
+        gens.set_option("unfold", unfold)
         P, C = bp.prove_batch(gens, circ, gd["label"].encode(), bytes.fromhex(gd["values"]), bytes.fromhex(gd["blindings"]),
                               bytes.fromhex(gd["seeds"]), 2, wires=None)
         assert [p.hex() for p in P] == gd["proofs"]

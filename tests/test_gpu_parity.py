@@ -59,25 +59,20 @@ def test_poseidon_hash_2_cube(hip_lib):
     common.check_against_oracle(hip_lib, lambda j: S.poseidon_hash_2(S.synth_scalar(b"xl", j), S.synth_scalar(b"xr", j), g.CUBE), 512, 2, 4)
 
 
-@pytest.mark.parametrize("mode", [1, 2, 3, 4, 5])
-def test_rng_chain_mappings_agree(hip_lib, mode):
-    """TranscriptRng chain: one Keccak state over 25 lanes (k_rng_stream), one state per thread (k_rng_thread) and one
-    state per wavefront on the scalar unit (k_rng_scalar) must all reproduce the oracle's blinding factors, i.e. its proof bytes; ragged batch (not a multiple of 64)."""
-    try:
-        hip_lib.bpr1cs_set_rng_mode(mode)
-        common.check_against_oracle(hip_lib, lambda j: S.bound_check(37 + j, 10, 100, 7), 16, 3, 2)
-        common.check_against_oracle(hip_lib, lambda j: S.set_membership([2, 3, 5, 6, 8, 20, 25][j % 7], [2, 3, 5, 6, 8, 20, 25]), 32, 2, 2)
-    finally:
-        hip_lib.bpr1cs_set_rng_mode(0)
+@pytest.mark.gpu
+def test_rng_chain_matches_oracle(hip_lib):
+    """TranscriptRng chain: one Keccak state over 25 lanes, theta through LDS atomics (k_rng_stream) must reproduce the oracle's
+    blinding factors, i.e. its proof bytes - the per-compiler gate of the kernel's LDS hand-offs; ragged batches (odd, not a multiple of 64)."""
+    common.check_against_oracle(hip_lib, lambda j: S.bound_check(37 + j, 10, 100, 7), 16, 3, 2)
+    common.check_against_oracle(hip_lib, lambda j: S.set_membership([2, 3, 5, 6, 8, 20, 25][j % 7], [2, 3, 5, 6, 8, 20, 25]), 32, 2, 2)
 
 
 def test_two_batches_in_flight_on_device(hip_lib):
     """bpr1cs_prove_batch_begin x2 before _end: the second job's front runs next to the first one's back; ragged batch sizes; proofs equal the oracle's."""
     bp = common.bp
     ob = common.oracle_batch(lambda j: S.bound_check(37 + j, 10, 100, 7), 16, 3)
-    gens = bp.Gens(16, lib=hip_lib)
+    gens = bp.Gens(16, lib=hip_lib, unfold=2)
     circ = common.circuit_from_oracle(ob, hip_lib)
-    hip_lib.bpr1cs_set_unfold_rounds(2)
     n32 = lambda x, k: x[:32 * circ.m * k]
     j1 = bp.ProveJob(gens, circ, ob["label"], ob["values"], ob["blindings"], ob["seeds"], 3, wires=ob["wires"])
     j2 = bp.ProveJob(gens, circ, ob["label"], n32(ob["values"], 2), n32(ob["blindings"], 2), ob["seeds"][:64], 2,

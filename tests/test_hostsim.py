@@ -16,13 +16,10 @@ def test_pipeline_varbase_rounds(sim_lib):
     bp = common.bp
     g = bp.Gens(16, lib=sim_lib)
     circ = common.circuit_from_oracle(ob, sim_lib)
-    try:
-        for unfold in (1, 0, 3):
-            sim_lib.bpr1cs_set_unfold_rounds(unfold)
-            P, _ = bp.prove_batch(g, circ, ob["label"], ob["values"], ob["blindings"], ob["seeds"], 2, wires=ob["wires"])
-            assert P == ob["proofs"], "unfold=%d" % unfold
-    finally:
-        sim_lib.bpr1cs_set_unfold_rounds(4)
+    for unfold in (1, 0, 3):
+        g.set_option("unfold", unfold)
+        P, _ = bp.prove_batch(g, circ, ob["label"], ob["values"], ob["blindings"], ob["seeds"], 2, wires=ob["wires"])
+        assert P == ob["proofs"], "unfold=%d" % unfold
 
 
 def test_pipeline_factors(sim_lib):
@@ -30,27 +27,24 @@ def test_pipeline_factors(sim_lib):
 
 
 def test_pipeline_other_window_widths(sim_lib):
-    """fixed-base tables with 5-, 10- and 11-bit signed windows (11: 23 windows, the top one keeps its digit), packed and
-    limb-form storage, give the same proofs"""
-    try:
-        for w, fmt in ((5, 0), (10, 0), (11, 0), (11, 1), (4, 1)):
-            sim_lib.bpr1cs_set_window_bits(w)
-            sim_lib.bpr1cs_set_table_format(fmt)
-            g = common.bp.Gens(16, lib=sim_lib)
-            info = g.table_info()
-            assert (info["window_bits"], info["format"], info["windows"]) == (w, fmt, -(-253 // w))
-            common.check_against_oracle(sim_lib, lambda j: S.bound_check(39 + j, 10, 100, 7), 16, 2, 2, gens=g)
-    finally:
-        sim_lib.bpr1cs_set_window_bits(8)
-        sim_lib.bpr1cs_set_table_format(-1)
+    """fixed-base tables with 4-, 5-, 10- and 11-bit signed windows (11: 23 windows, the top one keeps its digit) give the same proofs"""
+    for w in (5, 10, 11, 4):
+        g = common.bp.Gens(16, lib=sim_lib, window_bits=w)
+        info = g.table_info()
+        assert (info["window_bits"], info["windows"]) == (w, -(-253 // w))
+        common.check_against_oracle(sim_lib, lambda j: S.bound_check(39 + j, 10, 100, 7), 16, 2, 2, gens=g)
+    import pytest
+    with pytest.raises(common.bp.R1CSError):   # a creation-only option cannot be changed afterwards, an unknown one is refused
+        g.set_option("window_bits", 8)
+    with pytest.raises(common.bp.R1CSError):
+        g.set_option(99, 1)
 
 
 def test_two_jobs_in_flight(sim_lib):
     """bpr1cs_prove_batch_begin x2 before _end: results independent of the interleaving"""
     ob1 = common.oracle_batch(lambda j: S.bound_check(37 + j, 10, 100, 7), 16, 2)
     ob2 = common.oracle_batch(lambda j: S.bound_check(50 + j, 10, 100, 7), 16, 3)
-    gens = common.bp.Gens(16, lib=sim_lib)
-    sim_lib.bpr1cs_set_unfold_rounds(2)
+    gens = common.bp.Gens(16, lib=sim_lib, unfold=2)
     c1, c2 = common.circuit_from_oracle(ob1, sim_lib), common.circuit_from_oracle(ob2, sim_lib)
     j1 = common.bp.ProveJob(gens, c1, ob1["label"], ob1["values"], ob1["blindings"], ob1["seeds"], 2, wires=ob1["wires"])
     j2 = common.bp.ProveJob(gens, c2, ob2["label"], ob2["values"], ob2["blindings"], ob2["seeds"], 3, wires=ob2["wires"])
@@ -103,3 +97,42 @@ def test_low_level_abi_transcript_and_msm(sim_lib):
     assert common.bp.msm(sc, [p.compress() for p in pts], lib=sim_lib) == msm(sc, pts).compress()
     with pytest.raises(Exception):
         common.bp.msm([1], [b"\xff" * 32], lib=sim_lib)
+
+
+def test_shipped_msm_loop_on_70_proof_batches(sim_lib, sim_glib):
+    """Batches of >= 32 proofs go through msm_fixed2_body (csrc/msm_kernel.hpp) - the body the gfx950 kernel is built from, run
+    lane by lane: polarity flips, two-layer order, digit recoding, wave votes on zero scalars, the a_O - 1 form, merged S-box
+    tables, the padded round-0 terms, the folded generators as interleaved chunks - and must reproduce the C oracle's bytes for
+    every one of 70 proofs (ragged: 64 + 6 lanes).  Also: ONE call cut into two device jobs of 35 proofs gives the same bytes."""
+    import hashlib
+    from cref import COracle
+    import frontend_cases as fc
+    bp = common.bp
+    o = COracle()
+    B = 70
+    for name, label, mk in (
+            ("bound_check", b"BoundsTest", lambda j: [37 + j % 50, 27 + j % 50, 63 - j % 50]),
+            ("poseidon_hash_2_inverse_pr1", b"Poseidon_hash_2", None)):
+        gname, ip, sp, _, cap = fc.case(name, 0)
+        circ = bp.CompiledGadget(gname, ip, sp, lib=sim_lib, glib=sim_glib)
+        if mk is None:   # one preimage, per-proof blindings and seeds; statics 0, 101, 0, 0 committed with blinding 0
+            xl, xr = S.synth_scalar(b"xl", 0), S.synth_scalar(b"xr", 0)
+            vals = [[xl, xr, 0, 101, 0, 0]] * B
+            bls = [[S.synth_scalar(b"hb", 2 * j), S.synth_scalar(b"hb", 2 * j + 1), 0, 0, 0, 0] for j in range(B)]
+        else:
+            vals = [mk(j) for j in range(B)]
+            bls = [[S.synth_scalar(b"hb", 3 * j + i) for i in range(3)] for j in range(B)]
+        enc = lambda rows: b"".join(int(x).to_bytes(32, "little") for r in rows for x in r)
+        values, blindings = enc(vals), enc(bls)
+        seeds = b"".join(hashlib.sha256(b"hs%d" % j).digest() for j in range(B))
+        m = circ.m
+        want = [o.prove_case(gname, ip, sp, label, values[j * m * 32:(j + 1) * m * 32], blindings[j * m * 32:(j + 1) * m * 32], seeds[32 * j:32 * j + 32])["proof"]
+                for j in range(B)]
+        gens = bp.Gens(cap, lib=sim_lib)
+        P, _ = bp.prove_batch(gens, circ, label, values, blindings, seeds, B)
+        assert P == want, name
+        assert bp.last_prove_stats(sim_lib)["jobs"] == 1
+        gens.set_option("job_proofs", 40)
+        P2, _ = bp.prove_batch(gens, circ, label, values, blindings, seeds, B)
+        st = bp.last_prove_stats(sim_lib)
+        assert P2 == want and (st["jobs"], st["job_proofs"]) == (2, 35), (name, st)

@@ -37,8 +37,7 @@ def _worker(rank, world, port, sim_path, global_batch, q):
     ob = common.oracle_batch(lambda j: S.bound_check(37 + lo + j, 10, 100, 7), 16, hi - lo)
     seeds = b"".join(S.synth_seed(j) for j in range(lo, hi))
     circ = common.circuit_from_oracle(ob, lib)
-    gens = bp.Gens(16, lib=lib)
-    lib.bpr1cs_set_unfold_rounds(2)
+    gens = bp.Gens(16, lib=lib, unfold=2)
     P, _ = bp.prove_batch(gens, circ, ob["label"], ob["values"], ob["blindings"], seeds, hi - lo, wires=ob["wires"])
     # the library-owned RCCL communicator cannot exist on the simulator: every rank learns that from the agreement step of
     # make_comm and none of them enters the (blocking) communicator creation
