@@ -103,6 +103,7 @@ static int prove_job_begin(const bpr1cs_gens* g, const bpr1cs_circuit* c, const 
         explicit Scope(bpr1cs_job* j) : prev(dev_deferred_frees()) { dev_deferred_frees() = &j->deferred; }
         ~Scope() { dev_deferred_frees() = prev; }
     };
+    if (g->in_flight.load() >= 2) return BPR1CS_ERR_INVALID_ARGUMENT;   // two jobs in flight per handle (the third would reuse the first one's slot)
     try {
     job = new bpr1cs_job();
     job->g = g;
@@ -115,6 +116,8 @@ static int prove_job_begin(const bpr1cs_gens* g, const bpr1cs_circuit* c, const 
     // streams' mapping onto the few hardware queues (measured: two more streams serialised the jobs, 2540 -> 2040 proofs/s)
     job->st4 = g->jstream[slot][2];
     Scope scope(job);
+    // everything the job owns comes from its slot's arena (a smaller job reuses the blocks of a larger one before it)
+    ArenaScope own_arena(&g->front[slot], true);
     // the handle's options, read once per job
     const int o_unfold = g->opts.unfold.load(), o_team = g->opts.witness_team.load(), o_tail = g->opts.tail_rounds.load();
     const uint32_t B = (uint32_t)batch, n = c->n, m = c->m, N = c->N, lgN = c->lgN;
@@ -231,6 +234,7 @@ static int prove_job_begin(const bpr1cs_gens* g, const bpr1cs_circuit* c, const 
                 bpr1cs_circuit::MergedTab*& mt = c->mt[g];
                 if (!mt) mt = new bpr1cs_circuit::MergedTab();
                 if (mt->W != g->tc.W || mt->cap != g->cap || !mt->tab.p) {
+                    ArenaScope persistent(nullptr);   // the tables outlive the job (and their construction scratch is a one-off)
                     DevBuf<ge> mp((size_t)2 * T3);
                     launch(T3, K_merge_points{g->pts.p, c->trip.p, mp.p, T3, baseG, baseH}, st);
                     mt->tab.alloc((size_t)2 * T3 * g->tc.base_bytes());
@@ -281,11 +285,6 @@ static int prove_job_begin(const bpr1cs_gens* g, const bpr1cs_circuit* c, const 
     // back phase is AHEAD of this one on the heavy stream (FIFO), and its tail - the only part that runs on another stream -
     // works on copies of its own (IpaIO::TailKeep) and on buffers allocated BEFORE the arena is installed (the proof bytes
     // `d_out` among them), so stream order alone keeps the two jobs apart: no event, no wait.
-    struct ArenaHook {
-        DevArena* prev;
-        explicit ArenaHook(DevArena* a) : prev(dev_arena()) { if (a) { a->next = 0; dev_arena() = a; } }
-        ~ArenaHook() { dev_arena() = prev; }
-    };
     // what the IPA tail and the proof assembly read stays the job's own: challenges, T commitments, t_x.., L/R, u_k
     DevBuf<sc> chal((size_t)CH_COUNT * B), txs((size_t)3 * B), uk((size_t)(lgN ? lgN : 1) * 2 * B);
     DevBuf<uint8_t> Tc((size_t)5 * B * 32), LR((size_t)(lgN ? lgN : 1) * 2 * B * 32);
@@ -293,7 +292,7 @@ static int prove_job_begin(const bpr1cs_gens* g, const bpr1cs_circuit* c, const 
     job->plen = plen;
     DevBuf<uint8_t> d_out((size_t)B * plen);   // written by K_assemble and read back on the TAIL stream: never an arena block
     const bool shared_back = g->opts.shared_back.load() != 0;
-    ArenaHook arena_hook(shared_back ? &g->arena : nullptr);
+    ArenaScope back_arena(shared_back ? &g->arena : &g->front[slot], shared_back);   // (not shared: the job's own arena goes on)
 
     // ---- P3/P4: challenges, flatten, t(x), T commitments, l(x), r(x)
     launch(B, K_transcript_A{tr.p, AOS.p, chal.p, B}, st);
@@ -345,11 +344,7 @@ static int prove_job_begin(const bpr1cs_gens* g, const bpr1cs_circuit* c, const 
         bpr1cs_circuit::MergedTab*& mt = c->mt[g];
         if (!mt) mt = new bpr1cs_circuit::MergedTab();
         if (!mt->hs_tab.p || mt->hs_W != g->tc.W || mt->hs_cap != g->cap) {
-            struct ArenaPause {  // the table outlives the job: it must not come from the jobs' shared arena
-                DevArena* saved;
-                ArenaPause() : saved(dev_arena()) { dev_arena() = nullptr; }
-                ~ArenaPause() { dev_arena() = saved; }
-            } pause;
+            ArenaScope persistent(nullptr);  // the table outlives the job: it must not come from an arena
             DevBuf<ge> part64(64), hsum(1);
             launch(64, K_range_sum_points{g->pts.p, part64.p, baseH + (n - N / 2), baseH + N / 2}, st);
             launch(1, K_ge_reduce{part64.p, hsum.p, 1, 64, 64}, st);
@@ -369,6 +364,7 @@ static int prove_job_begin(const bpr1cs_gens* g, const bpr1cs_circuit* c, const 
     io.sG_pre = sG_p; io.sH_pre = sH_p;
     io.vtab_pre = (ge_cached*)shared_blk.p; io.vtab_pre_count = shared_blk.n / sizeof(ge_cached);
     io.tail_keep = &job->tail;
+    io.own_arena = &g->front[slot];
     const IpaEnd ipa_end = enqueue_ipa(io, st, stats);
     st = ipa_end.st;  // from here on `st` may be the job's tail stream: only the job's own buffers are touched below
     launch(B, K_assemble{AOS.p, Tc.p, txs.p, LR.p, ipa_end.a, ipa_end.bb, d_out.p, B, lgN, (uint32_t)plen}, st);
@@ -458,7 +454,7 @@ static uint32_t auto_job_proofs(const bpr1cs_gens* g, const bpr1cs_circuit* c, b
         auto it = c->mt.find(g);
         if (it == c->mt.end() || !it->second->tab.p) fixed += 2 * c->h_trip.size() * g->tc.base_bytes();
     }
-    const size_t avail = dev_free_memory() + g->arena.bytes();
+    const size_t avail = dev_free_memory() + g->arena.bytes() + g->front[0].bytes() + g->front[1].bytes();
     const size_t reserve = (size_t)2 << 30;
     const uint64_t grid_per_proof = (uint64_t)4 * c->N + 3ull * c->n + c->m + 64;
     for (uint32_t J = 4096; J > 64; J >>= 1) {
@@ -509,6 +505,8 @@ static int prove_batch_impl(const bpr1cs_gens* g, const bpr1cs_circuit* c, const
             // and go on with jobs of half the size
             while (!fl.empty()) finish_oldest();
             g->arena.release();
+            g->front[0].release();
+            g->front[1].release();
 #if !defined(BPR1CS_HOSTSIM)
             dev_pool().release_all();
 #endif

@@ -36,6 +36,8 @@ int bpr1cs_gens_release_scratch(bpr1cs_gens* g) {
     if (!g) return BPR1CS_ERR_INVALID_ARGUMENT;
     if (g->in_flight.load() > 0) return BPR1CS_ERR_INVALID_ARGUMENT;  // the jobs in flight are working in it
     g->arena.release();
+    g->front[0].release();
+    g->front[1].release();
     return BPR1CS_OK;
 }
 int bpr1cs_release_cached_memory(void) {
@@ -57,14 +59,14 @@ int bpr1cs_gens_create_opts(uint32_t cap, const int32_t* pairs, size_t n_pairs, 
         if (!opt_apply(g->opts, pairs[2 * i], pairs[2 * i + 1], true)) { delete g; return BPR1CS_ERR_INVALID_ARGUMENT; }
     int window_bits = g->opts.window_bits;
     if (window_bits == 0) {
-        // automatic: the widest window (<= 11) whose tables take at most two thirds of the free device memory - W = 11 (198 GB) for
+        // automatic: the widest window (<= 11) whose tables take at most 70 % of the free device memory - W = 11 (198 GB) for
         // capacity 32768 on a 288 GB device, 8 / 7 for the reference's as-shipped depths (capacity 131072 / 262144); what is left is
         // for a circuit's merged tables and the prove jobs, whose size follows from it (BPR1CS_OPT_JOB_PROOFS)
 #if defined(BPR1CS_HOSTSIM)
         window_bits = 8;   // (the simulator builds its tables on one CPU core)
 #else
         window_bits = 4;
-        const double room = (double)dev_free_memory() * (2.0 / 3.0);
+        const double room = (double)dev_free_memory() * 0.7;
         for (int w = 11; w >= 4; w--)
             if ((double)(2 + 2 * (size_t)cap) * (double)tab_cfg((uint32_t)w).base_bytes() <= room) { window_bits = w; break; }
 #endif
@@ -111,6 +113,8 @@ int bpr1cs_gens_create(uint32_t cap, bpr1cs_gens** out) { return bpr1cs_gens_cre
 void bpr1cs_gens_destroy(bpr1cs_gens* g) {
     if (!g) return;
     g->arena.release();
+    g->front[0].release();
+    g->front[1].release();
 #if !defined(BPR1CS_HOSTSIM)
     if (g->stream) (void)hipStreamDestroy(g->stream);
     for (int a = 0; a < 2; a++)

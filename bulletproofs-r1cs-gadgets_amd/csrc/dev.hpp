@@ -232,14 +232,15 @@ inline void launch_wave(uint64_t n, const F& f, dev_stream_t s) {
 }
 #endif
 
-// Arena of device blocks that successive prove jobs of one generator handle REUSE for the buffers of their "back" phase
-// (everything after the commitment sums): the backs of the jobs in flight run one after the other on the handle's heavy
-// stream, so their scratch can be the same memory - a job only has to wait for its predecessor's tail before its first
-// write (bpr1cs_prove_batch_begin).  While a job's enqueue code has the arena installed (dev_arena()), every
-// DevBuf::alloc takes the next slot instead of asking the allocator: jobs of the same shape issue the same sequence of
-// requests and get the same addresses.  A slot that is too small (or much too large) is replaced; the old block goes to
-// the current job's deferred frees, i.e. it returns to the pool only after this job - and with it every earlier job -
-// has drained.
+// Arena of device blocks that successive prove jobs of one generator handle REUSE.  A handle has three: one for the buffers of
+// the "back" phase (everything after the commitment sums), shared by the jobs in flight - their backs run one after the other on
+// the handle's heavy stream, so stream order alone separates them (the only part of a job that runs elsewhere, its IPA tail,
+// works on buffers of the job's own) - and one per job slot for everything a job owns (inputs, wires, TranscriptRng output,
+// outputs, the tail's copies): the job that used the slot before has ended when the next one begins.  While a job's enqueue code
+// has an arena installed (dev_arena()), every DevBuf::alloc takes the next slot instead of asking the allocator: jobs of the same
+// shape issue the same sequence of requests and get the same addresses, and a smaller job fits into the blocks of a larger one.
+// A slot that is too small (or much too large) is replaced; the old block goes to the current job's deferred frees, i.e. it
+// returns to the pool only after this job - and with it every earlier job - has drained.
 struct DevArena {
     std::vector<std::pair<void*, size_t>> slots;
     size_t next = 0;
@@ -269,6 +270,15 @@ inline DevArena*& dev_arena() {
     static thread_local DevArena* a = nullptr;
     return a;
 }
+// install an arena (or none: allocations go to the pool) for a scope; `rewind`: the scope starts a new job in it
+struct ArenaScope {
+    DevArena* prev;
+    explicit ArenaScope(DevArena* a, bool rewind = false) : prev(dev_arena()) {
+        if (a && rewind) a->next = 0;
+        dev_arena() = a;
+    }
+    ~ArenaScope() { dev_arena() = prev; }
+};
 
 template <class T>
 struct DevBuf {

@@ -39,6 +39,7 @@ struct IpaIO {
         DevBuf<ge_cached> vtab;
         DevBuf<uint32_t> vdig;
     }* tail_keep = nullptr;
+    DevArena* own_arena = nullptr;      // where the job's own buffers come from (nullptr: the allocator)
     // optional: room provided by the caller for the product scalars of the un-folded rounds (2 x N*B) and for the Straus
     // multiples of the first variable-base pair - the prover lets them SHARE one block with buffers that are dead by then
     sc* sG_pre = nullptr; sc* sH_pre = nullptr;
@@ -114,15 +115,13 @@ static IpaEnd enqueue_ipa(const IpaIO& io, dev_stream_t st, MsmStats* stats) {
         if (k == tail_from && k + 1 < lgN) {
             // ---- leave the shared arena: copy the live state into the job's own buffers (on the heavy stream, before the event)
             IpaIO::TailKeep& T = *io.tail_keep;
-            DevArena* saved = dev_arena();
-            dev_arena() = nullptr;
-            try {
+            {
+                ArenaScope own(io.own_arena);
                 T.a.alloc((size_t)Nk * B); T.bb.alloc((size_t)Nk * B); T.linv.alloc((size_t)2 * B); T.cross.alloc((size_t)2 * B);
                 T.GH.alloc((size_t)2 * Nk * B);
                 T.vtab.alloc((size_t)VB_MULT * 4 * mk * B); T.vdig.alloc((size_t)VB_WORDS * 4 * mk * B);
                 T.vwin.alloc((size_t)2 * VB_WINDOWS * VC * B); T.vsum.alloc((size_t)2 * VB_WINDOWS * B); T.vout.alloc((size_t)2 * B);
-            } catch (...) { dev_arena() = saved; throw; }
-            dev_arena() = saved;
+            }
             dev_d2d(T.a.p, a, (size_t)Nk * B * sizeof(sc), st);
             dev_d2d(T.bb.p, bb, (size_t)Nk * B * sizeof(sc), st);
             dev_d2d(T.linv.p, linvp, (size_t)2 * B * sizeof(sc), st);
@@ -150,10 +149,8 @@ static IpaEnd enqueue_ipa(const IpaIO& io, dev_stream_t st, MsmStats* stats) {
         uint32_t cchunk, CC = pick_chunks(mk, B, 1u << 18, cchunk);
         if (cpart_n < (size_t)2 * CC * B) {
             if (k >= tail_from && io.tail_keep) {
-                DevArena* saved = dev_arena();
-                dev_arena() = nullptr;
-                try { io.tail_keep->cpart.alloc((size_t)2 * CC * B); } catch (...) { dev_arena() = saved; throw; }
-                dev_arena() = saved;
+                ArenaScope own(io.own_arena);
+                io.tail_keep->cpart.alloc((size_t)2 * CC * B);
                 cpartp = io.tail_keep->cpart.p;
             } else {
                 cpart.alloc((size_t)2 * CC * B);

@@ -151,7 +151,7 @@ int bpr1cs_gens_table_info(const bpr1cs_gens* g, uint32_t* window_bits, uint32_t
 #define BPR1CS_OPT_WINDOW_BITS 16     /* creation only: signed window width W (4..12) of the fixed-base tables.  A term costs
                                          ceil(253/W) mixed additions; table bytes = (2+2*cap) * ceil(253/W) * (2^(W-1)+1) * 128
                                          (W=8: 35 GB, W=11: 198 GB at capacity 32768).  Default 0 = the widest W <= 11 whose tables fit in
-                                         two thirds of the free device memory: 11 for N <= 32768 on a 288 GB device, 8 / 7 for the
+                                         70 % of the free device memory: 11 for N <= 32768 on a 288 GB device, 8 / 7 for the
                                          reference's as-shipped tree depths (N = 131072 / 262144, gadget_vsmt_4.rs:25, gadget_vsmt_2.rs:23) */
 int bpr1cs_gens_set_option(bpr1cs_gens* g, int option, int value);
 /* bpr1cs_gens_create with options: `pairs` = n_pairs x (option, value).  BPR1CS_ERR_INVALID_ARGUMENT for an unknown option. */
@@ -200,7 +200,8 @@ int bpr1cs_prove_batch_transcripts(const bpr1cs_gens* g, const bpr1cs_circuit* c
 
 /* Asynchronous form of bpr1cs_prove_batch: `begin` uploads the inputs and enqueues the whole prove on
  * one of two per-handle HIP stream pairs and returns without waiting; `end` waits for that job and
- * copies the results out.  Two jobs may be in flight per gens handle: the latency-bound phase of
+ * copies the results out.  Two jobs may be in flight per gens handle (a third `begin` before an `end` is refused with
+ * BPR1CS_ERR_INVALID_ARGUMENT: a job owns one of the handle's two stream / buffer slots): the latency-bound phase of
  * batch k+1 (TranscriptRng Keccak chain, witness synthesis) then overlaps the VALU-bound MSM/IPA
  * phase of batch k.  Input buffers may be released as soon as `begin` returns. */
 typedef struct bpr1cs_job bpr1cs_job;

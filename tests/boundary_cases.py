@@ -144,7 +144,7 @@ def check_validation(lib):
     gname, ip, sp, sc0, cap = __import__("frontend_cases").case("bound_check", 0)
     ob = common.oracle_batch(lambda j: __import__("frontend_cases").case("bound_check", j)[3], cap, 1)
     circ = common.circuit_from_oracle(ob, lib)
-    gens = bp.Gens(cap, lib=lib)
+    gens = bp.Gens(cap, lib=lib, window_bits=8)
     bigL, big = L.to_bytes(32, "little"), (2**256 - 1).to_bytes(32, "little")
 
     def rc_of(values=None, bl=None, wires=None):
@@ -216,7 +216,7 @@ def check_two_threads_two_handles(lib, glib, rounds=3):
 
     def worker(k):
         try:
-            gens = bp.Gens(cap, lib=lib)
+            gens = bp.Gens(cap, lib=lib, window_bits=8)
             gens.set_option(bp.OPT_UNFOLD_ROUNDS, 1 + 2 * k)
             sl = slice(k * batch * m * 32, (k + 1) * batch * m * 32)
             for _ in range(rounds):

@@ -126,7 +126,7 @@ def check_compiled(lib, glib, name, batch, unfold=4, gens_cache={}, **opts):
     assert circ.has_witness_program
     key = (id(lib), cap)
     if key not in gens_cache:
-        gens_cache[key] = bp.Gens(cap, lib=lib)
+        gens_cache[key] = bp.Gens(cap, lib=lib, window_bits=8)   # (W = 11, the default, would keep tens of GB per cached handle)
     gens = gens_cache[key]
     opts = dict(opts, unfold=unfold)
     try:
@@ -277,7 +277,7 @@ def check_prove_verify_roundtrip(lib, glib, name, batch=2):
     gname, ip, sp, _, cap = case(name, 0)
     ob = common.oracle_batch(lambda j: case(name, j)[3], cap, batch, key=name)
     circ = bp.CompiledGadget(gname, ip, sp, lib=lib, glib=glib)
-    gens = bp.Gens(cap, lib=lib)
+    gens = bp.Gens(cap, lib=lib, window_bits=8)
     P, C = bp.prove_batch(gens, circ, ob["label"], ob["values"], ob["blindings"], ob["seeds"], batch, wires=None)
     assert P == ob["proofs"]
     per_proof_public = name.startswith("poseidon") or name.startswith("mimc")   # the hash output (a public constant of the circuit) differs per proof

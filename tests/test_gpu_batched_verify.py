@@ -18,7 +18,7 @@ def test_batched_verify_vsmt4_four_levels(hip_lib, hip_glib):
     ob, P, C = fc.check_compiled(hip_lib, hip_glib, "vsmt_4_l4", batch=3)
     gname, ip, sp, _, cap = fc.case("vsmt_4_l4", 0)
     circ = bp.CompiledGadget(gname, ip, sp, lib=hip_lib, glib=hip_glib)
-    gens = bp.Gens(cap, lib=hip_lib)
+    gens = bp.Gens(cap, lib=hip_lib, window_bits=8)
     pt, wf = bp.verify_batch_combined(gens, circ, ob["label"], P, C, 3, tb.SEED)
     assert wf and pt == bytes(32)
     bad = bytearray(P[2]); bad[40] ^= 1

@@ -17,7 +17,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def w11_gens(hip_lib):
     """32768-capacity generators exactly as bench.py and any plain caller get them: bpr1cs_gens_create with no options picks
     W = 11 from the free memory of the device."""
+    import gc
     bp = importlib.import_module("bulletproofs-r1cs-gadgets_amd")
+    gc.collect()                       # handles of earlier tests that are no longer referenced give their tables back
     bp.release_cached_memory(hip_lib)
     gens = bp.Gens(32768, lib=hip_lib)
     info = gens.table_info()

@@ -77,8 +77,10 @@ def test_two_batches_in_flight_on_device(hip_lib):
     j1 = bp.ProveJob(gens, circ, ob["label"], ob["values"], ob["blindings"], ob["seeds"], 3, wires=ob["wires"])
     j2 = bp.ProveJob(gens, circ, ob["label"], n32(ob["values"], 2), n32(ob["blindings"], 2), ob["seeds"][:64], 2,
                      wires=b"".join(ob["wires"][96 * circ.n * k:96 * circ.n * (k + 1)] for k in range(2)))
-    j3 = bp.ProveJob(gens, circ, ob["label"], ob["values"], ob["blindings"], ob["seeds"], 3, wires=ob["wires"])
+    with pytest.raises(bp.R1CSError):   # two jobs in flight per handle: a third would take the first one's slot (its streams and buffers)
+        bp.ProveJob(gens, circ, ob["label"], ob["values"], ob["blindings"], ob["seeds"], 3, wires=ob["wires"])
     P1, _ = j1.finish()
+    j3 = bp.ProveJob(gens, circ, ob["label"], ob["values"], ob["blindings"], ob["seeds"], 3, wires=ob["wires"])   # ... which is free now
     P2, _ = j2.finish()
     P3, _ = j3.finish()
     assert P1 == ob["proofs"] and P2 == ob["proofs"][:2] and P3 == ob["proofs"]
@@ -107,7 +109,7 @@ def test_large_variable_base_msm_pippenger_buckets(hip_lib):
     from pyref.ed import L
     o = COracle()
     bp = common.bp
-    gens = bp.Gens(4096, lib=hip_lib)
+    gens = bp.Gens(4096, lib=hip_lib, window_bits=8)
     base = [gens.point(2, i) for i in range(4096)] + [gens.point(3, i) for i in range(4096)]
     for n in (4096, 5000, 20011):
         pts = [base[(7 * i) % len(base)] for i in range(n)]
