@@ -333,6 +333,8 @@ def run_short_config(bp, lib, name, args, gens_by_cap):
     if st["msm_ms"] > 0 and st["msm_terms"]:
         out["msm_table_adds_per_s"] = st["msm_terms"] * gens.table_info()["windows"] / (st["msm_ms"] / 1e3)
     if "fixture_build" in cfg:   # the throughput inputs are not the fixture's: prove the fixture's batch as well
+        circ.close()             # (its merged S-box tables - tens of GB at the deep circuits - make room for the fixture circuit's)
+        gens.release_scratch()
         fw = cfg["fixture_build"](bp)
         fcirc = bp.CompiledGadget(fw["gadget"], fw["ip"], fw["sp"])
         fproofs, _ = bp.prove_batch_raw(gens, fcirc, fw["label"], fw["values"], fw["blindings"], fw["seeds"], fw["B"])
@@ -449,6 +451,7 @@ def main():
     proofs = [proofs_raw[i * plen:(i + 1) * plen] for i in range(Bj)]
     comms = [[comms_raw[(i * m + j) * 32:(i * m + j + 1) * 32] for j in range(m)] for i in range(Bj)]
 
+    gens.release_scratch()   # the verifiers below allocate their own scratch (8 GiB per vector at N = 262144): hand the prover's arenas back first
     # Outside the timed region, on every rank: cross-proof batched verification of one job's proofs
     # (bpr1cs_verify_batch_combined) and the path's only exchange step, an all_gather of one 32-byte point per rank.
     batched = None

@@ -131,7 +131,7 @@ struct bpr1cs_gens {
     dev_stream_t jstream[2][3]{};  // [slot][heavy, front, witness (later: the job's IPA tail)]
     mutable DevArena arena;           // back-phase scratch shared by the handle's jobs (one thread at a time uses a handle)
     mutable DevArena front[2];        // what a job owns, per job slot (the slot's previous job has ended when the next begins)
-    mutable std::atomic<uint32_t> next_job{0};
+    mutable std::atomic<uint32_t> busy_slots{0};  // bit s: job slot s (streams jstream[s], arena front[s]) belongs to a job in flight
     mutable std::atomic<int> in_flight{0};  // jobs begun and not yet ended
     mutable BpOpts opts;
 };

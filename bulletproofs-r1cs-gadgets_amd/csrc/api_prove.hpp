@@ -14,6 +14,7 @@ struct bpr1cs_job {
     int* h_err = nullptr;
     strobe* h_tr = nullptr;       // final transcript states (only when the caller handed in its own transcripts)
     bool counted = false;         // contributes to g->in_flight
+    int slot = -1;                // the handle's job slot it holds (released with the job)
     IpaIO::TailKeep tail;         // the IPA tail's own buffers (outside the handle's shared arena)
     dev_event_t ev_in{}, ev_rng{}, ev_wit{}, ev_done{}, ev_tail{};
 };
@@ -79,6 +80,7 @@ static void job_release(bpr1cs_job* job) {
     host_stage_free(job->h_err);
     host_stage_free(job->h_tr);
     if (job->counted) job->g->in_flight--;
+    if (job->slot >= 0) job->g->busy_slots.fetch_and(~(1u << job->slot));
     delete job;
 }
 
@@ -103,11 +105,18 @@ static int prove_job_begin(const bpr1cs_gens* g, const bpr1cs_circuit* c, const 
         explicit Scope(bpr1cs_job* j) : prev(dev_deferred_frees()) { dev_deferred_frees() = &j->deferred; }
         ~Scope() { dev_deferred_frees() = prev; }
     };
-    if (g->in_flight.load() >= 2) return BPR1CS_ERR_INVALID_ARGUMENT;   // two jobs in flight per handle (the third would reuse the first one's slot)
+    // two jobs in flight per handle: a job takes the first free slot (synchronous callers always get slot 0 and its buffers)
+    uint32_t slot = 0;
+    for (;;) {
+        uint32_t busy = g->busy_slots.load();
+        if ((busy & 3u) == 3u) return BPR1CS_ERR_INVALID_ARGUMENT;
+        slot = (busy & 1u) ? 1u : 0u;
+        if (g->busy_slots.compare_exchange_weak(busy, busy | (1u << slot))) break;
+    }
     try {
     job = new bpr1cs_job();
     job->g = g;
-    uint32_t slot = g->next_job++ & 1u;
+    job->slot = (int)slot;
     job->st = g->jstream[0][0];  // ONE heavy stream: MSM/IPA phases of successive jobs run back to back (FIFO; a heavy stream per job measured 3.4 % slower)
     job->st2 = g->jstream[slot][1];
     job->st3 = g->jstream[slot][2];
@@ -397,9 +406,9 @@ static int prove_job_begin(const bpr1cs_gens* g, const bpr1cs_circuit* c, const 
     *job_out = job;
     return BPR1CS_OK;
     }
-    catch (const DevError& e_) { job_release(job); return e_.code; }
-    catch (const std::bad_alloc&) { job_release(job); return BPR1CS_ERR_OUT_OF_MEMORY; }
-    catch (...) { job_release(job); return BPR1CS_ERR_DEVICE; }
+    catch (const DevError& e_) { if (!job) g->busy_slots.fetch_and(~(1u << slot)); job_release(job); return e_.code; }
+    catch (const std::bad_alloc&) { if (!job) g->busy_slots.fetch_and(~(1u << slot)); job_release(job); return BPR1CS_ERR_OUT_OF_MEMORY; }
+    catch (...) { if (!job) g->busy_slots.fetch_and(~(1u << slot)); job_release(job); return BPR1CS_ERR_DEVICE; }
 }
 
 // wait for a job, copy its results out and add its statistics to `acc` (nullptr: none)
