@@ -568,7 +568,7 @@ int bpr1cs_prove_batch_transcripts(const bpr1cs_gens* g, const bpr1cs_circuit* c
     try {
         std::vector<strobe> init(n_transcripts);
         for (size_t i = 0; i < n_transcripts; i++) init[i] = transcripts[i]->s;
-        return prove_batch_impl(g, c, init.data(), n_transcripts, n_transcripts == 1 ? nullptr : transcripts, values, v_blindings, rng_seeds, wires,
+        return prove_batch_impl(g, c, init.data(), n_transcripts, n_transcripts == batch ? transcripts : nullptr, values, v_blindings, rng_seeds, wires,
                                 batch, proofs_out, commitments_out);
     } catch (const std::bad_alloc&) { return BPR1CS_ERR_OUT_OF_MEMORY; }
 }

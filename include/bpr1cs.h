@@ -191,8 +191,9 @@ int bpr1cs_prove_batch(const bpr1cs_gens* g, const bpr1cs_circuit* c, const uint
 /* The same with the caller's transcripts, for Prover::new(&pc_gens, &mut transcript) on a transcript that is not fresh
  * (reference src/gadget_vsmt_4.rs:390-391: `let mut prover_transcript = Transcript::new(b"VSMT"); Prover::new(&pc_gens,
  * &mut prover_transcript)` - any messages appended in between are part of the state).  `transcripts`: n_transcripts = batch
- * handles (proof i starts from transcripts[i] and leaves it in the state upstream's `&mut` transcript has when prove() returns),
- * or n_transcripts = 1: every proof starts from a copy of transcripts[0], which is left untouched. */
+ * handles (proof i starts from transcripts[i] and leaves it in the state upstream's `&mut` transcript has when prove() returns;
+ * a batch of one with its one transcript is this case), or n_transcripts = 1 < batch: every proof starts from a copy of
+ * transcripts[0], which is left untouched. */
 typedef struct bpr1cs_transcript bpr1cs_transcript;
 int bpr1cs_prove_batch_transcripts(const bpr1cs_gens* g, const bpr1cs_circuit* c, bpr1cs_transcript* const* transcripts, size_t n_transcripts,
                                    const uint8_t* values, const uint8_t* v_blindings, const uint8_t* rng_seeds,
