@@ -54,3 +54,19 @@ def test_upstream_vectors_equal_ours():
             ours = gold[case]["commitments"][j]
             assert t[3:3 + len(ours)] == ours, "%s commitments %d differ" % (case, j)
     assert seen > 0
+
+
+def test_first_divergence_probes_in_the_readme_are_current():
+    """tools/upstream_golden/README.md carries the oracle's values of the first-divergence probes (generators, first TranscriptRng
+    draw, A_I1, challenges ...): they must be what tools/upstream_golden/print_probes.py prints now"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "upstream_golden", "print_probes.py")], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr
+    readme = open(os.path.join(root, "tools", "upstream_golden", "README.md")).read()
+    for line in out.stdout.strip().split("\n"):
+        name, value = line.split()[0], line.split()[1]
+        if name == "proof":
+            continue
+        assert value in readme, name
