@@ -131,6 +131,12 @@ struct bpr1cs_gens {
     dev_stream_t jstream[2][3]{};  // [slot][heavy, front, witness (later: the job's IPA tail)]
     mutable DevArena arena;           // back-phase scratch shared by the handle's jobs (one thread at a time uses a handle)
     mutable DevArena front[2];        // what a job owns, per job slot (the slot's previous job has ended when the next begins)
+    // The two largest buffers of a job's front are needed for a short time only and are shared by the jobs in flight: the wires and
+    // blinding vectors (5 n scalars per proof: dead after l(x), r(x), early in the back phase) and the raw TranscriptRng output (64 B
+    // per draw: dead after its reduction mod l).  The next job's writers wait for the event the previous job records when it is done
+    // with them - long before, in steady state: a job's front starts when its predecessor's back phase does.
+    mutable DevArena shared_front;
+    mutable dev_event_t w_free_ev{}, rng_free_ev{};
     mutable std::atomic<uint32_t> busy_slots{0};  // bit s: job slot s (streams jstream[s], arena front[s]) belongs to a job in flight
     mutable std::atomic<int> in_flight{0};  // jobs begun and not yet ended
     mutable BpOpts opts;
@@ -156,11 +162,13 @@ struct bpr1cs_circuit {
     DevBuf<uint32_t> trip, rest, ones;  // ones: the multipliers m, m+2 of every triple (a_O = 1 by construction)
     // merged tables, one set per generator handle that has proved this circuit (built on first use, under mt_mu)
     struct MergedTab {
-        uint32_t W = 0, cap = 0;
+        uint32_t W = 0, cap = 0;   // of the generator handle they were built for
+        TabCfg tc{};               // their own geometry: a window narrower by one when W = 11-style tables would take tens of GB
         DevBuf<uint8_t> tab;
         DevBuf<ge> ones_pt;  // sum over the triples of G_m + G_m+2: the constant part of A_O (K_triple_ones_point)
         DevBuf<uint8_t> hs_tab;  // table of the single point sum_{n - N/2 <= i < N/2} H_i (K_range_sum_points), when n > N/2
         uint32_t hs_W = 0, hs_cap = 0;
+        uint32_t job_proofs = 0;   // proofs per device job chosen for (this circuit, this handle) by the first bpr1cs_prove_batch: kept for the later ones
     };
     mutable std::mutex mt_mu;
     mutable std::map<const bpr1cs_gens*, MergedTab*> mt;

@@ -84,6 +84,16 @@ static void job_release(bpr1cs_job* job) {
     delete job;
 }
 
+// Geometry of a circuit's merged S-box tables (one table per wire triple and side: 2 T3 bases).  They serve ~3 % of a job's table
+// terms; at the generator tables' own window they would take 36 GB for the depth-32 tree circuits - memory that is worth more as
+// job size (more proofs per fetched table row) - so from 8 GiB on they are built one window bit narrower (+13 % additions on 3 %
+// of the terms, half the bytes).
+static TabCfg merged_tab_cfg(const bpr1cs_gens* g, uint32_t T3) {
+    const char* force = getenv("BPR1CS_TEST_NARROW_MERGED");   // test knob: take the narrower window whatever the size
+    if (g->tc.W > 4 && ((size_t)2 * T3 * g->tc.base_bytes() > ((size_t)8 << 30) || (force && force[0] == '1'))) return tab_cfg(g->tc.W - 1);
+    return g->tc;
+}
+
 // One device job.  `init`: the transcripts the proofs start from - n_init = 1 (every proof starts from a copy of init[0]: what
 // Transcript::new(label) gives) or n_init = batch (the caller's own); want_tr: read the final transcript states back.
 static int prove_job_begin(const bpr1cs_gens* g, const bpr1cs_circuit* c, const strobe* init, size_t n_init, bool want_tr,
@@ -157,7 +167,17 @@ static int prove_job_begin(const bpr1cs_gens* g, const bpr1cs_circuit* c, const 
     DevBuf<uint8_t> Vcomp((size_t)B * m * 32 + 1);
     launch((uint64_t)m * B, K_commit_v{g->tab.p, g->tc, v_raw.p, vbl_raw.p, Vcomp.p, B, m}, sl);
     DevBuf<strobe> tr(B);
-    DevBuf<sc> blind((size_t)8 * B), W((size_t)5 * n * B + 1);
+    const bool shared = g->opts.shared_back.load() != 0;   // jobs in flight share W / the raw RNG output / the back-phase scratch
+    DevBuf<sc> blind((size_t)8 * B), W;
+    DevBuf<uint64_t> rng_raw;
+    const uint32_t draws = 2 * n + 7;
+    {
+        ArenaScope sh(shared ? &g->shared_front : &g->front[slot], shared);
+        W.alloc((size_t)5 * n * B + 1);
+#if !defined(BPR1CS_HOSTSIM)
+        rng_raw.alloc((size_t)draws * B * 8);
+#endif
+    }
     sc* sL = W.p + (size_t)3 * n * B;
     sc* sR = W.p + (size_t)4 * n * B;
     pt.mark(sl);
@@ -172,17 +192,18 @@ static int prove_job_begin(const bpr1cs_gens* g, const bpr1cs_circuit* c, const 
 #else
     // TranscriptRng: the sequential STROBE chain of a proof (2n + 7 draws, one Keccak-f[1600] each) runs lane-parallel - one state
     // on 25 lanes, two proofs per wavefront (k_rng_stream) -, the wide reductions mod l of its outputs afterwards in parallel
-    const uint32_t draws = 2 * n + 7;
     DevBuf<strobe> rng(B);
-    DevBuf<uint64_t> rng_raw((size_t)draws * B * 8);
     DevBuf<int> rng_err(1);
     dev_zero(rng_err.p, sizeof(int), sl);
     launch(B, K_transcript_init{d_init.p, init_stride, Vcomp.p, vbl_raw.p, d_seeds.p, tr.p, blind.p, sL, sR, rng.p, B, m, n}, sl);
+    if (shared) dev_stream_wait(sl, g->rng_free_ev);   // the job before has reduced (and wiped) its raw output
     hipLaunchKernelGGL(k_rng_stream, dim3((B + 1) / 2), dim3(64), 0, sl, rng.p, rng_raw.p, rng_err.p, B, draws);
     HIPCHK(hipGetLastError());
+    if (shared) dev_stream_wait(sl, g->w_free_ev);     // s_L / s_R live in W: the job before is past its l(x), r(x)
     launch((uint64_t)draws * B, K_rng_reduce{rng_raw.p, blind.p, sL, sR, B, n}, sl);
     dev_zero(rng_raw.p, rng_raw.bytes(), sl);  // raw blinding material
     dev_zero(rng.p, rng.bytes(), sl);
+    if (shared) dev_event_record(g->rng_free_ev, sl);
 #endif
     dev_event_record(job->ev_rng, sl);
 
@@ -191,6 +212,7 @@ static int prove_job_begin(const bpr1cs_gens* g, const bpr1cs_circuit* c, const 
     if (wires) {
         DevBuf<sc> raw;
         upload_transposed(raw, wires, B, (size_t)3 * n, sl);
+        if (shared) dev_stream_wait(sl, g->w_free_ev);
         launch((uint64_t)3 * n * B, K_load_wires{raw.p, W.p}, sl);
         dev_zero(raw.p, raw.bytes(), sl);
         dev_sync(sl);
@@ -211,6 +233,7 @@ static int prove_job_begin(const bpr1cs_gens* g, const bpr1cs_circuit* c, const 
         kw.prio = 2;  // above the co-resident MSM waves (default 0), below the RNG chain (3)
         uint32_t blocks = (uint32_t)(((uint64_t)B * T + 63) / 64);
         dev_stream_wait(job->st3, job->ev_in);
+        if (shared) dev_stream_wait(job->st3, g->w_free_ev);
         if (T == 4) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_witness_team<4>), dim3(blocks), dim3(64), 0, job->st3, kw);
         else if (T == 8) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_witness_team<8>), dim3(blocks), dim3(64), 0, job->st3, kw);
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_witness_team<16>), dim3(blocks), dim3(64), 0, job->st3, kw);
@@ -222,8 +245,19 @@ static int prove_job_begin(const bpr1cs_gens* g, const bpr1cs_circuit* c, const 
     }
     // ---- P2: A_I1, A_O1, S1.  The sums of A_I1 and A_O1 need the wires only, so they are enqueued BEFORE the heavy stream
     // waits for the TranscriptRng chain (the longer of the two front kernels); their blinding terms and all of S1 follow it.
-    DevBuf<ge> partial, partialO;
     DevBuf<uint8_t> AOS((size_t)3 * B * 32);
+    // ---- from here on the job's scratch comes from the handle's arena, shared with the other job in flight: that job's
+    // back phase is AHEAD of this one on the heavy stream (FIFO), and its tail - the only part that runs on another stream -
+    // works on copies of its own (IpaIO::TailKeep) and on buffers allocated BEFORE the arena is installed (the proof bytes
+    // `d_out` among them), so stream order alone keeps the two jobs apart: no event, no wait.
+    // what the IPA tail and the proof assembly read stays the job's own: challenges, T commitments, t_x.., L/R, u_k
+    DevBuf<sc> chal((size_t)CH_COUNT * B), txs((size_t)3 * B), uk((size_t)(lgN ? lgN : 1) * 2 * B);
+    DevBuf<uint8_t> Tc((size_t)5 * B * 32), LR((size_t)(lgN ? lgN : 1) * 2 * B * 32);
+    const size_t plen = bpr1cs_proof_len(c);
+    job->plen = plen;
+    DevBuf<uint8_t> d_out((size_t)B * plen);   // written by K_assemble and read back on the TAIL stream: never an arena block
+    ArenaScope back_arena(shared ? &g->arena : &g->front[slot], shared);   // (not shared: the job's own arena goes on)
+    DevBuf<ge> partial, partialO;   // chunk partial sums of the launches (heavy stream only): arena blocks from here on
     MsmPlan plan;
     {
         sc* aL = W.p; sc* aR = W.p + (size_t)n * B; sc* aO = W.p + (size_t)2 * n * B;
@@ -238,6 +272,7 @@ static int prove_job_begin(const bpr1cs_gens* g, const bpr1cs_circuit* c, const 
             // A_I1 with the repeated S-box wires merged: 2 terms per S-box instead of 5 (see K_merge_points).  The merged
             // tables belong to (circuit, generator handle); the first job that needs them builds them on the heavy stream.
             const uint8_t* mtab = nullptr;
+            TabCfg mtc{};
             {
                 std::lock_guard<std::mutex> lk(c->mt_mu);
                 bpr1cs_circuit::MergedTab*& mt = c->mt[g];
@@ -246,8 +281,9 @@ static int prove_job_begin(const bpr1cs_gens* g, const bpr1cs_circuit* c, const 
                     ArenaScope persistent(nullptr);   // the tables outlive the job (and their construction scratch is a one-off)
                     DevBuf<ge> mp((size_t)2 * T3);
                     launch(T3, K_merge_points{g->pts.p, c->trip.p, mp.p, T3, baseG, baseH}, st);
-                    mt->tab.alloc((size_t)2 * T3 * g->tc.base_bytes());
-                    launch((uint64_t)2 * T3 * g->tc.windows, K_build_table{mp.p, mt->tab.p, g->tc}, st);
+                    mt->tc = merged_tab_cfg(g, T3);
+                    mt->tab.alloc((size_t)2 * T3 * mt->tc.base_bytes());
+                    launch((uint64_t)2 * T3 * mt->tc.windows, K_build_table{mp.p, mt->tab.p, mt->tc}, st);
                     DevBuf<ge> part64(64);
                     mt->ones_pt.alloc(1);
                     launch(64, K_triple_ones_point{g->pts.p, c->trip.p, part64.p, T3, baseG}, st);
@@ -255,6 +291,7 @@ static int prove_job_begin(const bpr1cs_gens* g, const bpr1cs_circuit* c, const 
                     mt->W = g->tc.W; mt->cap = g->cap;
                 }
                 mtab = mt->tab.p;
+                mtc = mt->tc;
                 ones_pt = mt->ones_pt.p;
             }
             const uint32_t nr = (uint32_t)c->h_rest.size();
@@ -266,7 +303,7 @@ static int prove_job_begin(const bpr1cs_gens* g, const bpr1cs_circuit* c, const 
             // but exceptional proofs: 608 real terms instead of 18 656 for the depth-32 circuit
             MsmSeg oRest{aO, nr, 1, 1, 0, baseG, MSM_MONT, c->rest.p, 0}, oOnes{aO, 2 * T3, 1, 1, 0, baseG, MSM_MINUS_ONE, c->ones.p, 0};
             // (measured against the plain n-term sum on one box: first launch of a batch 27 -> 13.5 ms)
-            MsmReq rq[4] = {{rG, rH, &partial, &plan, nullptr}, {mG, mH, &partial2, &plan2, mtab}, {oRest, none, &partialO, &planO, nullptr},
+            MsmReq rq[4] = {{rG, rH, &partial, &plan, nullptr}, {mG, mH, &partial2, &plan2, mtab, 0, &mtc}, {oRest, none, &partialO, &planO, nullptr},
                             {oOnes, none, &partialO1, &planO1, nullptr, 256}};
             run_msm_multi(g, rq, 4, B, st, stats);  // the sums that need the wires only share one launch
             finI.partial = partial.p;
@@ -289,19 +326,6 @@ static int prove_job_begin(const bpr1cs_gens* g, const bpr1cs_circuit* c, const 
         launch(B, K_msm_finish{g->tab.p, g->tc, partial.p, blind.p + 2 * (size_t)B, nullptr, AOS.p + 2 * (size_t)B * 32, B, plan.nchunks, 1}, st);
     }
     pt.mark(st);
-
-    // ---- from here on the job's scratch comes from the handle's arena, shared with the other job in flight: that job's
-    // back phase is AHEAD of this one on the heavy stream (FIFO), and its tail - the only part that runs on another stream -
-    // works on copies of its own (IpaIO::TailKeep) and on buffers allocated BEFORE the arena is installed (the proof bytes
-    // `d_out` among them), so stream order alone keeps the two jobs apart: no event, no wait.
-    // what the IPA tail and the proof assembly read stays the job's own: challenges, T commitments, t_x.., L/R, u_k
-    DevBuf<sc> chal((size_t)CH_COUNT * B), txs((size_t)3 * B), uk((size_t)(lgN ? lgN : 1) * 2 * B);
-    DevBuf<uint8_t> Tc((size_t)5 * B * 32), LR((size_t)(lgN ? lgN : 1) * 2 * B * 32);
-    const size_t plen = bpr1cs_proof_len(c);
-    job->plen = plen;
-    DevBuf<uint8_t> d_out((size_t)B * plen);   // written by K_assemble and read back on the TAIL stream: never an arena block
-    const bool shared_back = g->opts.shared_back.load() != 0;
-    ArenaScope back_arena(shared_back ? &g->arena : &g->front[slot], shared_back);   // (not shared: the job's own arena goes on)
 
     // ---- P3/P4: challenges, flatten, t(x), T commitments, l(x), r(x)
     launch(B, K_transcript_A{tr.p, AOS.p, chal.p, B}, st);
@@ -340,6 +364,9 @@ static int prove_job_begin(const bpr1cs_gens* g, const bpr1cs_circuit* c, const 
     launch(B, K_transcript_T{tr.p, Tc.p, tco.p, blind.p, wvec.p + (size_t)3 * n * B, vbl_m.p, chal.p, txs.p, B, m, (uint64_t)N}, st);
     DevBuf<sc> a((size_t)N * B), bb((size_t)N * B);
     launch((uint64_t)N * B, K_lr_eval{W.p, wvec.p, plo.p, phi.p, chal.p, a.p, bb.p, cG.p, cH.p, B, H, n}, st);
+    // the wires and blinding vectors are dead: wiped here (upstream: clear_on_drop), and the next job in flight may write its own
+    dev_zero(W.p, W.bytes(), st);
+    if (shared) dev_event_record(g->w_free_ev, st);
     pt.mark(st);
 
     // ---- P5: inner-product argument
@@ -390,7 +417,6 @@ static int prove_job_begin(const bpr1cs_gens* g, const bpr1cs_circuit* c, const 
     }
     // secrets do not stay in the allocator's cache (upstream wipes them with clear_on_drop): witness, blindings, the
     // blinding vectors s_L / s_R, the l / r vectors and the Poseidon scratch are zeroed before their blocks are released
-    dev_zero(W.p, W.bytes(), st);
     dev_zero(blind.p, blind.bytes(), st);
     dev_zero(v_raw.p, v_raw.bytes(), st); dev_zero(vbl_raw.p, vbl_raw.bytes(), st);
     dev_zero(v_m.p, v_m.bytes(), st); dev_zero(vbl_m.p, vbl_m.bytes(), st);
@@ -435,7 +461,7 @@ static int prove_job_end(bpr1cs_job* job, uint8_t* proofs_out, uint8_t* commitme
             acc->jobs++;
             if (job->B > acc->job_proofs) acc->job_proofs = job->B;
             for (int i = 0; i < 6; i++) acc->phase_ms[i] += ph[i];
-            acc->msm_ms += job->msm.ms; acc->msm_launches += job->msm.launches; acc->msm_terms += job->msm.terms;
+            acc->msm_ms += job->msm.ms; acc->msm_launches += job->msm.launches; acc->msm_terms += job->msm.terms; acc->msm_adds += job->msm.adds;
         }
     }
     job_release(job);
@@ -453,22 +479,24 @@ static uint32_t auto_job_proofs(const bpr1cs_gens* g, const bpr1cs_circuit* c, b
     const uint32_t r = std::min<uint32_t>((uint32_t)std::max(0, g->opts.unfold.load()), c->lgN);
     const size_t Mr = N >> r, nfl = c->h_slot_chunk.empty() ? 0 : c->h_slot_chunk[3 * n + m];
     const size_t tail_m = std::min<size_t>(N, 128);
-    const size_t front = 160 * n + 64 * (2 * n + 7) + 200 * m + 4 * 32 * (size_t)c->px_stride + 512 + c->lgN * 128 +
-                         tail_m * (2 * 32 + 2 * sizeof(ge)) + (tail_m / 2) * (4 * VB_MULT * sizeof(ge_cached) + 4 * VB_WORDS * 4) + 2 * VB_WINDOWS * 17 * sizeof(ge);
+    const size_t front_shared = 160 * n + 64 * (2 * n + 7);   // W and the raw TranscriptRng output: ONE copy for the jobs in flight
+    const size_t front = 200 * m + 4 * 32 * (size_t)c->px_stride + 512 + c->lgN * 128 +
+                         tail_m * (2 * 32 + 2 * sizeof(ge)) + (tail_m / 2) * (4 * VB_MULT * sizeof(ge_cached) + 4 * VB_WORDS * 4) + 2 * VB_WINDOWS * 5 * sizeof(ge);
     const size_t others = 32 * (3 * n + m + nfl) + 64 * N, vt = r < c->lgN ? (size_t)VB_MULT * 4 * std::max<size_t>(1, Mr / 2) * sizeof(ge_cached) : 0;
-    const size_t back = std::max(others, vt) + 64 * N + 2 * Mr * sizeof(ge) + 4 * VB_WORDS * 4 * std::max<size_t>(1, Mr / 2) + 2 * VB_WINDOWS * 17 * sizeof(ge) + 30000;
-    size_t fixed = (size_t)3 << 30;   // chunk partial sums of the MSM launches (~2^21 points each, whatever the batch), transposition staging
+    const size_t back = std::max(others, vt) + 64 * N + 2 * VB_WINDOWS * sizeof(ge) + 30000;   // (folded generators, digits, window sums: inside the dead rows of l / r)
+    size_t fixed = (size_t)5 << 29;   // chunk partial sums of the MSM launches (~2^21 points each, whatever the batch: six buffers in the shared arena), staging
     if (have_program && !c->h_trip.empty()) {
         std::lock_guard<std::mutex> lk(c->mt_mu);
         auto it = c->mt.find(g);
-        if (it == c->mt.end() || !it->second->tab.p) fixed += 2 * c->h_trip.size() * g->tc.base_bytes();
+        if (it == c->mt.end() || !it->second->tab.p) fixed += 2 * c->h_trip.size() * merged_tab_cfg(g, (uint32_t)c->h_trip.size()).base_bytes();
     }
-    const size_t avail = dev_free_memory() + g->arena.bytes() + g->front[0].bytes() + g->front[1].bytes();
-    const size_t reserve = (size_t)2 << 30;
+    const size_t avail = dev_free_memory() + g->arena.bytes() + g->front[0].bytes() + g->front[1].bytes() + g->shared_front.bytes();
+    const size_t reserve = (size_t)4 << 30;   // what must stay free at the peak (the HIP runtime's own needs, another handle's small jobs)
     const uint64_t grid_per_proof = (uint64_t)4 * c->N + 3ull * c->n + c->m + 64;
-    for (uint32_t J = 4096; J > 64; J >>= 1) {
+    static const uint32_t sizes[] = {4096, 3584, 3072, 2560, 2048, 1536, 1024, 768, 512, 384, 256, 128};
+    for (uint32_t J : sizes) {
         if (grid_per_proof * J > 0xffffffffull) continue;
-        if ((double)J * ((double)front * in_flight + (double)back) + (double)fixed + (double)reserve <= (double)avail) return J;
+        if ((double)J * ((double)front * in_flight + (double)front_shared + (double)back) + (double)fixed + (double)reserve <= (double)avail) return J;
     }
     return 64;
 }
@@ -487,7 +515,23 @@ static int prove_batch_impl(const bpr1cs_gens* g, const bpr1cs_circuit* c, const
     const uint64_t grid_per_proof = (uint64_t)4 * c->N + 3ull * c->n + c->m + 64;
     const size_t grid_max = (size_t)std::min<uint64_t>(0xffffffffull / grid_per_proof, 1u << 20);
     if (grid_max == 0) return BPR1CS_ERR_INVALID_ARGUMENT;
-    if (J == 0) J = batch <= 64 ? batch : auto_job_proofs(g, c, wires == nullptr, depth);
+    const bool automatic = J == 0;
+    auto remember = [&](size_t j, bool overwrite) {   // the automatic choice belongs to (circuit, handle): the same for every call
+        std::lock_guard<std::mutex> lk(c->mt_mu);
+        bpr1cs_circuit::MergedTab*& mt = c->mt[g];
+        if (!mt) mt = new bpr1cs_circuit::MergedTab();
+        if (overwrite || !mt->job_proofs) mt->job_proofs = (uint32_t)j;
+        return (size_t)mt->job_proofs;
+    };
+    if (automatic) {
+        size_t known = 0;
+        {
+            std::lock_guard<std::mutex> lk(c->mt_mu);
+            auto it = c->mt.find(g);
+            if (it != c->mt.end()) known = it->second->job_proofs;
+        }
+        J = known ? known : remember(auto_job_proofs(g, c, wires == nullptr, depth), false);
+    }
     J = std::min(J, grid_max);
     const size_t m = c->m, plen = bpr1cs_proof_len(c), wn = 3 * (size_t)c->n;
     struct Pending { bpr1cs_job* job; size_t first; };
@@ -501,28 +545,35 @@ static int prove_batch_impl(const bpr1cs_gens* g, const bpr1cs_circuit* c, const
         if (e != BPR1CS_OK && rc == BPR1CS_OK) rc = e;
     };
     size_t done = 0;
+    bool retried = false;
     while (done < batch && rc == BPR1CS_OK) {
-        // full jobs of J proofs; what is left once fewer than 2 J remain is cut into two equal jobs (no short straggler whose
-        // latency-bound front would have nothing to hide behind).  The first job is the largest: it sizes the shared arena.
-        const size_t rest = batch - done, take = (rest >= 2 * J || rest <= J) ? std::min(J, rest) : (rest + 1) / 2;
+        // full jobs of J proofs and a shorter last one.  The first job is the largest: it sizes the handle's arenas.
+        const size_t rest = batch - done, take = std::min(J, rest);
         bpr1cs_job* job = nullptr;
         int e = prove_job_begin(g, c, n_init == 1 ? init : init + done, n_init == 1 ? 1 : take, tr_out != nullptr,
                                 values ? values + done * m * 32 : nullptr, v_blindings ? v_blindings + done * m * 32 : nullptr,
                                 rng_seeds ? rng_seeds + done * 32 : nullptr, wires ? wires + done * wn * 32 : nullptr, take, &job);
-        if (e == BPR1CS_ERR_OUT_OF_MEMORY && take > 64) {
-            // less memory than estimated (another process, a second handle): let the jobs in flight finish, hand the scratch back
-            // and go on with jobs of half the size
+        if (e == BPR1CS_ERR_OUT_OF_MEMORY && (take > 64 || !retried)) {
+            // out of memory: let the jobs in flight finish and hand the scratch back (arenas sized for the smaller jobs of an
+            // earlier call sit next to the blocks that replace them until their last user has drained) - then the same job once
+            // more; if that fails too there is less memory than estimated (another process, a second handle): half the job size
             while (!fl.empty()) finish_oldest();
             g->arena.release();
             g->front[0].release();
             g->front[1].release();
+            g->shared_front.release();
 #if !defined(BPR1CS_HOSTSIM)
             dev_pool().release_all();
 #endif
-            J = std::max<size_t>(64, take / 2);
+            if (retried) {
+                J = std::max<size_t>(64, take / 2);
+                if (automatic) remember(J, true);
+            }
+            retried = !retried;
             continue;
         }
         if (e != BPR1CS_OK) { rc = e; break; }
+        retried = false;
         fl.push_back({job, done});
         done += take;
         if ((int)fl.size() >= depth) finish_oldest();

@@ -38,6 +38,7 @@ int bpr1cs_gens_release_scratch(bpr1cs_gens* g) {
     g->arena.release();
     g->front[0].release();
     g->front[1].release();
+    g->shared_front.release();
     return BPR1CS_OK;
 }
 int bpr1cs_release_cached_memory(void) {
@@ -79,6 +80,8 @@ int bpr1cs_gens_create_opts(uint32_t cap, const int32_t* pairs, size_t n_pairs, 
     for (int a = 0; a < 2; a++)
         for (int b = 0; b < 3; b++) HIPCHK(hipStreamCreateWithPriority(&g->jstream[a][b], hipStreamNonBlocking, b == 0 ? prio_lo : prio_hi));
 #endif
+    dev_event_create(&g->w_free_ev);
+    dev_event_create(&g->rng_free_ev);
     CallScope scope(g->stream);
     uint32_t nb = 2 + 2 * cap;
     // uniform bytes: B~ <- SHA3-512(compress(B)); G/H <- SHAKE256("GeneratorsChain"||'G'|'H'||LE32(0))  
@@ -115,6 +118,9 @@ void bpr1cs_gens_destroy(bpr1cs_gens* g) {
     g->arena.release();
     g->front[0].release();
     g->front[1].release();
+    g->shared_front.release();
+    dev_event_destroy(&g->w_free_ev);
+    dev_event_destroy(&g->rng_free_ev);
 #if !defined(BPR1CS_HOSTSIM)
     if (g->stream) (void)hipStreamDestroy(g->stream);
     for (int a = 0; a < 2; a++)

@@ -54,7 +54,7 @@ static void verify_front(VerifyCtx& v, const bpr1cs_gens* g, const bpr1cs_circui
     v.P = 8 + m + 2 * lgN;
 }
 
-extern "C" int bpr1cs_verify_batch(const bpr1cs_gens* g, const bpr1cs_circuit* c, const uint8_t* label, size_t label_len,
+static int verify_batch_once(const bpr1cs_gens* g, const bpr1cs_circuit* c, const uint8_t* label, size_t label_len,
                                    const uint8_t* proofs, const uint8_t* commitments, const uint8_t* verifier_rng_seeds, size_t batch,
                                    int* ok_out) {
     if (!ok_out) return BPR1CS_ERR_INVALID_ARGUMENT;
@@ -124,7 +124,7 @@ static void verify_combine(CombinedCtx& k, VerifyCtx& v, const uint8_t* batch_se
 // Cross-proof batched verification: one identity test for the whole batch (and, summed over ranks, for the whole job).
 // Returns this rank's partial point; the caller adds the ranks' points (bpr1cs_points_sum) and accepts iff the sum
 // is the identity (32 zero bytes) and every rank reported `wellformed`.
-extern "C" int bpr1cs_verify_batch_combined(const bpr1cs_gens* g, const bpr1cs_circuit* c, const uint8_t* label, size_t label_len,
+static int verify_batch_combined_once(const bpr1cs_gens* g, const bpr1cs_circuit* c, const uint8_t* label, size_t label_len,
                                             const uint8_t* proofs, const uint8_t* commitments, const uint8_t* verifier_rng_seeds,
                                             const uint8_t* batch_seed, uint64_t index_base, size_t batch, uint8_t* partial_point_out,
                                             int* wellformed_out) {
@@ -167,7 +167,7 @@ extern "C" int bpr1cs_verify_batch_combined(const bpr1cs_gens* g, const bpr1cs_c
 // Multi-GPU form of the batched verifier: instead of evaluating the shared-base MSM itself, a rank
 // returns its combined scalar vector; the ranks add their vectors (all_gather / all_reduce of 2N+2 scalars, ~2 MB at
 // N = 32768), each evaluates 1/world of the bases with bpr1cs_msm_fixed, and the points are gathered and summed.
-extern "C" int bpr1cs_verify_batch_scalars(const bpr1cs_gens* g, const bpr1cs_circuit* c, const uint8_t* label, size_t label_len,
+static int verify_batch_scalars_once(const bpr1cs_gens* g, const bpr1cs_circuit* c, const uint8_t* label, size_t label_len,
                                            const uint8_t* proofs, const uint8_t* commitments, const uint8_t* verifier_rng_seeds,
                                            const uint8_t* batch_seed, uint64_t index_base, size_t batch, uint8_t* combined_scalars_out,
                                            uint8_t* own_points_sum_out, int* wellformed_out) {
@@ -211,4 +211,36 @@ extern "C" int bpr1cs_scalars_sum(const uint8_t* vectors, size_t count, size_t l
         sc_store_raw(acc, out + 32 * i);
     }
     return BPR1CS_OK;
+}
+
+// The prover keeps its scratch (the handle's arenas) between calls; a verifier call that finds no memory next to it hands that
+// scratch - and the allocator's cache - back and tries once more (only while no prove job of the handle is in flight).
+template <class F>
+static int with_scratch_retry(const bpr1cs_gens* g, F&& once) {
+    int rc = once();
+    if (rc == BPR1CS_ERR_OUT_OF_MEMORY && g && g->in_flight.load() == 0) {
+        g->arena.release(); g->front[0].release(); g->front[1].release(); g->shared_front.release();
+#if !defined(BPR1CS_HOSTSIM)
+        dev_pool().release_all();
+#endif
+        rc = once();
+    }
+    return rc;
+}
+extern "C" int bpr1cs_verify_batch(const bpr1cs_gens* g, const bpr1cs_circuit* c, const uint8_t* label, size_t label_len,
+                                   const uint8_t* proofs, const uint8_t* commitments, const uint8_t* verifier_rng_seeds, size_t batch,
+                                   int* ok_out) {
+    return with_scratch_retry(g, [&] { return verify_batch_once(g, c, label, label_len, proofs, commitments, verifier_rng_seeds, batch, ok_out); });
+}
+extern "C" int bpr1cs_verify_batch_combined(const bpr1cs_gens* g, const bpr1cs_circuit* c, const uint8_t* label, size_t label_len,
+                                            const uint8_t* proofs, const uint8_t* commitments, const uint8_t* verifier_rng_seeds,
+                                            const uint8_t* batch_seed, uint64_t index_base, size_t batch, uint8_t* partial_point_out,
+                                            int* wellformed_out) {
+    return with_scratch_retry(g, [&] { return verify_batch_combined_once(g, c, label, label_len, proofs, commitments, verifier_rng_seeds, batch_seed, index_base, batch, partial_point_out, wellformed_out); });
+}
+extern "C" int bpr1cs_verify_batch_scalars(const bpr1cs_gens* g, const bpr1cs_circuit* c, const uint8_t* label, size_t label_len,
+                                           const uint8_t* proofs, const uint8_t* commitments, const uint8_t* verifier_rng_seeds,
+                                           const uint8_t* batch_seed, uint64_t index_base, size_t batch, uint8_t* combined_scalars_out,
+                                           uint8_t* own_points_sum_out, int* wellformed_out) {
+    return with_scratch_retry(g, [&] { return verify_batch_scalars_once(g, c, label, label_len, proofs, commitments, verifier_rng_seeds, batch_seed, index_base, batch, combined_scalars_out, own_points_sum_out, wellformed_out); });
 }

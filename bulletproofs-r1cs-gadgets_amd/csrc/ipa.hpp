@@ -91,6 +91,8 @@ static IpaEnd enqueue_ipa(const IpaIO& io, dev_stream_t st, MsmStats* stats) {
         launch((uint64_t)N * B, K_ipa_scalars_geo{va, vb, fac.p, hfp, io.geo, sGp, sHp, B, N >> k, lgNk, facT, hfJ}, st);
     };
     const uint32_t VC = 16;  // chunks per Straus output (8 / 32 / 64 measured within 0.3 %)
+    const uint32_t VC_TAIL = 4;  // ... in the rounds that run on the job's tail stream (at most 256 terms per output, latency bound anyway): a
+                                 // quarter of the window-sum buffer, of which every job slot holds a copy
     // variable-base rounds come in pairs on one set of multiples, generators folded two levels at a time (K_ipa_vb_dig2 / _fold2)
     bool vb_reuse = false;
     auto finisher = [&](const ge* part, uint32_t nch, const sc* c, uint8_t* out) {
@@ -120,7 +122,7 @@ static IpaEnd enqueue_ipa(const IpaIO& io, dev_stream_t st, MsmStats* stats) {
                 T.a.alloc((size_t)Nk * B); T.bb.alloc((size_t)Nk * B); T.linv.alloc((size_t)2 * B); T.cross.alloc((size_t)2 * B);
                 T.GH.alloc((size_t)2 * Nk * B);
                 T.vtab.alloc((size_t)VB_MULT * 4 * mk * B); T.vdig.alloc((size_t)VB_WORDS * 4 * mk * B);
-                T.vwin.alloc((size_t)2 * VB_WINDOWS * VC * B); T.vsum.alloc((size_t)2 * VB_WINDOWS * B); T.vout.alloc((size_t)2 * B);
+                T.vwin.alloc((size_t)2 * VB_WINDOWS * VC_TAIL * B); T.vsum.alloc((size_t)2 * VB_WINDOWS * B); T.vout.alloc((size_t)2 * B);
             }
             dev_d2d(T.a.p, a, (size_t)Nk * B * sizeof(sc), st);
             dev_d2d(T.bb.p, bb, (size_t)Nk * B * sizeof(sc), st);
@@ -189,7 +191,23 @@ static IpaEnd enqueue_ipa(const IpaIO& io, dev_stream_t st, MsmStats* stats) {
             launch((uint64_t)2 * B, K_pair<K_msm_finish>{fL, finisher(partialR.p, planR.nchunks, crossp + B, Rout), B}, st);
         } else {
             if (k == r) {
-                GH.alloc((size_t)2 * M * B);
+                // The folded generators, the Straus digits and the window sums move into memory that is DEAD from here on: after
+                // r folds the vectors a and b are M = N >> r entries long, rows M.. of their N-row arrays are never read again
+                // (3.75 of 4 GiB each for 4096 depth-32 proofs) - 3.7 GiB less per job than blocks of their own.
+                const size_t dead = r >= 1 ? (size_t)(N - M) * B * sizeof(sc) : 0;
+                const size_t gh_b = (size_t)2 * M * B * sizeof(ge), vwin_b = ((size_t)2 * VB_WINDOWS * VC * B * sizeof(ge) + 255) & ~(size_t)255,
+                             vdig_b = (size_t)VB_WORDS * 4 * (M / 2 ? M / 2 : 1) * B * sizeof(uint32_t);
+                if (gh_b <= dead) GHp = (ge*)(io.a + (size_t)M * B);
+                else { GH.alloc((size_t)2 * M * B); GHp = GH.p; }
+                if (vwin_b + vdig_b <= dead) {
+                    uint8_t* base = (uint8_t*)(io.bb + (size_t)M * B);
+                    vwinp = (ge*)base;
+                    vdigp = (uint32_t*)(base + vwin_b);
+                } else {
+                    vdig.alloc((size_t)VB_WORDS * 4 * (M / 2 ? M / 2 : 1) * B);
+                    vwin.alloc((size_t)2 * VB_WINDOWS * VC * B);
+                    vdigp = vdig.p; vwinp = vwin.p;
+                }
                 const sc* fG = cG; const sc* fH = cH;   // scalars of the folded generators: Montgomery factor vectors, or ...
                 if (geo) {  // ... their closed form, written out once (canonical) where the product scalars of the rounds before lived
                     geo_scalars(k, nullptr, nullptr);
@@ -197,38 +215,38 @@ static IpaEnd enqueue_ipa(const IpaIO& io, dev_stream_t st, MsmStats* stats) {
                 }
                 const uint32_t f_mont = geo ? 0u : 1u;
                 if (B < 32) {
-                    launch_wave((uint64_t)2 * M * B, K_ipa_fold_from_tables{g->tab.p, g->tc, fG, fH, GH.p, B, M, N, baseG, baseH, geo ? 1u : 0u}, st);
+                    launch_wave((uint64_t)2 * M * B, K_ipa_fold_from_tables{g->tab.p, g->tc, fG, fH, GHp, B, M, N, baseG, baseH, geo ? 1u : 0u}, st);
                 } else {
                     // the folded generators through the MSM kernel: output j of a side = the "chunk" of terms i = j (mod M), two
                     // sides = two jobs of one launch (prefetch pipeline, XCD-aware placement of the workgroups sharing a row)
                     MsmLaunch L{};
-                    L.B = B; L.nbk = (B + 63u) / 64u; L.tc = g->tc; L.njobs = 2;
+                    L.B = B; L.nbk = (B + 63u) / 64u; L.njobs = 2;
                     const MsmSeg none{nullptr, 0, 1, 1, 0, 0, 0};
-                    L.job[0] = MsmJob{{MsmSeg{fG, N, N, N, 0, baseG, f_mont}, none}, g->tab.p, GH.p, N / M, M, 1};
-                    L.job[1] = MsmJob{{MsmSeg{fH, N, N, N, 0, baseH, f_mont}, none}, g->tab.p, GH.p + (size_t)M * B, N / M, M, 1};
+                    L.job[0] = MsmJob{{MsmSeg{fG, N, N, N, 0, baseG, f_mont}, none}, g->tab.p, g->tc, GHp, N / M, M, 1};
+                    L.job[1] = MsmJob{{MsmSeg{fH, N, N, N, 0, baseH, f_mont}, none}, g->tab.p, g->tc, GHp + (size_t)M * B, N / M, M, 1};
                     L.wg_end[0] = M * L.nbk; L.wg_end[1] = 2 * M * L.nbk;
-                    launch_msm_kernel(g, L, st, stats, (uint64_t)2 * N * B);
+                    launch_msm_kernel(g, L, st, stats, (uint64_t)2 * N * B, (uint64_t)2 * N * B * g->tc.windows);
                 }
                 const size_t vtab_need = (size_t)VB_MULT * 4 * (M / 2 ? M / 2 : 1) * B;
                 if (!(io.vtab_pre && io.vtab_pre_count >= vtab_need)) vtab.alloc(vtab_need);
-                vdig.alloc((size_t)VB_WORDS * 4 * (M / 2 ? M / 2 : 1) * B);
-                vwin.alloc((size_t)2 * VB_WINDOWS * VC * B);
                 vsum.alloc((size_t)2 * VB_WINDOWS * B);
                 vout.alloc((size_t)2 * B);
                 linv.alloc((size_t)2 * B);
                 launch((uint64_t)2 * B, K_set_one{linv.p}, st);
-                GHp = GH.p; vtabp = vtab.p ? vtab.p : io.vtab_pre; vdigp = vdig.p; vwinp = vwin.p; vsump = vsum.p; voutp = vout.p; linvp = linv.p;
+                vtabp = vtab.p ? vtab.p : io.vtab_pre; vsump = vsum.p; voutp = vout.p; linvp = linv.p;
             }
             const uint32_t remap = 1u;  // XCD-aware workgroup order of the window sums (vb_win_index; +1 % end to end)
             if (!vb_reuse) {
                 // multiples 1P..8P and digits of every term of this round
-                const uint32_t vc = 2 * mk < VC ? 2 * mk : VC;  // chunks of the 2*mk terms of one output
+                const uint32_t vcmax = handed_off ? VC_TAIL : VC;
+                const uint32_t vc = 2 * mk < vcmax ? 2 * mk : vcmax;  // chunks of the 2*mk terms of one output
                 emit((uint64_t)4 * mk * B, K_ipa_vb_tab{a, bb, GHp, linvp, vtabp, vdigp, B, mk, M}, false);
                 emit((uint64_t)2 * VB_WINDOWS * vc * B, K_ipa_vb_win{vtabp, vdigp, vwinp, B, mk, vc, remap, 0}, true);
                 emit((uint64_t)2 * VB_WINDOWS * B, K_ge_reduce{vwinp, vsump, B, 2 * VB_WINDOWS * vc, vc}, false);  // chunk sums -> window sums
             } else {
                 // the round after: same multiples (the generators were not folded), product scalars
-                const uint32_t m0 = 2 * mk, vc = 2 * m0 < VC ? 2 * m0 : VC;
+                const uint32_t vcmax = handed_off ? VC_TAIL : VC;
+                const uint32_t m0 = 2 * mk, vc = 2 * m0 < vcmax ? 2 * m0 : vcmax;
                 emit((uint64_t)4 * m0 * B, K_ipa_vb_dig2{a, bb, linvp, io.uk + (size_t)(k - 1) * 2 * B, vdigp, B, m0}, false);
                 emit((uint64_t)2 * VB_WINDOWS * vc * B, K_ipa_vb_win{vtabp, vdigp, vwinp, B, m0, vc, remap, 1}, true);
                 emit((uint64_t)2 * VB_WINDOWS * B, K_ge_reduce{vwinp, vsump, B, 2 * VB_WINDOWS * vc, vc}, false);

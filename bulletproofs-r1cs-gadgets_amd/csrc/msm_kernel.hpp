@@ -21,7 +21,8 @@
 
 struct MsmJob {
     MsmSeg seg[2];
-    const uint8_t* tab;  // table the job's base indices refer to
+    const uint8_t* tab;  // table the job's base indices refer to ...
+    TabCfg tc;           // ... and its geometry (a circuit's merged S-box tables may use a narrower window than the generator tables)
     ge* partial;         // [nchunks][B] chunk sums (ordinary class)
     uint32_t chunk, nchunks;
     uint32_t interleave; // 0: chunk c = ordinals [c*chunk, (c+1)*chunk) ; 1: chunk c = ordinals c, c + nchunks, c + 2 nchunks, ...
@@ -31,7 +32,7 @@ struct MsmLaunch {
     MsmJob job[MSM_MAX_JOBS];
     uint32_t wg_end[MSM_MAX_JOBS];  // exclusive end of every job's workgroup range
     uint32_t njobs, B, nbk, nwg;    // nbk = ceil(B / 64) workgroups per chunk; nwg = workgroups launched
-    TabCfg tc;
+    uint32_t max_windows;           // over the jobs' tables: sizes the digit buffers (LDS)
 };
 
 // What the body needs from the wavefront it runs in.  Device: the hardware's vote and broadcast.  Simulator: lanes run one after
@@ -127,7 +128,6 @@ MSM_FN void msm_recode(const sc& x, uint16_t* dst, const TabCfg& tc) {
 
 // the work of lane `lane` of logical workgroup `wg_raw` of a launch; msm_dig: [2][windows][64] uint16 (LDS on the device)
 MSM_FN void msm_fixed2_body(const MsmLaunch& L, uint32_t wg_raw, const uint32_t lane, uint16_t* msm_dig) {
-    const TabCfg tc = L.tc;
     uint32_t wg = wg_raw;
     if ((L.nwg & 7u) == 0) wg = (wg & 7u) * (L.nwg >> 3) + (wg >> 3);  // XCD-aware: consecutive logical workgroups share an XCD
     uint32_t j = 0, w0 = 0;
@@ -137,6 +137,7 @@ MSM_FN void msm_fixed2_body(const MsmLaunch& L, uint32_t wg_raw, const uint32_t 
     if (wg >= L.wg_end[L.njobs - 1]) return;  // padding up to a multiple of 8
     j = MsmWave::uniform(j);
     const MsmJob& J = L.job[j];
+    const TabCfg tc = J.tc;
     wg -= w0;
     const uint32_t B = L.B, c = wg / L.nbk, b0 = (wg % L.nbk) * 64u;
     uint32_t b = b0 + lane;
@@ -146,7 +147,7 @@ MSM_FN void msm_fixed2_body(const MsmLaunch& L, uint32_t wg_raw, const uint32_t 
     const uint32_t step = J.interleave ? J.nchunks : 1u;
     const uint32_t lo = J.interleave ? c : c * J.chunk;
     const uint32_t hi = J.interleave ? total : (lo + J.chunk < total ? lo + J.chunk : total);
-    const uint32_t dig_buf = tc.windows * 64u;  // digits of term parity p start at msm_dig[p * dig_buf + lane]
+    const uint32_t dig_buf = L.max_windows * 64u;  // digits of term parity p start at msm_dig[p * dig_buf + lane]
     const size_t row_bytes = (size_t)tc.row * tc.stride;
 
     // fetch the next term whose scalars are not all zero (IPA round 0: the l-vector is zero beyond n)
@@ -235,7 +236,7 @@ MSM_FN void msm_fixed2_body(const MsmLaunch& L, uint32_t wg_raw, const uint32_t 
 #if defined(BPR1CS_HOSTSIM)
 // the simulator's "launch": every lane of every workgroup runs the body, one after the other
 inline void msm_fixed2_sim(const MsmLaunch& L) {
-    std::vector<uint16_t> dig((size_t)2 * L.tc.windows * 64u);
+    std::vector<uint16_t> dig((size_t)2 * L.max_windows * 64u);
     for (uint32_t wg = 0; wg < L.nwg; wg++)
         for (uint32_t lane = 0; lane < 64; lane++) msm_fixed2_body(L, wg, lane, dig.data());
 }

@@ -51,7 +51,7 @@ struct MsmPlan {
 // object.  One instance per prove job (or per synchronous call): nothing is shared between handles or threads.
 struct MsmStats {
     double ms = 0;
-    uint64_t launches = 0, terms = 0;  // terms = scalar*point products (summed over the batch)
+    uint64_t launches = 0, terms = 0, adds = 0;  // terms = scalar*point products (summed over the batch); adds = table additions (terms x windows of their table)
 #if !defined(BPR1CS_HOSTSIM)
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
     hipEvent_t get() {
@@ -86,12 +86,14 @@ static const uint32_t MSM_REDUCE_GROUP = 16;
 // products of the launch summed over the batch (every launch of k_msm_fixed2 goes through here, so that bench.py's roofline
 // object describes the whole kernel: the commit sums, L_k / R_k of the un-folded rounds AND the folded generators).
 // The simulator runs the same body lane by lane (msm_fixed2_sim).
-static void launch_msm_kernel(const bpr1cs_gens* g, MsmLaunch& L, dev_stream_t st, MsmStats* stats, uint64_t terms) {
+static void launch_msm_kernel(const bpr1cs_gens* g, MsmLaunch& L, dev_stream_t st, MsmStats* stats, uint64_t terms, uint64_t adds) {
     L.nwg = (L.wg_end[L.njobs - 1] + 7u) & ~7u;  // a multiple of 8 keeps the XCD-aware remap on
+    L.max_windows = 0;
+    for (uint32_t r = 0; r < L.njobs; r++) L.max_windows = std::max(L.max_windows, L.job[r].tc.windows);
 #if defined(BPR1CS_HOSTSIM)
     (void)g; (void)st;
     msm_fixed2_sim(L);
-    if (stats) { stats->launches++; stats->terms += terms; }
+    if (stats) { stats->launches++; stats->terms += terms; stats->adds += adds; }
 #else
     hipEvent_t e0{}, e1{};
     if (stats) {
@@ -99,13 +101,14 @@ static void launch_msm_kernel(const bpr1cs_gens* g, MsmLaunch& L, dev_stream_t s
         stats->ev.push_back({e0, e1});
         HIPCHK(hipEventRecord(e0, st));
     }
-    const size_t lds = (size_t)2 * g->tc.windows * 64 * sizeof(uint16_t);
+    const size_t lds = (size_t)2 * L.max_windows * 64 * sizeof(uint16_t);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_msm_fixed2<3>), dim3(L.nwg), dim3(64), lds, st, L);
     HIPCHK(hipGetLastError());
     if (stats) {
         HIPCHK(hipEventRecord(e1, st));
         stats->launches++;
         stats->terms += terms;
+        stats->adds += adds;
     }
 #endif
 }
@@ -116,6 +119,7 @@ struct MsmReq {
     const uint8_t* table;  // nullptr = the generator tables of `g`
     uint32_t chunk_hint = 0;  // terms per chunk (0: from the launch geometry).  Sums whose terms are skipped in all but exceptional
                               // proofs (MSM_MINUS_ONE) take few, long chunks: an empty workgroup still costs its dispatch
+    const TabCfg* tc = nullptr;  // geometry of `table` (nullptr: that of the generator tables)
 };
 static void run_msm_multi(const bpr1cs_gens* g, MsmReq* reqs, uint32_t nreq, uint32_t B, dev_stream_t st, MsmStats* stats) {
     if (B < 32) {  // a wavefront per (chunk, 64 proofs) would be mostly idle: lanes take different chunks instead
@@ -127,10 +131,10 @@ static void run_msm_multi(const bpr1cs_gens* g, MsmReq* reqs, uint32_t nreq, uin
             size_t need = ((size_t)nchunks + l1) * B;
             if (q.partial->n < need) q.partial->alloc(need);
             ge* raw = q.partial->p + (size_t)l1 * B;
-            launch_wave((uint64_t)nchunks * B, K_msm_fixed_small{q.table ? q.table : g->tab.p, g->tc, {q.s0, q.s1}, raw, B, q.plan->chunk, nchunks}, st);
+            launch_wave((uint64_t)nchunks * B, K_msm_fixed_small{q.table ? q.table : g->tab.p, q.tc ? *q.tc : g->tc, {q.s0, q.s1}, raw, B, q.plan->chunk, nchunks}, st);
             if (l1) launch((uint64_t)l1 * B, K_ge_reduce{raw, q.partial->p, B, nchunks, MSM_REDUCE_GROUP}, st);
             q.plan->nchunks = l1 ? l1 : nchunks;
-            if (stats) { stats->launches++; stats->terms += (uint64_t)total * B; }
+            if (stats) { stats->launches++; stats->terms += (uint64_t)total * B; stats->adds += (uint64_t)total * B * (q.tc ? q.tc->windows : g->tc.windows); }
         }
         return;
     }
@@ -138,10 +142,10 @@ static void run_msm_multi(const bpr1cs_gens* g, MsmReq* reqs, uint32_t nreq, uin
     struct Lay { uint32_t nchunks, l1, l2; ge* raw; ge* p1; ge* p2; };
     Lay lay[MSM_MAX_JOBS];
     MsmLaunch L{};
-    L.B = B; L.nbk = nbk; L.tc = g->tc;
+    L.B = B; L.nbk = nbk;
     L.njobs = nreq;
     uint32_t wg = 0;
-    uint64_t terms = 0;
+    uint64_t terms = 0, adds = 0;
     for (uint32_t r = 0; r < nreq; r++) {
         MsmReq& q = reqs[r];
         uint32_t total = q.s0.count + q.s1.count;
@@ -162,11 +166,12 @@ static void run_msm_multi(const bpr1cs_gens* g, MsmReq* reqs, uint32_t nreq, uin
         lay[r] = Lay{nchunks, l1, l2, q.partial->p + (size_t)(l1 + l2) * B, q.partial->p + (size_t)l2 * B, q.partial->p};
         q.plan->nchunks = l2 ? l2 : (l1 ? l1 : nchunks);
         terms += (uint64_t)total * B;
+        adds += (uint64_t)total * B * (q.tc ? q.tc->windows : g->tc.windows);
         wg += nchunks * nbk;
-        L.job[r] = MsmJob{{q.s0, q.s1}, q.table ? q.table : g->tab.p, lay[r].raw, q.plan->chunk, nchunks, 0};
+        L.job[r] = MsmJob{{q.s0, q.s1}, q.table ? q.table : g->tab.p, q.tc ? *q.tc : g->tc, lay[r].raw, q.plan->chunk, nchunks, 0};
         L.wg_end[r] = wg;
     }
-    launch_msm_kernel(g, L, st, stats, terms);
+    launch_msm_kernel(g, L, st, stats, terms, adds);
     for (uint32_t r = 0; r < nreq; r++) {
         if (lay[r].l1) launch((uint64_t)lay[r].l1 * B, K_ge_reduce{lay[r].raw, lay[r].p1, B, lay[r].nchunks, MSM_REDUCE_GROUP}, st);
         if (lay[r].l2) launch((uint64_t)lay[r].l2 * B, K_ge_reduce{lay[r].p1, lay[r].p2, B, lay[r].l1, MSM_REDUCE_GROUP}, st);

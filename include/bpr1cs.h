@@ -140,12 +140,14 @@ int bpr1cs_gens_table_info(const bpr1cs_gens* g, uint32_t* window_bits, uint32_t
 #define BPR1CS_OPT_WITNESS_TEAM 2     /* lanes of a wavefront cooperating on one proof during witness synthesis: 4, 8 (default) or 16 */
 #define BPR1CS_OPT_TAIL_ROUNDS 3      /* how many of the LAST inner-product rounds (latency bound) a job enqueues on its own tail stream
                                          instead of the handle's heavy stream (default 7 = the rounds with m_k <= 64; 0 = none) */
-#define BPR1CS_OPT_SHARED_BACK 4      /* 1 (default): the jobs in flight on a handle share the device scratch of their back phases */
+#define BPR1CS_OPT_SHARED_BACK 4      /* 1 (default): the jobs in flight on a handle share the device scratch of their back phases, the wire /
+                                         blinding vectors and the raw TranscriptRng output (each is live for a part of a job only) */
 #define BPR1CS_OPT_FACTOR_VECTORS 5   /* measuring option: 1 = the prover writes the argument's factor vectors out as N x B arrays
                                          (the form bpr1cs_ipa_create always uses) instead of their closed form (default 0) */
 #define BPR1CS_OPT_MSM_THREADS_LOG2 6 /* measuring option: log2 of the (chunk, proof) threads per launch of the MSM kernel (default 21) */
 #define BPR1CS_OPT_JOB_PROOFS 7       /* proofs per device job when bpr1cs_prove_batch cuts a batch into jobs (default 0 = the largest of
-                                         4096, 2048, ... 64 whose working set fits next to the tables: 2048 for N = 32768 on 288 GB) */
+                                         4096, 3584, 3072, 2560, 2048, 1536, 1024 ... 64 whose working set fits next to the tables:
+                                         3072 for N = 32768 on 288 GB) */
 #define BPR1CS_OPT_JOBS_IN_FLIGHT 8   /* device jobs bpr1cs_prove_batch keeps in flight: 1 or 2 (default 2: the latency-bound front of
                                          job k+1 runs next to the multiscalar multiplications of job k) */
 #define BPR1CS_OPT_WINDOW_BITS 16     /* creation only: signed window width W (4..12) of the fixed-base tables.  A term costs
@@ -343,6 +345,7 @@ typedef struct {
     double msm_ms;          /* summed launch durations of the dominant kernel (k_msm_fixed2), events recorded on its own stream */
     uint64_t msm_launches;
     uint64_t msm_terms;     /* scalar*point terms it processed, summed over the batch */
+    uint64_t msm_adds;      /* table additions = terms x windows of the table a term reads (a circuit's merged tables may be narrower) */
 } bpr1cs_prove_stats;
 int bpr1cs_last_prove_stats(bpr1cs_prove_stats* out);
 

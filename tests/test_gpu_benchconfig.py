@@ -61,7 +61,7 @@ def test_vsmt4_depth32_bench_configuration_two_jobs_in_flight(hip_lib, hip_glib,
     assert P2 == PA + PB and C2 == CA + CB
     st = bp.last_prove_stats(hip_lib)
     assert st["jobs"] == 1 and st["job_proofs"] == 2024 and st["msm_launches"] == 7
-    # ... and cut into FOUR jobs (512, 512, 500, 500 proofs), two in flight (what a larger batch or a smaller device gets): the same bytes
+    # ... and cut into FOUR jobs (512, 512, 512, 488 proofs), two in flight (what a larger batch or a smaller device gets): the same bytes
     w11_gens.release_scratch()
     w11_gens.set_option("job_proofs", 512)
     try:

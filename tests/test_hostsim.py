@@ -103,7 +103,7 @@ def test_shipped_msm_loop_on_70_proof_batches(sim_lib, sim_glib):
     """Batches of >= 32 proofs go through msm_fixed2_body (csrc/msm_kernel.hpp) - the body the gfx950 kernel is built from, run
     lane by lane: polarity flips, two-layer order, digit recoding, wave votes on zero scalars, the a_O - 1 form, merged S-box
     tables, the padded round-0 terms, the folded generators as interleaved chunks - and must reproduce the C oracle's bytes for
-    every one of 70 proofs (ragged: 64 + 6 lanes).  Also: ONE call cut into two device jobs of 35 proofs gives the same bytes."""
+    every one of 70 proofs (ragged: 64 + 6 lanes).  Also: ONE call cut into two device jobs (40 + 30 proofs) gives the same bytes."""
     import hashlib
     from cref import COracle
     import frontend_cases as fc
@@ -131,8 +131,21 @@ def test_shipped_msm_loop_on_70_proof_batches(sim_lib, sim_glib):
         gens = bp.Gens(cap, lib=sim_lib)
         P, _ = bp.prove_batch(gens, circ, label, values, blindings, seeds, B)
         assert P == want, name
-        assert bp.last_prove_stats(sim_lib)["jobs"] == 1
+        st = bp.last_prove_stats(sim_lib)
+        assert st["jobs"] == 1 and st["msm_adds"] == st["msm_terms"] * gens.table_info()["windows"]
         gens.set_option("job_proofs", 40)
         P2, _ = bp.prove_batch(gens, circ, label, values, blindings, seeds, B)
         st = bp.last_prove_stats(sim_lib)
-        assert P2 == want and (st["jobs"], st["job_proofs"]) == (2, 35), (name, st)
+        assert P2 == want and (st["jobs"], st["job_proofs"]) == (2, 40), (name, st)
+        if mk is None:
+            # the circuit's merged S-box tables one window bit narrower than the generator tables (what the library does from 8 GiB on):
+            # two table geometries in ONE launch of the kernel, the same bytes
+            import os
+            os.environ["BPR1CS_TEST_NARROW_MERGED"] = "1"
+            try:
+                circ2 = bp.CompiledGadget(gname, ip, sp, lib=sim_lib, glib=sim_glib)
+                P3, _ = bp.prove_batch(gens, circ2, label, values, blindings, seeds, B)
+            finally:
+                os.environ.pop("BPR1CS_TEST_NARROW_MERGED", None)
+            st3 = bp.last_prove_stats(sim_lib)
+            assert P3 == want and st3["msm_adds"] > st3["msm_terms"] * gens.table_info()["windows"]

@@ -79,6 +79,7 @@ pub const BPR1CS_ERR_OUT_OF_MEMORY: i32 = -19;
     pub msm_ms: f64,
     pub msm_launches: u64,
     pub msm_terms: u64,
+    pub msm_adds: u64,
 }
 #[link(name = "bpr1cs_hip")]
 extern "C" {
