@@ -1,16 +1,17 @@
 #!/bin/bash
-# Everything profiles/<tag>_* is made from, in one call on the GPU box:  gpurun -- 'bash tools/profile_round.sh r02z [tests]'
+# Everything profiles/<tag>_* is made from, in one call on the GPU box:  gpurun -- 'bash tools/profile_round.sh r04a [tests]'
 # (counters in their own passes with --kernel-trace only; raw rocprofv3 databases are removed, the summaries stay under gpurun_out/<tag>/)
 tag=${1:-rXX}; out=gpurun_out/$tag; mkdir -p $out
 export TMPDIR=/tmp
-B="--steps 12 --warmup 1 --cpu-proofs 0"
-timeout 900 python bench.py 2> $out/bench_default.err | grep -a "^{" | tail -1 > $out/bench_default.json; cut -c1-200 $out/bench_default.json
-timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 8 --warmup 1 --cpu-proofs 0 2> $out/bench_torchrun.err | grep -a "^{" | tail -1 > $out/bench_torchrun_1rank.json
-timeout 600 python bench.py --pipeline 1 --steps 6 --cpu-proofs 0 2>/dev/null | grep -a "^{" | tail -1 > $out/bench_sync.json
+B="--steps 16 --warmup 4 --cpu-proofs 0 --configs none"
+# the driver's command (all configurations in the one line), then the same under torchrun with one rank, then one job in flight
+timeout 900 python bench.py --steps 20 --warmup 5 2> $out/bench_default.err | grep -a "^{" | tail -1 > $out/bench_default.json; cut -c1-200 $out/bench_default.json
+timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 16 --warmup 4 --cpu-proofs 0 --configs none 2> $out/bench_torchrun.err | grep -a "^{" | tail -1 > $out/bench_torchrun_1rank.json
+timeout 600 python bench.py --opt jobs_in_flight=1 --steps 8 --warmup 4 --cpu-proofs 0 --configs none 2>/dev/null | grep -a "^{" | tail -1 > $out/bench_sync.json
 for c in c2 c3 c5 vsmt4_d128 vsmt2_d253; do
-  s=12; [ $c = vsmt4_d128 ] && s=6; [ $c = vsmt2_d253 ] && s=4
-  timeout 900 python bench.py --config $c --steps $s 2>&1 | grep -a "^{" | tail -1 > $out/bench_$c.json
-  timeout 900 rocprofv3 --kernel-trace --stats -d $out/kt_$c -o out -- python bench.py --config $c --steps $s --warmup 1 --cpu-proofs 0 > $out/kt_$c.log 2>&1
+  s=16; [ $c = vsmt4_d128 ] && s=6; [ $c = vsmt2_d253 ] && s=8
+  timeout 900 python bench.py --config $c --steps $s --warmup 4 2>&1 | grep -a "^{" | tail -1 > $out/bench_$c.json
+  timeout 900 rocprofv3 --kernel-trace --stats -d $out/kt_$c -o out -- python bench.py --config $c --steps $s --warmup 4 --cpu-proofs 0 > $out/kt_$c.log 2>&1
   python tools/rocprof_summary.py stats $out/kt_$c > $out/${c}_kernel_stats.txt 2>&1
   rm -rf $out/kt_$c
 done
@@ -19,11 +20,10 @@ python tools/rocprof_summary.py stats $out/kt > $out/kernel_stats.txt 2>&1
 python tools/trace_perjob.py $out/kt 30 > $out/pipeline_perjob.txt 2>&1; head -8 $out/pipeline_perjob.txt
 python tools/trace_timeline.py $out/kt > $out/pipeline_timeline.txt 2>/dev/null
 for c in FETCH_SIZE WRITE_SIZE GRBM_GUI_ACTIVE; do
-  timeout 600 rocprofv3 --pmc $c --kernel-trace -d $out/pmc_$c -o out -- python bench.py --steps 4 --warmup 1 --cpu-proofs 0 > $out/pmc_$c.log 2>&1
+  timeout 600 rocprofv3 --pmc $c --kernel-trace -d $out/pmc_$c -o out -- python bench.py --steps 8 --warmup 4 --cpu-proofs 0 --configs none > $out/pmc_$c.log 2>&1
 done
 python tools/rocprof_summary.py pmc $out/pmc_FETCH_SIZE $out/pmc_WRITE_SIZE > $out/pmc_hbm_traffic.txt 2>&1
 python tools/rocprof_summary.py pmc $out/pmc_GRBM_GUI_ACTIVE > $out/pmc_clock.txt 2>&1
 rm -rf $out/kt $out/pmc_FETCH_SIZE $out/pmc_WRITE_SIZE $out/pmc_GRBM_GUI_ACTIVE
 [ -x tools/ubench ] && timeout 300 tools/ubench > $out/ubench.txt 2>&1
-[ -x tools/msm_ubench ] && timeout 300 tools/msm_ubench 32768 1024 11 3 2097152 3 > $out/msm_ubench.txt 2>&1
 if [ "$2" = tests ]; then timeout 1700 python -m pytest tests -m gpu -x -q > $out/gputests.txt 2>&1; tail -3 $out/gputests.txt; fi
