@@ -111,12 +111,12 @@ extern "C" void hs_ge_madd_t_limbs(const int32_t* p, const int32_t* q, int negat
         fe_tobytes(*c[k], out_bytes + 32 * k);
     }
 }
-// sum_k s_k * P_k over a freshly built table (both storage formats, any window width): exercises tab_digit's
+// sum_k s_k * P_k over a freshly built table (any window width): exercises tab_digit's
 // top-window rule, the identity slot and the table-class accumulator chain.  pts: compressed; scalars canonical.
 #include "kernels.hpp"
 #include <vector>
-extern "C" int hs_table_msm(const uint8_t* pts, const uint8_t* scalars, uint32_t n, uint32_t W, uint32_t fmt, uint32_t stride, uint8_t* out) {
-    TabCfg tc = tab_cfg(W, fmt, stride);
+extern "C" int hs_table_msm(const uint8_t* pts, const uint8_t* scalars, uint32_t n, uint32_t W, uint8_t* out) {
+    TabCfg tc = tab_cfg(W);
     std::vector<ge> P(n);
     for (uint32_t i = 0; i < n; i++)
         if (!ge_decompress(pts + 32 * i, P[i])) return 0;
