@@ -49,7 +49,7 @@ def build_workload(bp, levels, batch, n_leaves, seed_base):
 # batch = proofs per GPU per step; short = (warm-up steps, timed steps) of the configuration's short run inside the headline run;
 # fixture = its batch in tests/golden/fullsize_digests.json (the C oracle's digest of every proof) when the inputs are the same
 CONFIGS = {
-    "c2": dict(metric="R1CS proofs/sec (Poseidon 2:1 cube-S-box preimage)", batch=4096, cpu_proofs=48, short=(2, 8), fixture="c2_poseidon2_cube_x4096",
+    "c2": dict(metric="R1CS proofs/sec (Poseidon 2:1 cube-S-box preimage)", batch=4096, cpu_proofs=48, short=(8, 48), fixture="c2_poseidon2_cube_x4096",
                workload="gadget_poseidon 2:1 Cube-S-box preimage proof (148 rounds; reference src/gadget_poseidon.rs:692-790)",
                build=lambda bp, B, base, a: wl.poseidon_2to1_cube(bp, None, B, index_base=base)),
     "c3": dict(metric="R1CS proofs/sec (Poseidon VSMT-2 depth-32)", batch=1024, cpu_proofs=2, short=(4, 8), fixture="c3_vsmt2_d32_x1024",
@@ -59,7 +59,7 @@ CONFIGS = {
                fixture_build=lambda bp: wl.vsmt4(bp, None, 32, 2024, 64, 0),
                workload=None,
                build=lambda bp, B, base, a: wl.vsmt4(bp, None, a.depth, B, a.leaves if a.leaves > 0 else B, base)),
-    "c5": dict(metric="R1CS proofs/sec (MiMC-322 preimage + set membership)", batch=8192, cpu_proofs=32, short=(2, 4), fixture="c5_mimc_set_x8192",
+    "c5": dict(metric="R1CS proofs/sec (MiMC-322 preimage + set membership)", batch=8192, cpu_proofs=32, short=(4, 24), fixture="c5_mimc_set_x8192",
                workload="gadget_mimc preimage + gadget_set_membership (k = 7) on one prover (reference src/gadget_mimc.rs:92-175, src/gadget_set_membership.rs:93-171)",
                build=lambda bp, B, base, a: wl.mimc_set_membership(B, index_base=base)),
     "vsmt4_d128": dict(metric="R1CS proofs/sec (Poseidon VSMT-4 depth-128, as shipped)", batch=1024, cpu_proofs=1, short=(2, 3), fixture="vsmt4_d128_x70",

@@ -493,7 +493,9 @@ static uint32_t auto_job_proofs(const bpr1cs_gens* g, const bpr1cs_circuit* c, b
     const size_t avail = dev_free_memory() + g->arena.bytes() + g->front[0].bytes() + g->front[1].bytes() + g->shared_front.bytes();
     const size_t reserve = (size_t)4 << 30;   // what must stay free at the peak (the HIP runtime's own needs, another handle's small jobs)
     const uint64_t grid_per_proof = (uint64_t)4 * c->N + 3ull * c->n + c->m + 64;
-    static const uint32_t sizes[] = {4096, 3584, 3072, 2560, 2048, 1536, 1024, 768, 512, 384, 256, 128};
+    // (small circuits: measured 104 k / 116 k / 126 k / 128 k proofs/s at 4096 / 8192 / 16384 / 32768 proofs per job for the 2:1 Poseidon
+    // preimage circuit, 62.8 k / 69.0 k / 71.6 k / 70.5 k for MiMC + set membership)
+    static const uint32_t sizes[] = {16384, 12288, 8192, 6144, 4096, 3584, 3072, 2560, 2048, 1536, 1024, 768, 512, 384, 256, 128};
     for (uint32_t J : sizes) {
         if (grid_per_proof * J > 0xffffffffull) continue;
         if ((double)J * ((double)front * in_flight + (double)front_shared + (double)back) + (double)fixed + (double)reserve <= (double)avail) return J;

@@ -146,8 +146,8 @@ int bpr1cs_gens_table_info(const bpr1cs_gens* g, uint32_t* window_bits, uint32_t
                                          (the form bpr1cs_ipa_create always uses) instead of their closed form (default 0) */
 #define BPR1CS_OPT_MSM_THREADS_LOG2 6 /* measuring option: log2 of the (chunk, proof) threads per launch of the MSM kernel (default 21) */
 #define BPR1CS_OPT_JOB_PROOFS 7       /* proofs per device job when bpr1cs_prove_batch cuts a batch into jobs (default 0 = the largest of
-                                         4096, 3584, 3072, 2560, 2048, 1536, 1024 ... 64 whose working set fits next to the tables:
-                                         3072 for N = 32768 on 288 GB) */
+                                         16384, 12288, 8192 ... 4096, 3584, 3072 ... 64 whose working set fits next to the tables:
+                                         4096 for N = 32768 on 288 GB) */
 #define BPR1CS_OPT_JOBS_IN_FLIGHT 8   /* device jobs bpr1cs_prove_batch keeps in flight: 1 or 2 (default 2: the latency-bound front of
                                          job k+1 runs next to the multiscalar multiplications of job k) */
 #define BPR1CS_OPT_WINDOW_BITS 16     /* creation only: signed window width W (4..12) of the fixed-base tables.  A term costs
