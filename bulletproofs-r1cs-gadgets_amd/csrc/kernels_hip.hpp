@@ -142,7 +142,10 @@ __device__ inline void lds_order() { __syncthreads(); }  // one wavefront per wo
 // blinding stream is byte-identical for every compiler version.
 #define LDS_HANDOFF() do { __atomic_signal_fence(__ATOMIC_SEQ_CST); __builtin_amdgcn_wave_barrier(); __atomic_signal_fence(__ATOMIC_SEQ_CST); } while (0)
 __global__ void __launch_bounds__(64) k_rng_stream(const strobe* rng_in, uint64_t* raw_out, int* err, uint32_t B, uint32_t draws) {
-    __builtin_amdgcn_s_setprio(3);  // one long dependent chain per state: take every issue slot it can use
+    // one long dependent chain per state: take every issue slot it can use.  (Round 4 measured the wave priorities of the two front
+    // kernels - (chain, witness) = (3,2) / (0,0) / (1,1) / (3,0) / (0,2): 2951 / 2945 / 2934 / 2941 / 2932 proofs/s on a box whose clock
+    // sagged 0.7 % over the series - what the front costs the co-running sums (+5 % on their launches) is its work, not the arbitration.)
+    __builtin_amdgcn_s_setprio(3);
     __shared__ uint64_t xch[2][32];      // [half][lane]: rho(theta(A)) for the pi/chi gather
     __shared__ uint64_t colp[2][8];      // [half][x]: column parities, accumulated by LDS atomics
     const uint32_t lane = threadIdx.x, i = lane & 31u, half = lane >> 5;
