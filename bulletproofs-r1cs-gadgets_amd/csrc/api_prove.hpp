@@ -548,6 +548,8 @@ static int prove_batch_impl(const bpr1cs_gens* g, const bpr1cs_circuit* c, const
     };
     size_t done = 0;
     bool retried = false;
+    // (A smaller first job - a quarter of the size, so that its exposed TranscriptRng chain is shorter and the full-size jobs start
+    // sooner - was measured in round 4: 3041-3049 against 3077-3090 proofs/s at 20 steps; the extra job costs more than it hides.)
     while (done < batch && rc == BPR1CS_OK) {
         // full jobs of J proofs and a shorter last one.  The first job is the largest: it sizes the handle's arenas.
         const size_t rest = batch - done, take = std::min(J, rest);
