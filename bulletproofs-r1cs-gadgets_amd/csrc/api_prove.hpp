@@ -104,7 +104,7 @@ static int prove_job_begin(const bpr1cs_gens* g, const bpr1cs_circuit* c, const 
     if (!have_device()) return BPR1CS_ERR_NO_DEVICE;
     if (g->cap < c->N) return BPR1CS_ERR_INVALID_GENERATORS_LENGTH;
     if (!wires && !c->has_program) return BPR1CS_ERR_MISSING_ASSIGNMENT;
-    // the largest grid of the call must fit 2^32 threads (N = 32768: batch <= 26 000; serve larger jobs in several calls)
+    // the largest grid of a JOB must fit 2^32 threads (N = 32768: 26 000 proofs; bpr1cs_prove_batch cuts larger batches into jobs)
     if (batch > (1u << 20) || ((uint64_t)4 * c->N + 3ull * c->n + c->m + 64) * batch > 0xffffffffull) return BPR1CS_ERR_INVALID_ARGUMENT;
     // Scalar inputs are canonical encodings (Scalar::to_bytes); anything else is refused here
     if (c->m && (!host_scalars_canonical(values, batch * c->m) || !host_scalars_canonical(v_blindings, batch * c->m))) return BPR1CS_ERR_INVALID_ARGUMENT;

@@ -31,6 +31,8 @@ def test_c_caller_proves_the_benchmark_workload(hip_lib, hip_glib, tmp_path):
     gens = bp.Gens(32768, lib=hip_lib)
     want, _ = bp.prove_batch_raw(gens, circ, w["label"], w["values"][:256 * w["m"] * 32], w["blindings"][:256 * w["m"] * 32], w["seeds"][:256 * 32], 256)
     gens.close(); circ.close()
+    import gc
+    gc.collect()                        # (what this process still holds on the device is what the C program cannot use: its job size follows)
     bp.release_cached_memory(hip_lib)
     out = tmp_path / "proofs.bin"
     r = subprocess.run([exe, str(inp), bp.POSEIDON_PARAMS_PATH, "8192", "16384", str(out)], capture_output=True, text=True, timeout=900)
@@ -39,7 +41,7 @@ def test_c_caller_proves_the_benchmark_workload(hip_lib, hip_glib, tmp_path):
     print("C caller:", res)
     got = out.read_bytes()
     assert got[:len(want)] == want                      # the same bytes as through ctypes
-    assert res["n"] == 18656 and res["m"] == 100 and res["jobs"] == 16384 // res["job_proofs"]
+    assert res["n"] == 18656 and res["m"] == 100 and res["jobs"] == -(-16384 // res["job_proofs"])
     assert res["job_proofs"] >= 2048                    # the library's own job size (4096 next to W = 11 tables on 288 GB)
     assert res["proofs_per_s"] > 2400                   # bench.py: 2870-3008 on the boxes of round 4
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
