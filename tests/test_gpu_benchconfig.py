@@ -200,3 +200,28 @@ def test_vsmt2_as_shipped_depth_253(hip_lib, hip_glib):
     finally:
         gens.close()
         bp.release_cached_memory(hip_lib)
+
+
+def test_two_circuits_alternating_in_small_jobs_on_one_handle(hip_lib, hip_glib):
+    """One generator handle, two circuits of very different shape (8-level VSMT-4: n = 4664, N = 8192; Poseidon 2:1 Cube: n = 376),
+    each batch cut into 64-proof jobs with two in flight: the handle's arenas are grown, shrunk and shared across circuits, the merged
+    tables of both circuits live side by side - EVERY proof against the digest fixture, three rounds."""
+    import fullsize_cases as fc
+    bp = importlib.import_module("bulletproofs-r1cs-gadgets_amd")
+    ca = fc.CASES["vsmt4_l8_x70"](bp, hip_glib)
+    cb = fc.CASES["c2_poseidon2_cube_x4096"](bp, hip_glib)
+    circa = bp.CompiledGadget("vsmt_4", ca["ip"], ca["sp"], lib=hip_lib, glib=hip_glib)
+    circb = bp.CompiledGadget("poseidon_hash_2", cb["ip"], cb["sp"], lib=hip_lib, glib=hip_glib)
+    gens = bp.Gens(8192, lib=hip_lib, window_bits=8, job_proofs=64)
+    nb, J = 300, 64
+    for rnd in range(3):
+        P, C = bp.prove_batch(gens, circa, b"VSMT", ca["values"], ca["blindings"], ca["seeds"], ca["B"])
+        fc.check_digests("vsmt4_l8_x70", ca, P, C)
+        assert bp.last_prove_stats(hip_lib)["jobs"] == -(-ca["B"] // J)
+        P, _ = bp.prove_batch(gens, circb, cb["label"], cb["values"][:nb * 6 * 32], cb["blindings"][:nb * 6 * 32], cb["seeds"][:nb * 32], nb)
+        fc.check_digests("c2_poseidon2_cube_x4096", cb, P, first=nb)
+        assert bp.last_prove_stats(hip_lib)["jobs"] == -(-nb // J)
+        if rnd == 1:
+            J = 128
+            gens.set_option("job_proofs", J)
+    gens.close()

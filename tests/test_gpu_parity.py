@@ -123,3 +123,11 @@ def test_large_variable_base_msm_pippenger_buckets(hip_lib):
         assert got == o.msm(sc, pts), "n = %d" % n
     with pytest.raises(bp.R1CSError):
         bp.msm([1] * 4096, [b"\xff" * 32] + base[:4095], lib=hip_lib)   # a point that does not decode: FormatError on the Pippenger path too
+
+
+def test_alternating_circuits_on_one_handle_on_device(hip_lib):
+    """as tests/test_hostsim.py::test_alternating_circuits_on_one_handle, with real streams and events: jobs of two circuits of
+    different shape in flight on one handle, arenas re-used / grown / shrunk, shared wires and RNG buffers handed over by events"""
+    import test_hostsim as th
+    th._alternating_circuits(hip_lib, {"window_bits": 8})
+    th._alternating_circuits(hip_lib, {"window_bits": 8, "shared_back": 0, "jobs_in_flight": 1})

@@ -149,3 +149,28 @@ def test_shipped_msm_loop_on_70_proof_batches(sim_lib, sim_glib):
                 os.environ.pop("BPR1CS_TEST_NARROW_MERGED", None)
             st3 = bp.last_prove_stats(sim_lib)
             assert P3 == want and st3["msm_adds"] > st3["msm_terms"] * gens.table_info()["windows"]
+
+
+def _alternating_circuits(lib, gens_kw):
+    """Two circuits of different shape proved alternately on ONE handle, every batch cut into jobs of two proofs (two in flight): the
+    handle's arenas - per-slot, the shared front (wires / raw RNG output) and the shared back - are re-used, grown and shrunk across
+    circuits; the bytes are the oracle's every time."""
+    bp = common.bp
+    st = [2, 3, 5, 6, 8, 20, 25]
+    obA = common.oracle_batch(lambda j: S.bound_check(37 + j, 10, 100, 7), 32, 5, key="alt-bound")
+    obB = common.oracle_batch(lambda j: S.set_membership(st[j % 7], st), 32, 3, key="alt-set")
+    gens = bp.Gens(32, lib=lib, job_proofs=2, **gens_kw)
+    cA, cB = common.circuit_from_oracle(obA, lib), common.circuit_from_oracle(obB, lib)
+    for rnd in range(3):
+        for ob, circ, B in ((obA, cA, 5), (obB, cB, 3), (obA, cA, 2)):
+            P, _ = bp.prove_batch(gens, circ, ob["label"], ob["values"][:B * circ.m * 32], ob["blindings"][:B * circ.m * 32], ob["seeds"][:B * 32], B,
+                                  wires=ob["wires"][:B * 96 * circ.n])
+            assert P == ob["proofs"][:B], (rnd, B)
+            assert bp.last_prove_stats(lib)["jobs"] == -(-B // 2)
+        if rnd == 1:
+            gens.release_scratch()
+
+
+def test_alternating_circuits_on_one_handle(sim_lib):
+    _alternating_circuits(sim_lib, {})
+    _alternating_circuits(sim_lib, {"shared_back": 0, "jobs_in_flight": 1})
