@@ -131,3 +131,9 @@ def test_alternating_circuits_on_one_handle_on_device(hip_lib):
     import test_hostsim as th
     th._alternating_circuits(hip_lib, {"window_bits": 8})
     th._alternating_circuits(hip_lib, {"window_bits": 8, "shared_back": 0, "jobs_in_flight": 1})
+
+
+def test_prove_from_advanced_transcripts_on_device(hip_lib):
+    """bpr1cs_prove_batch_transcripts against the oracle's prover on transcripts that already hold messages (per proof and shared)"""
+    import test_hostsim as th
+    th.test_prove_from_advanced_transcripts(hip_lib)

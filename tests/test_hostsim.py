@@ -174,3 +174,53 @@ def _alternating_circuits(lib, gens_kw):
 def test_alternating_circuits_on_one_handle(sim_lib):
     _alternating_circuits(sim_lib, {})
     _alternating_circuits(sim_lib, {"shared_back": 0, "jobs_in_flight": 1})
+
+
+def test_prove_from_advanced_transcripts(sim_lib):
+    """bpr1cs_prove_batch_transcripts: Prover::new(&pc_gens, &mut transcript) on transcripts that are NOT fresh (messages appended
+    before, different per proof).  The oracle's prover run on the same advanced transcript gives the same proof bytes, and afterwards
+    both transcripts answer the same challenge - the state upstream's `&mut transcript` is left in.  One shared transcript for a
+    batch (n_transcripts = 1) starts every proof from a copy and leaves the original untouched."""
+    from pyref.merlin import Transcript as OTranscript
+    from pyref.r1cs import Prover
+    bp = common.bp
+    B = 3
+    scen = [S.bound_check(37 + j, 10, 100, 7) for j in range(B)]
+    obp = common.oracle_gens(16)
+    want, after, ob = [], [], None
+    vals, bls, wires = b"", b"", b""
+    for j, sc in enumerate(scen):
+        t = OTranscript(sc.label)
+        t.append_message(b"session", b"context %d" % j)          # the transcript is advanced before Prover::new
+        p = Prover(common.PC, t)
+        bl = [S.synth_scalar(b"bl%d" % j, i) for i in range(512)]
+        sc.build_prover(p, bl)
+        tr = {}
+        tr["constraints"] = [list(lc.terms) for lc in p.constraints]
+        n, m = p.num_multipliers(), len(p.v)
+        vals += b"".join(common.sc_to_bytes(x) for x in p.v)
+        bls += b"".join(common.sc_to_bytes(x) for x in p.v_blinding)
+        proof = p.prove(obp, S.synth_seed(j), tr)
+        wires += b"".join(common.sc_to_bytes(x) for x in tr["a_L"] + tr["a_R"] + tr["a_O"])
+        want.append(proof.to_bytes())
+        after.append(t.challenge_bytes(b"probe", 32))
+        ob = dict(n=n, m=m, constraints=tr["constraints"])
+    circ = common.circuit_from_oracle(ob, sim_lib)
+    gens = bp.Gens(16, lib=sim_lib)
+    seeds = b"".join(S.synth_seed(j) for j in range(B))
+    ts = []
+    for j, sc in enumerate(scen):
+        t = bp.Transcript(sc.label, lib=sim_lib)
+        t.append_message(b"session", b"context %d" % j)
+        ts.append(t)
+    P, _ = bp.prove_batch_transcripts(gens, circ, ts, vals, bls, seeds, B, wires=wires)
+    assert P == want
+    assert [t.challenge_bytes(b"probe", 32) for t in ts] == after
+    # one shared (advanced) transcript for the whole batch: copies, the original stays where it was
+    shared = bp.Transcript(scen[0].label, lib=sim_lib)
+    shared.append_message(b"session", b"context 0")
+    P1, _ = bp.prove_batch_transcripts(gens, circ, shared, vals, bls, seeds, B, wires=wires)
+    assert P1[0] == want[0] and P1[1] != want[1]
+    twin = bp.Transcript(scen[0].label, lib=sim_lib)
+    twin.append_message(b"session", b"context 0")
+    assert shared.challenge_bytes(b"probe", 32) == twin.challenge_bytes(b"probe", 32)
