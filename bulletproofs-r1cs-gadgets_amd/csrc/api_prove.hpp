@@ -548,15 +548,21 @@ static int prove_batch_impl(const bpr1cs_gens* g, const bpr1cs_circuit* c, const
     };
     size_t done = 0;
     bool retried = false;
+    // test knob (tests/test_hostsim.py): BPR1CS_TEST_FAIL_JOBS=k makes the first k job submissions of this call report "out of
+    // memory", so that the drain / hand back / retry / halve path below runs without a device that is actually full
+    const char* inj = getenv("BPR1CS_TEST_FAIL_JOBS");
+    int inject_oom = inj ? atoi(inj) : 0;
     // (A smaller first job - a quarter of the size, so that its exposed TranscriptRng chain is shorter and the full-size jobs start
     // sooner - was measured in round 4: 3041-3049 against 3077-3090 proofs/s at 20 steps; the extra job costs more than it hides.)
     while (done < batch && rc == BPR1CS_OK) {
         // full jobs of J proofs and a shorter last one.  The first job is the largest: it sizes the handle's arenas.
         const size_t rest = batch - done, take = std::min(J, rest);
         bpr1cs_job* job = nullptr;
-        int e = prove_job_begin(g, c, n_init == 1 ? init : init + done, n_init == 1 ? 1 : take, tr_out != nullptr,
-                                values ? values + done * m * 32 : nullptr, v_blindings ? v_blindings + done * m * 32 : nullptr,
-                                rng_seeds ? rng_seeds + done * 32 : nullptr, wires ? wires + done * wn * 32 : nullptr, take, &job);
+        int e;
+        if (inject_oom > 0) { inject_oom--; e = BPR1CS_ERR_OUT_OF_MEMORY; }   // (test knob, see above)
+        else e = prove_job_begin(g, c, n_init == 1 ? init : init + done, n_init == 1 ? 1 : take, tr_out != nullptr,
+                                 values ? values + done * m * 32 : nullptr, v_blindings ? v_blindings + done * m * 32 : nullptr,
+                                 rng_seeds ? rng_seeds + done * 32 : nullptr, wires ? wires + done * wn * 32 : nullptr, take, &job);
         if (e == BPR1CS_ERR_OUT_OF_MEMORY && (take > 64 || !retried)) {
             // out of memory: let the jobs in flight finish and hand the scratch back (arenas sized for the smaller jobs of an
             // earlier call sit next to the blocks that replace them until their last user has drained) - then the same job once

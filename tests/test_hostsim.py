@@ -224,3 +224,36 @@ def test_prove_from_advanced_transcripts(sim_lib):
     twin = bp.Transcript(scen[0].label, lib=sim_lib)
     twin.append_message(b"session", b"context 0")
     assert shared.challenge_bytes(b"probe", 32) == twin.challenge_bytes(b"probe", 32)
+
+
+def test_out_of_memory_fallback_of_prove_batch(sim_lib):
+    """bpr1cs_prove_batch when a job submission reports OUT_OF_MEMORY (injected: BPR1CS_TEST_FAIL_JOBS): the jobs in flight are
+    drained, the handle's scratch is handed back and the same job is tried again; a second failure halves the job size (down to 64
+    proofs).  The bytes never change; a failure that persists is returned as BPR1CS_ERR_OUT_OF_MEMORY."""
+    import os
+    import pytest
+    bp = common.bp
+    ob = common.oracle_batch(lambda j: S.bound_check(37 + j, 10, 100, 7), 16, 2)
+    circ = common.circuit_from_oracle(ob, sim_lib)
+    B, m = 300, circ.m
+    args = (ob["values"][:m * 32] * B, ob["blindings"][:m * 32] * B, ob["seeds"][:32] * B, B)
+    wires = ob["wires"][:96 * circ.n] * B
+    gens = bp.Gens(16, lib=sim_lib, job_proofs=256)
+    want, _ = bp.prove_batch(gens, circ, ob["label"], *args, wires=wires)
+    assert want == [ob["proofs"][0]] * B
+    try:
+        # 1 failure: the same job again (256 + 44); 2: half the size (128, 128, 44); 3: the retry at 128 fails once more, then passes;
+        # 4: 64-proof jobs (the smallest size a failure leads to); 5: their retry
+        for fails, jobs, largest in ((1, 2, 256), (2, 3, 128), (3, 3, 128), (4, 5, 64), (5, 5, 64)):
+            os.environ["BPR1CS_TEST_FAIL_JOBS"] = str(fails)
+            P, _ = bp.prove_batch(gens, circ, ob["label"], *args, wires=wires)
+            st = bp.last_prove_stats(sim_lib)
+            assert P == want and (st["jobs"], st["job_proofs"]) == (jobs, largest), (fails, st)
+        os.environ["BPR1CS_TEST_FAIL_JOBS"] = "1000"
+        with pytest.raises(bp.R1CSError) as e:
+            bp.prove_batch(gens, circ, ob["label"], *args, wires=wires)
+        assert e.value.code == -19
+    finally:
+        os.environ.pop("BPR1CS_TEST_FAIL_JOBS", None)
+    P, _ = bp.prove_batch(gens, circ, ob["label"], *args, wires=wires)   # the handle is as usable as before
+    assert P == want
