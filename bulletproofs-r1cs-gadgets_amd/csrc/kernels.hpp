@@ -7,10 +7,11 @@
 // identity, slot j the multiple j * 2^(W k) * P in halved affine Niels form (TabCfg below, ge.hpp):
 //     tab + ((base * windows + k) * row + j) * stride
 // Signed radix-2^W digits turn s*P into ceil(253/W) table additions, no doublings
-// (W = 8: 32 additions, 26 / 35 GB of tables at capacity 32768; W = 11: 23 additions, 148 / 198 GB).
+// (W = 8: 32 additions, 35 GB of tables at capacity 32768; W = 11: 23 additions, 198 GB).
 //
-// The functors below are what the CPU simulator of the tests runs kernel by kernel; on the device the dominant one
-// (K_msm_fixed) is replaced by csrc/msm_hip.hpp and the cooperative ones by csrc/kernels_hip.hpp.
+// The functors below are what the CPU simulator of the tests runs kernel by kernel, and what the device runs through k_functor;
+// the dominant kernel has its own file (csrc/msm_kernel.hpp: one body for both builds), the cooperative front kernels
+// (witness teams, TranscriptRng chain) are device-only (csrc/kernels_hip.hpp; their per-proof functors here serve the simulator).
 // Each functor is one kernel; `gid` enumerates (index, proof) pairs with the
 // proof index fastest.
 #pragma once

@@ -13,7 +13,7 @@ def open_db(d):
 
 def short(n):
     n = n.split("(")[0]
-    for k in ("k_rng_stream", "k_rng_thread", "k_witness_team", "k_msm_fixed2", "k_poseidon_team", "k_probe_mad", "k_probe_madd"):
+    for k in ("k_rng_stream", "k_witness_team", "k_msm_fixed2", "k_poseidon_team", "k_probe_mad", "k_probe_madd"):
         if k in n:
             return k
     if "k_functor" in n and "<" in n:

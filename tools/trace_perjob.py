@@ -10,7 +10,7 @@ con = sqlite3.connect(db)
 kt = [r[0] for r in con.execute("select name from sqlite_master where type in ('table','view')") if r[0].startswith("kernels")][0]
 def short(n):
     n = n.split("(")[0]
-    for k in ("k_rng_stream", "k_rng_rows", "k_witness_team", "k_msm_fixed2", "k_poseidon_team", "k_probe_madd", "k_probe_mad"):
+    for k in ("k_rng_stream", "k_witness_team", "k_msm_fixed2", "k_poseidon_team", "k_probe_madd", "k_probe_mad"):
         if k in n: return k
     if "k_functor_wave<" in n: return n.split("k_functor_wave<")[1].split(">")[0]
     if "k_functor<" in n: return n.split("k_functor<")[1].split(">")[0]
@@ -61,12 +61,12 @@ if tail:
         if t: spans.append((t[-1][2] - t[0][1]) / 1e6)
     print("# IPA tail on the jobs' own streams (next to the following job's sums): %d launches per job, %.2f ms of kernel time per job, %.1f ms from its first launch to K_assemble's end" %
           (len(tail) // nb, sum(r[2] - r[1] for r in tail) / 1e6 / nb, sum(spans) / max(1, len(spans))))
-front = [r for r in rows if r[0] in ("k_rng_stream", "k_rng_rows", "k_witness_team") and r[1] >= lo and r[2] <= hi]
+front = [r for r in rows if r[0] in ("k_rng_stream", "k_witness_team") and r[1] >= lo and r[2] <= hi]
 fa = collections.defaultdict(lambda: [0, 0.0])
 for r in front:
     a = fa[r[0]]; a[0] += 1; a[1] += (r[2] - r[1]) / 1e6
 print("# front kernels (own streams, overlapping the back stream of the batch before): " + ", ".join("%s %.1f ms x %d" % (k, a[1] / a[0], a[0]) for k, a in fa.items()))
-rng = [r for r in rows if r[0] in ("k_rng_stream", "k_rng_rows")]
+rng = [r for r in rows if r[0] in ("k_rng_stream",)]
 one = [r for r in msm if r[1] >= asm[2][1] and r[2] <= asm[3][1]]
 print("# MSM launches between two jobs' K_transcript_A (IPA of one job, commitment sums of the next): ms (share of it a TranscriptRng chain was running)")
 print("  " + "  ".join("%.1f (%.0f %%)" % ((r[2] - r[1]) / 1e6, 100.0 * sum(max(0, min(r[2], f[2]) - max(r[1], f[1])) for f in rng) / (r[2] - r[1])) for r in one))

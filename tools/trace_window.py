@@ -8,7 +8,7 @@ tabs = [r[0] for r in con.execute("select name from sqlite_master where type in 
 kt = [t for t in tabs if t.startswith("kernels")][0]
 def short(n):
     n = n.split("(")[0]
-    for k in ("k_rng_stream", "k_rng_rows", "k_witness_team", "k_msm_fixed2", "k_poseidon_team"):
+    for k in ("k_rng_stream", "k_witness_team", "k_msm_fixed2", "k_poseidon_team"):
         if k in n: return k
     if "k_functor_wave<" in n: return n.split("k_functor_wave<")[1].split(">")[0]
     if "k_functor<" in n: return n.split("k_functor<")[1].split(">")[0]
