@@ -158,8 +158,10 @@ int bpr1cs_gens_table_info(const bpr1cs_gens* g, uint32_t* window_bits, uint32_t
 int bpr1cs_gens_set_option(bpr1cs_gens* g, int option, int value);
 /* bpr1cs_gens_create with options: `pairs` = n_pairs x (option, value).  BPR1CS_ERR_INVALID_ARGUMENT for an unknown option. */
 int bpr1cs_gens_create_opts(uint32_t gens_capacity, const int32_t* pairs, size_t n_pairs, bpr1cs_gens** out);
-/* hand the back-phase scratch arena of a handle (BPR1CS_OPT_SHARED_BACK; ~13 GB per 1024 proofs of the depth-32 circuit, kept
- * between jobs) to the allocator's cache; BPR1CS_ERR_INVALID_ARGUMENT while a job of the handle is in flight */
+/* A handle keeps the device scratch of its prove jobs between calls (per job slot, shared front, shared back phase: ~19 MB per proof
+ * of the depth-32 circuit, 80 GB at the default job size), so that no allocation happens in steady state.  This hands all of it to
+ * the allocator's cache (bpr1cs_release_cached_memory then returns it to the driver); BPR1CS_ERR_INVALID_ARGUMENT while a job of
+ * the handle is in flight.  The verifier entry points do it themselves when they find no memory. */
 int bpr1cs_gens_release_scratch(bpr1cs_gens* g);
 /* give the device memory cached by the library's allocator (freed tables, workspaces) back to the driver */
 int bpr1cs_release_cached_memory(void);
