@@ -566,6 +566,7 @@ def load_gadgets_library(path=None):
     vp, u32, sz, cp, ip = ctypes.c_void_p, ctypes.c_uint32, ctypes.c_size_t, ctypes.c_char_p, ctypes.POINTER(ctypes.c_uint32)
     g.bpr1cs_gadget_compile.argtypes = [cp, ip, sz, cp, sz, cp, sz, ctypes.POINTER(vp), ip, ip, ip, ctypes.POINTER(ctypes.c_int)]
     g.bpr1cs_gadget_prove_single.argtypes = [cp, ip, sz, cp, sz, cp, sz, u32, cp, sz, cp, cp, sz, cp, cp, sz, ctypes.POINTER(sz), cp]
+    g.bpr1cs_gadget_prove_on.argtypes = [vp, cp, ip, sz, cp, sz, cp, sz, cp, sz, cp, cp, sz, sz, cp, cp, sz, ctypes.POINTER(sz), cp, ctypes.POINTER(ctypes.c_double)]
     g.bpr1cs_gadget_verify_single.argtypes = [cp, ip, sz, cp, sz, cp, sz, u32, cp, sz, cp, sz, cp, sz]
     g.bpr1cs_poseidon_hash.argtypes = [ctypes.c_int, ctypes.c_int, u32, cp, sz, cp, cp]
     g.bpr1cs_mimc.argtypes = [cp, cp, cp, sz, cp]
@@ -628,6 +629,26 @@ def prove_single(name, iparams, sparams, gens_capacity, label, values, blindings
                                       gens_capacity, label, len(label), b"".join(_sc(v) for v in values), b"".join(_sc(v) for v in blindings),
                                       m, rng_seed, proof, len(proof), ctypes.byref(plen), comms))
     return proof.raw[:plen.value], [comms.raw[32 * i:32 * i + 32] for i in range(m)]
+
+
+def gadget_prove_on(gens, name, iparams, sparams, label, values, blindings, m, batch, rng_seeds, glib=None):
+    """bpr1cs_gadget_prove_on: the reference's call shape (Prover::new -> commit x m -> gadget on the host -> prove) on generators
+    created once; batch > 1 = one host synthesis per witness, ONE device prove with host wires.
+    -> (proofs, commitments per proof, dict of seconds: commit / gadget / circuit / prove / total)"""
+    g = glib or load_gadgets_library()
+    blob = poseidon_blob()
+    sp = b"".join(_sc(s) for s in sparams)
+    cap = 1 + 32 * (13 + 2 * 32)
+    proofs = ctypes.create_string_buffer(cap * batch)
+    plen = ctypes.c_size_t()
+    comms = ctypes.create_string_buffer(32 * max(1, m) * batch)
+    sec = (ctypes.c_double * 5)()
+    _chk(g.bpr1cs_gadget_prove_on(gens.h, name.encode(), _u32arr(list(iparams)), len(iparams), sp or b"\0", len(sparams), blob, len(blob),
+                                  label, len(label), values or b"\0", blindings or b"\0", m, batch, rng_seeds, proofs, cap, ctypes.byref(plen), comms, sec))
+    n, praw, craw = plen.value, proofs.raw, comms.raw
+    return ([praw[i * n:(i + 1) * n] for i in range(batch)],
+            [[craw[(i * m + j) * 32:(i * m + j + 1) * 32] for j in range(m)] for i in range(batch)],
+            dict(zip(("commit", "gadget", "circuit", "prove", "total"), sec)))
 
 
 def verify_single(name, iparams, sparams, gens_capacity, label, proof, commitments, glib=None):

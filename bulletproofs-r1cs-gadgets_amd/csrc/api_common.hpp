@@ -40,7 +40,7 @@ static void host_sponge(uint32_t rate, uint8_t suffix, const uint8_t* in, size_t
 // creation (bpr1cs_gens_create_opts) or set on the handle later (bpr1cs_gens_set_option) and read once when a call starts.
 // Defaults = the configuration bench.py measures.
 struct BpOpts {
-    std::atomic<int> unfold{4};            // IPA rounds computed from the un-folded generator tables
+    std::atomic<int> unfold{-1};           // IPA rounds computed from the un-folded generator tables (-1: chosen per job, eff_unfold)
     std::atomic<int> witness_team{8};      // lanes cooperating on one proof in k_witness_team (4, 8 or 16)
     std::atomic<int> tail_rounds{7};       // final IPA rounds (m_k <= 64 at 7) enqueued on the job's own tail stream
     std::atomic<int> shared_back{1};       // the jobs in flight on a handle share the scratch of their back phases (DevArena)
@@ -53,7 +53,7 @@ struct BpOpts {
 // -> false for an unknown option (or a creation-only one after creation)
 static bool opt_apply(BpOpts& o, int option, int value, bool creating) {
     switch (option) {
-        case BPR1CS_OPT_UNFOLD_ROUNDS: o.unfold = value < 0 ? 4 : value; return true;
+        case BPR1CS_OPT_UNFOLD_ROUNDS: o.unfold = value < 0 ? -1 : value; return true;
         case BPR1CS_OPT_WITNESS_TEAM: o.witness_team = (value == 4 || value == 8 || value == 16) ? value : 8; return true;
         case BPR1CS_OPT_TAIL_ROUNDS: o.tail_rounds = value < 0 ? 7 : value; return true;
         case BPR1CS_OPT_SHARED_BACK: o.shared_back = value < 0 ? 1 : (value ? 1 : 0); return true;
@@ -67,6 +67,17 @@ static bool opt_apply(BpOpts& o, int option, int value, bool creating) {
             return true;
         default: return false;
     }
+}
+// Un-folded IPA rounds of a job of B proofs (BPR1CS_OPT_UNFOLD_ROUNDS unless set): a round computed from the generator TABLES costs
+// 2N x windows additions per proof whatever the round, a variable-base round (Straus on per-proof points, generators folded with
+// ~255 doublings per output) costs less work from round 4 on - but its chains of doublings are serial per output, so with few
+// proofs in flight it is pure latency (measured on MI355X, depth-32 tree circuit, ONE proof: 4.5 ms per variable-base round against
+// 0.3 ms per table round).  Small jobs therefore take EVERY round from the tables; large jobs switch after 4.
+static const uint32_t SMALL_JOB_PROOFS = 64;
+static uint32_t eff_unfold(const BpOpts& o, uint32_t B, uint32_t lgN) {
+    const int u = o.unfold.load();
+    if (u >= 0) return std::min<uint32_t>((uint32_t)u, lgN);
+    return B <= SMALL_JOB_PROOFS ? lgN : std::min<uint32_t>(4u, lgN);
 }
 // statistics of the last prove call that RETURNED ON THIS THREAD (bpr1cs_last_prove_stats)
 inline bpr1cs_prove_stats& tl_last_stats() {
@@ -172,8 +183,121 @@ struct bpr1cs_circuit {
     };
     mutable std::mutex mt_mu;
     mutable std::map<const bpr1cs_gens*, MergedTab*> mt;
+    // circuit cache (below): the description this object was built from, and how many handles the callers hold on it
+    int cache_refs = -1;   // -1: not in the cache (bpr1cs_circuit_destroy deletes it)
+    int cache_device = 0;  // the device its buffers live on
+    uint64_t cache_key = 0, cache_stamp = 0;
+    std::vector<uint32_t> k_row_off, k_term_var;
+    std::vector<uint8_t> k_term_coeff;
     ~bpr1cs_circuit() { for (auto& kv : mt) delete kv.second; }
 };
+
+// ---- circuit cache.  The reference builds its constraint system anew for every proof (Prover::new -> gadget -> prove(),
+// src/gadget_vsmt_4.rs:390-434), so a drop-in Prover::prove calls bpr1cs_circuit_create + bpr1cs_circuit_destroy once per PROOF with the
+// same description: 20 ms of validation, CSR -> CSC conversion and uploads for the depth-32 tree circuit, and the circuit's
+// per-generator-handle tables (the summed-generator table of IPA round 0) rebuilt each time.  Descriptions WITHOUT a witness program
+// (what a Prover / Verifier hands over) are therefore kept: a later bpr1cs_circuit_create with a byte-identical description returns
+// the object built before.  Lookup = a cheap hash of the shape and the variable list, then a FULL comparison of the description (no
+// collision can hand out a wrong circuit).  Bounded (entries and bytes, least recently used first out); objects nobody holds are
+// dropped by bpr1cs_release_cached_memory.  A circuit is immutable once built and already shareable between threads (mt_mu).
+struct CircuitCache {
+    std::mutex mu;
+    std::vector<bpr1cs_circuit*> items;
+    uint64_t clock = 0;
+    static const size_t MAX_ITEMS = 8, MAX_BYTES = (size_t)1 << 30;
+};
+inline CircuitCache& circuit_cache() {
+    static CircuitCache* c = new CircuitCache();  // intentionally leaked: must outlive static destructors
+    return *c;
+}
+static uint64_t circuit_desc_hash(const bpr1cs_circuit_desc* d) {
+    const uint32_t nnz = d->q ? d->row_off[d->q] : 0;
+    uint64_t h = 0x9e3779b97f4a7c15ull ^ ((uint64_t)d->n << 40) ^ ((uint64_t)d->q << 20) ^ d->m ^ ((uint64_t)nnz << 8);
+    auto mix = [&](uint64_t v) { h = (h ^ v) * 0xff51afd7ed558ccdull; h ^= h >> 29; };
+    for (uint32_t t = 0; t < nnz; t++) mix(d->term_var[t]);
+    const size_t cb = (size_t)nnz * 32, head = std::min<size_t>(cb, 4096);
+    for (size_t i = 0; i + 8 <= head; i += 8) { uint64_t v; memcpy(&v, d->term_coeff + i, 8); mix(v); }
+    for (size_t i = cb - head; i + 8 <= cb; i += 8) { uint64_t v; memcpy(&v, d->term_coeff + i, 8); mix(v); }
+    return h;
+}
+static bool circuit_desc_equal(const bpr1cs_circuit* c, const bpr1cs_circuit_desc* d) {
+    if (c->n != d->n || c->q != d->q || c->m != d->m || c->k_row_off.size() != (size_t)d->q + 1) return false;
+    if (d->q == 0) return true;
+    const uint32_t nnz = d->row_off[d->q];
+    return c->k_term_var.size() == nnz && memcmp(c->k_row_off.data(), d->row_off, ((size_t)d->q + 1) * 4) == 0 &&
+           memcmp(c->k_term_var.data(), d->term_var, (size_t)nnz * 4) == 0 && memcmp(c->k_term_coeff.data(), d->term_coeff, (size_t)nnz * 32) == 0;
+}
+static int current_device() {
+#if defined(BPR1CS_HOSTSIM)
+    return 0;
+#else
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = 0; }
+    return dev;
+#endif
+}
+static bpr1cs_circuit* circuit_cache_lookup(const bpr1cs_circuit_desc* d, uint64_t key) {
+    const int dev = current_device();
+    CircuitCache& cc = circuit_cache();
+    std::lock_guard<std::mutex> lk(cc.mu);
+    for (bpr1cs_circuit* c : cc.items)
+        if (c->cache_key == key && c->cache_device == dev && circuit_desc_equal(c, d)) {
+            c->cache_refs++;
+            c->cache_stamp = ++cc.clock;
+            return c;
+        }
+    return nullptr;
+}
+// -> objects that fell out of the cache (nobody holds them): the caller deletes them outside the lock
+static void circuit_cache_trim(CircuitCache& cc, size_t max_items, size_t max_bytes, std::vector<bpr1cs_circuit*>& dead) {
+    auto bytes_of = [](const bpr1cs_circuit* c) { return c->k_term_coeff.size() + 4 * (c->k_term_var.size() + c->k_row_off.size()); };
+    for (;;) {
+        size_t total = 0;
+        for (auto* c : cc.items) total += bytes_of(c);
+        if (cc.items.size() <= max_items && total <= max_bytes) return;
+        size_t victim = cc.items.size();
+        for (size_t i = 0; i < cc.items.size(); i++)
+            if (cc.items[i]->cache_refs == 0 && (victim == cc.items.size() || cc.items[i]->cache_stamp < cc.items[victim]->cache_stamp)) victim = i;
+        if (victim == cc.items.size()) return;   // everything is in use: nothing to drop
+        dead.push_back(cc.items[victim]);
+        cc.items.erase(cc.items.begin() + victim);
+    }
+}
+static void circuit_cache_insert(bpr1cs_circuit* c, const bpr1cs_circuit_desc* d, uint64_t key) {
+    const uint32_t nnz = d->q ? d->row_off[d->q] : 0;
+    if (d->q) c->k_row_off.assign(d->row_off, d->row_off + d->q + 1); else c->k_row_off.assign(1, 0);
+    c->k_term_var.assign(d->term_var, d->term_var + nnz);
+    c->k_term_coeff.assign(d->term_coeff, d->term_coeff + (size_t)nnz * 32);
+    c->cache_key = key;
+    c->cache_device = current_device();
+    c->cache_refs = 1;
+    std::vector<bpr1cs_circuit*> dead;
+    {
+        CircuitCache& cc = circuit_cache();
+        std::lock_guard<std::mutex> lk(cc.mu);
+        c->cache_stamp = ++cc.clock;
+        cc.items.push_back(c);
+        circuit_cache_trim(cc, CircuitCache::MAX_ITEMS, CircuitCache::MAX_BYTES, dead);
+    }
+    for (auto* x : dead) delete x;
+}
+// bpr1cs_circuit_destroy: a cached object stays (until it is the least recently used one nobody holds)
+static bool circuit_cache_release(bpr1cs_circuit* c) {
+    if (c->cache_refs < 0) return false;
+    CircuitCache& cc = circuit_cache();
+    std::lock_guard<std::mutex> lk(cc.mu);
+    if (c->cache_refs > 0) c->cache_refs--;
+    return true;
+}
+static void circuit_cache_purge() {
+    std::vector<bpr1cs_circuit*> dead;
+    {
+        CircuitCache& cc = circuit_cache();
+        std::lock_guard<std::mutex> lk(cc.mu);
+        circuit_cache_trim(cc, 0, 0, dead);
+    }
+    for (auto* x : dead) delete x;
+}
 
 static bool have_device() {
 #if defined(BPR1CS_HOSTSIM)

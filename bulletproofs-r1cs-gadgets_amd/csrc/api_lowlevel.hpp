@@ -83,8 +83,8 @@ extern "C" int bpr1cs_ipa_create(const bpr1cs_gens* g, bpr1cs_transcript* t, con
     launch((uint64_t)4 * N, K_load_wires{raw.p, vec.p}, st);
     DevBuf<uint8_t> LR((size_t)(lgN ? lgN : 1) * 2 * 32), ab(64);
     DevBuf<sc> uk((size_t)(lgN ? lgN : 1) * 2);
-    const int unfold = g->opts.unfold.load();
-    IpaIO io{g, 1, N, lgN, (uint32_t)unfold, tr.p, vec.p, vec.p + N, vec.p + (size_t)2 * N, vec.p + (size_t)3 * N, nullptr, dq.p, LR.p, uk.p};
+    const uint32_t unfold = eff_unfold(g->opts, 1, lgN);
+    IpaIO io{g, 1, N, lgN, unfold, tr.p, vec.p, vec.p + N, vec.p + (size_t)2 * N, vec.p + (size_t)3 * N, nullptr, dq.p, LR.p, uk.p};
     (void)enqueue_ipa(io, st, &stats);
     std::vector<sc> fin(N + 1);
     dev_d2h(fin.data(), vec.p, (size_t)(N + 1) * sizeof(sc), st);  // a' = vec[0], b' = vec[N]
@@ -189,6 +189,19 @@ extern "C" int bpr1cs_msm_fixed(const bpr1cs_gens* g, const uint32_t* bases, siz
     const uint32_t B = (uint32_t)batch;
     dev_stream_t st = g->stream;
     CallScope scope(st);
+    if (terms == 2 && bases[0] == 0 && bases[1] == 1) {
+        // pc_gens.commit(v, blinding) = v*B + blinding*B_blinding - what Prover::commit calls once per committed value (reference
+        // src/gadget_vsmt_4.rs:393-410: 100 calls for one depth-32 proof): one upload, ONE kernel (the prover's own K_commit_v), one read-back
+        std::vector<sc> h((size_t)2 * B);
+        for (uint32_t b = 0; b < B; b++) { h[b] = sc_load_raw(scalars + 64 * (size_t)b); h[(size_t)B + b] = sc_load_raw(scalars + 64 * (size_t)b + 32); }
+        DevBuf<sc> d((size_t)2 * B);
+        DevBuf<uint8_t> d_out((size_t)B * 32);
+        dev_h2d_async(d.p, h.data(), h.size() * sizeof(sc), st);
+        launch(B, K_commit_v{g->tab.p, g->tc, d.p, d.p + B, d_out.p, B, 1}, st);
+        dev_zero(d.p, d.bytes(), st);   // value and blinding are secrets
+        dev_d2h(out, d_out.p, (size_t)B * 32, st);
+        return BPR1CS_OK;
+    }
     MsmStats stats;
     DevBuf<sc> sc_dev;
     upload_transposed(sc_dev, scalars, B, terms, st);

@@ -138,8 +138,9 @@ static int prove_job_begin(const bpr1cs_gens* g, const bpr1cs_circuit* c, const 
     // everything the job owns comes from its slot's arena (a smaller job reuses the blocks of a larger one before it)
     ArenaScope own_arena(&g->front[slot], true);
     // the handle's options, read once per job
-    const int o_unfold = g->opts.unfold.load(), o_team = g->opts.witness_team.load(), o_tail = g->opts.tail_rounds.load();
+    const int o_team = g->opts.witness_team.load(), o_tail = g->opts.tail_rounds.load();
     const uint32_t B = (uint32_t)batch, n = c->n, m = c->m, N = c->N, lgN = c->lgN;
+    const int o_unfold = (int)eff_unfold(g->opts, B, lgN);
     const uint32_t baseG = 2, baseH = 2 + g->cap;
     dev_stream_t st = job->st;
     PhaseTimer& pt = job->pt;
@@ -356,7 +357,7 @@ static int prove_job_begin(const bpr1cs_gens* g, const bpr1cs_circuit* c, const 
     struct { sc* p; } wvec{wvec_p}, cG{cG_p}, cH{cH_p};
     run_flatten(c, 3 * n + m, plo.p, phi.p, wvec.p, B, H, st, fpart_p);
     // 4 wavefronts per SIMD: with one (2^16 threads) the kernel is latency bound and a co-running front kernel doubles its time (9 -> 4 ms)
-    uint32_t tchunk, TC = pick_chunks(n, B, 1u << 18, tchunk);
+    uint32_t tchunk, TC = pick_chunks(n, B, std::min<uint32_t>(1u << 18, MAX_SUM_CHUNKS * B), tchunk);
     DevBuf<sc> tpart((size_t)6 * TC * B), tco((size_t)6 * B);
     launch((uint64_t)TC * B, K_tcoef_partial{W.p, wvec.p, plo.p, phi.p, tpart.p, B, H, n, tchunk, TC}, st);
     launch((uint64_t)6 * B, K_sum_partials{tpart.p, tco.p, B, TC}, st);
@@ -476,7 +477,7 @@ static int prove_job_end(bpr1cs_job* job, uint8_t* proofs_out, uint8_t* commitme
 // variable-base pair) and the folded generators.  2048 for the depth-32 tree circuits on a 288 GB device.
 static uint32_t auto_job_proofs(const bpr1cs_gens* g, const bpr1cs_circuit* c, bool have_program, int in_flight) {
     const size_t n = c->n, m = c->m, N = c->N;
-    const uint32_t r = std::min<uint32_t>((uint32_t)std::max(0, g->opts.unfold.load()), c->lgN);
+    const uint32_t r = eff_unfold(g->opts, 4096, c->lgN);   // (the job sizes considered here are large ones)
     const size_t Mr = N >> r, nfl = c->h_slot_chunk.empty() ? 0 : c->h_slot_chunk[3 * n + m];
     const size_t tail_m = std::min<size_t>(N, 128);
     const size_t front_shared = 160 * n + 64 * (2 * n + 7);   // W and the raw TranscriptRng output: ONE copy for the jobs in flight

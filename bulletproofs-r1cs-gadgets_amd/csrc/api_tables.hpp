@@ -42,6 +42,7 @@ int bpr1cs_gens_release_scratch(bpr1cs_gens* g) {
     return BPR1CS_OK;
 }
 int bpr1cs_release_cached_memory(void) {
+    circuit_cache_purge();   // cached circuits nobody holds (their device buffers go to the pool first)
 #if !defined(BPR1CS_HOSTSIM)
     dev_pool().release_all();
 #endif
@@ -182,6 +183,13 @@ int bpr1cs_circuit_create(const bpr1cs_circuit_desc* d, bpr1cs_circuit** out) {
         for (uint32_t i = 0; i < d->n; i++)
             if (!operand_ok(d->wops[i].lkind, d->wops[i].larg, i, false) || !operand_ok(d->wops[i].rkind, d->wops[i].rarg, i, true))
                 return BPR1CS_ERR_INVALID_ARGUMENT;
+    }
+    // a description without a witness program that was built before (the per-proof circuit of a drop-in Prover / Verifier): the same object
+    const bool cacheable = !d->wops;
+    uint64_t cache_key = 0;
+    if (cacheable) {
+        cache_key = circuit_desc_hash(d);
+        if (bpr1cs_circuit* hit = circuit_cache_lookup(d, cache_key)) { *out = hit; return BPR1CS_OK; }
     }
     bpr1cs_circuit* c = nullptr;
     API_TRY
@@ -345,6 +353,7 @@ int bpr1cs_circuit_create(const bpr1cs_circuit_desc* d, bpr1cs_circuit** out) {
         upload(c->lc_var, lv, s);
         upload(c->lc_coeff, lcf, s);
     }
+    if (cacheable) circuit_cache_insert(c, d, cache_key);
     *out = c;
     return BPR1CS_OK;
     }
@@ -352,7 +361,9 @@ int bpr1cs_circuit_create(const bpr1cs_circuit_desc* d, bpr1cs_circuit** out) {
     catch (const std::bad_alloc&) { delete c; return BPR1CS_ERR_OUT_OF_MEMORY; }
     catch (...) { delete c; return BPR1CS_ERR_DEVICE; }
 }
-void bpr1cs_circuit_destroy(bpr1cs_circuit* c) { delete c; }
+void bpr1cs_circuit_destroy(bpr1cs_circuit* c) {
+    if (c && !circuit_cache_release(c)) delete c;
+}
 size_t bpr1cs_proof_len(const bpr1cs_circuit* c) { return c ? 1 + 32 * (size_t)(13 + 2 * c->lgN) : 0; }
 
 }  // extern "C"

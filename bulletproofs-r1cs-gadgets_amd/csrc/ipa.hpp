@@ -148,7 +148,7 @@ static IpaEnd enqueue_ipa(const IpaIO& io, dev_stream_t st, MsmStats* stats) {
                 st = io.tail_stream;
             }
         }
-        uint32_t cchunk, CC = pick_chunks(mk, B, 1u << 18, cchunk);
+        uint32_t cchunk, CC = pick_chunks(mk, B, std::min<uint32_t>(1u << 18, MAX_SUM_CHUNKS * B), cchunk);
         if (cpart_n < (size_t)2 * CC * B) {
             if (k >= tail_from && io.tail_keep) {
                 ArenaScope own(io.own_arena);

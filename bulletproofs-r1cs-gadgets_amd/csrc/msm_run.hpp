@@ -43,6 +43,10 @@ static void upload_transposed(DevBuf<sc>& d, const uint8_t* h, size_t B, size_t 
     if (cnt * B) dev_h2d(d.p, t.data(), t.size() * sizeof(sc), s);
 }
 
+// Chunk sums that ONE thread per proof adds up afterwards (K_sum_partials): at most this many chunks, so that a job of a few
+// proofs does not end in a serial sum of thousands of partials (one proof: 16 384 at 2^18 (chunk, proof) threads)
+static const uint32_t MAX_SUM_CHUNKS = 256;
+
 struct MsmPlan {
     uint32_t nchunks, chunk;
 };
@@ -125,15 +129,29 @@ static void run_msm_multi(const bpr1cs_gens* g, MsmReq* reqs, uint32_t nreq, uin
     if (B < 32) {  // a wavefront per (chunk, 64 proofs) would be mostly idle: lanes take different chunks instead
         for (uint32_t r = 0; r < nreq; r++) {
             MsmReq& q = reqs[r];
-            uint32_t total = q.s0.count + q.s1.count;
-            uint32_t nchunks = pick_chunks(total, B, 1u << 16, q.plan->chunk);
-            uint32_t l1 = nchunks > MSM_REDUCE_GROUP ? (nchunks + MSM_REDUCE_GROUP - 1) / MSM_REDUCE_GROUP : 0;
-            size_t need = ((size_t)nchunks + l1) * B;
+            const uint32_t total = q.s0.count + q.s1.count;
+            const uint32_t nchunks = pick_chunks(total, B, 1u << 18, q.plan->chunk);
+            // the chunk sums are folded MSM_REDUCE_GROUP at a time until at most that many are left for the per-proof finish kernel:
+            // with ONE proof a 65 536-term sum is 65 536 chunks (one term per thread) -> 4096 -> 256 -> 16
+            uint32_t lv[8], nl = 0, cnt = nchunks;
+            size_t need = nchunks;
+            while (cnt > MSM_REDUCE_GROUP && nl < 8) { cnt = (cnt + MSM_REDUCE_GROUP - 1) / MSM_REDUCE_GROUP; lv[nl++] = cnt; need += cnt; }
+            need *= B;
             if (q.partial->n < need) q.partial->alloc(need);
-            ge* raw = q.partial->p + (size_t)l1 * B;
+            // layout: [last level][...][first level][raw]
+            size_t off = 0;
+            for (uint32_t t = 0; t < nl; t++) off += lv[t];
+            ge* raw = q.partial->p + off * B;
             launch_wave((uint64_t)nchunks * B, K_msm_fixed_small{q.table ? q.table : g->tab.p, q.tc ? *q.tc : g->tc, {q.s0, q.s1}, raw, B, q.plan->chunk, nchunks}, st);
-            if (l1) launch((uint64_t)l1 * B, K_ge_reduce{raw, q.partial->p, B, nchunks, MSM_REDUCE_GROUP}, st);
-            q.plan->nchunks = l1 ? l1 : nchunks;
+            const ge* in = raw;
+            uint32_t in_cnt = nchunks;
+            for (uint32_t t = 0; t < nl; t++) {
+                off -= lv[t];
+                ge* out = q.partial->p + off * B;
+                launch((uint64_t)lv[t] * B, K_ge_reduce{in, out, B, in_cnt, MSM_REDUCE_GROUP}, st);
+                in = out; in_cnt = lv[t];
+            }
+            q.plan->nchunks = in_cnt;
             if (stats) { stats->launches++; stats->terms += (uint64_t)total * B; stats->adds += (uint64_t)total * B * (q.tc ? q.tc->windows : g->tc.windows); }
         }
         return;

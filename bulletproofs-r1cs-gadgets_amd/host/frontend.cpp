@@ -2,6 +2,7 @@
 // C ABI of include/bpr1cs_gadgets.h (the reference's proving harnesses restated over
 // the C++ mirror of its gadget API).  Links against libbpr1cs_hip.so; contains no
 // group arithmetic and no prover of its own.
+#include <chrono>
 #include <functional>
 #include <random>
 #include <memory>
@@ -10,13 +11,34 @@
 
 namespace bpr1cs {
 
+static double now_s() {
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+void Prover::export_witness(std::vector<uint8_t>& vals, std::vector<uint8_t>& bls, std::vector<uint8_t>& wires) const {
+    const size_t n = a_L.size(), m = v_.size();
+    size_t v0 = vals.size(), b0 = bls.size(), w0 = wires.size();
+    vals.resize(v0 + 32 * m); bls.resize(b0 + 32 * m); wires.resize(w0 + 96 * n);
+    for (size_t i = 0; i < m; i++) {
+        v_[i].write_bytes(&vals[v0 + 32 * i]);
+        v_blinding_[i].write_bytes(&bls[b0 + 32 * i]);
+    }
+    for (size_t i = 0; i < n; i++) {
+        a_L[i].write_bytes(&wires[w0 + 32 * i]);
+        a_R[i].write_bytes(&wires[w0 + 32 * (n + i)]);
+        a_O[i].write_bytes(&wires[w0 + 32 * (2 * n + i)]);
+    }
+}
+
 R1CSProof Prover::prove(const BulletproofGens& bp_gens) {
-    // Prover::prove (reference src/gadget_vsmt_4.rs:434): constraints + host-synthesised wires
-    // go to the device prover as a batch of one.
+    // Prover::prove (reference src/gadget_vsmt_4.rs:434): constraints + host-synthesised wires go to the device prover as a batch
+    // of one, starting from the caller's transcript (bpr1cs_prove_batch_transcripts: the handle is advanced to the state upstream's
+    // `&mut` transcript has afterwards) - the same calls tools/rust_shim/prover.rs makes.
     size_t n = a_L.size(), m = v_.size();
     size_t padded = 1;
     while (padded < n) padded <<= 1;
     if (bp_gens.gens_capacity < padded) throw R1CSError::InvalidGeneratorsLength();
+    double t0 = now_s();
     std::vector<uint32_t> row_off, tvar;
     std::vector<uint8_t> tcoeff;
     export_csr(row_off, tvar, tcoeff);
@@ -26,18 +48,10 @@ R1CSProof Prover::prove(const BulletproofGens& bp_gens) {
     bpr1cs_circuit* c = nullptr;
     int rc = bpr1cs_circuit_create(&d, &c);
     if (rc) throw R1CSError::Backend(rc);
-    std::vector<uint8_t> vals(32 * m + 1), bls(32 * m + 1), wires(32 * 3 * n + 1);
-    for (size_t i = 0; i < m; i++) {
-        auto a = v_[i].to_bytes(), b = v_blinding_[i].to_bytes();
-        memcpy(&vals[32 * i], a.data(), 32);
-        memcpy(&bls[32 * i], b.data(), 32);
-    }
-    for (size_t i = 0; i < n; i++) {
-        auto l = a_L[i].to_bytes(), r = a_R[i].to_bytes(), o = a_O[i].to_bytes();
-        memcpy(&wires[32 * i], l.data(), 32);
-        memcpy(&wires[32 * (n + i)], r.data(), 32);
-        memcpy(&wires[32 * (2 * n + i)], o.data(), 32);
-    }
+    double t1 = now_s();
+    std::vector<uint8_t> vals, bls, wires;
+    export_witness(vals, bls, wires);
+    vals.push_back(0); bls.push_back(0); wires.push_back(0);   // (never a null pointer for m = 0 / n = 0)
     std::array<uint8_t, 32> seed;
     if (rng_seed) seed = *rng_seed;
     else {
@@ -45,14 +59,20 @@ R1CSProof Prover::prove(const BulletproofGens& bp_gens) {
         for (auto& x : seed) x = (uint8_t)rd();
     }
     std::vector<uint8_t> bytes(bpr1cs_proof_len(c));
-    rc = bpr1cs_prove_batch(bp_gens.h, c, (const uint8_t*)transcript.label.data(), transcript.label.size(), vals.data(), bls.data(),
-                            seed.data(), wires.data(), 1, bytes.data(), nullptr);
+    bpr1cs_transcript* ts[1] = {transcript.h};
+    rc = bpr1cs_prove_batch_transcripts(bp_gens.h, c, ts, 1, vals.data(), bls.data(), seed.data(), wires.data(), 1, bytes.data(), nullptr);
+    transcript.fresh = false;
     bpr1cs_circuit_destroy(c);
+    if (seconds) { seconds[0] += t1 - t0; seconds[1] += now_s() - t1; }
     if (rc) throw R1CSError::Backend(rc);
     return R1CSProof::from_bytes(bytes);
 }
 
 void Verifier::verify(const R1CSProof& proof, const PedersenGens&, const BulletproofGens& bp_gens, const std::array<uint8_t, 32>* rng_seed) {
+    // bpr1cs_verify_batch starts from Transcript::new(label) - all the reference ever hands over (its call sites create the
+    // transcript on the line before, e.g. src/gadget_vsmt_4.rs:442-443); a transcript that already holds messages is refused
+    // rather than silently mis-verified (as tools/rust_shim/verifier.rs)
+    if (!transcript.fresh) throw R1CSError::GadgetError("Verifier::new on a transcript that already holds messages is not supported by the device verifier");
     size_t n = num_vars, padded = 1;
     while (padded < n) padded <<= 1;
     if (bp_gens.gens_capacity < padded) throw R1CSError::InvalidGeneratorsLength();
@@ -82,6 +102,7 @@ void Verifier::verify(const R1CSProof& proof, const PedersenGens&, const Bulletp
     rc = bpr1cs_verify_batch(bp_gens.h, c, (const uint8_t*)transcript.label.data(), transcript.label.size(), bytes.data(),
                              comms.data(), seed.data(), 1, &ok);
     bpr1cs_circuit_destroy(c);
+    transcript.fresh = false;
     if (rc) throw R1CSError::Backend(rc);
     if (!ok) throw R1CSError::VerificationError();
 }
@@ -416,6 +437,105 @@ int bpr1cs_gadget_prove_single(const char* gadget, const uint32_t* iparams, size
         *proof_len = bytes.size();
         if (commitments_out)
             for (size_t i = 0; i < comms.size(); i++) memcpy(commitments_out + 32 * i, comms[i].data(), 32);
+        return BPR1CS_OK;
+    } catch (const R1CSError& e) {
+        return e.code;
+    } catch (const std::exception&) {
+        return BPR1CS_ERR_INVALID_ARGUMENT;
+    }
+}
+
+// The reference's call shape on generators created ONCE, outside the timed region (src/gadget_vsmt_4.rs:386-387 against the Instant
+// bracket :421-435; gadget_bound_check.rs:49-87 is the whole helper).  batch = 1: Prover::new -> commit x m (one device call each)
+// -> gadget -> prove, literally.  batch > 1: what a service does with the same API - one Prover per witness for the synthesis
+// (commitments deferred), then ONE bpr1cs_prove_batch_transcripts call with the host-synthesised wires of all of them.
+int bpr1cs_gadget_prove_on(const bpr1cs_gens* gens, const char* gadget, const uint32_t* iparams, size_t n_iparams, const uint8_t* sparams,
+                           size_t n_sparams, const uint8_t* poseidon_blob, size_t blob_len, const uint8_t* label, size_t label_len,
+                           const uint8_t* values, const uint8_t* v_blindings, size_t m, size_t batch, const uint8_t* rng_seeds,
+                           uint8_t* proofs_out, size_t proof_cap, size_t* proof_len, uint8_t* commitments_out, double seconds_out[5]) {
+    if (!gens || !gadget || !label || !rng_seeds || !proofs_out || !proof_len || batch == 0 || (m && (!values || !v_blindings))) return BPR1CS_ERR_INVALID_ARGUMENT;
+    double sec[5] = {0, 0, 0, 0, 0};
+    const double t_start = now_s();
+    try {
+        GadgetSpec g = make_spec(gadget, iparams, n_iparams, sparams, n_sparams, poseidon_blob, blob_len);
+        BulletproofGens bp_gens(const_cast<bpr1cs_gens*>(gens), BulletproofGens::Borrowed{});
+        PedersenGens pc_gens(bp_gens);
+        auto synth = [&](Prover& prover, size_t b, std::vector<CompressedRistretto>* comms) {
+            std::vector<Scalar> vals;
+            for (size_t i = 0; i < m; i++) vals.push_back(Scalar::from_bytes_mod_order(values + 32 * (b * m + i)));
+            double t_commit = 0;
+            Harness h{prover,
+                      [&](size_t k) {
+                          if (k >= m) throw R1CSError::MissingAssignment();
+                          double t0 = now_s();
+                          auto cv = prover.commit(vals[k], Scalar::from_bytes_mod_order(v_blindings + 32 * (b * m + k)));
+                          t_commit += now_s() - t0;
+                          if (comms) comms->push_back(cv.first);
+                          return cv.second;
+                      },
+                      [&](size_t k) { return std::optional<Scalar>(vals.at(k)); },
+                      [&](size_t k) { return std::optional<uint64_t>(low64(vals.at(k))); }};
+            double t0 = now_s();
+            run_gadget(g, h);
+            sec[0] += t_commit;
+            sec[1] += now_s() - t0 - t_commit;
+        };
+        if (batch == 1) {
+            Transcript t((const char*)label, label_len);
+            Prover prover(pc_gens, t);
+            std::vector<CompressedRistretto> comms;
+            synth(prover, 0, &comms);
+            std::array<uint8_t, 32> seed;
+            memcpy(seed.data(), rng_seeds, 32);
+            prover.set_rng_seed(seed);
+            prover.seconds = sec + 2;
+            std::vector<uint8_t> bytes = prover.prove(bp_gens).to_bytes();
+            if (bytes.size() > proof_cap) return BPR1CS_ERR_INVALID_ARGUMENT;
+            memcpy(proofs_out, bytes.data(), bytes.size());
+            *proof_len = bytes.size();
+            if (commitments_out)
+                for (size_t i = 0; i < comms.size(); i++) memcpy(commitments_out + 32 * i, comms[i].data(), 32);
+        } else {
+            std::vector<uint8_t> vals, bls, wires;
+            bpr1cs_circuit* c = nullptr;
+            size_t n0 = 0, q0 = 0;
+            for (size_t b = 0; b < batch; b++) {
+                Transcript t((const char*)label, label_len);
+                Prover prover(pc_gens, t);
+                prover.defer_commitments = true;
+                synth(prover, b, nullptr);
+                if (b == 0) {   // one circuit for the batch: the constraint system does not depend on the witness
+                    double t0 = now_s();
+                    std::vector<uint32_t> row_off, tvar;
+                    std::vector<uint8_t> tcoeff;
+                    prover.export_csr(row_off, tvar, tcoeff);
+                    bpr1cs_circuit_desc d{};
+                    n0 = prover.a_L.size(); q0 = prover.constraints.size();
+                    d.n = (uint32_t)n0; d.q = (uint32_t)q0; d.m = (uint32_t)m;
+                    d.row_off = row_off.data(); d.term_var = tvar.data(); d.term_coeff = tcoeff.data();
+                    int rc = bpr1cs_circuit_create(&d, &c);
+                    if (rc) throw R1CSError::Backend(rc);
+                    sec[2] += now_s() - t0;
+                } else if (prover.a_L.size() != n0 || prover.constraints.size() != q0) {
+                    bpr1cs_circuit_destroy(c);
+                    return BPR1CS_ERR_INVALID_ARGUMENT;   // a gadget whose shape depends on the witness cannot be batched
+                }
+                prover.export_witness(vals, bls, wires);
+            }
+            vals.push_back(0); bls.push_back(0); wires.push_back(0);
+            const size_t plen = bpr1cs_proof_len(c);
+            if (plen > proof_cap) { bpr1cs_circuit_destroy(c); return BPR1CS_ERR_INVALID_ARGUMENT; }
+            double t0 = now_s();
+            Transcript t((const char*)label, label_len);
+            bpr1cs_transcript* ts[1] = {t.h};
+            int rc = bpr1cs_prove_batch_transcripts(gens, c, ts, 1, vals.data(), bls.data(), rng_seeds, wires.data(), batch, proofs_out, commitments_out);
+            sec[3] += now_s() - t0;
+            bpr1cs_circuit_destroy(c);
+            if (rc) return rc;
+            *proof_len = plen;
+        }
+        sec[4] = now_s() - t_start;
+        if (seconds_out) memcpy(seconds_out, sec, sizeof sec);
         return BPR1CS_OK;
     } catch (const R1CSError& e) {
         return e.code;

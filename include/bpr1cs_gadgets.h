@@ -45,6 +45,20 @@ int bpr1cs_gadget_prove_single(const char* gadget, const uint32_t* iparams, size
                                const uint8_t* values, const uint8_t* v_blindings, size_t m, const uint8_t rng_seed[32],
                                uint8_t* proof_out, size_t proof_cap, size_t* proof_len, uint8_t* commitments_out);
 
+/* The same call shape on generators the caller created ONCE (the reference creates them outside its timed region:
+ * src/gadget_vsmt_4.rs:386-387 against the Instant bracket :421-435), for `batch` witnesses of one gadget.
+ *   batch = 1   literally the reference: Prover::new -> commit x m (one bpr1cs_msm_fixed call each) -> gadget (host synthesis)
+ *               -> prove = bpr1cs_circuit_create + bpr1cs_prove_batch_transcripts(batch 1, host wires), what tools/rust_shim/prover.rs does
+ *   batch > 1   one C++ Prover per witness for the synthesis, then ONE bpr1cs_prove_batch_transcripts call with all the wires
+ *               (the commitments come out of that call)
+ * values / v_blindings: batch*m*32 proof-major; rng_seeds: batch*32; proofs_out: batch * (*proof_len) bytes, proof_cap = room per
+ * proof; commitments_out: batch*m*32 or NULL.  seconds_out (may be NULL): [0] commit calls, [1] gadget synthesis on the host,
+ * [2] CSR export + bpr1cs_circuit_create, [3] the prove call, [4] the whole call. */
+int bpr1cs_gadget_prove_on(const bpr1cs_gens* gens, const char* gadget, const uint32_t* iparams, size_t n_iparams, const uint8_t* sparams,
+                           size_t n_sparams, const uint8_t* poseidon_blob, size_t blob_len, const uint8_t* label, size_t label_len,
+                           const uint8_t* values, const uint8_t* v_blindings, size_t m, size_t batch, const uint8_t* rng_seeds,
+                           uint8_t* proofs_out, size_t proof_cap, size_t* proof_len, uint8_t* commitments_out, double seconds_out[5]);
+
 /* Verifier::new -> commit(V) x m -> gadget (no assignments) -> verify, as the second half of every reference test
  * (e.g. src/gadget_vsmt_4.rs:442-479).  `commitments` = all m commitments in gadget order (statics included).
  * 0 = accepted, BPR1CS_ERR_VERIFICATION / BPR1CS_ERR_FORMAT otherwise. */
