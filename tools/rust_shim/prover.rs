@@ -51,6 +51,15 @@ impl<'t, 'g> Prover<'t, 'g> {
         (self.pc_gens.commit(v, v_blinding), Variable::Committed(i))
     }
 
+    /// reference: `prover.num_constraints()` src/gadget_poseidon.rs:664,743,835, gadget_mimc.rs:138, gadget_vsmt_2.rs:345
+    pub fn num_constraints(&self) -> usize {
+        self.constraints.len()
+    }
+    /// reference: `prover.num_multipliers()` src/gadget_poseidon.rs:664,743,835, gadget_vsmt_2.rs:345
+    pub fn num_multipliers(&self) -> usize {
+        self.a_L.len()
+    }
+
     fn eval(&self, lc: &LinearCombination) -> Scalar {
         lc.terms.iter().map(|(var, coeff)| coeff * match var {
             Variable::MultiplierLeft(i) => self.a_L[*i],
@@ -123,21 +132,23 @@ impl<'t, 'g> ConstraintSystem for Prover<'t, 'g> {
         self.constrain(right);
         (lv, rv, ov)
     }
-    /// the fork's single-wire allocation (src/gadget_poseidon.rs:160-166 pairs two of them into one multiplier)
-    fn allocate(&mut self, assignment: Option<Scalar>) -> Result<Variable, R1CSError> {
+    /// the fork's single-wire allocation, `cs.allocate_single(val) -> Result<(Variable, Option<Variable>), R1CSError>`
+    /// (src/gadget_poseidon.rs:165-166): the first call of a pair opens a multiplier and returns (left, None), the second fills
+    /// its right wire and returns (right, Some(output)) - the output variable the gadget constrains to 1 (gadget_poseidon.rs:184).
+    fn allocate_single(&mut self, assignment: Option<Scalar>) -> Result<(Variable, Option<Variable>), R1CSError> {
         let scalar = assignment.ok_or(R1CSError::MissingAssignment)?;
         match self.pending_multiplier {
             None => {
                 let i = self.a_L.len();
                 self.pending_multiplier = Some(i);
                 self.a_L.push(scalar); self.a_R.push(Scalar::zero()); self.a_O.push(Scalar::zero());
-                Ok(Variable::MultiplierLeft(i))
+                Ok((Variable::MultiplierLeft(i), None))
             }
             Some(i) => {
                 self.pending_multiplier = None;
                 self.a_R[i] = scalar;
                 self.a_O[i] = self.a_L[i] * self.a_R[i];
-                Ok(Variable::MultiplierRight(i))
+                Ok((Variable::MultiplierRight(i), Some(Variable::MultiplierOutput(i))))
             }
         }
     }

@@ -30,6 +30,13 @@ impl<'t> Verifier<'t> {
         self.V.push(commitment);
         Variable::Committed(i)
     }
+    /// the fork's counters (the reference prints them from the Prover; kept on both sides like the C++ twin, host/r1cs.hpp:250-251)
+    pub fn num_constraints(&self) -> usize {
+        self.constraints.len()
+    }
+    pub fn num_multipliers(&self) -> usize {
+        self.num_vars
+    }
     /// reference: `verifier.verify(&proof, &pc_gens, &bp_gens).is_ok()` src/gadget_vsmt_4.rs:479
     pub fn verify(self, proof: &R1CSProof, _pc_gens: &PedersenGens, bp_gens: &BulletproofGens) -> Result<(), R1CSError> {
         // bpr1cs_verify_batch starts from Transcript::new(label): all the reference ever hands over (its 30 call sites create the
@@ -85,17 +92,18 @@ impl<'t> ConstraintSystem for Verifier<'t> {
         self.constrain(right);
         (lv, rv, ov)
     }
-    fn allocate(&mut self, _: Option<Scalar>) -> Result<Variable, R1CSError> {
+    /// the fork's `allocate_single` (src/gadget_poseidon.rs:165-166): same pairing as the Prover, no assignments
+    fn allocate_single(&mut self, _: Option<Scalar>) -> Result<(Variable, Option<Variable>), R1CSError> {
         match self.pending_multiplier {
             None => {
                 let i = self.num_vars;
                 self.num_vars += 1;
                 self.pending_multiplier = Some(i);
-                Ok(Variable::MultiplierLeft(i))
+                Ok((Variable::MultiplierLeft(i), None))
             }
             Some(i) => {
                 self.pending_multiplier = None;
-                Ok(Variable::MultiplierRight(i))
+                Ok((Variable::MultiplierRight(i), Some(Variable::MultiplierOutput(i))))
             }
         }
     }
