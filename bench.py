@@ -11,7 +11,7 @@ The timed region is ONE call of the library's plain entry point - bpr1cs_prove_b
 created with NO options: window width, proofs per device job and jobs in flight are the library's defaults, so what is
 measured is what any caller of the C ABI gets (config keys `proofs_per_device_job`, `device_jobs` report what it chose).
 
-    python bench.py [--config c2|c3|c4|c5|vsmt4_d128|vsmt2_d253] [--gpus N] [--steps K] [--warmup W] [--configs LIST]
+    python bench.py [--config c1|c2|c3|c4|c5|vsmt4_d128|vsmt2_d253] [--gpus N] [--steps K] [--warmup W] [--configs LIST]
 `--gpus N` with N > 1 launches N ranks by itself (python -m torch.distributed.run --nnodes=1 --nproc-per-node N, rendezvous on
 127.0.0.1) unless it already runs under a launcher (WORLD_SIZE set, which must then equal N); one rank per GPU over RCCL.
 After the headline the same run times the other BASELINE configurations (`configs` block of the JSON: c2, c3, c5 and the
@@ -49,6 +49,9 @@ def build_workload(bp, levels, batch, n_leaves, seed_base):
 # batch = proofs per GPU per step; short = (warm-up steps, timed steps) of the configuration's short run inside the headline run;
 # fixture = its batch in tests/golden/fullsize_digests.json (the C oracle's digest of every proof) when the inputs are the same
 CONFIGS = {
+    "c1": dict(metric="R1CS proofs/sec (64-bit bound check)", batch=4096, cpu_proofs=64, short=(8, 48), fixture="c1_bound_check64_x4096",
+               workload="gadget_bound_check 64-bit range proof (n = 128; reference src/gadget_bound_check.rs:18-87), BASELINE config 1; its single-prover form is in the `latency` block",
+               build=lambda bp, B, base, a: wl.bound_check64(B, index_base=base)),
     "c2": dict(metric="R1CS proofs/sec (Poseidon 2:1 cube-S-box preimage)", batch=4096, cpu_proofs=48, short=(8, 48), fixture="c2_poseidon2_cube_x4096",
                workload="gadget_poseidon 2:1 Cube-S-box preimage proof (148 rounds; reference src/gadget_poseidon.rs:692-790)",
                build=lambda bp, B, base, a: wl.poseidon_2to1_cube(bp, None, B, index_base=base)),
@@ -315,6 +318,43 @@ def measure(bp, lib, gens, circ, w, B, steps, warm_steps, barrier=None):
     return dt, proofs, comms, bp.last_prove_stats(lib)
 
 
+LATENCY_SHAPE = ("the reference's own call shape - ONE proof per prove() inside its timed bracket (src/gadget_vsmt_4.rs:421-435, "
+                 "gadget_bound_check.rs:49-87, gadget_poseidon.rs:734-747): Prover::new -> commit x m -> gadget synthesis on the host -> prove(), on "
+                 "generators created once outside the bracket (:386-387).  = bpr1cs_gadget_prove_on: per commit one bpr1cs_msm_fixed call, then CSR "
+                 "export + bpr1cs_circuit_create (cached per description) + bpr1cs_prove_batch_transcripts(batch, HOST wires) - exactly what "
+                 "tools/rust_shim/prover.rs does for batch 1; batch 8 / 64 = that many host syntheses, ONE device call")
+
+
+def run_latency(bp, lib, case, w, gens, fixture, batches=(1, 8, 64)):
+    """ms per proof of `case` through the reference's call shape at batch 1 / 8 / 64 (median of a few calls each, first call
+    untimed), every proof compared with the committed digest of the C oracle's proof of the same witness"""
+    import statistics
+    fx = json.load(open(os.path.join(ROOT, "tests", "golden", "fullsize_digests.json")))[fixture]["proofs"]
+    m, out = w["m"], {}
+    for B in batches:
+        v, b, s = w["values"][:B * m * 32], w["blindings"][:B * m * 32], w["seeds"][:B * 32]
+        reps = 5 if B == 1 else (3 if B <= 8 else 2)
+        walls, stages, phases, ok, checked = [], [], [], True, 0
+        for rep in range(reps + 1):
+            t0 = time.perf_counter()
+            P, C, sec = bp.gadget_prove_on(gens, w["gadget"], w["ip"], w["sp"], w["label"], v, b, m, B, s)
+            wall = time.perf_counter() - t0
+            if rep == 0:   # (first call of a shape: arenas, the circuit cache)
+                ok = all(hashlib.sha256(P[j]).hexdigest()[:32] == fx[j] for j in range(B))
+                checked = B
+                continue
+            walls.append(wall)
+            stages.append(sec)
+            phases.append(bp.last_prove_stats(lib)["phase_ms"])
+        med = statistics.median(walls)
+        k = walls.index(sorted(walls)[len(walls) // 2])
+        out["b%d" % B] = {"ms_per_call": 1e3 * med, "ms_per_proof": 1e3 * med / B, "calls_timed": reps, "ms_per_call_min": 1e3 * min(walls),
+                          "stage_ms": {kk: 1e3 * x for kk, x in stages[k].items()},
+                          "device_phase_ms": dict(zip(["total", "inputs+commitV", "rng||witness", "commit_msm", "poly", "ipa"], phases[k])),
+                          "parity": {"ok": ok, "proofs": checked, "source": "tests/golden/fullsize_digests.json[%s]" % fixture}}
+    return out
+
+
 def run_short_config(bp, lib, name, args, gens_by_cap):
     """One of the other BASELINE configurations inside the headline run: fixture-sized batch, library defaults, a short timed
     region -> dict for the `configs` block (throughput + parity of EVERY proof of one batch against the committed oracle digests)"""
@@ -368,8 +408,9 @@ def main():
     ap.add_argument("--leaves", type=int, default=0, help="c4 only: distinct synthetic leaves cycled over the batch (0 = one per proof)")
     ap.add_argument("--cpu-proofs", type=int, default=-1, help="proofs timed on ONE thread of the CPU oracle (0 = skip the CPU leg, -1 = the configuration's)")
     ap.add_argument("--cpu-threads", type=int, default=128, help="upper bound of the all-cores CPU run")
-    ap.add_argument("--configs", default="default", help="other configurations timed after the headline (rank 0 of a 1-GPU run): 'default' = c4,c3,c2,c5,vsmt4_d128,vsmt2_d253 (those on the headline's generator tables first) "
+    ap.add_argument("--configs", default="default", help="other configurations timed after the headline (rank 0 of a 1-GPU run): 'default' = c4,c3,c1,c2,c5,vsmt4_d128,vsmt2_d253 (those on the headline's generator tables first) "
                     "for the default c4 run, 'none', or a comma list")
+    ap.add_argument("--latency", type=int, default=1, help="1 (default): the `latency` block - ONE proof per prove() call and 8 / 64 witnesses per call, c1 and c4 (1-GPU c4 runs)")
     ap.add_argument("--dry-run", action="store_true", help="CPU rehearsal of the launch / rendezvous / timing path (no prover)")
     # measuring options: anything given here is an EXPLICIT option of the generator handle (the default run sets none)
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE", help="option of the generator handle (bpr1cs_gens_create_opts), e.g. unfold=3, job_proofs=1024, "
@@ -578,10 +619,28 @@ def main():
                 out["parity_vs_cpu_oracle"] = all(cproofs[j] == proofs[j] for j in range(len(cproofs)))
         else:
             out["cpu_baseline"] = None
+        # the reference's own call shape: one proof per prove() (and 8 / 64 witnesses per call), c4 on the headline's tables, c1 on its own
+        if world == 1 and args.latency and args.config == "c4" and args.depth == 32:
+            try:
+                gens.release_scratch()
+                lat = {"call_shape": LATENCY_SHAPE}
+                lat["c4"] = run_latency(bp, lib, "c4", wl.vsmt4(bp, None, 32, 64, 64, 0), gens, "c4_vsmt4_d32_x2024")
+                gens.release_scratch()
+                g1 = bp.Gens(128)
+                lat["c1"] = run_latency(bp, lib, "c1", wl.bound_check64(64), g1, "c1_bound_check64_x4096")
+                g1.close()
+                cb = out.get("cpu_baseline") or {}
+                st1 = (cb.get("single_thread") or {}).get("value")
+                if st1:
+                    lat["c4"]["cpu_port_ms_per_proof"] = 1e3 / st1
+                    lat["c4"]["speedup_b1_vs_cpu_port_1_thread"] = (1e3 / st1) / lat["c4"]["b1"]["ms_per_proof"]
+                out["latency"] = lat
+            except Exception as e:  # pragma: no cover
+                out["latency"] = {"error": repr(e)}
         # the other BASELINE configurations, each a short run of its own with the library's defaults (1-GPU runs only)
         which = args.configs
         if which == "default":
-            which = "c4,c3,c2,c5,vsmt4_d128,vsmt2_d253" if (args.config == "c4" and args.depth == 32 and not options and world == 1) else "none"
+            which = "c4,c3,c1,c2,c5,vsmt4_d128,vsmt2_d253" if (args.config == "c4" and args.depth == 32 and not options and world == 1) else "none"
         if which != "none" and world == 1:
             circ.close()
             gens_by_cap = {N: gens}

@@ -6,7 +6,6 @@
 // The batched verifier of a job sharded over several GPUs is the path's only inter-GPU step.  A host in any language gets
 // it here: RCCL (librccl, loaded on first use: the library carries no link-time dependency on it) all_gathers the ranks'
 // combined scalar vectors and their 65 result bytes over xGMI; everything else is the entry points above.
-#if !defined(BPR1CS_HOSTSIM)
 #include <dlfcn.h>
 // The four RCCL entry points this file uses, declared HERE: building the library needs no RCCL headers, and its ABI does not
 // follow whichever rccl.h happens to be installed (the NCCL C ABI of these functions has been stable since NCCL 2.0).
@@ -16,7 +15,7 @@ enum { BP_NCCL_SUCCESS = 0, BP_NCCL_UINT8 = 1 };     // ncclSuccess, ncclUint8
 typedef int (*bp_nccl_get_unique_id_fn)(bp_nccl_unique_id*);
 typedef int (*bp_nccl_comm_init_rank_fn)(bp_nccl_comm*, int, bp_nccl_unique_id, int);
 typedef int (*bp_nccl_comm_destroy_fn)(bp_nccl_comm);
-typedef int (*bp_nccl_all_gather_fn)(const void*, void*, size_t, int, bp_nccl_comm, hipStream_t);
+typedef int (*bp_nccl_all_gather_fn)(const void*, void*, size_t, int, bp_nccl_comm, void* /* hipStream_t */);
 struct RcclApi {
     bp_nccl_get_unique_id_fn get_unique_id = nullptr;
     bp_nccl_comm_init_rank_fn comm_init_rank = nullptr;
@@ -27,8 +26,15 @@ struct RcclApi {
 static RcclApi& rccl_api() {
     static RcclApi api = [] {
         RcclApi a;
+#if defined(BPR1CS_HOSTSIM)
+        // the CPU simulator of the tests has no device for RCCL to drive: its communicator is whatever library the test names
+        // (tests/fake_rccl: the same four entry points over shared memory, ranks = processes).  Test build only.
+        const char* path = getenv("BPR1CS_SIM_RCCL");
+        void* h = path ? dlopen(path, RTLD_NOW | RTLD_LOCAL) : nullptr;
+#else
         void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
         if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+#endif
         if (!h) return a;
         a.get_unique_id = (bp_nccl_get_unique_id_fn)dlsym(h, "ncclGetUniqueId");
         a.comm_init_rank = (bp_nccl_comm_init_rank_fn)dlsym(h, "ncclCommInitRank");
@@ -39,19 +45,18 @@ static RcclApi& rccl_api() {
     }();
     return api;
 }
+static void comm_release_cached() {
+#if !defined(BPR1CS_HOSTSIM)
+    dev_pool().release_all();
 #endif
+}
 struct bpr1cs_comm {
     int rank = 0, world = 1;
     bool owned = false;
-#if !defined(BPR1CS_HOSTSIM)
     bp_nccl_comm comm = nullptr;
-#endif
 };
 extern "C" int bpr1cs_comm_unique_id(uint8_t id_out[128]) {
     if (!id_out) return BPR1CS_ERR_INVALID_ARGUMENT;
-#if defined(BPR1CS_HOSTSIM)
-    return BPR1CS_ERR_NO_DEVICE;
-#else
     if (!have_device()) return BPR1CS_ERR_NO_DEVICE;
     if (!rccl_api().ok) return BPR1CS_ERR_DEVICE;
     bp_nccl_unique_id id;
@@ -59,13 +64,9 @@ extern "C" int bpr1cs_comm_unique_id(uint8_t id_out[128]) {
     if (rccl_api().get_unique_id(&id) != BP_NCCL_SUCCESS) return BPR1CS_ERR_DEVICE;
     memcpy(id_out, &id, 128);
     return BPR1CS_OK;
-#endif
 }
 extern "C" int bpr1cs_comm_create(const uint8_t id[128], int rank, int world, bpr1cs_comm** out) {
     if (!id || !out || world < 1 || rank < 0 || rank >= world) return BPR1CS_ERR_INVALID_ARGUMENT;
-#if defined(BPR1CS_HOSTSIM)
-    return BPR1CS_ERR_NO_DEVICE;
-#else
     if (!have_device()) return BPR1CS_ERR_NO_DEVICE;
     if (!rccl_api().ok) return BPR1CS_ERR_DEVICE;
     bp_nccl_unique_id uid;
@@ -77,57 +78,60 @@ extern "C" int bpr1cs_comm_create(const uint8_t id[128], int rank, int world, bp
         // RCCL allocates its own device buffers: when this library's allocator cache holds the rest of the device, give it back
         // and try once more (only where no other rank is waiting inside the same collective initialisation)
         if (rccl_api().comm_init_rank(&c->comm, world, uid, rank) != BP_NCCL_SUCCESS) {
-            dev_pool().release_all();
+            comm_release_cached();
             bp_nccl_unique_id uid2;
             if (rccl_api().get_unique_id(&uid2) != BP_NCCL_SUCCESS || rccl_api().comm_init_rank(&c->comm, 1, uid2, 0) != BP_NCCL_SUCCESS) { delete c; return BPR1CS_ERR_DEVICE; }
         }
     } else {
-        dev_pool().release_all();   // before the ranks meet: cached blocks are of no use to RCCL
+        comm_release_cached();   // before the ranks meet: cached blocks are of no use to RCCL
         if (rccl_api().comm_init_rank(&c->comm, world, uid, rank) != BP_NCCL_SUCCESS) { delete c; return BPR1CS_ERR_DEVICE; }
     }
     *out = c;
     return BPR1CS_OK;
-#endif
 }
 extern "C" int bpr1cs_comm_wrap(void* nccl_comm, int rank, int world, bpr1cs_comm** out) {
     if (!nccl_comm || !out || world < 1 || rank < 0 || rank >= world) return BPR1CS_ERR_INVALID_ARGUMENT;
-#if defined(BPR1CS_HOSTSIM)
-    return BPR1CS_ERR_NO_DEVICE;
-#else
     if (!rccl_api().ok) return BPR1CS_ERR_DEVICE;
     bpr1cs_comm* c = new (std::nothrow) bpr1cs_comm();
     if (!c) return BPR1CS_ERR_OUT_OF_MEMORY;
     c->rank = rank; c->world = world; c->owned = false; c->comm = (bp_nccl_comm)nccl_comm;
     *out = c;
     return BPR1CS_OK;
-#endif
 }
 extern "C" void bpr1cs_comm_destroy(bpr1cs_comm* c) {
     if (!c) return;
-#if !defined(BPR1CS_HOSTSIM)
     if (c->owned && c->comm && rccl_api().ok) (void)rccl_api().comm_destroy(c->comm);
-#endif
     delete c;
 }
-// all_gather of `len` bytes per rank through device buffers on the handle's stream (no communicator: a copy)
-static int comm_all_gather(const bpr1cs_gens* g, const bpr1cs_comm* c, const uint8_t* mine, size_t len, std::vector<uint8_t>& all) {
+// One all_gather of `len` bytes per rank through device buffers on the handle's stream (no communicator: a copy).  The buffers of
+// BOTH collectives of a sharded verification are allocated before the first is posted (GatherBufs), so that no rank can fail
+// between them for want of memory; a rank whose upload fails still POSTS the collective - with whatever the zeroed buffer
+// holds - and reports the failure afterwards: its peers are inside the same collective and must not be left there, and a rank
+// that skipped the first collective would meet them with a different byte count in the second (undefined in RCCL).
+struct GatherBufs {
+    DevBuf<uint8_t> in, out;
+    size_t len = 0;
+    void alloc(size_t len_, int world, dev_stream_t st) {
+        len = len_;
+        in.alloc(len);
+        out.alloc((size_t)world * len);
+        dev_zero(in.p, len, st);
+    }
+};
+static int comm_all_gather(const bpr1cs_gens* g, const bpr1cs_comm* c, GatherBufs& b, const uint8_t* mine, std::vector<uint8_t>& all) {
     const int world = c ? c->world : 1;
+    const size_t len = b.len;
     all.assign((size_t)world * len, 0);
     if (!c) { memcpy(all.data(), mine, len); return BPR1CS_OK; }   // (a communicator of ONE rank still goes through RCCL)
-#if defined(BPR1CS_HOSTSIM)
-    (void)g;
-    return BPR1CS_ERR_NO_DEVICE;
-#else
-    API_TRY
     dev_stream_t st = g->stream;
-    CallScope scope(st);
-    DevBuf<uint8_t> d_in(len), d_out((size_t)world * len);
-    dev_h2d(d_in.p, mine, len, st);
-    if (rccl_api().all_gather(d_in.p, d_out.p, len, BP_NCCL_UINT8, c->comm, st) != BP_NCCL_SUCCESS) return BPR1CS_ERR_DEVICE;
-    dev_d2h(all.data(), d_out.p, (size_t)world * len, st);
+    int rc = BPR1CS_OK;
+    try { dev_h2d(b.in.p, mine, len, st); } catch (...) { rc = BPR1CS_ERR_DEVICE; }
+    if (rccl_api().all_gather(b.in.p, b.out.p, len, BP_NCCL_UINT8, c->comm, (void*)(uintptr_t)st) != BP_NCCL_SUCCESS) return BPR1CS_ERR_DEVICE;
+    if (rc != BPR1CS_OK) return rc;
+    API_TRY
+    dev_d2h(all.data(), b.out.p, (size_t)world * len, st);
     return BPR1CS_OK;
     API_CATCH
-#endif
 }
 extern "C" int bpr1cs_verify_batch_sharded(const bpr1cs_gens* g, const bpr1cs_circuit* c, const uint8_t* label, size_t label_len,
                                            const uint8_t* proofs, const uint8_t* commitments, const uint8_t* verifier_rng_seeds,
@@ -137,6 +141,18 @@ extern "C" int bpr1cs_verify_batch_sharded(const bpr1cs_gens* g, const bpr1cs_ci
     *accepted_out = 0;
     const int rank = comm ? comm->rank : 0, world = comm ? comm->world : 1;
     const size_t N = c->N, nb = 2 * N + 2, vlen = 32 * nb;
+    if (comm && !rccl_api().ok) return BPR1CS_ERR_DEVICE;
+    // 0. the device buffers of both collectives, before anything is posted: a rank that cannot have them returns HERE, where no
+    //    peer can be inside a collective it will not join (they are: the caller's protocol has to treat an error of one rank of
+    //    a sharded call as fatal for the job, as with any collective library)
+    CallScope scope(g->stream);
+    GatherBufs gb1, gb2;
+    if (comm) {
+        API_TRY
+        gb1.alloc(vlen, world, g->stream);
+        gb2.alloc(72, world, g->stream);
+        API_CATCH
+    } else { gb1.len = vlen; gb2.len = 72; }
     // 1. this rank's combined scalar vector and the weighted sum of its proofs' own points.  A rank that fails locally still
     //    takes part in both collectives (zero vector, "not well-formed"): the others must never be left waiting.
     std::vector<uint8_t> vec(vlen, 0), all;
@@ -148,7 +164,7 @@ extern "C" int bpr1cs_verify_batch_sharded(const bpr1cs_gens* g, const bpr1cs_ci
     // 2. all_gather of the scalar vectors ((2N+2)*32 bytes per rank, ~2 MB at N = 32768), summed mod l
     //    A failure of the gather on THIS rank (allocation, HIP error) does not end the call either: the second collective below
     //    is still entered - with "not well-formed" - so that no other rank is left blocked in it; the first error is what is returned.
-    int rc = comm_all_gather(g, comm, vec.data(), vlen, all);
+    int rc = comm_all_gather(g, comm, gb1, vec.data(), all);
     if (rc_local == BPR1CS_OK) rc_local = rc;
     std::vector<uint8_t> total(vlen);
     if (rc != BPR1CS_OK || bpr1cs_scalars_sum(all.data(), (size_t)world, nb, total.data()) != BPR1CS_OK) wf = 0;
@@ -166,7 +182,7 @@ extern "C" int bpr1cs_verify_batch_sharded(const bpr1cs_gens* g, const bpr1cs_ci
     // 4. all_gather of (slice point, own-points sum, well-formed flag): 65 bytes per rank, padded to 72
     uint8_t mine[72] = {0};
     memcpy(mine, slice_pt, 32); memcpy(mine + 32, own, 32); mine[64] = wf ? 1 : 0;
-    rc = comm_all_gather(g, comm, mine, sizeof mine, all);
+    rc = comm_all_gather(g, comm, gb2, mine, all);
     if (rc_local == BPR1CS_OK) rc_local = rc;
     if (rc_local != BPR1CS_OK) return rc_local;   // a local failure (out of memory, invalid argument ...) is an error, not a rejected proof
     std::vector<uint8_t> pts((size_t)2 * world * 32);

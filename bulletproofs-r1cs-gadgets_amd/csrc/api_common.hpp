@@ -150,6 +150,9 @@ struct bpr1cs_gens {
     mutable dev_event_t w_free_ev{}, rng_free_ev{};
     mutable std::atomic<uint32_t> busy_slots{0};  // bit s: job slot s (streams jstream[s], arena front[s]) belongs to a job in flight
     mutable std::atomic<int> in_flight{0};  // jobs begun and not yet ended
+    // bumped whenever something the automatic job size depends on changes (an option set, the scratch released, an
+    // out-of-memory fallback): a job size remembered for (circuit, handle) under an older value is computed afresh
+    mutable std::atomic<uint32_t> sizing_epoch{1};
     mutable BpOpts opts;
 };
 
@@ -179,7 +182,8 @@ struct bpr1cs_circuit {
         DevBuf<ge> ones_pt;  // sum over the triples of G_m + G_m+2: the constant part of A_O (K_triple_ones_point)
         DevBuf<uint8_t> hs_tab;  // table of the single point sum_{n - N/2 <= i < N/2} H_i (K_range_sum_points), when n > N/2
         uint32_t hs_W = 0, hs_cap = 0;
-        uint32_t job_proofs = 0;   // proofs per device job chosen for (this circuit, this handle) by the first bpr1cs_prove_batch: kept for the later ones
+        uint32_t job_proofs = 0;   // proofs per device job chosen for (this circuit, this handle) by the first bpr1cs_prove_batch: kept for the later ones ...
+        uint32_t job_epoch = 0;    // ... while the handle's sizing_epoch is the one it was chosen under
     };
     mutable std::mutex mt_mu;
     mutable std::map<const bpr1cs_gens*, MergedTab*> mt;

@@ -59,7 +59,7 @@ static void host_stage_free(void* p) {
 #endif
 }
 // wait for everything a job has enqueued and release what it holds (normal end and error paths)
-static void job_release(bpr1cs_job* job) {
+static void job_wait(bpr1cs_job* job) {
     if (!job) return;
     // the heavy stream is shared with the NEXT job in flight: wait for this job's own completion event, and for the
     // whole stream only when the job failed before recording it
@@ -68,6 +68,12 @@ static void job_release(bpr1cs_job* job) {
     else if (job->st) (void)hipStreamSynchronize(job->st);
     if (job->st2) (void)hipStreamSynchronize(job->st2);
     if (job->st3) (void)hipStreamSynchronize(job->st3);
+#endif
+}
+static void job_release(bpr1cs_job* job) {
+    if (!job) return;
+    job_wait(job);
+#if !defined(BPR1CS_HOSTSIM)
     for (auto e : job->pt.ev) (void)hipEventDestroy(e);
     job->pt.ev.clear();
 #endif
@@ -89,9 +95,32 @@ static void job_release(bpr1cs_job* job) {
 // job size (more proofs per fetched table row) - so from 8 GiB on they are built one window bit narrower (+13 % additions on 3 %
 // of the terms, half the bytes).
 static TabCfg merged_tab_cfg(const bpr1cs_gens* g, uint32_t T3) {
-    const char* force = getenv("BPR1CS_TEST_NARROW_MERGED");   // test knob: take the narrower window whatever the size
+#if defined(BPR1CS_HOSTSIM)
+    const char* force = getenv("BPR1CS_TEST_NARROW_MERGED");   // test knob (simulator build only): take the narrower window whatever the size
+#else
+    const char* force = nullptr;
+#endif
     if (g->tc.W > 4 && ((size_t)2 * T3 * g->tc.base_bytes() > ((size_t)8 << 30) || (force && force[0] == '1'))) return tab_cfg(g->tc.W - 1);
     return g->tc;
+}
+
+// A job that failed while it was being enqueued (out of memory in the back phase, a HIP error): the kernels it did enqueue have
+// written wires, blindings, s_L / s_R and TranscriptRng output into blocks whose wipes were never reached.  include/bpr1cs.h promises
+// that secrets are zeroed before their blocks return to the allocator, so: wait for what the job enqueued, zero the slot's own
+// arena - and, when no other job of the handle is in flight (their blocks are shared with it otherwise, and that job wipes them
+// itself at its end), the shared front and the back arena - and only then release.
+static int prove_job_fail(const bpr1cs_gens* g, bpr1cs_job* job, uint32_t slot, int code) {
+    if (!job) { g->busy_slots.fetch_and(~(1u << slot)); return code; }
+    job_wait(job);
+    try {
+        const dev_stream_t st = g->jstream[slot][1];
+        g->front[slot].wipe(st);
+        if (g->in_flight.load() == 0) { g->shared_front.wipe(st); g->arena.wipe(st); }
+        for (void* p : job->deferred) (void)p;   // (blocks replaced while enqueuing: too small to have been written by this job's kernels)
+        dev_sync(st);
+    } catch (...) {}
+    job_release(job);
+    return code;
 }
 
 // One device job.  `init`: the transcripts the proofs start from - n_init = 1 (every proof starts from a copy of init[0]: what
@@ -433,9 +462,9 @@ static int prove_job_begin(const bpr1cs_gens* g, const bpr1cs_circuit* c, const 
     *job_out = job;
     return BPR1CS_OK;
     }
-    catch (const DevError& e_) { if (!job) g->busy_slots.fetch_and(~(1u << slot)); job_release(job); return e_.code; }
-    catch (const std::bad_alloc&) { if (!job) g->busy_slots.fetch_and(~(1u << slot)); job_release(job); return BPR1CS_ERR_OUT_OF_MEMORY; }
-    catch (...) { if (!job) g->busy_slots.fetch_and(~(1u << slot)); job_release(job); return BPR1CS_ERR_DEVICE; }
+    catch (const DevError& e_) { return prove_job_fail(g, job, slot, e_.code); }
+    catch (const std::bad_alloc&) { return prove_job_fail(g, job, slot, BPR1CS_ERR_OUT_OF_MEMORY); }
+    catch (...) { return prove_job_fail(g, job, slot, BPR1CS_ERR_DEVICE); }
 }
 
 // wait for a job, copy its results out and add its statistics to `acc` (nullptr: none)
@@ -469,12 +498,13 @@ static int prove_job_end(bpr1cs_job* job, uint8_t* proofs_out, uint8_t* commitme
     return rc;
 }
 
-// Proofs per device job when a batch is cut into jobs (BPR1CS_OPT_JOB_PROOFS = 0): the largest of 4096, 2048, ... 64 whose working
+// Proofs per device job when a batch is cut into jobs (BPR1CS_OPT_JOB_PROOFS = 0): the largest candidate size whose working
 // set - the fronts of the jobs in flight, ONE shared back phase, the circuit's merged tables if they are still to be built - fits
 // into the memory the device has left next to the generator tables.  Per proof: the front holds the wires and blinding vectors
 // (5 n scalars), the raw TranscriptRng output (64 B x (2n + 7)) and the IPA tail's copies; the back holds l / r (2 N scalars),
 // the shared block (the larger of the flattened constraints + product scalars and the Straus multiples of the first
-// variable-base pair) and the folded generators.  2048 for the depth-32 tree circuits on a 288 GB device.
+// variable-base pair) and the folded generators.  Candidates: sizes[] below (16384 ... 128, then 64); 4096 for the depth-32
+// tree circuits next to W = 11 tables on a 288 GB device, 16384 for the small circuits.
 static uint32_t auto_job_proofs(const bpr1cs_gens* g, const bpr1cs_circuit* c, bool have_program, int in_flight) {
     const size_t n = c->n, m = c->m, N = c->N;
     const uint32_t r = eff_unfold(g->opts, 4096, c->lgN);   // (the job sizes considered here are large ones)
@@ -512,6 +542,9 @@ static int prove_batch_impl(const bpr1cs_gens* g, const bpr1cs_circuit* c, const
     if (!g || !c || !proofs_out || batch == 0) return BPR1CS_ERR_INVALID_ARGUMENT;
     if (batch > ((size_t)1 << 28)) return BPR1CS_ERR_INVALID_ARGUMENT;
     if (!have_device()) return BPR1CS_ERR_NO_DEVICE;
+    // this call uses both job slots of the handle and may, on out of memory, hand the handle's arenas back: not while a job the
+    // caller opened with bpr1cs_prove_batch_begin is still in flight on it (include/bpr1cs.h)
+    if (g->in_flight.load() != 0) return BPR1CS_ERR_INVALID_ARGUMENT;
     bpr1cs_prove_stats acc{};
     const int depth = g->opts.jobs_in_flight.load() == 1 ? 1 : 2;
     size_t J = (size_t)g->opts.job_proofs.load();
@@ -519,11 +552,14 @@ static int prove_batch_impl(const bpr1cs_gens* g, const bpr1cs_circuit* c, const
     const size_t grid_max = (size_t)std::min<uint64_t>(0xffffffffull / grid_per_proof, 1u << 20);
     if (grid_max == 0) return BPR1CS_ERR_INVALID_ARGUMENT;
     const bool automatic = J == 0;
-    auto remember = [&](size_t j, bool overwrite) {   // the automatic choice belongs to (circuit, handle): the same for every call
+    // the automatic choice belongs to (circuit, handle) and to the handle's sizing epoch: the same for every call until an option
+    // changes, the scratch is released or a call ran out of memory
+    auto remember = [&](size_t j) {
         std::lock_guard<std::mutex> lk(c->mt_mu);
         bpr1cs_circuit::MergedTab*& mt = c->mt[g];
         if (!mt) mt = new bpr1cs_circuit::MergedTab();
-        if (overwrite || !mt->job_proofs) mt->job_proofs = (uint32_t)j;
+        const uint32_t ep = g->sizing_epoch.load();
+        if (!mt->job_proofs || mt->job_epoch != ep) { mt->job_proofs = (uint32_t)j; mt->job_epoch = ep; }
         return (size_t)mt->job_proofs;
     };
     if (automatic) {
@@ -531,9 +567,9 @@ static int prove_batch_impl(const bpr1cs_gens* g, const bpr1cs_circuit* c, const
         {
             std::lock_guard<std::mutex> lk(c->mt_mu);
             auto it = c->mt.find(g);
-            if (it != c->mt.end()) known = it->second->job_proofs;
+            if (it != c->mt.end() && it->second->job_epoch == g->sizing_epoch.load()) known = it->second->job_proofs;
         }
-        J = known ? known : remember(auto_job_proofs(g, c, wires == nullptr, depth), false);
+        J = known ? known : remember(auto_job_proofs(g, c, wires == nullptr, depth));
     }
     J = std::min(J, grid_max);
     const size_t m = c->m, plen = bpr1cs_proof_len(c), wn = 3 * (size_t)c->n;
@@ -551,8 +587,12 @@ static int prove_batch_impl(const bpr1cs_gens* g, const bpr1cs_circuit* c, const
     bool retried = false;
     // test knob (tests/test_hostsim.py): BPR1CS_TEST_FAIL_JOBS=k makes the first k job submissions of this call report "out of
     // memory", so that the drain / hand back / retry / halve path below runs without a device that is actually full
-    const char* inj = getenv("BPR1CS_TEST_FAIL_JOBS");
+#if defined(BPR1CS_HOSTSIM)
+    const char* inj = getenv("BPR1CS_TEST_FAIL_JOBS");   // (simulator build only: the shipped library reads no test knobs)
     int inject_oom = inj ? atoi(inj) : 0;
+#else
+    int inject_oom = 0;
+#endif
     // (A smaller first job - a quarter of the size, so that its exposed TranscriptRng chain is shorter and the full-size jobs start
     // sooner - was measured in round 4: 3041-3049 against 3077-3090 proofs/s at 20 steps; the extra job costs more than it hides.)
     while (done < batch && rc == BPR1CS_OK) {
@@ -577,8 +617,10 @@ static int prove_batch_impl(const bpr1cs_gens* g, const bpr1cs_circuit* c, const
             dev_pool().release_all();
 #endif
             if (retried) {
-                J = std::max<size_t>(64, take / 2);
-                if (automatic) remember(J, true);
+                // half of what just failed, for the rest of THIS call only; the remembered choice is dropped, so the next call sizes
+                // its jobs from the memory that is free then - a transient shortage (or a short last job) does not pin a small size
+                J = std::max<size_t>(64, std::min(J, take) / 2);
+                if (automatic) g->sizing_epoch++;
             }
             retried = !retried;
             continue;

@@ -22,7 +22,9 @@ int bpr1cs_set_device(int ordinal) {
 int bpr1cs_circuit_macro_perms(const bpr1cs_circuit* c) { return c ? (int)c->n_perms : 0; }
 int bpr1cs_gens_set_option(bpr1cs_gens* g, int option, int value) {
     if (!g) return BPR1CS_ERR_INVALID_ARGUMENT;
-    return opt_apply(g->opts, option, value, false) ? BPR1CS_OK : BPR1CS_ERR_INVALID_ARGUMENT;
+    if (!opt_apply(g->opts, option, value, false)) return BPR1CS_ERR_INVALID_ARGUMENT;
+    g->sizing_epoch++;   // job sizes remembered under the old options are chosen again
+    return BPR1CS_OK;
 }
 int bpr1cs_gens_table_info(const bpr1cs_gens* g, uint32_t* window_bits, uint32_t* windows, uint32_t* format, uint64_t* bytes) {
     if (!g) return BPR1CS_ERR_INVALID_ARGUMENT;
@@ -39,6 +41,7 @@ int bpr1cs_gens_release_scratch(bpr1cs_gens* g) {
     g->front[0].release();
     g->front[1].release();
     g->shared_front.release();
+    g->sizing_epoch++;
     return BPR1CS_OK;
 }
 int bpr1cs_release_cached_memory(void) {
@@ -199,7 +202,7 @@ int bpr1cs_circuit_create(const bpr1cs_circuit_desc* d, bpr1cs_circuit** out) {
     while (c->N < d->n) { c->N <<= 1; c->lgN++; }
     dev_stream_t s{};
     CallScope scope(s);
-    const char* wm_env = getenv("BPR1CS_WITNESS_MACRO");   // test knob: 0 = run every S-box op by op (one inversion each)
+    const char* wm_env = getenv("BPR1CS_WITNESS_MACRO");   // diagnostic (include/bpr1cs.h, "Environment"): 0 = run every S-box op by op (one inversion each); same results
     const int witness_macro = !(wm_env && wm_env[0] == '0');
     // CSR by row -> CSC by wire slot (LEFT i -> i, RIGHT -> n+i, OUT -> 2n+i, COMMITTED -> 3n+i, One -> 3n+m).
     // The prover flattens slots [0, 3n+m) (it ignores constant terms); the verifier also needs slot 3n+m (w_c).

@@ -260,6 +260,10 @@ struct DevArena {
         for (auto& sl : slots) t += sl.second;
         return t;
     }
+    // zero every block (error paths: a job that failed half way has left secrets in blocks it never reached the wipes of)
+    void wipe(dev_stream_t st) {
+        for (auto& s : slots) dev_zero(s.first, s.second, st);
+    }
     void release() {  // only when no job of the handle is in flight
         for (auto& s : slots) dev_free_now(s.first);
         slots.clear();

@@ -15,7 +15,8 @@
  * Threading: a handle may be used from one thread at a time; distinct handles are
  * independent (two threads may prove / verify concurrently on two bpr1cs_gens handles,
  * sharing a bpr1cs_circuit); options belong to a handle (bpr1cs_gens_create_opts,
- * bpr1cs_gens_set_option) - the library has no process-wide settings.  bpr1cs_last_prove_stats
+ * bpr1cs_gens_set_option) - the library has no process-wide settings that change what a call does (the environment is read
+ * for diagnostics only, listed under "Environment" below).  bpr1cs_last_prove_stats
  * reports the last prove call that returned on the calling thread.  There is NO CPU fallback: every compute entry point fails with
  * BPR1CS_ERR_NO_DEVICE when no gfx950 device is visible.  Device failures (HIP errors,
  * out of memory) are reported as BPR1CS_ERR_DEVICE / BPR1CS_ERR_OUT_OF_MEMORY; the
@@ -36,6 +37,12 @@
  * partial inner products) are wiped from device memory before their blocks return to the allocator (upstream: clear_on_drop).
  * Memory: the allocator refuses a large block that would leave less than BPR1CS_MEM_RESERVE_MB (environment, default 1024) of
  * device memory free - the HIP runtime aborts the process when IT finds none - and reports BPR1CS_ERR_OUT_OF_MEMORY instead.
+ *
+ * Environment (everything the shipped library reads; none changes a result): BPR1CS_MEM_RESERVE_MB (above, read once),
+ * BPR1CS_DEBUG_MEM (prints the free device memory after every large allocation), BPR1CS_DEBUG_SYNC (synchronises after every
+ * launch so that a faulting kernel is named), BPR1CS_WITNESS_MACRO=0 (bpr1cs_circuit_create ignores the joint-evaluation
+ * annotations of Poseidon permutations: the witness program then runs S-box by S-box - slower, same wires).  Failure
+ * injection and table-geometry overrides of the test suite exist in the CPU simulator build of the tests only.
  */
 #ifndef BPR1CS_H
 #define BPR1CS_H
@@ -188,7 +195,10 @@ size_t bpr1cs_proof_len(const bpr1cs_circuit* c);
  *   commitments_out    batch * m * 32 (may be NULL)
  * Any batch size: the call cuts the batch into device jobs of BPR1CS_OPT_JOB_PROOFS proofs (default: what fits next to the
  * tables) and keeps BPR1CS_OPT_JOBS_IN_FLIGHT of them in flight, so ONE call with a large batch runs the device at the rate
- * bench.py reports; if the device runs out of memory the job size is halved and the call goes on. */
+ * bench.py reports; if the device runs out of memory the jobs in flight are drained, the handle's scratch is handed back and
+ * the job is tried again - then with half the job size for the rest of THIS call (the automatic choice is made afresh by the
+ * next call).  Not while a job opened with bpr1cs_prove_batch_begin is in flight on the same handle
+ * (BPR1CS_ERR_INVALID_ARGUMENT): the call needs both job slots of the handle and may release its arenas. */
 int bpr1cs_prove_batch(const bpr1cs_gens* g, const bpr1cs_circuit* c, const uint8_t* label, size_t label_len,
                        const uint8_t* values, const uint8_t* v_blindings, const uint8_t* rng_seeds,
                        const uint8_t* wires, size_t batch, uint8_t* proofs_out, uint8_t* commitments_out);

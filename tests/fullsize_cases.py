@@ -28,6 +28,7 @@ def poseidon_2to1_cube(bp, glib, B):
 
 # name -> builder(bp, glib).  The batches are exactly the ones tests/test_gpu_benchconfig.py and tests/test_gpu_fullsize.py prove.
 CASES = {
+    "c1_bound_check64_x4096": lambda bp, glib: wl.bound_check64(4096),               # BASELINE config 1 (src/gadget_bound_check.rs:18-87), the single-proof latency case
     "c4_vsmt4_d32_x2024": lambda bp, glib: vsmt4(bp, glib, 32, 2024, 64, 0),       # C4: two jobs in flight, 1024 + a ragged 1000
     "vsmt4_l8_x70": lambda bp, glib: vsmt4(bp, glib, 8, 70, 70, 7),
     "c3_vsmt2_d32_x1024": lambda bp, glib: vsmt2(bp, glib, 32, 1024, b"l2", 0xffffffff, 10**6),

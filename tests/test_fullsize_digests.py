@@ -36,7 +36,7 @@ def test_fixture_covers_every_bench_size_case():
     assert (FX["vsmt2_d253_x66"]["n"], FX["vsmt4_d128_x70"]["n"]) == (568 * 253, 583 * 128)
 
 
-@pytest.mark.parametrize("name,samples", [("vsmt4_l8_x70", [0, 69]), ("c5_mimc_set_x8192", [0, 4099, 8191]), ("c2_poseidon2_cube_x4096", [0, 1777]),
+@pytest.mark.parametrize("name,samples", [("c1_bound_check64_x4096", [0, 1, 2047, 4095]), ("vsmt4_l8_x70", [0, 69]), ("c5_mimc_set_x8192", [0, 4099, 8191]), ("c2_poseidon2_cube_x4096", [0, 1777]),
                                           ("c4_vsmt4_d32_x2024", [1500])])
 def test_inputs_and_sampled_proofs_reproduce(host, corc, name, samples):
     import fullsize_cases as fc
@@ -70,3 +70,19 @@ def test_pyref_agrees_on_a_sample_of_the_fixture():
     blind = [int.from_bytes(bl[32 * i:32 * i + 32], "little") for i in range(2)]
     pf, _ = sc.prove(common.PC, common.oracle_gens(512), blind, seed)
     assert fc.proof_digest(pf) == FX["c2_poseidon2_cube_x4096"]["proofs"][3]
+
+
+def test_pyref_agrees_on_the_single_proof_latency_case():
+    """proofs 0 and 9 of the C1 batch (64-bit bound check, BASELINE config 1: the case bench.py's `latency` block proves one at a
+    time) from the pure-Python oracle"""
+    import fullsize_cases as fc
+    import common
+    from pyref import scenarios as S
+    case = fc.wl.bound_check64(10)
+    for j in (0, 9):
+        v, bl, seed = fc.slice_proof(case, j)
+        val = int.from_bytes(v[:32], "little")
+        sc = S.bound_check(val, fc.wl.BOUND_MIN, fc.wl.BOUND_MAX, 64)
+        blind = [int.from_bytes(bl[32 * i:32 * i + 32], "little") for i in range(3)]
+        pf, _ = sc.prove(common.PC, common.oracle_gens(128), blind, seed)
+        assert fc.proof_digest(pf) == FX["c1_bound_check64_x4096"]["proofs"][j]

@@ -257,3 +257,53 @@ def test_out_of_memory_fallback_of_prove_batch(sim_lib):
         os.environ.pop("BPR1CS_TEST_FAIL_JOBS", None)
     P, _ = bp.prove_batch(gens, circ, ob["label"], *args, wires=wires)   # the handle is as usable as before
     assert P == want
+
+
+def test_out_of_memory_fallback_does_not_pin_the_job_size(sim_lib):
+    """the halved job size of an out-of-memory fallback lasts for the call that met it; the automatic choice is made
+    afresh by the next call (and after bpr1cs_gens_set_option / bpr1cs_gens_release_scratch)"""
+    import os
+    bp = common.bp
+    ob = common.oracle_batch(lambda j: S.bound_check(37 + j, 10, 100, 7), 16, 2)
+    circ = common.circuit_from_oracle(ob, sim_lib)
+    B, m = 300, circ.m
+    args = (ob["values"][:m * 32] * B, ob["blindings"][:m * 32] * B, ob["seeds"][:32] * B, B)
+    wires = ob["wires"][:96 * circ.n] * B
+    gens = bp.Gens(16, lib=sim_lib)            # automatic job size
+    want, _ = bp.prove_batch(gens, circ, ob["label"], *args, wires=wires)
+    st0 = bp.last_prove_stats(sim_lib)
+    assert (st0["jobs"], st0["job_proofs"]) == (1, 300)
+    try:
+        os.environ["BPR1CS_TEST_FAIL_JOBS"] = "2"
+        P, _ = bp.prove_batch(gens, circ, ob["label"], *args, wires=wires)
+        st = bp.last_prove_stats(sim_lib)
+        assert P == want and (st["jobs"], st["job_proofs"]) == (2, 150), st     # half of the 300-proof job that failed twice
+    finally:
+        os.environ.pop("BPR1CS_TEST_FAIL_JOBS", None)
+    P, _ = bp.prove_batch(gens, circ, ob["label"], *args, wires=wires)
+    st = bp.last_prove_stats(sim_lib)
+    assert P == want and (st["jobs"], st["job_proofs"]) == (1, 300), st          # not pinned at 150
+    gens.set_option("job_proofs", 100)
+    bp.prove_batch(gens, circ, ob["label"], *args, wires=wires)
+    assert bp.last_prove_stats(sim_lib)["jobs"] == 3
+    gens.set_option("job_proofs", -1)          # back to automatic: chosen again, not a stale value
+    bp.prove_batch(gens, circ, ob["label"], *args, wires=wires)
+    assert bp.last_prove_stats(sim_lib)["jobs"] == 1
+
+
+def test_prove_batch_refused_while_an_async_job_is_open(sim_lib):
+    """bpr1cs_prove_batch needs both job slots of the handle and may release its arenas on out of memory - with a job
+    from bpr1cs_prove_batch_begin still in flight on the handle it returns INVALID_ARGUMENT and leaves that job intact"""
+    import pytest
+    bp = common.bp
+    ob = common.oracle_batch(lambda j: S.bound_check(37 + j, 10, 100, 7), 16, 2)
+    circ = common.circuit_from_oracle(ob, sim_lib)
+    gens = bp.Gens(16, lib=sim_lib)
+    job = bp.ProveJob(gens, circ, ob["label"], ob["values"], ob["blindings"], ob["seeds"], 2, wires=ob["wires"])
+    with pytest.raises(bp.R1CSError) as e:
+        bp.prove_batch(gens, circ, ob["label"], ob["values"], ob["blindings"], ob["seeds"], 2, wires=ob["wires"])
+    assert e.value.code == -17
+    P, _ = job.finish()
+    assert P == ob["proofs"]
+    P2, _ = bp.prove_batch(gens, circ, ob["label"], ob["values"], ob["blindings"], ob["seeds"], 2, wires=ob["wires"])
+    assert P2 == ob["proofs"]

@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--batches", default="1,8,64")
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--opt", action="append", default=[])
+    ap.add_argument("--no-device-program", action="store_true")
     args = ap.parse_args()
     lib = bp.load_library()
     bp.load_gadgets_library()
@@ -48,7 +49,7 @@ def main():
             out["%s_b%d" % (case, B)] = rows
         # the device-program path at the same batch sizes (no host synthesis), for comparison
         circ = bp.CompiledGadget(w["gadget"], w["ip"], w["sp"])
-        for B in [int(x) for x in args.batches.split(",")]:
+        for B in ([] if args.no_device_program else [int(x) for x in args.batches.split(",")]):
             for rep in range(2):
                 v, b, s = w["values"][:B * m * 32], w["blindings"][:B * m * 32], w["seeds"][:B * 32]
                 t0 = time.perf_counter()
