@@ -82,7 +82,7 @@ static IpaEnd enqueue_ipa(const IpaIO& io, dev_stream_t st, MsmStats* stats) {
     // closed-form factors of round k: the per-proof products (and, for blocks of >= 256 positions, their table by i >> 8), then the scalars
     auto geo_scalars = [&](uint32_t k, const sc* va, const sc* vb) {
         const uint32_t lgNk = lgN - k;
-        launch((uint64_t)2 * B, K_ipa_fac{fac.p, k ? io.uk + (size_t)(k - 1) * 2 * B : nullptr, io.geo.upad, B, k, facT}, st);
+        launch((uint64_t)2 * (k ? 1u << (k - 1) : 1u) * B, K_ipa_fac{fac.p, k ? io.uk + (size_t)(k - 1) * 2 * B : nullptr, io.geo.upad, B, k, facT}, st);
         const sc* hfp = nullptr;
         if (lgNk >= 8 && hfJ) {
             launch((uint64_t)2 * hfJ * B, K_ipa_hf{fac.p, io.geo.phi + (size_t)io.geo.H * B, hf.p, B, hfJ, lgNk - 8, facT}, st);

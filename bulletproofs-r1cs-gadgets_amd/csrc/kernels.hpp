@@ -1036,32 +1036,46 @@ struct IpaGeo {
 // fac: [6][T][B] - 0 / 1: the G / H products in Montgomery form (the chain the next round extends); 2, 3: the G products and the
 // G products times the padding factor as CANONICAL integers; 4, 5: the same for H.  A Montgomery product of a Montgomery-form
 // scalar with a canonical one is the canonical product, so the product scalars come out table-ready without a conversion.
-struct K_ipa_fac {  // gid = side*B + b : the 2^k products of round k from the 2^(k-1) of the round before and its challenge
+struct K_ipa_fac {  // gid = (side*half + s)*B + b, half = max(1, 2^(k-1)): the 2^k products of round k from the 2^(k-1) of the round before and its challenge
     sc* fac;
     const sc* uk;     // [2][B] u, u^-1 of round k-1 (unused for k = 0)
     const sc* upad;   // [B]
     uint32_t B, k, T;
+    // One thread per product of the round before (a job of ONE proof takes all lg N rounds from the tables: 2^14 products per side
+    // in the last one - as a serial loop of one thread per proof that was 71 of the 79 ms of a depth-32 proof's IPA).  The
+    // Montgomery chain (arrays 0 / 1) is kept in the order in which it GROWS - entry s of round k-1 becomes entries s (lower
+    // half of its block: u^-1 for G) and s + half (upper half: u), so no thread writes what another one reads - i.e. indexed by
+    // the bit-reversed block number; the canonical arrays the other kernels read (2..5) are written at the block number itself.
+    HD static uint32_t brev(uint32_t x, uint32_t bits) {
+        uint32_t r = 0;
+        for (uint32_t i = 0; i < bits; i++) r |= ((x >> i) & 1u) << (bits - 1u - i);
+        return r;
+    }
     HD void operator()(uint32_t g) const {
-        uint32_t side = g / B, b = g % B;
+        const uint32_t half = k ? 1u << (k - 1) : 1u;
+        const uint32_t b = g % B, ss = g / B, side = ss / half, s = ss % half;
         sc* f = fac + (size_t)side * T * B + b;
-        if (k == 0) f[0] = sc_one_mont();
-        else {
-            sc u = uk[b], ui = uk[(size_t)B + b];
-            sc fhi = side ? ui : u, flo = side ? u : ui;   // G: the upper half of a block takes u, the lower u^-1; H the other way round
-            for (uint32_t t = 1u << (k - 1); t-- > 0;) {
-                sc x = f[(size_t)t * B];
-                f[(size_t)(2 * t + 1) * B] = sc_mul(x, fhi);
-                f[(size_t)(2 * t) * B] = sc_mul(x, flo);
-            }
-        }
         sc* c0 = fac + (size_t)(2 + 2 * side) * T * B + b;
         sc* c1 = c0 + (size_t)T * B;
-        sc up = upad[b];
-        for (uint32_t t = 0; t < (1u << k); t++) {
-            sc x = f[(size_t)t * B];
-            c0[(size_t)t * B] = sc_from_mont(x);
-            c1[(size_t)t * B] = sc_from_mont(sc_mul(x, up));
+        const sc up = upad[b];
+        if (k == 0) {
+            const sc one = sc_one_mont();
+            f[0] = one;
+            c0[0] = sc_from_mont(one);
+            c1[0] = sc_from_mont(sc_mul(one, up));
+            return;
         }
+        const sc u = uk[b], ui = uk[(size_t)B + b];
+        const sc fhi = side ? ui : u, flo = side ? u : ui;   // G: the upper half of a block takes u, the lower u^-1; H the other way round
+        const sc x = f[(size_t)s * B];
+        const sc lo = sc_mul(x, flo), hi = sc_mul(x, fhi);
+        f[(size_t)s * B] = lo;
+        f[(size_t)(s + half) * B] = hi;
+        const uint32_t t_lo = brev(s, k), t_hi = brev(s + half, k);
+        c0[(size_t)t_lo * B] = sc_from_mont(lo);
+        c1[(size_t)t_lo * B] = sc_from_mont(sc_mul(lo, up));
+        c0[(size_t)t_hi * B] = sc_from_mont(hi);
+        c1[(size_t)t_hi * B] = sc_from_mont(sc_mul(hi, up));
     }
 };
 // blocks of >= 256 positions: the H product and the upper power-table entry of y^-i depend on i >> 8 only - one combined table

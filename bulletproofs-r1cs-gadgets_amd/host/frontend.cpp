@@ -6,6 +6,9 @@
 #include <functional>
 #include <random>
 #include <memory>
+#include <atomic>
+#include <mutex>
+#include <thread>
 #include "gadgets.hpp"
 #include "../../include/bpr1cs_gadgets.h"
 
@@ -460,6 +463,7 @@ int bpr1cs_gadget_prove_on(const bpr1cs_gens* gens, const char* gadget, const ui
         GadgetSpec g = make_spec(gadget, iparams, n_iparams, sparams, n_sparams, poseidon_blob, blob_len);
         BulletproofGens bp_gens(const_cast<bpr1cs_gens*>(gens), BulletproofGens::Borrowed{});
         PedersenGens pc_gens(bp_gens);
+        std::mutex sec_mu;
         auto synth = [&](Prover& prover, size_t b, std::vector<CompressedRistretto>* comms) {
             std::vector<Scalar> vals;
             for (size_t i = 0; i < m; i++) vals.push_back(Scalar::from_bytes_mod_order(values + 32 * (b * m + i)));
@@ -477,6 +481,7 @@ int bpr1cs_gadget_prove_on(const bpr1cs_gens* gens, const char* gadget, const ui
                       [&](size_t k) { return std::optional<uint64_t>(low64(vals.at(k))); }};
             double t0 = now_s();
             run_gadget(g, h);
+            std::lock_guard<std::mutex> lk(sec_mu);
             sec[0] += t_commit;
             sec[1] += now_s() - t0 - t_commit;
         };
@@ -496,10 +501,16 @@ int bpr1cs_gadget_prove_on(const bpr1cs_gens* gens, const char* gadget, const ui
             if (commitments_out)
                 for (size_t i = 0; i < comms.size(); i++) memcpy(commitments_out + 32 * i, comms[i].data(), 32);
         } else {
+            // The witnesses are independent: their host syntheses run on a few threads (one Prover each; nothing of it touches the
+            // device - the commitments are deferred to the one prove call).  Witness 0 first, alone: it also yields the circuit.
             std::vector<uint8_t> vals, bls, wires;
             bpr1cs_circuit* c = nullptr;
             size_t n0 = 0, q0 = 0;
-            for (size_t b = 0; b < batch; b++) {
+            std::vector<std::vector<uint8_t>> pv(batch), pb(batch), pw(batch);
+            const double t_synth0 = now_s();
+            std::mutex mu;
+            int first_err = 0;
+            auto synth_one = [&](size_t b) {
                 Transcript t((const char*)label, label_len);
                 Prover prover(pc_gens, t);
                 prover.defer_commitments = true;
@@ -517,10 +528,43 @@ int bpr1cs_gadget_prove_on(const bpr1cs_gens* gens, const char* gadget, const ui
                     if (rc) throw R1CSError::Backend(rc);
                     sec[2] += now_s() - t0;
                 } else if (prover.a_L.size() != n0 || prover.constraints.size() != q0) {
-                    bpr1cs_circuit_destroy(c);
-                    return BPR1CS_ERR_INVALID_ARGUMENT;   // a gadget whose shape depends on the witness cannot be batched
+                    throw R1CSError::Backend(BPR1CS_ERR_INVALID_ARGUMENT);   // a gadget whose shape depends on the witness cannot be batched
                 }
-                prover.export_witness(vals, bls, wires);
+                prover.export_witness(pv[b], pb[b], pw[b]);
+            };
+            synth_one(0);
+            {
+                const size_t hw = std::max<size_t>(1, std::thread::hardware_concurrency());
+                const size_t nthreads = std::min<size_t>({batch - 1, hw, (size_t)16});
+                std::atomic<size_t> next{1};
+                auto worker = [&]() {
+                    for (;;) {
+                        const size_t b = next.fetch_add(1);
+                        if (b >= batch) return;
+                        try {
+                            synth_one(b);
+                        } catch (const R1CSError& e) {
+                            std::lock_guard<std::mutex> lk(mu);
+                            if (!first_err) first_err = e.code ? e.code : BPR1CS_ERR_INVALID_ARGUMENT;
+                        } catch (...) {
+                            std::lock_guard<std::mutex> lk(mu);
+                            if (!first_err) first_err = BPR1CS_ERR_INVALID_ARGUMENT;
+                        }
+                    }
+                };
+                std::vector<std::thread> pool;
+                for (size_t k = 0; k + 1 < nthreads; k++) pool.emplace_back(worker);
+                worker();
+                for (auto& th : pool) th.join();
+            }
+            if (first_err) { bpr1cs_circuit_destroy(c); return first_err; }
+            // the stage times of a threaded synthesis: wall time of the stage (commit calls: none, they are deferred)
+            sec[0] = 0;
+            sec[1] = now_s() - t_synth0 - sec[2];
+            for (size_t b = 0; b < batch; b++) {
+                vals.insert(vals.end(), pv[b].begin(), pv[b].end());
+                bls.insert(bls.end(), pb[b].begin(), pb[b].end());
+                wires.insert(wires.end(), pw[b].begin(), pw[b].end());
             }
             vals.push_back(0); bls.push_back(0); wires.push_back(0);
             const size_t plen = bpr1cs_proof_len(c);

@@ -170,6 +170,30 @@ def check_prove_single(glib, name):
     assert comms[:len(ob["comms"][0])] == ob["comms"][0]
 
 
+def check_prove_on(lib, glib, name, batch, gens_cache={}):
+    """bpr1cs_gadget_prove_on - the reference's call shape (Prover::new -> commit x m -> gadget on the host -> prove) on generators made
+    ONCE: one proof per call (batch 1: literally tools/rust_shim/prover.rs - per-commit device calls, CSR export, circuit create /
+    cache hit, bpr1cs_prove_batch_transcripts with host wires), then `batch` witnesses in one call (host syntheses on threads, ONE
+    device call); twice each, so that the second call runs on the cached circuit.  Bytes = the oracle's."""
+    gname, ip, sp, _, cap = case(name, 0)
+    ob = common.oracle_batch(lambda j: case(name, j)[3], cap, batch, key=name)
+    m = ob["m"]
+    key = (id(lib), cap)
+    if key not in gens_cache:
+        gens_cache[key] = bp.Gens(cap, lib=lib, window_bits=8)
+    gens = gens_cache[key]
+    for rep in range(2):
+        for j in range(min(batch, 2)):
+            P, C, sec = bp.gadget_prove_on(gens, gname, ip, sp, ob["label"], ob["values"][j * m * 32:(j + 1) * m * 32],
+                                           ob["blindings"][j * m * 32:(j + 1) * m * 32], m, 1, ob["seeds"][32 * j:32 * j + 32], glib=glib)
+            assert P == [ob["proofs"][j]], "%s: single proof %d differs" % (name, j)
+            assert C[0][:len(ob["comms"][j])] == ob["comms"][j]
+            assert sec["total"] > 0 and sec["prove"] > 0
+        P, C, sec = bp.gadget_prove_on(gens, gname, ip, sp, ob["label"], ob["values"], ob["blindings"], m, batch, ob["seeds"], glib=glib)
+        assert P == ob["proofs"], "%s: batch of %d differs" % (name, batch)
+        assert all(C[j][:len(ob["comms"][j])] == ob["comms"][j] for j in range(batch))
+
+
 def check_native_hashes(glib):
     for pr in (140, 2):
         params = S.poseidon_params(pr)

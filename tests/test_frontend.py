@@ -34,6 +34,12 @@ def test_prover_single(sim_lib, sim_glib):
     fc.check_prove_single(sim_glib, "set_membership")
 
 
+@pytest.mark.parametrize("case,batch", [("bound_check", 5), ("set_membership", 3), ("poseidon_hash_2_inverse_pr1", 3)])
+def test_reference_call_shape_on_shared_generators(sim_lib, sim_glib, case, batch):
+    """one proof per prove() on generators created once (bpr1cs_gadget_prove_on), and several witnesses per call"""
+    fc.check_prove_on(sim_lib, sim_glib, case, batch)
+
+
 @pytest.mark.parametrize("case", ["bound_check", "set_membership", "not_equals", "set_non_membership"])
 def test_prove_verify_roundtrip(sim_lib, sim_glib, case):
     fc.check_prove_verify_roundtrip(sim_lib, sim_glib, case)

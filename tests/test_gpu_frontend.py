@@ -110,3 +110,11 @@ def test_zero_sbox_input_inside_a_full_wavefront_batch(hip_lib, hip_glib):
     # (no proof of this batch verifies: is_nonzero_gadget, src/gadget_zero_nonzero.rs:46-66, demands x * x^-1 = 1, which an S-box
     # input of 0 cannot satisfy, and the other 95 claim proof 40's output - byte parity is the point here)
     assert bp.verify_batch(gens, circ, b"Poseidon_hash_2", [P[special], P[0]], [C[special], C[0]], 2) == [False, False]
+
+
+@pytest.mark.parametrize("case,batch", [("bound_check_64", 9), ("poseidon_hash_2_inverse", 3), ("vsmt_4_l4", 3)])
+def test_reference_call_shape_on_shared_generators_on_device(hip_lib, hip_glib, case, batch):
+    """ONE proof per prove() (bpr1cs_gadget_prove_on, batch 1 = what tools/rust_shim/prover.rs does: per-commit device calls, circuit
+    create / cache hit, bpr1cs_prove_batch_transcripts with host wires; every IPA round from the tables for such small jobs), then
+    `batch` witnesses synthesised on host threads and proved by one device call: the oracle's bytes"""
+    fc.check_prove_on(hip_lib, hip_glib, case, batch)

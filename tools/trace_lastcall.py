@@ -17,10 +17,12 @@ def short(n):
     if "k_functor<" in n: return n.split("k_functor<")[1].rsplit(">", 1)[0]
     return n[:40]
 rows = [(short(n), s, e, q) for n, s, e, q in con.execute("select name, start, end, queue_id from %s order by start" % kt)]
-# the last window: walk back from the end until a gap > gap_ms with nothing running
+# the window of the last prove call: it ends with the last K_assemble (proof bytes); walk back from there to the first launch
+# that follows an idle gap longer than gap_ms on all queues
+last = max(i for i, r in enumerate(rows) if "K_assemble" in r[0])
+rows = rows[:last + 1]
 cut = 0
 busy_until = 0
-ends = []
 for i, r in enumerate(rows):
     if i and r[1] - busy_until > gap_ms * 1e6: cut = i
     busy_until = max(busy_until, r[2])
