@@ -76,18 +76,35 @@ CONFIGS = {
 }
 
 
-def pmc_profile(kind, table_format):
+def loaded_kernel_hash(bp):
+    """identity of the k_msm_fixed2 build in the library this run has loaded (tools/kernel_isa_stats.py: SHA-256 of its disassembly)"""
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import kernel_isa_stats
+        return kernel_isa_stats.kernel_hash(bp.LIB_PATH, "k_msm_fixed2")
+    except Exception:
+        return None
+
+
+def pmc_profile(kind, table_format, kernel_hash=None):
     """Figures of the dominant kernel from the committed rocprofv3 PMC passes of THIS kernel build (separate --pmc runs of
     `bench.py --steps 3`, profiles/r0*_pmc_*.txt), newest round first.
     kind "traffic": FETCH_SIZE + WRITE_SIZE per launch -> (bytes, proofs per launch of the profiled run, source).  Counter
     values are taken as reported (KB * 1024); MI355X_MICROARCH.md: on gfx950 FETCH_SIZE under-reports wide coalesced streams
     2x and is uncalibrated for the 128-byte gathers this kernel issues, so the figure is a lower bound.
-    kind "clock": GRBM_GUI_ACTIVE / 8 XCDs / duration -> (GHz, source)."""
+    kind "clock": GRBM_GUI_ACTIVE / 8 XCDs / duration -> (GHz, source).
+    A profile is only quoted for the kernel build it was taken from: its header carries kernel_isa_sha256= (stamped by
+    tools/install_profiles.py from the profiled library); a profile without the stamp, or with another one than `kernel_hash`
+    (the loaded library's), yields None with the reason as the source."""
     import glob
     import re
     name = "pmc_hbm_traffic" if kind == "traffic" else "pmc_clock"
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r0*_%s.txt" % name)), reverse=True):
         text = open(path).read()
+        stamp = re.search(r"kernel_isa_sha256=([0-9a-f]+)", text)
+        if not stamp or not kernel_hash or stamp.group(1) != kernel_hash:
+            why = "%s is of another build of k_msm_fixed2 (profile %s, loaded %s): not quoted" % (os.path.relpath(path, ROOT), stamp.group(1) if stamp else "unstamped", kernel_hash)
+            return (None, None, why) if kind == "traffic" else (None, why)
         for line in text.split("\n"):
             if not line.startswith("k_msm_fixed2"):
                 continue
@@ -468,7 +485,10 @@ def main():
 
     B = args.batch if args.batch > 0 else cfg["batch"]
     steps = max(1, args.steps)
-    Bw = B * min(2, steps)                          # distinct synthetic inputs: two steps' worth (own leaves, blindings, seeds), repeated over the steps
+    # distinct synthetic inputs (own leaves, blindings, seeds) for EVERY timed step, up to 32 steps of the depth-32 / small circuits;
+    # longer runs and the as-shipped depths (50 KB of path values per proof) repeat two steps' worth.  `config.distinct_inputs_steps` says which.
+    distinct_steps = steps if (steps <= 32 and args.config not in ("vsmt4_d128", "vsmt2_d253")) else min(2, steps)
+    Bw = B * distinct_steps
     t0 = time.time()
     w = cfg["build"](bp, Bw, rank * Bw, args)
     t_witness = time.time() - t0
@@ -547,8 +567,9 @@ def main():
         achieved = (msm_alg_bytes / 1e9) / (msm_ms / 1e3) if msm_ms > 0 else None
         tinfo = gens.table_info()
         default_knobs = args.config == "c4" and args.depth == 32 and not options
-        traffic, traffic_ppl, traffic_src = pmc_profile("traffic", tinfo["format"]) if default_knobs else (None, None, None)
-        clock_ghz, clock_src = pmc_profile("clock", tinfo["format"]) if default_knobs else (None, None)
+        khash = loaded_kernel_hash(bp)
+        traffic, traffic_ppl, traffic_src = pmc_profile("traffic", tinfo["format"], khash) if default_knobs else (None, None, None)
+        clock_ghz, clock_src = pmc_profile("clock", tinfo["format"], khash) if default_knobs else (None, None)
         # integer ceilings, measured NOW on this device by the library's probes (bpr1cs_device_rates, ~80 ms each)
         mad_rate, madd_chain_rate = bp.device_rates(0.08, lib)
         adds = st["msm_adds"]
@@ -559,7 +580,7 @@ def main():
             "metric": metric, "value": value, "unit": "proofs/s",
             "n_gpus": world, "steps": steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
-            "config": {"workload": workload, "name": args.config,
+            "config": {"workload": workload, "name": args.config, "distinct_inputs_steps": distinct_steps,
                        "batch_per_gpu": B, "global_batch": B * world, "n_multipliers": n, "padded_n": N, "constraints": circ.q,
                        "commitments": m, "proof_bytes": circ.proof_len, "sharding": "independent proofs per rank, no collective",
                        "entry_point": "ONE bpr1cs_prove_batch call over steps x batch proofs per rank; handle created with %s" % ("no options (library defaults)" if not options else "options %r" % options),
@@ -572,8 +593,8 @@ def main():
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
                          "traffic": (traffic * st["job_proofs"] / traffic_ppl) if traffic else None,
-                         "traffic_source": traffic_src,
-                         "traffic_note": "PMC FETCH_SIZE + WRITE_SIZE per launch of the same kernel build and configuration, from the named profile (separate "
+                         "traffic_source": traffic_src, "kernel_isa_sha256": khash,
+                         "traffic_note": "PMC FETCH_SIZE + WRITE_SIZE per launch from the named profile - quoted only when the profile is stamped with the ISA hash of the k_msm_fixed2 build this run has loaded, null otherwise (separate "
                                          "rocprofv3 --pmc passes; scaled by proofs per launch if the profiled run used another job size); as reported by the "
                                          "counters: on gfx950 FETCH_SIZE under-reports wide reads 2x and is uncalibrated for 128-byte gathers - a lower bound",
                          "avg_launch_ms": (msm_ms / msm_launches) if msm_launches else None, "launches_per_step": msm_launches / steps,

@@ -3,6 +3,7 @@ import sys, os, json
 that says which command produced them (bench.py reads table_format= / proofs_per_launch= from the PMC header)."""
 tag = sys.argv[1]; src = "gpurun_out/" + tag; dst = "profiles/" + tag + "_"
 commit = os.popen("git rev-parse --short HEAD").read().strip()
+khash = open(os.path.join(src, "kernel_hash.txt")).read().strip() if os.path.exists(os.path.join(src, "kernel_hash.txt")) else "unknown"
 cfg = json.loads(open(os.path.join(src, "bench_default.json")).read().strip())["config"]
 what = "default c4, library defaults: ONE bpr1cs_prove_batch call per timed region, cut by the library into device jobs of %d proofs, %d jobs in flight, W=%d tables (%d windows; the circuit's merged S-box tables one bit narrower), unfold %d, IPA tail on the job's own stream, shared arenas" % (
     cfg["proofs_per_device_job"], cfg["jobs_in_flight"], cfg["table_window_bits"], cfg["table_windows"], cfg["ipa_unfold_rounds"])
@@ -10,8 +11,8 @@ hdr = {
  "kernel_stats.txt": "# rocprofv3 --kernel-trace --stats -- python bench.py --steps 16 --warmup 4 --cpu-proofs 0 --configs none   (%s)\n# %s, code of commit %s: prove jobs of VSMT-4 depth-32 proofs + verify (per proof, batched, sharded through RCCL) + the two rate probes; K_build_table / K_merge_points / k_poseidon_team / K_triple_ones_point / K_range_sum_points are one-time setup\n# k_msm_fixed2: 7 launches per job = A_I(rest)+A_I(merged)+A_O(-1 form)+ones | S | 4 x (L_k + R_k) | folded generators (2 sides)\n" % (what, tag, commit),
  "pipeline_perjob.txt": "# rocprofv3 --kernel-trace -- python bench.py --steps 16 --warmup 4 --cpu-proofs 0 --configs none ; tools/trace_perjob.py (%s, same database as %s_kernel_stats.txt; %s)\n" % (tag, tag, what),
  "pipeline_timeline.txt": "# same database ; tools/trace_timeline.py (%s): front kernels of every job; heavy kernels split by whether a front kernel ran at the same time\n" % tag,
- "pmc_hbm_traffic.txt": "# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate runs, --kernel-trace only) -- python bench.py --steps 8 --warmup 4 --cpu-proofs 0 --configs none\n# %s: table_format=%d, W=%d, %d windows, proofs_per_launch=%d, 7 launches of the kernel per device job, unfold %d\n# values as reported by the counters in KB (x1024 = bytes); gfx950: FETCH_SIZE under-reports wide coalesced reads 2x, uncalibrated for 128-byte gathers\n" % (tag, cfg["table_format"], cfg["table_window_bits"], cfg["table_windows"], cfg["proofs_per_device_job"], cfg["ipa_unfold_rounds"]),
- "pmc_clock.txt": "# rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace -- python bench.py --steps 8 --warmup 4 --cpu-proofs 0 --configs none (%s).  GRBM_GUI_ACTIVE is summed over the 8 XCDs: effective clock = value / 8 / duration\n" % tag,
+ "pmc_hbm_traffic.txt": "# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate runs, --kernel-trace only) -- python bench.py --steps 8 --warmup 4 --cpu-proofs 0 --configs none\n# code of commit " + commit + ", kernel_isa_sha256=" + khash + " (tools/kernel_isa_stats.py k_msm_fixed2 --hash of the profiled library; bench.py quotes this file only for that build)\n# %s: table_format=%d, W=%d, %d windows, proofs_per_launch=%d, 7 launches of the kernel per device job, unfold %d\n# values as reported by the counters in KB (x1024 = bytes); gfx950: FETCH_SIZE under-reports wide coalesced reads 2x, uncalibrated for 128-byte gathers\n" % (tag, cfg["table_format"], cfg["table_window_bits"], cfg["table_windows"], cfg["proofs_per_device_job"], cfg["ipa_unfold_rounds"]),
+ "pmc_clock.txt": "# rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace -- python bench.py --steps 8 --warmup 4 --cpu-proofs 0 --configs none (%s; kernel_isa_sha256=%s).  GRBM_GUI_ACTIVE is summed over the 8 XCDs: effective clock = value / 8 / duration\n" % (tag, khash),
  "ubench.txt": "# tools/ubench on MI355X (%s).  Cycle figures assume 2.4 GHz; the chip clocks to its power budget (see %s_pmc_clock.txt), so short kernels (first block) and sustained ones (last lines, >= 120 ms) differ.  Last two lines: the Karatsuba kill-test\n" % (tag, tag),
 }
 for c in ("c2", "c3", "c5", "vsmt4_d128", "vsmt2_d253"):

@@ -27,7 +27,40 @@ def code_object(lib):
     raise SystemExit("no gfx950 code object in " + lib)
 
 
+def kernel_hash(lib, pattern):
+    """SHA-256 (hex, 16 digits) over the disassembled instruction text of the kernels whose symbol contains `pattern` - the identity of
+    a kernel BUILD: bench.py compares it with the value stamped into profiles/*_pmc_hbm_traffic.txt before it quotes that
+    profile's counters for the library it has loaded.  None if the tools or the kernel are missing."""
+    import hashlib
+    try:
+        with tempfile.NamedTemporaryFile(suffix=".co", delete=False) as f:
+            f.write(code_object(lib))
+            co = f.name
+        try:
+            syms = subprocess.run([LLVM + "/llvm-readelf", "-sW", co], capture_output=True, text=True).stdout
+            names = sorted(set(l.split()[-1] for l in syms.split("\n") if " FUNC " in l and pattern in l))
+            if not names:
+                return None
+            h = hashlib.sha256()
+            for name in names:
+                dis = subprocess.run([LLVM + "/llvm-objdump", "-d", "--disassemble-symbols=" + name, co], capture_output=True, text=True).stdout
+                for l in dis.split("\n"):
+                    if l.startswith("\t"):
+                        h.update(l.split("//")[0].strip().encode() + b"\n")
+            return h.hexdigest()[:16]
+        finally:
+            os.unlink(co)
+    except Exception:
+        return None
+
+
 def main():
+    if "--hash" in sys.argv:
+        args = [a for a in sys.argv[1:] if not a.startswith("--")]
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        lib = args.pop(0) if len(args) == 2 else os.path.join(root, "bulletproofs-r1cs-gadgets_amd", "csrc", "libbpr1cs_hip.so")
+        print(kernel_hash(lib, args[0]))
+        return
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     lib = os.path.join(root, "bulletproofs-r1cs-gadgets_amd", "csrc", "libbpr1cs_hip.so")

@@ -3,11 +3,12 @@
 # (counters in their own passes with --kernel-trace only; raw rocprofv3 databases are removed, the summaries stay under gpurun_out/<tag>/)
 tag=${1:-rXX}; out=gpurun_out/$tag; mkdir -p $out
 export TMPDIR=/tmp
-B="--steps 16 --warmup 4 --cpu-proofs 0 --configs none"
+B="--steps 16 --warmup 4 --cpu-proofs 0 --configs none --latency 0"
+python tools/kernel_isa_stats.py k_msm_fixed2 --hash > $out/kernel_hash.txt
 # the driver's command (all configurations in the one line), then the same under torchrun with one rank, then one job in flight
 timeout 900 python bench.py --steps 20 --warmup 5 2> $out/bench_default.err | grep -a "^{" | tail -1 > $out/bench_default.json; cut -c1-200 $out/bench_default.json
-timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 16 --warmup 4 --cpu-proofs 0 --configs none 2> $out/bench_torchrun.err | grep -a "^{" | tail -1 > $out/bench_torchrun_1rank.json
-timeout 600 python bench.py --opt jobs_in_flight=1 --steps 8 --warmup 4 --cpu-proofs 0 --configs none 2>/dev/null | grep -a "^{" | tail -1 > $out/bench_sync.json
+timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 16 --warmup 4 --cpu-proofs 0 --configs none --latency 0 2> $out/bench_torchrun.err | grep -a "^{" | tail -1 > $out/bench_torchrun_1rank.json
+timeout 600 python bench.py --opt jobs_in_flight=1 --steps 8 --warmup 4 --cpu-proofs 0 --configs none --latency 0 2>/dev/null | grep -a "^{" | tail -1 > $out/bench_sync.json
 for c in c2 c3 c5 vsmt4_d128 vsmt2_d253; do
   s=16; [ $c = vsmt4_d128 ] && s=6; [ $c = vsmt2_d253 ] && s=8
   timeout 900 python bench.py --config $c --steps $s --warmup 4 2>&1 | grep -a "^{" | tail -1 > $out/bench_$c.json
@@ -20,7 +21,7 @@ python tools/rocprof_summary.py stats $out/kt > $out/kernel_stats.txt 2>&1
 python tools/trace_perjob.py $out/kt 30 > $out/pipeline_perjob.txt 2>&1; head -8 $out/pipeline_perjob.txt
 python tools/trace_timeline.py $out/kt > $out/pipeline_timeline.txt 2>/dev/null
 for c in FETCH_SIZE WRITE_SIZE GRBM_GUI_ACTIVE; do
-  timeout 600 rocprofv3 --pmc $c --kernel-trace -d $out/pmc_$c -o out -- python bench.py --steps 8 --warmup 4 --cpu-proofs 0 --configs none > $out/pmc_$c.log 2>&1
+  timeout 600 rocprofv3 --pmc $c --kernel-trace -d $out/pmc_$c -o out -- python bench.py --steps 8 --warmup 4 --cpu-proofs 0 --configs none --latency 0 > $out/pmc_$c.log 2>&1
 done
 python tools/rocprof_summary.py pmc $out/pmc_FETCH_SIZE $out/pmc_WRITE_SIZE > $out/pmc_hbm_traffic.txt 2>&1
 python tools/rocprof_summary.py pmc $out/pmc_GRBM_GUI_ACTIVE > $out/pmc_clock.txt 2>&1
