@@ -534,9 +534,27 @@ def prove_batch_transcripts(gens, circuit, transcripts, values, v_blindings, rng
             [[craw[(i * m + j) * 32:(i * m + j + 1) * 32] for j in range(m)] for i in range(batch)])
 
 
-def prove_batch_raw(gens, circuit, label, values, v_blindings, rng_seeds, batch):
-    """ONE bpr1cs_prove_batch call over any batch (the library cuts it into device jobs) -> (proof bytes, commitment bytes), unsplit"""
+def output_buffers(circuit, batch):
+    """caller-owned output memory for prove_batch_raw(out=...): (proofs, commitments) as writable bytearrays, pages touched -
+    what a C caller hands to bpr1cs_prove_batch (a timed region then holds the library call, not the allocation of its result)"""
+    bufs = bytearray(batch * circuit.proof_len), bytearray(max(1, batch * circuit.m * 32))
+    for b in bufs:   # first touch of every page now, not inside the caller's timed region
+        b[0::4096] = bytes(len(range(0, len(b), 4096)))
+    return bufs
+
+
+def prove_batch_raw(gens, circuit, label, values, v_blindings, rng_seeds, batch, out=None):
+    """ONE bpr1cs_prove_batch call over any batch (the library cuts it into device jobs) -> (proof bytes, commitment bytes), unsplit.
+    out: (proofs, commitments) from output_buffers() - filled in place and returned as they are (no copy)"""
     m, plen = circuit.m, circuit.proof_len
+    if out is not None:
+        pbuf, cbuf = out
+        assert len(pbuf) >= batch * plen and len(cbuf) >= max(1, batch * m * 32)
+        proofs = (ctypes.c_char * len(pbuf)).from_buffer(pbuf)
+        comms = (ctypes.c_char * len(cbuf)).from_buffer(cbuf)
+        _chk(gens.lib.bpr1cs_prove_batch(gens.h, circuit.h, label, len(label), values or b"\0", v_blindings or b"\0", rng_seeds, None, batch, proofs, comms))
+        del proofs, comms
+        return pbuf, cbuf
     proofs = ctypes.create_string_buffer(batch * plen)
     comms = ctypes.create_string_buffer(max(1, batch * m * 32))
     _chk(gens.lib.bpr1cs_prove_batch(gens.h, circuit.h, label, len(label), values or b"\0", v_blindings or b"\0", rng_seeds, None, batch, proofs, comms))

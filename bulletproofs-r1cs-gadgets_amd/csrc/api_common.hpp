@@ -1,5 +1,6 @@
 // Shared host-side state of the C ABI (include/bpr1cs.h): options, error boundary, handle structs.
 #pragma once
+#include <chrono>
 #include <vector>
 #include <map>
 #include <algorithm>
@@ -63,7 +64,7 @@ static bool opt_apply(BpOpts& o, int option, int value, bool creating) {
         case BPR1CS_OPT_JOBS_IN_FLIGHT: o.jobs_in_flight = (value == 1) ? 1 : 2; return true;
         case BPR1CS_OPT_WINDOW_BITS:
             if (!creating) return false;
-            o.window_bits = value <= 0 ? 0 : (value < 4 ? 4 : (value > 12 ? 12 : value));
+            o.window_bits = value <= 0 ? 0 : (value < 4 ? 4 : (value > 15 ? 15 : value));   // (digits travel as sign + 15-bit magnitude: |d| <= 2^14 at W = 15)
             return true;
         default: return false;
     }

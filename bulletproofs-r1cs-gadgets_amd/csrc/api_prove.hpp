@@ -58,6 +58,16 @@ static void host_stage_free(void* p) {
     hs.live.erase(it);
 #endif
 }
+// diagnostic (include/bpr1cs.h, "Environment"): BPR1CS_DEBUG_JOBS prints host-side timestamps of the job pipeline to stderr
+static bool dbg_jobs() {
+    static const bool on = getenv("BPR1CS_DEBUG_JOBS") != nullptr;
+    return on;
+}
+static double dbg_ms() {
+    static const auto t0 = std::chrono::steady_clock::now();
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+}
+#define DBG_JOB(...) do { if (dbg_jobs()) { fprintf(stderr, "bpr1cs[%9.2f ms] ", dbg_ms()); fprintf(stderr, __VA_ARGS__); fputc('\n', stderr); } } while (0)
 // wait for everything a job has enqueued and release what it holds (normal end and error paths)
 static void job_wait(bpr1cs_job* job) {
     if (!job) return;
@@ -181,6 +191,7 @@ static int prove_job_begin(const bpr1cs_gens* g, const bpr1cs_circuit* c, const 
     dev_stream_t sl = job->st2;  // the latency-bound front of the job never touches the heavy stream
 #endif
     pt.mark(sl);
+    DBG_JOB("begin: slot %u, %u proofs", slot, B);
 
     // ---- inputs
     DevBuf<sc> v_raw, vbl_raw, v_m((size_t)m * B), vbl_m((size_t)m * B);
@@ -193,6 +204,7 @@ static int prove_job_begin(const bpr1cs_gens* g, const bpr1cs_circuit* c, const 
     const uint32_t init_stride = n_init == 1 ? 0u : 1u;
     launch((uint64_t)m * B, K_load_inputs{v_raw.p, vbl_raw.p, v_m.p, vbl_m.p}, sl);
 
+    DBG_JOB("begin: inputs uploaded");
     // ---- P1: V commitments, transcript, RNG stream
     DevBuf<uint8_t> Vcomp((size_t)B * m * 32 + 1);
     launch((uint64_t)m * B, K_commit_v{g->tab.p, g->tc, v_raw.p, vbl_raw.p, Vcomp.p, B, m}, sl);
@@ -273,6 +285,7 @@ static int prove_job_begin(const bpr1cs_gens* g, const bpr1cs_circuit* c, const 
         dev_stream_wait(st, job->ev_wit);
 #endif
     }
+    DBG_JOB("begin: front enqueued");
     // ---- P2: A_I1, A_O1, S1.  The sums of A_I1 and A_O1 need the wires only, so they are enqueued BEFORE the heavy stream
     // waits for the TranscriptRng chain (the longer of the two front kernels); their blinding terms and all of S1 follow it.
     DevBuf<uint8_t> AOS((size_t)3 * B * 32);
@@ -459,6 +472,7 @@ static int prove_job_begin(const bpr1cs_gens* g, const bpr1cs_circuit* c, const 
     dev_event_record(job->ev_done, st);
     g->in_flight++;
     job->counted = true;
+    DBG_JOB("begin: back enqueued, job submitted");
     *job_out = job;
     return BPR1CS_OK;
     }
@@ -471,7 +485,9 @@ static int prove_job_begin(const bpr1cs_gens* g, const bpr1cs_circuit* c, const 
 static int prove_job_end(bpr1cs_job* job, uint8_t* proofs_out, uint8_t* commitments_out, bpr1cs_transcript* const* tr_out, bpr1cs_prove_stats* acc) {
     if (!job || !proofs_out) return BPR1CS_ERR_INVALID_ARGUMENT;
     int rc = BPR1CS_OK;
+    DBG_JOB("end: waiting for slot %d", job->slot);
     if (!dev_event_sync(job->ev_done)) rc = BPR1CS_ERR_DEVICE;
+    DBG_JOB("end: job of slot %d done", job->slot);
 #if !defined(BPR1CS_HOSTSIM)
     (void)hipStreamSynchronize(job->st2);
     (void)hipStreamSynchronize(job->st3);

@@ -66,14 +66,24 @@ int bpr1cs_gens_create_opts(uint32_t cap, const int32_t* pairs, size_t n_pairs, 
     if (window_bits == 0) {
         // automatic: the widest window (<= 11) whose tables take at most 70 % of the free device memory - W = 11 (198 GB) for
         // capacity 32768 on a 288 GB device, 8 / 7 for the reference's as-shipped depths (capacity 131072 / 262144); what is left is
-        // for a circuit's merged tables and the prove jobs, whose size follows from it (BPR1CS_OPT_JOB_PROOFS)
+        // for a circuit's merged tables and the prove jobs, whose size follows from it (BPR1CS_OPT_JOB_PROOFS).  Small capacities
+        // go wider still - up to W = 15 (17 additions per term instead of 23) - while the tables stay under 30 % of the free
+        // memory: 36.6 GB at capacity 512, 73 GB at 1024 (measured, 16384-proof jobs: W = 11 / 13 / 14 / 15 = 126 / 130 / 131 / 137.5 k
+        // proofs/s for the 2:1 Poseidon preimage circuit, 72.1 / 75.1 / 76.2 / 79.6 k for MiMC + set membership - the additions
+        // saved outweigh the HBM bytes per addition, which grow with the row length: 32 -> 29 G additions/s).  15 is the limit of
+        // the digit format (sign + 15-bit magnitude).
 #if defined(BPR1CS_HOSTSIM)
         window_bits = 8;   // (the simulator builds its tables on one CPU core)
 #else
         window_bits = 4;
-        const double room = (double)dev_free_memory() * 0.7;
-        for (int w = 11; w >= 4; w--)
-            if ((double)(2 + 2 * (size_t)cap) * (double)tab_cfg((uint32_t)w).base_bytes() <= room) { window_bits = w; break; }
+        const double freeb = (double)dev_free_memory();
+        auto bytes_at = [&](int w) { return (double)(2 + 2 * (size_t)cap) * (double)tab_cfg((uint32_t)w).base_bytes(); };
+        int pick = 0;
+        for (int w = 15; w >= 12 && !pick; w--)
+            if (bytes_at(w) <= 0.3 * freeb) pick = w;
+        for (int w = 11; w >= 4 && !pick; w--)
+            if (bytes_at(w) <= 0.7 * freeb) pick = w;
+        if (pick) window_bits = pick;
 #endif
     }
     g->tc = tab_cfg((uint32_t)window_bits);

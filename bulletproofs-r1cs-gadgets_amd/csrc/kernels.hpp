@@ -800,16 +800,31 @@ struct K_flatten_chunks {  // gid = c*B + b -> part[c][b]
     const sc* phi;
     sc* part;  // [nchunks][B]
     uint32_t B, H;
+    // z^(j+1) = lo[(j+1) & 255] * hi[(j+1) >> 8] (K_pow_tables): the entries of a slot come in ascending row order, so they are
+    // summed per block of 256 rows against the LOW table only - no multiplication at all for the +-1 coefficients, one for the
+    // others - and every block sum is multiplied by its HIGH table entry once (was: one product per entry for z^(j+1) alone;
+    // 9.2 of 104 ms of a 16384-proof job of the 2:1 Poseidon circuit, 10 of 192 for MiMC + set membership).  Any order is
+    // correct; a sorted one just makes the blocks few.
     HD void operator()(uint32_t g) const {
         uint32_t c = g / B, b = g % B;
-        sc acc = sc_zero();
+        const sc* lo = plo + (size_t)2 * 256 * B;
+        const sc* hi = phi + (size_t)2 * H * B;
+        sc acc = sc_zero(), inner = sc_zero();
+        uint32_t cur = 0xffffffffu;
         for (uint32_t t = chunk_lo[c]; t < chunk_lo[c + 1]; t++) {
             const uint32_t rw = ent_row[t];   // the same for every proof of a wavefront: the branches below do not diverge
-            sc zp = pow_lookup(plo, phi, 2, H, B, (rw & 0x3fffffffu) + 1, b);
-            if (rw & 0x80000000u) acc = sc_add(acc, zp);
-            else if (rw & 0x40000000u) acc = sc_sub(acc, zp);
-            else acc = sc_add(acc, sc_mul(zp, ent_coeff[t]));
+            const uint32_t e = (rw & 0x3fffffffu) + 1, blk = e >> 8;
+            if (blk != cur) {
+                if (cur != 0xffffffffu) acc = sc_add(acc, sc_mul(inner, hi[(size_t)cur * B + b]));
+                inner = sc_zero();
+                cur = blk;
+            }
+            const sc zl = lo[(size_t)(e & 255u) * B + b];
+            if (rw & 0x80000000u) inner = sc_add(inner, zl);
+            else if (rw & 0x40000000u) inner = sc_sub(inner, zl);
+            else inner = sc_add(inner, sc_mul(zl, ent_coeff[t]));
         }
+        if (cur != 0xffffffffu) acc = sc_add(acc, sc_mul(inner, hi[(size_t)cur * B + b]));
         part[g] = acc;
     }
 };

@@ -27,8 +27,9 @@ def test_pipeline_factors(sim_lib):
 
 
 def test_pipeline_other_window_widths(sim_lib):
-    """fixed-base tables with 4-, 5-, 10- and 11-bit signed windows (11: 23 windows, the top one keeps its digit) give the same proofs"""
-    for w in (5, 10, 11, 4):
+    """fixed-base tables with 4-, 5-, 10-, 11-, 13- and 15-bit signed windows (11: 23 windows, the top one keeps its digit; 15: the widest
+    the digit format - sign + 15-bit magnitude - carries, what small capacities get by default on the device) give the same proofs"""
+    for w in (5, 10, 11, 4, 13, 15):
         g = common.bp.Gens(16, lib=sim_lib, window_bits=w)
         info = g.table_info()
         assert (info["window_bits"], info["windows"]) == (w, -(-253 // w))
