@@ -24,6 +24,7 @@
 #include <vector>
 #include "../../include/bpr1cs.h"
 #include "../csrc/sc.hpp"
+#include "scalar_host.hpp"
 
 namespace bpr1cs {
 
@@ -39,39 +40,10 @@ struct R1CSError {
     static R1CSError Backend(int code) { return {code, "backend"}; }
 };
 
-// Host-side Montgomery product on 4 x 64-bit limbs (unsigned __int128): the same function as csrc/sc.hpp's sc_mul (a*b*2^-256 mod l,
-// canonical result), which is laid out for the GPU's 32-bit multiplier (9 x 29-bit limbs) and is ~4x slower on an x86-64 core.  The
-// front-end's linear-combination bookkeeping is scalar multiplications and nothing else: ~10^7 of them for ONE depth-32 tree proof
-// (Poseidon_permutation_constraints scales every state combination by the MDS matrix in every round, gadget_poseidon.rs:291-299).
-inline sc sc_mul_host(const sc& a, const sc& b) {
-    typedef unsigned __int128 u128;
-    static const uint64_t L[4] = {0x5812631a5cf5d3edull, 0x14def9dea2f79cd6ull, 0ull, 0x1000000000000000ull};
-    static const uint64_t LINV = [] {   // -l^-1 mod 2^64 (Newton iteration on the low limb)
-        uint64_t x = 1;
-        for (int i = 0; i < 7; i++) x *= 2 - L[0] * x;
-        return (uint64_t)0 - x;
-    }();
-    uint64_t A[4], B[4], t[6] = {0, 0, 0, 0, 0, 0};
-    memcpy(A, a.v, 32);
-    memcpy(B, b.v, 32);
-    for (int i = 0; i < 4; i++) {
-        u128 c = 0;
-        for (int j = 0; j < 4; j++) { c += (u128)A[i] * B[j] + t[j]; t[j] = (uint64_t)c; c >>= 64; }
-        c += t[4]; t[4] = (uint64_t)c; t[5] = (uint64_t)(c >> 64);
-        const uint64_t m = t[0] * LINV;
-        c = ((u128)m * L[0] + t[0]) >> 64;
-        for (int j = 1; j < 4; j++) { c += (u128)m * L[j] + t[j]; t[j - 1] = (uint64_t)c; c >>= 64; }
-        c += t[4]; t[3] = (uint64_t)c; t[4] = t[5] + (uint64_t)(c >> 64);
-    }
-    // t < 2l (a, b < l): one conditional subtraction
-    uint64_t r[4];
-    u128 br = 0;
-    for (int j = 0; j < 4; j++) { u128 d = (u128)t[j] - L[j] - (uint64_t)br; r[j] = (uint64_t)d; br = (d >> 64) & 1; }
-    const bool keep = br != 0 && t[4] == 0;
-    sc out;
-    memcpy(out.v, keep ? t : r, 32);
-    return out;
-}
+// Host-side arithmetic mod l on 64-bit limbs (scalar_host.hpp): the same functions as csrc/sc.hpp's sc_mul / sc_add / sc_sub /
+// sc_invert, which are laid out for the GPU's 32-bit multiplier and are 3-4x slower on an x86-64 core.  The front-end's
+// linear-combination bookkeeping is scalar arithmetic and nothing else: ~3 x 10^5 products and 6016 inversions for ONE depth-32 tree proof.
+inline sc sc_mul_host(const sc& a, const sc& b) { return hostsc::mul(a, b); }
 
 // curve25519_dalek::scalar::Scalar; Montgomery form inside.
 struct Scalar {
@@ -90,12 +62,12 @@ struct Scalar {
         memcpy(out, c.v, 32);
     }
     uint8_t operator[](size_t i) const { return to_bytes()[i]; }  // `l[i]` at gadget_vsmt_4.rs:227
-    Scalar invert() const { Scalar r; r.m = sc_invert(m); return r; }  // 0 -> 0
-    Scalar operator+(const Scalar& o) const { Scalar r; r.m = sc_add(m, o.m); return r; }
-    Scalar operator-(const Scalar& o) const { Scalar r; r.m = sc_sub(m, o.m); return r; }
+    Scalar invert() const { Scalar r; r.m = hostsc::invert(m); return r; }  // 0 -> 0
+    Scalar operator+(const Scalar& o) const { Scalar r; r.m = hostsc::add(m, o.m); return r; }
+    Scalar operator-(const Scalar& o) const { Scalar r; r.m = hostsc::sub(m, o.m); return r; }
     Scalar operator*(const Scalar& o) const { Scalar r; r.m = sc_mul_host(m, o.m); return r; }
-    Scalar operator-() const { Scalar r; r.m = sc_neg(m); return r; }
-    Scalar& operator+=(const Scalar& o) { m = sc_add(m, o.m); return *this; }
+    Scalar operator-() const { Scalar r; r.m = hostsc::sub(sc_zero(), m); return r; }
+    Scalar& operator+=(const Scalar& o) { m = hostsc::add(m, o.m); return *this; }
     bool operator==(const Scalar& o) const { for (int i = 0; i < 8; i++) if (m.v[i] != o.m.v[i]) return false; return true; }
     bool is_zero() const { return sc_is_zero(m); }
 };
