@@ -585,6 +585,7 @@ def load_gadgets_library(path=None):
     g.bpr1cs_gadget_compile.argtypes = [cp, ip, sz, cp, sz, cp, sz, ctypes.POINTER(vp), ip, ip, ip, ctypes.POINTER(ctypes.c_int)]
     g.bpr1cs_gadget_prove_single.argtypes = [cp, ip, sz, cp, sz, cp, sz, u32, cp, sz, cp, cp, sz, cp, cp, sz, ctypes.POINTER(sz), cp]
     g.bpr1cs_gadget_prove_on.argtypes = [vp, cp, ip, sz, cp, sz, cp, sz, cp, sz, cp, cp, sz, sz, cp, cp, sz, ctypes.POINTER(sz), cp, ctypes.POINTER(ctypes.c_double)]
+    g.bpr1cs_gadget_synthesize.argtypes = [cp, ip, sz, cp, sz, cp, sz, cp, sz, cp, sz, ip, ip]
     g.bpr1cs_gadget_verify_single.argtypes = [cp, ip, sz, cp, sz, cp, sz, u32, cp, sz, cp, sz, cp, sz]
     g.bpr1cs_poseidon_hash.argtypes = [ctypes.c_int, ctypes.c_int, u32, cp, sz, cp, cp]
     g.bpr1cs_mimc.argtypes = [cp, cp, cp, sz, cp]
@@ -667,6 +668,19 @@ def gadget_prove_on(gens, name, iparams, sparams, label, values, blindings, m, b
     return ([praw[i * n:(i + 1) * n] for i in range(batch)],
             [[craw[(i * m + j) * 32:(i * m + j + 1) * 32] for j in range(m)] for i in range(batch)],
             dict(zip(("commit", "gadget", "circuit", "prove", "total"), sec)))
+
+
+def gadget_synthesize(name, iparams, sparams, values, m, glib=None):
+    """bpr1cs_gadget_synthesize: host synthesis alone -> (wires a_L | a_R | a_O as bytes, n, q); no device call"""
+    g = glib or load_gadgets_library()
+    blob = poseidon_blob()
+    sp = b"".join(_sc(s) for s in sparams)
+    n, q = ctypes.c_uint32(), ctypes.c_uint32()
+    args = (name.encode(), _u32arr(list(iparams)), len(iparams), sp or b"\0", len(sparams), blob, len(blob), values or b"\0", m)
+    _chk(g.bpr1cs_gadget_synthesize(*args, None, 0, ctypes.byref(n), ctypes.byref(q)))
+    wires = ctypes.create_string_buffer(96 * max(1, n.value))
+    _chk(g.bpr1cs_gadget_synthesize(*args, wires, 96 * n.value, ctypes.byref(n), ctypes.byref(q)))
+    return wires.raw[:96 * n.value], n.value, q.value
 
 
 def verify_single(name, iparams, sparams, gens_capacity, label, proof, commitments, glib=None):

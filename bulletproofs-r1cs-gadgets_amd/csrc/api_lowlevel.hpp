@@ -197,6 +197,12 @@ extern "C" int bpr1cs_msm_fixed(const bpr1cs_gens* g, const uint32_t* bases, siz
         DevBuf<sc> d((size_t)2 * B);
         DevBuf<uint8_t> d_out((size_t)B * 32);
         dev_h2d_async(d.p, h.data(), h.size() * sizeof(sc), st);
+#if !defined(BPR1CS_HOSTSIM)
+        if (B <= 256) {   // a handful of commitments: a wavefront each (k_commit_wave), latency of ~6 additions instead of 2 x windows
+            hipLaunchKernelGGL(k_commit_wave, dim3(B), dim3(64), 0, st, (const uint8_t*)g->tab.p, g->tc, (const sc*)d.p, (const sc*)(d.p + B), d_out.p, B, 1u);
+            HIPCHK(hipGetLastError());
+        } else
+#endif
         launch(B, K_commit_v{g->tab.p, g->tc, d.p, d.p + B, d_out.p, B, 1}, st);
         dev_zero(d.p, d.bytes(), st);   // value and blinding are secrets
         dev_d2h(out, d_out.p, (size_t)B * 32, st);

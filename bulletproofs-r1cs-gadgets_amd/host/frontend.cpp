@@ -588,6 +588,46 @@ int bpr1cs_gadget_prove_on(const bpr1cs_gens* gens, const char* gadget, const ui
     }
 }
 
+// Host synthesis alone: what Prover::new -> commit x m -> gadget leaves in the Prover when prove() is called - the wires - without
+// touching the device (the commitments are not computed).  For callers that batch host-synthesised witnesses themselves
+// (bpr1cs_prove_batch with `wires`), and for the CPU tests of the front-end.
+int bpr1cs_gadget_synthesize(const char* gadget, const uint32_t* iparams, size_t n_iparams, const uint8_t* sparams, size_t n_sparams,
+                             const uint8_t* poseidon_blob, size_t blob_len, const uint8_t* values, size_t m, uint8_t* wires_out, size_t wires_cap,
+                             uint32_t* n_out, uint32_t* q_out) {
+    if (!gadget || (m && !values)) return BPR1CS_ERR_INVALID_ARGUMENT;
+    try {
+        GadgetSpec g = make_spec(gadget, iparams, n_iparams, sparams, n_sparams, poseidon_blob, blob_len);
+        PedersenGens pc_gens{PedersenGens::Detached{}};
+        Transcript t("synth", 5);
+        Prover prover(pc_gens, t);
+        prover.defer_commitments = true;
+        std::vector<Scalar> vals;
+        for (size_t i = 0; i < m; i++) vals.push_back(Scalar::from_bytes_mod_order(values + 32 * i));
+        Harness h{prover,
+                  [&](size_t k) {
+                      if (k >= m) throw R1CSError::MissingAssignment();
+                      return prover.commit(vals[k], Scalar()).second;
+                  },
+                  [&](size_t k) { return std::optional<Scalar>(vals.at(k)); },
+                  [&](size_t k) { return std::optional<uint64_t>(low64(vals.at(k))); }};
+        run_gadget(g, h);
+        const size_t n = prover.a_L.size();
+        if (n_out) *n_out = (uint32_t)n;
+        if (q_out) *q_out = (uint32_t)prover.constraints.size();
+        if (wires_out) {
+            if (wires_cap < 96 * n) return BPR1CS_ERR_INVALID_ARGUMENT;
+            const std::vector<Scalar>* w[3] = {&prover.a_L, &prover.a_R, &prover.a_O};
+            for (int s = 0; s < 3; s++)
+                for (size_t i = 0; i < n; i++) (*w[s])[i].write_bytes(wires_out + 32 * (s * n + i));
+        }
+        return BPR1CS_OK;
+    } catch (const R1CSError& e) {
+        return e.code;
+    } catch (const std::exception&) {
+        return BPR1CS_ERR_INVALID_ARGUMENT;
+    }
+}
+
 // the verifier half of the reference's tests: commit every V, run the gadget with no assignments, verify
 int bpr1cs_gadget_verify_single(const char* gadget, const uint32_t* iparams, size_t n_iparams, const uint8_t* sparams, size_t n_sparams,
                                 const uint8_t* poseidon_blob, size_t blob_len, uint32_t gens_capacity, const uint8_t* label, size_t label_len,

@@ -217,6 +217,21 @@ inline Variable synthesize_sbox(ConstraintSystem& cs, SboxType t, const LinearCo
     return r.first;
 }
 
+// The Inverse branch of synthesize_sbox for a constraint system that does not record witness hints: the same calls on `cs` in the
+// same order (poseidon_sbox, allocate_single x 2, is_nonzero_gadget, the output constraint) from the VALUE of input + round key
+// alone - the combination itself is only ever evaluated (trap T2), so whoever knows the value need not build it.
+inline Variable synthesize_inverse_sbox_from_value(ConstraintSystem& cs, const std::optional<Scalar>& val_l, std::optional<Scalar>* val_r_out = nullptr) {
+    std::optional<Scalar> val_r;
+    if (val_l) val_r = val_l->invert();
+    if (val_r_out) *val_r_out = val_r;
+    cs.poseidon_sbox();
+    auto l = cs.allocate_single(val_l, WitnessHint());
+    auto r = cs.allocate_single(val_r, WitnessHint::inverse_of_left());
+    is_nonzero_gadget(cs, AllocatedScalar{l.first, val_l}, AllocatedScalar{r.first, val_r});
+    constrain_lc_with_scalar(cs, LinearCombination(*r.second), Scalar::one());
+    return r.first;
+}
+
 // Poseidon_permutation (gadget_poseidon.rs:189-280)
 inline std::vector<Scalar> Poseidon_permutation(const std::vector<Scalar>& input, const PoseidonParams& params, SboxType sbox) {
     size_t w = params.width;
@@ -335,10 +350,39 @@ inline std::vector<LinearCombination> Poseidon_permutation_constraints(Constrain
             lc.terms.push_back({Variable::One(), T.cst[r][e]});
             return lc;
         };
-        for (size_t r = 0; r < pr; r++) {
-            const Scalar& rk = params.round_keys[off + width - 1];
-            v.push_back(synthesize_sbox(cs, sbox_type, element(r, width - 1), rk));
-            off += width;
+        if (sbox_type == SboxType::Inverse && !cs.uses_witness_hints()) {
+            // Prover / Verifier: the S-box input of a partial round is needed as a VALUE only (see synthesize_inverse_sbox_from_value),
+            // and the value is the native permutation's state (Poseidon_permutation above: add the keys, invert the last element,
+            // multiply by the matrix - 36 products per round), not an evaluation of a combination of 37 + r terms that first has to
+            // be built: ~5 x 10^5 of the 5.7 x 10^5 products of a depth-32 tree proof's synthesis were spent there.
+            std::vector<Scalar> st, tmp(width);
+            bool have = true;
+            for (size_t i = 0; i < width && have; i++) {
+                std::optional<Scalar> x = cs.evaluate_lc(s0[i]);
+                if (x) st.push_back(*x); else have = false;
+            }
+            for (size_t r = 0; r < pr; r++) {
+                std::optional<Scalar> val_l, val_r;
+                if (have) {
+                    for (size_t i = 0; i < width; i++) st[i] += params.round_keys[off + i];
+                    val_l = st[width - 1];
+                }
+                v.push_back(synthesize_inverse_sbox_from_value(cs, val_l, &val_r));
+                if (have) {
+                    st[width - 1] = *val_r;
+                    for (size_t i = 0; i < width; i++) tmp[i] = Scalar();
+                    for (size_t j = 0; j < width; j++)
+                        for (size_t i = 0; i < width; i++) tmp[i] += st[j] * params.MDS_matrix[i][j];
+                    st = tmp;
+                }
+                off += width;
+            }
+        } else {
+            for (size_t r = 0; r < pr; r++) {
+                const Scalar& rk = params.round_keys[off + width - 1];
+                v.push_back(synthesize_sbox(cs, sbox_type, element(r, width - 1), rk));
+                off += width;
+            }
         }
         for (size_t e = 0; e < width; e++) input_vars[e] = element(pr, e).simplify();
     }

@@ -49,11 +49,21 @@ inline sc sc_mul_host(const sc& a, const sc& b) { return hostsc::mul(a, b); }
 struct Scalar {
     sc m;
     Scalar() : m(sc_zero()) {}
-    Scalar(uint64_t x) : m(sc_mont_from_u64(x)) {}  // From<u8/u32/u64>
+    Scalar(uint64_t x) {  // From<u8/u32/u64>
+        sc a = sc_zero();
+        a.v[0] = (uint32_t)x;
+        a.v[1] = (uint32_t)(x >> 32);
+        m = hostsc::mul(a, sc_const(SC_R2));
+    }
     static Scalar zero() { return Scalar(); }
     static Scalar one() { return Scalar(1); }
-    static Scalar from_bytes_mod_order(const uint8_t b[32]) { Scalar s; s.m = sc_mont_from_bytes_mod_order(b); return s; }
-    static Scalar from_bytes_mod_order_wide(const uint8_t b[64]) { Scalar s; s.m = sc_mont_from_wide(b); return s; }
+    // (a < 2^256, R^2 < l: the Montgomery product is < 2l before its one conditional subtraction - canonical out)
+    static Scalar from_bytes_mod_order(const uint8_t b[32]) { Scalar s; s.m = hostsc::mul(sc_load_raw(b), sc_const(SC_R2)); return s; }
+    static Scalar from_bytes_mod_order_wide(const uint8_t b[64]) {
+        Scalar s;
+        s.m = hostsc::add(hostsc::mul(sc_load_raw(b), sc_const(SC_R2)), hostsc::mul(sc_load_raw(b + 32), sc_const(SC_R3)));
+        return s;
+    }
     std::array<uint8_t, 32> to_bytes() const { std::array<uint8_t, 32> o; write_bytes(o.data()); return o; }
     void write_bytes(uint8_t* out) const {   // canonical little-endian: out of Montgomery form = a product with 1
         sc one = sc_zero();
@@ -221,6 +231,11 @@ public:
     virtual void constrain(LinearCombination lc) = 0;
     virtual size_t num_constraints() const = 0;
     virtual size_t num_multipliers() const = 0;
+    // true for a constraint system that RECORDS WitnessHint arguments (the CircuitCompiler).  The others never look at the linear
+    // combination that only describes how a wire is computed - and the Inverse S-box gadget's input combination is exactly that: the
+    // reference evaluates it and allocates the value, but never constrains it (trap T2, gadget_poseidon.rs:160-166) - so the gadget
+    // may hand them the VALUE alone (gadgets.hpp: Poseidon_permutation_constraints).
+    virtual bool uses_witness_hints() const { return false; }
     // Extension over the reference API (no-ops by default): the Inverse-S-box Poseidon gadget brackets a permutation
     // with begin/end and announces every S-box right before allocating its (x, 1/x) multiplier, so that a
     // CircuitCompiler can annotate the witness program (bpr1cs_poseidon_perm, include/bpr1cs.h).
@@ -281,7 +296,11 @@ public:
         bpr1cs_gens_point(gens, 0, 0, B.data());
         bpr1cs_gens_point(gens, 1, 0, B_blinding.data());
     }
+    // no device behind it: for a Prover that only synthesises (defer_commitments), commit() refuses
+    struct Detached {};
+    explicit PedersenGens(Detached) : gens(nullptr) { B.fill(0); B_blinding.fill(0); }
     CompressedRistretto commit(const Scalar& v, const Scalar& blinding) const {  // .compress()ed
+        if (!gens) throw R1CSError::Backend(BPR1CS_ERR_NO_DEVICE);
         uint32_t bases[2] = {0, 1};
         uint8_t s[64];
         auto a = v.to_bytes(), b = blinding.to_bytes();
@@ -466,6 +485,7 @@ public:
 class CircuitCompiler : public Verifier {
 public:
     explicit CircuitCompiler(Transcript& t) : Verifier(t) {}
+    bool uses_witness_hints() const override { return true; }
     // Prover-side API so that gadget harnesses written for `Prover` compile unchanged
     Variable commit_placeholder() { return commit(CompressedRistretto{}); }
 

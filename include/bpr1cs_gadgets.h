@@ -59,6 +59,12 @@ int bpr1cs_gadget_prove_on(const bpr1cs_gens* gens, const char* gadget, const ui
                            const uint8_t* values, const uint8_t* v_blindings, size_t m, size_t batch, const uint8_t* rng_seeds,
                            uint8_t* proofs_out, size_t proof_cap, size_t* proof_len, uint8_t* commitments_out, double seconds_out[5]);
 
+/* Host synthesis alone (no device call): the wires Prover::new -> commit x m -> gadget leaves behind, a_L | a_R | a_O, 3 * n * 32
+ * bytes - what bpr1cs_prove_batch / _transcripts take as `wires`.  wires_out may be NULL (n_out / q_out only); wires_cap in bytes. */
+int bpr1cs_gadget_synthesize(const char* gadget, const uint32_t* iparams, size_t n_iparams, const uint8_t* sparams, size_t n_sparams,
+                             const uint8_t* poseidon_blob, size_t blob_len, const uint8_t* values, size_t m, uint8_t* wires_out, size_t wires_cap,
+                             uint32_t* n_out, uint32_t* q_out);
+
 /* Verifier::new -> commit(V) x m -> gadget (no assignments) -> verify, as the second half of every reference test
  * (e.g. src/gadget_vsmt_4.rs:442-479).  `commitments` = all m commitments in gadget order (statics included).
  * 0 = accepted, BPR1CS_ERR_VERIFICATION / BPR1CS_ERR_FORMAT otherwise. */

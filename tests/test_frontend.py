@@ -81,3 +81,31 @@ def test_job_memory_knobs_do_not_change_a_byte(sim_lib, sim_glib):
         fc.check_compiled(sim_lib, sim_glib, "vsmt_2_cube", batch=2, unfold=unfold, factor_vectors=1)
     for unfold in (0, 1, 9):   # closed form: no un-folded round / one / every round from the tables
         fc.check_compiled(sim_lib, sim_glib, "vsmt_2_cube", batch=2, unfold=unfold)
+
+
+def test_host_synthesis_wires_equal_the_c_oracle_at_full_size(sim_glib):
+    """bpr1cs_gadget_synthesize (host front-end alone, no device) against oracle/c's own synthesis, wire for wire, on the circuits whose
+    host path the GPU suite proves: 140-round Inverse-S-box Poseidon 2:1 (partial rounds taken from the native state's VALUES,
+    gadgets.hpp), the depth-32 4-ary tree circuit (n = 18 656), the 64-bit bound check, MiMC + set membership"""
+    import importlib
+    import subprocess
+    import os
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle", "c")])
+    from cref import COracle
+    import fullsize_cases as fcs
+    wl = importlib.import_module("bulletproofs-r1cs-gadgets_amd.workloads")
+    o = COracle()
+    cases = [wl.bound_check64(3), wl.mimc_set_membership(2), wl.poseidon_2to1_cube(bp, sim_glib, 2), wl.vsmt4(bp, sim_glib, 32, 2, 2, 0),
+             wl.vsmt2(bp, sim_glib, 32, 2, b"l2", 0xffffffff, 10**6)]
+    # + the Inverse 2:1 preimage circuit (a frontend_cases scenario: the oracle's values)
+    gname, ip, sp, sc, cap = fc.case("poseidon_hash_2_inverse", 1)
+    ob = common.oracle_batch(lambda j: fc.case("poseidon_hash_2_inverse", 1)[3], cap, 1, key="p2inv_j1")
+    cases.append(dict(gadget=gname, ip=ip, sp=sp, label=ob["label"], B=1, m=ob["m"], values=ob["values"], blindings=ob["blindings"], seeds=ob["seeds"]))
+    for w in cases:
+        for j in range(min(2, w["B"])):
+            v, bl, seed = fcs.slice_proof(w, j)
+            r = o.prove_case(w["gadget"], w["ip"], w["sp"], w["label"], v, bl, seed, want_wires=True, prove=False)
+            wires, n, q = bp.gadget_synthesize(w["gadget"], w["ip"], w["sp"], v, w["m"], glib=sim_glib)
+            assert (n, q) == (r["n"], r["q"]), (w["gadget"], n, q, r["n"], r["q"])
+            assert wires == r["wires"][:96 * n], "%s proof %d: host wires differ from the C oracle's" % (w["gadget"], j)
