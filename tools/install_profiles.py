@@ -15,7 +15,7 @@ hdr = {
  "pmc_clock.txt": "# rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace -- python bench.py --steps 8 --warmup 4 --cpu-proofs 0 --configs none (%s; kernel_isa_sha256=%s).  GRBM_GUI_ACTIVE is summed over the 8 XCDs: effective clock = value / 8 / duration\n" % (tag, khash),
  "ubench.txt": "# tools/ubench on MI355X (%s).  Cycle figures assume 2.4 GHz; the chip clocks to its power budget (see %s_pmc_clock.txt), so short kernels (first block) and sustained ones (last lines, >= 120 ms) differ.  Last two lines: the Karatsuba kill-test\n" % (tag, tag),
 }
-for c in ("c2", "c3", "c5", "vsmt4_d128", "vsmt2_d253"):
+for c in ("c1", "c2", "c3", "c5", "vsmt4_d128", "vsmt2_d253"):
     hdr["%s_kernel_stats.txt" % c] = "# rocprofv3 --kernel-trace --stats -- python bench.py --config %s --warmup 4 --cpu-proofs 0 (%s, commit %s; the unprofiled line of the same command: %s_bench_%s.json)\n" % (c, tag, commit, tag, c)
 names = {"ubench.txt": "ubench_gfx950.txt"}
 for f, h in hdr.items():
@@ -27,7 +27,7 @@ for f, h in hdr.items():
         clk = {r[0]: float(r[2]) / 8 / (float(r[3]) * 1e6) for r in rows}
         h += "#   " + "   ".join("%s: %.2f GHz" % (k, clk[k]) for k in ("k_msm_fixed2", "k_probe_mad", "K_ipa_vb_fold2", "K_ipa_vb_win", "K_build_table") if k in clk) + "\n"
     open(dst + names.get(f, f), "w").write(h + body)
-for f in ["bench_default.json", "bench_torchrun_1rank.json", "bench_sync.json"] + ["bench_%s.json" % c for c in ("c2", "c3", "c5", "vsmt4_d128", "vsmt2_d253")]:
+for f in ["bench_default.json", "bench_torchrun_1rank.json", "bench_sync.json"] + ["bench_%s.json" % c for c in ("c1", "c2", "c3", "c5", "vsmt4_d128", "vsmt2_d253")]:
     p = os.path.join(src, f)
     if os.path.exists(p):
         line = [l for l in open(p).read().strip().split("\n") if l.startswith("{")][-1]

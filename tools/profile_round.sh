@@ -9,7 +9,7 @@ python tools/kernel_isa_stats.py k_msm_fixed2 --hash > $out/kernel_hash.txt
 timeout 900 python bench.py --steps 20 --warmup 5 2> $out/bench_default.err | grep -a "^{" | tail -1 > $out/bench_default.json; cut -c1-200 $out/bench_default.json
 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 16 --warmup 4 --cpu-proofs 0 --configs none --latency 0 2> $out/bench_torchrun.err | grep -a "^{" | tail -1 > $out/bench_torchrun_1rank.json
 timeout 600 python bench.py --opt jobs_in_flight=1 --steps 8 --warmup 4 --cpu-proofs 0 --configs none --latency 0 2>/dev/null | grep -a "^{" | tail -1 > $out/bench_sync.json
-for c in c2 c3 c5 vsmt4_d128 vsmt2_d253; do
+for c in c1 c2 c3 c5 vsmt4_d128 vsmt2_d253; do
   s=16; [ $c = vsmt4_d128 ] && s=6; [ $c = vsmt2_d253 ] && s=8
   timeout 900 python bench.py --config $c --steps $s --warmup 4 2>&1 | grep -a "^{" | tail -1 > $out/bench_$c.json
   timeout 900 rocprofv3 --kernel-trace --stats -d $out/kt_$c -o out -- python bench.py --config $c --steps $s --warmup 4 --cpu-proofs 0 > $out/kt_$c.log 2>&1
