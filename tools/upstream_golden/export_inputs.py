@@ -13,7 +13,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 
-FULLSIZE = {"vsmt4_d128_x70": [0, 69], "vsmt2_d253_x66": [0], "c5_mimc_set_x8192": [0, 8191], "c2_poseidon2_cube_x4096": [0]}
+FULLSIZE = {"c1_bound_check64_x4096": [0, 4095], "vsmt4_d128_x70": [0, 69], "vsmt2_d253_x66": [0], "c5_mimc_set_x8192": [0, 8191], "c2_poseidon2_cube_x4096": [0]}
 
 
 def hx(b):
