@@ -35,6 +35,29 @@ def test_msm_fixed_matches_oracle(hip_lib):
     assert gens.msm_fixed(bases, scal, batch) == exp
 
 
+_COMMIT_CASES = {}
+
+
+@pytest.mark.parametrize("wbits", [4, 8, 11, 15])
+def test_pedersen_commitment_calls_match_oracle(hip_lib, wbits):
+    """pc_gens.commit(v, blinding) = bpr1cs_msm_fixed(bases (B, B~)) - what Prover::commit calls once per value: a wavefront per
+    commitment (k_commit_wave: one lane per table entry, 2 x windows of them - 128 at W = 4, two per lane - then a shuffle
+    butterfly) for a handful of commitments, a lane per commitment for many; edge scalars 0, 1, l - 1, 2^252, both paths, four widths"""
+    from pyref.ed import msm, sc_to_bytes, L
+    gens = common.bp.Gens(4, lib=hip_lib, window_bits=wbits)
+    pts = [common.PC.B, common.PC.B_blinding]
+    edge = [(0, 0), (1, 0), (0, 1), (L - 1, L - 1), (2**252, 2**252 - 1), (1 << 44, (1 << 15 * 7) - 1)]
+    pairs = edge + [(S.synth_scalar(b"cv", i), S.synth_scalar(b"cb", i)) for i in range(300 - len(edge))]
+    if "exp" not in _COMMIT_CASES:   # (pure-Python group arithmetic: once for the four widths)
+        _COMMIT_CASES["exp"] = [msm([v, r], pts).compress() for v, r in pairs]
+    exp = _COMMIT_CASES["exp"]
+    scal = b"".join(sc_to_bytes(v) + sc_to_bytes(r) for v, r in pairs)
+    for j in range(12):                                            # one call per commitment, as the reference does
+        assert gens.msm_fixed([0, 1], scal[64 * j:64 * j + 64], 1) == [exp[j]]
+    assert gens.msm_fixed([0, 1], scal[:64 * 200], 200) == exp[:200]   # <= 256: the wavefront kernel, 200 workgroups
+    assert gens.msm_fixed([0, 1], scal, 300) == exp                    # > 256: a lane per commitment
+
+
 @pytest.mark.parametrize("unfold", [0, 2, 4])
 def test_bound_check_7bit(hip_lib, unfold):
     common.check_against_oracle(hip_lib, lambda j: S.bound_check(37 + j, 10, 100, 7), 16, 3, unfold)
