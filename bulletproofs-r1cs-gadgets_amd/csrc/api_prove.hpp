@@ -361,12 +361,12 @@ static int prove_job_begin(const bpr1cs_gens* g, const bpr1cs_circuit* c, const 
         }
         dev_stream_wait(st, job->ev_rng);  // (in the wires path everything on `sl` was synchronised above)
         pt.mark(st);
-        launch(B, finI, st);
+        launch_finish(finI, B, st);
         K_msm_finish finO{g->tab.p, g->tc, partialO.p, blind.p + 1 * (size_t)B, nullptr, AOS.p + 1 * (size_t)B * 32, B, planO.nchunks, 1};
         if (ones_pt) { finO.shared_pt = ones_pt; finO.partial_b = partialO1.p; finO.nchunks_b = planO1.nchunks; }
-        launch(B, finO, st);
+        launch_finish(finO, B, st);
         run_msm(g, seg(sL, baseG), seg(sR, baseH), B, partial, plan, st, stats);
-        launch(B, K_msm_finish{g->tab.p, g->tc, partial.p, blind.p + 2 * (size_t)B, nullptr, AOS.p + 2 * (size_t)B * 32, B, plan.nchunks, 1}, st);
+        launch_finish(K_msm_finish{g->tab.p, g->tc, partial.p, blind.p + 2 * (size_t)B, nullptr, AOS.p + 2 * (size_t)B * 32, B, plan.nchunks, 1}, B, st);
     }
     pt.mark(st);
 

@@ -188,7 +188,7 @@ static IpaEnd enqueue_ipa(const IpaIO& io, dev_stream_t st, MsmStats* stats) {
             run_msm_multi(g, rq, 2, B, st, stats);  // L_k and R_k share one launch
             K_msm_finish fL = finisher(partial.p, plan.nchunks, crossp, Lout);
             if (hs) { fL.tab2 = io.hs_tab; fL.extra_b = io.hs_scal; }
-            launch((uint64_t)2 * B, K_pair<K_msm_finish>{fL, finisher(partialR.p, planR.nchunks, crossp + B, Rout), B}, st);
+            launch_finish_pair(fL, finisher(partialR.p, planR.nchunks, crossp + B, Rout), B, st);
         } else {
             if (k == r) {
                 // The folded generators, the Straus digits and the window sums move into memory that is DEAD from here on: after
@@ -252,7 +252,7 @@ static IpaEnd enqueue_ipa(const IpaIO& io, dev_stream_t st, MsmStats* stats) {
                 emit((uint64_t)2 * VB_WINDOWS * B, K_ge_reduce{vwinp, vsump, B, 2 * VB_WINDOWS * vc, vc}, false);
             }
             emit((uint64_t)2 * B, K_ipa_vb_horner{vsump, voutp, B, 1}, false);
-            emit((uint64_t)2 * B, K_pair<K_msm_finish>{finisher(voutp, 1, crossp, Lout), finisher(voutp + (size_t)B, 1, crossp + B, Rout), B}, false);
+            launch_finish_pair(finisher(voutp, 1, crossp, Lout), finisher(voutp + (size_t)B, 1, crossp + B, Rout), B, st);
         }
         sc* ukk = io.uk + (size_t)k * 2 * B;
         emit(B, K_transcript_LR{io.tr, Lout, ukk, B}, false);

@@ -51,6 +51,30 @@ struct MsmPlan {
     uint32_t nchunks, chunk;
 };
 
+// K_msm_finish launches: a lane per output for a batch, a wavefront per output for a job of a few proofs (k_finish_wave: the finish
+// is on the critical path of every IPA round of a single proof)
+static const uint32_t FINISH_WAVE_MAX_PROOFS = 32;
+static void launch_finish(const K_msm_finish& f, uint32_t B, dev_stream_t st) {
+#if !defined(BPR1CS_HOSTSIM)
+    if (B <= FINISH_WAVE_MAX_PROOFS && !f.extra_pt) {
+        hipLaunchKernelGGL(k_finish_wave, dim3(B), dim3(64), 0, st, f, f, B, 1u);
+        HIPCHK(hipGetLastError());
+        return;
+    }
+#endif
+    launch(B, f, st);
+}
+static void launch_finish_pair(const K_msm_finish& a, const K_msm_finish& b, uint32_t B, dev_stream_t st) {
+#if !defined(BPR1CS_HOSTSIM)
+    if (B <= FINISH_WAVE_MAX_PROOFS && !a.extra_pt && !b.extra_pt) {
+        hipLaunchKernelGGL(k_finish_wave, dim3(2 * B), dim3(64), 0, st, a, b, B, 2u);
+        HIPCHK(hipGetLastError());
+        return;
+    }
+#endif
+    launch((uint64_t)2 * B, K_pair<K_msm_finish>{a, b, B}, st);
+}
+
 // HIP-event timing of every launch of the dominant kernel (k_msm_fixed2) on its own stream, for bench.py's roofline
 // object.  One instance per prove job (or per synchronous call): nothing is shared between handles or threads.
 struct MsmStats {

@@ -6,7 +6,7 @@ export TMPDIR=/tmp
 B="--steps 16 --warmup 4 --cpu-proofs 0 --configs none --latency 0"
 python tools/kernel_isa_stats.py k_msm_fixed2 --hash > $out/kernel_hash.txt
 # the driver's command (all configurations in the one line), then the same under torchrun with one rank, then one job in flight
-timeout 900 python bench.py --steps 20 --warmup 5 2> $out/bench_default.err | grep -a "^{" | tail -1 > $out/bench_default.json; cut -c1-200 $out/bench_default.json
+t0=$(date +%s); timeout 900 python bench.py --steps 20 --warmup 5 2> $out/bench_default.err | grep -a "^{" | tail -1 > $out/bench_default.json; cut -c1-200 $out/bench_default.json; echo "driver command wall seconds: $(( $(date +%s) - t0 ))" | tee $out/bench_default_wall.txt
 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 16 --warmup 4 --cpu-proofs 0 --configs none --latency 0 2> $out/bench_torchrun.err | grep -a "^{" | tail -1 > $out/bench_torchrun_1rank.json
 timeout 600 python bench.py --opt jobs_in_flight=1 --steps 8 --warmup 4 --cpu-proofs 0 --configs none --latency 0 2>/dev/null | grep -a "^{" | tail -1 > $out/bench_sync.json
 for c in c1 c2 c3 c5 vsmt4_d128 vsmt2_d253; do
