@@ -553,7 +553,9 @@ int bpr1cs_gadget_prove_on(const bpr1cs_gens* gens, const char* gadget, const ui
                     }
                 };
                 std::vector<std::thread> pool;
-                for (size_t k = 0; k + 1 < nthreads; k++) pool.emplace_back(worker);
+                try {
+                    for (size_t k = 0; k + 1 < nthreads; k++) pool.emplace_back(worker);
+                } catch (...) {}   // (no more threads to be had: the ones that started and this one share the work)
                 worker();
                 for (auto& th : pool) th.join();
             }

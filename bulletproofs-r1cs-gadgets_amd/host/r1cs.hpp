@@ -56,7 +56,7 @@ struct Scalar {
         m = hostsc::mul(a, sc_const(SC_R2));
     }
     static Scalar zero() { return Scalar(); }
-    static Scalar one() { return Scalar(1); }
+    static Scalar one() { static const Scalar o(1); return o; }   // (a conversion into Montgomery form is a product: not once per LinearCombination::from(Variable))
     // (a < 2^256, R^2 < l: the Montgomery product is < 2l before its one conditional subtraction - canonical out)
     static Scalar from_bytes_mod_order(const uint8_t b[32]) { Scalar s; s.m = hostsc::mul(sc_load_raw(b), sc_const(SC_R2)); return s; }
     static Scalar from_bytes_mod_order_wide(const uint8_t b[64]) {
