@@ -585,6 +585,7 @@ def load_gadgets_library(path=None):
     g.bpr1cs_gadget_compile.argtypes = [cp, ip, sz, cp, sz, cp, sz, ctypes.POINTER(vp), ip, ip, ip, ctypes.POINTER(ctypes.c_int)]
     g.bpr1cs_gadget_prove_single.argtypes = [cp, ip, sz, cp, sz, cp, sz, u32, cp, sz, cp, cp, sz, cp, cp, sz, ctypes.POINTER(sz), cp]
     g.bpr1cs_gadget_prove_on.argtypes = [vp, cp, ip, sz, cp, sz, cp, sz, cp, sz, cp, cp, sz, sz, cp, cp, sz, ctypes.POINTER(sz), cp, ctypes.POINTER(ctypes.c_double)]
+    g.bpr1cs_gadget_verify_on.argtypes = [vp, cp, ip, sz, cp, sz, cp, sz, cp, sz, cp, sz, cp, sz, ctypes.POINTER(ctypes.c_double)]
     g.bpr1cs_gadget_synthesize.argtypes = [cp, ip, sz, cp, sz, cp, sz, cp, sz, cp, sz, ip, ip]
     g.bpr1cs_gadget_verify_single.argtypes = [cp, ip, sz, cp, sz, cp, sz, u32, cp, sz, cp, sz, cp, sz]
     g.bpr1cs_poseidon_hash.argtypes = [ctypes.c_int, ctypes.c_int, u32, cp, sz, cp, cp]
@@ -668,6 +669,21 @@ def gadget_prove_on(gens, name, iparams, sparams, label, values, blindings, m, b
     return ([praw[i * n:(i + 1) * n] for i in range(batch)],
             [[craw[(i * m + j) * 32:(i * m + j + 1) * 32] for j in range(m)] for i in range(batch)],
             dict(zip(("commit", "gadget", "circuit", "prove", "total"), sec)))
+
+
+def gadget_verify_on(gens, name, iparams, sparams, label, proof, commitments, glib=None):
+    """bpr1cs_gadget_verify_on: Verifier::new -> commit(V) x m -> gadget -> verify of ONE proof on generators created once
+    -> (True / False, dict of seconds: gadget / verify / total)"""
+    g = glib or load_gadgets_library()
+    blob = poseidon_blob()
+    sp = b"".join(_sc(s) for s in sparams)
+    cm = b"".join(commitments)
+    sec = (ctypes.c_double * 3)()
+    rc = g.bpr1cs_gadget_verify_on(gens.h, name.encode(), _u32arr(list(iparams)), len(iparams), sp or b"\0", len(sparams), blob, len(blob),
+                                   label, len(label), proof, len(proof), cm or b"\0", len(commitments), sec)
+    if rc not in (0, -2, -3):
+        raise R1CSError(rc)
+    return rc == 0, dict(zip(("gadget", "verify", "total"), sec))
 
 
 def gadget_synthesize(name, iparams, sparams, values, m, glib=None):

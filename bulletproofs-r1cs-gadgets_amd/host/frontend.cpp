@@ -659,6 +659,49 @@ int bpr1cs_gadget_verify_single(const char* gadget, const uint32_t* iparams, siz
     }
 }
 
+// The verifier half on generators created ONCE (the reference creates them outside its timed region, src/gadget_vsmt_4.rs:386-387, and
+// verifies one proof per verify(): :442-479).  seconds_out (may be NULL): [0] gadget run without assignments (host), [1] the verify
+// call (CSR export + bpr1cs_circuit_create - a cache hit from the second proof on - + bpr1cs_verify_batch of one proof), [2] total.
+int bpr1cs_gadget_verify_on(const bpr1cs_gens* gens, const char* gadget, const uint32_t* iparams, size_t n_iparams, const uint8_t* sparams,
+                            size_t n_sparams, const uint8_t* poseidon_blob, size_t blob_len, const uint8_t* label, size_t label_len,
+                            const uint8_t* proof, size_t proof_len, const uint8_t* commitments, size_t m, double seconds_out[3]) {
+    if (!gens || !gadget || !label || !proof || (m && !commitments)) return BPR1CS_ERR_INVALID_ARGUMENT;
+    const double t_start = now_s();
+    double sec[3] = {0, 0, 0};
+    try {
+        GadgetSpec g = make_spec(gadget, iparams, n_iparams, sparams, n_sparams, poseidon_blob, blob_len);
+        BulletproofGens bp_gens(const_cast<bpr1cs_gens*>(gens), BulletproofGens::Borrowed{});
+        PedersenGens pc_gens(bp_gens);
+        Transcript t((const char*)label, label_len);
+        Verifier verifier(t);
+        Harness h{verifier,
+                  [&](size_t k) {
+                      if (k >= m) throw R1CSError::MissingAssignment();
+                      CompressedRistretto c;
+                      memcpy(c.data(), commitments + 32 * k, 32);
+                      return verifier.commit(c);
+                  },
+                  [](size_t) { return std::optional<Scalar>(); }, [](size_t) { return std::optional<uint64_t>(); }};
+        run_gadget(g, h);
+        sec[0] = now_s() - t_start;
+        int rc = BPR1CS_OK;
+        try {
+            R1CSProof p = R1CSProof::from_bytes(proof, proof_len);
+            verifier.verify(p, pc_gens, bp_gens, nullptr);
+        } catch (const R1CSError& e) {
+            rc = e.code;
+        }
+        sec[1] = now_s() - t_start - sec[0];
+        sec[2] = now_s() - t_start;
+        if (seconds_out) memcpy(seconds_out, sec, sizeof sec);
+        return rc;
+    } catch (const R1CSError& e) {
+        return e.code;
+    } catch (const std::exception&) {
+        return BPR1CS_ERR_INVALID_ARGUMENT;
+    }
+}
+
 // ---- native hashes / trees (witness generation; reference L1) ------------------------------------
 int bpr1cs_poseidon_hash(int arity, int sbox_inverse, uint32_t partial_rounds, const uint8_t* blob, size_t blob_len, const uint8_t* inputs,
                          uint8_t out[32]) {

@@ -72,6 +72,13 @@ int bpr1cs_gadget_verify_single(const char* gadget, const uint32_t* iparams, siz
                                 const uint8_t* poseidon_blob, size_t blob_len, uint32_t gens_capacity, const uint8_t* label, size_t label_len,
                                 const uint8_t* proof, size_t proof_len, const uint8_t* commitments, size_t m);
 
+/* The same on generators the caller created once (one proof per verify(), the reference's call shape: src/gadget_vsmt_4.rs:442-479 with
+ * the generators of :386-387).  seconds_out (may be NULL): [0] gadget run without assignments, [1] the verify call (circuit from the
+ * cache from the second proof on + bpr1cs_verify_batch of one proof), [2] total. */
+int bpr1cs_gadget_verify_on(const bpr1cs_gens* gens, const char* gadget, const uint32_t* iparams, size_t n_iparams, const uint8_t* sparams,
+                            size_t n_sparams, const uint8_t* poseidon_blob, size_t blob_len, const uint8_t* label, size_t label_len,
+                            const uint8_t* proof, size_t proof_len, const uint8_t* commitments, size_t m, double seconds_out[3]);
+
 /* Poseidon_hash_2 / Poseidon_hash_4 (arity 2 / 4) or the raw permutation (arity 6, out = 192 bytes) */
 int bpr1cs_poseidon_hash(int arity, int sbox_inverse, uint32_t partial_rounds, const uint8_t* blob, size_t blob_len, const uint8_t* inputs,
                          uint8_t* out);

@@ -182,6 +182,7 @@ def check_prove_on(lib, glib, name, batch, gens_cache={}):
     if key not in gens_cache:
         gens_cache[key] = bp.Gens(cap, lib=lib, window_bits=8)
     gens = gens_cache[key]
+    full = {}   # all m commitments of a proof in gadget order (the oracle's list leaves the gadget's static commitments out)
     for rep in range(2):
         for j in range(min(batch, 2)):
             P, C, sec = bp.gadget_prove_on(gens, gname, ip, sp, ob["label"], ob["values"][j * m * 32:(j + 1) * m * 32],
@@ -189,6 +190,14 @@ def check_prove_on(lib, glib, name, batch, gens_cache={}):
             assert P == [ob["proofs"][j]], "%s: single proof %d differs" % (name, j)
             assert C[0][:len(ob["comms"][j])] == ob["comms"][j]
             assert sec["total"] > 0 and sec["prove"] > 0
+            full[j] = C[0]
+        # ... and the verifier half on the same generators: one proof per verify(), a tampered proof and a foreign commitment rejected
+        ok, vsec = bp.gadget_verify_on(gens, gname, ip, sp, ob["label"], ob["proofs"][0], full[0], glib=glib)
+        assert ok and vsec["total"] > 0
+        bad = bytearray(ob["proofs"][0]); bad[1 + 8 * 32 + 3] ^= 1
+        assert not bp.gadget_verify_on(gens, gname, ip, sp, ob["label"], bytes(bad), full[0], glib=glib)[0]
+        if batch > 1 and full[1] != full[0]:
+            assert not bp.gadget_verify_on(gens, gname, ip, sp, ob["label"], ob["proofs"][0], full[1], glib=glib)[0]
         P, C, sec = bp.gadget_prove_on(gens, gname, ip, sp, ob["label"], ob["values"], ob["blindings"], m, batch, ob["seeds"], glib=glib)
         assert P == ob["proofs"], "%s: batch of %d differs" % (name, batch)
         assert all(C[j][:len(ob["comms"][j])] == ob["comms"][j] for j in range(batch))

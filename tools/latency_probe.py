@@ -47,6 +47,11 @@ def main():
                 print(case, "B=%d rep %d: %.1f ms  (%.2f ms/proof)  stages %s  phases %s msm %.1f ms / %d" % (
                     B, rep, 1e3 * wall, 1e3 * wall / B, {k: round(1e3 * x, 1) for k, x in sec.items()}, [round(x, 1) for x in st["phase_ms"]], st["msm_ms"], st["msm_launches"]), flush=True)
             out["%s_b%d" % (case, B)] = rows
+            if B == 1:   # the verifier half of the reference's tests: one proof per verify()
+                for rep in range(args.reps):
+                    t0 = time.perf_counter()
+                    ok, vsec = bp.gadget_verify_on(gens, w["gadget"], w["ip"], w["sp"], w["label"], P[0], C[0])
+                    print(case, "verify rep %d: %.1f ms  ok=%s  stages %s" % (rep, 1e3 * (time.perf_counter() - t0), ok, {k: round(1e3 * x, 1) for k, x in vsec.items()}), flush=True)
         # the device-program path at the same batch sizes (no host synthesis), for comparison
         circ = bp.CompiledGadget(w["gadget"], w["ip"], w["sp"])
         for B in ([] if args.no_device_program else [int(x) for x in args.batches.split(",")]):
