@@ -340,7 +340,8 @@ LATENCY_SHAPE = ("the reference's own call shape - ONE proof per prove() inside 
                  "gadget_bound_check.rs:49-87, gadget_poseidon.rs:734-747): Prover::new -> commit x m -> gadget synthesis on the host -> prove(), on "
                  "generators created once outside the bracket (:386-387).  = bpr1cs_gadget_prove_on: per commit one bpr1cs_msm_fixed call, then CSR "
                  "export + bpr1cs_circuit_create (cached per description) + bpr1cs_prove_batch_transcripts(batch, HOST wires) - exactly what "
-                 "tools/rust_shim/prover.rs does for batch 1; batch 8 / 64 = that many host syntheses, ONE device call")
+                 "tools/rust_shim/prover.rs does for batch 1; batch 8 / 64 = that many host syntheses, ONE device call.  verify_b1 = the verifier half, "
+                 "bpr1cs_gadget_verify_on: Verifier::new -> commit(V) x m -> gadget -> verify of one proof")
 
 
 def run_latency(bp, lib, case, w, gens, fixture, batches=(1, 8, 64)):
@@ -370,6 +371,19 @@ def run_latency(bp, lib, case, w, gens, fixture, batches=(1, 8, 64)):
                           "stage_ms": {kk: 1e3 * x for kk, x in stages[k].items()},
                           "device_phase_ms": dict(zip(["total", "inputs+commitV", "rng||witness", "commit_msm", "poly", "ipa"], phases[k])),
                           "parity": {"ok": ok, "proofs": checked, "source": "tests/golden/fullsize_digests.json[%s]" % fixture}}
+        if B == 1:   # the other half of every reference test: Verifier::new -> commit(V) x m -> gadget -> verify of that ONE proof (e.g. src/gadget_vsmt_4.rs:442-479)
+            vt, vok, vst = [], True, None
+            for rep in range(4):
+                t0 = time.perf_counter()
+                okv, vsec = bp.gadget_verify_on(gens, w["gadget"], w["ip"], w["sp"], w["label"], P[0], C[0])
+                vok = vok and okv
+                if rep:
+                    vt.append(time.perf_counter() - t0)
+                    vst = vsec
+            bad = bytearray(P[0]); bad[1 + 8 * 32 + 3] ^= 1
+            rejected = not bp.gadget_verify_on(gens, w["gadget"], w["ip"], w["sp"], w["label"], bytes(bad), C[0])[0]
+            out["verify_b1"] = {"ms_per_call": 1e3 * statistics.median(vt), "accepted": vok, "tampered_rejected": rejected,
+                                "stage_ms": {kk: 1e3 * x for kk, x in vst.items()}}
     return out
 
 
