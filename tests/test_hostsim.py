@@ -312,3 +312,46 @@ def test_prove_batch_refused_while_an_async_job_is_open(sim_lib):
     assert P == ob["proofs"]
     P2, _ = bp.prove_batch(gens, circ, ob["label"], ob["values"], ob["blindings"], ob["seeds"], 2, wires=ob["wires"])
     assert P2 == ob["proofs"]
+
+
+def test_circuit_cache_returns_equal_descriptions_only(sim_lib):
+    """bpr1cs_circuit_create keeps descriptions without a witness program (what a Prover / Verifier hands over once per proof):
+    a byte-identical description gets the object built before; one that differs in a single coefficient FAR from both ends of the
+    coefficient array (the lookup hash samples the ends only: the full comparison decides) gets its own; objects nobody holds are
+    dropped beyond 8 entries and by bpr1cs_release_cached_memory; a held one stays valid through both"""
+    bp = common.bp
+    ob = common.oracle_batch(lambda j: S.bound_check(37 + j, 10, 100, 7), 16, 2)
+    base_rows = [[((v[0], v[1]), c) for v, c in row] for row in ob["constraints"]]
+    # pad with rows that carry many terms, so that a middle coefficient is outside the 4096 bytes hashed at either end
+    pad = [[((1 + t % 3, t % ob["n"]), 7 + t) for t in range(64)] for _ in range(8)]   # 8 rows x 64 wire terms x 32 bytes = 16 KB of coefficients
+    rows = base_rows[:2] + pad + base_rows[2:]
+    a = bp.Circuit(ob["n"], ob["m"], rows, lib=sim_lib)
+    b = bp.Circuit(ob["n"], ob["m"], rows, lib=sim_lib)
+    assert a.h.value == b.h.value, "an identical description must hit the cache"
+    rows2 = [list(r) for r in rows]
+    rows2[6][30] = (rows2[6][30][0], 12345)                            # one coefficient in the middle
+    c = bp.Circuit(ob["n"], ob["m"], rows2, lib=sim_lib)
+    assert c.h.value != a.h.value, "a different description must not be served from the cache"
+    # (the witness does not satisfy the padded rows - irrelevant here: the prover's bytes are a function of the description, and
+    # they must differ exactly when the descriptions do)
+    gens = bp.Gens(16, lib=sim_lib)
+    Pa, _ = bp.prove_batch(gens, a, ob["label"], ob["values"], ob["blindings"], ob["seeds"], 2, wires=ob["wires"])
+    Pb, _ = bp.prove_batch(gens, b, ob["label"], ob["values"], ob["blindings"], ob["seeds"], 2, wires=ob["wires"])
+    Pc, _ = bp.prove_batch(gens, c, ob["label"], ob["values"], ob["blindings"], ob["seeds"], 2, wires=ob["wires"])
+    assert Pa == Pb and Pa != Pc
+    # eviction: ten more descriptions nobody holds; `a` (held twice) and `c` survive, stay usable
+    for k in range(10):
+        r = [list(x) for x in rows]
+        r[5][10] = (r[5][10][0], 1000 + k)
+        bp.Circuit(ob["n"], ob["m"], r, lib=sim_lib).close()
+    sim_lib.bpr1cs_release_cached_memory()
+    Pa2, _ = bp.prove_batch(gens, a, ob["label"], ob["values"], ob["blindings"], ob["seeds"], 2, wires=ob["wires"])
+    assert Pa2 == Pa
+    d = bp.Circuit(ob["n"], ob["m"], rows, lib=sim_lib)
+    assert d.h.value == a.h.value                                       # still the cached object: two handles are out on it
+    for x in (a, b, c, d):
+        x.close()
+    sim_lib.bpr1cs_release_cached_memory()
+    e = bp.Circuit(ob["n"], ob["m"], rows, lib=sim_lib)                 # rebuilt after the purge: works as before
+    Pe, _ = bp.prove_batch(gens, e, ob["label"], ob["values"], ob["blindings"], ob["seeds"], 2, wires=ob["wires"])
+    assert Pe == Pa
