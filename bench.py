@@ -665,6 +665,12 @@ def main():
                 g1 = bp.Gens(128)
                 lat["c1"] = run_latency(bp, lib, "c1", wl.bound_check64(64), g1, "c1_bound_check64_x4096")
                 g1.close()
+                if n_cpu > 0:   # the CPU port on the single-prover configuration (BASELINE config 1), one thread
+                    cb1, _ = cpu_baseline(wl.bound_check64(64), 32, 1)
+                    st1c = (cb1.get("single_thread") or {}).get("value")
+                    if st1c:
+                        lat["c1"]["cpu_port_ms_per_proof"] = 1e3 / st1c
+                        lat["c1"]["speedup_b1_vs_cpu_port_1_thread"] = (1e3 / st1c) / lat["c1"]["b1"]["ms_per_proof"]
                 cb = out.get("cpu_baseline") or {}
                 st1 = (cb.get("single_thread") or {}).get("value")
                 if st1:
