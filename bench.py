@@ -65,11 +65,11 @@ CONFIGS = {
     "c5": dict(metric="R1CS proofs/sec (MiMC-322 preimage + set membership)", batch=8192, cpu_proofs=32, short=(4, 24), fixture="c5_mimc_set_x8192",
                workload="gadget_mimc preimage + gadget_set_membership (k = 7) on one prover (reference src/gadget_mimc.rs:92-175, src/gadget_set_membership.rs:93-171)",
                build=lambda bp, B, base, a: wl.mimc_set_membership(B, index_base=base)),
-    "vsmt4_d128": dict(metric="R1CS proofs/sec (Poseidon VSMT-4 depth-128, as shipped)", batch=1024, cpu_proofs=1, short=(2, 3), fixture="vsmt4_d128_x70",
+    "vsmt4_d128": dict(metric="R1CS proofs/sec (Poseidon VSMT-4 depth-128, as shipped)", batch=1024, cpu_proofs=1, short=(2, 6), fixture="vsmt4_d128_x70",
                        fixture_build=lambda bp: wl.vsmt4(bp, None, 128, 70, 70, 11),
                        workload="gadget_vsmt_4 at the depth the reference ships (TreeDepth = 128, src/gadget_vsmt_4.rs:25): n = 74 624, N = 131 072",
                        build=lambda bp, B, base, a: wl.vsmt4(bp, None, 128, B, B, base)),
-    "vsmt2_d253": dict(metric="R1CS proofs/sec (Poseidon VSMT-2 depth-253, as shipped)", batch=256, cpu_proofs=1, short=(4, 6), fixture="vsmt2_d253_x66",
+    "vsmt2_d253": dict(metric="R1CS proofs/sec (Poseidon VSMT-2 depth-253, as shipped)", batch=256, cpu_proofs=1, short=(4, 9), fixture="vsmt2_d253_x66",
                        fixture_build=lambda bp: wl.vsmt2(bp, None, 253, 66, b"l253", (1 << 250) - 1, 2 * 10**6),
                        workload="gadget_vsmt_2 at the depth the reference ships (TreeDepth = 253, src/gadget_vsmt_2.rs:23): n = 143 704, N = 262 144",
                        build=lambda bp, B, base, a: wl.vsmt2(bp, None, 253, B, b"l253", (1 << 250) - 1, 2 * 10**6 + base)),
