@@ -45,7 +45,7 @@ struct BpOpts {
     std::atomic<int> witness_team{8};      // lanes cooperating on one proof in k_witness_team (4, 8 or 16)
     std::atomic<int> tail_rounds{7};       // final IPA rounds (m_k <= 64 at 7) enqueued on the job's own tail stream
     std::atomic<int> shared_back{1};       // the jobs in flight on a handle share the scratch of their back phases (DevArena)
-    std::atomic<int> factor_vectors{0};    // 1: the prover hands the IPA its factor vectors as N x B arrays, 0: closed form (IpaGeo)
+    std::atomic<int> factor_vectors{0};    // 1: the prover hands the IPA its factor vectors as N x B arrays, 0: closed form (IpaGeo), scalars produced by the MSM kernel from N = 4096 on, 2: closed form, scalars always written out, 3: always produced
     std::atomic<int> msm_threads_log2{21}; // (chunk, proof) threads per MSM launch
     std::atomic<int> job_proofs{0};        // proofs per device job of bpr1cs_prove_batch (0: from the free memory)
     std::atomic<int> jobs_in_flight{2};
@@ -58,7 +58,7 @@ static bool opt_apply(BpOpts& o, int option, int value, bool creating) {
         case BPR1CS_OPT_WITNESS_TEAM: o.witness_team = (value == 4 || value == 8 || value == 16) ? value : 8; return true;
         case BPR1CS_OPT_TAIL_ROUNDS: o.tail_rounds = value < 0 ? 7 : value; return true;
         case BPR1CS_OPT_SHARED_BACK: o.shared_back = value < 0 ? 1 : (value ? 1 : 0); return true;
-        case BPR1CS_OPT_FACTOR_VECTORS: o.factor_vectors = value < 0 ? 0 : (value ? 1 : 0); return true;
+        case BPR1CS_OPT_FACTOR_VECTORS: o.factor_vectors = value < 0 ? 0 : (value > 3 ? 1 : value); return true;
         case BPR1CS_OPT_MSM_THREADS_LOG2: o.msm_threads_log2 = value < 0 ? 21 : (value < 16 ? 16 : (value > 26 ? 26 : value)); return true;
         case BPR1CS_OPT_JOB_PROOFS: o.job_proofs = value < 0 ? 0 : value; return true;
         case BPR1CS_OPT_JOBS_IN_FLIGHT: o.jobs_in_flight = (value == 1) ? 1 : 2; return true;

@@ -381,7 +381,7 @@ static int prove_job_begin(const bpr1cs_gens* g, const bpr1cs_circuit* c, const 
     // (dead after round r-1) share their memory with the Straus multiples of the first variable-base pair, which K_ipa_vb_tab
     // writes at round r, after the launch that materialises the folded generators: 15 of 40 GiB of a 2048-proof job's back phase.
     const uint32_t r_eff = std::min<uint32_t>((uint32_t)o_unfold, lgN);
-    const bool fvec = g->opts.factor_vectors.load() != 0;   // factor vectors as arrays (measuring knob); default: closed form, no cG / cH
+    const bool fvec = g->opts.factor_vectors.load() == 1;   // factor vectors as arrays (measuring knob); default: closed form, no cG / cH
     const uint32_t nfl = c->h_slot_chunk[3 * n + m];
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     const size_t w_bytes = al(((size_t)(3 * n + m) * B + 1) * sizeof(sc)), p_bytes = al((size_t)(nfl ? nfl : 1) * B * sizeof(sc)),
@@ -414,6 +414,9 @@ static int prove_job_begin(const bpr1cs_gens* g, const bpr1cs_circuit* c, const 
 
     // ---- P5: inner-product argument
     IpaIO io{g, B, N, lgN, (uint32_t)o_unfold, tr.p, a.p, bb.p, cG.p, cH.p, chal.p + (size_t)CH_W * B, nullptr, LR.p, uk.p};
+    // same box, alternating runs: 2957 / 2960 against 2948 / 2955 proofs/s for the depth-32 circuit (the term fetch costs a launch 3.3 ms, the
+    // kernel it replaces took 26 ms per job); nothing for N = 512 / 1024 (148.7 against 149.1 k, 83.26 against 83.29 k): from N = 4096 on
+    io.fuse_scalars = g->opts.factor_vectors.load() == 3 || (g->opts.factor_vectors.load() == 0 && N >= 4096);
     if (!fvec) { io.geo.plo = plo.p; io.geo.phi = phi.p; io.geo.upad = chal.p + (size_t)CH_U * B; io.geo.H = H; io.geo.n1 = n; }
     DevBuf<sc> hs_scal;
     if (lgN >= 1 && n > N / 2 && n < N && o_unfold >= 1) {

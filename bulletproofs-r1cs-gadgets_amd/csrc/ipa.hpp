@@ -44,6 +44,7 @@ struct IpaIO {
     // multiples of the first variable-base pair - the prover lets them SHARE one block with buffers that are dead by then
     sc* sG_pre = nullptr; sc* sH_pre = nullptr;
     IpaGeo geo;      // the R1CS prover's factor vectors in closed form (kernels.hpp) instead of cG / cH
+    bool fuse_scalars = true;   // with `geo`: launches of the shipped MSM kernel produce their scalars at the term fetch (MsmGeo)
     ge_cached* vtab_pre = nullptr; size_t vtab_pre_count = 0;
     dev_event_t* tail_event = nullptr;
 };
@@ -80,6 +81,11 @@ static IpaEnd enqueue_ipa(const IpaIO& io, dev_stream_t st, MsmStats* stats) {
         if (hfJ) hf.alloc((size_t)2 * hfJ * B);
     }
     // closed-form factors of round k: the per-proof products (and, for blocks of >= 256 positions, their table by i >> 8), then the scalars
+    // closed-form factors of round k: the per-proof products (and, for blocks of >= 256 positions, their table by i >> 8), then the
+    // scalars - written out (K_ipa_scalars_geo) for the small-job path, or produced by the MSM kernel at its term fetch (`fused`:
+    // MsmGeo, csrc/msm_kernel.hpp) for launches of the shipped kernel, which then need no N x B scalar arrays at all
+    const bool fused = geo && B >= 32 && io.fuse_scalars;
+    MsmGeo mg;
     auto geo_scalars = [&](uint32_t k, const sc* va, const sc* vb) {
         const uint32_t lgNk = lgN - k;
         launch((uint64_t)2 * (k ? 1u << (k - 1) : 1u) * B, K_ipa_fac{fac.p, k ? io.uk + (size_t)(k - 1) * 2 * B : nullptr, io.geo.upad, B, k, facT}, st);
@@ -87,6 +93,11 @@ static IpaEnd enqueue_ipa(const IpaIO& io, dev_stream_t st, MsmStats* stats) {
         if (lgNk >= 8 && hfJ) {
             launch((uint64_t)2 * hfJ * B, K_ipa_hf{fac.p, io.geo.phi + (size_t)io.geo.H * B, hf.p, B, hfJ, lgNk - 8, facT}, st);
             hfp = hf.p;
+        }
+        if (fused) {
+            mg.fac = fac.p; mg.hf = hfp; mg.lo1 = io.geo.plo + (size_t)256 * B; mg.hi1 = io.geo.phi + (size_t)io.geo.H * B;
+            mg.T = facT; mg.J = hfJ; mg.Nk = N >> k; mg.lgNk = lgNk; mg.n1 = io.geo.n1;
+            return;
         }
         launch((uint64_t)N * B, K_ipa_scalars_geo{va, vb, fac.p, hfp, io.geo, sGp, sHp, B, N >> k, lgNk, facT, hfJ}, st);
     };
@@ -176,6 +187,10 @@ static IpaEnd enqueue_ipa(const IpaIO& io, dev_stream_t st, MsmStats* stats) {
             // L: G-terms with pos >= m, H-terms with pos < m ; R: the complement
             MsmSeg gL{sGp, half, mk, Nk, mk, baseG, 0}, hL{sHp, half, mk, Nk, 0, baseH, 0};
             MsmSeg gR{sGp, half, mk, Nk, 0, baseG, 0}, hR{sHp, half, mk, Nk, mk, baseH, 0};
+            if (fused) {   // scalar of generator i = a / b [partner(i)] * factor(i), produced at the term fetch
+                gL.scal = gR.scal = a; hL.scal = hR.scal = bb;
+                gL.geo = gR.geo = 1; hL.geo = hR.geo = 2;
+            }
             // (round 0 of the R1CS prover: l(x) is zero and r(x) is -y^i beyond n, so of the 65 536 terms 14 112 G-terms of R_0
             // vanish and 14 112 H-terms of L_0 share one scalar: both blocks are left out of the segments - 50 -> 36 ms for the launch)
             const bool hs = k == 0 && io.hs_tab && io.hs_from < mk;
@@ -185,7 +200,7 @@ static IpaEnd enqueue_ipa(const IpaIO& io, dev_stream_t st, MsmStats* stats) {
             }
             MsmPlan planR;
             MsmReq rq[2] = {{gL, hL, &partial, &plan, nullptr}, {gR, hR, &partialR, &planR, nullptr}};
-            run_msm_multi(g, rq, 2, B, st, stats);  // L_k and R_k share one launch
+            run_msm_multi(g, rq, 2, B, st, stats, fused ? &mg : nullptr);  // L_k and R_k share one launch
             K_msm_finish fL = finisher(partial.p, plan.nchunks, crossp, Lout);
             if (hs) { fL.tab2 = io.hs_tab; fL.extra_b = io.hs_scal; }
             launch_finish_pair(fL, finisher(partialR.p, planR.nchunks, crossp + B, Rout), B, st);
@@ -224,6 +239,11 @@ static IpaEnd enqueue_ipa(const IpaIO& io, dev_stream_t st, MsmStats* stats) {
                     const MsmSeg none{nullptr, 0, 1, 1, 0, 0, 0};
                     L.job[0] = MsmJob{{MsmSeg{fG, N, N, N, 0, baseG, f_mont}, none}, g->tab.p, g->tc, GHp, N / M, M, 1};
                     L.job[1] = MsmJob{{MsmSeg{fH, N, N, N, 0, baseH, f_mont}, none}, g->tab.p, g->tc, GHp + (size_t)M * B, N / M, M, 1};
+                    if (fused) {   // the factors themselves, produced at the term fetch (no vector)
+                        L.job[0].seg[0].scal = nullptr; L.job[0].seg[0].geo = 1;
+                        L.job[1].seg[0].scal = nullptr; L.job[1].seg[0].geo = 2;
+                        L.geo = mg;
+                    }
                     L.wg_end[0] = M * L.nbk; L.wg_end[1] = 2 * M * L.nbk;
                     launch_msm_kernel(g, L, st, stats, (uint64_t)2 * N * B, (uint64_t)2 * N * B * g->tc.windows);
                 }

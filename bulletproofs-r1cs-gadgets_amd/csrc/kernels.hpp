@@ -693,6 +693,22 @@ struct MsmSeg {
     // optional gather form: element index = sidx[o]; base = base0 + (bdense ? o : sidx[o])
     const uint32_t* sidx = nullptr;
     uint32_t bdense = 0;
+    // optional (shipped kernel only): the scalar of element i is not stored but PRODUCED at the term fetch from the launch's MsmGeo -
+    // 1: vector[partner(i)] * G-factor(i), 2: vector[partner(i)] * H-factor(i), `scal` = the folded a / b vector (Montgomery), or
+    // null for the factors alone (the folded generators).  See MsmGeo.
+    uint32_t geo = 0;
+};
+// The product scalars of an un-folded IPA round in closed form (IpaGeo / K_ipa_fac / K_ipa_hf below), for a launch of the shipped MSM
+// kernel that computes them where it fetches a term instead of reading an N x B array a separate kernel wrote (K_ipa_scalars_geo:
+// 26 ms and 17 GB of traffic per 4096-proof job of the depth-32 circuit, for one or two Montgomery products per term that cost
+// the fetch ~1 % of the term's table additions).  fac: [6][T][B] (K_ipa_fac); hf: [2][J][B] or null (K_ipa_hf); lo1 / hi1: the
+// y^-1 power tables (low: 256 entries, high: H entries).  Round k works on vectors of length Nk = N >> k.
+struct MsmGeo {
+    const sc* fac = nullptr;
+    const sc* hf = nullptr;
+    const sc* lo1 = nullptr;
+    const sc* hi1 = nullptr;
+    uint32_t T = 0, J = 0, Nk = 0, lgNk = 0, n1 = 0;
 };
 // canonical scalar of a term from its stored form.  MSM_MINUS_ONE: the stored wire is 1 by construction in all but
 // exceptional proofs (the a_O wires of an Inverse S-box, x * 1/x), so its generator is added ONCE, as part of a
@@ -700,6 +716,9 @@ struct MsmSeg {
 #define MSM_CANONICAL 0u
 #define MSM_MONT 1u
 #define MSM_MINUS_ONE 2u
+#define MSM_GEO_G 3u    // scalar = [vector *] one canonical factor           (MsmSeg::geo = 1)
+#define MSM_GEO_H 4u    // scalar = [vector *] (low-table entry * hf entry)    (MsmSeg::geo = 2, blocks of >= 256 positions)
+#define MSM_GEO_H3 5u   // scalar = [vector *] (low * high * factor)           (MsmSeg::geo = 2, shorter blocks)
 HD inline sc msm_scalar(const sc& x, uint32_t form) {
     if (form == MSM_CANONICAL) return x;
     if (form == MSM_MONT) return sc_from_mont(x);

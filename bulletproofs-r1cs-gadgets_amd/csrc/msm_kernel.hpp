@@ -33,6 +33,7 @@ struct MsmLaunch {
     uint32_t wg_end[MSM_MAX_JOBS];  // exclusive end of every job's workgroup range
     uint32_t njobs, B, nbk, nwg;    // nbk = ceil(B / 64) workgroups per chunk; nwg = workgroups launched
     uint32_t max_windows;           // over the jobs' tables: sizes the digit buffers (LDS)
+    MsmGeo geo;                     // for segments with MsmSeg::geo set: where their scalars come from
 };
 
 // What the body needs from the wavefront it runs in.  Device: the hardware's vote and broadcast.  Simulator: lanes run one after
@@ -87,16 +88,37 @@ struct MsmTerm {
     const sc* scal;      // + b
     const uint8_t* tab;  // rows of its base
     uint32_t mont;
+    const sc* f1; const sc* f2; const sc* f3;   // MSM_GEO_*: the factors of the scalar (+ b)
 };
-MSM_FN MsmTerm msm_term(const MsmJob& J, uint32_t o, uint32_t B, const TabCfg& tc) {
+MSM_FN MsmTerm msm_term(const MsmJob& J, uint32_t o, uint32_t B, const TabCfg& tc, const MsmGeo& G) {
     const bool first = o < J.seg[0].count;
     const MsmSeg& s = first ? J.seg[0] : J.seg[1];
     uint32_t oo = first ? o : o - J.seg[0].count;
     uint32_t i = s.sidx ? s.sidx[oo] : (oo / s.run) * s.period + s.off + (oo % s.run);
     uint32_t base = s.base0 + (s.bdense ? oo : i);
     MsmTerm t;
-    t.scal = s.scal + (size_t)i * B;
     t.tab = J.tab + (size_t)base * tc.base_bytes();
+    t.f1 = t.f2 = t.f3 = nullptr;
+    if (s.geo) {   // (as K_ipa_scalars_geo: partner within the block of Nk positions, factor by block number and padding flag)
+        const uint32_t m = G.Nk >> 1, pos = i & (G.Nk - 1u), blk = i >> G.lgNk, e = i >= G.n1 ? 1u : 0u;
+        const uint32_t partner = pos >= m ? pos - m : pos + m;
+        t.scal = s.scal ? s.scal + (size_t)partner * B : nullptr;
+        if (s.geo == 1u) {
+            t.mont = MSM_GEO_G;
+            t.f1 = G.fac + ((size_t)(2u + e) * G.T + blk) * B;
+        } else if (G.hf) {
+            t.mont = MSM_GEO_H;
+            t.f1 = G.lo1 + (size_t)(i & 255u) * B;
+            t.f2 = G.hf + ((size_t)e * G.J + (i >> 8)) * B;
+        } else {
+            t.mont = MSM_GEO_H3;
+            t.f1 = G.lo1 + (size_t)(i & 255u) * B;
+            t.f2 = G.hi1 + (size_t)(i >> 8) * B;
+            t.f3 = G.fac + ((size_t)(4u + e) * G.T + blk) * B;
+        }
+        return t;
+    }
+    t.scal = s.scal + (size_t)i * B;
     t.mont = s.mont;
     return t;
 }
@@ -153,16 +175,23 @@ MSM_FN void msm_fixed2_body(const MsmLaunch& L, uint32_t wg_raw, const uint32_t 
     // fetch the next term whose scalars are not all zero (IPA round 0: the l-vector is zero beyond n)
     auto fetch = [&](uint32_t& o, sc& x, MsmTerm& t) -> bool {
         for (; o < hi; o += step) {
-            t = msm_term(J, o, B, tc);
+            t = msm_term(J, o, B, tc, L.geo);
             const uint32_t form = t.mont;
             // wires that are 1 by construction (MSM_MINUS_ONE): the term is (wire - 1) * Base, zero in all but exceptional proofs
             auto scalar_of = [&](uint32_t proof) {
+                if (form >= MSM_GEO_G) {   // produced here (MsmGeo): canonical out - a Montgomery-form vector entry times canonical factors
+                    sc f = t.f1[proof];
+                    if (form != MSM_GEO_G) f = sc_mul(f, t.f2[proof]);
+                    if (form == MSM_GEO_H3) f = sc_mul(f, t.f3[proof]);
+                    return t.scal ? sc_mul(t.scal[proof], f) : f;
+                }
                 sc v = t.scal[proof];
                 if (form == MSM_MINUS_ONE) v = sc_sub(v, sc_one_mont());
                 return v;
             };
             x = scalar_of(b);
             if (form == MSM_MINUS_ONE) t.mont = MSM_MONT;
+            if (form >= MSM_GEO_G) t.mont = MSM_CANONICAL;
             if (MsmWave::any(!sc_is_zero(x), [&](uint32_t l) { return !sc_is_zero(scalar_of(b0 + l < B ? b0 + l : B - 1)); })) return true;
         }
         return false;

@@ -149,7 +149,7 @@ struct MsmReq {
                               // proofs (MSM_MINUS_ONE) take few, long chunks: an empty workgroup still costs its dispatch
     const TabCfg* tc = nullptr;  // geometry of `table` (nullptr: that of the generator tables)
 };
-static void run_msm_multi(const bpr1cs_gens* g, MsmReq* reqs, uint32_t nreq, uint32_t B, dev_stream_t st, MsmStats* stats) {
+static void run_msm_multi(const bpr1cs_gens* g, MsmReq* reqs, uint32_t nreq, uint32_t B, dev_stream_t st, MsmStats* stats, const MsmGeo* geo = nullptr) {
     if (B < 32) {  // a wavefront per (chunk, 64 proofs) would be mostly idle: lanes take different chunks instead
         for (uint32_t r = 0; r < nreq; r++) {
             MsmReq& q = reqs[r];
@@ -186,6 +186,7 @@ static void run_msm_multi(const bpr1cs_gens* g, MsmReq* reqs, uint32_t nreq, uin
     MsmLaunch L{};
     L.B = B; L.nbk = nbk;
     L.njobs = nreq;
+    if (geo) L.geo = *geo;
     uint32_t wg = 0;
     uint64_t terms = 0, adds = 0;
     for (uint32_t r = 0; r < nreq; r++) {

@@ -150,8 +150,10 @@ int bpr1cs_gens_table_info(const bpr1cs_gens* g, uint32_t* window_bits, uint32_t
                                          instead of the handle's heavy stream (default 7 = the rounds with m_k <= 64; 0 = none) */
 #define BPR1CS_OPT_SHARED_BACK 4      /* 1 (default): the jobs in flight on a handle share the device scratch of their back phases, the wire /
                                          blinding vectors and the raw TranscriptRng output (each is live for a part of a job only) */
-#define BPR1CS_OPT_FACTOR_VECTORS 5   /* measuring option: 1 = the prover writes the argument's factor vectors out as N x B arrays
-                                         (the form bpr1cs_ipa_create always uses) instead of their closed form (default 0) */
+#define BPR1CS_OPT_FACTOR_VECTORS 5   /* measuring option: 0 (default) = closed form of the argument's factor vectors, the product scalars of
+                                         an un-folded round produced by the MSM kernel where it fetches a term (from N = 4096 on; 3 =
+                                         for every N); 2 = closed form, the scalars written out as N x B arrays by a kernel of their
+                                         own (round 4); 1 = the factor vectors themselves as N x B arrays (what bpr1cs_ipa_create uses) */
 #define BPR1CS_OPT_MSM_THREADS_LOG2 6 /* measuring option: log2 of the (chunk, proof) threads per launch of the MSM kernel (default 21) */
 #define BPR1CS_OPT_JOB_PROOFS 7       /* proofs per device job when bpr1cs_prove_batch cuts a batch into jobs (default 0 = the largest of
                                          16384, 12288, 8192 ... 4096, 3584, 3072 ... 64 whose working set fits next to the tables:

@@ -88,6 +88,13 @@ def test_vsmt4_8_levels_w11_every_proof_of_a_ragged_batch(hip_lib, hip_glib):
     P, C = bp.prove_batch(gens, circ, b"VSMT", case["values"], case["blindings"], case["seeds"], B)
     fc.check_digests("vsmt4_l8_x70", case, P, C)
     assert bp.verify_batch(gens, circ, b"VSMT", P, C, B) == [True] * B
+    # (default at N = 8192: the product scalars of the un-folded rounds are produced inside the MSM kernel's term fetch, MsmGeo) the same bytes
+    # with the scalars written out by their own kernel (2) and with the factor vectors as arrays (1)
+    for fv in (2, 1):
+        gens.set_option("factor_vectors", fv)
+        Pv, _ = bp.prove_batch(gens, circ, b"VSMT", case["values"], case["blindings"], case["seeds"], B)
+        assert Pv == P, fv
+    gens.set_option("factor_vectors", -1)
     # every proof from its caller's own transcript (bpr1cs_prove_batch_transcripts, Prover::new(&pc_gens, &mut transcript)): the same
     # bytes when the transcripts are fresh Transcript::new(b"VSMT"), and every transcript advances
     ts = [bp.Transcript(b"VSMT", lib=hip_lib) for _ in range(B)]

@@ -142,6 +142,14 @@ def test_shipped_msm_loop_on_70_proof_batches(sim_lib, sim_glib):
         P2, _ = bp.prove_batch(gens, circ, label, values, blindings, seeds, B)
         st = bp.last_prove_stats(sim_lib)
         assert P2 == want and (st["jobs"], st["job_proofs"]) == (2, 40), (name, st)
+        if mk is not None:
+            # the same bytes with the product scalars of the un-folded rounds produced inside the kernel's term fetch (3: MsmGeo - the
+            # default from N = 4096 on), written out by a kernel of their own (2), and with the factor vectors as arrays (1)
+            for fv in (3, 2, 1):
+                gens.set_option("factor_vectors", fv)
+                P3, _ = bp.prove_batch(gens, circ, label, values, blindings, seeds, B)
+                assert P3 == want, (name, fv)
+            gens.set_option("factor_vectors", -1)
         if mk is None:
             # the circuit's merged S-box tables one window bit narrower than the generator tables (what the library does from 8 GiB on):
             # two table geometries in ONE launch of the kernel, the same bytes
