@@ -17,6 +17,9 @@ hdr = {
 }
 for c in ("c1", "c2", "c3", "c5", "vsmt4_d128", "vsmt2_d253"):
     hdr["%s_kernel_stats.txt" % c] = "# rocprofv3 --kernel-trace --stats -- python bench.py --config %s --warmup 4 --cpu-proofs 0 (%s, commit %s; the unprofiled line of the same command: %s_bench_%s.json)\n" % (c, tag, commit, tag, c)
+for c in ("c4", "c1"):
+    hdr["latency_%s_one_proof_timeline.txt" % c] = "# rocprofv3 --kernel-trace -- python tools/latency_probe.py --cases %s --batches 1 --reps 3 --no-device-program ; tools/trace_lastcall.py (%s, commit %s): every launch of the last bpr1cs_prove_batch_transcripts(batch 1, host wires) call%s, then the totals per kernel\n" % (
+        c, tag, commit, " (c1: the window holds the three timed calls, divide the totals by 3)" if c == "c1" else "")
 names = {"ubench.txt": "ubench_gfx950.txt"}
 for f, h in hdr.items():
     p = os.path.join(src, f)

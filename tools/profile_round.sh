@@ -26,5 +26,12 @@ done
 python tools/rocprof_summary.py pmc $out/pmc_FETCH_SIZE $out/pmc_WRITE_SIZE > $out/pmc_hbm_traffic.txt 2>&1
 python tools/rocprof_summary.py pmc $out/pmc_GRBM_GUI_ACTIVE > $out/pmc_clock.txt 2>&1
 rm -rf $out/kt $out/pmc_FETCH_SIZE $out/pmc_WRITE_SIZE $out/pmc_GRBM_GUI_ACTIVE
+# the reference's call shape - ONE proof per prove() - launch by launch (tools/trace_lastcall.py: the last call of the probe)
+for c in c4 c1; do
+  timeout 600 rocprofv3 --kernel-trace -d $out/kt_lat_$c -o out -- python tools/latency_probe.py --cases $c --batches 1 --reps 3 --no-device-program > $out/kt_lat_$c.log 2>&1
+  gap=5; [ $c = c1 ] && gap=2
+  python tools/trace_lastcall.py $out/kt_lat_$c $gap 3000 > $out/latency_${c}_one_proof_timeline.txt 2>&1
+  rm -rf $out/kt_lat_$c
+done
 [ -x tools/ubench ] && timeout 300 tools/ubench > $out/ubench.txt 2>&1
 if [ "$2" = tests ]; then timeout 1700 python -m pytest tests -m gpu -x -q > $out/gputests.txt 2>&1; tail -3 $out/gputests.txt; fi
