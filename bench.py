@@ -349,7 +349,7 @@ def run_latency(bp, lib, case, w, gens, fixture, batches=(1, 8, 64)):
     untimed), every proof compared with the committed digest of the C oracle's proof of the same witness"""
     import statistics
     fx = json.load(open(os.path.join(ROOT, "tests", "golden", "fullsize_digests.json")))[fixture]["proofs"]
-    m, out = w["m"], {}
+    m, out, compiled = w["m"], {}, {}
     for B in batches:
         v, b, s = w["values"][:B * m * 32], w["blindings"][:B * m * 32], w["seeds"][:B * 32]
         reps = 5 if B == 1 else (3 if B <= 8 else 2)
@@ -371,6 +371,18 @@ def run_latency(bp, lib, case, w, gens, fixture, batches=(1, 8, 64)):
                           "stage_ms": {kk: 1e3 * x for kk, x in stages[k].items()},
                           "device_phase_ms": dict(zip(["total", "inputs+commitV", "rng||witness", "commit_msm", "poly", "ipa"], phases[k])),
                           "parity": {"ok": ok, "proofs": checked, "source": "tests/golden/fullsize_digests.json[%s]" % fixture}}
+        # the same witnesses through the COMPILED circuit (bpr1cs_gadget_compile once, outside the clock; the witness program runs on the
+        # device, the commitments come out of the call): what a caller does that can keep a circuit handle - no host synthesis, no per-commit calls
+        circ = compiled.setdefault("c", bp.CompiledGadget(w["gadget"], w["ip"], w["sp"]))
+        cw = []
+        for rep in range(reps + 1):
+            t0 = time.perf_counter()
+            Pc, _ = bp.prove_batch(gens, circ, w["label"], v, b, s, B)
+            if rep:
+                cw.append(time.perf_counter() - t0)
+            else:
+                okc = all(hashlib.sha256(Pc[j]).hexdigest()[:32] == fx[j] for j in range(B))
+        out["b%d" % B]["compiled_circuit"] = {"ms_per_call": 1e3 * statistics.median(cw), "ms_per_proof": 1e3 * statistics.median(cw) / B, "parity_ok": okc}
         if B == 1:   # the other half of every reference test: Verifier::new -> commit(V) x m -> gadget -> verify of that ONE proof (e.g. src/gadget_vsmt_4.rs:442-479)
             vt, vok, vst = [], True, None
             for rep in range(4):
@@ -384,6 +396,8 @@ def run_latency(bp, lib, case, w, gens, fixture, batches=(1, 8, 64)):
             rejected = not bp.gadget_verify_on(gens, w["gadget"], w["ip"], w["sp"], w["label"], bytes(bad), C[0])[0]
             out["verify_b1"] = {"ms_per_call": 1e3 * statistics.median(vt), "accepted": vok, "tampered_rejected": rejected,
                                 "stage_ms": {kk: 1e3 * x for kk, x in vst.items()}}
+    if "c" in compiled:
+        compiled["c"].close()
     return out
 
 
