@@ -160,3 +160,10 @@ def test_prove_from_advanced_transcripts_on_device(hip_lib):
     """bpr1cs_prove_batch_transcripts against the oracle's prover on transcripts that already hold messages (per proof and shared)"""
     import test_hostsim as th
     th.test_prove_from_advanced_transcripts(hip_lib)
+
+
+def test_random_constraint_systems_match_oracle_on_device(hip_lib):
+    """tests/random_circuits.py on the device, every IPA round from the tables (the small-job default) and with the switch to
+    variable-base rounds after 0 and 2"""
+    import random_circuits
+    random_circuits.check(hip_lib, common, unfolds=(None, 0, 2))

@@ -363,3 +363,10 @@ def test_circuit_cache_returns_equal_descriptions_only(sim_lib):
     e = bp.Circuit(ob["n"], ob["m"], rows, lib=sim_lib)                 # rebuilt after the purge: works as before
     Pe, _ = bp.prove_batch(gens, e, ob["label"], ob["values"], ob["blindings"], ob["seeds"], 2, wires=ob["wires"])
     assert Pe == Pa
+
+
+def test_random_constraint_systems_match_oracle(sim_lib):
+    """tests/random_circuits.py: shapes the reference's gadgets never produce (a variable twice in a row, 0 and l - 1 coefficients,
+    empty rows, m = 0, n = 1, violated witnesses) - the oracle's bytes, and the device verifier's verdict = satisfiability"""
+    import random_circuits
+    random_circuits.check(sim_lib, common)
