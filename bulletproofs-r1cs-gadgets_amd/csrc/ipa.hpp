@@ -84,7 +84,7 @@ static IpaEnd enqueue_ipa(const IpaIO& io, dev_stream_t st, MsmStats* stats) {
     // closed-form factors of round k: the per-proof products (and, for blocks of >= 256 positions, their table by i >> 8), then the
     // scalars - written out (K_ipa_scalars_geo) for the small-job path, or produced by the MSM kernel at its term fetch (`fused`:
     // MsmGeo, csrc/msm_kernel.hpp) for launches of the shipped kernel, which then need no N x B scalar arrays at all
-    const bool fused = geo && B >= 32 && io.fuse_scalars;
+    const bool fused = geo && B > MSM_LANE_PATH_MAX_PROOFS && io.fuse_scalars;
     MsmGeo mg;
     auto geo_scalars = [&](uint32_t k, const sc* va, const sc* vb) {
         const uint32_t lgNk = lgN - k;
@@ -229,7 +229,7 @@ static IpaEnd enqueue_ipa(const IpaIO& io, dev_stream_t st, MsmStats* stats) {
                     fG = sGp; fH = sHp;
                 }
                 const uint32_t f_mont = geo ? 0u : 1u;
-                if (B < 32) {
+                if (B <= MSM_LANE_PATH_MAX_PROOFS) {
                     launch_wave((uint64_t)2 * M * B, K_ipa_fold_from_tables{g->tab.p, g->tc, fG, fH, GHp, B, M, N, baseG, baseH, geo ? 1u : 0u}, st);
                 } else {
                     // the folded generators through the MSM kernel: output j of a side = the "chunk" of terms i = j (mod M), two

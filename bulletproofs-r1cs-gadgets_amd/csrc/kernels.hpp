@@ -725,7 +725,7 @@ HD inline sc msm_scalar(const sc& x, uint32_t form) {
     return sc_from_mont(sc_sub(x, sc_one_mont()));
 }
 #define MSM_MAX_JOBS 4  // independent sums that may share one launch of the shipped kernel (csrc/msm_kernel.hpp)
-// Small batches (B < 32: the cross-proof batched verifier evaluates ONE combined scalar vector): a wavefront of
+// Small batches (B <= 64, MSM_LANE_PATH_MAX_PROOFS: a single proof per prove(), the cross-proof batched verifier's ONE combined scalar vector): a wavefront of
 // k_msm_fixed2 would carry B active lanes only, so here the lanes of a wave take different CHUNKS - thread
 // g = c * B + b sums chunk c for proof b; table rows differ per lane (gathers), scalar loads stay coalesced over b.
 struct K_msm_fixed_small {  // gid = c*B + b -> partial[c*B + b]

@@ -53,7 +53,11 @@ struct MsmPlan {
 
 // K_msm_finish launches: a lane per output for a batch, a wavefront per output for a job of a few proofs (k_finish_wave: the finish
 // is on the critical path of every IPA round of a single proof)
-static const uint32_t FINISH_WAVE_MAX_PROOFS = 32;
+// Jobs of up to this many proofs sum with lanes over (chunk, proof) (K_msm_fixed_small + reduction tree) instead of a wavefront per
+// (chunk, 64 proofs): the shipped kernel with one or two half-empty wavefronts per chunk takes 3.6 ms per un-folded round of the
+// depth-32 circuit whatever the batch (measured: 54.6 ms of argument for 32 proofs, 61.3 for 64, against 15.8 for 8 on the lane path).
+static const uint32_t MSM_LANE_PATH_MAX_PROOFS = 64;
+static const uint32_t FINISH_WAVE_MAX_PROOFS = 64;
 static void launch_finish(const K_msm_finish& f, uint32_t B, dev_stream_t st) {
 #if !defined(BPR1CS_HOSTSIM)
     if (B <= FINISH_WAVE_MAX_PROOFS && !f.extra_pt) {
@@ -150,7 +154,7 @@ struct MsmReq {
     const TabCfg* tc = nullptr;  // geometry of `table` (nullptr: that of the generator tables)
 };
 static void run_msm_multi(const bpr1cs_gens* g, MsmReq* reqs, uint32_t nreq, uint32_t B, dev_stream_t st, MsmStats* stats, const MsmGeo* geo = nullptr) {
-    if (B < 32) {  // a wavefront per (chunk, 64 proofs) would be mostly idle: lanes take different chunks instead
+    if (B <= MSM_LANE_PATH_MAX_PROOFS) {  // a wavefront per (chunk, 64 proofs) would be mostly idle: lanes take different chunks instead
         for (uint32_t r = 0; r < nreq; r++) {
             MsmReq& q = reqs[r];
             const uint32_t total = q.s0.count + q.s1.count;

@@ -105,7 +105,7 @@ def test_low_level_abi_transcript_and_msm(sim_lib):
 
 
 def test_shipped_msm_loop_on_70_proof_batches(sim_lib, sim_glib):
-    """Batches of >= 32 proofs go through msm_fixed2_body (csrc/msm_kernel.hpp) - the body the gfx950 kernel is built from, run
+    """Batches of more than 64 proofs go through msm_fixed2_body (csrc/msm_kernel.hpp) - the body the gfx950 kernel is built from, run
     lane by lane: polarity flips, two-layer order, digit recoding, wave votes on zero scalars, the a_O - 1 form, merged S-box
     tables, the padded round-0 terms, the folded generators as interleaved chunks - and must reproduce the C oracle's bytes for
     every one of 70 proofs (ragged: 64 + 6 lanes).  Also: ONE call cut into two device jobs (40 + 30 proofs) gives the same bytes."""
