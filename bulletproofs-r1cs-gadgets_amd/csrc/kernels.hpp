@@ -734,8 +734,8 @@ struct K_msm_fixed_small {  // gid = c*B + b -> partial[c*B + b]
     MsmSeg seg[2];
     ge* partial;
     uint32_t B, chunk, nchunks;
-    HD void operator()(uint32_t g) const {
-        uint32_t c = g / B, b = g % B;
+    // the sum of chunk c for proof b (ordinary class)
+    HD ge chunk_sum(uint32_t c, uint32_t b) const {
         uint32_t total = seg[0].count + seg[1].count;
         uint32_t lo = c * chunk, hi = lo + chunk < total ? lo + chunk : total;
         ge acc = ge_identity();
@@ -748,8 +748,9 @@ struct K_msm_fixed_small {  // gid = c*B + b -> partial[c*B + b]
             x = msm_scalar(x, s.mont);
             acc = table_mul_acc_raw(acc, tab + (size_t)base * tc.base_bytes(), x, tc);
         }
-        partial[g] = ge_from_table_class(acc);
+        return ge_from_table_class(acc);
     }
+    HD void operator()(uint32_t g) const { partial[g] = chunk_sum(g / B, g % B); }
 };
 // second-level reduction of chunk partials: out[r*B + b] = sum_{k < group} in[(r*group + k)*B + b]
 struct K_ge_reduce {  // gid = r*B + b

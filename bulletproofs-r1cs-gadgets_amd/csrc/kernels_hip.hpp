@@ -202,6 +202,21 @@ __global__ void __launch_bounds__(64) k_finish_wave(K_msm_finish fa, K_msm_finis
     if (threadIdx.x == 0) ge_compress(acc, (inst ? fb.out : fa.out) + 32 * (size_t)b);
 }
 
+// K_msm_fixed_small with the first level of its reduction tree inside the wavefront: workgroup (request r, proof b, group w) sums the
+// 64 chunks w*64 .. w*64+63 of proof b - a lane each - and folds them with the shuffle butterfly: partial[w*B + b].  One or two requests
+// per launch (L_k and R_k of an IPA round): for ONE proof a round is then a launch of 2 x nchunks/64 wavefronts and one K_ge_reduce per side
+// instead of two launches and two reduction levels each (the launches of a round are dependent and ~50 us apiece).
+__global__ void __launch_bounds__(64) k_msm_small_wave(K_msm_fixed_small fa, K_msm_fixed_small fb, uint32_t groups) {
+    const uint32_t per_req = groups * fa.B;
+    const uint32_t wg = blockIdx.x, r = wg / per_req, rest = wg % per_req, w = rest / fa.B, b = rest % fa.B;
+    const K_msm_fixed_small& f = r ? fb : fa;
+    const uint32_t c = w * 64u + threadIdx.x;
+    ge acc = c < f.nchunks ? f.chunk_sum(c, b) : ge_identity();
+#pragma unroll 1
+    for (int sft = 32; sft > 0; sft >>= 1) acc = ge_add_ge(acc, ge_shfl_xor(acc, sft));
+    if (threadIdx.x == 0) f.partial[(size_t)w * f.B + b] = acc;
+}
+
 // ---------------------------------------------------------------- TranscriptRng stream
 // The 2n+8 blinding draws of a proof are a strictly sequential chain of Keccak-f[1600]
 // permutations (STROBE prf, one permutation per 64-byte draw: SURVEY §8a P6), 37k of them for

@@ -58,6 +58,7 @@ struct MsmPlan {
 // depth-32 circuit whatever the batch (measured: 54.6 ms of argument for 32 proofs, 61.3 for 64, against 15.8 for 8 on the lane path).
 static const uint32_t MSM_LANE_PATH_MAX_PROOFS = 64;
 static const uint32_t FINISH_WAVE_MAX_PROOFS = 64;
+static const uint32_t MSM_WAVE_REDUCE_MAX_CHUNK = 2;    // k_msm_small_wave (first reduction level inside the wavefront) while a lane sums at most this many terms (see run_msm_multi)
 static void launch_finish(const K_msm_finish& f, uint32_t B, dev_stream_t st) {
 #if !defined(BPR1CS_HOSTSIM)
     if (B <= FINISH_WAVE_MAX_PROOFS && !f.extra_pt) {
@@ -155,32 +156,68 @@ struct MsmReq {
 };
 static void run_msm_multi(const bpr1cs_gens* g, MsmReq* reqs, uint32_t nreq, uint32_t B, dev_stream_t st, MsmStats* stats, const MsmGeo* geo = nullptr) {
     if (B <= MSM_LANE_PATH_MAX_PROOFS) {  // a wavefront per (chunk, 64 proofs) would be mostly idle: lanes take different chunks instead
+        // the chunk sums are folded until at most MSM_REDUCE_GROUP are left for the per-proof finish kernel: 64 at a time inside the
+        // wavefronts that computed them (k_msm_small_wave), then MSM_REDUCE_GROUP at a time (K_ge_reduce) - with ONE proof a 65 536-term
+        // sum is 65 536 chunks (one term per lane) -> 1024 -> 64 -> 4
+        struct Small { K_msm_fixed_small f; uint32_t nchunks, groups; ge* first; size_t first_off; uint32_t lv[8], nl; bool in_wave; };
+        Small sm[MSM_MAX_JOBS];
         for (uint32_t r = 0; r < nreq; r++) {
             MsmReq& q = reqs[r];
             const uint32_t total = q.s0.count + q.s1.count;
-            const uint32_t nchunks = pick_chunks(total, B, 1u << 18, q.plan->chunk);
-            // the chunk sums are folded MSM_REDUCE_GROUP at a time until at most that many are left for the per-proof finish kernel:
-            // with ONE proof a 65 536-term sum is 65 536 chunks (one term per thread) -> 4096 -> 256 -> 16
-            uint32_t lv[8], nl = 0, cnt = nchunks;
-            size_t need = nchunks;
-            while (cnt > MSM_REDUCE_GROUP && nl < 8) { cnt = (cnt + MSM_REDUCE_GROUP - 1) / MSM_REDUCE_GROUP; lv[nl++] = cnt; need += cnt; }
+            Small& S = sm[r];
+            S.nchunks = pick_chunks(total, B, 1u << 18, q.plan->chunk);
+#if defined(BPR1CS_HOSTSIM)
+            const bool in_wave = false;      // (the simulator has no wavefronts: the functor writes one sum per chunk)
+#else
+            // a wavefront per 64 chunks of ONE proof gives up what the lane-per-(chunk, proof) order has for a batch - 64 proofs reading
+            // the same table rows and consecutive scalars - which only matters when a lane walks several terms: taken while a chunk is
+            // one or two terms (measured: depth-32 circuit's argument, 1 proof 11.1 -> 8.8 ms, 8 proofs (2 terms per lane) 15.8 -> 16.0,
+            // 64 proofs (16 terms per lane) 61 -> 135; the 64-bit bound check, one term per lane at every batch: 1 / 8 / 64 proofs
+            // 6.0 / 5.9 / 7.1 -> 4.9 / 5.1 / 6.0 ms per call)
+            const bool in_wave = q.plan->chunk <= MSM_WAVE_REDUCE_MAX_CHUNK;
+#endif
+            S.in_wave = in_wave;
+            S.groups = in_wave ? (S.nchunks + 63u) / 64u : S.nchunks;
+            uint32_t cnt = S.groups;
+            size_t need = S.groups;
+            S.nl = 0;
+            while (cnt > MSM_REDUCE_GROUP && S.nl < 8) { cnt = (cnt + MSM_REDUCE_GROUP - 1) / MSM_REDUCE_GROUP; S.lv[S.nl++] = cnt; need += cnt; }
             need *= B;
             if (q.partial->n < need) q.partial->alloc(need);
-            // layout: [last level][...][first level][raw]
+            // layout: [last level][...][first level][wave sums]
             size_t off = 0;
-            for (uint32_t t = 0; t < nl; t++) off += lv[t];
-            ge* raw = q.partial->p + off * B;
-            launch_wave((uint64_t)nchunks * B, K_msm_fixed_small{q.table ? q.table : g->tab.p, q.tc ? *q.tc : g->tc, {q.s0, q.s1}, raw, B, q.plan->chunk, nchunks}, st);
-            const ge* in = raw;
-            uint32_t in_cnt = nchunks;
-            for (uint32_t t = 0; t < nl; t++) {
-                off -= lv[t];
+            for (uint32_t t = 0; t < S.nl; t++) off += S.lv[t];
+            S.first_off = off;
+            S.first = q.partial->p + off * B;
+            S.f = K_msm_fixed_small{q.table ? q.table : g->tab.p, q.tc ? *q.tc : g->tc, {q.s0, q.s1}, S.first, B, q.plan->chunk, S.nchunks};
+            if (stats) { stats->launches++; stats->terms += (uint64_t)total * B; stats->adds += (uint64_t)total * B * (q.tc ? q.tc->windows : g->tc.windows); }
+        }
+#if defined(BPR1CS_HOSTSIM)
+        for (uint32_t r = 0; r < nreq; r++) launch_wave((uint64_t)sm[r].nchunks * B, sm[r].f, st);
+#else
+        for (uint32_t r = 0; r < nreq;) {   // two requests of the same shape (L_k, R_k) share a launch; an empty request launches nothing
+            if (sm[r].groups == 0) { r++; continue; }
+            if (!sm[r].in_wave) { launch_wave((uint64_t)sm[r].nchunks * B, sm[r].f, st); r++; continue; }
+            const bool pair = r + 1 < nreq && sm[r + 1].in_wave && sm[r + 1].groups == sm[r].groups;
+            const uint32_t wgs = (pair ? 2u : 1u) * sm[r].groups * B;
+            hipLaunchKernelGGL(k_msm_small_wave, dim3(wgs), dim3(64), 0, st, sm[r].f, sm[pair ? r + 1 : r].f, sm[r].groups);
+            HIPCHK(hipGetLastError());
+            r += pair ? 2 : 1;
+        }
+#endif
+        for (uint32_t r = 0; r < nreq; r++) {
+            Small& S = sm[r];
+            MsmReq& q = reqs[r];
+            const ge* in = S.first;
+            uint32_t in_cnt = S.groups;
+            size_t off = S.first_off;
+            for (uint32_t t = 0; t < S.nl; t++) {
+                off -= S.lv[t];
                 ge* out = q.partial->p + off * B;
-                launch((uint64_t)lv[t] * B, K_ge_reduce{in, out, B, in_cnt, MSM_REDUCE_GROUP}, st);
-                in = out; in_cnt = lv[t];
+                launch((uint64_t)S.lv[t] * B, K_ge_reduce{in, out, B, in_cnt, MSM_REDUCE_GROUP}, st);
+                in = out; in_cnt = S.lv[t];
             }
             q.plan->nchunks = in_cnt;
-            if (stats) { stats->launches++; stats->terms += (uint64_t)total * B; stats->adds += (uint64_t)total * B * (q.tc ? q.tc->windows : g->tc.windows); }
         }
         return;
     }
