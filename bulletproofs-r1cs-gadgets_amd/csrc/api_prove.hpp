@@ -228,7 +228,7 @@ static int prove_job_begin(const bpr1cs_gens* g, const bpr1cs_circuit* c, const 
     dev_event_record(job->ev_in, sl);
 #if defined(BPR1CS_HOSTSIM)
     (void)o_team;
-    launch(B, K_transcript_init{d_init.p, init_stride, Vcomp.p, vbl_raw.p, d_seeds.p, tr.p, blind.p, sL, sR, nullptr, B, m, n}, st);
+    launch_transcript(B, K_transcript_init{d_init.p, init_stride, Vcomp.p, vbl_raw.p, d_seeds.p, tr.p, blind.p, sL, sR, nullptr, B, m, n}, st);
     DevBuf<int> rng_err(1);
     dev_zero(rng_err.p, sizeof(int), sl);
 #else
@@ -237,7 +237,7 @@ static int prove_job_begin(const bpr1cs_gens* g, const bpr1cs_circuit* c, const 
     DevBuf<strobe> rng(B);
     DevBuf<int> rng_err(1);
     dev_zero(rng_err.p, sizeof(int), sl);
-    launch(B, K_transcript_init{d_init.p, init_stride, Vcomp.p, vbl_raw.p, d_seeds.p, tr.p, blind.p, sL, sR, rng.p, B, m, n}, sl);
+    launch_transcript(B, K_transcript_init{d_init.p, init_stride, Vcomp.p, vbl_raw.p, d_seeds.p, tr.p, blind.p, sL, sR, rng.p, B, m, n}, sl);
     if (shared) dev_stream_wait(sl, g->rng_free_ev);   // the job before has reduced (and wiped) its raw output
     hipLaunchKernelGGL(k_rng_stream, dim3((B + 1) / 2), dim3(64), 0, sl, rng.p, rng_raw.p, rng_err.p, B, draws);
     HIPCHK(hipGetLastError());
@@ -371,7 +371,7 @@ static int prove_job_begin(const bpr1cs_gens* g, const bpr1cs_circuit* c, const 
     pt.mark(st);
 
     // ---- P3/P4: challenges, flatten, t(x), T commitments, l(x), r(x)
-    launch(B, K_transcript_A{tr.p, AOS.p, chal.p, B}, st);
+    launch_transcript(B, K_transcript_A{tr.p, AOS.p, chal.p, B}, st);
     uint32_t maxe = std::max<uint32_t>(N, c->q + 1);
     uint32_t H = (maxe >> 8) + 1;
     DevBuf<sc> plo((size_t)3 * 256 * B), phi((size_t)3 * H * B);
@@ -404,7 +404,7 @@ static int prove_job_begin(const bpr1cs_gens* g, const bpr1cs_circuit* c, const 
     launch((uint64_t)TC * B, K_tcoef_partial{W.p, wvec.p, plo.p, phi.p, tpart.p, B, H, n, tchunk, TC}, st);
     launch((uint64_t)6 * B, K_sum_partials{tpart.p, tco.p, B, TC}, st);
     launch((uint64_t)5 * B, K_commit_T{g->tab.p, g->tc, tco.p, blind.p, Tc.p, B}, st);
-    launch(B, K_transcript_T{tr.p, Tc.p, tco.p, blind.p, wvec.p + (size_t)3 * n * B, vbl_m.p, chal.p, txs.p, B, m, (uint64_t)N}, st);
+    launch_transcript(B, K_transcript_T{tr.p, Tc.p, tco.p, blind.p, wvec.p + (size_t)3 * n * B, vbl_m.p, chal.p, txs.p, B, m, (uint64_t)N}, st);
     DevBuf<sc> a((size_t)N * B), bb((size_t)N * B);
     launch((uint64_t)N * B, K_lr_eval{W.p, wvec.p, plo.p, phi.p, chal.p, a.p, bb.p, cG.p, cH.p, B, H, n}, st);
     // the wires and blinding vectors are dead: wiped here (upstream: clear_on_drop), and the next job in flight may write its own

@@ -33,7 +33,7 @@ static void verify_front(VerifyCtx& v, const bpr1cs_gens* g, const bpr1cs_circui
     dev_zero(v.fail.p, sizeof(int) * B, st);
     K_verify_transcript kt{v.d_label.p, (uint32_t)label_len, v.d_pf.p, v.d_vc.p, v.d_seed.p, v.chal.p, v.uk.p, v.fail.p, B, m, lgN, (uint32_t)v.plen, (uint64_t)N};
     if (want_bind) { v.bind.alloc((size_t)B * 32); kt.bind = v.bind.p; }
-    launch(B, kt, st);
+    launch_transcript(B, kt, st);
     uint32_t maxe = std::max<uint32_t>(N, c->q + 1);
     v.H = (maxe >> 8) + 1;
     v.plo.alloc((size_t)3 * 256 * B); v.phi.alloc((size_t)3 * v.H * B);

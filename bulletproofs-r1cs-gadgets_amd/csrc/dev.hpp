@@ -61,6 +61,8 @@ inline void launch(uint64_t n, const F& f, dev_stream_t) {
 }
 template <class F>
 inline void launch_wave(uint64_t n, const F& f, dev_stream_t s) { launch(n, f, s); }
+template <class F>
+inline void launch_transcript(uint64_t n, const F& f, dev_stream_t s) { launch(n, f, s); }
 #else
 #include <hip/hip_runtime.h>
 typedef hipStream_t dev_stream_t;
@@ -227,6 +229,27 @@ inline void launch_wave(uint64_t n, const F& f, dev_stream_t s) {
     static const bool dbg = getenv("BPR1CS_DEBUG_SYNC") != nullptr;
     if (dbg) {
         fprintf(stderr, "bpr1cs: launched (wave) %s n=%llu\n", typeid(F).name(), (unsigned long long)n);
+        HIPCHK(hipStreamSynchronize(s));
+    }
+}
+// Transcript kernels of a handful of proofs: one 32-lane workgroup per transcript, every lane running the functor for the SAME
+// proof (identical loads, identical stores) so that the permutations inside - the whole cost of such a kernel - can be split
+// over the lanes (merlin.hpp keccak_f1600_lockstep, keyed on this workgroup size).  Only for functors whose stores are
+// idempotent; above LOCKSTEP_MAX_PROOFS the lanes are worth more as separate proofs.
+constexpr uint64_t LOCKSTEP_MAX_PROOFS = 16;
+template <class F>
+__global__ void __launch_bounds__(32) k_functor_lockstep(F f, uint32_t n) {
+    if (blockIdx.x < n) INLINE_CALL f(blockIdx.x);
+}
+template <class F>
+inline void launch_transcript(uint64_t n, const F& f, dev_stream_t s) {
+    if (n == 0) return;
+    if (n > LOCKSTEP_MAX_PROOFS) { launch(n, f, s); return; }
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_functor_lockstep<F>), dim3((uint32_t)n), dim3(32), 0, s, f, (uint32_t)n);
+    HIPCHK(hipGetLastError());
+    static const bool dbg = getenv("BPR1CS_DEBUG_SYNC") != nullptr;
+    if (dbg) {
+        fprintf(stderr, "bpr1cs: launched (lockstep) %s n=%llu\n", typeid(F).name(), (unsigned long long)n);
         HIPCHK(hipStreamSynchronize(s));
     }
 }

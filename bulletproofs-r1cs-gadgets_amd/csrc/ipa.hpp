@@ -275,7 +275,7 @@ static IpaEnd enqueue_ipa(const IpaIO& io, dev_stream_t st, MsmStats* stats) {
             launch_finish_pair(finisher(voutp, 1, crossp, Lout), finisher(voutp + (size_t)B, 1, crossp + B, Rout), B, st);
         }
         sc* ukk = io.uk + (size_t)k * 2 * B;
-        emit(B, K_transcript_LR{io.tr, Lout, ukk, B}, false);
+        launch_transcript(B, K_transcript_LR{io.tr, Lout, ukk, B}, st);
         emit((uint64_t)mk * B, K_ipa_fold_ab{a, bb, ukk, B, mk}, false);
         if (k + 1 == r && !geo) launch((uint64_t)N * B, K_ipa_update_c{cG, cH, ukk, B, Nk}, st);   // (earlier rounds: inside the next K_ipa_scalars)
         else if (k < r) {}

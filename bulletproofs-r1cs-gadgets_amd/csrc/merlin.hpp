@@ -19,7 +19,55 @@ HD_CONST uint64_t KECCAK_RC[24] = {
 
 HD inline uint64_t rol64(uint64_t x, int n) { return (x << n) | (x >> (64 - n)); }
 
+#if defined(__HIP_DEVICE_COMPILE__)
+// Lockstep launches (dev.hpp launch_lockstep): the 32 lanes of a one-wave workgroup run the SAME transcript, every lane
+// holding the whole state; only the permutation is split - lane j carries word j through the 24 rounds (the lane mapping of
+// k_rng_stream: column parities by LDS atomics, pi as an LDS gather) and the words are handed back to every lane at the end.
+// A single transcript is a chain of permutations nothing else can overlap with: ~2.7 us each this way instead of ~25 us on
+// one lane.  A 32-thread workgroup IS the marker of such a launch - no other kernel of the library uses that size.
+__device__ inline bool keccak_lockstep_launch() { return blockDim.x == 32u; }
+__device__ inline void keccak_f1600_lockstep(uint64_t* s) {
+    __shared__ uint64_t xch[32];
+    __shared__ uint64_t colp[8];
+#define KL_HANDOFF() do { __atomic_signal_fence(__ATOMIC_SEQ_CST); __builtin_amdgcn_wave_barrier(); __atomic_signal_fence(__ATOMIC_SEQ_CST); } while (0)
+    const uint32_t i = threadIdx.x, j = i % 25u, x = j % 5u, y = j / 5u;
+    uint64_t a = s[j];
+    const int ROT[25] = {0, 1, 62, 28, 27, 36, 44, 6, 55, 20, 3, 10, 43, 25, 39, 41, 45, 15, 21, 8, 18, 2, 61, 56, 14};  // [x + 5y]
+    const int rot = ROT[j];
+    const uint32_t xm = (x + 4u) % 5u, xp = (x + 1u) % 5u;
+    const uint32_t s0 = (x + 3u * y) % 5u + 5u * x;            // chi operands from the pre-pi lanes: B[X][Y] = rot(A)[(X + 3Y) % 5 + 5X]
+    const uint32_t x1 = (x + 1u) % 5u, x2 = (x + 2u) % 5u;
+    const uint32_t s1 = (x1 + 3u * y) % 5u + 5u * x1, s2 = (x2 + 3u * y) % 5u + 5u * x2;
+    const bool real = i < 25u;                                   // lanes 25..31 mirror lanes 0..6
+    if (i < 8u) colp[i] = 0;
+    KL_HANDOFF();
+    for (int r = 0; r < 24; r++) {
+        if (real) __hip_atomic_fetch_xor(&colp[x], a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        KL_HANDOFF();   // one wavefront: its LDS operations execute in issue order
+        uint64_t m = colp[xm], p = colp[xp];
+        KL_HANDOFF();
+        if (y == 0u) colp[x] = 0;
+        uint64_t t = a ^ m ^ ((p << 1) | (p >> 63));             // theta
+        uint64_t n = rot ? ((t << rot) | (t >> (64 - rot))) : t;  // rho
+        xch[i] = n;
+        KL_HANDOFF();
+        uint64_t b0 = xch[s0], b1 = xch[s1], b2 = xch[s2];       // pi
+        a = b0 ^ (~b1 & b2);                                     // chi
+        if (j == 0u) a ^= KECCAK_RC[r];                          // iota
+        KL_HANDOFF();
+    }
+    xch[i] = a;                                                  // (lanes 25..31 write their mirrors' values to slots nobody reads)
+    KL_HANDOFF();
+    for (int k = 0; k < 25; k++) s[k] = xch[k];
+    KL_HANDOFF();
+#undef KL_HANDOFF
+}
+#endif
+
 HD inline void keccak_f1600(uint64_t* s) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (keccak_lockstep_launch()) { keccak_f1600_lockstep(s); return; }
+#endif
     uint64_t a00 = s[0], a01 = s[1], a02 = s[2], a03 = s[3], a04 = s[4];
     uint64_t a05 = s[5], a06 = s[6], a07 = s[7], a08 = s[8], a09 = s[9];
     uint64_t a10 = s[10], a11 = s[11], a12 = s[12], a13 = s[13], a14 = s[14];
@@ -82,23 +130,55 @@ HD inline void strobe_run_f(strobe& s) {
     s.pos = 0;
     s.pos_begin = 0;
 }
+// The three duplex operations work a state WORD at a time: the bytes that fall into one 64-bit word of the rate are collected
+// first and the word is touched once.  (The state is indexed by a run-time position, so it lives in private memory: a read-modify-
+// write per byte was a dependent round trip to it per byte - the larger part of a transcript kernel's time.)
 HD inline void strobe_absorb(strobe& s, const uint8_t* d, uint32_t n) {
-    for (uint32_t i = 0; i < n; i++) {
-        strobe_xor_byte(s, s.pos, d[i]);
-        if (++s.pos == STROBE_R) strobe_run_f(s);
+    uint32_t i = 0;
+    while (i < n) {
+        const uint32_t w = s.pos >> 3;
+        uint32_t sh = 8 * (s.pos & 7);
+        uint64_t acc = 0;
+        do {
+            acc |= (uint64_t)d[i++] << sh;
+            sh += 8;
+            s.pos++;
+        } while (i < n && sh < 64 && s.pos != STROBE_R);
+        s.st[w] ^= acc;
+        if (s.pos == STROBE_R) strobe_run_f(s);
     }
 }
 HD inline void strobe_overwrite(strobe& s, const uint8_t* d, uint32_t n) {
-    for (uint32_t i = 0; i < n; i++) {
-        strobe_set_byte(s, s.pos, d[i]);
-        if (++s.pos == STROBE_R) strobe_run_f(s);
+    uint32_t i = 0;
+    while (i < n) {
+        const uint32_t w = s.pos >> 3;
+        uint32_t sh = 8 * (s.pos & 7);
+        uint64_t acc = 0, mask = 0;
+        do {
+            acc |= (uint64_t)d[i++] << sh;
+            mask |= 0xffull << sh;
+            sh += 8;
+            s.pos++;
+        } while (i < n && sh < 64 && s.pos != STROBE_R);
+        s.st[w] = (s.st[w] & ~mask) | acc;
+        if (s.pos == STROBE_R) strobe_run_f(s);
     }
 }
 HD inline void strobe_squeeze(strobe& s, uint8_t* d, uint32_t n) {
-    for (uint32_t i = 0; i < n; i++) {
-        d[i] = strobe_get_byte(s, s.pos);
-        strobe_set_byte(s, s.pos, 0);
-        if (++s.pos == STROBE_R) strobe_run_f(s);
+    uint32_t i = 0;
+    while (i < n) {
+        const uint32_t w = s.pos >> 3;
+        uint32_t sh = 8 * (s.pos & 7);
+        const uint64_t word = s.st[w];
+        uint64_t mask = 0;
+        do {
+            d[i++] = (uint8_t)(word >> sh);
+            mask |= 0xffull << sh;
+            sh += 8;
+            s.pos++;
+        } while (i < n && sh < 64 && s.pos != STROBE_R);
+        s.st[w] = word & ~mask;
+        if (s.pos == STROBE_R) strobe_run_f(s);
     }
 }
 HD inline void strobe_begin_op(strobe& s, uint32_t flags, int more) {

@@ -32,7 +32,7 @@ def kernels():
         names = sorted(set(l.split()[-1] for l in syms.split("\n") if " FUNC " in l))
         out = {}
         for name in names:
-            if not any(k in name for k in ("k_msm_fixed2", "k_rng_stream", "k_witness_team", "k_pip_buckets")):
+            if not any(k in name for k in ("k_msm_fixed2", "k_rng_stream", "k_witness_team", "k_pip_buckets", "k_functor_lockstep")):
                 continue
             blk = next((e for e in notes.split("\n  - ") if (".name:           " + name + "\n") in e + "\n"), "")
             meta = {k: int(v) for k, v in re.findall(r"\.(vgpr_count|sgpr_count|private_segment_fixed_size|group_segment_fixed_size):\s+(\d+)", blk)}
@@ -111,3 +111,15 @@ def test_witness_and_bucket_kernels_fit(kernels):
     meta, ins = kernels[name]
     assert 65536 <= meta["group_segment_fixed_size"] <= 81920, "512 buckets of a window live in LDS, two workgroups per CU"
     assert meta["vgpr_count"] <= 256
+
+
+def test_lockstep_transcript_kernels_split_the_permutation(kernels):
+    """the transcript kernels of a handful of proofs (dev.hpp launch_transcript): one 32-lane workgroup per transcript, the permutation
+    on the lanes - the LDS-atomic parity step must be in every one of them, and a 32-lane workgroup is what selects it"""
+    names = pick(kernels, "k_functor_lockstep")
+    assert len(names) >= 5, names  # init, A, T, LR of the prover; the verifier's replay
+    for name in names:
+        meta, ins = kernels[name]
+        c = collections.Counter(t.split()[0] for _, _, t in ins)
+        assert c["ds_xor_b64"] >= 1, "%s: no lockstep permutation" % name
+        assert 0 < meta["group_segment_fixed_size"] <= 16384  # the exchange buffers, plus whatever private arrays the compiler moved to LDS
