@@ -167,3 +167,21 @@ def test_random_constraint_systems_match_oracle_on_device(hip_lib):
     variable-base rounds after 0 and 2"""
     import random_circuits
     random_circuits.check(hip_lib, common, unfolds=(None, 0, 2))
+
+
+@pytest.mark.parametrize("batch", [16, 17])
+def test_transcript_launch_boundary(hip_lib, batch):
+    """Both sides of LOCKSTEP_MAX_PROOFS (csrc/dev.hpp launch_transcript): up to 16 proofs a transcript kernel runs one 32-lane
+    workgroup per transcript with the permutation split over the lanes (merlin.hpp keccak_f1600_lockstep), from 17 on a lane per
+    proof.  Prover: the oracle's bytes either way; verifier (its transcript kernels take the same launch): accepts them, names the
+    tampered proof."""
+    bp = common.bp
+    ob, P, C = common.check_against_oracle(hip_lib, lambda j: S.bound_check(37 + (j % 60), 10, 100, 7), 16, batch, 3)
+    gens = bp.Gens(16, lib=hip_lib)
+    circ = common.circuit_from_oracle(ob, hip_lib)
+    assert bp.verify_batch(gens, circ, ob["label"], P, C, batch) == [True] * batch
+    bad = list(P)
+    k = batch - 1
+    bad[k] = bad[k][:77] + bytes([bad[k][77] ^ 4]) + bad[k][78:]
+    got = bp.verify_batch(gens, circ, ob["label"], bad, C, batch)
+    assert got == [True] * k + [False]
