@@ -340,7 +340,10 @@ LATENCY_SHAPE = ("the reference's own call shape - ONE proof per prove() inside 
                  "gadget_bound_check.rs:49-87, gadget_poseidon.rs:734-747): Prover::new -> commit x m -> gadget synthesis on the host -> prove(), on "
                  "generators created once outside the bracket (:386-387).  = bpr1cs_gadget_prove_on: per commit one bpr1cs_msm_fixed call, then CSR "
                  "export + bpr1cs_circuit_create (cached per description) + bpr1cs_prove_batch_transcripts(batch, HOST wires) - exactly what "
-                 "tools/rust_shim/prover.rs does for batch 1; batch 8 / 64 = that many host syntheses, ONE device call.  verify_b1 = the verifier half, "
+                 "tools/rust_shim/prover.rs does for batch 1; from the second proof of a statement on, the proof's TranscriptRng chain is started at the "
+                 "gadget's first multiplier with the n of the proof before (bpr1cs_prove_prefetch; calls_with_chain_started_ahead) and runs next to the host "
+                 "synthesis - every call computes its own chain, nothing is kept between calls but that n; first_call_ms = the call without it; "
+                 "batch 8 / 64 = that many host syntheses, ONE device call.  verify_b1 = the verifier half, "
                  "bpr1cs_gadget_verify_on: Verifier::new -> commit(V) x m -> gadget -> verify of one proof")
 
 
@@ -353,24 +356,31 @@ def run_latency(bp, lib, case, w, gens, fixture, batches=(1, 8, 64)):
     for B in batches:
         v, b, s = w["values"][:B * m * 32], w["blindings"][:B * m * 32], w["seeds"][:B * 32]
         reps = 5 if B == 1 else (3 if B <= 8 else 2)
-        walls, stages, phases, ok, checked = [], [], [], True, 0
+        walls, stages, phases, ok, checked, ahead, first_ms = [], [], [], True, 0, 0, None
         for rep in range(reps + 1):
             t0 = time.perf_counter()
             P, C, sec = bp.gadget_prove_on(gens, w["gadget"], w["ip"], w["sp"], w["label"], v, b, m, B, s)
             wall = time.perf_counter() - t0
-            if rep == 0:   # (first call of a shape: arenas, the circuit cache)
+            if rep == 0:   # (first call of a shape: arenas, the circuit cache, no n of an earlier proof for the chain to start ahead with)
                 ok = all(hashlib.sha256(P[j]).hexdigest()[:32] == fx[j] for j in range(B))
                 checked = B
+                first_ms = 1e3 * wall
                 continue
+            ok = ok and all(hashlib.sha256(P[j]).hexdigest()[:32] == fx[j] for j in range(B))
             walls.append(wall)
             stages.append(sec)
-            phases.append(bp.last_prove_stats(lib)["phase_ms"])
+            st = bp.last_prove_stats(lib)
+            phases.append(st["phase_ms"])
+            ahead += st["chains_ahead"]
         med = statistics.median(walls)
         k = walls.index(sorted(walls)[len(walls) // 2])
         out["b%d" % B] = {"ms_per_call": 1e3 * med, "ms_per_proof": 1e3 * med / B, "calls_timed": reps, "ms_per_call_min": 1e3 * min(walls),
                           "stage_ms": {kk: 1e3 * x for kk, x in stages[k].items()},
                           "device_phase_ms": dict(zip(["total", "inputs+commitV", "rng||witness", "commit_msm", "poly", "ipa"], phases[k])),
-                          "parity": {"ok": ok, "proofs": checked, "source": "tests/golden/fullsize_digests.json[%s]" % fixture}}
+                          "parity": {"ok": ok, "proofs": checked, "calls_checked": reps + 1, "source": "tests/golden/fullsize_digests.json[%s]" % fixture}}
+        if B == 1:
+            out["b1"]["first_call_ms"] = first_ms
+            out["b1"]["calls_with_chain_started_ahead"] = ahead
         # the same witnesses through the COMPILED circuit (bpr1cs_gadget_compile once, outside the clock; the witness program runs on the
         # device, the commitments come out of the call): what a caller does that can keep a circuit handle - no host synthesis, no per-commit calls
         circ = compiled.setdefault("c", bp.CompiledGadget(w["gadget"], w["ip"], w["sp"]))

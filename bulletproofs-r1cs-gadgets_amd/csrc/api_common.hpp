@@ -128,6 +128,25 @@ struct bpr1cs_transcript {  // merlin::Transcript (host side)
     strobe s;
 };
 
+// The TranscriptRng chain of ONE proof started ahead of its prove call (bpr1cs_prove_prefetch): everything the chain depends on -
+// the transcript, the committed values' blindings, the 32 bytes of outside randomness - is known once the commitments are made,
+// before the gadget is synthesised on the host; its length (2n + 7 draws) is the caller's guess.  The prove call that follows on
+// the handle takes the raw draws if it presents the same inputs and the same n, and ignores them otherwise.
+struct RngPrefetch {
+    strobe init{};
+    std::vector<uint8_t> values, blindings;   // m x 32 each, as presented
+    uint8_t seed[32] = {0};
+    uint32_t n = 0, m = 0;
+    DevBuf<sc> v_raw, vbl_raw, blind;
+    DevBuf<uint8_t> seeds, Vcomp;
+    DevBuf<strobe> init_d, tr, rng;
+    DevBuf<uint64_t> rng_raw;                  // [2n + 7][8]
+    DevBuf<int> err;
+    dev_event_t done{};
+    bool have_event = false;
+    dev_stream_t st{};
+};
+
 struct bpr1cs_gens {
     uint32_t cap = 0;
     TabCfg tc{};             // fixed-base table geometry (window bits chosen at creation)
@@ -155,6 +174,11 @@ struct bpr1cs_gens {
     // out-of-memory fallback): a job size remembered for (circuit, handle) under an older value is computed afresh
     mutable std::atomic<uint32_t> sizing_epoch{1};
     mutable BpOpts opts;
+    // pinned host block of the one-commitment call (bpr1cs_msm_fixed, batch 1, bases (B, B~)): [0, 64) value and blinding as the
+    // kernel reads them, [64, 96) the compressed point as the kernel writes it; created at the first such call
+    mutable uint8_t* commit_pin = nullptr;
+    mutable RngPrefetch* prefetch = nullptr;   // at most one chain running ahead (bpr1cs_prove_prefetch); taken or dropped by the next prove job
+    mutable std::vector<RngPrefetch*> parked;  // chains no job took and that were still running when their job ended: freed once they have finished
 };
 
 struct bpr1cs_circuit {

@@ -192,6 +192,25 @@ extern "C" int bpr1cs_msm_fixed(const bpr1cs_gens* g, const uint32_t* bases, siz
     if (terms == 2 && bases[0] == 0 && bases[1] == 1) {
         // pc_gens.commit(v, blinding) = v*B + blinding*B_blinding - what Prover::commit calls once per committed value (reference
         // src/gadget_vsmt_4.rs:393-410: 100 calls for one depth-32 proof): one upload, ONE kernel (the prover's own K_commit_v), one read-back
+#if !defined(BPR1CS_HOSTSIM)
+        if (B == 1) {
+            // ONE commitment per call - the reference's own shape (100 calls in a row for a depth-32 proof, each result needed at
+            // once): value and blinding are read by the kernel from a pinned host block of the handle and the 32 bytes written
+            // back into it - a launch and a stream synchronisation per call instead of upload + launch + wipe + read-back
+            // (DESIGN 5.38); the block is zeroed before the call returns.
+            static_assert(sizeof(sc) == 32, "two scalars in 64 bytes");
+            if (!g->commit_pin) g->commit_pin = (uint8_t*)host_stage_alloc(96);
+            sc* pin = (sc*)g->commit_pin;
+            struct PinWipe { uint8_t* p; ~PinWipe() { memset(p, 0, 64); } } wipe{g->commit_pin};   // value and blinding are secrets: zeroed on every way out
+            pin[0] = sc_load_raw(scalars);
+            pin[1] = sc_load_raw(scalars + 32);
+            hipLaunchKernelGGL(k_commit_wave, dim3(1), dim3(64), 0, st, (const uint8_t*)g->tab.p, g->tc, (const sc*)pin, (const sc*)(pin + 1), g->commit_pin + 64, 1u, 1u);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipStreamSynchronize(st));
+            memcpy(out, g->commit_pin + 64, 32);
+            return BPR1CS_OK;
+        }
+#endif
         std::vector<sc> h((size_t)2 * B);
         for (uint32_t b = 0; b < B; b++) { h[b] = sc_load_raw(scalars + 64 * (size_t)b); h[(size_t)B + b] = sc_load_raw(scalars + 64 * (size_t)b + 32); }
         DevBuf<sc> d((size_t)2 * B);

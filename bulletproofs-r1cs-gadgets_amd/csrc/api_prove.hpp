@@ -17,6 +17,8 @@ struct bpr1cs_job {
     int slot = -1;                // the handle's job slot it holds (released with the job)
     IpaIO::TailKeep tail;         // the IPA tail's own buffers (outside the handle's shared arena)
     dev_event_t ev_in{}, ev_rng{}, ev_wit{}, ev_done{}, ev_tail{};
+    RngPrefetch* prefetch = nullptr;   // the chain that ran ahead of this job (taken or not): released with the job
+    bool prefetch_taken = false;
 };
 // pinned staging buffers are cached: hipHostFree (like hipFree) synchronises the whole device, which
 // would serialise the in-flight jobs
@@ -68,6 +70,29 @@ static double dbg_ms() {
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
 }
 #define DBG_JOB(...) do { if (dbg_jobs()) { fprintf(stderr, "bpr1cs[%9.2f ms] ", dbg_ms()); fprintf(stderr, __VA_ARGS__); fputc('\n', stderr); } } while (0)
+// A chain that ran ahead: wait for it, wipe what it produced (raw blinding material, the blindings it was given) and free it.
+static void prefetch_free(RngPrefetch* pf) {
+    if (!pf) return;
+#if !defined(BPR1CS_HOSTSIM)
+    if (pf->st) {
+        (void)hipStreamSynchronize(pf->st);
+        try {
+            if (pf->rng_raw.p) dev_zero(pf->rng_raw.p, pf->rng_raw.bytes(), pf->st);
+            if (pf->rng.p) dev_zero(pf->rng.p, pf->rng.bytes(), pf->st);
+            if (pf->blind.p) dev_zero(pf->blind.p, pf->blind.bytes(), pf->st);
+            if (pf->v_raw.p) dev_zero(pf->v_raw.p, pf->v_raw.bytes(), pf->st);
+            if (pf->vbl_raw.p) dev_zero(pf->vbl_raw.p, pf->vbl_raw.bytes(), pf->st);
+            if (pf->seeds.p) dev_zero(pf->seeds.p, pf->seeds.bytes(), pf->st);
+            dev_sync(pf->st);
+        } catch (...) {}
+    }
+#endif
+    if (pf->have_event) dev_event_destroy(&pf->done);
+    if (!pf->values.empty()) memset(pf->values.data(), 0, pf->values.size());
+    if (!pf->blindings.empty()) memset(pf->blindings.data(), 0, pf->blindings.size());
+    memset(pf->seed, 0, 32);
+    delete pf;
+}
 // wait for everything a job has enqueued and release what it holds (normal end and error paths)
 static void job_wait(bpr1cs_job* job) {
     if (!job) return;
@@ -91,6 +116,16 @@ static void job_release(bpr1cs_job* job) {
     for (auto e : evs) dev_event_destroy(e);
     for (void* p : job->deferred) dev_free_now(p);
     job->deferred.clear();
+    if (job->prefetch) {
+        // a chain the job did not take may still be running (a guess of n that was too long): the caller does not wait for it
+        bool running = false;
+#if !defined(BPR1CS_HOSTSIM)
+        running = !job->prefetch_taken && job->prefetch->have_event && hipEventQuery(job->prefetch->done) == hipErrorNotReady;
+#endif
+        if (running && job->g) job->g->parked.push_back(job->prefetch);
+        else prefetch_free(job->prefetch);
+        job->prefetch = nullptr;
+    }
     host_stage_free(job->h_proofs);
     host_stage_free(job->h_comms);
     host_stage_free(job->h_err);
@@ -173,6 +208,9 @@ static int prove_job_begin(const bpr1cs_gens* g, const bpr1cs_circuit* c, const 
     // priority, and never used by the other job in flight (that one has the other slot).  A stream of its own would change the
     // streams' mapping onto the few hardware queues (measured: two more streams serialised the jobs, 2540 -> 2040 proofs/s)
     job->st4 = g->jstream[slot][2];
+    // a chain that ran ahead of this call (bpr1cs_prove_prefetch) belongs to this job from here on, used or not
+    job->prefetch = g->prefetch;
+    g->prefetch = nullptr;
     Scope scope(job);
     // everything the job owns comes from its slot's arena (a smaller job reuses the blocks of a larger one before it)
     ArenaScope own_arena(&g->front[slot], true);
@@ -207,6 +245,12 @@ static int prove_job_begin(const bpr1cs_gens* g, const bpr1cs_circuit* c, const 
     DBG_JOB("begin: inputs uploaded");
     // ---- P1: V commitments, transcript, RNG stream
     DevBuf<uint8_t> Vcomp((size_t)B * m * 32 + 1);
+#if !defined(BPR1CS_HOSTSIM)
+    if ((uint64_t)m * B <= 256 && m * B > 0) {   // a handful of commitments in front of the transcript chain: a wavefront each (180 -> ~25 us for one proof)
+        hipLaunchKernelGGL(k_commit_wave, dim3(m * B), dim3(64), 0, sl, (const uint8_t*)g->tab.p, g->tc, (const sc*)v_raw.p, (const sc*)vbl_raw.p, Vcomp.p, B, m);
+        HIPCHK(hipGetLastError());
+    } else
+#endif
     launch((uint64_t)m * B, K_commit_v{g->tab.p, g->tc, v_raw.p, vbl_raw.p, Vcomp.p, B, m}, sl);
     DevBuf<strobe> tr(B);
     const bool shared = g->opts.shared_back.load() != 0;   // jobs in flight share W / the raw RNG output / the back-phase scratch
@@ -238,11 +282,28 @@ static int prove_job_begin(const bpr1cs_gens* g, const bpr1cs_circuit* c, const 
     DevBuf<int> rng_err(1);
     dev_zero(rng_err.p, sizeof(int), sl);
     launch_transcript(B, K_transcript_init{d_init.p, init_stride, Vcomp.p, vbl_raw.p, d_seeds.p, tr.p, blind.p, sL, sR, rng.p, B, m, n}, sl);
+    // The chain may have run ahead of this call (bpr1cs_prove_prefetch, one proof): its raw draws are this proof's if it started
+    // from the same transcript, blindings and outside randomness and was given the right n - anything else and it is ignored.
+    const RngPrefetch* pf = job->prefetch;
+    if (pf && !(B == 1 && n_init == 1 && pf->n == n && pf->m == m && pf->have_event && memcmp(pf->init.st, init[0].st, sizeof(init[0].st)) == 0 &&
+                pf->init.pos == init[0].pos && pf->init.pos_begin == init[0].pos_begin && pf->init.cur_flags == init[0].cur_flags &&
+                memcmp(pf->seed, rng_seeds, 32) == 0 && (m == 0 || (memcmp(pf->values.data(), values, (size_t)32 * m) == 0 && memcmp(pf->blindings.data(), v_blindings, (size_t)32 * m) == 0))))
+        pf = nullptr;
+    DBG_JOB("begin: chain %s", pf ? "ran ahead (prefetch taken)" : (job->prefetch ? "prefetch ignored" : "starts here"));
+    job->prefetch_taken = pf != nullptr;
+    const uint64_t* raw_src = rng_raw.p;
     if (shared) dev_stream_wait(sl, g->rng_free_ev);   // the job before has reduced (and wiped) its raw output
-    hipLaunchKernelGGL(k_rng_stream, dim3((B + 1) / 2), dim3(64), 0, sl, rng.p, rng_raw.p, rng_err.p, B, draws);
-    HIPCHK(hipGetLastError());
+    if (pf) {
+        dev_stream_wait(sl, pf->done);
+        dev_d2d(rng_err.p, pf->err.p, sizeof(int), sl);
+        raw_src = pf->rng_raw.p;
+    } else {
+        hipLaunchKernelGGL(k_rng_stream, dim3((B + 1) / 2), dim3(64), 0, sl, rng.p, rng_raw.p, rng_err.p, B, draws);
+        HIPCHK(hipGetLastError());
+    }
     if (shared) dev_stream_wait(sl, g->w_free_ev);     // s_L / s_R live in W: the job before is past its l(x), r(x)
-    launch((uint64_t)draws * B, K_rng_reduce{rng_raw.p, blind.p, sL, sR, B, n}, sl);
+    launch((uint64_t)draws * B, K_rng_reduce{raw_src, blind.p, sL, sR, B, n}, sl);
+    if (pf) dev_zero(pf->rng_raw.p, pf->rng_raw.bytes(), sl);
     dev_zero(rng_raw.p, rng_raw.bytes(), sl);  // raw blinding material
     dev_zero(rng.p, rng.bytes(), sl);
     if (shared) dev_event_record(g->rng_free_ev, sl);
@@ -511,6 +572,7 @@ static int prove_job_end(bpr1cs_job* job, uint8_t* proofs_out, uint8_t* commitme
             if (job->B > acc->job_proofs) acc->job_proofs = job->B;
             for (int i = 0; i < 6; i++) acc->phase_ms[i] += ph[i];
             acc->msm_ms += job->msm.ms; acc->msm_launches += job->msm.launches; acc->msm_terms += job->msm.terms; acc->msm_adds += job->msm.adds;
+            if (job->prefetch_taken) acc->chains_ahead++;
         }
     }
     job_release(job);
@@ -694,6 +756,63 @@ int bpr1cs_prove_batch_transcripts(const bpr1cs_gens* g, const bpr1cs_circuit* c
         return prove_batch_impl(g, c, init.data(), n_transcripts, n_transcripts == batch ? transcripts : nullptr, values, v_blindings, rng_seeds, wires,
                                 batch, proofs_out, commitments_out);
     } catch (const std::bad_alloc&) { return BPR1CS_ERR_OUT_OF_MEMORY; }
+}
+int bpr1cs_prove_prefetch(const bpr1cs_gens* g, const bpr1cs_transcript* transcript, const uint8_t* values, const uint8_t* v_blindings, size_t m,
+                          const uint8_t* rng_seed, uint32_t n_multipliers) {
+    if (!g || !transcript || !rng_seed || (m && (!values || !v_blindings)) || m > (1u << 20) || n_multipliers == 0 || n_multipliers > (1u << 24))
+        return BPR1CS_ERR_INVALID_ARGUMENT;
+    if (!have_device()) return BPR1CS_ERR_NO_DEVICE;
+    if (m && (!host_scalars_canonical(values, m) || !host_scalars_canonical(v_blindings, m))) return BPR1CS_ERR_INVALID_ARGUMENT;
+#if defined(BPR1CS_HOSTSIM)
+    return BPR1CS_OK;   // the simulator is synchronous: nothing can run ahead
+#else
+    if (g->in_flight.load() != 0) return BPR1CS_OK;   // a job of the handle is in flight: no chain beside it (the prove call starts its own)
+    RngPrefetch* pf = nullptr;
+    try {
+        if (g->prefetch) { prefetch_free(g->prefetch); g->prefetch = nullptr; }
+        for (size_t i = 0; i < g->parked.size();) {   // chains nobody took: gone once they have run out
+            if (hipEventQuery(g->parked[i]->done) != hipErrorNotReady) { prefetch_free(g->parked[i]); g->parked.erase(g->parked.begin() + i); }
+            else i++;
+        }
+        pf = new RngPrefetch();
+        const uint32_t B = 1, n = n_multipliers, mm = (uint32_t)m, draws = 2 * n + 7;
+        pf->init = transcript->s;
+        pf->values.assign(values, values + 32 * m);
+        pf->blindings.assign(v_blindings, v_blindings + 32 * m);
+        memcpy(pf->seed, rng_seed, 32);
+        pf->n = n; pf->m = mm;
+        // the front stream of the job slot the next synchronous call does NOT take (slot 0): idle, high priority
+        const dev_stream_t st = g->jstream[1][1];
+        pf->st = st;
+        upload_transposed(pf->v_raw, values, B, m, st);
+        upload_transposed(pf->vbl_raw, v_blindings, B, m, st);
+        pf->seeds.alloc(32);
+        dev_h2d(pf->seeds.p, rng_seed, 32, st);
+        pf->init_d.alloc(1);
+        dev_h2d(pf->init_d.p, &pf->init, sizeof(strobe), st);
+        pf->Vcomp.alloc((size_t)mm * 32 + 1);
+        pf->tr.alloc(1); pf->rng.alloc(1); pf->blind.alloc(8); pf->err.alloc(1);
+        pf->rng_raw.alloc((size_t)draws * 8);
+        if (mm) {
+            if (mm <= 256) {
+                hipLaunchKernelGGL(k_commit_wave, dim3(mm), dim3(64), 0, st, (const uint8_t*)g->tab.p, g->tc, (const sc*)pf->v_raw.p, (const sc*)pf->vbl_raw.p, pf->Vcomp.p, B, mm);
+                HIPCHK(hipGetLastError());
+            } else launch((uint64_t)mm, K_commit_v{g->tab.p, g->tc, pf->v_raw.p, pf->vbl_raw.p, pf->Vcomp.p, B, mm}, st);
+        }
+        dev_zero(pf->err.p, sizeof(int), st);
+        launch_transcript(B, K_transcript_init{pf->init_d.p, 0u, pf->Vcomp.p, pf->vbl_raw.p, pf->seeds.p, pf->tr.p, pf->blind.p, nullptr, nullptr, pf->rng.p, B, mm, n}, st);
+        hipLaunchKernelGGL(k_rng_stream, dim3(1), dim3(64), 0, st, (const strobe*)pf->rng.p, pf->rng_raw.p, pf->err.p, B, draws);
+        HIPCHK(hipGetLastError());
+        dev_event_create(&pf->done);
+        pf->have_event = true;
+        dev_event_record(pf->done, st);
+        g->prefetch = pf;
+        return BPR1CS_OK;
+    }
+    catch (const DevError& e_) { prefetch_free(pf); return e_.code; }
+    catch (const std::bad_alloc&) { prefetch_free(pf); return BPR1CS_ERR_OUT_OF_MEMORY; }
+    catch (...) { prefetch_free(pf); return BPR1CS_ERR_DEVICE; }
+#endif
 }
 int bpr1cs_last_prove_stats(bpr1cs_prove_stats* out) {
     if (!out) return BPR1CS_ERR_INVALID_ARGUMENT;

@@ -68,6 +68,10 @@ R1CSProof Prover::prove(const BulletproofGens& bp_gens) {
     bpr1cs_circuit_destroy(c);
     if (seconds) { seconds[0] += t1 - t0; seconds[1] += now_s() - t1; }
     if (rc) throw R1CSError::Backend(rc);
+    if (!defer_commitments && n) {   // the next proof with this label and this many commitments starts its chain ahead (chain_ahead)
+        std::lock_guard<std::mutex> lk(hint_mu());
+        n_hints()[{transcript.label, m}] = (uint32_t)n;
+    }
     return R1CSProof::from_bytes(bytes);
 }
 
@@ -489,10 +493,10 @@ int bpr1cs_gadget_prove_on(const bpr1cs_gens* gens, const char* gadget, const ui
             Transcript t((const char*)label, label_len);
             Prover prover(pc_gens, t);
             std::vector<CompressedRistretto> comms;
-            synth(prover, 0, &comms);
             std::array<uint8_t, 32> seed;
             memcpy(seed.data(), rng_seeds, 32);
-            prover.set_rng_seed(seed);
+            prover.set_rng_seed(seed);   // (before the synthesis: the chain that runs ahead of prove() needs it)
+            synth(prover, 0, &comms);
             prover.seconds = sec + 2;
             std::vector<uint8_t> bytes = prover.prove(bp_gens).to_bytes();
             if (bytes.size() > proof_cap) return BPR1CS_ERR_INVALID_ARGUMENT;

@@ -16,7 +16,10 @@
 #include <string.h>
 #include <array>
 #include <algorithm>
+#include <map>
+#include <mutex>
 #include <optional>
+#include <random>
 #include <string>
 #include <tuple>
 #include <unordered_map>
@@ -393,6 +396,7 @@ public:
     }
     std::optional<Scalar> evaluate_lc(const LinearCombination& lc) const override { return eval(lc); }
     MulVars multiply(LinearCombination left, LinearCombination right) override {
+        if (!chain_tried) chain_ahead();
         Scalar l = eval(left), r = eval(right);
         uint32_t i = (uint32_t)a_L.size();
         a_L.push_back(l); a_R.push_back(r); a_O.push_back(l * r);
@@ -406,6 +410,7 @@ public:
     }
     MulVars allocate_multiplier(const std::optional<std::pair<Scalar, Scalar>>& a, const WitnessHint&, const WitnessHint&) override {
         if (!a) throw R1CSError::MissingAssignment();
+        if (!chain_tried) chain_ahead();
         uint32_t i = (uint32_t)a_L.size();
         a_L.push_back(a->first); a_R.push_back(a->second); a_O.push_back(a->first * a->second);
         num_vars = a_L.size();
@@ -413,6 +418,7 @@ public:
     }
     std::pair<Variable, std::optional<Variable>> allocate_single(const std::optional<Scalar>& a, const WitnessHint&) override {
         if (!a) throw R1CSError::MissingAssignment();
+        if (!chain_tried) chain_ahead();
         if (!pending_multiplier) {
             uint32_t i = (uint32_t)a_L.size();
             pending_multiplier = i;
@@ -433,6 +439,35 @@ public:
     // what prove() hands to the device: committed values, blindings (m x 32 each) and the wires a_L | a_R | a_O (3 n x 32), appended
     void export_witness(std::vector<uint8_t>& vals, std::vector<uint8_t>& bls, std::vector<uint8_t>& wires) const;
     bool defer_commitments = false;
+    // The first multiplier of the gadget: every commitment is made (the reference's harnesses commit first, then synthesise - e.g.
+    // src/gadget_vsmt_4.rs:393-420), so everything the proof's TranscriptRng chain depends on is known except its length, 2n + 7
+    // draws.  The chain - 90 of the 105 ms a depth-32 proof spends on the device - is started now, next to the synthesis on the
+    // host, with the n of the last proof that had this label and this many commitments (bpr1cs_prove_prefetch); prove() presents
+    // the same inputs and takes its draws when n was right, and starts its own chain when it was not.  A later commit() makes the
+    // prove call ignore it likewise.  Same bytes either way.
+    bool chain_tried = false;
+    void chain_ahead() {
+        chain_tried = true;
+        if (defer_commitments || !pc_gens.gens) return;
+        uint32_t n_guess = 0;
+        {
+            std::lock_guard<std::mutex> lk(hint_mu());
+            auto it = n_hints().find({transcript.label, v_.size()});
+            if (it != n_hints().end()) n_guess = it->second;
+        }
+        if (!n_guess) return;
+        if (!rng_seed) {
+            std::array<uint8_t, 32> s;
+            std::random_device rd;  // stands in for rand::thread_rng()
+            for (auto& x : s) x = (uint8_t)rd();
+            rng_seed = s;
+        }
+        std::vector<uint8_t> vals(32 * v_.size() + 1), bls(32 * v_.size() + 1);
+        for (size_t i = 0; i < v_.size(); i++) { v_[i].write_bytes(&vals[32 * i]); v_blinding_[i].write_bytes(&bls[32 * i]); }
+        (void)bpr1cs_prove_prefetch(pc_gens.gens, transcript.h, vals.data(), bls.data(), v_.size(), rng_seed->data(), n_guess);   // advisory
+    }
+    static std::mutex& hint_mu() { static std::mutex m; return m; }
+    static std::map<std::pair<std::string, size_t>, uint32_t>& n_hints() { static std::map<std::pair<std::string, size_t>, uint32_t> h; return h; }
     double* seconds = nullptr;   // optional [2]: seconds spent in (CSR export + bpr1cs_circuit_create, the prove call) of prove()
 
     const PedersenGens& pc_gens;

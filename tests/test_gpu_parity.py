@@ -185,3 +185,57 @@ def test_transcript_launch_boundary(hip_lib, batch):
     bad[k] = bad[k][:77] + bytes([bad[k][77] ^ 4]) + bad[k][78:]
     got = bp.verify_batch(gens, circ, ob["label"], bad, C, batch)
     assert got == [True] * k + [False]
+
+
+def test_chain_started_ahead_of_the_prove_call(hip_lib):
+    """bpr1cs_prove_prefetch: the TranscriptRng chain of ONE proof started before its prove call (next to the host's gadget synthesis
+    in the reference's call shape).  Taken - chains_ahead = 1 - only when the prove call presents the same transcript state, values,
+    blindings and rng_seed and its circuit has the guessed n; in every other case ignored.  The oracle's bytes in every case."""
+    bp = common.bp
+    ob = common.oracle_batch(lambda j: S.bound_check(37 + j, 10, 100, 7), 16, 3)
+    gens = bp.Gens(16, lib=hip_lib)
+    circ = common.circuit_from_oracle(ob, hip_lib)
+    m, n = ob["m"], ob["n"]
+    one = lambda key, j, w: ob[key][w * j:w * (j + 1)]
+
+    def prove(j, msg=None):
+        t = bp.Transcript(ob["label"], lib=hip_lib)
+        if msg:
+            t.append_message(b"ctx", msg)
+        P, _ = bp.prove_batch_transcripts(gens, circ, t, one("values", j, 32 * m), one("blindings", j, 32 * m), one("seeds", j, 32), 1,
+                                          wires=one("wires", j, 96 * n))
+        return P[0], bp.last_prove_stats(hip_lib)["chains_ahead"]
+
+    def ahead(j, n_guess, seed=None, msg=None):
+        t = bp.Transcript(ob["label"], lib=hip_lib)
+        if msg:
+            t.append_message(b"ctx", msg)
+        bp.prove_prefetch(gens, t, one("values", j, 32 * m), one("blindings", j, 32 * m), m, seed or one("seeds", j, 32), n_guess)
+
+    assert prove(0) == (ob["proofs"][0], 0)                      # nothing ran ahead
+    ahead(0, n)
+    assert prove(0) == (ob["proofs"][0], 1)                      # taken
+    assert prove(0) == (ob["proofs"][0], 0)                      # ... once
+    ahead(1, n + 5)
+    assert prove(1) == (ob["proofs"][1], 0)                      # a wrong guess of n (too long: the chain is still running, nobody waits for it)
+    ahead(1, n - 1)
+    assert prove(1) == (ob["proofs"][1], 0)                      # too short
+    ahead(2, n, seed=one("seeds", 0, 32))
+    assert prove(2) == (ob["proofs"][2], 0)                      # other outside randomness
+    ahead(1, n)
+    assert prove(2) == (ob["proofs"][2], 0)                      # another proof's values and blindings
+    ahead(2, n)
+    ahead(0, n)                                                  # a second call replaces the first
+    assert prove(0) == (ob["proofs"][0], 1)
+    ahead(0, n, msg=b"x")
+    assert prove(0) == (ob["proofs"][0], 0)                      # the transcript held a message the prove call's does not
+    p_adv, took = (lambda: (ahead(0, n, msg=b"x"), prove(0, msg=b"x"))[1])()
+    assert took == 1 and p_adv != ob["proofs"][0]                # taken on a transcript that is not fresh, too
+    assert prove(0, msg=b"x") == (p_adv, 0)                      # ... with the bytes of the call that starts its own chain
+    ahead(0, n)
+    P, _ = bp.prove_batch(gens, circ, ob["label"], ob["values"], ob["blindings"], ob["seeds"], 3, wires=ob["wires"])
+    assert P == ob["proofs"] and bp.last_prove_stats(hip_lib)["chains_ahead"] == 0   # a batch ignores it
+    ahead(1, n)
+    assert prove(1) == (ob["proofs"][1], 1)
+    ahead(2, n)                                                  # never taken: released with the handle
+    del gens
