@@ -370,3 +370,24 @@ def test_random_constraint_systems_match_oracle(sim_lib):
     empty rows, m = 0, n = 1, violated witnesses) - the oracle's bytes, and the device verifier's verdict = satisfiability"""
     import random_circuits
     random_circuits.check(sim_lib, common)
+
+
+def test_prove_prefetch_arguments_and_noop_on_the_simulator(sim_lib):
+    """bpr1cs_prove_prefetch: the argument checks of the entry point (shared with the device build) - null pointers, a value that is
+    not a canonical scalar, n = 0 - and that the synchronous simulator starts nothing: the prove call after it computes its own
+    chain (chains_ahead = 0) and returns the oracle's bytes.  The chain that does run ahead is a device test
+    (tests/test_gpu_parity.py::test_chain_started_ahead_of_the_prove_call)."""
+    bp = common.bp
+    ob = common.oracle_batch(lambda j: S.bound_check(37 + j, 10, 100, 7), 16, 2)
+    gens = bp.Gens(16, lib=sim_lib)
+    circ = common.circuit_from_oracle(ob, sim_lib)
+    m, n = ob["m"], ob["n"]
+    v, b, s = ob["values"][:32 * m], ob["blindings"][:32 * m], ob["seeds"][:32]
+    t = bp.Transcript(ob["label"], lib=sim_lib)
+    f = sim_lib.bpr1cs_prove_prefetch
+    assert f(gens.h, t.h, v, b, m, s, n) == 0
+    assert f(None, t.h, v, b, m, s, n) == -17 and f(gens.h, None, v, b, m, s, n) == -17 and f(gens.h, t.h, v, b, m, None, n) == -17
+    assert f(gens.h, t.h, None, b, m, s, n) == -17 and f(gens.h, t.h, v, b, m, s, 0) == -17
+    assert f(gens.h, t.h, b"\xff" * 32 + v[32:], b, m, s, n) == -17          # not a canonical scalar
+    P, _ = bp.prove_batch_transcripts(gens, circ, t, v, b, s, 1, wires=ob["wires"][:96 * n])
+    assert P == ob["proofs"][:1] and bp.last_prove_stats(sim_lib)["chains_ahead"] == 0
