@@ -111,7 +111,7 @@ def load_library(path=None):
     lib.bpr1cs_circuit_macro_perms.restype = ctypes.c_int
     lib.bpr1cs_gens_create_opts.argtypes = [u32, ctypes.POINTER(ctypes.c_int32), sz, ctypes.POINTER(vp)]
     lib.bpr1cs_prove_batch_transcripts.argtypes = [vp, vp, ctypes.POINTER(vp), sz, cp, cp, cp, cp, sz, cp, cp]
-    lib.bpr1cs_prove_prefetch.argtypes = [vp, vp, cp, cp, sz, cp, ctypes.c_uint32]
+    lib.bpr1cs_prove_prefetch.argtypes = [vp, vp, cp, cp, sz, cp, sz, ctypes.c_uint32]
     lib.bpr1cs_last_prove_stats.argtypes = [ctypes.POINTER(ProveStats)]
     lib.bpr1cs_gens_set_option.argtypes = [vp, ctypes.c_int, ctypes.c_int]
     lib.bpr1cs_gens_release_scratch.argtypes = [vp]
@@ -520,9 +520,10 @@ def last_prove_stats(lib=None):
     return dict(jobs=st.jobs, job_proofs=st.job_proofs, phase_ms=list(st.phase_ms), msm_ms=st.msm_ms, msm_launches=st.msm_launches, msm_terms=st.msm_terms, msm_adds=st.msm_adds, chains_ahead=st.chains_ahead)
 
 
-def prove_prefetch(gens, transcript, values, v_blindings, m, rng_seed, n_multipliers):
-    """bpr1cs_prove_prefetch: start the TranscriptRng chain of ONE proof ahead of its prove call (advisory; returns at once)"""
-    _chk(gens.lib.bpr1cs_prove_prefetch(gens.h, transcript.h, values or b"\0", v_blindings or b"\0", m, rng_seed, n_multipliers))
+def prove_prefetch(gens, transcript, values, v_blindings, m, rng_seeds, n_multipliers, batch=1):
+    """bpr1cs_prove_prefetch: start the TranscriptRng chains of ONE proof (or of `batch` proofs from one transcript) ahead of the prove
+    call (advisory; returns at once)"""
+    _chk(gens.lib.bpr1cs_prove_prefetch(gens.h, transcript.h, values or b"\0", v_blindings or b"\0", m, rng_seeds, batch, n_multipliers))
 
 
 def prove_batch_transcripts(gens, circuit, transcripts, values, v_blindings, rng_seeds, batch, wires=None):

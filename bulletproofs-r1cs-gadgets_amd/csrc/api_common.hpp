@@ -128,19 +128,18 @@ struct bpr1cs_transcript {  // merlin::Transcript (host side)
     strobe s;
 };
 
-// The TranscriptRng chain of ONE proof started ahead of its prove call (bpr1cs_prove_prefetch): everything the chain depends on -
+// The TranscriptRng chains of ONE proof (or of a small batch) started ahead of the prove call (bpr1cs_prove_prefetch): everything the chain depends on -
 // the transcript, the committed values' blindings, the 32 bytes of outside randomness - is known once the commitments are made,
 // before the gadget is synthesised on the host; its length (2n + 7 draws) is the caller's guess.  The prove call that follows on
 // the handle takes the raw draws if it presents the same inputs and the same n, and ignores them otherwise.
 struct RngPrefetch {
     strobe init{};
-    std::vector<uint8_t> values, blindings;   // m x 32 each, as presented
-    uint8_t seed[32] = {0};
-    uint32_t n = 0, m = 0;
+    std::vector<uint8_t> values, blindings, seed;   // B x m x 32 each and B x 32, as presented
+    uint32_t n = 0, m = 0, B = 0;
     DevBuf<sc> v_raw, vbl_raw, blind;
     DevBuf<uint8_t> seeds, Vcomp;
     DevBuf<strobe> init_d, tr, rng;
-    DevBuf<uint64_t> rng_raw;                  // [2n + 7][8]
+    DevBuf<uint64_t> rng_raw;                  // [2n + 7][B][8]
     DevBuf<int> err;
     dev_event_t done{};
     bool have_event = false;

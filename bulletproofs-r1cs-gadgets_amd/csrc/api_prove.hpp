@@ -90,7 +90,7 @@ static void prefetch_free(RngPrefetch* pf) {
     if (pf->have_event) dev_event_destroy(&pf->done);
     if (!pf->values.empty()) memset(pf->values.data(), 0, pf->values.size());
     if (!pf->blindings.empty()) memset(pf->blindings.data(), 0, pf->blindings.size());
-    memset(pf->seed, 0, 32);
+    if (!pf->seed.empty()) memset(pf->seed.data(), 0, pf->seed.size());
     delete pf;
 }
 // wait for everything a job has enqueued and release what it holds (normal end and error paths)
@@ -285,9 +285,10 @@ static int prove_job_begin(const bpr1cs_gens* g, const bpr1cs_circuit* c, const 
     // The chain may have run ahead of this call (bpr1cs_prove_prefetch, one proof): its raw draws are this proof's if it started
     // from the same transcript, blindings and outside randomness and was given the right n - anything else and it is ignored.
     const RngPrefetch* pf = job->prefetch;
-    if (pf && !(B == 1 && n_init == 1 && pf->n == n && pf->m == m && pf->have_event && memcmp(pf->init.st, init[0].st, sizeof(init[0].st)) == 0 &&
+    if (pf && !(B == pf->B && n_init == 1 && pf->n == n && pf->m == m && pf->have_event && memcmp(pf->init.st, init[0].st, sizeof(init[0].st)) == 0 &&
                 pf->init.pos == init[0].pos && pf->init.pos_begin == init[0].pos_begin && pf->init.cur_flags == init[0].cur_flags &&
-                memcmp(pf->seed, rng_seeds, 32) == 0 && (m == 0 || (memcmp(pf->values.data(), values, (size_t)32 * m) == 0 && memcmp(pf->blindings.data(), v_blindings, (size_t)32 * m) == 0))))
+                memcmp(pf->seed.data(), rng_seeds, (size_t)32 * B) == 0 &&
+                (m == 0 || (memcmp(pf->values.data(), values, (size_t)32 * m * B) == 0 && memcmp(pf->blindings.data(), v_blindings, (size_t)32 * m * B) == 0))))
         pf = nullptr;
     DBG_JOB("begin: chain %s", pf ? "ran ahead (prefetch taken)" : (job->prefetch ? "prefetch ignored" : "starts here"));
     job->prefetch_taken = pf != nullptr;
@@ -572,7 +573,7 @@ static int prove_job_end(bpr1cs_job* job, uint8_t* proofs_out, uint8_t* commitme
             if (job->B > acc->job_proofs) acc->job_proofs = job->B;
             for (int i = 0; i < 6; i++) acc->phase_ms[i] += ph[i];
             acc->msm_ms += job->msm.ms; acc->msm_launches += job->msm.launches; acc->msm_terms += job->msm.terms; acc->msm_adds += job->msm.adds;
-            if (job->prefetch_taken) acc->chains_ahead++;
+            if (job->prefetch_taken) acc->chains_ahead += job->B;
         }
     }
     job_release(job);
@@ -758,15 +759,17 @@ int bpr1cs_prove_batch_transcripts(const bpr1cs_gens* g, const bpr1cs_circuit* c
     } catch (const std::bad_alloc&) { return BPR1CS_ERR_OUT_OF_MEMORY; }
 }
 int bpr1cs_prove_prefetch(const bpr1cs_gens* g, const bpr1cs_transcript* transcript, const uint8_t* values, const uint8_t* v_blindings, size_t m,
-                          const uint8_t* rng_seed, uint32_t n_multipliers) {
-    if (!g || !transcript || !rng_seed || (m && (!values || !v_blindings)) || m > (1u << 20) || n_multipliers == 0 || n_multipliers > (1u << 24))
+                          const uint8_t* rng_seeds, size_t batch, uint32_t n_multipliers) {
+    if (!g || !transcript || !rng_seeds || batch == 0 || batch > (1u << 20) || (m && (!values || !v_blindings)) || m > (1u << 20) ||
+        n_multipliers == 0 || n_multipliers > (1u << 24))
         return BPR1CS_ERR_INVALID_ARGUMENT;
     if (!have_device()) return BPR1CS_ERR_NO_DEVICE;
-    if (m && (!host_scalars_canonical(values, m) || !host_scalars_canonical(v_blindings, m))) return BPR1CS_ERR_INVALID_ARGUMENT;
+    if (m && (!host_scalars_canonical(values, batch * m) || !host_scalars_canonical(v_blindings, batch * m))) return BPR1CS_ERR_INVALID_ARGUMENT;
 #if defined(BPR1CS_HOSTSIM)
     return BPR1CS_OK;   // the simulator is synchronous: nothing can run ahead
 #else
     if (g->in_flight.load() != 0) return BPR1CS_OK;   // a job of the handle is in flight: no chain beside it (the prove call starts its own)
+    if (batch > 256) return BPR1CS_OK;                // the throughput path hides the chain behind the job before: nothing to gain
     RngPrefetch* pf = nullptr;
     try {
         if (g->prefetch) { prefetch_free(g->prefetch); g->prefetch = nullptr; }
@@ -775,33 +778,35 @@ int bpr1cs_prove_prefetch(const bpr1cs_gens* g, const bpr1cs_transcript* transcr
             else i++;
         }
         pf = new RngPrefetch();
-        const uint32_t B = 1, n = n_multipliers, mm = (uint32_t)m, draws = 2 * n + 7;
+        const uint32_t B = (uint32_t)batch, n = n_multipliers, mm = (uint32_t)m, draws = 2 * n + 7;
         pf->init = transcript->s;
-        pf->values.assign(values, values + 32 * m);
-        pf->blindings.assign(v_blindings, v_blindings + 32 * m);
-        memcpy(pf->seed, rng_seed, 32);
-        pf->n = n; pf->m = mm;
+        if (m) {
+            pf->values.assign(values, values + 32 * m * batch);
+            pf->blindings.assign(v_blindings, v_blindings + 32 * m * batch);
+        }
+        pf->seed.assign(rng_seeds, rng_seeds + 32 * batch);
+        pf->n = n; pf->m = mm; pf->B = B;
         // the front stream of the job slot the next synchronous call does NOT take (slot 0): idle, high priority
         const dev_stream_t st = g->jstream[1][1];
         pf->st = st;
         upload_transposed(pf->v_raw, values, B, m, st);
         upload_transposed(pf->vbl_raw, v_blindings, B, m, st);
-        pf->seeds.alloc(32);
-        dev_h2d(pf->seeds.p, rng_seed, 32, st);
+        pf->seeds.alloc((size_t)32 * B);
+        dev_h2d(pf->seeds.p, rng_seeds, (size_t)32 * B, st);
         pf->init_d.alloc(1);
         dev_h2d(pf->init_d.p, &pf->init, sizeof(strobe), st);
-        pf->Vcomp.alloc((size_t)mm * 32 + 1);
-        pf->tr.alloc(1); pf->rng.alloc(1); pf->blind.alloc(8); pf->err.alloc(1);
-        pf->rng_raw.alloc((size_t)draws * 8);
+        pf->Vcomp.alloc((size_t)B * mm * 32 + 1);
+        pf->tr.alloc(B); pf->rng.alloc(B); pf->blind.alloc((size_t)8 * B); pf->err.alloc(1);
+        pf->rng_raw.alloc((size_t)draws * B * 8);
         if (mm) {
-            if (mm <= 256) {
-                hipLaunchKernelGGL(k_commit_wave, dim3(mm), dim3(64), 0, st, (const uint8_t*)g->tab.p, g->tc, (const sc*)pf->v_raw.p, (const sc*)pf->vbl_raw.p, pf->Vcomp.p, B, mm);
+            if ((uint64_t)mm * B <= 256) {
+                hipLaunchKernelGGL(k_commit_wave, dim3(mm * B), dim3(64), 0, st, (const uint8_t*)g->tab.p, g->tc, (const sc*)pf->v_raw.p, (const sc*)pf->vbl_raw.p, pf->Vcomp.p, B, mm);
                 HIPCHK(hipGetLastError());
-            } else launch((uint64_t)mm, K_commit_v{g->tab.p, g->tc, pf->v_raw.p, pf->vbl_raw.p, pf->Vcomp.p, B, mm}, st);
+            } else launch((uint64_t)mm * B, K_commit_v{g->tab.p, g->tc, pf->v_raw.p, pf->vbl_raw.p, pf->Vcomp.p, B, mm}, st);
         }
         dev_zero(pf->err.p, sizeof(int), st);
         launch_transcript(B, K_transcript_init{pf->init_d.p, 0u, pf->Vcomp.p, pf->vbl_raw.p, pf->seeds.p, pf->tr.p, pf->blind.p, nullptr, nullptr, pf->rng.p, B, mm, n}, st);
-        hipLaunchKernelGGL(k_rng_stream, dim3(1), dim3(64), 0, st, (const strobe*)pf->rng.p, pf->rng_raw.p, pf->err.p, B, draws);
+        hipLaunchKernelGGL(k_rng_stream, dim3((B + 1) / 2), dim3(64), 0, st, (const strobe*)pf->rng.p, pf->rng_raw.p, pf->err.p, B, draws);
         HIPCHK(hipGetLastError());
         dev_event_create(&pf->done);
         pf->have_event = true;

@@ -511,6 +511,20 @@ int bpr1cs_gadget_prove_on(const bpr1cs_gens* gens, const char* gadget, const ui
             bpr1cs_circuit* c = nullptr;
             size_t n0 = 0, q0 = 0;
             std::vector<std::vector<uint8_t>> pv(batch), pb(batch), pw(batch);
+            {   // the proofs' TranscriptRng chains run on the device while the host synthesises (bpr1cs_prove_prefetch; n = the last
+                // proof's with this label and this many commitments; advisory - the prove call below starts its own if n is not its n)
+                uint32_t n_guess = 0;
+                {
+                    std::lock_guard<std::mutex> lk(Prover::hint_mu());
+                    auto it = Prover::n_hints().find({std::string((const char*)label, label_len), m});
+                    if (it != Prover::n_hints().end()) n_guess = it->second;
+                }
+                if (n_guess) {
+                    Transcript t0((const char*)label, label_len);
+                    const uint8_t zero = 0;
+                    (void)bpr1cs_prove_prefetch(gens, t0.h, m ? values : &zero, m ? v_blindings : &zero, m, rng_seeds, batch, n_guess);
+                }
+            }
             const double t_synth0 = now_s();
             std::mutex mu;
             int first_err = 0;
@@ -582,6 +596,10 @@ int bpr1cs_gadget_prove_on(const bpr1cs_gens* gens, const char* gadget, const ui
             sec[3] += now_s() - t0;
             bpr1cs_circuit_destroy(c);
             if (rc) return rc;
+            if (n0) {
+                std::lock_guard<std::mutex> lk(Prover::hint_mu());
+                Prover::n_hints()[{std::string((const char*)label, label_len), m}] = (uint32_t)n0;
+            }
             *proof_len = plen;
         }
         sec[4] = now_s() - t_start;

@@ -464,7 +464,7 @@ public:
         }
         std::vector<uint8_t> vals(32 * v_.size() + 1), bls(32 * v_.size() + 1);
         for (size_t i = 0; i < v_.size(); i++) { v_[i].write_bytes(&vals[32 * i]); v_blinding_[i].write_bytes(&bls[32 * i]); }
-        (void)bpr1cs_prove_prefetch(pc_gens.gens, transcript.h, vals.data(), bls.data(), v_.size(), rng_seed->data(), n_guess);   // advisory
+        (void)bpr1cs_prove_prefetch(pc_gens.gens, transcript.h, vals.data(), bls.data(), v_.size(), rng_seed->data(), 1, n_guess);   // advisory
     }
     static std::mutex& hint_mu() { static std::mutex m; return m; }
     static std::map<std::pair<std::string, size_t>, uint32_t>& n_hints() { static std::map<std::pair<std::string, size_t>, uint32_t> h; return h; }

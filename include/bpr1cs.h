@@ -220,15 +220,17 @@ int bpr1cs_prove_batch_transcripts(const bpr1cs_gens* g, const bpr1cs_circuit* c
  * on the host, prove) - spends most of its device time in the proof's TranscriptRng chain: 2n + 7 sequential permutations that depend
  * on the transcript, the commitments' blindings and the 32 bytes of outside randomness, not on the wires.  This call starts that chain
  * as soon as the commitments are made, next to the host's synthesis, and returns at once; `n_multipliers` is the caller's guess of n
- * (e.g. the n of its last proof of this statement).  The next bpr1cs_prove_batch_transcripts / bpr1cs_prove_batch call of ONE proof on
- * the handle takes the chain's draws if it presents the same transcript state, values, blindings and rng_seed and its circuit has that
- * n; in every other case the chain is ignored and the call starts its own.  The proof bytes are the same either way.  Advisory: with
- * a job of the handle in flight nothing is started (BPR1CS_OK); a second call replaces the first.
+ * (e.g. the n of its last proof of this statement).  `batch` > 1: the chains of that many proofs that all start from a copy of
+ * `transcript` (a service that synthesises several witnesses on the host and proves them in one call).  The next
+ * bpr1cs_prove_batch_transcripts / bpr1cs_prove_batch call on the handle takes the chains' draws if it is a call of `batch` proofs in one
+ * device job from ONE transcript in the same state, presents the same values, blindings and rng_seeds, and its circuit has that n; in
+ * every other case they are ignored and the call starts its own.  The proof bytes are the same either way.  Advisory: with a job of
+ * the handle in flight, or batch > 256, nothing is started (BPR1CS_OK); a second call replaces the first.
  *   transcript         the state Prover::new would be given (not advanced by this call)
- *   values, v_blindings   m * 32 each, canonical
- *   rng_seed           32 bytes */
+ *   values, v_blindings   batch * m * 32 each, canonical
+ *   rng_seeds          batch * 32 */
 int bpr1cs_prove_prefetch(const bpr1cs_gens* g, const bpr1cs_transcript* transcript, const uint8_t* values, const uint8_t* v_blindings, size_t m,
-                          const uint8_t* rng_seed, uint32_t n_multipliers);
+                          const uint8_t* rng_seeds, size_t batch, uint32_t n_multipliers);
 
 /* Asynchronous form of bpr1cs_prove_batch: `begin` uploads the inputs and enqueues the whole prove on
  * one of two per-handle HIP stream pairs and returns without waiting; `end` waits for that job and
@@ -375,7 +377,7 @@ typedef struct {
     uint64_t msm_launches;
     uint64_t msm_terms;     /* scalar*point terms it processed, summed over the batch */
     uint64_t msm_adds;      /* table additions = terms x windows of the table a term reads (a circuit's merged tables may be narrower) */
-    uint64_t chains_ahead;  /* proofs that took the TranscriptRng chain bpr1cs_prove_prefetch had started for them (0 or 1) */
+    uint64_t chains_ahead;  /* proofs that took the TranscriptRng chain bpr1cs_prove_prefetch had started for them */
 } bpr1cs_prove_stats;
 int bpr1cs_last_prove_stats(bpr1cs_prove_stats* out);
 

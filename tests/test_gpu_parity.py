@@ -234,8 +234,18 @@ def test_chain_started_ahead_of_the_prove_call(hip_lib):
     assert prove(0, msg=b"x") == (p_adv, 0)                      # ... with the bytes of the call that starts its own chain
     ahead(0, n)
     P, _ = bp.prove_batch(gens, circ, ob["label"], ob["values"], ob["blindings"], ob["seeds"], 3, wires=ob["wires"])
-    assert P == ob["proofs"] and bp.last_prove_stats(hip_lib)["chains_ahead"] == 0   # a batch ignores it
+    assert P == ob["proofs"] and bp.last_prove_stats(hip_lib)["chains_ahead"] == 0   # one chain, a batch of three: ignored
     ahead(1, n)
     assert prove(1) == (ob["proofs"][1], 1)
+    # the chains of a small batch from one transcript (what bpr1cs_gadget_prove_on(batch > 1) starts before its host syntheses)
+    t = bp.Transcript(ob["label"], lib=hip_lib)
+    bp.prove_prefetch(gens, t, ob["values"], ob["blindings"], m, ob["seeds"], n, batch=3)
+    P, _ = bp.prove_batch_transcripts(gens, circ, t, ob["values"], ob["blindings"], ob["seeds"], 3, wires=ob["wires"])
+    assert P == ob["proofs"] and bp.last_prove_stats(hip_lib)["chains_ahead"] == 3
+    bp.prove_prefetch(gens, t, ob["values"], ob["blindings"], m, ob["seeds"], n, batch=3)
+    assert prove(0) == (ob["proofs"][0], 0)                      # three chains, a call of one proof: ignored
+    bp.prove_prefetch(gens, t, ob["values"][:64 * m], ob["blindings"][:64 * m], m, ob["seeds"][:64], n, batch=2)
+    P, _ = bp.prove_batch(gens, circ, ob["label"], ob["values"], ob["blindings"], ob["seeds"], 3, wires=ob["wires"])
+    assert P == ob["proofs"] and bp.last_prove_stats(hip_lib)["chains_ahead"] == 0   # two chains, three proofs
     ahead(2, n)                                                  # never taken: released with the handle
     del gens

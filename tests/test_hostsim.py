@@ -385,9 +385,10 @@ def test_prove_prefetch_arguments_and_noop_on_the_simulator(sim_lib):
     v, b, s = ob["values"][:32 * m], ob["blindings"][:32 * m], ob["seeds"][:32]
     t = bp.Transcript(ob["label"], lib=sim_lib)
     f = sim_lib.bpr1cs_prove_prefetch
-    assert f(gens.h, t.h, v, b, m, s, n) == 0
-    assert f(None, t.h, v, b, m, s, n) == -17 and f(gens.h, None, v, b, m, s, n) == -17 and f(gens.h, t.h, v, b, m, None, n) == -17
-    assert f(gens.h, t.h, None, b, m, s, n) == -17 and f(gens.h, t.h, v, b, m, s, 0) == -17
-    assert f(gens.h, t.h, b"\xff" * 32 + v[32:], b, m, s, n) == -17          # not a canonical scalar
+    assert f(gens.h, t.h, v, b, m, s, 1, n) == 0
+    assert f(gens.h, t.h, ob["values"], ob["blindings"], m, ob["seeds"], 2, n) == 0
+    assert f(None, t.h, v, b, m, s, 1, n) == -17 and f(gens.h, None, v, b, m, s, 1, n) == -17 and f(gens.h, t.h, v, b, m, None, 1, n) == -17
+    assert f(gens.h, t.h, None, b, m, s, 1, n) == -17 and f(gens.h, t.h, v, b, m, s, 1, 0) == -17 and f(gens.h, t.h, v, b, m, s, 0, n) == -17
+    assert f(gens.h, t.h, b"\xff" * 32 + v[32:], b, m, s, 1, n) == -17       # not a canonical scalar
     P, _ = bp.prove_batch_transcripts(gens, circ, t, v, b, s, 1, wires=ob["wires"][:96 * n])
     assert P == ob["proofs"][:1] and bp.last_prove_stats(sim_lib)["chains_ahead"] == 0

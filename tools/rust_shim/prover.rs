@@ -70,7 +70,7 @@ impl<'t, 'g> Prover<'t, 'g> {
             let values: Vec<u8> = self.v.iter().flat_map(|s| s.to_bytes()).collect();
             let blindings: Vec<u8> = self.v_blinding.iter().flat_map(|s| s.to_bytes()).collect();
             // advisory: the return code does not matter
-            let _ = unsafe { ffi::bpr1cs_prove_prefetch(gens.0, self.transcript.h, values.as_ptr(), blindings.as_ptr(), self.v.len(), self.seed.as_ptr(), n) };
+            let _ = unsafe { ffi::bpr1cs_prove_prefetch(gens.0, self.transcript.h, values.as_ptr(), blindings.as_ptr(), self.v.len(), self.seed.as_ptr(), 1, n) };
         }
     }
 
