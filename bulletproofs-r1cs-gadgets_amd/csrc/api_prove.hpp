@@ -314,12 +314,19 @@ static int prove_job_begin(const bpr1cs_gens* g, const bpr1cs_circuit* c, const 
     // ---- P7/P8: witness (device program) or host-synthesised wires
     DevBuf<sc> px;
     if (wires) {
+        // Host wires go in on the job's witness stream, as the device program's do: the A_I1 / A_O1 sums need nothing else, so they -
+        // and the host's enqueuing of the whole back phase - no longer wait for the TranscriptRng chain on the front stream (this
+        // job's own, or one that was started ahead of the call): the heavy stream waits for the wires here and for the chain in
+        // front of S1.  (Was: upload and K_load_wires behind the chain on the front stream, then a host synchronisation.)
+        const dev_stream_t sw = job->st3;
         DevBuf<sc> raw;
-        upload_transposed(raw, wires, B, (size_t)3 * n, sl);
-        if (shared) dev_stream_wait(sl, g->w_free_ev);
-        launch((uint64_t)3 * n * B, K_load_wires{raw.p, W.p}, sl);
-        dev_zero(raw.p, raw.bytes(), sl);
-        dev_sync(sl);
+        upload_transposed(raw, wires, B, (size_t)3 * n, sw);
+        if (shared) dev_stream_wait(sw, g->w_free_ev);
+        launch((uint64_t)3 * n * B, K_load_wires{raw.p, W.p}, sw);
+        dev_zero(raw.p, raw.bytes(), sw);
+        dev_event_create(&job->ev_wit);
+        dev_event_record(job->ev_wit, sw);
+        dev_stream_wait(st, job->ev_wit);
     } else {
         K_witness kw{c->wops.p, c->lc_off.p, c->lc_var.p, c->lc_coeff.p, v_raw.p, v_m.p, W.p, B, n};
         DevBuf<uint8_t> pzf;
@@ -421,7 +428,7 @@ static int prove_job_begin(const bpr1cs_gens* g, const bpr1cs_circuit* c, const 
             finI.partial = partial.p;
             finI.nchunks = plan.nchunks;
         }
-        dev_stream_wait(st, job->ev_rng);  // (in the wires path everything on `sl` was synchronised above)
+        dev_stream_wait(st, job->ev_rng);  // the chain's draws (blindings, s_L, s_R), the transcript after the V's
         pt.mark(st);
         launch_finish(finI, B, st);
         K_msm_finish finO{g->tab.p, g->tc, partialO.p, blind.p + 1 * (size_t)B, nullptr, AOS.p + 1 * (size_t)B * 32, B, planO.nchunks, 1};
