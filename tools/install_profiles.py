@@ -20,6 +20,8 @@ for c in ("c1", "c2", "c3", "c5", "vsmt4_d128", "vsmt2_d253"):
 for c in ("c4", "c1"):
     hdr["latency_%s_one_proof_timeline.txt" % c] = "# rocprofv3 --kernel-trace -- python tools/latency_probe.py --cases %s --batches 1 --reps 3 --no-device-program ; tools/trace_lastcall.py (%s, commit %s): every launch of the last bpr1cs_prove_batch_transcripts(batch 1, host wires) call%s, then the totals per kernel\n" % (
         c, tag, commit, " (c1: the window holds the three timed calls, divide the totals by 3)" if c == "c1" else "")
+for c in ("c4", "c1"):
+    hdr["latency_%s_one_proof_call2.txt" % c] = "# the SECOND call of the same trace (tools/timeline_call.py; %s, commit %s): one proof per prove() with its TranscriptRng chain started at the gadget's first multiplier (bpr1cs_prove_prefetch, the queue beside the commitments') - runs of one kernel collapsed\n" % (tag, commit)
 names = {"ubench.txt": "ubench_gfx950.txt"}
 for f, h in hdr.items():
     p = os.path.join(src, f)
