@@ -65,11 +65,11 @@ CONFIGS = {
     "c5": dict(metric="R1CS proofs/sec (MiMC-322 preimage + set membership)", batch=8192, cpu_proofs=32, short=(4, 24), fixture="c5_mimc_set_x8192",
                workload="gadget_mimc preimage + gadget_set_membership (k = 7) on one prover (reference src/gadget_mimc.rs:92-175, src/gadget_set_membership.rs:93-171)",
                build=lambda bp, B, base, a: wl.mimc_set_membership(B, index_base=base)),
-    "vsmt4_d128": dict(metric="R1CS proofs/sec (Poseidon VSMT-4 depth-128, as shipped)", batch=1024, cpu_proofs=1, short=(2, 6), fixture="vsmt4_d128_x70",
+    "vsmt4_d128": dict(metric="R1CS proofs/sec (Poseidon VSMT-4 depth-128, as shipped)", batch=1024, cpu_proofs=1, short=(2, 6), fixture="vsmt4_d128_x70", latency_row="d128",
                        fixture_build=lambda bp: wl.vsmt4(bp, None, 128, 70, 70, 11),
                        workload="gadget_vsmt_4 at the depth the reference ships (TreeDepth = 128, src/gadget_vsmt_4.rs:25): n = 74 624, N = 131 072",
                        build=lambda bp, B, base, a: wl.vsmt4(bp, None, 128, B, B, base)),
-    "vsmt2_d253": dict(metric="R1CS proofs/sec (Poseidon VSMT-2 depth-253, as shipped)", batch=256, cpu_proofs=1, short=(4, 9), fixture="vsmt2_d253_x66",
+    "vsmt2_d253": dict(metric="R1CS proofs/sec (Poseidon VSMT-2 depth-253, as shipped)", batch=256, cpu_proofs=1, short=(4, 9), fixture="vsmt2_d253_x66", latency_row="d253",
                        fixture_build=lambda bp: wl.vsmt2(bp, None, 253, 66, b"l253", (1 << 250) - 1, 2 * 10**6),
                        workload="gadget_vsmt_2 at the depth the reference ships (TreeDepth = 253, src/gadget_vsmt_2.rs:23): n = 143 704, N = 262 144",
                        build=lambda bp, B, base, a: wl.vsmt2(bp, None, 253, B, b"l253", (1 << 250) - 1, 2 * 10**6 + base)),
@@ -152,6 +152,21 @@ PHASES = ["gadget synthesis", "V commitments + TranscriptRng", "A_I/A_O/S multis
           "IPA: L/R multiscalar mults", "IPA: generator folds (two-point Straus per element) + scalar folds"]
 
 
+def cargo_probe():
+    """SURVEY 8d / BASELINE.md 2: the reference's own Rust prover could only be timed where cargo exists - probe and record the outcome"""
+    import shutil
+    import subprocess
+    exe = shutil.which("cargo")
+    if not exe:
+        return {"cargo": None, "note": "`cargo` is not on PATH of this box: the reference (Rust; bulletproofs fork + curve25519-dalek + merlin, not vendored) "
+                                        "cannot be built here, so cpu_baseline.kind is \"port\" (oracle/c)"}
+    try:
+        r = subprocess.run([exe, "--version"], capture_output=True, text=True, timeout=20)
+        return {"cargo": (r.stdout or r.stderr).strip(), "note": "cargo is present, but the reference's git dependencies are not vendored and the box has no network: kind stays \"port\""}
+    except Exception as e:  # pragma: no cover
+        return {"cargo": None, "note": "cargo --version failed: %r" % (e,)}
+
+
 def cpu_baseline(w, n_proofs, max_threads):
     """Oracle leg, same run, same inputs, host cores of this box: the C restatement (oracle/c) proves witnesses of the batch
     (gadget synthesis + prove, the reference's timed region, e.g. src/gadget_vsmt_4.rs:421-435; generator setup excluded)
@@ -216,7 +231,7 @@ def cpu_baseline(w, n_proofs, max_threads):
     dtn = time.time() - t0
     assert all(len(d) == 32 for d in digests), "a CPU worker failed"
     tot = sum(phase) or 1.0
-    return ({"value": threads * per_worker / dtn, "unit": "proofs/s", "cores": threads, "kind": "port",
+    return ({"value": threads * per_worker / dtn, "unit": "proofs/s", "cores": threads, "kind": "port", "reference_toolchain": cargo_probe(),
              "single_thread": {"value": n_proofs / dt1, "proofs": n_proofs, "seconds": dt1,
                                "phase_seconds_per_proof": {k: v / n_proofs for k, v in zip(PHASES, phase)}},
              "cpu_model": model, "logical_cpus": logical, "usable_cpus": usable, "cgroup_cpu_quota": quota,
@@ -226,6 +241,20 @@ def cpu_baseline(w, n_proofs, max_threads):
                        "dalek-AVX2; generator setup (%.1f s) excluded"
                        % (threads * per_worker, per_worker, threads, dtn, threads * dtn, n_proofs, dt1,
                           ", ".join("%s %.0f %%" % (k, 100 * v / tot) for k, v in zip(PHASES, phase)), t_setup)}, proofs)
+
+
+def cpu_port_one_proof(w, j=0):
+    """The CPU port (oracle/c) on ONE witness of `w`, one thread: gadget synthesis + prove, generator setup excluded - the timed
+    bracket of the reference's tests (e.g. src/gadget_vsmt_4.rs:421-435).  -> (ms, proof bytes)"""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    from cref import COracle  # noqa
+    o = COracle()
+    args = wl.slice_proof(w, j)
+    shape = o.prove_case(w["gadget"], w["ip"], w["sp"], w["label"], *args, prove=False)
+    o.lib.oracle_warm_gens(1 << max(0, shape["n"] - 1).bit_length())
+    t0 = time.time()
+    proof = o.prove_case(w["gadget"], w["ip"], w["sp"], w["label"], *args)["proof"]
+    return 1e3 * (time.time() - t0), proof
 
 
 def input_digest(case):
@@ -340,14 +369,16 @@ LATENCY_SHAPE = ("the reference's own call shape - ONE proof per prove() inside 
                  "gadget_bound_check.rs:49-87, gadget_poseidon.rs:734-747): Prover::new -> commit x m -> gadget synthesis on the host -> prove(), on "
                  "generators created once outside the bracket (:386-387).  = bpr1cs_gadget_prove_on: per commit one bpr1cs_msm_fixed call, then CSR "
                  "export + bpr1cs_circuit_create (cached per description) + bpr1cs_prove_batch_transcripts(batch, HOST wires) - exactly what "
-                 "tools/rust_shim/prover.rs does for batch 1; from the second proof of a statement on, the proof's TranscriptRng chain is started at the "
-                 "gadget's first multiplier with the n of the proof before (bpr1cs_prove_prefetch; calls_with_chain_started_ahead) and runs next to the host "
-                 "synthesis - every call computes its own chain, nothing is kept between calls but that n; first_call_ms = the call without it; "
-                 "batch 8 / 64 = that many host syntheses, ONE device call.  verify_b1 = the verifier half, "
-                 "bpr1cs_gadget_verify_on: Verifier::new -> commit(V) x m -> gadget -> verify of one proof")
+                 "tools/rust_shim/prover.rs does for batch 1.  Nothing is kept between calls and nothing is speculated on: the proof's TranscriptRng "
+                 "chain (2n + 8 sequential Keccak-f[1600]) runs INSIDE the prove call on a host thread while the device takes the wires and computes "
+                 "A_I / A_O (BPR1CS_OPT_HOST_CHAIN_PROOFS; proofs_with_host_chain), so the first proof of a statement costs what every later one does "
+                 "(first_call_ms additionally pays the handle's arenas and the circuit-cache miss); batch 8 / 64 = that many host syntheses, ONE device "
+                 "call.  verify_b1 = the verifier half, bpr1cs_gadget_verify_on: Verifier::new -> commit(V) x m -> gadget -> verify of one proof.  "
+                 "d128 / d253 = the reference's literal tests: test_VSMT_4_Verif at TreeDepth = 128 (src/gadget_vsmt_4.rs:25,363-482) and test_VSMT_Verif at "
+                 "TreeDepth = 253 (src/gadget_vsmt_2.rs:23,262-399), one prove() + one verify() each, on the tables of the `configs` rows of the same depth")
 
 
-def run_latency(bp, lib, case, w, gens, fixture, batches=(1, 8, 64)):
+def run_latency(bp, lib, case, w, gens, fixture, batches=(1, 8, 64), compiled_rows=True):
     """ms per proof of `case` through the reference's call shape at batch 1 / 8 / 64 (median of a few calls each, first call
     untimed), every proof compared with the committed digest of the C oracle's proof of the same witness"""
     import statistics
@@ -356,7 +387,7 @@ def run_latency(bp, lib, case, w, gens, fixture, batches=(1, 8, 64)):
     for B in batches:
         v, b, s = w["values"][:B * m * 32], w["blindings"][:B * m * 32], w["seeds"][:B * 32]
         reps = 5 if B == 1 else (3 if B <= 8 else 2)
-        walls, stages, phases, ok, checked, ahead, first_ms = [], [], [], True, 0, 0, None
+        walls, stages, phases, ok, checked, on_host, first_ms = [], [], [], True, 0, 0, None
         for rep in range(reps + 1):
             t0 = time.perf_counter()
             P, C, sec = bp.gadget_prove_on(gens, w["gadget"], w["ip"], w["sp"], w["label"], v, b, m, B, s)
@@ -371,7 +402,7 @@ def run_latency(bp, lib, case, w, gens, fixture, batches=(1, 8, 64)):
             stages.append(sec)
             st = bp.last_prove_stats(lib)
             phases.append(st["phase_ms"])
-            ahead += st["chains_ahead"]
+            on_host += st["host_chains"]
         med = statistics.median(walls)
         k = walls.index(sorted(walls)[len(walls) // 2])
         out["b%d" % B] = {"ms_per_call": 1e3 * med, "ms_per_proof": 1e3 * med / B, "calls_timed": reps, "ms_per_call_min": 1e3 * min(walls),
@@ -380,19 +411,20 @@ def run_latency(bp, lib, case, w, gens, fixture, batches=(1, 8, 64)):
                           "parity": {"ok": ok, "proofs": checked, "calls_checked": reps + 1, "source": "tests/golden/fullsize_digests.json[%s]" % fixture}}
         if B == 1:
             out["b1"]["first_call_ms"] = first_ms
-            out["b1"]["calls_with_chain_started_ahead"] = ahead
+            out["b1"]["proofs_with_host_chain"] = on_host
         # the same witnesses through the COMPILED circuit (bpr1cs_gadget_compile once, outside the clock; the witness program runs on the
         # device, the commitments come out of the call): what a caller does that can keep a circuit handle - no host synthesis, no per-commit calls
-        circ = compiled.setdefault("c", bp.CompiledGadget(w["gadget"], w["ip"], w["sp"]))
+        circ = compiled.setdefault("c", bp.CompiledGadget(w["gadget"], w["ip"], w["sp"])) if compiled_rows else None
         cw = []
-        for rep in range(reps + 1):
+        for rep in range(reps + 1 if compiled_rows else 0):
             t0 = time.perf_counter()
             Pc, _ = bp.prove_batch(gens, circ, w["label"], v, b, s, B)
             if rep:
                 cw.append(time.perf_counter() - t0)
             else:
                 okc = all(hashlib.sha256(Pc[j]).hexdigest()[:32] == fx[j] for j in range(B))
-        out["b%d" % B]["compiled_circuit"] = {"ms_per_call": 1e3 * statistics.median(cw), "ms_per_proof": 1e3 * statistics.median(cw) / B, "parity_ok": okc}
+        if compiled_rows:
+            out["b%d" % B]["compiled_circuit"] = {"ms_per_call": 1e3 * statistics.median(cw), "ms_per_proof": 1e3 * statistics.median(cw) / B, "parity_ok": okc}
         if B == 1:   # the other half of every reference test: Verifier::new -> commit(V) x m -> gadget -> verify of that ONE proof (e.g. src/gadget_vsmt_4.rs:442-479)
             vt, vok, vst = [], True, None
             for rep in range(4):
@@ -447,6 +479,20 @@ def run_short_config(bp, lib, name, args, gens_by_cap):
         fproofs, _ = bp.prove_batch_raw(gens, fcirc, fw["label"], fw["values"], fw["blindings"], fw["seeds"], fw["B"])
         out["parity"] = fixture_parity(cfg["fixture"], fw, fproofs, fcirc.proof_len)
         fcirc.close()
+        if cfg.get("latency_row") and args.latency:
+            # the reference's literal test at this depth: ONE proof per prove() + one verify(), on these tables, against the same digests
+            gens.release_scratch()
+            out["latency"] = run_latency(bp, lib, name, fw, gens, cfg["fixture"], batches=(1,), compiled_rows=False)
+            if args.cpu_proofs != 0:
+                try:
+                    ms, cproof = cpu_port_one_proof(fw)
+                    out["latency"]["cpu_port_ms_per_proof"] = ms
+                    out["latency"]["speedup_b1_vs_cpu_port_1_thread"] = ms / out["latency"]["b1"]["ms_per_proof"]
+                    out["latency"]["cpu_port_proof_matches_fixture"] = hashlib.sha256(cproof).hexdigest()[:32] == json.load(
+                        open(os.path.join(ROOT, "tests", "golden", "fullsize_digests.json")))[cfg["fixture"]]["proofs"][0]
+                except Exception as e:  # pragma: no cover
+                    out["latency"]["cpu_port_ms_per_proof"] = None
+                    out["latency"]["cpu_port_error"] = repr(e)
     else:
         out["parity"] = fixture_parity(cfg["fixture"], w, proofs, circ.proof_len)
     circ.close()
@@ -727,6 +773,9 @@ def main():
                     blk[name] = {"error": repr(e)}
                 blk[name]["wall_s"] = time.time() - t1
             out["configs"] = blk
+            for name, row in blk.items():   # the literal reference tests of the as-shipped depths belong to the `latency` block
+                if isinstance(row, dict) and "latency" in row and isinstance(out.get("latency"), dict):
+                    out["latency"][CONFIGS[name]["latency_row"]] = row.pop("latency")
         result_line = json.dumps(out)
     else:
         result_line = None

@@ -59,16 +59,16 @@ class ProofStruct(ctypes.Structure):
 
 # options of a generator handle (include/bpr1cs.h BPR1CS_OPT_*)
 OPT_UNFOLD_ROUNDS, OPT_WITNESS_TEAM, OPT_TAIL_ROUNDS, OPT_SHARED_BACK, OPT_FACTOR_VECTORS = 0, 2, 3, 4, 5
-OPT_MSM_THREADS_LOG2, OPT_JOB_PROOFS, OPT_JOBS_IN_FLIGHT, OPT_WINDOW_BITS = 6, 7, 8, 16
+OPT_MSM_THREADS_LOG2, OPT_JOB_PROOFS, OPT_JOBS_IN_FLIGHT, OPT_HOST_CHAIN_PROOFS, OPT_WINDOW_BITS = 6, 7, 8, 9, 16
 OPTIONS = dict(unfold=OPT_UNFOLD_ROUNDS, witness_team=OPT_WITNESS_TEAM, tail_rounds=OPT_TAIL_ROUNDS, shared_back=OPT_SHARED_BACK,
                factor_vectors=OPT_FACTOR_VECTORS, msm_threads_log2=OPT_MSM_THREADS_LOG2, job_proofs=OPT_JOB_PROOFS,
-               jobs_in_flight=OPT_JOBS_IN_FLIGHT, window_bits=OPT_WINDOW_BITS)
+               jobs_in_flight=OPT_JOBS_IN_FLIGHT, host_chain_proofs=OPT_HOST_CHAIN_PROOFS, window_bits=OPT_WINDOW_BITS)
 
 
 class ProveStats(ctypes.Structure):
     """bpr1cs_prove_stats (include/bpr1cs.h)"""
     _fields_ = [("jobs", ctypes.c_uint32), ("job_proofs", ctypes.c_uint32), ("phase_ms", ctypes.c_float * 6), ("msm_ms", ctypes.c_double),
-                ("msm_launches", ctypes.c_uint64), ("msm_terms", ctypes.c_uint64), ("msm_adds", ctypes.c_uint64), ("chains_ahead", ctypes.c_uint64)]
+                ("msm_launches", ctypes.c_uint64), ("msm_terms", ctypes.c_uint64), ("msm_adds", ctypes.c_uint64), ("host_chains", ctypes.c_uint64)]
 
 
 def load_library(path=None):
@@ -111,7 +111,6 @@ def load_library(path=None):
     lib.bpr1cs_circuit_macro_perms.restype = ctypes.c_int
     lib.bpr1cs_gens_create_opts.argtypes = [u32, ctypes.POINTER(ctypes.c_int32), sz, ctypes.POINTER(vp)]
     lib.bpr1cs_prove_batch_transcripts.argtypes = [vp, vp, ctypes.POINTER(vp), sz, cp, cp, cp, cp, sz, cp, cp]
-    lib.bpr1cs_prove_prefetch.argtypes = [vp, vp, cp, cp, sz, cp, sz, ctypes.c_uint32]
     lib.bpr1cs_last_prove_stats.argtypes = [ctypes.POINTER(ProveStats)]
     lib.bpr1cs_gens_set_option.argtypes = [vp, ctypes.c_int, ctypes.c_int]
     lib.bpr1cs_gens_release_scratch.argtypes = [vp]
@@ -517,13 +516,7 @@ def last_prove_stats(lib=None):
     lib = lib or load_library()
     st = ProveStats()
     _chk(lib.bpr1cs_last_prove_stats(ctypes.byref(st)))
-    return dict(jobs=st.jobs, job_proofs=st.job_proofs, phase_ms=list(st.phase_ms), msm_ms=st.msm_ms, msm_launches=st.msm_launches, msm_terms=st.msm_terms, msm_adds=st.msm_adds, chains_ahead=st.chains_ahead)
-
-
-def prove_prefetch(gens, transcript, values, v_blindings, m, rng_seeds, n_multipliers, batch=1):
-    """bpr1cs_prove_prefetch: start the TranscriptRng chains of ONE proof (or of `batch` proofs from one transcript) ahead of the prove
-    call (advisory; returns at once)"""
-    _chk(gens.lib.bpr1cs_prove_prefetch(gens.h, transcript.h, values or b"\0", v_blindings or b"\0", m, rng_seeds, batch, n_multipliers))
+    return dict(jobs=st.jobs, job_proofs=st.job_proofs, phase_ms=list(st.phase_ms), msm_ms=st.msm_ms, msm_launches=st.msm_launches, msm_terms=st.msm_terms, msm_adds=st.msm_adds, host_chains=st.host_chains)
 
 
 def prove_batch_transcripts(gens, circuit, transcripts, values, v_blindings, rng_seeds, batch, wires=None):
@@ -592,6 +585,7 @@ def load_gadgets_library(path=None):
     g.bpr1cs_gadget_compile.argtypes = [cp, ip, sz, cp, sz, cp, sz, ctypes.POINTER(vp), ip, ip, ip, ctypes.POINTER(ctypes.c_int)]
     g.bpr1cs_gadget_prove_single.argtypes = [cp, ip, sz, cp, sz, cp, sz, u32, cp, sz, cp, cp, sz, cp, cp, sz, ctypes.POINTER(sz), cp]
     g.bpr1cs_gadget_prove_on.argtypes = [vp, cp, ip, sz, cp, sz, cp, sz, cp, sz, cp, cp, sz, sz, cp, cp, sz, ctypes.POINTER(sz), cp, ctypes.POINTER(ctypes.c_double)]
+    g.bpr1cs_gadget_prove_on_flags.argtypes = g.bpr1cs_gadget_prove_on.argtypes + [ctypes.c_uint32]
     g.bpr1cs_gadget_verify_on.argtypes = [vp, cp, ip, sz, cp, sz, cp, sz, cp, sz, cp, sz, cp, sz, ctypes.POINTER(ctypes.c_double)]
     g.bpr1cs_gadget_synthesize.argtypes = [cp, ip, sz, cp, sz, cp, sz, cp, sz, cp, sz, ip, ip]
     g.bpr1cs_gadget_verify_single.argtypes = [cp, ip, sz, cp, sz, cp, sz, u32, cp, sz, cp, sz, cp, sz]
@@ -658,9 +652,13 @@ def prove_single(name, iparams, sparams, gens_capacity, label, values, blindings
     return proof.raw[:plen.value], [comms.raw[32 * i:32 * i + 32] for i in range(m)]
 
 
-def gadget_prove_on(gens, name, iparams, sparams, label, values, blindings, m, batch, rng_seeds, glib=None):
-    """bpr1cs_gadget_prove_on: the reference's call shape (Prover::new -> commit x m -> gadget on the host -> prove) on generators
-    created once; batch > 1 = one host synthesis per witness, ONE device prove with host wires.
+GADGET_EAGER_COMMITS = 1
+
+
+def gadget_prove_on(gens, name, iparams, sparams, label, values, blindings, m, batch, rng_seeds, glib=None, eager_commits=False):
+    """bpr1cs_gadget_prove_on[_flags]: the reference's call shape (Prover::new -> commit x m -> gadget on the host -> prove) on generators
+    created once; batch > 1 = one host synthesis per witness, ONE device prove with host wires.  eager_commits: every commit() computes
+    its point at once, one device call each (upstream's signature; default: resolved after prove() from the prove call's own V's).
     -> (proofs, commitments per proof, dict of seconds: commit / gadget / circuit / prove / total)"""
     g = glib or load_gadgets_library()
     blob = poseidon_blob()
@@ -670,8 +668,9 @@ def gadget_prove_on(gens, name, iparams, sparams, label, values, blindings, m, b
     plen = ctypes.c_size_t()
     comms = ctypes.create_string_buffer(32 * max(1, m) * batch)
     sec = (ctypes.c_double * 5)()
-    _chk(g.bpr1cs_gadget_prove_on(gens.h, name.encode(), _u32arr(list(iparams)), len(iparams), sp or b"\0", len(sparams), blob, len(blob),
-                                  label, len(label), values or b"\0", blindings or b"\0", m, batch, rng_seeds, proofs, cap, ctypes.byref(plen), comms, sec))
+    _chk(g.bpr1cs_gadget_prove_on_flags(gens.h, name.encode(), _u32arr(list(iparams)), len(iparams), sp or b"\0", len(sparams), blob, len(blob),
+                                        label, len(label), values or b"\0", blindings or b"\0", m, batch, rng_seeds, proofs, cap, ctypes.byref(plen), comms, sec,
+                                        GADGET_EAGER_COMMITS if eager_commits else 0))
     n, praw, craw = plen.value, proofs.raw, comms.raw
     return ([praw[i * n:(i + 1) * n] for i in range(batch)],
             [[craw[(i * m + j) * 32:(i * m + j + 1) * 32] for j in range(m)] for i in range(batch)],

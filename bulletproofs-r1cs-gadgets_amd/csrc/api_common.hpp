@@ -49,6 +49,7 @@ struct BpOpts {
     std::atomic<int> msm_threads_log2{21}; // (chunk, proof) threads per MSM launch
     std::atomic<int> job_proofs{0};        // proofs per device job of bpr1cs_prove_batch (0: from the free memory)
     std::atomic<int> jobs_in_flight{2};
+    std::atomic<int> host_chain{-1};       // jobs of up to this many proofs run their TranscriptRng chains on host threads (-1: 4 per usable CPU; 0: never)
     int window_bits = 0;                   // creation only (0: from the free memory)
 };
 // -> false for an unknown option (or a creation-only one after creation)
@@ -62,6 +63,7 @@ static bool opt_apply(BpOpts& o, int option, int value, bool creating) {
         case BPR1CS_OPT_MSM_THREADS_LOG2: o.msm_threads_log2 = value < 0 ? 21 : (value < 16 ? 16 : (value > 26 ? 26 : value)); return true;
         case BPR1CS_OPT_JOB_PROOFS: o.job_proofs = value < 0 ? 0 : value; return true;
         case BPR1CS_OPT_JOBS_IN_FLIGHT: o.jobs_in_flight = (value == 1) ? 1 : 2; return true;
+        case BPR1CS_OPT_HOST_CHAIN_PROOFS: o.host_chain = value < 0 ? -1 : value; return true;
         case BPR1CS_OPT_WINDOW_BITS:
             if (!creating) return false;
             o.window_bits = value <= 0 ? 0 : (value < 4 ? 4 : (value > 15 ? 15 : value));   // (digits travel as sign + 15-bit magnitude: |d| <= 2^14 at W = 15)
@@ -128,24 +130,6 @@ struct bpr1cs_transcript {  // merlin::Transcript (host side)
     strobe s;
 };
 
-// The TranscriptRng chains of ONE proof (or of a small batch) started ahead of the prove call (bpr1cs_prove_prefetch): everything the chain depends on -
-// the transcript, the committed values' blindings, the 32 bytes of outside randomness - is known once the commitments are made,
-// before the gadget is synthesised on the host; its length (2n + 7 draws) is the caller's guess.  The prove call that follows on
-// the handle takes the raw draws if it presents the same inputs and the same n, and ignores them otherwise.
-struct RngPrefetch {
-    strobe init{};
-    std::vector<uint8_t> values, blindings, seed;   // B x m x 32 each and B x 32, as presented
-    uint32_t n = 0, m = 0, B = 0;
-    DevBuf<sc> v_raw, vbl_raw, blind;
-    DevBuf<uint8_t> seeds, Vcomp;
-    DevBuf<strobe> init_d, tr, rng;
-    DevBuf<uint64_t> rng_raw;                  // [2n + 7][B][8]
-    DevBuf<int> err;
-    dev_event_t done{};
-    bool have_event = false;
-    dev_stream_t st{};
-};
-
 struct bpr1cs_gens {
     uint32_t cap = 0;
     TabCfg tc{};             // fixed-base table geometry (window bits chosen at creation)
@@ -176,8 +160,6 @@ struct bpr1cs_gens {
     // pinned host block of the one-commitment call (bpr1cs_msm_fixed, batch 1, bases (B, B~)): [0, 64) value and blinding as the
     // kernel reads them, [64, 96) the compressed point as the kernel writes it; created at the first such call
     mutable uint8_t* commit_pin = nullptr;
-    mutable RngPrefetch* prefetch = nullptr;   // at most one chain running ahead (bpr1cs_prove_prefetch); taken or dropped by the next prove job
-    mutable std::vector<RngPrefetch*> parked;  // chains no job took and that were still running when their job ended: freed once they have finished
 };
 
 struct bpr1cs_circuit {

@@ -1,6 +1,7 @@
 // C ABI: the batched prover (Prover::commit x m + gadget synthesis + Prover::prove), asynchronous jobs.
 #pragma once
 #include "ipa.hpp"
+#include "host_chain.hpp"
 struct bpr1cs_job {
     const bpr1cs_gens* g = nullptr;
     dev_stream_t st{}, st2{}, st3{}, st4{};
@@ -17,8 +18,13 @@ struct bpr1cs_job {
     int slot = -1;                // the handle's job slot it holds (released with the job)
     IpaIO::TailKeep tail;         // the IPA tail's own buffers (outside the handle's shared arena)
     dev_event_t ev_in{}, ev_rng{}, ev_wit{}, ev_done{}, ev_tail{};
-    RngPrefetch* prefetch = nullptr;   // the chain that ran ahead of this job (taken or not): released with the job
-    bool prefetch_taken = false;
+    // host-side TranscriptRng chains of a small job (csrc/host_chain.hpp): pinned staging of the V commitments read back for them,
+    // of their raw draws and of the transcripts they leave; the draws are blinding material and are wiped when the job is released
+    uint8_t* h_V = nullptr;
+    uint64_t* h_raw = nullptr;
+    size_t h_raw_bytes = 0;
+    strobe* h_tr0 = nullptr;
+    bool host_chain = false;
 };
 // pinned staging buffers are cached: hipHostFree (like hipFree) synchronises the whole device, which
 // would serialise the in-flight jobs
@@ -70,28 +76,10 @@ static double dbg_ms() {
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
 }
 #define DBG_JOB(...) do { if (dbg_jobs()) { fprintf(stderr, "bpr1cs[%9.2f ms] ", dbg_ms()); fprintf(stderr, __VA_ARGS__); fputc('\n', stderr); } } while (0)
-// A chain that ran ahead: wait for it, wipe what it produced (raw blinding material, the blindings it was given) and free it.
-static void prefetch_free(RngPrefetch* pf) {
-    if (!pf) return;
-#if !defined(BPR1CS_HOSTSIM)
-    if (pf->st) {
-        (void)hipStreamSynchronize(pf->st);
-        try {
-            if (pf->rng_raw.p) dev_zero(pf->rng_raw.p, pf->rng_raw.bytes(), pf->st);
-            if (pf->rng.p) dev_zero(pf->rng.p, pf->rng.bytes(), pf->st);
-            if (pf->blind.p) dev_zero(pf->blind.p, pf->blind.bytes(), pf->st);
-            if (pf->v_raw.p) dev_zero(pf->v_raw.p, pf->v_raw.bytes(), pf->st);
-            if (pf->vbl_raw.p) dev_zero(pf->vbl_raw.p, pf->vbl_raw.bytes(), pf->st);
-            if (pf->seeds.p) dev_zero(pf->seeds.p, pf->seeds.bytes(), pf->st);
-            dev_sync(pf->st);
-        } catch (...) {}
-    }
-#endif
-    if (pf->have_event) dev_event_destroy(&pf->done);
-    if (!pf->values.empty()) memset(pf->values.data(), 0, pf->values.size());
-    if (!pf->blindings.empty()) memset(pf->blindings.data(), 0, pf->blindings.size());
-    if (!pf->seed.empty()) memset(pf->seed.data(), 0, pf->seed.size());
-    delete pf;
+// secrets in host memory: a plain memset in front of a free is a dead store the compiler may drop
+static void host_wipe(void* p, size_t n) {
+    volatile uint8_t* v = (volatile uint8_t*)p;
+    for (size_t i = 0; i < n; i++) v[i] = 0;
 }
 // wait for everything a job has enqueued and release what it holds (normal end and error paths)
 static void job_wait(bpr1cs_job* job) {
@@ -116,16 +104,10 @@ static void job_release(bpr1cs_job* job) {
     for (auto e : evs) dev_event_destroy(e);
     for (void* p : job->deferred) dev_free_now(p);
     job->deferred.clear();
-    if (job->prefetch) {
-        // a chain the job did not take may still be running (a guess of n that was too long): the caller does not wait for it
-        bool running = false;
-#if !defined(BPR1CS_HOSTSIM)
-        running = !job->prefetch_taken && job->prefetch->have_event && hipEventQuery(job->prefetch->done) == hipErrorNotReady;
-#endif
-        if (running && job->g) job->g->parked.push_back(job->prefetch);
-        else prefetch_free(job->prefetch);
-        job->prefetch = nullptr;
-    }
+    if (job->h_raw) host_wipe(job->h_raw, job->h_raw_bytes);
+    host_stage_free(job->h_raw);
+    host_stage_free(job->h_V);
+    host_stage_free(job->h_tr0);
     host_stage_free(job->h_proofs);
     host_stage_free(job->h_comms);
     host_stage_free(job->h_err);
@@ -208,9 +190,6 @@ static int prove_job_begin(const bpr1cs_gens* g, const bpr1cs_circuit* c, const 
     // priority, and never used by the other job in flight (that one has the other slot).  A stream of its own would change the
     // streams' mapping onto the few hardware queues (measured: two more streams serialised the jobs, 2540 -> 2040 proofs/s)
     job->st4 = g->jstream[slot][2];
-    // a chain that ran ahead of this call (bpr1cs_prove_prefetch) belongs to this job from here on, used or not
-    job->prefetch = g->prefetch;
-    g->prefetch = nullptr;
     Scope scope(job);
     // everything the job owns comes from its slot's arena (a smaller job reuses the blocks of a larger one before it)
     ArenaScope own_arena(&g->front[slot], true);
@@ -257,12 +236,15 @@ static int prove_job_begin(const bpr1cs_gens* g, const bpr1cs_circuit* c, const 
     DevBuf<sc> blind((size_t)8 * B), W;
     DevBuf<uint64_t> rng_raw;
     const uint32_t draws = 2 * n + 7;
+    // A small job's TranscriptRng chains run on host threads (csrc/host_chain.hpp): BPR1CS_OPT_HOST_CHAIN_PROOFS, default = jobs of up
+    // to 4 proofs per usable CPU.  One more draw travels then: the chain's first (i_bl), which the device path makes in K_transcript_init.
+    const int o_hc = g->opts.host_chain.load();
+    const bool host_chain = o_hc < 0 ? B <= 4u * host_cpu_budget() : B <= (uint32_t)o_hc;
+    job->host_chain = host_chain;
     {
         ArenaScope sh(shared ? &g->shared_front : &g->front[slot], shared);
         W.alloc((size_t)5 * n * B + 1);
-#if !defined(BPR1CS_HOSTSIM)
-        rng_raw.alloc((size_t)draws * B * 8);
-#endif
+        rng_raw.alloc((size_t)(draws + (host_chain ? 1 : 0)) * B * 8);
     }
     sc* sL = W.p + (size_t)3 * n * B;
     sc* sR = W.p + (size_t)4 * n * B;
@@ -270,54 +252,46 @@ static int prove_job_begin(const bpr1cs_gens* g, const bpr1cs_circuit* c, const 
     dev_event_create(&job->ev_in);
     dev_event_create(&job->ev_rng);
     dev_event_record(job->ev_in, sl);
-#if defined(BPR1CS_HOSTSIM)
-    (void)o_team;
-    launch_transcript(B, K_transcript_init{d_init.p, init_stride, Vcomp.p, vbl_raw.p, d_seeds.p, tr.p, blind.p, sL, sR, nullptr, B, m, n}, st);
     DevBuf<int> rng_err(1);
     dev_zero(rng_err.p, sizeof(int), sl);
-#else
-    // TranscriptRng: the sequential STROBE chain of a proof (2n + 7 draws, one Keccak-f[1600] each) runs lane-parallel - one state
-    // on 25 lanes, two proofs per wavefront (k_rng_stream) -, the wide reductions mod l of its outputs afterwards in parallel
-    DevBuf<strobe> rng(B);
-    DevBuf<int> rng_err(1);
-    dev_zero(rng_err.p, sizeof(int), sl);
-    launch_transcript(B, K_transcript_init{d_init.p, init_stride, Vcomp.p, vbl_raw.p, d_seeds.p, tr.p, blind.p, sL, sR, rng.p, B, m, n}, sl);
-    // The chain may have run ahead of this call (bpr1cs_prove_prefetch, one proof): its raw draws are this proof's if it started
-    // from the same transcript, blindings and outside randomness and was given the right n - anything else and it is ignored.
-    const RngPrefetch* pf = job->prefetch;
-    if (pf && !(B == pf->B && n_init == 1 && pf->n == n && pf->m == m && pf->have_event && memcmp(pf->init.st, init[0].st, sizeof(init[0].st)) == 0 &&
-                pf->init.pos == init[0].pos && pf->init.pos_begin == init[0].pos_begin && pf->init.cur_flags == init[0].cur_flags &&
-                memcmp(pf->seed.data(), rng_seeds, (size_t)32 * B) == 0 &&
-                (m == 0 || (memcmp(pf->values.data(), values, (size_t)32 * m * B) == 0 && memcmp(pf->blindings.data(), v_blindings, (size_t)32 * m * B) == 0))))
-        pf = nullptr;
-    DBG_JOB("begin: chain %s", pf ? "ran ahead (prefetch taken)" : (job->prefetch ? "prefetch ignored" : "starts here"));
-    job->prefetch_taken = pf != nullptr;
-    const uint64_t* raw_src = rng_raw.p;
-    if (shared) dev_stream_wait(sl, g->rng_free_ev);   // the job before has reduced (and wiped) its raw output
-    if (pf) {
-        dev_stream_wait(sl, pf->done);
-        dev_d2d(rng_err.p, pf->err.p, sizeof(int), sl);
-        raw_src = pf->rng_raw.p;
+    DevBuf<strobe> rng;
+    HostChains chains;   // (joined by its destructor on every path out of this function)
+    if (host_chain) {
+        // the chains need the V commitments (their compressed encodings are transcript messages): read them back now; the wires go
+        // in and the A_I / A_O sums run on the device while the host hashes
+        job->h_V = (uint8_t*)host_stage_alloc((size_t)B * m * 32);
+        if (m) dev_d2h_async(job->h_V, Vcomp.p, (size_t)B * m * 32, sl);
+        job->h_raw_bytes = (size_t)(draws + 1) * B * 64;
+        job->h_raw = (uint64_t*)host_stage_alloc(job->h_raw_bytes);
+        job->h_tr0 = (strobe*)host_stage_alloc((size_t)B * sizeof(strobe));
     } else {
+#if defined(BPR1CS_HOSTSIM)
+        // (the simulator runs a kernel's functor proof by proof: the whole chain inside K_transcript_init)
+        launch_transcript(B, K_transcript_init{d_init.p, init_stride, Vcomp.p, vbl_raw.p, d_seeds.p, tr.p, blind.p, sL, sR, nullptr, B, m, n}, sl);
+#else
+        // TranscriptRng on the device: the sequential STROBE chain of a proof (2n + 7 draws, one Keccak-f[1600] each) runs lane-parallel -
+        // one state on 25 lanes, two proofs per wavefront (k_rng_stream) -, the wide reductions mod l of its outputs afterwards in
+        // parallel.  Hidden behind the sums of the job before this one when a batch is cut into jobs.
+        rng.alloc(B);
+        launch_transcript(B, K_transcript_init{d_init.p, init_stride, Vcomp.p, vbl_raw.p, d_seeds.p, tr.p, blind.p, sL, sR, rng.p, B, m, n}, sl);
+        if (shared) dev_stream_wait(sl, g->rng_free_ev);   // the job before has reduced (and wiped) its raw output
         hipLaunchKernelGGL(k_rng_stream, dim3((B + 1) / 2), dim3(64), 0, sl, rng.p, rng_raw.p, rng_err.p, B, draws);
         HIPCHK(hipGetLastError());
-    }
-    if (shared) dev_stream_wait(sl, g->w_free_ev);     // s_L / s_R live in W: the job before is past its l(x), r(x)
-    launch((uint64_t)draws * B, K_rng_reduce{raw_src, blind.p, sL, sR, B, n}, sl);
-    if (pf) dev_zero(pf->rng_raw.p, pf->rng_raw.bytes(), sl);
-    dev_zero(rng_raw.p, rng_raw.bytes(), sl);  // raw blinding material
-    dev_zero(rng.p, rng.bytes(), sl);
-    if (shared) dev_event_record(g->rng_free_ev, sl);
+        if (shared) dev_stream_wait(sl, g->w_free_ev);     // s_L / s_R live in W: the job before is past its l(x), r(x)
+        launch((uint64_t)draws * B, K_rng_reduce{rng_raw.p, blind.p, sL, sR, B, n, 0u}, sl);
+        dev_zero(rng_raw.p, rng_raw.bytes(), sl);  // raw blinding material
+        dev_zero(rng.p, rng.bytes(), sl);
+        if (shared) dev_event_record(g->rng_free_ev, sl);
 #endif
-    dev_event_record(job->ev_rng, sl);
+        dev_event_record(job->ev_rng, sl);
+    }
 
     // ---- P7/P8: witness (device program) or host-synthesised wires
     DevBuf<sc> px;
     if (wires) {
         // Host wires go in on the job's witness stream, as the device program's do: the A_I1 / A_O1 sums need nothing else, so they -
-        // and the host's enqueuing of the whole back phase - no longer wait for the TranscriptRng chain on the front stream (this
-        // job's own, or one that was started ahead of the call): the heavy stream waits for the wires here and for the chain in
-        // front of S1.  (Was: upload and K_load_wires behind the chain on the front stream, then a host synchronisation.)
+        // and the host's enqueuing of the whole back phase - do not wait for the TranscriptRng chain: the heavy stream waits for the
+        // wires here and for the chain in front of S1.
         const dev_stream_t sw = job->st3;
         DevBuf<sc> raw;
         upload_transposed(raw, wires, B, (size_t)3 * n, sw);
@@ -337,6 +311,7 @@ static int prove_job_begin(const bpr1cs_gens* g, const bpr1cs_circuit* c, const 
             kw.px = px.p; kw.pzf = pzf.p; kw.px_stride = c->px_stride;
         }
 #if defined(BPR1CS_HOSTSIM)
+        (void)o_team;
         launch(B, kw, st);
 #else
         int T = o_team;
@@ -354,6 +329,25 @@ static int prove_job_begin(const bpr1cs_gens* g, const bpr1cs_circuit* c, const 
         dev_stream_wait(st, job->ev_wit);
 #endif
     }
+    if (host_chain) {
+        dev_sync(sl);   // the V commitments are on the host
+        DBG_JOB("begin: %u host chain(s) start", B);
+        chains.start(init, n_init, job->h_V, v_blindings, rng_seeds, B, m, n, job->h_tr0, job->h_raw);
+    }
+    // the chains' end of the hand-over: called where the heavy stream is about to wait for the draws (in front of S1)
+    auto finish_host_chains = [&]() {
+        if (!host_chain) return;
+        chains.wait();
+        DBG_JOB("begin: host chain(s) done");
+        dev_h2d_async(tr.p, job->h_tr0, (size_t)B * sizeof(strobe), sl);
+        if (shared) dev_stream_wait(sl, g->rng_free_ev);
+        dev_h2d_async(rng_raw.p, job->h_raw, job->h_raw_bytes, sl);
+        if (shared) dev_stream_wait(sl, g->w_free_ev);
+        launch((uint64_t)(draws + 1) * B, K_rng_reduce{rng_raw.p, blind.p, sL, sR, B, n, 1u}, sl);
+        dev_zero(rng_raw.p, rng_raw.bytes(), sl);
+        if (shared) dev_event_record(g->rng_free_ev, sl);
+        dev_event_record(job->ev_rng, sl);
+    };
     DBG_JOB("begin: front enqueued");
     // ---- P2: A_I1, A_O1, S1.  The sums of A_I1 and A_O1 need the wires only, so they are enqueued BEFORE the heavy stream
     // waits for the TranscriptRng chain (the longer of the two front kernels); their blinding terms and all of S1 follow it.
@@ -428,6 +422,7 @@ static int prove_job_begin(const bpr1cs_gens* g, const bpr1cs_circuit* c, const 
             finI.partial = partial.p;
             finI.nchunks = plan.nchunks;
         }
+        finish_host_chains();
         dev_stream_wait(st, job->ev_rng);  // the chain's draws (blindings, s_L, s_R), the transcript after the V's
         pt.mark(st);
         launch_finish(finI, B, st);
@@ -580,7 +575,7 @@ static int prove_job_end(bpr1cs_job* job, uint8_t* proofs_out, uint8_t* commitme
             if (job->B > acc->job_proofs) acc->job_proofs = job->B;
             for (int i = 0; i < 6; i++) acc->phase_ms[i] += ph[i];
             acc->msm_ms += job->msm.ms; acc->msm_launches += job->msm.launches; acc->msm_terms += job->msm.terms; acc->msm_adds += job->msm.adds;
-            if (job->prefetch_taken) acc->chains_ahead += job->B;
+            if (job->host_chain) acc->host_chains += job->B;
         }
     }
     job_release(job);
@@ -764,67 +759,6 @@ int bpr1cs_prove_batch_transcripts(const bpr1cs_gens* g, const bpr1cs_circuit* c
         return prove_batch_impl(g, c, init.data(), n_transcripts, n_transcripts == batch ? transcripts : nullptr, values, v_blindings, rng_seeds, wires,
                                 batch, proofs_out, commitments_out);
     } catch (const std::bad_alloc&) { return BPR1CS_ERR_OUT_OF_MEMORY; }
-}
-int bpr1cs_prove_prefetch(const bpr1cs_gens* g, const bpr1cs_transcript* transcript, const uint8_t* values, const uint8_t* v_blindings, size_t m,
-                          const uint8_t* rng_seeds, size_t batch, uint32_t n_multipliers) {
-    if (!g || !transcript || !rng_seeds || batch == 0 || batch > (1u << 20) || (m && (!values || !v_blindings)) || m > (1u << 20) ||
-        n_multipliers == 0 || n_multipliers > (1u << 24))
-        return BPR1CS_ERR_INVALID_ARGUMENT;
-    if (!have_device()) return BPR1CS_ERR_NO_DEVICE;
-    if (m && (!host_scalars_canonical(values, batch * m) || !host_scalars_canonical(v_blindings, batch * m))) return BPR1CS_ERR_INVALID_ARGUMENT;
-#if defined(BPR1CS_HOSTSIM)
-    return BPR1CS_OK;   // the simulator is synchronous: nothing can run ahead
-#else
-    if (g->in_flight.load() != 0) return BPR1CS_OK;   // a job of the handle is in flight: no chain beside it (the prove call starts its own)
-    if (batch > 256) return BPR1CS_OK;                // the throughput path hides the chain behind the job before: nothing to gain
-    RngPrefetch* pf = nullptr;
-    try {
-        if (g->prefetch) { prefetch_free(g->prefetch); g->prefetch = nullptr; }
-        for (size_t i = 0; i < g->parked.size();) {   // chains nobody took: gone once they have run out
-            if (hipEventQuery(g->parked[i]->done) != hipErrorNotReady) { prefetch_free(g->parked[i]); g->parked.erase(g->parked.begin() + i); }
-            else i++;
-        }
-        pf = new RngPrefetch();
-        const uint32_t B = (uint32_t)batch, n = n_multipliers, mm = (uint32_t)m, draws = 2 * n + 7;
-        pf->init = transcript->s;
-        if (m) {
-            pf->values.assign(values, values + 32 * m * batch);
-            pf->blindings.assign(v_blindings, v_blindings + 32 * m * batch);
-        }
-        pf->seed.assign(rng_seeds, rng_seeds + 32 * batch);
-        pf->n = n; pf->m = mm; pf->B = B;
-        // the front stream of the job slot the next synchronous call does NOT take (slot 0): idle, high priority
-        const dev_stream_t st = g->jstream[1][1];
-        pf->st = st;
-        upload_transposed(pf->v_raw, values, B, m, st);
-        upload_transposed(pf->vbl_raw, v_blindings, B, m, st);
-        pf->seeds.alloc((size_t)32 * B);
-        dev_h2d(pf->seeds.p, rng_seeds, (size_t)32 * B, st);
-        pf->init_d.alloc(1);
-        dev_h2d(pf->init_d.p, &pf->init, sizeof(strobe), st);
-        pf->Vcomp.alloc((size_t)B * mm * 32 + 1);
-        pf->tr.alloc(B); pf->rng.alloc(B); pf->blind.alloc((size_t)8 * B); pf->err.alloc(1);
-        pf->rng_raw.alloc((size_t)draws * B * 8);
-        if (mm) {
-            if ((uint64_t)mm * B <= 256) {
-                hipLaunchKernelGGL(k_commit_wave, dim3(mm * B), dim3(64), 0, st, (const uint8_t*)g->tab.p, g->tc, (const sc*)pf->v_raw.p, (const sc*)pf->vbl_raw.p, pf->Vcomp.p, B, mm);
-                HIPCHK(hipGetLastError());
-            } else launch((uint64_t)mm * B, K_commit_v{g->tab.p, g->tc, pf->v_raw.p, pf->vbl_raw.p, pf->Vcomp.p, B, mm}, st);
-        }
-        dev_zero(pf->err.p, sizeof(int), st);
-        launch_transcript(B, K_transcript_init{pf->init_d.p, 0u, pf->Vcomp.p, pf->vbl_raw.p, pf->seeds.p, pf->tr.p, pf->blind.p, nullptr, nullptr, pf->rng.p, B, mm, n}, st);
-        hipLaunchKernelGGL(k_rng_stream, dim3((B + 1) / 2), dim3(64), 0, st, (const strobe*)pf->rng.p, pf->rng_raw.p, pf->err.p, B, draws);
-        HIPCHK(hipGetLastError());
-        dev_event_create(&pf->done);
-        pf->have_event = true;
-        dev_event_record(pf->done, st);
-        g->prefetch = pf;
-        return BPR1CS_OK;
-    }
-    catch (const DevError& e_) { prefetch_free(pf); return e_.code; }
-    catch (const std::bad_alloc&) { prefetch_free(pf); return BPR1CS_ERR_OUT_OF_MEMORY; }
-    catch (...) { prefetch_free(pf); return BPR1CS_ERR_DEVICE; }
-#endif
 }
 int bpr1cs_last_prove_stats(bpr1cs_prove_stats* out) {
     if (!out) return BPR1CS_ERR_INVALID_ARGUMENT;

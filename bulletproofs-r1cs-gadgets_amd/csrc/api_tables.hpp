@@ -53,7 +53,6 @@ int bpr1cs_release_cached_memory(void) {
 }
 void bpr1cs_gens_destroy(bpr1cs_gens* g);
 static void host_stage_free(void* p);
-static void prefetch_free(RngPrefetch* pf);
 int bpr1cs_gens_create_opts(uint32_t cap, const int32_t* pairs, size_t n_pairs, bpr1cs_gens** out) {
     if (!out || cap == 0 || (n_pairs && !pairs)) return BPR1CS_ERR_INVALID_ARGUMENT;
     if (!have_device()) return BPR1CS_ERR_NO_DEVICE;
@@ -138,9 +137,6 @@ void bpr1cs_gens_destroy(bpr1cs_gens* g) {
     dev_event_destroy(&g->w_free_ev);
     dev_event_destroy(&g->rng_free_ev);
     if (g->commit_pin) { host_stage_free(g->commit_pin); g->commit_pin = nullptr; }
-    if (g->prefetch) { prefetch_free(g->prefetch); g->prefetch = nullptr; }
-    for (RngPrefetch* pf : g->parked) prefetch_free(pf);
-    g->parked.clear();
 #if !defined(BPR1CS_HOSTSIM)
     if (g->stream) (void)hipStreamDestroy(g->stream);
     for (int a = 0; a < 2; a++)

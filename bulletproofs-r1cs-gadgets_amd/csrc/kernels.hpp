@@ -285,16 +285,27 @@ struct K_transcript_init {
         for (int k = 3; k < 8; k++) blind[(size_t)k * B + b] = merlin_rng_scalar(r);
     }
 };
-// raw 64-byte RNG outputs (draw d >= 1 of the stream, proof b) -> Montgomery scalars in their slots
-struct K_rng_reduce {  // gid = d*B + b, d < 2n+7 : o_bl, s_bl, s_L[n], s_R[n], t1 t3 t4 t5 t6 blindings
-    const uint64_t* raw;  // [2n+7][B][8]
+// raw 64-byte RNG outputs -> Montgomery scalars in their slots.  lead = 0: draws d >= 1 of the stream as k_rng_stream writes them,
+// [2n+7][B][8] words, gid = d*B + b.  lead = 1: all 2n+8 draws of chains that ran on host threads (csrc/host_chain.hpp), one proof's
+// draws after the other's - [B][2n+8][8] words, gid = b*(2n+8) + d: a thread per proof writes its own run of cache lines
+struct K_rng_reduce {  // [i_bl,] o_bl, s_bl, s_L[n], s_R[n], t1 t3 t4 t5 t6 blindings
+    const uint64_t* raw;
     sc* blind;
     sc* sL;
     sc* sR;
-    uint32_t B, n;
+    uint32_t B, n, lead;
     HD void operator()(uint32_t g) const {
-        uint32_t d = g / B, b = g % B;
+        uint32_t d, b;
+        if (lead) {
+            b = g / (2 * n + 8); d = g % (2 * n + 8);
+        } else {
+            d = g / B; b = g % B;
+        }
         sc x = sc_mont_from_wide_lanes(raw + (size_t)g * 8);
+        if (lead) {
+            if (d == 0) { blind[b] = x; return; }
+            d -= 1;
+        }
         if (d < 2) blind[(size_t)(1 + d) * B + b] = x;
         else if (d < 2 + n) sL[(size_t)(d - 2) * B + b] = x;
         else if (d < 2 + 2 * n) sR[(size_t)(d - 2 - n) * B + b] = x;

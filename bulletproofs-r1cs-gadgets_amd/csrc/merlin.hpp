@@ -64,42 +64,70 @@ __device__ inline void keccak_f1600_lockstep(uint64_t* s) {
 }
 #endif
 
+// The 24 rounds on 25 local words (the compiler keeps them in registers): ONE body for the device's one-lane form and for the host.
+#define KECCAK_F1600_BODY(s)                                                                                                              \
+    uint64_t a00 = s[0], a01 = s[1], a02 = s[2], a03 = s[3], a04 = s[4];                                                                  \
+    uint64_t a05 = s[5], a06 = s[6], a07 = s[7], a08 = s[8], a09 = s[9];                                                                  \
+    uint64_t a10 = s[10], a11 = s[11], a12 = s[12], a13 = s[13], a14 = s[14];                                                             \
+    uint64_t a15 = s[15], a16 = s[16], a17 = s[17], a18 = s[18], a19 = s[19];                                                             \
+    uint64_t a20 = s[20], a21 = s[21], a22 = s[22], a23 = s[23], a24 = s[24];                                                             \
+    for (int r = 0; r < 24; r++) {                                                                                                        \
+        uint64_t c0 = a00 ^ a05 ^ a10 ^ a15 ^ a20, c1 = a01 ^ a06 ^ a11 ^ a16 ^ a21;                                                      \
+        uint64_t c2 = a02 ^ a07 ^ a12 ^ a17 ^ a22, c3 = a03 ^ a08 ^ a13 ^ a18 ^ a23;                                                      \
+        uint64_t c4 = a04 ^ a09 ^ a14 ^ a19 ^ a24;                                                                                        \
+        uint64_t d0 = c4 ^ rol64(c1, 1), d1 = c0 ^ rol64(c2, 1), d2 = c1 ^ rol64(c3, 1);                                                  \
+        uint64_t d3 = c2 ^ rol64(c4, 1), d4 = c3 ^ rol64(c0, 1);                                                                          \
+        a00 ^= d0; a05 ^= d0; a10 ^= d0; a15 ^= d0; a20 ^= d0;                                                                            \
+        a01 ^= d1; a06 ^= d1; a11 ^= d1; a16 ^= d1; a21 ^= d1;                                                                            \
+        a02 ^= d2; a07 ^= d2; a12 ^= d2; a17 ^= d2; a22 ^= d2;                                                                            \
+        a03 ^= d3; a08 ^= d3; a13 ^= d3; a18 ^= d3; a23 ^= d3;                                                                            \
+        a04 ^= d4; a09 ^= d4; a14 ^= d4; a19 ^= d4; a24 ^= d4;                                                                            \
+        /* rho + pi : B[y][2x+3y] = rol(A[x][y], r[x][y]);  index = x + 5y */                                                             \
+        uint64_t b00 = a00,             b10 = rol64(a01, 1),  b20 = rol64(a02, 62), b05 = rol64(a03, 28), b15 = rol64(a04, 27);           \
+        uint64_t b16 = rol64(a05, 36), b01 = rol64(a06, 44), b11 = rol64(a07, 6),  b21 = rol64(a08, 55), b06 = rol64(a09, 20);            \
+        uint64_t b07 = rol64(a10, 3),  b17 = rol64(a11, 10), b02 = rol64(a12, 43), b12 = rol64(a13, 25), b22 = rol64(a14, 39);            \
+        uint64_t b23 = rol64(a15, 41), b08 = rol64(a16, 45), b18 = rol64(a17, 15), b03 = rol64(a18, 21), b13 = rol64(a19, 8);             \
+        uint64_t b14 = rol64(a20, 18), b24 = rol64(a21, 2),  b09 = rol64(a22, 61), b19 = rol64(a23, 56), b04 = rol64(a24, 14);            \
+        a00 = b00 ^ (~b01 & b02); a01 = b01 ^ (~b02 & b03); a02 = b02 ^ (~b03 & b04); a03 = b03 ^ (~b04 & b00); a04 = b04 ^ (~b00 & b01); \
+        a05 = b05 ^ (~b06 & b07); a06 = b06 ^ (~b07 & b08); a07 = b07 ^ (~b08 & b09); a08 = b08 ^ (~b09 & b05); a09 = b09 ^ (~b05 & b06); \
+        a10 = b10 ^ (~b11 & b12); a11 = b11 ^ (~b12 & b13); a12 = b12 ^ (~b13 & b14); a13 = b13 ^ (~b14 & b10); a14 = b14 ^ (~b10 & b11); \
+        a15 = b15 ^ (~b16 & b17); a16 = b16 ^ (~b17 & b18); a17 = b17 ^ (~b18 & b19); a18 = b18 ^ (~b19 & b15); a19 = b19 ^ (~b15 & b16); \
+        a20 = b20 ^ (~b21 & b22); a21 = b21 ^ (~b22 & b23); a22 = b22 ^ (~b23 & b24); a23 = b23 ^ (~b24 & b20); a24 = b24 ^ (~b20 & b21); \
+        a00 ^= KECCAK_RC[r];                                                                                                              \
+    }                                                                                                                                     \
+    s[0] = a00; s[1] = a01; s[2] = a02; s[3] = a03; s[4] = a04; s[5] = a05; s[6] = a06; s[7] = a07; s[8] = a08; s[9] = a09;               \
+    s[10] = a10; s[11] = a11; s[12] = a12; s[13] = a13; s[14] = a14; s[15] = a15; s[16] = a16; s[17] = a17; s[18] = a18; s[19] = a19;     \
+    s[20] = a20; s[21] = a21; s[22] = a22; s[23] = a23; s[24] = a24;
+
+// Host side (the library's own merlin::Transcript behind bpr1cs_transcript_*, and - csrc/host_chain.hpp - the TranscriptRng chain of
+// a small job: 2n + 8 strictly sequential permutations per proof, which one x86-64 core runs in 0.15-0.3 us each where the lane-parallel
+// device kernel needs 2.5): the same rounds compiled once for the baseline ISA and once with BMI (andn: chi without the 25 NOTs),
+// chosen once per process by what the CPU reports.
+#if !defined(__HIP_DEVICE_COMPILE__)
+#if defined(__x86_64__)
+__attribute__((target("bmi,bmi2"))) inline void keccak_f1600_host_bmi(uint64_t* s) { KECCAK_F1600_BODY(s) }
+#endif
+inline void keccak_f1600_host_generic(uint64_t* s) { KECCAK_F1600_BODY(s) }
+typedef void (*keccak_host_fn)(uint64_t*);
+inline keccak_host_fn keccak_host_select() {
+#if defined(__x86_64__)
+    if (__builtin_cpu_supports("bmi") && __builtin_cpu_supports("bmi2")) return keccak_f1600_host_bmi;
+#endif
+    return keccak_f1600_host_generic;
+}
+inline void keccak_f1600_host(uint64_t* s) {
+    static const keccak_host_fn fn = keccak_host_select();
+    fn(s);
+}
+#endif
+
 HD inline void keccak_f1600(uint64_t* s) {
 #if defined(__HIP_DEVICE_COMPILE__)
     if (keccak_lockstep_launch()) { keccak_f1600_lockstep(s); return; }
+    KECCAK_F1600_BODY(s)
+#else
+    keccak_f1600_host(s);
 #endif
-    uint64_t a00 = s[0], a01 = s[1], a02 = s[2], a03 = s[3], a04 = s[4];
-    uint64_t a05 = s[5], a06 = s[6], a07 = s[7], a08 = s[8], a09 = s[9];
-    uint64_t a10 = s[10], a11 = s[11], a12 = s[12], a13 = s[13], a14 = s[14];
-    uint64_t a15 = s[15], a16 = s[16], a17 = s[17], a18 = s[18], a19 = s[19];
-    uint64_t a20 = s[20], a21 = s[21], a22 = s[22], a23 = s[23], a24 = s[24];
-    for (int r = 0; r < 24; r++) {
-        uint64_t c0 = a00 ^ a05 ^ a10 ^ a15 ^ a20, c1 = a01 ^ a06 ^ a11 ^ a16 ^ a21;
-        uint64_t c2 = a02 ^ a07 ^ a12 ^ a17 ^ a22, c3 = a03 ^ a08 ^ a13 ^ a18 ^ a23;
-        uint64_t c4 = a04 ^ a09 ^ a14 ^ a19 ^ a24;
-        uint64_t d0 = c4 ^ rol64(c1, 1), d1 = c0 ^ rol64(c2, 1), d2 = c1 ^ rol64(c3, 1);
-        uint64_t d3 = c2 ^ rol64(c4, 1), d4 = c3 ^ rol64(c0, 1);
-        a00 ^= d0; a05 ^= d0; a10 ^= d0; a15 ^= d0; a20 ^= d0;
-        a01 ^= d1; a06 ^= d1; a11 ^= d1; a16 ^= d1; a21 ^= d1;
-        a02 ^= d2; a07 ^= d2; a12 ^= d2; a17 ^= d2; a22 ^= d2;
-        a03 ^= d3; a08 ^= d3; a13 ^= d3; a18 ^= d3; a23 ^= d3;
-        a04 ^= d4; a09 ^= d4; a14 ^= d4; a19 ^= d4; a24 ^= d4;
-        // rho + pi : B[y][2x+3y] = rol(A[x][y], r[x][y]);  index = x + 5y
-        uint64_t b00 = a00,             b10 = rol64(a01, 1),  b20 = rol64(a02, 62), b05 = rol64(a03, 28), b15 = rol64(a04, 27);
-        uint64_t b16 = rol64(a05, 36), b01 = rol64(a06, 44), b11 = rol64(a07, 6),  b21 = rol64(a08, 55), b06 = rol64(a09, 20);
-        uint64_t b07 = rol64(a10, 3),  b17 = rol64(a11, 10), b02 = rol64(a12, 43), b12 = rol64(a13, 25), b22 = rol64(a14, 39);
-        uint64_t b23 = rol64(a15, 41), b08 = rol64(a16, 45), b18 = rol64(a17, 15), b03 = rol64(a18, 21), b13 = rol64(a19, 8);
-        uint64_t b14 = rol64(a20, 18), b24 = rol64(a21, 2),  b09 = rol64(a22, 61), b19 = rol64(a23, 56), b04 = rol64(a24, 14);
-        a00 = b00 ^ (~b01 & b02); a01 = b01 ^ (~b02 & b03); a02 = b02 ^ (~b03 & b04); a03 = b03 ^ (~b04 & b00); a04 = b04 ^ (~b00 & b01);
-        a05 = b05 ^ (~b06 & b07); a06 = b06 ^ (~b07 & b08); a07 = b07 ^ (~b08 & b09); a08 = b08 ^ (~b09 & b05); a09 = b09 ^ (~b05 & b06);
-        a10 = b10 ^ (~b11 & b12); a11 = b11 ^ (~b12 & b13); a12 = b12 ^ (~b13 & b14); a13 = b13 ^ (~b14 & b10); a14 = b14 ^ (~b10 & b11);
-        a15 = b15 ^ (~b16 & b17); a16 = b16 ^ (~b17 & b18); a17 = b17 ^ (~b18 & b19); a18 = b18 ^ (~b19 & b15); a19 = b19 ^ (~b15 & b16);
-        a20 = b20 ^ (~b21 & b22); a21 = b21 ^ (~b22 & b23); a22 = b22 ^ (~b23 & b24); a23 = b23 ^ (~b24 & b20); a24 = b24 ^ (~b20 & b21);
-        a00 ^= KECCAK_RC[r];
-    }
-    s[0] = a00; s[1] = a01; s[2] = a02; s[3] = a03; s[4] = a04; s[5] = a05; s[6] = a06; s[7] = a07; s[8] = a08; s[9] = a09;
-    s[10] = a10; s[11] = a11; s[12] = a12; s[13] = a13; s[14] = a14; s[15] = a15; s[16] = a16; s[17] = a17; s[18] = a18; s[19] = a19;
-    s[20] = a20; s[21] = a21; s[22] = a22; s[23] = a23; s[24] = a24;
 }
 
 // ---------------------------------------------------------------- STROBE-128
@@ -305,4 +333,26 @@ HD inline sc merlin_rng_scalar(strobe& s) {
     uint8_t buf[64];
     merlin_rng_fill(s, buf, 64);
     return sc_mont_from_wide(buf);
+}
+// The same draw as its 64 raw bytes (8 little-endian words), not yet reduced mod l: what k_rng_stream writes per draw and K_rng_reduce
+// reads - for the host-side chain of a small job (csrc/host_chain.hpp).
+HD inline void merlin_rng_raw(strobe& s, uint64_t out[8]) {
+    if (s.pos == 64 && s.pos_begin == 0) {
+        s.st[8] ^= 0x0741000000401200ull;
+        s.st[9] ^= 0x0000000000000447ull;
+        s.st[20] ^= 0x8000000000000000ull;
+        keccak_f1600(s.st);
+#pragma unroll
+        for (int k = 0; k < 8; k++) { out[k] = s.st[k]; s.st[k] = 0; }
+        s.cur_flags = SFLAG_I | SFLAG_A | SFLAG_C;
+        return;
+    }
+    uint8_t buf[64];
+    merlin_rng_fill(s, buf, 64);
+    for (int k = 0; k < 8; k++) {
+        uint64_t w = 0;
+        for (int i = 0; i < 8; i++) w |= (uint64_t)buf[8 * k + i] << (8 * i);
+        out[k] = w;
+    }
+    for (int i = 0; i < 64; i++) ((volatile uint8_t*)buf)[i] = 0;
 }

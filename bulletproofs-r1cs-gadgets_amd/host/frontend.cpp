@@ -61,17 +61,14 @@ R1CSProof Prover::prove(const BulletproofGens& bp_gens) {
         std::random_device rd;  // stands in for rand::thread_rng()
         for (auto& x : seed) x = (uint8_t)rd();
     }
-    std::vector<uint8_t> bytes(bpr1cs_proof_len(c));
+    std::vector<uint8_t> bytes(bpr1cs_proof_len(c)), comm_bytes(32 * m + 1);
     bpr1cs_transcript* ts[1] = {transcript.h};
-    rc = bpr1cs_prove_batch_transcripts(bp_gens.h, c, ts, 1, vals.data(), bls.data(), seed.data(), wires.data(), 1, bytes.data(), nullptr);
+    rc = bpr1cs_prove_batch_transcripts(bp_gens.h, c, ts, 1, vals.data(), bls.data(), seed.data(), wires.data(), 1, bytes.data(), comm_bytes.data());
+    if (rc == 0 && ledger && !defer_commitments) ledger->fill(comm_bytes.data(), m);   // commitments nobody has read yet: the job computed them
     transcript.fresh = false;
     bpr1cs_circuit_destroy(c);
     if (seconds) { seconds[0] += t1 - t0; seconds[1] += now_s() - t1; }
     if (rc) throw R1CSError::Backend(rc);
-    if (!defer_commitments && n) {   // the next proof with this label and this many commitments starts its chain ahead (chain_ahead)
-        std::lock_guard<std::mutex> lk(hint_mu());
-        n_hints()[{transcript.label, m}] = (uint32_t)n;
-    }
     return R1CSProof::from_bytes(bytes);
 }
 
@@ -423,7 +420,7 @@ int bpr1cs_gadget_prove_single(const char* gadget, const uint32_t* iparams, size
             vals.push_back(Scalar::from_bytes_mod_order(values + 32 * i));
             bls.push_back(Scalar::from_bytes_mod_order(v_blindings + 32 * i));
         }
-        std::vector<CompressedRistretto> comms;
+        std::vector<Commitment> comms;   // (read after prove(): the prove call's own V's, no device call per commitment)
         Harness h{prover,
                   [&](size_t k) {
                       if (k >= m) throw R1CSError::MissingAssignment();
@@ -460,6 +457,13 @@ int bpr1cs_gadget_prove_on(const bpr1cs_gens* gens, const char* gadget, const ui
                            size_t n_sparams, const uint8_t* poseidon_blob, size_t blob_len, const uint8_t* label, size_t label_len,
                            const uint8_t* values, const uint8_t* v_blindings, size_t m, size_t batch, const uint8_t* rng_seeds,
                            uint8_t* proofs_out, size_t proof_cap, size_t* proof_len, uint8_t* commitments_out, double seconds_out[5]) {
+    return bpr1cs_gadget_prove_on_flags(gens, gadget, iparams, n_iparams, sparams, n_sparams, poseidon_blob, blob_len, label, label_len, values, v_blindings, m,
+                                        batch, rng_seeds, proofs_out, proof_cap, proof_len, commitments_out, seconds_out, 0);
+}
+int bpr1cs_gadget_prove_on_flags(const bpr1cs_gens* gens, const char* gadget, const uint32_t* iparams, size_t n_iparams, const uint8_t* sparams,
+                                 size_t n_sparams, const uint8_t* poseidon_blob, size_t blob_len, const uint8_t* label, size_t label_len,
+                                 const uint8_t* values, const uint8_t* v_blindings, size_t m, size_t batch, const uint8_t* rng_seeds,
+                                 uint8_t* proofs_out, size_t proof_cap, size_t* proof_len, uint8_t* commitments_out, double seconds_out[5], uint32_t flags) {
     if (!gens || !gadget || !label || !rng_seeds || !proofs_out || !proof_len || batch == 0 || (m && (!values || !v_blindings))) return BPR1CS_ERR_INVALID_ARGUMENT;
     double sec[5] = {0, 0, 0, 0, 0};
     const double t_start = now_s();
@@ -468,7 +472,7 @@ int bpr1cs_gadget_prove_on(const bpr1cs_gens* gens, const char* gadget, const ui
         BulletproofGens bp_gens(const_cast<bpr1cs_gens*>(gens), BulletproofGens::Borrowed{});
         PedersenGens pc_gens(bp_gens);
         std::mutex sec_mu;
-        auto synth = [&](Prover& prover, size_t b, std::vector<CompressedRistretto>* comms) {
+        auto synth = [&](Prover& prover, size_t b, std::vector<Commitment>* comms) {
             std::vector<Scalar> vals;
             for (size_t i = 0; i < m; i++) vals.push_back(Scalar::from_bytes_mod_order(values + 32 * (b * m + i)));
             double t_commit = 0;
@@ -492,10 +496,11 @@ int bpr1cs_gadget_prove_on(const bpr1cs_gens* gens, const char* gadget, const ui
         if (batch == 1) {
             Transcript t((const char*)label, label_len);
             Prover prover(pc_gens, t);
-            std::vector<CompressedRistretto> comms;
+            prover.eager_commitments = (flags & BPR1CS_GADGET_EAGER_COMMITS) != 0;
+            std::vector<Commitment> comms;
             std::array<uint8_t, 32> seed;
             memcpy(seed.data(), rng_seeds, 32);
-            prover.set_rng_seed(seed);   // (before the synthesis: the chain that runs ahead of prove() needs it)
+            prover.set_rng_seed(seed);
             synth(prover, 0, &comms);
             prover.seconds = sec + 2;
             std::vector<uint8_t> bytes = prover.prove(bp_gens).to_bytes();
@@ -506,25 +511,13 @@ int bpr1cs_gadget_prove_on(const bpr1cs_gens* gens, const char* gadget, const ui
                 for (size_t i = 0; i < comms.size(); i++) memcpy(commitments_out + 32 * i, comms[i].data(), 32);
         } else {
             // The witnesses are independent: their host syntheses run on a few threads (one Prover each; nothing of it touches the
-            // device - the commitments are deferred to the one prove call).  Witness 0 first, alone: it also yields the circuit.
+            // device - the commitments are deferred to the one prove call).  Witness 0 also yields the circuit (the constraint system
+            // does not depend on the witness); the others' shapes are checked against it afterwards.
             std::vector<uint8_t> vals, bls, wires;
             bpr1cs_circuit* c = nullptr;
             size_t n0 = 0, q0 = 0;
             std::vector<std::vector<uint8_t>> pv(batch), pb(batch), pw(batch);
-            {   // the proofs' TranscriptRng chains run on the device while the host synthesises (bpr1cs_prove_prefetch; n = the last
-                // proof's with this label and this many commitments; advisory - the prove call below starts its own if n is not its n)
-                uint32_t n_guess = 0;
-                {
-                    std::lock_guard<std::mutex> lk(Prover::hint_mu());
-                    auto it = Prover::n_hints().find({std::string((const char*)label, label_len), m});
-                    if (it != Prover::n_hints().end()) n_guess = it->second;
-                }
-                if (n_guess) {
-                    Transcript t0((const char*)label, label_len);
-                    const uint8_t zero = 0;
-                    (void)bpr1cs_prove_prefetch(gens, t0.h, m ? values : &zero, m ? v_blindings : &zero, m, rng_seeds, batch, n_guess);
-                }
-            }
+            std::vector<std::pair<size_t, size_t>> shape(batch);
             const double t_synth0 = now_s();
             std::mutex mu;
             int first_err = 0;
@@ -533,7 +526,9 @@ int bpr1cs_gadget_prove_on(const bpr1cs_gens* gens, const char* gadget, const ui
                 Prover prover(pc_gens, t);
                 prover.defer_commitments = true;
                 synth(prover, b, nullptr);
-                if (b == 0) {   // one circuit for the batch: the constraint system does not depend on the witness
+                shape[b] = {prover.a_L.size(), prover.constraints.size()};
+                prover.export_witness(pv[b], pb[b], pw[b]);
+                if (b == 0) {
                     double t0 = now_s();
                     std::vector<uint32_t> row_off, tvar;
                     std::vector<uint8_t> tcoeff;
@@ -544,17 +539,14 @@ int bpr1cs_gadget_prove_on(const bpr1cs_gens* gens, const char* gadget, const ui
                     d.row_off = row_off.data(); d.term_var = tvar.data(); d.term_coeff = tcoeff.data();
                     int rc = bpr1cs_circuit_create(&d, &c);
                     if (rc) throw R1CSError::Backend(rc);
+                    std::lock_guard<std::mutex> lk(sec_mu);
                     sec[2] += now_s() - t0;
-                } else if (prover.a_L.size() != n0 || prover.constraints.size() != q0) {
-                    throw R1CSError::Backend(BPR1CS_ERR_INVALID_ARGUMENT);   // a gadget whose shape depends on the witness cannot be batched
                 }
-                prover.export_witness(pv[b], pb[b], pw[b]);
             };
-            synth_one(0);
             {
                 const size_t hw = std::max<size_t>(1, std::thread::hardware_concurrency());
-                const size_t nthreads = std::min<size_t>({batch - 1, hw, (size_t)16});
-                std::atomic<size_t> next{1};
+                const size_t nthreads = std::min<size_t>({batch, hw, (size_t)16});
+                std::atomic<size_t> next{0};
                 auto worker = [&]() {
                     for (;;) {
                         const size_t b = next.fetch_add(1);
@@ -577,10 +569,13 @@ int bpr1cs_gadget_prove_on(const bpr1cs_gens* gens, const char* gadget, const ui
                 worker();
                 for (auto& th : pool) th.join();
             }
+            // a gadget whose shape depends on the witness cannot be batched
+            for (size_t b = 1; b < batch && !first_err; b++)
+                if (shape[b] != shape[0]) first_err = BPR1CS_ERR_INVALID_ARGUMENT;
             if (first_err) { bpr1cs_circuit_destroy(c); return first_err; }
             // the stage times of a threaded synthesis: wall time of the stage (commit calls: none, they are deferred)
             sec[0] = 0;
-            sec[1] = now_s() - t_synth0 - sec[2];
+            sec[1] = now_s() - t_synth0;   // (the circuit is created by the thread of witness 0 while the others synthesise: inside this wall time)
             for (size_t b = 0; b < batch; b++) {
                 vals.insert(vals.end(), pv[b].begin(), pv[b].end());
                 bls.insert(bls.end(), pb[b].begin(), pb[b].end());
@@ -596,10 +591,6 @@ int bpr1cs_gadget_prove_on(const bpr1cs_gens* gens, const char* gadget, const ui
             sec[3] += now_s() - t0;
             bpr1cs_circuit_destroy(c);
             if (rc) return rc;
-            if (n0) {
-                std::lock_guard<std::mutex> lk(Prover::hint_mu());
-                Prover::n_hints()[{std::string((const char*)label, label_len), m}] = (uint32_t)n0;
-            }
             *proof_len = plen;
         }
         sec[4] = now_s() - t_start;

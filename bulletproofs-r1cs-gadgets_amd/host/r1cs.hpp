@@ -17,6 +17,7 @@
 #include <array>
 #include <algorithm>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <optional>
 #include <random>
@@ -318,6 +319,73 @@ public:
     CompressedRistretto B, B_blinding;
 };
 
+// What Prover::commit returns in place of upstream's CompressedRistretto.  Upstream computes the point inside commit() - a caller
+// bound to that signature (tools/rust_shim/prover.rs) pays one device round trip per commitment, 100 of them in front of one depth-32
+// proof (src/gadget_vsmt_4.rs:393-416), although nothing reads a commitment before prove() has returned (the harnesses collect them
+// for the verifier, :442-470).  This twin hands out a handle: the point is computed when somebody reads it - every commitment the
+// Prover has made and nobody has read yet in ONE device call - or, if nobody does, it is taken from the prove call, whose device job
+// computes the V's for the transcript anyway and returns them.  Prover::eager_commitments restores upstream's behaviour.
+struct CommitLedger {
+    bpr1cs_gens* gens = nullptr;             // null: a Prover that only synthesises (defer_commitments) - the points read as zeros
+    std::vector<uint8_t> scalars;            // 64 bytes per commitment asked for: value | blinding (secrets: wiped once resolved)
+    std::vector<CompressedRistretto> points; // resolved so far: points[0 .. points.size())
+    size_t asked = 0;
+    ~CommitLedger() { wipe(); }
+    void wipe() {
+        volatile uint8_t* v = scalars.data();
+        for (size_t i = 0; i < scalars.size(); i++) v[i] = 0;
+    }
+    size_t add(const Scalar& v, const Scalar& blinding) {
+        scalars.resize(64 * (asked + 1));
+        v.write_bytes(&scalars[64 * asked]);
+        blinding.write_bytes(&scalars[64 * asked + 32]);
+        return asked++;
+    }
+    void resolve() {   // every commitment asked for and not yet computed, in one call
+        const size_t have = points.size(), k = asked - have;
+        if (!k) return;
+        points.resize(asked);
+        if (!gens) { for (size_t i = have; i < asked; i++) points[i].fill(0); return; }
+        const uint32_t bases[2] = {0, 1};
+        std::vector<uint8_t> out(32 * k);
+        int rc = bpr1cs_msm_fixed(gens, bases, 2, &scalars[64 * have], k, out.data());
+        if (rc) { points.resize(have); throw R1CSError::Backend(rc); }
+        for (size_t i = 0; i < k; i++) memcpy(points[have + i].data(), &out[32 * i], 32);
+        wipe();
+    }
+    void fill(const uint8_t* comms, size_t m) {   // the V's a prove call returned (all m, in commitment order)
+        const size_t have = points.size();
+        if (m < asked) return;
+        points.resize(asked);
+        for (size_t i = have; i < asked; i++) memcpy(points[i].data(), comms + 32 * i, 32);
+        wipe();
+    }
+};
+class Commitment {
+public:
+    Commitment() { value.fill(0); have = true; }
+    Commitment(const CompressedRistretto& c) : value(c), have(true) {}
+    Commitment(std::shared_ptr<CommitLedger> l, size_t i) : ledger(std::move(l)), index(i) {}
+    const CompressedRistretto& get() const {
+        if (!have) {
+            if (index >= ledger->points.size()) ledger->resolve();
+            value = ledger->points[index];
+            have = true;
+            ledger.reset();
+        }
+        return value;
+    }
+    operator CompressedRistretto() const { return get(); }
+    const uint8_t* data() const { return get().data(); }          // CompressedRistretto::as_bytes
+    std::array<uint8_t, 32> to_bytes() const { return get(); }
+    bool operator==(const Commitment& o) const { return get() == o.get(); }
+private:
+    mutable std::shared_ptr<CommitLedger> ledger;
+    size_t index = 0;
+    mutable CompressedRistretto value{};
+    mutable bool have = false;
+};
+
 // bulletproofs::r1cs::R1CSProof: the typed proof the reference's helpers return and consume
 // (src/gadget_bound_check.rs:49-116, src/gadget_set_membership.rs:93-171) with upstream's wire format
 // (to_bytes / from_bytes; one-phase form when the phase-2 commitments are the identity).
@@ -371,13 +439,16 @@ public:
 
 class Prover : public CSBase {
 public:
-    Prover(const PedersenGens& pc, Transcript& t) : pc_gens(pc), transcript(t) {}
-    std::pair<CompressedRistretto, Variable> commit(const Scalar& v, const Scalar& v_blinding) {
+    Prover(const PedersenGens& pc, Transcript& t) : pc_gens(pc), transcript(t), ledger(std::make_shared<CommitLedger>()) { ledger->gens = pc.gens; }
+    std::pair<Commitment, Variable> commit(const Scalar& v, const Scalar& v_blinding) {
         uint32_t i = (uint32_t)v_.size();
         v_.push_back(v);
         v_blinding_.push_back(v_blinding);
-        // (defer_commitments: a batch harness takes the V's from the one batched prove call instead of one device call each)
-        return {defer_commitments ? CompressedRistretto{} : pc_gens.commit(v, v_blinding), Variable::Committed(i)};
+        // (defer_commitments: a batch harness takes the V's from the one batched prove call; nothing may be computed for this Prover)
+        if (defer_commitments) return {Commitment(), Variable::Committed(i)};
+        Commitment c(ledger, ledger->add(v, v_blinding));
+        if (eager_commitments) (void)c.get();   // upstream's behaviour: the point exists when commit() returns (one device call)
+        return {c, Variable::Committed(i)};
     }
     Scalar eval(const LinearCombination& lc) const {
         Scalar acc;
@@ -396,7 +467,6 @@ public:
     }
     std::optional<Scalar> evaluate_lc(const LinearCombination& lc) const override { return eval(lc); }
     MulVars multiply(LinearCombination left, LinearCombination right) override {
-        if (!chain_tried) chain_ahead();
         Scalar l = eval(left), r = eval(right);
         uint32_t i = (uint32_t)a_L.size();
         a_L.push_back(l); a_R.push_back(r); a_O.push_back(l * r);
@@ -410,7 +480,6 @@ public:
     }
     MulVars allocate_multiplier(const std::optional<std::pair<Scalar, Scalar>>& a, const WitnessHint&, const WitnessHint&) override {
         if (!a) throw R1CSError::MissingAssignment();
-        if (!chain_tried) chain_ahead();
         uint32_t i = (uint32_t)a_L.size();
         a_L.push_back(a->first); a_R.push_back(a->second); a_O.push_back(a->first * a->second);
         num_vars = a_L.size();
@@ -418,7 +487,6 @@ public:
     }
     std::pair<Variable, std::optional<Variable>> allocate_single(const std::optional<Scalar>& a, const WitnessHint&) override {
         if (!a) throw R1CSError::MissingAssignment();
-        if (!chain_tried) chain_ahead();
         if (!pending_multiplier) {
             uint32_t i = (uint32_t)a_L.size();
             pending_multiplier = i;
@@ -439,35 +507,8 @@ public:
     // what prove() hands to the device: committed values, blindings (m x 32 each) and the wires a_L | a_R | a_O (3 n x 32), appended
     void export_witness(std::vector<uint8_t>& vals, std::vector<uint8_t>& bls, std::vector<uint8_t>& wires) const;
     bool defer_commitments = false;
-    // The first multiplier of the gadget: every commitment is made (the reference's harnesses commit first, then synthesise - e.g.
-    // src/gadget_vsmt_4.rs:393-420), so everything the proof's TranscriptRng chain depends on is known except its length, 2n + 7
-    // draws.  The chain - 90 of the 105 ms a depth-32 proof spends on the device - is started now, next to the synthesis on the
-    // host, with the n of the last proof that had this label and this many commitments (bpr1cs_prove_prefetch); prove() presents
-    // the same inputs and takes its draws when n was right, and starts its own chain when it was not.  A later commit() makes the
-    // prove call ignore it likewise.  Same bytes either way.
-    bool chain_tried = false;
-    void chain_ahead() {
-        chain_tried = true;
-        if (defer_commitments || !pc_gens.gens) return;
-        uint32_t n_guess = 0;
-        {
-            std::lock_guard<std::mutex> lk(hint_mu());
-            auto it = n_hints().find({transcript.label, v_.size()});
-            if (it != n_hints().end()) n_guess = it->second;
-        }
-        if (!n_guess) return;
-        if (!rng_seed) {
-            std::array<uint8_t, 32> s;
-            std::random_device rd;  // stands in for rand::thread_rng()
-            for (auto& x : s) x = (uint8_t)rd();
-            rng_seed = s;
-        }
-        std::vector<uint8_t> vals(32 * v_.size() + 1), bls(32 * v_.size() + 1);
-        for (size_t i = 0; i < v_.size(); i++) { v_[i].write_bytes(&vals[32 * i]); v_blinding_[i].write_bytes(&bls[32 * i]); }
-        (void)bpr1cs_prove_prefetch(pc_gens.gens, transcript.h, vals.data(), bls.data(), v_.size(), rng_seed->data(), 1, n_guess);   // advisory
-    }
-    static std::mutex& hint_mu() { static std::mutex m; return m; }
-    static std::map<std::pair<std::string, size_t>, uint32_t>& n_hints() { static std::map<std::pair<std::string, size_t>, uint32_t> h; return h; }
+    bool eager_commitments = false;   // true: every commit() computes its point at once (what a caller bound to upstream's signature pays)
+    std::shared_ptr<CommitLedger> ledger;
     double* seconds = nullptr;   // optional [2]: seconds spent in (CSR export + bpr1cs_circuit_create, the prove call) of prove()
 
     const PedersenGens& pc_gens;

@@ -160,6 +160,12 @@ int bpr1cs_gens_table_info(const bpr1cs_gens* g, uint32_t* window_bits, uint32_t
                                          4096 for N = 32768 on 288 GB) */
 #define BPR1CS_OPT_JOBS_IN_FLIGHT 8   /* device jobs bpr1cs_prove_batch keeps in flight: 1 or 2 (default 2: the latency-bound front of
                                          job k+1 runs next to the multiscalar multiplications of job k) */
+#define BPR1CS_OPT_HOST_CHAIN_PROOFS 9 /* a job of up to this many proofs runs its TranscriptRng chains (2n + 8 strictly sequential Keccak-f[1600]
+                                         per proof: 0.15-0.3 us each on an x86-64 core, 2.5 us on a GPU lane group) on host threads, one proof
+                                         per thread, while the device takes the wires and computes A_I / A_O; the raw 64-byte draws are
+                                         uploaded and reduced mod l on the device.  Default (-1): 4 proofs per CPU the process may use
+                                         (affinity mask, cgroup quota); 0: never (the device chain, what a large batch hides behind the job
+                                         before it).  Hashing only - no group or field arithmetic ever runs on the host */
 #define BPR1CS_OPT_WINDOW_BITS 16     /* creation only: signed window width W (4..12) of the fixed-base tables.  A term costs
                                          ceil(253/W) mixed additions; table bytes = (2+2*cap) * ceil(253/W) * (2^(W-1)+1) * 128
                                          (W=8: 35 GB, W=11: 198 GB at capacity 32768).  Default 0 = the widest W <= 11 whose tables fit in
@@ -215,22 +221,6 @@ typedef struct bpr1cs_transcript bpr1cs_transcript;
 int bpr1cs_prove_batch_transcripts(const bpr1cs_gens* g, const bpr1cs_circuit* c, bpr1cs_transcript* const* transcripts, size_t n_transcripts,
                                    const uint8_t* values, const uint8_t* v_blindings, const uint8_t* rng_seeds,
                                    const uint8_t* wires, size_t batch, uint8_t* proofs_out, uint8_t* commitments_out);
-
-/* ONE proof per prove() - the reference's call shape (src/gadget_vsmt_4.rs:386-435: Prover::new, commit x m, the gadget's synthesis
- * on the host, prove) - spends most of its device time in the proof's TranscriptRng chain: 2n + 7 sequential permutations that depend
- * on the transcript, the commitments' blindings and the 32 bytes of outside randomness, not on the wires.  This call starts that chain
- * as soon as the commitments are made, next to the host's synthesis, and returns at once; `n_multipliers` is the caller's guess of n
- * (e.g. the n of its last proof of this statement).  `batch` > 1: the chains of that many proofs that all start from a copy of
- * `transcript` (a service that synthesises several witnesses on the host and proves them in one call).  The next
- * bpr1cs_prove_batch_transcripts / bpr1cs_prove_batch call on the handle takes the chains' draws if it is a call of `batch` proofs in one
- * device job from ONE transcript in the same state, presents the same values, blindings and rng_seeds, and its circuit has that n; in
- * every other case they are ignored and the call starts its own.  The proof bytes are the same either way.  Advisory: with a job of
- * the handle in flight, or batch > 256, nothing is started (BPR1CS_OK); a second call replaces the first.
- *   transcript         the state Prover::new would be given (not advanced by this call)
- *   values, v_blindings   batch * m * 32 each, canonical
- *   rng_seeds          batch * 32 */
-int bpr1cs_prove_prefetch(const bpr1cs_gens* g, const bpr1cs_transcript* transcript, const uint8_t* values, const uint8_t* v_blindings, size_t m,
-                          const uint8_t* rng_seeds, size_t batch, uint32_t n_multipliers);
 
 /* Asynchronous form of bpr1cs_prove_batch: `begin` uploads the inputs and enqueues the whole prove on
  * one of two per-handle HIP stream pairs and returns without waiting; `end` waits for that job and
@@ -377,7 +367,7 @@ typedef struct {
     uint64_t msm_launches;
     uint64_t msm_terms;     /* scalar*point terms it processed, summed over the batch */
     uint64_t msm_adds;      /* table additions = terms x windows of the table a term reads (a circuit's merged tables may be narrower) */
-    uint64_t chains_ahead;  /* proofs that took the TranscriptRng chain bpr1cs_prove_prefetch had started for them */
+    uint64_t host_chains;   /* proofs whose TranscriptRng chain ran on a host thread (BPR1CS_OPT_HOST_CHAIN_PROOFS) */
 } bpr1cs_prove_stats;
 int bpr1cs_last_prove_stats(bpr1cs_prove_stats* out);
 

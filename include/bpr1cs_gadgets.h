@@ -47,8 +47,9 @@ int bpr1cs_gadget_prove_single(const char* gadget, const uint32_t* iparams, size
 
 /* The same call shape on generators the caller created ONCE (the reference creates them outside its timed region:
  * src/gadget_vsmt_4.rs:386-387 against the Instant bracket :421-435), for `batch` witnesses of one gadget.
- *   batch = 1   literally the reference: Prover::new -> commit x m (one bpr1cs_msm_fixed call each) -> gadget (host synthesis)
- *               -> prove = bpr1cs_circuit_create + bpr1cs_prove_batch_transcripts(batch 1, host wires), what tools/rust_shim/prover.rs does
+ *   batch = 1   the reference's sequence: Prover::new -> commit x m -> gadget (host synthesis) -> prove = bpr1cs_circuit_create +
+ *               bpr1cs_prove_batch_transcripts(batch 1, host wires); the commitments are read after prove() (as the reference's
+ *               harnesses do, src/gadget_vsmt_4.rs:442-470) and come out of the prove call (_flags: one device call each)
  *   batch > 1   one C++ Prover per witness for the synthesis, then ONE bpr1cs_prove_batch_transcripts call with all the wires
  *               (the commitments come out of that call)
  * values / v_blindings: batch*m*32 proof-major; rng_seeds: batch*32; proofs_out: batch * (*proof_len) bytes, proof_cap = room per
@@ -58,6 +59,16 @@ int bpr1cs_gadget_prove_on(const bpr1cs_gens* gens, const char* gadget, const ui
                            size_t n_sparams, const uint8_t* poseidon_blob, size_t blob_len, const uint8_t* label, size_t label_len,
                            const uint8_t* values, const uint8_t* v_blindings, size_t m, size_t batch, const uint8_t* rng_seeds,
                            uint8_t* proofs_out, size_t proof_cap, size_t* proof_len, uint8_t* commitments_out, double seconds_out[5]);
+
+/* The same with flags.  BPR1CS_GADGET_EAGER_COMMITS (batch = 1): every Prover::commit computes its point before it returns - one
+ * bpr1cs_msm_fixed call per commitment, what a caller bound to upstream's signature `commit(v, blinding) -> (CompressedRistretto,
+ * Variable)` pays (tools/rust_shim/prover.rs).  Without it (and in bpr1cs_gadget_prove_on) the C++ Prover hands out commitments that
+ * are resolved when read - here after prove(), from the V's the prove call returns - host/r1cs.hpp class Commitment.  Same bytes. */
+#define BPR1CS_GADGET_EAGER_COMMITS 1u
+int bpr1cs_gadget_prove_on_flags(const bpr1cs_gens* gens, const char* gadget, const uint32_t* iparams, size_t n_iparams, const uint8_t* sparams,
+                                 size_t n_sparams, const uint8_t* poseidon_blob, size_t blob_len, const uint8_t* label, size_t label_len,
+                                 const uint8_t* values, const uint8_t* v_blindings, size_t m, size_t batch, const uint8_t* rng_seeds,
+                                 uint8_t* proofs_out, size_t proof_cap, size_t* proof_len, uint8_t* commitments_out, double seconds_out[5], uint32_t flags);
 
 /* Host synthesis alone (no device call): the wires Prover::new -> commit x m -> gadget leaves behind, a_L | a_R | a_O, 3 * n * 32
  * bytes - what bpr1cs_prove_batch / _transcripts take as `wires`.  wires_out may be NULL (n_out / q_out only); wires_cap in bytes. */

@@ -187,65 +187,45 @@ def test_transcript_launch_boundary(hip_lib, batch):
     assert got == [True] * k + [False]
 
 
-def test_chain_started_ahead_of_the_prove_call(hip_lib):
-    """bpr1cs_prove_prefetch: the TranscriptRng chain of ONE proof started before its prove call (next to the host's gadget synthesis
-    in the reference's call shape).  Taken - chains_ahead = 1 - only when the prove call presents the same transcript state, values,
-    blindings and rng_seed and its circuit has the guessed n; in every other case ignored.  The oracle's bytes in every case."""
+def test_transcriptrng_chain_on_host_threads_equals_the_device_chain(hip_lib):
+    """BPR1CS_OPT_HOST_CHAIN_PROOFS on the device build: a small job's TranscriptRng chains run on host threads next to the wires' upload and the
+    A_I / A_O sums (V commitments read back for them, raw draws uploaded, K_rng_reduce with the leading draw), a large job's in
+    k_rng_stream.  Same witnesses both ways - one proof per call, 3 and 17 per call, fresh label / one advanced transcript / one
+    transcript per proof, host wires and the device witness program: the oracle's bytes; host_chains says which form ran."""
     bp = common.bp
-    ob = common.oracle_batch(lambda j: S.bound_check(37 + j, 10, 100, 7), 16, 3)
-    gens = bp.Gens(16, lib=hip_lib)
+    ob = common.oracle_batch(lambda j: S.bound_check(37 + j, 10, 100, 7), 16, 17)
     circ = common.circuit_from_oracle(ob, hip_lib)
     m, n = ob["m"], ob["n"]
-    one = lambda key, j, w: ob[key][w * j:w * (j + 1)]
-
-    def prove(j, msg=None):
+    cut = lambda key, k, w: ob[key][:w * k]
+    got = {}
+    for host in (0, 1, 3, 1000):
+        gens = bp.Gens(16, lib=hip_lib, host_chain_proofs=host)
+        for k in (1, 3, 17):
+            P, C = bp.prove_batch(gens, circ, ob["label"], cut("values", k, 32 * m), cut("blindings", k, 32 * m), cut("seeds", k, 32), k,
+                                  wires=cut("wires", k, 96 * n))
+            assert P == ob["proofs"][:k], "host_chain_proofs=%d, %d proofs" % (host, k)
+            assert all(C[j][:len(ob["comms"][j])] == ob["comms"][j] for j in range(k))
+            assert bp.last_prove_stats(hip_lib)["host_chains"] == (k if host >= k else 0)
         t = bp.Transcript(ob["label"], lib=hip_lib)
-        if msg:
-            t.append_message(b"ctx", msg)
-        P, _ = bp.prove_batch_transcripts(gens, circ, t, one("values", j, 32 * m), one("blindings", j, 32 * m), one("seeds", j, 32), 1,
-                                          wires=one("wires", j, 96 * n))
-        return P[0], bp.last_prove_stats(hip_lib)["chains_ahead"]
-
-    def ahead(j, n_guess, seed=None, msg=None):
-        t = bp.Transcript(ob["label"], lib=hip_lib)
-        if msg:
-            t.append_message(b"ctx", msg)
-        bp.prove_prefetch(gens, t, one("values", j, 32 * m), one("blindings", j, 32 * m), m, seed or one("seeds", j, 32), n_guess)
-
-    assert prove(0) == (ob["proofs"][0], 0)                      # nothing ran ahead
-    ahead(0, n)
-    assert prove(0) == (ob["proofs"][0], 1)                      # taken
-    assert prove(0) == (ob["proofs"][0], 0)                      # ... once
-    ahead(1, n + 5)
-    assert prove(1) == (ob["proofs"][1], 0)                      # a wrong guess of n (too long: the chain is still running, nobody waits for it)
-    ahead(1, n - 1)
-    assert prove(1) == (ob["proofs"][1], 0)                      # too short
-    ahead(2, n, seed=one("seeds", 0, 32))
-    assert prove(2) == (ob["proofs"][2], 0)                      # other outside randomness
-    ahead(1, n)
-    assert prove(2) == (ob["proofs"][2], 0)                      # another proof's values and blindings
-    ahead(2, n)
-    ahead(0, n)                                                  # a second call replaces the first
-    assert prove(0) == (ob["proofs"][0], 1)
-    ahead(0, n, msg=b"x")
-    assert prove(0) == (ob["proofs"][0], 0)                      # the transcript held a message the prove call's does not
-    p_adv, took = (lambda: (ahead(0, n, msg=b"x"), prove(0, msg=b"x"))[1])()
-    assert took == 1 and p_adv != ob["proofs"][0]                # taken on a transcript that is not fresh, too
-    assert prove(0, msg=b"x") == (p_adv, 0)                      # ... with the bytes of the call that starts its own chain
-    ahead(0, n)
-    P, _ = bp.prove_batch(gens, circ, ob["label"], ob["values"], ob["blindings"], ob["seeds"], 3, wires=ob["wires"])
-    assert P == ob["proofs"] and bp.last_prove_stats(hip_lib)["chains_ahead"] == 0   # one chain, a batch of three: ignored
-    ahead(1, n)
-    assert prove(1) == (ob["proofs"][1], 1)
-    # the chains of a small batch from one transcript (what bpr1cs_gadget_prove_on(batch > 1) starts before its host syntheses)
-    t = bp.Transcript(ob["label"], lib=hip_lib)
-    bp.prove_prefetch(gens, t, ob["values"], ob["blindings"], m, ob["seeds"], n, batch=3)
-    P, _ = bp.prove_batch_transcripts(gens, circ, t, ob["values"], ob["blindings"], ob["seeds"], 3, wires=ob["wires"])
-    assert P == ob["proofs"] and bp.last_prove_stats(hip_lib)["chains_ahead"] == 3
-    bp.prove_prefetch(gens, t, ob["values"], ob["blindings"], m, ob["seeds"], n, batch=3)
-    assert prove(0) == (ob["proofs"][0], 0)                      # three chains, a call of one proof: ignored
-    bp.prove_prefetch(gens, t, ob["values"][:64 * m], ob["blindings"][:64 * m], m, ob["seeds"][:64], n, batch=2)
-    P, _ = bp.prove_batch(gens, circ, ob["label"], ob["values"], ob["blindings"], ob["seeds"], 3, wires=ob["wires"])
-    assert P == ob["proofs"] and bp.last_prove_stats(hip_lib)["chains_ahead"] == 0   # two chains, three proofs
-    ahead(2, n)                                                  # never taken: released with the handle
+        t.append_message(b"ctx", b"session 7")
+        Pa, _ = bp.prove_batch_transcripts(gens, circ, t, cut("values", 3, 32 * m), cut("blindings", 3, 32 * m), cut("seeds", 3, 32), 3, wires=cut("wires", 3, 96 * n))
+        ts = []
+        for j in range(3):
+            tj = bp.Transcript(ob["label"], lib=hip_lib)
+            tj.append_message(b"ctx", b"session %d" % (7 if j != 2 else 8))
+            ts.append(tj)
+        Pb, _ = bp.prove_batch_transcripts(gens, circ, ts, cut("values", 3, 32 * m), cut("blindings", 3, 32 * m), cut("seeds", 3, 32), 3, wires=cut("wires", 3, 96 * n))
+        got[host] = (Pa, Pb, [tj.challenge_bytes(b"after", 16) for tj in ts])
+        assert Pa != ob["proofs"][:3] and Pb[:2] == Pa[:2] and Pb[2] != Pa[2]
+        gens.close()
+    assert got[0] == got[1] == got[3] == got[1000]
+    # the default takes one proof per call on the host; a 4096-proof job never
+    gens = bp.Gens(16, lib=hip_lib)
+    P, _ = bp.prove_batch(gens, circ, ob["label"], cut("values", 1, 32 * m), cut("blindings", 1, 32 * m), cut("seeds", 1, 32), 1, wires=cut("wires", 1, 96 * n))
+    assert P == ob["proofs"][:1] and bp.last_prove_stats(hip_lib)["host_chains"] == 1
+    big = 4096
+    rep = lambda key: (ob[key] * (big // 17 + 1))
+    P, _ = bp.prove_batch(gens, circ, ob["label"], rep("values")[:32 * m * big], rep("blindings")[:32 * m * big], rep("seeds")[:32 * big], big,
+                          wires=rep("wires")[:96 * n * big])
+    assert bp.last_prove_stats(hip_lib)["host_chains"] == 0 and P[:17] == ob["proofs"] and P[17:34] == ob["proofs"]
     del gens

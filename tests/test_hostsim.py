@@ -372,23 +372,42 @@ def test_random_constraint_systems_match_oracle(sim_lib):
     random_circuits.check(sim_lib, common)
 
 
-def test_prove_prefetch_arguments_and_noop_on_the_simulator(sim_lib):
-    """bpr1cs_prove_prefetch: the argument checks of the entry point (shared with the device build) - null pointers, a value that is
-    not a canonical scalar, n = 0 - and that the synchronous simulator starts nothing: the prove call after it computes its own
-    chain (chains_ahead = 0) and returns the oracle's bytes.  The chain that does run ahead is a device test
-    (tests/test_gpu_parity.py::test_chain_started_ahead_of_the_prove_call)."""
+def test_transcriptrng_chain_on_host_threads_equals_the_kernel_chain(sim_lib):
+    """BPR1CS_OPT_HOST_CHAIN_PROOFS: a small job's TranscriptRng chains (csrc/host_chain.hpp: Prover::new's and commit's transcript
+    messages, the RNG keyed with the blindings and the outside randomness, all 2n + 8 draws raw) run on host threads and go through
+    K_rng_reduce; a large job's inside the transcript kernel.  Both forms on the same witnesses: the oracle's bytes, from a fresh
+    label, from ONE advanced transcript for the whole batch and from one advanced transcript per proof; host_chains says which form ran."""
     bp = common.bp
-    ob = common.oracle_batch(lambda j: S.bound_check(37 + j, 10, 100, 7), 16, 2)
-    gens = bp.Gens(16, lib=sim_lib)
+    ob = common.oracle_batch(lambda j: S.bound_check(37 + j, 10, 100, 7), 16, 5)
     circ = common.circuit_from_oracle(ob, sim_lib)
     m, n = ob["m"], ob["n"]
-    v, b, s = ob["values"][:32 * m], ob["blindings"][:32 * m], ob["seeds"][:32]
-    t = bp.Transcript(ob["label"], lib=sim_lib)
-    f = sim_lib.bpr1cs_prove_prefetch
-    assert f(gens.h, t.h, v, b, m, s, 1, n) == 0
-    assert f(gens.h, t.h, ob["values"], ob["blindings"], m, ob["seeds"], 2, n) == 0
-    assert f(None, t.h, v, b, m, s, 1, n) == -17 and f(gens.h, None, v, b, m, s, 1, n) == -17 and f(gens.h, t.h, v, b, m, None, 1, n) == -17
-    assert f(gens.h, t.h, None, b, m, s, 1, n) == -17 and f(gens.h, t.h, v, b, m, s, 1, 0) == -17 and f(gens.h, t.h, v, b, m, s, 0, n) == -17
-    assert f(gens.h, t.h, b"\xff" * 32 + v[32:], b, m, s, 1, n) == -17       # not a canonical scalar
-    P, _ = bp.prove_batch_transcripts(gens, circ, t, v, b, s, 1, wires=ob["wires"][:96 * n])
-    assert P == ob["proofs"][:1] and bp.last_prove_stats(sim_lib)["chains_ahead"] == 0
+    got = {}
+    for host in (0, 1, 3, 64):
+        gens = bp.Gens(16, lib=sim_lib, host_chain_proofs=host)
+        P, C = bp.prove_batch(gens, circ, ob["label"], ob["values"], ob["blindings"], ob["seeds"], 5, wires=ob["wires"])
+        assert P == ob["proofs"], "host_chain_proofs=%d" % host
+        assert bp.last_prove_stats(sim_lib)["host_chains"] == (5 if host >= 5 else 0)
+        # one proof per call (what Prover::prove does)
+        P1, _ = bp.prove_batch(gens, circ, ob["label"], ob["values"][:32 * m], ob["blindings"][:32 * m], ob["seeds"][:32], 1, wires=ob["wires"][:96 * n])
+        assert P1 == ob["proofs"][:1] and bp.last_prove_stats(sim_lib)["host_chains"] == (1 if host >= 1 else 0)
+        # advanced transcripts: one for the batch (copied), and one per proof (each left in its final state)
+        t = bp.Transcript(ob["label"], lib=sim_lib)
+        t.append_message(b"ctx", b"session 7")
+        Pa, _ = bp.prove_batch_transcripts(gens, circ, t, ob["values"], ob["blindings"], ob["seeds"], 5, wires=ob["wires"])
+        ts = []
+        for j in range(5):
+            tj = bp.Transcript(ob["label"], lib=sim_lib)
+            tj.append_message(b"ctx", b"session %d" % (7 if j != 2 else 8))
+            ts.append(tj)
+        Pb, _ = bp.prove_batch_transcripts(gens, circ, ts, ob["values"], ob["blindings"], ob["seeds"], 5, wires=ob["wires"])
+        got[host] = (Pa, Pb, [tj.challenge_bytes(b"after", 16) for tj in ts])
+        assert Pa != ob["proofs"] and Pb[2] != Pa[2] and Pb[:2] + Pb[3:] == Pa[:2] + Pa[3:]
+        gens.close()
+    assert got[0] == got[1] == got[3] == got[64]
+    # the default on this machine (4 proofs per usable CPU) takes a single proof on the host; set_option switches an existing handle
+    gens = bp.Gens(16, lib=sim_lib)
+    P1, _ = bp.prove_batch(gens, circ, ob["label"], ob["values"][:32 * m], ob["blindings"][:32 * m], ob["seeds"][:32], 1, wires=ob["wires"][:96 * n])
+    assert P1 == ob["proofs"][:1] and bp.last_prove_stats(sim_lib)["host_chains"] == 1
+    gens.set_option("host_chain_proofs", 0)
+    P1, _ = bp.prove_batch(gens, circ, ob["label"], ob["values"][:32 * m], ob["blindings"][:32 * m], ob["seeds"][:32], 1, wires=ob["wires"][:96 * n])
+    assert P1 == ob["proofs"][:1] and bp.last_prove_stats(sim_lib)["host_chains"] == 0

@@ -80,7 +80,7 @@ pub const BPR1CS_ERR_OUT_OF_MEMORY: i32 = -19;
     pub msm_launches: u64,
     pub msm_terms: u64,
     pub msm_adds: u64,
-    pub chains_ahead: u64,
+    pub host_chains: u64,
 }
 #[link(name = "bpr1cs_hip")]
 extern "C" {
@@ -100,7 +100,6 @@ extern "C" {
     pub fn bpr1cs_proof_len(c: *const bpr1cs_circuit) -> usize;
     pub fn bpr1cs_prove_batch(g: *const bpr1cs_gens, c: *const bpr1cs_circuit, label: *const u8, label_len: usize, values: *const u8, v_blindings: *const u8, rng_seeds: *const u8, wires: *const u8, batch: usize, proofs_out: *mut u8, commitments_out: *mut u8) -> i32;
     pub fn bpr1cs_prove_batch_transcripts(g: *const bpr1cs_gens, c: *const bpr1cs_circuit, transcripts: *mut *mut bpr1cs_transcript, n_transcripts: usize, values: *const u8, v_blindings: *const u8, rng_seeds: *const u8, wires: *const u8, batch: usize, proofs_out: *mut u8, commitments_out: *mut u8) -> i32;
-    pub fn bpr1cs_prove_prefetch(g: *const bpr1cs_gens, transcript: *const bpr1cs_transcript, values: *const u8, v_blindings: *const u8, m: usize, rng_seeds: *const u8, batch: usize, n_multipliers: u32) -> i32;
     pub fn bpr1cs_prove_batch_begin(g: *const bpr1cs_gens, c: *const bpr1cs_circuit, label: *const u8, label_len: usize, values: *const u8, v_blindings: *const u8, rng_seeds: *const u8, wires: *const u8, batch: usize, job_out: *mut *mut bpr1cs_job) -> i32;
     pub fn bpr1cs_prove_batch_end(job: *mut bpr1cs_job, proofs_out: *mut u8, commitments_out: *mut u8) -> i32;
     pub fn bpr1cs_verify_batch(g: *const bpr1cs_gens, c: *const bpr1cs_circuit, label: *const u8, label_len: usize, proofs: *const u8, commitments: *const u8, verifier_rng_seeds: *const u8, batch: usize, ok_out: *mut i32) -> i32;

@@ -10,16 +10,6 @@ use curve25519_dalek::ristretto::CompressedRistretto;
 use curve25519_dalek::scalar::Scalar;
 use merlin::Transcript; // = transcript.rs of this directory
 use rand::RngCore;
-use std::collections::HashMap;
-use std::sync::{Arc, Mutex, OnceLock};
-use crate::generators::GensHandle;
-
-/// (transcript label, number of commitments) -> (n of the last proof of that statement, the generators it was proved on): what the
-/// next proof of the statement starts its TranscriptRng chain ahead with (`chain_ahead`; C++ twin: Prover::n_hints in host/r1cs.hpp)
-fn n_hints() -> &'static Mutex<HashMap<(Vec<u8>, usize), (u32, Arc<GensHandle>)>> {
-    static H: OnceLock<Mutex<HashMap<(Vec<u8>, usize), (u32, Arc<GensHandle>)>>> = OnceLock::new();
-    H.get_or_init(|| Mutex::new(HashMap::new()))
-}
 
 pub struct Prover<'t, 'g> {
     transcript: &'t mut Transcript,
@@ -31,10 +21,6 @@ pub struct Prover<'t, 'g> {
     v: Vec<Scalar>,
     v_blinding: Vec<Scalar>,
     pending_multiplier: Option<usize>,
-    /// the 32 bytes upstream's TranscriptRng::finalize draws from thread_rng() inside prove(): drawn at new(), because the chain
-    /// that runs ahead of prove() needs them
-    seed: [u8; 32],
-    chain_tried: bool,
 }
 
 /// (kind << 28) | index, include/bpr1cs.h BPR1CS_VAR_*
@@ -53,25 +39,7 @@ impl<'t, 'g> Prover<'t, 'g> {
     /// ("dom-sep", "r1cs v1") here; the library appends it when the proof starts (K_transcript_init), so the transcript handed to
     /// bpr1cs_prove_batch_transcripts is exactly the caller's - fresh or not.
     pub fn new(pc_gens: &'g PedersenGens, transcript: &'t mut Transcript) -> Self {
-        let mut seed = [0u8; 32];
-        rand::thread_rng().fill_bytes(&mut seed);
-        Prover { transcript, pc_gens, constraints: vec![], a_L: vec![], a_R: vec![], a_O: vec![], v: vec![], v_blinding: vec![], pending_multiplier: None,
-                 seed, chain_tried: false }
-    }
-
-    /// The gadget's first multiplier: every commitment of the reference's harnesses is made by now (src/gadget_vsmt_4.rs:393-420
-    /// commit, :421-432 synthesise), so all the proof's TranscriptRng chain depends on is known except its length.  Start it now,
-    /// next to the synthesis, with the n of the last proof of this statement (include/bpr1cs.h bpr1cs_prove_prefetch): prove()
-    /// takes its draws when n was right and starts its own chain when it was not.  Same bytes either way.
-    fn chain_ahead(&mut self) {
-        self.chain_tried = true;
-        let hint = n_hints().lock().unwrap().get(&(self.transcript.label.clone(), self.v.len())).cloned();
-        if let Some((n, gens)) = hint {
-            let values: Vec<u8> = self.v.iter().flat_map(|s| s.to_bytes()).collect();
-            let blindings: Vec<u8> = self.v_blinding.iter().flat_map(|s| s.to_bytes()).collect();
-            // advisory: the return code does not matter
-            let _ = unsafe { ffi::bpr1cs_prove_prefetch(gens.0, self.transcript.h, values.as_ptr(), blindings.as_ptr(), self.v.len(), self.seed.as_ptr(), 1, n) };
-        }
+        Prover { transcript, pc_gens, constraints: vec![], a_L: vec![], a_R: vec![], a_O: vec![], v: vec![], v_blinding: vec![], pending_multiplier: None }
     }
 
     /// reference: `prover.commit(leaf, Scalar::random(&mut rng))` src/gadget_vsmt_4.rs:393.  The V append to the transcript happens
@@ -135,7 +103,10 @@ impl<'t, 'g> Prover<'t, 'g> {
         }
         let values: Vec<u8> = self.v.iter().flat_map(|s| s.to_bytes()).collect();
         let blindings: Vec<u8> = self.v_blinding.iter().flat_map(|s| s.to_bytes()).collect();
-        let seed = self.seed;
+        // (drawn here, where upstream draws them; the proof's TranscriptRng chain - 2n + 8 sequential Keccak-f[1600] - runs inside
+        // the call on a host thread, BPR1CS_OPT_HOST_CHAIN_PROOFS: a job of one proof has nothing to hide a device chain behind)
+        let mut seed = [0u8; 32];
+        rand::thread_rng().fill_bytes(&mut seed);
         let plen = unsafe { ffi::bpr1cs_proof_len(circuit) };
         let mut proof = vec![0u8; plen];
         let ts = [self.transcript.h];
@@ -147,14 +118,12 @@ impl<'t, 'g> Prover<'t, 'g> {
         // (with ONE transcript handle for a batch of one the library advances that handle: n_transcripts == batch)
         self.transcript.fresh = false;
         check(rc)?;
-        n_hints().lock().unwrap().insert((self.transcript.label.clone(), self.v.len()), (n as u32, bp_gens.handle.clone()));
         R1CSProof::from_bytes(&proof)
     }
 }
 
 impl<'t, 'g> ConstraintSystem for Prover<'t, 'g> {
     fn multiply(&mut self, mut left: LinearCombination, mut right: LinearCombination) -> (Variable, Variable, Variable) {
-        if !self.chain_tried { self.chain_ahead(); }
         let (l, r) = (self.eval(&left), self.eval(&right));
         let i = self.a_L.len();
         self.a_L.push(l); self.a_R.push(r); self.a_O.push(l * r);
@@ -170,7 +139,6 @@ impl<'t, 'g> ConstraintSystem for Prover<'t, 'g> {
     /// its right wire and returns (right, Some(output)) - the output variable the gadget constrains to 1 (gadget_poseidon.rs:184).
     fn allocate_single(&mut self, assignment: Option<Scalar>) -> Result<(Variable, Option<Variable>), R1CSError> {
         let scalar = assignment.ok_or(R1CSError::MissingAssignment)?;
-        if !self.chain_tried { self.chain_ahead(); }
         match self.pending_multiplier {
             None => {
                 let i = self.a_L.len();
@@ -188,7 +156,6 @@ impl<'t, 'g> ConstraintSystem for Prover<'t, 'g> {
     }
     fn allocate_multiplier(&mut self, input_assignments: Option<(Scalar, Scalar)>) -> Result<(Variable, Variable, Variable), R1CSError> {
         let (l, r) = input_assignments.ok_or(R1CSError::MissingAssignment)?;
-        if !self.chain_tried { self.chain_ahead(); }
         let i = self.a_L.len();
         self.a_L.push(l); self.a_R.push(r); self.a_O.push(l * r);
         Ok((Variable::MultiplierLeft(i), Variable::MultiplierRight(i), Variable::MultiplierOutput(i)))
