@@ -286,17 +286,24 @@ static int prove_job_begin(const bpr1cs_gens* g, const bpr1cs_circuit* c, const 
         dev_event_record(job->ev_rng, sl);
     }
 
-    // ---- P7/P8: witness (device program) or host-synthesised wires
+    if (host_chain) {
+        dev_sync(sl);   // the V commitments are on the host
+        DBG_JOB("begin: %u host chain(s) start", B);
+        chains.start(init, n_init, job->h_V, v_blindings, rng_seeds, B, m, n, job->h_tr0, job->h_raw);
+    }
+
+    // ---- P7/P8: witness (device program) or host-synthesised wires (in a small job: while the host threads hash)
     DevBuf<sc> px;
     if (wires) {
         // Host wires go in on the job's witness stream, as the device program's do: the A_I1 / A_O1 sums need nothing else, so they -
         // and the host's enqueuing of the whole back phase - do not wait for the TranscriptRng chain: the heavy stream waits for the
         // wires here and for the chain in front of S1.
         const dev_stream_t sw = job->st3;
-        DevBuf<sc> raw;
-        upload_transposed(raw, wires, B, (size_t)3 * n, sw);
+        DevBuf<sc> raw((size_t)3 * n * B);
+        static_assert(sizeof(sc) == 32, "a canonical scalar's 32 little-endian bytes are an sc as they are");
+        if (raw.bytes()) dev_h2d(raw.p, wires, raw.bytes(), sw);   // as the caller holds them (proof-major): transposed by the load kernel
         if (shared) dev_stream_wait(sw, g->w_free_ev);
-        launch((uint64_t)3 * n * B, K_load_wires{raw.p, W.p}, sw);
+        launch((uint64_t)3 * n * B, K_load_wires_pm{raw.p, W.p, B, 3 * n}, sw);
         dev_zero(raw.p, raw.bytes(), sw);
         dev_event_create(&job->ev_wit);
         dev_event_record(job->ev_wit, sw);
@@ -328,11 +335,6 @@ static int prove_job_begin(const bpr1cs_gens* g, const bpr1cs_circuit* c, const 
         dev_event_record(job->ev_wit, job->st3);
         dev_stream_wait(st, job->ev_wit);
 #endif
-    }
-    if (host_chain) {
-        dev_sync(sl);   // the V commitments are on the host
-        DBG_JOB("begin: %u host chain(s) start", B);
-        chains.start(init, n_init, job->h_V, v_blindings, rng_seeds, B, m, n, job->h_tr0, job->h_raw);
     }
     // the chains' end of the hand-over: called where the heavy stream is about to wait for the draws (in front of S1)
     auto finish_host_chains = [&]() {

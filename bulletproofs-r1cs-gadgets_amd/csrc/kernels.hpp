@@ -693,6 +693,17 @@ struct K_load_wires {  // host-synthesised a_L a_R a_O (canonical) -> Montgomery
     sc* W;
     HD void operator()(uint32_t g) const { W[g] = sc_to_mont(raw[g]); }
 };
+// the same from the caller's own layout - proof-major [B][cnt] - into the element-major W[cnt][B]: the transposition happens here, on
+// the device (a strided 32-byte read per thread), not in a host loop over 1.8 MB per depth-32 proof
+struct K_load_wires_pm {  // gid = j*B + b
+    const sc* raw;
+    sc* W;
+    uint32_t B, cnt;
+    HD void operator()(uint32_t g) const {
+        const uint32_t j = g / B, b = g % B;
+        W[g] = sc_to_mont(raw[(size_t)b * cnt + j]);
+    }
+};
 
 // ---------------------------------------------------------- fixed-base MSM
 // Segment: ordinal o in [0,count) -> element index i = (o / run)*period + off + (o % run);
