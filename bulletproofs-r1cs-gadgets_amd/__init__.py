@@ -68,7 +68,8 @@ OPTIONS = dict(unfold=OPT_UNFOLD_ROUNDS, witness_team=OPT_WITNESS_TEAM, tail_rou
 class ProveStats(ctypes.Structure):
     """bpr1cs_prove_stats (include/bpr1cs.h)"""
     _fields_ = [("jobs", ctypes.c_uint32), ("job_proofs", ctypes.c_uint32), ("phase_ms", ctypes.c_float * 6), ("msm_ms", ctypes.c_double),
-                ("msm_launches", ctypes.c_uint64), ("msm_terms", ctypes.c_uint64), ("msm_adds", ctypes.c_uint64), ("host_chains", ctypes.c_uint64)]
+                ("msm_launches", ctypes.c_uint64), ("msm_terms", ctypes.c_uint64), ("msm_adds", ctypes.c_uint64), ("host_chains", ctypes.c_uint64),
+                ("sizing_free_bytes", ctypes.c_uint64), ("sizing_bytes_per_proof", ctypes.c_uint64), ("sizing_fixed_bytes", ctypes.c_uint64)]
 
 
 def load_library(path=None):
@@ -516,7 +517,8 @@ def last_prove_stats(lib=None):
     lib = lib or load_library()
     st = ProveStats()
     _chk(lib.bpr1cs_last_prove_stats(ctypes.byref(st)))
-    return dict(jobs=st.jobs, job_proofs=st.job_proofs, phase_ms=list(st.phase_ms), msm_ms=st.msm_ms, msm_launches=st.msm_launches, msm_terms=st.msm_terms, msm_adds=st.msm_adds, host_chains=st.host_chains)
+    return dict(jobs=st.jobs, job_proofs=st.job_proofs, phase_ms=list(st.phase_ms), msm_ms=st.msm_ms, msm_launches=st.msm_launches, msm_terms=st.msm_terms, msm_adds=st.msm_adds, host_chains=st.host_chains,
+                sizing_free_bytes=st.sizing_free_bytes, sizing_bytes_per_proof=st.sizing_bytes_per_proof, sizing_fixed_bytes=st.sizing_fixed_bytes)
 
 
 def prove_batch_transcripts(gens, circuit, transcripts, values, v_blindings, rng_seeds, batch, wires=None):

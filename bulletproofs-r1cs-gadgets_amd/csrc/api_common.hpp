@@ -190,6 +190,7 @@ struct bpr1cs_circuit {
         uint32_t hs_W = 0, hs_cap = 0;
         uint32_t job_proofs = 0;   // proofs per device job chosen for (this circuit, this handle) by the first bpr1cs_prove_batch: kept for the later ones ...
         uint32_t job_epoch = 0;    // ... while the handle's sizing_epoch is the one it was chosen under
+        uint64_t sz_avail = 0, sz_per_proof = 0, sz_fixed = 0;   // what that choice was made from (bpr1cs_prove_stats.sizing_*)
     };
     mutable std::mutex mt_mu;
     mutable std::map<const bpr1cs_gens*, MergedTab*> mt;

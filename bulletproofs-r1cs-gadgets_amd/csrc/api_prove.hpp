@@ -441,7 +441,7 @@ static int prove_job_begin(const bpr1cs_gens* g, const bpr1cs_circuit* c, const 
     uint32_t maxe = std::max<uint32_t>(N, c->q + 1);
     uint32_t H = (maxe >> 8) + 1;
     DevBuf<sc> plo((size_t)3 * 256 * B), phi((size_t)3 * H * B);
-    launch((uint64_t)3 * B, K_pow_tables{chal.p, plo.p, phi.p, B, H}, st);
+    launch_pow_tables(K_pow_tables{chal.p, plo.p, phi.p, B, H}, B, st);
     // ONE block for buffers whose lives do not overlap: the flattened constraints and their chunk sums (dead after l(x), r(x)),
     // the generator factors cG / cH (dead once the folded generators exist) and the product scalars of the un-folded rounds
     // (dead after round r-1) share their memory with the Straus multiples of the first variable-base pair, which K_ipa_vb_tab
@@ -465,11 +465,11 @@ static int prove_job_begin(const bpr1cs_gens* g, const bpr1cs_circuit* c, const 
     struct { sc* p; } wvec{wvec_p}, cG{cG_p}, cH{cH_p};
     run_flatten(c, 3 * n + m, plo.p, phi.p, wvec.p, B, H, st, fpart_p);
     // 4 wavefronts per SIMD: with one (2^16 threads) the kernel is latency bound and a co-running front kernel doubles its time (9 -> 4 ms)
-    uint32_t tchunk, TC = pick_chunks(n, B, std::min<uint32_t>(1u << 18, MAX_SUM_CHUNKS * B), tchunk);
+    uint32_t tchunk, TC = pick_chunks(n, B, std::min<uint32_t>(1u << 18, sum_chunk_cap(B, 6) * B), tchunk);
     DevBuf<sc> tpart((size_t)6 * TC * B), tco((size_t)6 * B);
     launch((uint64_t)TC * B, K_tcoef_partial{W.p, wvec.p, plo.p, phi.p, tpart.p, B, H, n, tchunk, TC}, st);
-    launch((uint64_t)6 * B, K_sum_partials{tpart.p, tco.p, B, TC}, st);
-    launch((uint64_t)5 * B, K_commit_T{g->tab.p, g->tc, tco.p, blind.p, Tc.p, B}, st);
+    launch_sum_partials((uint64_t)6 * B, K_sum_partials{tpart.p, tco.p, B, TC}, st);
+    launch_commit_T(K_commit_T{g->tab.p, g->tc, tco.p, blind.p, Tc.p, B}, B, st);
     launch_transcript(B, K_transcript_T{tr.p, Tc.p, tco.p, blind.p, wvec.p + (size_t)3 * n * B, vbl_m.p, chal.p, txs.p, B, m, (uint64_t)N}, st);
     DevBuf<sc> a((size_t)N * B), bb((size_t)N * B);
     launch((uint64_t)N * B, K_lr_eval{W.p, wvec.p, plo.p, phi.p, chal.p, a.p, bb.p, cG.p, cH.p, B, H, n}, st);
@@ -591,7 +591,8 @@ static int prove_job_end(bpr1cs_job* job, uint8_t* proofs_out, uint8_t* commitme
 // the shared block (the larger of the flattened constraints + product scalars and the Straus multiples of the first
 // variable-base pair) and the folded generators.  Candidates: sizes[] below (16384 ... 128, then 64); 4096 for the depth-32
 // tree circuits next to W = 11 tables on a 288 GB device, 16384 for the small circuits.
-static uint32_t auto_job_proofs(const bpr1cs_gens* g, const bpr1cs_circuit* c, bool have_program, int in_flight) {
+struct JobSizing { uint64_t avail = 0, per_proof = 0, fixed = 0; };
+static uint32_t auto_job_proofs(const bpr1cs_gens* g, const bpr1cs_circuit* c, bool have_program, int in_flight, JobSizing* why = nullptr) {
     const size_t n = c->n, m = c->m, N = c->N;
     const uint32_t r = eff_unfold(g->opts, 4096, c->lgN);   // (the job sizes considered here are large ones)
     const size_t Mr = N >> r, nfl = c->h_slot_chunk.empty() ? 0 : c->h_slot_chunk[3 * n + m];
@@ -612,6 +613,7 @@ static uint32_t auto_job_proofs(const bpr1cs_gens* g, const bpr1cs_circuit* c, b
     const uint64_t grid_per_proof = (uint64_t)4 * c->N + 3ull * c->n + c->m + 64;
     // (small circuits: measured 104 k / 116 k / 126 k / 128 k proofs/s at 4096 / 8192 / 16384 / 32768 proofs per job for the 2:1 Poseidon
     // preimage circuit, 62.8 k / 69.0 k / 71.6 k / 70.5 k for MiMC + set membership)
+    if (why) { why->avail = avail; why->per_proof = (uint64_t)front * in_flight + front_shared + back; why->fixed = fixed + reserve; }
     static const uint32_t sizes[] = {16384, 12288, 8192, 6144, 4096, 3584, 3072, 2560, 2048, 1536, 1024, 768, 512, 384, 256, 128};
     for (uint32_t J : sizes) {
         if (grid_per_proof * J > 0xffffffffull) continue;
@@ -640,12 +642,13 @@ static int prove_batch_impl(const bpr1cs_gens* g, const bpr1cs_circuit* c, const
     const bool automatic = J == 0;
     // the automatic choice belongs to (circuit, handle) and to the handle's sizing epoch: the same for every call until an option
     // changes, the scratch is released or a call ran out of memory
+    JobSizing why;
     auto remember = [&](size_t j) {
         std::lock_guard<std::mutex> lk(c->mt_mu);
         bpr1cs_circuit::MergedTab*& mt = c->mt[g];
         if (!mt) mt = new bpr1cs_circuit::MergedTab();
         const uint32_t ep = g->sizing_epoch.load();
-        if (!mt->job_proofs || mt->job_epoch != ep) { mt->job_proofs = (uint32_t)j; mt->job_epoch = ep; }
+        if (!mt->job_proofs || mt->job_epoch != ep) { mt->job_proofs = (uint32_t)j; mt->job_epoch = ep; mt->sz_avail = why.avail; mt->sz_per_proof = why.per_proof; mt->sz_fixed = why.fixed; }
         return (size_t)mt->job_proofs;
     };
     if (automatic) {
@@ -655,7 +658,12 @@ static int prove_batch_impl(const bpr1cs_gens* g, const bpr1cs_circuit* c, const
             auto it = c->mt.find(g);
             if (it != c->mt.end() && it->second->job_epoch == g->sizing_epoch.load()) known = it->second->job_proofs;
         }
-        J = known ? known : remember(auto_job_proofs(g, c, wires == nullptr, depth));
+        J = known ? known : remember(auto_job_proofs(g, c, wires == nullptr, depth, &why));
+        {   // what the choice was made from (the call that made it, or an earlier one of this circuit on this handle)
+            std::lock_guard<std::mutex> lk(c->mt_mu);
+            auto it = c->mt.find(g);
+            if (it != c->mt.end()) { acc.sizing_free_bytes = it->second->sz_avail; acc.sizing_bytes_per_proof = it->second->sz_per_proof; acc.sizing_fixed_bytes = it->second->sz_fixed; }
+        }
     }
     J = std::min(J, grid_max);
     const size_t m = c->m, plen = bpr1cs_proof_len(c), wn = 3 * (size_t)c->n;
@@ -699,6 +707,7 @@ static int prove_batch_impl(const bpr1cs_gens* g, const bpr1cs_circuit* c, const
             g->front[0].release();
             g->front[1].release();
             g->shared_front.release();
+            circuit_cache_purge();   // (circuits nobody holds, with their per-handle tables)
 #if !defined(BPR1CS_HOSTSIM)
             dev_pool().release_all();
 #endif

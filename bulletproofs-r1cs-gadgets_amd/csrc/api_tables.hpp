@@ -130,6 +130,16 @@ int bpr1cs_gens_create_opts(uint32_t cap, const int32_t* pairs, size_t n_pairs, 
 int bpr1cs_gens_create(uint32_t cap, bpr1cs_gens** out) { return bpr1cs_gens_create_opts(cap, nullptr, 0, out); }
 void bpr1cs_gens_destroy(bpr1cs_gens* g) {
     if (!g) return;
+    {   // what the cached circuits keep per generator handle (merged tables, the remembered job size) goes with the handle: a later
+        // handle at the same address must not inherit it
+        CircuitCache& cc = circuit_cache();
+        std::lock_guard<std::mutex> lk(cc.mu);
+        for (bpr1cs_circuit* c : cc.items) {
+            std::lock_guard<std::mutex> lk2(c->mt_mu);
+            auto it = c->mt.find(g);
+            if (it != c->mt.end()) { delete it->second; c->mt.erase(it); }
+        }
+    }
     g->arena.release();
     g->front[0].release();
     g->front[1].release();

@@ -37,7 +37,7 @@ static void verify_front(VerifyCtx& v, const bpr1cs_gens* g, const bpr1cs_circui
     uint32_t maxe = std::max<uint32_t>(N, c->q + 1);
     v.H = (maxe >> 8) + 1;
     v.plo.alloc((size_t)3 * 256 * B); v.phi.alloc((size_t)3 * v.H * B);
-    launch((uint64_t)3 * B, K_pow_tables{v.chal.p, v.plo.p, v.phi.p, B, v.H}, st);
+    launch_pow_tables(K_pow_tables{v.chal.p, v.plo.p, v.phi.p, B, v.H}, B, st);
     const uint32_t nslots = 3 * n + m + 1;
     v.wvec.alloc((size_t)nslots * B);
     run_flatten(c, nslots, v.plo.p, v.phi.p, v.wvec.p, B, v.H, st);
@@ -45,10 +45,10 @@ static void verify_front(VerifyCtx& v, const bpr1cs_gens* g, const bpr1cs_circui
     launch((uint64_t)N * B, K_verify_gh{v.wvec.p, v.plo.p, v.phi.p, v.chal.p, v.uk.p, v.gh.p, v.gh.p + (size_t)N * B, v.dpart.p, B, v.H, n, N, lgN}, st);
     if (N >= 1024) {  // delta = sum_i y^-i wR_i wL_i in two levels (one thread per proof walking N values alone takes ~12 ms)
         DevBuf<sc> dsum((size_t)(N / 256) * B);
-        launch((uint64_t)(N / 256) * B, K_sum_partials{v.dpart.p, dsum.p, B, 256}, st);
-        launch(B, K_sum_partials{dsum.p, v.delta.p, B, N / 256}, st);
+        launch_sum_partials((uint64_t)(N / 256) * B, K_sum_partials{v.dpart.p, dsum.p, B, 256}, st);
+        launch_sum_partials(B, K_sum_partials{dsum.p, v.delta.p, B, N / 256}, st);
     } else {
-        launch(B, K_sum_partials{v.dpart.p, v.delta.p, B, N}, st);
+        launch_sum_partials(B, K_sum_partials{v.dpart.p, v.delta.p, B, N}, st);
     }
     launch(B, K_verify_bscalars{v.chal.p, v.wvec.p + (size_t)(3 * n + m) * B, v.delta.p, v.bsc.p, B}, st);
     v.P = 8 + m + 2 * lgN;

@@ -80,7 +80,6 @@ static IpaEnd enqueue_ipa(const IpaIO& io, dev_stream_t st, MsmStats* stats) {
         fac.alloc((size_t)6 * facT * B);
         if (hfJ) hf.alloc((size_t)2 * hfJ * B);
     }
-    // closed-form factors of round k: the per-proof products (and, for blocks of >= 256 positions, their table by i >> 8), then the scalars
     // closed-form factors of round k: the per-proof products (and, for blocks of >= 256 positions, their table by i >> 8), then the
     // scalars - written out (K_ipa_scalars_geo) for the small-job path, or produced by the MSM kernel at its term fetch (`fused`:
     // MsmGeo, csrc/msm_kernel.hpp) for launches of the shipped kernel, which then need no N x B scalar arrays at all
@@ -159,7 +158,7 @@ static IpaEnd enqueue_ipa(const IpaIO& io, dev_stream_t st, MsmStats* stats) {
                 st = io.tail_stream;
             }
         }
-        uint32_t cchunk, CC = pick_chunks(mk, B, std::min<uint32_t>(1u << 18, MAX_SUM_CHUNKS * B), cchunk);
+        uint32_t cchunk, CC = pick_chunks(mk, B, std::min<uint32_t>(1u << 18, sum_chunk_cap(B, 2) * B), cchunk);
         if (cpart_n < (size_t)2 * CC * B) {
             if (k >= tail_from && io.tail_keep) {
                 ArenaScope own(io.own_arena);
@@ -172,7 +171,7 @@ static IpaEnd enqueue_ipa(const IpaIO& io, dev_stream_t st, MsmStats* stats) {
             cpart_n = (size_t)2 * CC * B;
         }
         emit((uint64_t)CC * B, K_ipa_cross{a, bb, cpartp, B, mk, cchunk, CC}, false);
-        emit((uint64_t)2 * B, K_sum_partials{cpartp, crossp, B, CC}, false);
+        launch_sum_partials((uint64_t)2 * B, K_sum_partials{cpartp, crossp, B, CC}, st);
         uint8_t* Lout = io.LR + ((size_t)k * 2 + 0) * B * 32;
         uint8_t* Rout = io.LR + ((size_t)k * 2 + 1) * B * 32;
         if (k < r) {

@@ -153,6 +153,81 @@ __global__ void __launch_bounds__(64) k_commit_wave(const uint8_t* tab, TabCfg t
     if (lane == 0) ge_compress(acc, out + ((size_t)b * m + j) * 32);
 }
 
+// K_sum_partials for a job of a few proofs: a wavefront per output.  One thread adding up to 256 chunk sums one after the other is
+// 60-70 us on the critical path of every inner-product round of a single proof (and of t(x)); here the lanes take every 64th chunk
+// and a shuffle butterfly adds the 64 partial sums (the sum mod l does not depend on the order).
+__global__ void __launch_bounds__(64) k_sum_partials_wave(K_sum_partials f) {
+    const uint32_t g = blockIdx.x, lane = threadIdx.x;
+    const uint32_t k = g / f.B, b = g % f.B;
+    sc acc = sc_zero();
+    for (uint32_t c = lane; c < f.C; c += 64u) acc = sc_add(acc, f.part[((size_t)k * f.C + c) * f.B + b]);
+#pragma unroll 1
+    for (int sft = 32; sft > 0; sft >>= 1) {
+        sc o;
+#pragma unroll
+        for (int i = 0; i < 8; i++) o.v[i] = (uint32_t)__shfl_xor((int)acc.v[i], sft, 64);
+        acc = sc_add(acc, o);
+    }
+    if (lane == 0) f.out[g] = acc;
+}
+
+// K_commit_T for a job of a few proofs: a wavefront per T commitment (as k_commit_wave: table entries on 2 x windows lanes, butterfly,
+// lane 0 compresses) instead of a lane walking 2 x windows additions.
+__global__ void __launch_bounds__(64) k_commit_T_wave(K_commit_T f) {
+    const uint32_t g = blockIdx.x, lane = threadIdx.x;
+    const uint32_t k = g / f.B, b = g % f.B;
+    const uint32_t ti[5] = {0, 2, 3, 4, 5};
+    const TabCfg tc = f.tc;
+    const sc s0 = sc_from_mont(f.tco[(size_t)ti[k] * f.B + b]), s1 = sc_from_mont(f.blind[(size_t)(3 + k) * f.B + b]);
+    ge acc = ge_identity();
+    for (uint32_t idx = lane; idx < 2u * tc.windows; idx += 64u) {
+        const uint32_t t = idx / tc.windows, w = idx % tc.windows;
+        const sc s = t ? s1 : s0;
+        int carry = 0, d = 0;
+        for (uint32_t kk = 0; kk <= w; kk++) d = tab_digit(s, kk, carry, tc);
+        if (d != 0) {
+            const int neg = d < 0;
+            const uint32_t mag = (uint32_t)(neg ? -d : d);
+            acc = ge_madd_t(acc, ge_niels_load(f.tab + (size_t)t * tc.base_bytes() + ((size_t)w * tc.row + mag) * tc.stride), neg);
+        }
+    }
+    acc = ge_from_table_class(acc);
+#pragma unroll 1
+    for (int sft = 32; sft > 0; sft >>= 1) acc = ge_add_ge(acc, ge_shfl_xor(acc, sft));
+    if (lane == 0) ge_compress(acc, f.out + 32 * (size_t)g);
+}
+
+// K_pow_tables for a job of a few proofs: a wavefront per (y | y^-1 | z, proof).  The functor's thread multiplies its way through
+// 256 + H powers one after the other (0.25 ms for the depth-32 circuit); here every lane builds its own powers from the squarings
+// x^(2^j): at most 8 + 8 dependent products for the low table, ~2 log2 H for the high one.  Same values (products mod l are exact).
+__global__ void __launch_bounds__(64) k_pow_tables_wave(K_pow_tables f) {
+    const uint32_t g = blockIdx.x, lane = threadIdx.x;
+    const uint32_t which = g / f.B, b = g % f.B;
+    const uint32_t src[3] = {CH_Y, CH_YINV, CH_Z};
+    sc* l = f.lo + (size_t)which * 256 * f.B;
+    sc* h = f.hi + (size_t)which * f.H * f.B;
+    sc cur = f.chal[(size_t)src[which] * f.B + b];
+    sc p[4] = {sc_one_mont(), sc_one_mont(), sc_one_mont(), sc_one_mont()};   // x^t for t = lane + 64 q
+#pragma unroll 1
+    for (int j = 0; j < 8; j++) {
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            if (((lane + 64u * q) >> j) & 1u) p[q] = sc_mul(p[q], cur);
+        cur = sc_sq(cur);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++) l[(size_t)(lane + 64u * q) * f.B + b] = p[q];
+    const sc x256 = cur;
+    for (uint32_t t = lane; t < f.H; t += 64u) {
+        sc acc = sc_one_mont(), c2 = x256;
+        for (uint32_t e = t; e; e >>= 1) {
+            if (e & 1u) acc = sc_mul(acc, c2);
+            if (e > 1u) c2 = sc_sq(c2);
+        }
+        h[(size_t)t * f.B + b] = acc;
+    }
+}
+
 // K_msm_finish for a job of a few proofs: one wavefront per output instead of one lane.  What the lane does one after the other - add
 // up to 32 chunk sums, one or two fixed-base products of `windows` table additions each, compress - is spread over the lanes (an
 // item each: a table entry or a chunk sum), summed by the butterfly and compressed by lane 0: the finish of L_k and R_k is on the
@@ -215,6 +290,21 @@ __global__ void __launch_bounds__(64) k_msm_small_wave(K_msm_fixed_small fa, K_m
 #pragma unroll 1
     for (int sft = 32; sft > 0; sft >>= 1) acc = ge_add_ge(acc, ge_shfl_xor(acc, sft));
     if (threadIdx.x == 0) f.partial[(size_t)w * f.B + b] = acc;
+}
+
+// K_ge_reduce for a job of a few proofs: a wavefront adds 64 partial sums by the shuffle butterfly (6 dependent additions) where
+// the functor's thread adds 16 one after the other - and one level (1024 -> 16) replaces two (1024 -> 64 -> 4); the two sums of an
+// inner-product round (L_k, R_k: same shape) share the launch.  out[w*B + b] = sum_{l < 64} in[(w*64 + l)*B + b].
+__global__ void __launch_bounds__(64) k_ge_reduce_wave(const ge* in_a, ge* out_a, const ge* in_b, ge* out_b, uint32_t B, uint32_t in_cnt, uint32_t groups) {
+    const uint32_t per_req = groups * B;
+    const uint32_t wg = blockIdx.x, r = wg / per_req, rest = wg % per_req, w = rest / B, b = rest % B;
+    const ge* in = r ? in_b : in_a;
+    ge* out = r ? out_b : out_a;
+    const uint32_t c = w * 64u + threadIdx.x;
+    ge acc = c < in_cnt ? in[(size_t)c * B + b] : ge_identity();
+#pragma unroll 1
+    for (int sft = 32; sft > 0; sft >>= 1) acc = ge_add_ge(acc, ge_shfl_xor(acc, sft));
+    if (threadIdx.x == 0) out[(size_t)w * B + b] = acc;
 }
 
 // ---------------------------------------------------------------- TranscriptRng stream

@@ -46,6 +46,17 @@ static void upload_transposed(DevBuf<sc>& d, const uint8_t* h, size_t B, size_t 
 // Chunk sums that ONE thread per proof adds up afterwards (K_sum_partials): at most this many chunks, so that a job of a few
 // proofs does not end in a serial sum of thousands of partials (one proof: 16 384 at 2^18 (chunk, proof) threads)
 static const uint32_t MAX_SUM_CHUNKS = 256;
+// ... unless a wavefront per output adds them up (launch_sum_partials, device build, <= 1024 outputs): then a small job cuts its
+// vectors into many more chunks, and the kernels that produce the chunk sums (K_tcoef_partial: 0.78 ms for ONE depth-32 proof in 256
+// chunks of 73 multipliers; K_ipa_cross) get that much shorter
+static uint32_t sum_chunk_cap(uint32_t B, uint32_t outputs_per_proof) {
+#if defined(BPR1CS_HOSTSIM)
+    (void)B; (void)outputs_per_proof;
+    return MAX_SUM_CHUNKS;
+#else
+    return (uint64_t)outputs_per_proof * B <= 1024 ? 4096u : MAX_SUM_CHUNKS;
+#endif
+}
 
 struct MsmPlan {
     uint32_t nchunks, chunk;
@@ -59,6 +70,36 @@ struct MsmPlan {
 static const uint32_t MSM_LANE_PATH_MAX_PROOFS = 64;
 static const uint32_t FINISH_WAVE_MAX_PROOFS = 64;
 static const uint32_t MSM_WAVE_REDUCE_MAX_CHUNK = 2;    // k_msm_small_wave (first reduction level inside the wavefront) while a lane sums at most this many terms (see run_msm_multi)
+static void launch_sum_partials(uint64_t outputs, const K_sum_partials& f, dev_stream_t st) {
+#if !defined(BPR1CS_HOSTSIM)
+    if (outputs <= 1024 && f.C >= 8) {
+        hipLaunchKernelGGL(k_sum_partials_wave, dim3((uint32_t)outputs), dim3(64), 0, st, f);
+        HIPCHK(hipGetLastError());
+        return;
+    }
+#endif
+    launch(outputs, f, st);
+}
+static void launch_commit_T(const K_commit_T& f, uint32_t B, dev_stream_t st) {
+#if !defined(BPR1CS_HOSTSIM)
+    if (B <= FINISH_WAVE_MAX_PROOFS) {
+        hipLaunchKernelGGL(k_commit_T_wave, dim3(5u * B), dim3(64), 0, st, f);
+        HIPCHK(hipGetLastError());
+        return;
+    }
+#endif
+    launch((uint64_t)5 * B, f, st);
+}
+static void launch_pow_tables(const K_pow_tables& f, uint32_t B, dev_stream_t st) {
+#if !defined(BPR1CS_HOSTSIM)
+    if (B <= FINISH_WAVE_MAX_PROOFS) {
+        hipLaunchKernelGGL(k_pow_tables_wave, dim3(3u * B), dim3(64), 0, st, f);
+        HIPCHK(hipGetLastError());
+        return;
+    }
+#endif
+    launch((uint64_t)3 * B, f, st);
+}
 static void launch_finish(const K_msm_finish& f, uint32_t B, dev_stream_t st) {
 #if !defined(BPR1CS_HOSTSIM)
     if (B <= FINISH_WAVE_MAX_PROOFS && !f.extra_pt) {
@@ -115,6 +156,12 @@ struct MsmStats {
 // sums share one launch (k_msm_fixed2).  The chunk partials are folded `MSM_REDUCE_GROUP` at a time (twice when
 // there are many) before the per-proof finish kernel, which then adds at most MSM_REDUCE_GROUP points.
 static const uint32_t MSM_REDUCE_GROUP = 16;
+// a small job's levels: 64 at a time by a wavefront's butterfly (k_ge_reduce_wave); the CPU simulator's functor adds them serially
+#if defined(BPR1CS_HOSTSIM)
+static const uint32_t SMALL_REDUCE_GROUP = 16;
+#else
+static const uint32_t SMALL_REDUCE_GROUP = 64;
+#endif
 // one launch of the dominant kernel, HIP-event timed on its own stream when `stats` is given; `terms` = scalar*point
 // products of the launch summed over the batch (every launch of k_msm_fixed2 goes through here, so that bench.py's roofline
 // object describes the whole kernel: the commit sums, L_k / R_k of the un-folded rounds AND the folded generators).
@@ -181,7 +228,7 @@ static void run_msm_multi(const bpr1cs_gens* g, MsmReq* reqs, uint32_t nreq, uin
             uint32_t cnt = S.groups;
             size_t need = S.groups;
             S.nl = 0;
-            while (cnt > MSM_REDUCE_GROUP && S.nl < 8) { cnt = (cnt + MSM_REDUCE_GROUP - 1) / MSM_REDUCE_GROUP; S.lv[S.nl++] = cnt; need += cnt; }
+            while (cnt > MSM_REDUCE_GROUP && S.nl < 8) { cnt = (cnt + SMALL_REDUCE_GROUP - 1) / SMALL_REDUCE_GROUP; S.lv[S.nl++] = cnt; need += cnt; }
             need *= B;
             if (q.partial->n < need) q.partial->alloc(need);
             // layout: [last level][...][first level][wave sums]
@@ -205,6 +252,7 @@ static void run_msm_multi(const bpr1cs_gens* g, MsmReq* reqs, uint32_t nreq, uin
             r += pair ? 2 : 1;
         }
 #endif
+#if defined(BPR1CS_HOSTSIM)
         for (uint32_t r = 0; r < nreq; r++) {
             Small& S = sm[r];
             MsmReq& q = reqs[r];
@@ -214,11 +262,33 @@ static void run_msm_multi(const bpr1cs_gens* g, MsmReq* reqs, uint32_t nreq, uin
             for (uint32_t t = 0; t < S.nl; t++) {
                 off -= S.lv[t];
                 ge* out = q.partial->p + off * B;
-                launch((uint64_t)S.lv[t] * B, K_ge_reduce{in, out, B, in_cnt, MSM_REDUCE_GROUP}, st);
+                launch((uint64_t)S.lv[t] * B, K_ge_reduce{in, out, B, in_cnt, SMALL_REDUCE_GROUP}, st);
                 in = out; in_cnt = S.lv[t];
             }
             q.plan->nchunks = in_cnt;
         }
+#else
+        for (uint32_t r = 0; r < nreq;) {   // (two requests of one shape - L_k, R_k - share the launches of their levels)
+            Small& S = sm[r];
+            const bool pair = r + 1 < nreq && sm[r + 1].groups == S.groups && sm[r + 1].nl == S.nl && S.nl > 0;
+            const ge* in[2] = {S.first, pair ? sm[r + 1].first : nullptr};
+            uint32_t in_cnt = S.groups;
+            size_t off[2] = {S.first_off, pair ? sm[r + 1].first_off : 0};
+            for (uint32_t t = 0; t < S.nl; t++) {
+                ge* out[2] = {nullptr, nullptr};
+                for (uint32_t u = 0; u < (pair ? 2u : 1u); u++) {
+                    off[u] -= sm[r + u].lv[t];
+                    out[u] = reqs[r + u].partial->p + off[u] * B;
+                }
+                hipLaunchKernelGGL(k_ge_reduce_wave, dim3((pair ? 2u : 1u) * S.lv[t] * B), dim3(64), 0, st, in[0], out[0], in[1], out[1], B, in_cnt, S.lv[t]);
+                HIPCHK(hipGetLastError());
+                in[0] = out[0]; in[1] = out[1]; in_cnt = S.lv[t];
+            }
+            reqs[r].plan->nchunks = in_cnt;
+            if (pair) reqs[r + 1].plan->nchunks = in_cnt;
+            r += pair ? 2 : 1;
+        }
+#endif
         return;
     }
     const uint32_t nbk = (B + 63u) / 64u;

@@ -166,11 +166,15 @@ int bpr1cs_gens_table_info(const bpr1cs_gens* g, uint32_t* window_bits, uint32_t
                                          uploaded and reduced mod l on the device.  Default (-1): 4 proofs per CPU the process may use
                                          (affinity mask, cgroup quota); 0: never (the device chain, what a large batch hides behind the job
                                          before it).  Hashing only - no group or field arithmetic ever runs on the host */
-#define BPR1CS_OPT_WINDOW_BITS 16     /* creation only: signed window width W (4..12) of the fixed-base tables.  A term costs
+#define BPR1CS_OPT_WINDOW_BITS 16     /* creation only: signed window width W (4..15) of the fixed-base tables.  A term costs
                                          ceil(253/W) mixed additions; table bytes = (2+2*cap) * ceil(253/W) * (2^(W-1)+1) * 128
-                                         (W=8: 35 GB, W=11: 198 GB at capacity 32768).  Default 0 = the widest W <= 11 whose tables fit in
-                                         70 % of the free device memory: 11 for N <= 32768 on a 288 GB device, 8 / 7 for the
-                                         reference's as-shipped tree depths (N = 131072 / 262144, gadget_vsmt_4.rs:25, gadget_vsmt_2.rs:23) */
+                                         (W=8: 35 GB, W=11: 198 GB at capacity 32768).  Default 0 = the widest W <= 15 whose tables fit in
+                                         30 % of the free device memory, else the widest W <= 11 under 70 %: W = 15 for capacities up to
+                                         1024 (9 / 37 / 73 GB and 0.4 / 1.2 / 2.5 s of table building at capacity 128 / 512 / 1024: the
+                                         price of 17 instead of 23 additions per term for the small circuits' throughput), 11 for
+                                         capacity 32768 on a 288 GB device, 8 / 7 for the reference's as-shipped tree depths (N = 131072 /
+                                         262144, gadget_vsmt_4.rs:25, gadget_vsmt_2.rs:23).  A process that creates several handles, or
+                                         wants small tables for a latency-only use, passes W explicitly (W = 8: 1/12 of the bytes) */
 int bpr1cs_gens_set_option(bpr1cs_gens* g, int option, int value);
 /* bpr1cs_gens_create with options: `pairs` = n_pairs x (option, value).  BPR1CS_ERR_INVALID_ARGUMENT for an unknown option. */
 int bpr1cs_gens_create_opts(uint32_t gens_capacity, const int32_t* pairs, size_t n_pairs, bpr1cs_gens** out);
@@ -368,6 +372,12 @@ typedef struct {
     uint64_t msm_terms;     /* scalar*point terms it processed, summed over the batch */
     uint64_t msm_adds;      /* table additions = terms x windows of the table a term reads (a circuit's merged tables may be narrower) */
     uint64_t host_chains;   /* proofs whose TranscriptRng chain ran on a host thread (BPR1CS_OPT_HOST_CHAIN_PROOFS) */
+    /* why the jobs have the size they have (BPR1CS_OPT_JOB_PROOFS = 0: chosen from the free memory; all 0 when the size was given):
+     * the largest candidate J with J * sizing_bytes_per_proof + sizing_fixed_bytes <= sizing_free_bytes was taken.  A caller that gets
+     * smaller jobs than bench.py (4096 for N = 32768 on 288 GB) reads here what else was holding device memory when the handle sized them */
+    uint64_t sizing_free_bytes;      /* device memory free (+ what the handle and the allocator's cache already hold) when the size was chosen */
+    uint64_t sizing_bytes_per_proof; /* working set per proof: own fronts of the jobs in flight + shared front + back phase */
+    uint64_t sizing_fixed_bytes;     /* per-job constants, the circuit's merged tables if still to be built, the 4 GiB that must stay free */
 } bpr1cs_prove_stats;
 int bpr1cs_last_prove_stats(bpr1cs_prove_stats* out);
 

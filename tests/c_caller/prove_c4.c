@@ -51,7 +51,9 @@ int main(int argc, char** argv) {
     double dt = now() - t0;
     bpr1cs_prove_stats st;
     bpr1cs_last_prove_stats(&st);
-    printf("{\"proofs_per_s\": %.1f, \"proofs\": %zu, \"seconds\": %.3f, \"jobs\": %u, \"job_proofs\": %u, \"n\": %u, \"m\": %u}\n", timed / dt, timed, dt, st.jobs, st.job_proofs, n, mm);
+    printf("{\"proofs_per_s\": %.1f, \"proofs\": %zu, \"seconds\": %.3f, \"jobs\": %u, \"job_proofs\": %u, \"n\": %u, \"m\": %u, "
+           "\"sizing_free_gib\": %.2f, \"sizing_mb_per_proof\": %.2f, \"sizing_fixed_gib\": %.2f}\n", timed / dt, timed, dt, st.jobs, st.job_proofs, n, mm,
+           st.sizing_free_bytes / 1073741824.0, st.sizing_bytes_per_proof / 1048576.0, st.sizing_fixed_bytes / 1073741824.0);
     FILE* f = fopen(argv[5], "wb");
     fwrite(proofs, 1, (have < timed ? have : timed) * plen, f);
     fclose(f);

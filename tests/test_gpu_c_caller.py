@@ -42,7 +42,11 @@ def test_c_caller_proves_the_benchmark_workload(hip_lib, hip_glib, tmp_path):
     got = out.read_bytes()
     assert got[:len(want)] == want                      # the same bytes as through ctypes
     assert res["n"] == 18656 and res["m"] == 100 and res["jobs"] == -(-16384 // res["job_proofs"])
-    assert res["job_proofs"] >= 2048                    # the library's own job size (4096 next to W = 11 tables on 288 GB)
+    # the library's own job size: 4096 next to W = 11 tables on 288 GB when nothing else holds device memory; this pytest process does
+    # (its HIP context, what earlier tests left in the allocator) - bpr1cs_prove_stats.sizing_* says what the handle saw and chose from
+    need = res["sizing_fixed_gib"] + 4096 * res["sizing_mb_per_proof"] / 1024.0
+    assert res["job_proofs"] == 4096 or res["sizing_free_gib"] < need, res
+    assert res["job_proofs"] >= 2048
     assert res["proofs_per_s"] > 2400                   # bench.py: 2870-3008 on the boxes of round 4
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     open(os.path.join(ROOT, "gpurun_out", "c_caller.json"), "w").write(json.dumps(res) + "\n")

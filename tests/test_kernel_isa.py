@@ -23,29 +23,30 @@ def kernels():
         pytest.skip("libbpr1cs_hip.so is not built (run __graft_entry__.build())")
     if not os.path.exists(K.LLVM + "/llvm-objdump"):
         pytest.skip("no llvm-objdump in this image")
-    with tempfile.NamedTemporaryFile(suffix=".co", delete=False) as f:
-        f.write(K.code_object(LIB))
-        co = f.name
-    try:
-        syms = subprocess.run([K.LLVM + "/llvm-readelf", "-sW", co], capture_output=True, text=True).stdout
-        notes = subprocess.run([K.LLVM + "/llvm-readelf", "--notes", co], capture_output=True, text=True).stdout
-        names = sorted(set(l.split()[-1] for l in syms.split("\n") if " FUNC " in l))
-        out = {}
-        for name in names:
-            if not any(k in name for k in ("k_msm_fixed2", "k_rng_stream", "k_witness_team", "k_pip_buckets", "k_functor_lockstep")):
-                continue
-            blk = next((e for e in notes.split("\n  - ") if (".name:           " + name + "\n") in e + "\n"), "")
-            meta = {k: int(v) for k, v in re.findall(r"\.(vgpr_count|sgpr_count|private_segment_fixed_size|group_segment_fixed_size):\s+(\d+)", blk)}
-            dis = subprocess.run([K.LLVM + "/llvm-objdump", "-d", "--disassemble-symbols=" + name, co], capture_output=True, text=True).stdout
-            ins = []
-            for l in dis.split("\n"):
-                m = re.search(r"//\s*([0-9A-Fa-f]+):\s*((?:[0-9A-Fa-f]{8}\s*)+)", l)
-                if l.startswith("\t") and m:
-                    ins.append((int(m.group(1), 16), len(m.group(2).split()), l.split("//")[0].strip()))
-            out[name] = (meta, ins)
-        return out
-    finally:
-        os.unlink(co)
+    out = {}
+    for blob in K.code_objects(LIB):   # one code object per translation unit (the dominant kernel is compiled as a unit of its own)
+        with tempfile.NamedTemporaryFile(suffix=".co", delete=False) as f:
+            f.write(blob)
+            co = f.name
+        try:
+            syms = subprocess.run([K.LLVM + "/llvm-readelf", "-sW", co], capture_output=True, text=True).stdout
+            notes = subprocess.run([K.LLVM + "/llvm-readelf", "--notes", co], capture_output=True, text=True).stdout
+            names = sorted(set(l.split()[-1] for l in syms.split("\n") if " FUNC " in l))
+            for name in names:
+                if not any(k in name for k in ("k_msm_fixed2", "k_rng_stream", "k_witness_team", "k_pip_buckets", "k_functor_lockstep")):
+                    continue
+                blk = next((e for e in notes.split("\n  - ") if (".name:           " + name + "\n") in e + "\n"), "")
+                meta = {k: int(v) for k, v in re.findall(r"\.(vgpr_count|sgpr_count|private_segment_fixed_size|group_segment_fixed_size):\s+(\d+)", blk)}
+                dis = subprocess.run([K.LLVM + "/llvm-objdump", "-d", "--disassemble-symbols=" + name, co], capture_output=True, text=True).stdout
+                ins = []
+                for l in dis.split("\n"):
+                    m = re.search(r"//\s*([0-9A-Fa-f]+):\s*((?:[0-9A-Fa-f]{8}\s*)+)", l)
+                    if l.startswith("\t") and m:
+                        ins.append((int(m.group(1), 16), len(m.group(2).split()), l.split("//")[0].strip()))
+                out[name] = (meta, ins)
+        finally:
+            os.unlink(co)
+    return out
 
 
 def pick(kernels, pat):
@@ -123,3 +124,24 @@ def test_lockstep_transcript_kernels_split_the_permutation(kernels):
         c = collections.Counter(t.split()[0] for _, _, t in ins)
         assert c["ds_xor_b64"] >= 1, "%s: no lockstep permutation" % name
         assert 0 < meta["group_segment_fixed_size"] <= 16384  # the exchange buffers, plus whatever private arrays the compiler moved to LDS
+
+
+def test_a_32_lane_workgroup_always_means_a_lockstep_transcript_launch():
+    """csrc/merlin.hpp: keccak_f1600 takes the cooperative 32-lane form whenever blockDim.x == 32 (an implicit contract).
+    Made checkable: the ONLY launch with 32 threads in the library's sources is dev.hpp's launch_transcript -> k_functor_lockstep, every
+    other launch site names 64 or 256 (or a constant that is one of them), and the probe kernels take no caller-chosen block size."""
+    csrc = os.path.join(ROOT, "bulletproofs-r1cs-gadgets_amd", "csrc")
+    sites = []
+    for fn in sorted(os.listdir(csrc)):
+        if not fn.endswith((".hpp", ".hip")):
+            continue
+        text = open(os.path.join(csrc, fn)).read()
+        for m in re.finditer(r"hipLaunchKernelGGL\(\s*((?:HIP_KERNEL_NAME\()?[\w<>:, ]+\)?)\s*,\s*dim3\(([^;]*?)\)\s*,\s*dim3\(([^)]*)\)", text, re.S):
+            sites.append((fn, m.group(1).strip(), m.group(3).strip()))
+    assert len(sites) >= 20, sites
+    blocks = collections.Counter(b for _, _, b in sites)
+    allowed = {"64", "256", "32", "threads", "WG", "PIP_WG"}
+    assert set(blocks) <= allowed, blocks
+    assert [(fn, k) for fn, k, b in sites if b == "32"] == [("dev.hpp", "HIP_KERNEL_NAME(k_functor_lockstep<F>)")]
+    probe = open(os.path.join(csrc, "api_probe.hpp")).read()
+    assert re.search(r"threads\s*=\s*256\b", probe), "api_probe.hpp: the probe kernels' block size is no longer the constant 256"

@@ -12,19 +12,39 @@ import tempfile
 LLVM = "/opt/rocm/lib/llvm/bin"
 
 
-def code_object(lib):
+def code_objects(lib):
+    """every gfx950 code object of the library: one clang offload bundle per translation unit (the dominant kernel is a unit of its own)"""
     data = open(lib, "rb").read()
-    i = data.find(b"__CLANG_OFFLOAD_BUNDLE__")
-    n = struct.unpack_from("<Q", data, i + 24)[0]
-    off = i + 32
-    for _ in range(n):
-        o, sz, tl = struct.unpack_from("<QQQ", data, off)
-        off += 24
-        triple = data[off:off + tl].decode()
-        off += tl
-        if "gfx950" in triple:
-            return data[i + o:i + o + sz]
-    raise SystemExit("no gfx950 code object in " + lib)
+    out, at = [], 0
+    while True:
+        i = data.find(b"__CLANG_OFFLOAD_BUNDLE__", at)
+        if i < 0:
+            break
+        at = i + 24
+        n = struct.unpack_from("<Q", data, i + 24)[0]
+        off = i + 32
+        if n > 16:
+            continue
+        for _ in range(n):
+            o, sz, tl = struct.unpack_from("<QQQ", data, off)
+            off += 24
+            triple = data[off:off + tl].decode(errors="replace")
+            off += tl
+            if "gfx950" in triple:
+                out.append(data[i + o:i + o + sz])
+    if not out:
+        raise SystemExit("no gfx950 code object in " + lib)
+    return out
+
+
+def code_object(lib, pattern=None):
+    """the code object that holds the kernels whose symbol contains `pattern` (None: the largest one)"""
+    cos = code_objects(lib)
+    if pattern:
+        hit = [c for c in cos if pattern.encode() in c]
+        if hit:
+            return hit[0]
+    return max(cos, key=len)
 
 
 def kernel_hash(lib, pattern):
@@ -34,7 +54,7 @@ def kernel_hash(lib, pattern):
     import hashlib
     try:
         with tempfile.NamedTemporaryFile(suffix=".co", delete=False) as f:
-            f.write(code_object(lib))
+            f.write(code_object(lib, pattern))
             co = f.name
         try:
             syms = subprocess.run([LLVM + "/llvm-readelf", "-sW", co], capture_output=True, text=True).stdout
@@ -68,7 +88,7 @@ def main():
         lib = args.pop(0)
     pat = args[0]
     with tempfile.NamedTemporaryFile(suffix=".co", delete=False) as f:
-        f.write(code_object(lib))
+        f.write(code_object(lib, pat))
         co = f.name
     syms = subprocess.run([LLVM + "/llvm-readelf", "-sW", co], capture_output=True, text=True).stdout
     names = [l.split()[-1] for l in syms.split("\n") if " FUNC " in l and pat in l]

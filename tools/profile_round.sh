@@ -31,9 +31,12 @@ for c in c4 c1; do
   timeout 600 rocprofv3 --kernel-trace -d $out/kt_lat_$c -o out -- python tools/latency_probe.py --cases $c --batches 1 --reps 3 --no-device-program > $out/kt_lat_$c.log 2>&1
   gap=5; [ $c = c1 ] && gap=2
   python tools/trace_lastcall.py $out/kt_lat_$c $gap 3000 > $out/latency_${c}_one_proof_timeline.txt 2>&1
-  # with the chain started ahead of prove() the device is never idle between two calls of the probe: the window above holds all of them - cut the second one out
-  python tools/timeline_call.py $out/latency_${c}_one_proof_timeline.txt 2 > $out/latency_${c}_one_proof_call2.txt 2>&1
   rm -rf $out/kt_lat_$c
 done
 [ -x tools/ubench ] && timeout 300 tools/ubench > $out/ubench.txt 2>&1
+[ -x tools/ubench_latency ] && timeout 120 tools/ubench_latency > $out/ubench_latency.txt 2>&1
+# the plain C caller alone on the device (the library sizes its jobs from the whole device), and the host-side chain's rate on this box
+timeout 900 python tools/c_caller_standalone.py 8192 20480 > $out/c_caller_standalone.json 2>$out/c_caller_standalone.err
+g++ -O3 -std=c++17 -DBPR1CS_HOST_ONLY -Ibulletproofs-r1cs-gadgets_amd/csrc tools/host_chain_bench.cpp -o /tmp/hcb -pthread 2>/dev/null && /tmp/hcb > $out/host_chain_rate.txt 2>&1
+timeout 600 python tools/latency_probe.py --cases c1,c4 --batches 1,8,64 --reps 3 --no-device-program > $out/latency_probe.txt 2>&1
 if [ "$2" = tests ]; then timeout 1700 python -m pytest tests -m gpu -x -q > $out/gputests.txt 2>&1; tail -3 $out/gputests.txt; fi

@@ -38,6 +38,27 @@ def stats(d):
     print("# kernel | calls | total_ms | avg_ms | percent")
     for k, a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
         print("%s | %d | %.3f | %.4f | %.2f" % (k, a[0], a[1], a[1] / a[0], 100 * a[1] / tot))
+    # the dominant kernel by launch geometry: the trace mixes the prove jobs' launches (7 per 4096-proof job: A_I/A_O, S, four un-folded
+    # rounds, the fold) with the warm-up's, the verifier's and the parity batch's - bench.py's roofline.avg_launch_ms is the mean over
+    # the launches of the TIMED prove call only, i.e. over the geometries that occur once per full-size job
+    cols = [r[1] for r in con.execute("pragma table_info(%s)" % kt)]
+    gcol = next((c for c in ("grid_size_x", "grid_x", "grid_size") if c in cols), None)
+    if gcol:
+        by = collections.defaultdict(lambda: [0, 0.0])
+        for n, s, e, g in con.execute("select name, start, end, %s from %s" % (gcol, kt)):
+            if "k_msm_fixed2" in n:
+                a = by[int(g)]
+                a[0] += 1
+                a[1] += (e - s) / 1e6
+        if by:
+            print("# k_msm_fixed2 by launch geometry: %s | calls | total_ms | avg_ms" % gcol)
+            for g, a in sorted(by.items(), key=lambda kv: -kv[1][1]):
+                print("k_msm_fixed2 %s=%d | %d | %.3f | %.4f" % (gcol, g, a[0], a[1], a[1] / a[0]))
+            most = max(a[0] for a in by.values())
+            full = [a for a in by.values() if a[0] == most]   # the geometries every full-size job launches once
+            if len(full) > 1:
+                print("k_msm_fixed2 [the %d geometries launched %d times each = once per full-size job] | %d | %.3f | %.4f" % (
+                    len(full), most, sum(a[0] for a in full), sum(a[1] for a in full), sum(a[1] for a in full) / sum(a[0] for a in full)))
 
 
 def pmc(dirs):

@@ -81,6 +81,9 @@ pub const BPR1CS_ERR_OUT_OF_MEMORY: i32 = -19;
     pub msm_terms: u64,
     pub msm_adds: u64,
     pub host_chains: u64,
+    pub sizing_free_bytes: u64,
+    pub sizing_bytes_per_proof: u64,
+    pub sizing_fixed_bytes: u64,
 }
 #[link(name = "bpr1cs_hip")]
 extern "C" {
