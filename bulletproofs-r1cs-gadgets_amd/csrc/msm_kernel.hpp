@@ -275,11 +275,8 @@ __global__ void __launch_bounds__(64, WAVES_PER_SIMD) k_msm_fixed2(const MsmLaun
     extern __shared__ uint16_t msm_dig[];  // [2][windows][64]
     msm_fixed2_body(L, blockIdx.x, threadIdx.x, msm_dig);
 }
-// The kernel is compiled as a translation unit of its own (csrc/msm_kernel_tu.hip) so that it can have its own instruction
-// scheduling strategy: -mllvm -amdgpu-sched-strategy=max-ilp makes ITS launches 3 % shorter (159.4 -> 154.8 ms per 4096-proof launch,
-// same box, alternating runs: profiles/r06c_ab_sched_strategy.txt) and the rest of the library slower by as much, so the option
-// is given to this unit only.  Everywhere else the instantiation is only declared.
-#if !defined(BPR1CS_MSM_KERNEL_TU)
-extern template __global__ void k_msm_fixed2<3>(const MsmLaunch L);
-#endif
+// (Round 6, measured and not kept: the AMDGPU back end's other instruction scheduling strategy, -mllvm -amdgpu-sched-strategy=max-ilp.
+// For the whole library: this kernel's launches 3 % shorter next to front kernels that had become slower, 2931 / 2923 -> 2921 / 2919
+// proofs/s.  For this kernel alone, as a translation unit of its own: launches 1.5 % LONGER, 2956 / 2944 / 2939 -> 2916 / 2907 / 2918.
+// Same box, alternating runs: profiles/r06c_ab_sched_strategy.txt, profiles/r06d_ab_msm_kernel_sched_strategy.txt.)
 #endif

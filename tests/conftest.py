@@ -50,7 +50,7 @@ def sim_glib(sim_lib):
     hdir = os.path.dirname(src)
     deps = [src] + [os.path.join(hdir, f) for f in os.listdir(hdir)] + [os.path.join(bdir, "libbpr1cs_sim.so")]
     if not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-DBPR1CS_HOST_ONLY", "-shared", "-fPIC", src, "-o", out,
+        subprocess.check_call(["g++", "-O3", "-std=c++17", "-DBPR1CS_HOST_ONLY", "-shared", "-fPIC", src, "-o", out,
                                "-L" + bdir, "-lbpr1cs_sim", "-Wl,-rpath," + bdir])
     return bp.load_gadgets_library(out)
 
