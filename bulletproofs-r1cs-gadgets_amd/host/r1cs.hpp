@@ -69,10 +69,13 @@ struct Scalar {
         return s;
     }
     std::array<uint8_t, 32> to_bytes() const { std::array<uint8_t, 32> o; write_bytes(o.data()); return o; }
-    void write_bytes(uint8_t* out) const {   // canonical little-endian: out of Montgomery form = a product with 1
-        sc one = sc_zero();
-        one.v[0] = 1;
-        sc c = sc_mul_host(m, one);
+    void write_bytes(uint8_t* out) const {   // canonical little-endian: out of Montgomery form
+        // (a constraint system's coefficients are mostly 1 and -1: exporting the depth-32 tree circuit is 87 348 of these calls per proof)
+        static const sc one_m = sc_const(SC_R), minus_one_m = hostsc::sub(sc_zero(), sc_const(SC_R));
+        static const sc minus_one_c = hostsc::from_mont(minus_one_m);
+        if (memcmp(m.v, one_m.v, 32) == 0) { memset(out, 0, 32); out[0] = 1; return; }
+        if (memcmp(m.v, minus_one_m.v, 32) == 0) { memcpy(out, minus_one_c.v, 32); return; }
+        sc c = hostsc::from_mont(m);
         memcpy(out, c.v, 32);
     }
     uint8_t operator[](size_t i) const { return to_bytes()[i]; }  // `l[i]` at gadget_vsmt_4.rs:227

@@ -42,6 +42,33 @@ inline sc mul(const sc& a, const sc& b) {
     memcpy(out.v, keep ? t : r, 32);
     return out;
 }
+// x * 2^-256 mod l, canonical: out of Montgomery form (= mul(x, 1) without the 16 limb products that multiply by zero limbs)
+inline sc from_mont(const sc& a) {
+    static const uint64_t LINV = [] {
+        uint64_t x = 1;
+        for (int i = 0; i < 7; i++) x *= 2 - L64[0] * x;
+        return (uint64_t)0 - x;
+    }();
+    uint64_t t[5];
+    memcpy(t, a.v, 32);
+    t[4] = 0;
+    for (int i = 0; i < 4; i++) {
+        const uint64_t m = t[0] * LINV;
+        u128 c = ((u128)m * L64[0] + t[0]) >> 64;
+        c += (u128)m * L64[1] + t[1]; t[0] = (uint64_t)c; c >>= 64;
+        c += t[2]; t[1] = (uint64_t)c; c >>= 64;                       // (limb 2 of l is zero)
+        c += (u128)m * L64[3] + t[3]; t[2] = (uint64_t)c; c >>= 64;
+        c += t[4]; t[3] = (uint64_t)c; t[4] = (uint64_t)(c >> 64);
+    }
+    // t < l + 1 (a < 2^256 <= 16 l, each round halves... a < l in every use): one conditional subtraction keeps it canonical
+    uint64_t r[4];
+    u128 br = 0;
+    for (int j = 0; j < 4; j++) { u128 d = (u128)t[j] - L64[j] - (uint64_t)br; r[j] = (uint64_t)d; br = (d >> 64) & 1; }
+    const bool keep = br != 0 && t[4] == 0;
+    sc out;
+    memcpy(out.v, keep ? t : r, 32);
+    return out;
+}
 // a + b mod l, a - b mod l (a, b < l)
 inline sc add(const sc& a, const sc& b) {
     uint64_t A[4], B[4], s[4], r[4];

@@ -15,6 +15,8 @@ int main() {
         if (memcmp(i1.v, i2.v, 32)) { bad++; if (bad < 5) printf("invert mismatch at %d\n", i); }
         sc m1 = sc_mul(a, b), m2 = hostsc::mul(a, b), s1 = sc_add(a, b), s2 = hostsc::add(a, b), d1 = sc_sub(a, b), d2 = hostsc::sub(a, b);
         if (memcmp(m1.v, m2.v, 32) || memcmp(s1.v, s2.v, 32) || memcmp(d1.v, d2.v, 32)) { bad++; if (bad < 5) printf("arith mismatch at %d\n", i); }
+        sc f1 = sc_from_mont(a), f2 = hostsc::from_mont(a);   // out of Montgomery form: the reduction alone
+        if (memcmp(f1.v, f2.v, 32)) { bad++; if (bad < 5) printf("from_mont mismatch at %d\n", i); }
     }
     sc x = rnd(), acc = sc_one_mont();
     auto t0 = std::chrono::steady_clock::now();
