@@ -367,9 +367,11 @@ def measure(bp, lib, gens, circ, w, B, steps, warm_steps, barrier=None):
 
 LATENCY_SHAPE = ("the reference's own call shape - ONE proof per prove() inside its timed bracket (src/gadget_vsmt_4.rs:421-435, "
                  "gadget_bound_check.rs:49-87, gadget_poseidon.rs:734-747): Prover::new -> commit x m -> gadget synthesis on the host -> prove(), on "
-                 "generators created once outside the bracket (:386-387).  = bpr1cs_gadget_prove_on: per commit one bpr1cs_msm_fixed call, then CSR "
-                 "export + bpr1cs_circuit_create (cached per description) + bpr1cs_prove_batch_transcripts(batch, HOST wires) - exactly what "
-                 "tools/rust_shim/prover.rs does for batch 1.  Nothing is kept between calls and nothing is speculated on: the proof's TranscriptRng "
+                 "generators created once outside the bracket (:386-387).  = bpr1cs_gadget_prove_on: the C++ Prover (host/r1cs.hpp), CSR "
+                 "export + bpr1cs_circuit_create (cached per description) + bpr1cs_prove_batch_transcripts(batch, HOST wires).  The C++ commit() hands "
+                 "out commitments that are resolved when read - after prove(), from the V's the prove call returns; b1_eager_commits = every commit() "
+                 "computing its point before it returns, one bpr1cs_msm_fixed call each: what upstream's signature forces and tools/rust_shim/prover.rs "
+                 "does.  Nothing is kept between calls and nothing is speculated on: the proof's TranscriptRng "
                  "chain (2n + 8 sequential Keccak-f[1600]) runs INSIDE the prove call on a host thread while the device takes the wires and computes "
                  "A_I / A_O (BPR1CS_OPT_HOST_CHAIN_PROOFS; proofs_with_host_chain), so the first proof of a statement costs what every later one does "
                  "(first_call_ms additionally pays the handle's arenas and the circuit-cache miss); batch 8 / 64 = that many host syntheses, ONE device "
@@ -412,6 +414,18 @@ def run_latency(bp, lib, case, w, gens, fixture, batches=(1, 8, 64), compiled_ro
         if B == 1:
             out["b1"]["first_call_ms"] = first_ms
             out["b1"]["proofs_with_host_chain"] = on_host
+            # the same with every commit() computing its point before it returns: what a caller bound to upstream's signature
+            # `commit(v, blinding) -> (CompressedRistretto, Variable)` pays (tools/rust_shim/prover.rs) - one device call per commitment
+            ew, es, eok = [], None, True
+            for rep in range(4):
+                t0 = time.perf_counter()
+                Pe, Ce, sece = bp.gadget_prove_on(gens, w["gadget"], w["ip"], w["sp"], w["label"], v, b, m, 1, s, eager_commits=True)
+                if rep:
+                    ew.append(time.perf_counter() - t0)
+                    es = sece
+                eok = eok and hashlib.sha256(Pe[0]).hexdigest()[:32] == fx[0] and Ce[0] == C[0]
+            out["b1_eager_commits"] = {"ms_per_call": 1e3 * statistics.median(ew), "stage_ms": {kk: 1e3 * x for kk, x in es.items()},
+                                       "commit_calls": m, "us_per_commit": 1e6 * es["commit"] / max(1, m), "parity_ok": eok}
         # the same witnesses through the COMPILED circuit (bpr1cs_gadget_compile once, outside the clock; the witness program runs on the
         # device, the commitments come out of the call): what a caller does that can keep a circuit handle - no host synthesis, no per-commit calls
         circ = compiled.setdefault("c", bp.CompiledGadget(w["gadget"], w["ip"], w["sp"])) if compiled_rows else None

@@ -20,8 +20,10 @@ for c in ("c1", "c2", "c3", "c5", "vsmt4_d128", "vsmt2_d253"):
 for c in ("c4", "c1"):
     hdr["latency_%s_one_proof_timeline.txt" % c] = "# rocprofv3 --kernel-trace -- python tools/latency_probe.py --cases %s --batches 1 --reps 3 --no-device-program ; tools/trace_lastcall.py (%s, commit %s): every launch of the last bpr1cs_prove_batch_transcripts(batch 1, host wires) call%s, then the totals per kernel\n" % (
         c, tag, commit, " (c1: the window holds the three timed calls, divide the totals by 3)" if c == "c1" else "")
-for c in ("c4", "c1"):
-    hdr["latency_%s_one_proof_call2.txt" % c] = "# the SECOND call of the same trace (tools/timeline_call.py; %s, commit %s): one proof per prove() with its TranscriptRng chain started at the gadget's first multiplier (bpr1cs_prove_prefetch, the queue beside the commitments') - runs of one kernel collapsed\n" % (tag, commit)
+hdr["ubench_latency.txt"] = "# tools/ubench_latency on MI355X (%s): ONE wavefront alone on the chip - nanoseconds and shader cycles per dependent operation (the single-commitment / single-proof kernels)\n" % tag
+hdr["host_chain_rate.txt"] = "# tools/host_chain_bench.cpp on the GPU box's host CPU (%s): the TranscriptRng chain of a depth-32 proof (csrc/host_chain.hpp) on 1 .. 64 threads at once\n" % tag
+hdr["latency_probe.txt"] = "# python tools/latency_probe.py --cases c1,c4 --batches 1,8,64 --reps 3 --no-device-program (%s, commit %s): bpr1cs_gadget_prove_on / _verify_on, wall ms and stage ms per call\n" % (tag, commit)
+hdr["gputests.txt"] = "# python -m pytest tests -m gpu -x -q (%s, commit %s)\n" % (tag, commit)
 names = {"ubench.txt": "ubench_gfx950.txt"}
 for f, h in hdr.items():
     p = os.path.join(src, f)
@@ -32,10 +34,12 @@ for f, h in hdr.items():
         clk = {r[0]: float(r[2]) / 8 / (float(r[3]) * 1e6) for r in rows}
         h += "#   " + "   ".join("%s: %.2f GHz" % (k, clk[k]) for k in ("k_msm_fixed2", "k_probe_mad", "K_ipa_vb_fold2", "K_ipa_vb_win", "K_build_table") if k in clk) + "\n"
     open(dst + names.get(f, f), "w").write(h + body)
-for f in ["bench_default.json", "bench_torchrun_1rank.json", "bench_sync.json"] + ["bench_%s.json" % c for c in ("c1", "c2", "c3", "c5", "vsmt4_d128", "vsmt2_d253")]:
+for f in ["bench_default.json", "bench_torchrun_1rank.json", "bench_sync.json", "c_caller_standalone.json"] + ["bench_%s.json" % c for c in ("c1", "c2", "c3", "c5", "vsmt4_d128", "vsmt2_d253")]:
     p = os.path.join(src, f)
     if os.path.exists(p):
-        line = [l for l in open(p).read().strip().split("\n") if l.startswith("{")][-1]
+        lines = [l for l in open(p).read().strip().split("\n") if l.startswith("{")]
+        if not lines: print("empty", p); continue
+        line = lines[-1]
         json.loads(line)
         open(dst + f, "w").write(line + "\n")
 print(sorted(x for x in os.listdir("profiles") if x.startswith(tag)))

@@ -54,11 +54,16 @@ def stats(d):
             print("# k_msm_fixed2 by launch geometry: %s | calls | total_ms | avg_ms" % gcol)
             for g, a in sorted(by.items(), key=lambda kv: -kv[1][1]):
                 print("k_msm_fixed2 %s=%d | %d | %.3f | %.4f" % (gcol, g, a[0], a[1], a[1] / a[0]))
-            most = max(a[0] for a in by.values())
-            full = [a for a in by.values() if a[0] == most]   # the geometries every full-size job launches once
-            if len(full) > 1:
-                print("k_msm_fixed2 [the %d geometries launched %d times each = once per full-size job] | %d | %.3f | %.4f" % (
-                    len(full), most, sum(a[0] for a in full), sum(a[1] for a in full), sum(a[1] for a in full) / sum(a[0] for a in full)))
+            # launches per full-size job: J = calls of the rarest geometry that matters (>= 5 % of the kernel's time) = number of such
+            # jobs in the trace; a geometry with k J (+ stragglers of other callers) calls is launched k times per job
+            tot_ms = sum(a[1] for a in by.values())
+            big = {g: a for g, a in by.items() if a[1] >= 0.05 * tot_ms}
+            J = min(a[0] for a in big.values())
+            per_job = {g: max(1, round(a[0] / J)) for g, a in big.items()}
+            n = sum(per_job.values())
+            avg = sum(per_job[g] * big[g][1] / big[g][0] for g in big) / n
+            print("k_msm_fixed2 [%d full-size jobs x %d launches per job: mean over a job's launches, what bench.py's roofline.avg_launch_ms is] | %d | %.3f | %.4f" % (
+                J, n, J * n, J * n * avg, avg))
 
 
 def pmc(dirs):

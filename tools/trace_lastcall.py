@@ -1,11 +1,13 @@
 #!/usr/bin/env python3
 """Timeline of the LAST prove call of a rocprofv3 --kernel-trace run (the single-proof latency probe): every launch after the
 last idle gap longer than `gap_ms` on all queues, with its offset, duration and the idle time before it on its queue, then the
-per-kernel totals of that window.   trace_lastcall.py DIR [gap_ms=20] [max_rows=400]"""
+per-kernel totals of that window.   trace_lastcall.py DIR [gap_ms=20] [max_rows=400] [marker=K_assemble]
+(marker: the kernel that ends the call looked for - K_assemble for a prove call, K_verify_finish for a verify call)"""
 import sqlite3, sys, glob, collections
 db = sorted(glob.glob(sys.argv[1] + "/**/*.db", recursive=True))[-1]
 gap_ms = float(sys.argv[2]) if len(sys.argv) > 2 else 20.0
 max_rows = int(sys.argv[3]) if len(sys.argv) > 3 else 400
+marker = sys.argv[4] if len(sys.argv) > 4 else "K_assemble"
 con = sqlite3.connect(db)
 tabs = [r[0] for r in con.execute("select name from sqlite_master where type in ('table','view')")]
 kt = [t for t in tabs if t.startswith("kernels")][0]
@@ -19,7 +21,7 @@ def short(n):
 rows = [(short(n), s, e, q) for n, s, e, q in con.execute("select name, start, end, queue_id from %s order by start" % kt)]
 # the window of the last prove call: it ends with the last K_assemble (proof bytes); walk back from there to the first launch
 # that follows an idle gap longer than gap_ms on all queues
-last = max(i for i, r in enumerate(rows) if "K_assemble" in r[0])
+last = max(i for i, r in enumerate(rows) if marker in r[0])
 rows = rows[:last + 1]
 cut = 0
 busy_until = 0
