@@ -20,6 +20,8 @@ struct bpr1cs_job {
     dev_event_t ev_in{}, ev_rng{}, ev_wit{}, ev_done{}, ev_tail{};
     // host-side TranscriptRng chains of a small job (csrc/host_chain.hpp): pinned staging of the V commitments read back for them,
     // of their raw draws and of the transcripts they leave; the draws are blinding material and are wiped when the job is released
+    uint8_t* h_in = nullptr;      // the call's inputs as they are uploaded (secrets: wiped when the job is released)
+    size_t h_in_bytes = 0;
     uint8_t* h_V = nullptr;
     uint64_t* h_raw = nullptr;
     size_t h_raw_bytes = 0;
@@ -105,6 +107,8 @@ static void job_release(bpr1cs_job* job) {
     for (void* p : job->deferred) dev_free_now(p);
     job->deferred.clear();
     if (job->h_raw) host_wipe(job->h_raw, job->h_raw_bytes);
+    if (job->h_in) host_wipe(job->h_in, job->h_in_bytes);
+    host_stage_free(job->h_in);
     host_stage_free(job->h_raw);
     host_stage_free(job->h_V);
     host_stage_free(job->h_tr0);
@@ -211,13 +215,29 @@ static int prove_job_begin(const bpr1cs_gens* g, const bpr1cs_circuit* c, const 
     DBG_JOB("begin: slot %u, %u proofs", slot, B);
 
     // ---- inputs
-    DevBuf<sc> v_raw, vbl_raw, v_m((size_t)m * B), vbl_m((size_t)m * B);
-    upload_transposed(v_raw, values, B, m, sl);
-    upload_transposed(vbl_raw, v_blindings, B, m, sl);
-    DevBuf<uint8_t> d_seeds((size_t)B * 32);
-    dev_h2d(d_seeds.p, rng_seeds, (size_t)B * 32, sl);
-    DevBuf<strobe> d_init(n_init);
-    dev_h2d(d_init.p, init, n_init * sizeof(strobe), sl);
+    // everything the caller hands over but the wires in ONE pinned block and ONE copy: committed values and blindings (element-major
+    // [m][B]), the outside randomness, the transcripts the proofs start from.  (Four synchronous copies of a few hundred bytes each were
+    // 0.1 ms in front of a 64-bit bound check's 3 ms.)
+    const size_t vb = (size_t)m * B * sizeof(sc), sb = (size_t)B * 32, ib = n_init * sizeof(strobe);
+    job->h_in_bytes = 2 * vb + sb + ib;
+    job->h_in = (uint8_t*)host_stage_alloc(job->h_in_bytes);
+    {
+        sc* hv = (sc*)job->h_in;
+        sc* hb = hv + (size_t)m * B;
+        for (size_t b = 0; b < B; b++)
+            for (size_t j = 0; j < m; j++) {
+                hv[j * B + b] = sc_load_raw(values + (b * m + j) * 32);
+                hb[j * B + b] = sc_load_raw(v_blindings + (b * m + j) * 32);
+            }
+        memcpy(job->h_in + 2 * vb, rng_seeds, sb);
+        memcpy(job->h_in + 2 * vb + sb, init, ib);
+    }
+    DevBuf<uint8_t> d_in(job->h_in_bytes);
+    dev_h2d_async(d_in.p, job->h_in, job->h_in_bytes, sl);
+    struct { sc* p; } v_raw{(sc*)d_in.p}, vbl_raw{(sc*)d_in.p + (size_t)m * B};
+    struct { uint8_t* p; } d_seeds{d_in.p + 2 * vb};
+    struct { strobe* p; } d_init{(strobe*)(d_in.p + 2 * vb + sb)};
+    DevBuf<sc> v_m((size_t)m * B), vbl_m((size_t)m * B);
     const uint32_t init_stride = n_init == 1 ? 0u : 1u;
     launch((uint64_t)m * B, K_load_inputs{v_raw.p, vbl_raw.p, v_m.p, vbl_m.p}, sl);
 
@@ -290,6 +310,7 @@ static int prove_job_begin(const bpr1cs_gens* g, const bpr1cs_circuit* c, const 
         dev_sync(sl);   // the V commitments are on the host
         DBG_JOB("begin: %u host chain(s) start", B);
         chains.start(init, n_init, job->h_V, v_blindings, rng_seeds, B, m, n, job->h_tr0, job->h_raw);
+        if ((uint64_t)B * (draws + 1) <= 4096) chains.wait();   // (a few thousand permutations - a bound check's 264 - are done before a thread has started)
     }
 
     // ---- P7/P8: witness (device program) or host-synthesised wires (in a small job: while the host threads hash)
@@ -515,7 +536,7 @@ static int prove_job_begin(const bpr1cs_gens* g, const bpr1cs_circuit* c, const 
     io.own_arena = &g->front[slot];
     const IpaEnd ipa_end = enqueue_ipa(io, st, stats);
     st = ipa_end.st;  // from here on `st` may be the job's tail stream: only the job's own buffers are touched below
-    launch(B, K_assemble{AOS.p, Tc.p, txs.p, LR.p, ipa_end.a, ipa_end.bb, d_out.p, B, lgN, (uint32_t)plen}, st);
+    launch_assemble(K_assemble{AOS.p, Tc.p, txs.p, LR.p, ipa_end.a, ipa_end.bb, d_out.p, B, lgN, (uint32_t)plen}, st);
     pt.mark(st);
     job->h_proofs = (uint8_t*)host_stage_alloc((size_t)B * plen);
     job->h_comms = (uint8_t*)host_stage_alloc((size_t)B * m * 32);
@@ -529,13 +550,17 @@ static int prove_job_begin(const bpr1cs_gens* g, const bpr1cs_circuit* c, const 
     }
     // secrets do not stay in the allocator's cache (upstream wipes them with clear_on_drop): witness, blindings, the
     // blinding vectors s_L / s_R, the l / r vectors and the Poseidon scratch are zeroed before their blocks are released
-    dev_zero(blind.p, blind.bytes(), st);
-    dev_zero(v_raw.p, v_raw.bytes(), st); dev_zero(vbl_raw.p, vbl_raw.bytes(), st);
-    dev_zero(v_m.p, v_m.bytes(), st); dev_zero(vbl_m.p, vbl_m.bytes(), st);
-    if (ipa_end.a == a.p) { dev_zero(a.p, a.bytes(), st); dev_zero(bb.p, bb.bytes(), st); }  // (else: zeroed at the hand-off, on the heavy stream)
-    else { dev_zero(job->tail.a.p, job->tail.a.bytes(), st); dev_zero(job->tail.bb.p, job->tail.bb.bytes(), st); }
-    if (px.p) dev_zero(px.p, px.bytes(), st);
-    dev_zero(d_seeds.p, d_seeds.bytes(), st);
+    {
+        K_wipe kw{};
+        auto add = [&](void* ptr, size_t bytes) { if (ptr && bytes) { kw.p[kw.n] = (uint32_t*)ptr; kw.words[kw.n] = (bytes + 3) / 4; kw.n++; } };
+        add(blind.p, blind.bytes());
+        add(d_in.p, d_in.bytes());   // values, blindings, outside randomness
+        add(v_m.p, v_m.bytes()); add(vbl_m.p, vbl_m.bytes());
+        if (ipa_end.a == a.p) { add(a.p, a.bytes()); add(bb.p, bb.bytes()); }  // (else: zeroed at the hand-off, on the heavy stream)
+        else { add(job->tail.a.p, job->tail.a.bytes()); add(job->tail.bb.p, job->tail.bb.bytes()); }
+        if (px.p) add(px.p, px.bytes());
+        launch_wipe(kw, st);
+    }
     dev_d2h_async(job->h_err, rng_err.p, sizeof(int), st);
     dev_event_create(&job->ev_done);
     dev_event_record(job->ev_done, st);

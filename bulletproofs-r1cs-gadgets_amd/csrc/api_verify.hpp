@@ -71,10 +71,43 @@ static int verify_batch_once(const bpr1cs_gens* g, const bpr1cs_circuit* c, cons
     MsmPlan plan;
     MsmSeg sg{v.gh.p, N, N, N, 0, baseG, 0}, sh{v.gh.p + (size_t)N * B, N, N, N, 0, baseH, 0};
     run_msm(g, sg, sh, B, partial, plan, st, &stats);
-    DevBuf<ge> pts((size_t)v.P * B);
+    DevBuf<ge> pts;
     DevBuf<int> ok(B);
-    launch((uint64_t)v.P * B, K_verify_points{v.d_pf.p, v.d_vc.p, v.chal.p, v.uk.p, v.wvec.p + (size_t)3 * v.n * B, pts.p, v.fail.p, B, v.m, v.lgN, (uint32_t)v.plen}, st);
-    launch(B, K_verify_finish{g->tab.p, g->tc, partial.p, pts.p, v.bsc.p, v.fail.p, ok.p, B, plan.nchunks, v.P}, st);
+    uint32_t n_pts = v.P;
+    K_verify_points kp{v.d_pf.p, v.d_vc.p, v.chal.p, v.uk.p, v.wvec.p + (size_t)3 * v.n * B, nullptr, v.fail.p, B, v.m, v.lgN, (uint32_t)v.plen};
+#if !defined(BPR1CS_HOSTSIM)
+    DevBuf<ge_cached> vtab;
+    DevBuf<uint32_t> vdig;
+    DevBuf<ge> vpart;
+    if (B <= FINISH_WAVE_MAX_PROOFS) {
+        // one proof per verify() (the reference's own call shape, src/gadget_vsmt_4.rs:442-479): the proof's own points summed by Straus
+        // with shared doublings - a thread per term prepares multiples and digits, a wavefront per (window, proof) adds, one chain of
+        // doublings per proof - instead of a 255-doubling scalar multiplication per term and a lane adding the results one by one
+        const size_t T = (size_t)v.P * B;
+        vtab.alloc((size_t)VB_MULT * T); vdig.alloc((size_t)VB_WORDS * T); vpart.alloc((size_t)VB_WINDOWS * B); pts.alloc(B);
+        kp.vtab = vtab.p; kp.vdig = vdig.p;
+        launch((uint64_t)T, kp, st);
+        hipLaunchKernelGGL(k_verify_win_wave, dim3(VB_WINDOWS * B), dim3(64), 0, st, (const ge_cached*)vtab.p, (const uint32_t*)vdig.p, vpart.p, B, v.P);
+        HIPCHK(hipGetLastError());
+        launch(B, K_ipa_vb_horner{vpart.p, pts.p, B, 1}, st);
+        n_pts = 1;
+    } else
+#endif
+    {
+        pts.alloc((size_t)v.P * B);
+        kp.out = pts.p;
+        launch((uint64_t)v.P * B, kp, st);
+    }
+    {
+        K_verify_finish kf{g->tab.p, g->tc, partial.p, pts.p, v.bsc.p, v.fail.p, ok.p, B, plan.nchunks, n_pts};
+#if !defined(BPR1CS_HOSTSIM)
+        if (B <= FINISH_WAVE_MAX_PROOFS) {
+            hipLaunchKernelGGL(k_verify_finish_wave, dim3(B), dim3(64), 0, st, kf);
+            HIPCHK(hipGetLastError());
+        } else
+#endif
+        launch(B, kf, st);
+    }
     dev_d2h(ok_out, ok.p, sizeof(int) * B, st);
     stats.collect();
     return BPR1CS_OK;

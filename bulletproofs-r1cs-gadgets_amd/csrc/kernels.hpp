@@ -1569,7 +1569,24 @@ struct K_verify_transcript {  // gid = b
             merlin_append(s, "R", 1, Lp + 32, 32);
             sc uu = merlin_challenge_scalar(s, "u", 1);
             uk[((size_t)k * 2 + 0) * B + b] = uu;
-            uk[((size_t)k * 2 + 1) * B + b] = sc_invert(uu);
+        }
+        // the inverses of y and of every u_k from ONE inversion (Montgomery's trick, as upstream's verifier: Scalar::batch_invert):
+        // slot [k][1] holds the product of what came before u_k on the way up and u_k^-1 on the way down.  (One safegcd per round was
+        // 0.65 of the 1.7 ms this kernel takes for one depth-32 proof.)  A zero challenge - probability 2^-252 - zeroes them all.
+        sc yinv;
+        {
+            sc acc = y;
+            for (uint32_t k = 0; k < lgN; k++) {
+                uk[((size_t)k * 2 + 1) * B + b] = acc;
+                acc = sc_mul(acc, uk[((size_t)k * 2 + 0) * B + b]);
+            }
+            sc inv = sc_invert(acc);
+            for (uint32_t k = lgN; k-- > 0;) {
+                const sc before = uk[((size_t)k * 2 + 1) * B + b];
+                uk[((size_t)k * 2 + 1) * B + b] = sc_mul(inv, before);
+                inv = sc_mul(inv, uk[((size_t)k * 2 + 0) * B + b]);
+            }
+            yinv = inv;
         }
         if (bind) {  // 32 bytes that depend on every byte of this proof and of its commitments (cross-proof batching)
             strobe t = s;  // the proof's own transcript never absorbs the two final IPA scalars: the clone does, so the weights bind them too
@@ -1581,7 +1598,7 @@ struct K_verify_transcript {  // gid = b
         merlin_rng_finalize(s, seeds + 32 * (size_t)b);
         sc r = merlin_rng_scalar(s);
         sc* c = chal;
-        c[(size_t)VCH_Y * B + b] = y; c[(size_t)VCH_Z * B + b] = z; c[(size_t)VCH_YINV * B + b] = sc_invert(y);
+        c[(size_t)VCH_Y * B + b] = y; c[(size_t)VCH_Z * B + b] = z; c[(size_t)VCH_YINV * B + b] = yinv;
         c[(size_t)VCH_U * B + b] = u; c[(size_t)VCH_X * B + b] = x; c[(size_t)VCH_W * B + b] = w; c[(size_t)VCH_R * B + b] = r;
         c[(size_t)VCH_TX * B + b] = sc_mont_from_bytes_mod_order(el + 8 * 32);
         c[(size_t)VCH_TXB * B + b] = sc_mont_from_bytes_mod_order(el + 9 * 32);
@@ -1657,6 +1674,8 @@ struct K_verify_points {  // gid = p*B + b, p < 8 + m + 2 lgN
     int* fail;
     uint32_t B, m, lgN, plen;
     const sc* rho = nullptr;  // optional per-proof weight (cross-proof batching), Montgomery
+    ge_cached* vtab = nullptr;  // optional (with vdig): prepare the terms for Straus instead of multiplying them out - [VB_MULT][P*B]
+    uint32_t* vdig = nullptr;   // [VB_WORDS][P*B]
     HD void operator()(uint32_t g) const {
         uint32_t p = g / B, b = g % B;
         const uint8_t* el = proofs + (size_t)b * plen + 1;
@@ -1683,13 +1702,28 @@ struct K_verify_points {  // gid = p*B + b, p < 8 + m + 2 lgN
             s = sc_mul(uu, uu);
         }
         ge P;
-        if (!ge_decompress(pt, P)) {
-            fail[b] = 1;
-            out[g] = ge_identity();
+        const bool bad = !ge_decompress(pt, P);
+        if (bad) { fail[b] = 1; P = ge_identity(); }
+        if (rho) s = sc_mul(s, rho[b]);
+        if (vtab) {
+            // a handful of proofs: the terms of a proof are summed by Straus with the doublings shared by all of them (one chain of
+            // 255 doublings per PROOF in K_ipa_vb_horner instead of one per term here): this thread only prepares its term - the
+            // multiples 1P..16P and the signed 5-bit digits of the scalar
+            const size_t T = (size_t)(8 + m + 2 * lgN) * B;
+            ge_cached c1 = ge_to_cached(P);
+            vtab[g] = c1;
+            ge q = P;
+            for (uint32_t e = 1; e < VB_MULT; e++) {
+                q = ge_add(q, c1);
+                vtab[(size_t)e * T + g] = ge_to_cached(q);
+            }
+            uint32_t dig[VB_WORDS];
+            vb_recode(bad ? sc_zero() : sc_from_mont(s), dig);
+#pragma unroll
+            for (uint32_t i = 0; i < VB_WORDS; i++) vdig[(size_t)i * T + g] = dig[i];
             return;
         }
-        if (rho) s = sc_mul(s, rho[b]);
-        out[g] = ge_scalarmul_naf(P, sc_from_mont(s));
+        out[g] = bad ? ge_identity() : ge_scalarmul_naf(P, sc_from_mont(s));
     }
 };
 // ---- cross-proof batching of the mega-check (SURVEY §8a P10 "batchable across proofs", §8e): with per-proof
@@ -1867,6 +1901,21 @@ struct K_verify_finish {  // gid = b : sum everything, accept iff identity
     }
 };
 
+// secrets zeroed before their blocks go back to the allocator: up to 8 regions in one launch (a job ends with 7 of them; seven
+// hipMemsetAsync are 35 us at the end of a 3 ms proof) - used while the regions are small, hipMemsetAsync each otherwise
+struct K_wipe {  // gid = word index over the concatenation of the regions
+    uint32_t* p[8];
+    uint64_t words[8];
+    uint32_t n;
+    HD void operator()(uint32_t g) const {
+        uint64_t w = g;
+        for (uint32_t r = 0; r < n; r++) {
+            if (w < words[r]) { p[r][w] = 0; return; }
+            w -= words[r];
+        }
+    }
+};
+
 // ---------------------------------------------------------------- proof out
 struct K_assemble {  // gid = b
     const uint8_t* AOS;  // [3][B][32]
@@ -1887,5 +1936,21 @@ struct K_assemble {  // gid = b
             for (int lr = 0; lr < 2; lr++) { for (int t = 0; t < 32; t++) o[t] = LR[(((size_t)k * 2 + lr) * B + b) * 32 + t]; o += 32; }
         sc_mont_tobytes(a[b], o); o += 32;
         sc_mont_tobytes(bb[b], o);
+    }
+};
+// the same, an element per thread (gid = e*B + b, e < 13 + 2 lgN: the version byte rides with element 0) - for a job of a few proofs
+struct K_assemble_el {
+    K_assemble k;
+    HD void operator()(uint32_t g) const {
+        const uint32_t B = k.B, lgN = k.lgN, e = g / B, b = g % B;
+        uint8_t* o = k.out + (size_t)b * k.len;
+        if (e == 0) o[0] = 0;
+        o += 1 + 32 * (size_t)e;
+        if (e < 3) { for (int t = 0; t < 32; t++) o[t] = k.AOS[((size_t)e * B + b) * 32 + t]; }
+        else if (e < 8) { for (int t = 0; t < 32; t++) o[t] = k.Tc[((size_t)(e - 3) * B + b) * 32 + t]; }
+        else if (e < 11) sc_mont_tobytes(k.txs[(size_t)(e - 8) * B + b], o);
+        else if (e < 11 + 2 * lgN) { for (int t = 0; t < 32; t++) o[t] = k.LR[((size_t)(e - 11) * B + b) * 32 + t]; }
+        else if (e == 11 + 2 * lgN) sc_mont_tobytes(k.a[b], o);
+        else sc_mont_tobytes(k.bb[b], o);
     }
 };

@@ -80,6 +80,17 @@ static void launch_sum_partials(uint64_t outputs, const K_sum_partials& f, dev_s
 #endif
     launch(outputs, f, st);
 }
+static void launch_wipe(const K_wipe& f, dev_stream_t st) {
+    uint64_t total = 0;
+    for (uint32_t r = 0; r < f.n; r++) total += f.words[r];
+    if (total == 0) return;
+    if (total <= ((uint64_t)16 << 20)) { launch(total, f, st); return; }   // (<= 64 MB: one launch)
+    for (uint32_t r = 0; r < f.n; r++) dev_zero(f.p[r], f.words[r] * 4, st);
+}
+static void launch_assemble(const K_assemble& f, dev_stream_t st) {
+    if (f.B <= 1024) launch((uint64_t)(13 + 2 * f.lgN) * f.B, K_assemble_el{f}, st);
+    else launch(f.B, f, st);
+}
 static void launch_commit_T(const K_commit_T& f, uint32_t B, dev_stream_t st) {
 #if !defined(BPR1CS_HOSTSIM)
     if (B <= FINISH_WAVE_MAX_PROOFS) {

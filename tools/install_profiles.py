@@ -20,6 +20,7 @@ for c in ("c1", "c2", "c3", "c5", "vsmt4_d128", "vsmt2_d253"):
 for c in ("c4", "c1"):
     hdr["latency_%s_one_proof_timeline.txt" % c] = "# rocprofv3 --kernel-trace -- python tools/latency_probe.py --cases %s --batches 1 --reps 3 --no-device-program ; tools/trace_lastcall.py (%s, commit %s): every launch of the last bpr1cs_prove_batch_transcripts(batch 1, host wires) call%s, then the totals per kernel\n" % (
         c, tag, commit, " (c1: the window holds the three timed calls, divide the totals by 3)" if c == "c1" else "")
+hdr["verify_c4_one_proof_timeline.txt"] = "# rocprofv3 --kernel-trace -- python tools/verify_probe.py c4 4 ; tools/trace_lastcall.py ... erify_finish (%s, commit %s): every launch of the last bpr1cs_verify_batch(batch 1) call of one depth-32 tree proof\n" % (tag, commit)
 hdr["ubench_latency.txt"] = "# tools/ubench_latency on MI355X (%s): ONE wavefront alone on the chip - nanoseconds and shader cycles per dependent operation (the single-commitment / single-proof kernels)\n" % tag
 hdr["host_chain_rate.txt"] = "# tools/host_chain_bench.cpp on the GPU box's host CPU (%s): the TranscriptRng chain of a depth-32 proof (csrc/host_chain.hpp) on 1 .. 64 threads at once\n" % tag
 hdr["latency_probe.txt"] = "# python tools/latency_probe.py --cases c1,c4 --batches 1,8,64 --reps 3 --no-device-program (%s, commit %s): bpr1cs_gadget_prove_on / _verify_on, wall ms and stage ms per call\n" % (tag, commit)

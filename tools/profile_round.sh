@@ -33,6 +33,10 @@ for c in c4 c1; do
   python tools/trace_lastcall.py $out/kt_lat_$c $gap 3000 > $out/latency_${c}_one_proof_timeline.txt 2>&1
   rm -rf $out/kt_lat_$c
 done
+# ... and the verifier half: one proof per verify()
+timeout 300 rocprofv3 --kernel-trace -d $out/kt_v -o out -- python tools/verify_probe.py c4 4 > $out/kt_verify_c4.log 2>&1
+python tools/trace_lastcall.py $out/kt_v 20 400 erify_finish > $out/verify_c4_one_proof_timeline.txt 2>&1
+rm -rf $out/kt_v
 [ -x tools/ubench ] && timeout 300 tools/ubench > $out/ubench.txt 2>&1
 [ -x tools/ubench_latency ] && timeout 120 tools/ubench_latency > $out/ubench_latency.txt 2>&1
 # the plain C caller alone on the device (the library sizes its jobs from the whole device), and the host-side chain's rate on this box
