@@ -506,7 +506,15 @@ static int prove_job_begin(const bpr1cs_gens* g, const bpr1cs_circuit* c, const 
     io.fuse_scalars = g->opts.factor_vectors.load() == 3 || (g->opts.factor_vectors.load() == 0 && N >= 4096);
     if (!fvec) { io.geo.plo = plo.p; io.geo.phi = phi.p; io.geo.upad = chal.p + (size_t)CH_U * B; io.geo.H = H; io.geo.n1 = n; }
     DevBuf<sc> hs_scal;
-    if (lgN >= 1 && n > N / 2 && n < N && o_unfold >= 1) {
+    bool use_hs = lgN >= 1 && n > N / 2 && n < N && o_unfold >= 1;
+    if (use_hs && B <= SMALL_JOB_PROOFS) {
+        // a job of a few proofs does not BUILD the table (12 ms of a one-proof call - the reference's tests prove one proof per process -
+        // to save 14 112 of round 0's 65 536 lane-terms); it uses one a larger job of this circuit on this handle has built
+        std::lock_guard<std::mutex> lk(c->mt_mu);
+        auto it = c->mt.find(g);
+        use_hs = it != c->mt.end() && it->second->hs_tab.p && it->second->hs_W == g->tc.W && it->second->hs_cap == g->cap;
+    }
+    if (use_hs) {
         // padding structure of round 0 (K_range_sum_points): the table of sum_{n - N/2 <= i < N/2} H_i belongs to
         // (circuit shape, generator handle) and is built by the first job that needs it
         std::lock_guard<std::mutex> lk(c->mt_mu);

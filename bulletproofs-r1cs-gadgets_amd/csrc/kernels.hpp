@@ -1902,7 +1902,7 @@ struct K_verify_finish {  // gid = b : sum everything, accept iff identity
 };
 
 // secrets zeroed before their blocks go back to the allocator: up to 8 regions in one launch (a job ends with 7 of them; seven
-// hipMemsetAsync are 35 us at the end of a 3 ms proof) - used while the regions are small, hipMemsetAsync each otherwise
+// hipMemsetAsync are 35 us at the end of a 3 ms proof) - used while the regions are small (1 MB in all), hipMemsetAsync each otherwise
 struct K_wipe {  // gid = word index over the concatenation of the regions
     uint32_t* p[8];
     uint64_t words[8];

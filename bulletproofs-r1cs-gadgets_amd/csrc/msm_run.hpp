@@ -84,7 +84,7 @@ static void launch_wipe(const K_wipe& f, dev_stream_t st) {
     uint64_t total = 0;
     for (uint32_t r = 0; r < f.n; r++) total += f.words[r];
     if (total == 0) return;
-    if (total <= ((uint64_t)16 << 20)) { launch(total, f, st); return; }   // (<= 64 MB: one launch)
+    if (total <= ((uint64_t)1 << 18)) { launch(total, f, st); return; }   // (<= 1 MB - a job of a few proofs: one launch; a word per thread is no way to clear tens of MB: 1.9 ms for a 16384-proof job of the small circuits against ~10 us per hipMemsetAsync)
     for (uint32_t r = 0; r < f.n; r++) dev_zero(f.p[r], f.words[r] * 4, st);
 }
 static void launch_assemble(const K_assemble& f, dev_stream_t st) {
