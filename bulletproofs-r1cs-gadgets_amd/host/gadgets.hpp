@@ -232,6 +232,16 @@ inline Variable synthesize_inverse_sbox_from_value(ConstraintSystem& cs, const s
     return r.first;
 }
 
+// ... and with the inverse already known (the partial rounds of a permutation: all their S-box values come out of one inversion)
+inline Variable synthesize_inverse_sbox_from_values(ConstraintSystem& cs, const Scalar& val_l, const Scalar& val_r) {
+    cs.poseidon_sbox();
+    auto l = cs.allocate_single(std::optional<Scalar>(val_l), WitnessHint());
+    auto r = cs.allocate_single(std::optional<Scalar>(val_r), WitnessHint::inverse_of_left());
+    is_nonzero_gadget(cs, AllocatedScalar{l.first, val_l}, AllocatedScalar{r.first, val_r});
+    constrain_lc_with_scalar(cs, LinearCombination(*r.second), Scalar::one());
+    return r.first;
+}
+
 // Poseidon_permutation (gadget_poseidon.rs:189-280)
 inline std::vector<Scalar> Poseidon_permutation(const std::vector<Scalar>& input, const PoseidonParams& params, SboxType sbox) {
     size_t w = params.width;
@@ -324,17 +334,40 @@ inline std::vector<LinearCombination> Poseidon_permutation_constraints(Constrain
     };
     std::vector<LinearCombination> input_vars = std::move(input);
     size_t off = 0;
+    // one full round: `width` S-boxes on independent inputs.  For a constraint system that knows the values (and records no hints) the
+    // `width` inverses come from ONE inversion (Montgomery's trick); the calls on `cs` are those of synthesize_sbox, in its order.
+    auto full_round = [&]() {
+        std::vector<LinearCombination> outs(width);
+        if (sbox_type == SboxType::Inverse && !cs.uses_witness_hints()) {
+            std::vector<Scalar> x(width), pre(width);
+            bool ok = true;
+            for (size_t i = 0; i < width && ok; i++) {
+                std::optional<Scalar> val = cs.evaluate_lc(input_vars[i]);
+                if (!val) { ok = false; break; }
+                x[i] = *val + params.round_keys[off + i];
+                if (x[i].is_zero()) ok = false;   // (1/0 = 0 by convention: the one-by-one path below)
+            }
+            if (ok) {
+                Scalar acc = Scalar::one();
+                for (size_t i = 0; i < width; i++) { pre[i] = acc; acc = acc * x[i]; }
+                Scalar inv = acc.invert();
+                for (size_t i = width; i-- > 0;) { const Scalar e = inv * pre[i]; inv = inv * x[i]; pre[i] = e; }
+                for (size_t i = 0; i < width; i++) outs[i] = LinearCombination(synthesize_inverse_sbox_from_values(cs, x[i], pre[i]));
+                off += width;
+                input_vars = apply_linear_layer(outs);
+                return;
+            }
+        }
+        for (size_t i = 0; i < width; i++) outs[i] = LinearCombination(synthesize_sbox(cs, sbox_type, input_vars[i], params.round_keys[off++]));
+        input_vars = apply_linear_layer(outs);
+    };
     if (sbox_type == SboxType::Inverse) {
         PoseidonShape sh;
         sh.width = width; sh.full_rounds_beginning = params.full_rounds_beginning; sh.partial_rounds = params.partial_rounds;
         sh.full_rounds_end = params.full_rounds_end; sh.mds = &params.MDS_matrix; sh.round_keys = &params.round_keys;
         cs.poseidon_begin(input_vars, sh);
     }
-    for (size_t k = 0; k < params.full_rounds_beginning; k++) {
-        std::vector<LinearCombination> outs(width);
-        for (size_t i = 0; i < width; i++) outs[i] = LinearCombination(synthesize_sbox(cs, sbox_type, input_vars[i], params.round_keys[off++]));
-        input_vars = apply_linear_layer(outs);
-    }
+    for (size_t k = 0; k < params.full_rounds_beginning; k++) full_round();
     {
         const PoseidonParams::PartialTables& T = params.partial_tables();
         std::vector<LinearCombination> s0;   // the state before the first partial round, merged once
@@ -361,8 +394,51 @@ inline std::vector<LinearCombination> Poseidon_permutation_constraints(Constrain
                 std::optional<Scalar> x = cs.evaluate_lc(s0[i]);
                 if (x) st.push_back(*x); else have = false;
             }
+            // The S-box values of ALL partial rounds from ONE inversion: the state is carried as numerators over a common
+            // denominator (x_r = N_last / D; after the S-box the denominator is D * N_last), every round's (N_last, D) is kept, the 2 pr
+            // values are inverted together (Montgomery's trick) and x_r = N_last * D^-1, 1 / x_r = D * N_last^-1.  57 products per round
+            // instead of 36 and an inversion worth ~48 (one safegcd per S-box was a third of the host's synthesis of a tree proof).  The
+            // same values, hence the same wires (tests/test_frontend.py: full-size synthesis against the C oracle).  A zero S-box input
+            // (an unsatisfiable witness: the convention 1/0 = 0 has no fraction) leaves `pre` empty: the round-by-round path below.
+            std::vector<Scalar> pre_l, pre_r;
+            if (have && pr > 0) {
+                std::vector<Scalar> N = st, T(width), seq;
+                Scalar D = Scalar::one();
+                seq.reserve(2 * pr);
+                bool ok = true;
+                size_t o2 = off;
+                for (size_t r = 0; r < pr && ok; r++) {
+                    if (r == 0) { for (size_t i = 0; i < width; i++) N[i] += params.round_keys[o2 + i]; }
+                    else { for (size_t i = 0; i < width; i++) N[i] += params.round_keys[o2 + i] * D; }
+                    const Scalar a = N[width - 1];
+                    if (a.is_zero()) { ok = false; break; }
+                    seq.push_back(a); seq.push_back(D);
+                    for (size_t i = 0; i + 1 < width; i++) N[i] = N[i] * a;
+                    N[width - 1] = D * D;
+                    D = D * a;
+                    for (size_t i = 0; i < width; i++) T[i] = Scalar();
+                    for (size_t j = 0; j < width; j++)
+                        for (size_t i = 0; i < width; i++) T[i] += N[j] * params.MDS_matrix[i][j];
+                    N = T;
+                    o2 += width;
+                }
+                if (ok) {
+                    std::vector<Scalar> prefix(seq.size());
+                    Scalar acc = Scalar::one();
+                    for (size_t k = 0; k < seq.size(); k++) { prefix[k] = acc; acc = acc * seq[k]; }
+                    Scalar inv = acc.invert();
+                    for (size_t k = seq.size(); k-- > 0;) { const Scalar e = inv * prefix[k]; inv = inv * seq[k]; prefix[k] = e; }   // prefix[k] = seq[k]^-1
+                    pre_l.resize(pr); pre_r.resize(pr);
+                    for (size_t r = 0; r < pr; r++) { pre_l[r] = seq[2 * r] * prefix[2 * r + 1]; pre_r[r] = seq[2 * r + 1] * prefix[2 * r]; }
+                }
+            }
             for (size_t r = 0; r < pr; r++) {
                 std::optional<Scalar> val_l, val_r;
+                if (!pre_l.empty()) {
+                    v.push_back(synthesize_inverse_sbox_from_values(cs, pre_l[r], pre_r[r]));
+                    off += width;
+                    continue;
+                }
                 if (have) {
                     for (size_t i = 0; i < width; i++) st[i] += params.round_keys[off + i];
                     val_l = st[width - 1];
@@ -386,11 +462,7 @@ inline std::vector<LinearCombination> Poseidon_permutation_constraints(Constrain
         }
         for (size_t e = 0; e < width; e++) input_vars[e] = element(pr, e).simplify();
     }
-    for (size_t k = 0; k < params.full_rounds_end; k++) {
-        std::vector<LinearCombination> outs(width);
-        for (size_t i = 0; i < width; i++) outs[i] = LinearCombination(synthesize_sbox(cs, sbox_type, input_vars[i], params.round_keys[off++]));
-        input_vars = apply_linear_layer(outs);
-    }
+    for (size_t k = 0; k < params.full_rounds_end; k++) full_round();
     if (sbox_type == SboxType::Inverse) cs.poseidon_end();
     return input_vars;
 }

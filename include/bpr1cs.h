@@ -231,7 +231,9 @@ int bpr1cs_prove_batch_transcripts(const bpr1cs_gens* g, const bpr1cs_circuit* c
  * copies the results out.  Two jobs may be in flight per gens handle (a third `begin` before an `end` is refused with
  * BPR1CS_ERR_INVALID_ARGUMENT: a job owns one of the handle's two stream / buffer slots): the latency-bound phase of
  * batch k+1 (TranscriptRng Keccak chain, witness synthesis) then overlaps the VALU-bound MSM/IPA
- * phase of batch k.  Input buffers may be released as soon as `begin` returns. */
+ * phase of batch k.  Input buffers may be released as soon as `begin` returns.  (A job small enough for BPR1CS_OPT_HOST_CHAIN_PROOFS
+ * hashes its TranscriptRng chains on host threads inside `begin`: the call then takes the chains' time - 7 ms for depth-32 proofs -
+ * before it returns; set the option to 0 on a handle whose small jobs must be enqueued without that.) */
 typedef struct bpr1cs_job bpr1cs_job;
 int bpr1cs_prove_batch_begin(const bpr1cs_gens* g, const bpr1cs_circuit* c, const uint8_t* label, size_t label_len,
                              const uint8_t* values, const uint8_t* v_blindings, const uint8_t* rng_seeds,

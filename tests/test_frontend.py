@@ -109,3 +109,15 @@ def test_host_synthesis_wires_equal_the_c_oracle_at_full_size(sim_glib):
             wires, n, q = bp.gadget_synthesize(w["gadget"], w["ip"], w["sp"], v, w["m"], glib=sim_glib)
             assert (n, q) == (r["n"], r["q"]), (w["gadget"], n, q, r["n"], r["q"])
             assert wires == r["wires"][:96 * n], "%s proof %d: host wires differ from the C oracle's" % (w["gadget"], j)
+
+
+def test_host_synthesis_with_a_zero_sbox_input_takes_the_one_by_one_path(sim_glib):
+    """The host front-end takes the S-box values of a full round, and of all partial rounds of a permutation, from ONE inversion each
+    (gadgets.hpp: Montgomery's trick / the state as fractions over a common denominator).  An S-box input of 0 - an unsatisfiable
+    witness, 1/0 = 0 by the reference's convention (gadget_poseidon.rs:120-125) - has no such form: those rounds fall back to one
+    inversion per S-box.  Wires against the Python oracle's for a zero in a FULL round, and (140 partial rounds) for inputs without one."""
+    for name in ("poseidon_hash_2_inverse_pr1_zero", "poseidon_hash_2_inverse_pr1", "poseidon_hash_2_inverse"):
+        gname, ip, sp, sc, cap = fc.case(name, 0)
+        ob = common.oracle_batch(lambda j: fc.case(name, 0)[3], cap, 1, satisfiable=not name.endswith("_zero"), key=name + "_synth")
+        wires, n, q = bp.gadget_synthesize(gname, ip, sp, ob["values"], ob["m"], glib=sim_glib)
+        assert n == ob["n"] and wires == ob["wires"], name
