@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Fills the @@PLACEHOLDER@@ fields of DESIGN.md / INTEGRATION.md / README.md from profiles/<tag>_bench_default.json and the tag's other
-summaries, so that the figures quoted in the documents are the committed ones.   python tools/fill_docs.py r06g [files...]"""
+summaries, so that the figures quoted in the documents are the committed ones.  The four measured blocks of the documents live as templates
+under tools/doc_templates/ (a document carries the marker @@NUMBERS@@ / @@ROUND6@@ / @@README_STATUS@@ / @@INTEGRATION_2A@@ where the block
+goes; to refresh a filled document, cut the block back to its marker).   python tools/fill_docs.py r06h [files...]"""
 import json
 import os
 import re
@@ -19,7 +21,7 @@ def f2(x): return "%.2f" % x
 def k(x): return "%.1f k" % (x / 1e3) if x >= 20000 else "%.0f" % x
 
 
-V = {}
+V = {"TAG": tag}
 V["WALL"] = re.search(r"(\d+)", open(P("bench_default_wall.txt")).read()).group(1)
 V["HEAD"] = "%.0f" % d["value"]; V["MSSTEP"] = f1(d["ms_per_step"])
 V["LAUNCH"] = f1(ro["avg_launch_ms"])
@@ -76,7 +78,9 @@ V.update(COMMIT_LAZY=V["C4COM"], COMMIT_EAGER=V["C4ECOM"], GADGET=V["C4GAD"], CI
 for fn in files:
     path = os.path.join(ROOT, fn)
     s = open(path).read()
-    for blk, src in (("@@NUMBERS@@", os.path.join(ROOT, "tools", "doc_templates", "design_numbers.md")), ("@@ROUND6@@", os.path.join(ROOT, "tools", "doc_templates", "design_round6.md"))):
+    T = lambda n: os.path.join(ROOT, "tools", "doc_templates", n)
+    for blk, src in (("@@NUMBERS@@", T("design_numbers.md")), ("@@ROUND6@@", T("design_round6.md")), ("@@README_STATUS@@", T("readme_status.md")),
+                     ("@@INTEGRATION_2A@@", T("integration_2a.md"))):
         if blk in s and os.path.exists(src):
             s = s.replace(blk, open(src).read().rstrip("\n"))
     missing = sorted(set(re.findall(r"@@([A-Z0-9_]+)@@", s)) - set(V))
