@@ -655,12 +655,14 @@ def prove_single(name, iparams, sparams, gens_capacity, label, values, blindings
 
 
 GADGET_EAGER_COMMITS = 1
+GADGET_NO_CHAIN_AHEAD = 2
 
 
-def gadget_prove_on(gens, name, iparams, sparams, label, values, blindings, m, batch, rng_seeds, glib=None, eager_commits=False):
+def gadget_prove_on(gens, name, iparams, sparams, label, values, blindings, m, batch, rng_seeds, glib=None, eager_commits=False, chain_ahead=True):
     """bpr1cs_gadget_prove_on[_flags]: the reference's call shape (Prover::new -> commit x m -> gadget on the host -> prove) on generators
     created once; batch > 1 = one host synthesis per witness, ONE device prove with host wires.  eager_commits: every commit() computes
-    its point at once, one device call each (upstream's signature; default: resolved after prove() from the prove call's own V's).
+    its point at once, one device call each (upstream's signature; default: resolved when read).  chain_ahead=False: the C++ Prover does
+    not run the proof's TranscriptRng chain beside the synthesis (the library then hashes it inside the prove call).
     -> (proofs, commitments per proof, dict of seconds: commit / gadget / circuit / prove / total)"""
     g = glib or load_gadgets_library()
     blob = poseidon_blob()
@@ -672,7 +674,7 @@ def gadget_prove_on(gens, name, iparams, sparams, label, values, blindings, m, b
     sec = (ctypes.c_double * 5)()
     _chk(g.bpr1cs_gadget_prove_on_flags(gens.h, name.encode(), _u32arr(list(iparams)), len(iparams), sp or b"\0", len(sparams), blob, len(blob),
                                         label, len(label), values or b"\0", blindings or b"\0", m, batch, rng_seeds, proofs, cap, ctypes.byref(plen), comms, sec,
-                                        GADGET_EAGER_COMMITS if eager_commits else 0))
+                                        (GADGET_EAGER_COMMITS if eager_commits else 0) | (0 if chain_ahead else GADGET_NO_CHAIN_AHEAD)))
     n, praw, craw = plen.value, proofs.raw, comms.raw
     return ([praw[i * n:(i + 1) * n] for i in range(batch)],
             [[craw[(i * m + j) * 32:(i * m + j + 1) * 32] for j in range(m)] for i in range(batch)],

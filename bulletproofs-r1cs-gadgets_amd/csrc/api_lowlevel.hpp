@@ -48,6 +48,40 @@ extern "C" void bpr1cs_transcript_append_message(bpr1cs_transcript* t, const uin
 extern "C" void bpr1cs_transcript_challenge_bytes(bpr1cs_transcript* t, const uint8_t* label, size_t label_len, uint8_t* out, size_t out_len) {
     if (t) merlin_challenge_bytes(t->s, (const char*)label, (uint32_t)label_len, out, (uint32_t)out_len);
 }
+extern "C" bpr1cs_transcript* bpr1cs_transcript_clone(const bpr1cs_transcript* t) {
+    if (!t) return nullptr;
+    bpr1cs_transcript* c = new (std::nothrow) bpr1cs_transcript();
+    if (c) c->s = t->s;
+    return c;
+}
+// merlin::TranscriptRng (merlin 2.0 transcript.rs: build_rng / rekey_with_witness_bytes / finalize / RngCore::fill_bytes), host side
+struct bpr1cs_transcript_rng {
+    strobe s;
+    ~bpr1cs_transcript_rng() { for (int k = 0; k < 25; k++) ((volatile uint64_t*)s.st)[k] = 0; }   // key material
+};
+extern "C" bpr1cs_transcript_rng* bpr1cs_transcript_build_rng(const bpr1cs_transcript* t, const uint8_t* witness_label, size_t label_len,
+                                                              const uint8_t* witnesses, size_t witness_len, size_t count, const uint8_t seed[32]) {
+    if (!t || !seed || (count && (!witnesses || !witness_label)) || witness_len > (1u << 20) || label_len > (1u << 20)) return nullptr;
+    bpr1cs_transcript_rng* r = new (std::nothrow) bpr1cs_transcript_rng();
+    if (!r) return nullptr;
+    r->s = t->s;
+    for (size_t j = 0; j < count; j++) merlin_rng_rekey(r->s, (const char*)witness_label, (uint32_t)label_len, witnesses + j * witness_len, (uint32_t)witness_len);
+    merlin_rng_finalize(r->s, seed);
+    return r;
+}
+extern "C" void bpr1cs_transcript_rng_fill_bytes(bpr1cs_transcript_rng* r, uint8_t* out, size_t len, size_t count) {
+    if (!r || !out || len == 0 || len > (1u << 30)) return;
+    for (size_t k = 0; k < count; k++) {
+        uint8_t* o = out + k * len;
+        if (len == 64 && r->s.pos == 64 && r->s.pos_begin == 0) {   // a run of 64-byte draws (Scalar::random): one permutation each
+            uint64_t w[8];
+            merlin_rng_raw(r->s, w);
+            memcpy(o, w, 64);
+            for (int i = 0; i < 8; i++) ((volatile uint64_t*)w)[i] = 0;
+        } else merlin_rng_fill(r->s, o, (uint32_t)len);
+    }
+}
+extern "C" void bpr1cs_transcript_rng_free(bpr1cs_transcript_rng* r) { delete r; }
 // InnerProductProof::create (bulletproofs inner_product_proof.rs; reached from every prove() of the
 // reference, e.g. src/gadget_vsmt_4.rs:434) over the handle's generators G[0..n), H[0..n), for ONE proof, on the device.
 extern "C" int bpr1cs_ipa_create(const bpr1cs_gens* g, bpr1cs_transcript* t, const uint8_t* Q, const uint8_t* G_factors, const uint8_t* H_factors,

@@ -158,8 +158,11 @@ static int prove_job_fail(const bpr1cs_gens* g, bpr1cs_job* job, uint32_t slot, 
 // Transcript::new(label) gives) or n_init = batch (the caller's own); want_tr: read the final transcript states back.
 static int prove_job_begin(const bpr1cs_gens* g, const bpr1cs_circuit* c, const strobe* init, size_t n_init, bool want_tr,
                            const uint8_t* values, const uint8_t* v_blindings, const uint8_t* rng_seeds,
-                           const uint8_t* wires, size_t batch, bpr1cs_job** job_out) {
-    if (!g || !c || !init || !rng_seeds || !job_out || batch == 0 || (n_init != 1 && n_init != batch)) return BPR1CS_ERR_INVALID_ARGUMENT;
+                           const uint8_t* wires, size_t batch, bpr1cs_job** job_out, const uint8_t* ext_draws = nullptr) {
+    // ext_draws (bpr1cs_prove_batch_draws): the caller has appended Prover::new's and commit's transcript messages and "m" itself - `init` holds
+    // one transcript per proof in that state - and has run the proof's TranscriptRng: batch x (2n + 8) raw 64-byte draws
+    if (!g || !c || !init || (!rng_seeds && !ext_draws) || !job_out || batch == 0 || (n_init != 1 && n_init != batch)) return BPR1CS_ERR_INVALID_ARGUMENT;
+    if (ext_draws && n_init != batch) return BPR1CS_ERR_INVALID_ARGUMENT;
     if (c->m && (!values || !v_blindings)) return BPR1CS_ERR_INVALID_ARGUMENT;
     if (!have_device()) return BPR1CS_ERR_NO_DEVICE;
     if (g->cap < c->N) return BPR1CS_ERR_INVALID_GENERATORS_LENGTH;
@@ -229,7 +232,7 @@ static int prove_job_begin(const bpr1cs_gens* g, const bpr1cs_circuit* c, const 
                 hv[j * B + b] = sc_load_raw(values + (b * m + j) * 32);
                 hb[j * B + b] = sc_load_raw(v_blindings + (b * m + j) * 32);
             }
-        memcpy(job->h_in + 2 * vb, rng_seeds, sb);
+        if (rng_seeds) memcpy(job->h_in + 2 * vb, rng_seeds, sb); else memset(job->h_in + 2 * vb, 0, sb);
         memcpy(job->h_in + 2 * vb + sb, init, ib);
     }
     DevBuf<uint8_t> d_in(job->h_in_bytes);
@@ -244,6 +247,9 @@ static int prove_job_begin(const bpr1cs_gens* g, const bpr1cs_circuit* c, const 
     DBG_JOB("begin: inputs uploaded");
     // ---- P1: V commitments, transcript, RNG stream
     DevBuf<uint8_t> Vcomp((size_t)B * m * 32 + 1);
+    if (ext_draws) {
+        dev_zero(Vcomp.p, Vcomp.bytes(), sl);   // (the caller has made the commitments - they are in its transcripts - and this call returns none)
+    } else
 #if !defined(BPR1CS_HOSTSIM)
     if ((uint64_t)m * B <= 256 && m * B > 0) {   // a handful of commitments in front of the transcript chain: a wavefront each (180 -> ~25 us for one proof)
         hipLaunchKernelGGL(k_commit_wave, dim3(m * B), dim3(64), 0, sl, (const uint8_t*)g->tab.p, g->tc, (const sc*)v_raw.p, (const sc*)vbl_raw.p, Vcomp.p, B, m);
@@ -259,12 +265,13 @@ static int prove_job_begin(const bpr1cs_gens* g, const bpr1cs_circuit* c, const 
     // A small job's TranscriptRng chains run on host threads (csrc/host_chain.hpp): BPR1CS_OPT_HOST_CHAIN_PROOFS, default = jobs of up
     // to 4 proofs per usable CPU.  One more draw travels then: the chain's first (i_bl), which the device path makes in K_transcript_init.
     const int o_hc = g->opts.host_chain.load();
-    const bool host_chain = o_hc < 0 ? B <= 4u * host_cpu_budget() : B <= (uint32_t)o_hc;
+    const bool ext = ext_draws != nullptr;
+    const bool host_chain = !ext && (o_hc < 0 ? B <= 4u * host_cpu_budget() : B <= (uint32_t)o_hc);
     job->host_chain = host_chain;
     {
         ArenaScope sh(shared ? &g->shared_front : &g->front[slot], shared);
         W.alloc((size_t)5 * n * B + 1);
-        rng_raw.alloc((size_t)(draws + (host_chain ? 1 : 0)) * B * 8);
+        rng_raw.alloc((size_t)(draws + (host_chain || ext ? 1 : 0)) * B * 8);
     }
     sc* sL = W.p + (size_t)3 * n * B;
     sc* sR = W.p + (size_t)4 * n * B;
@@ -276,7 +283,20 @@ static int prove_job_begin(const bpr1cs_gens* g, const bpr1cs_circuit* c, const 
     dev_zero(rng_err.p, sizeof(int), sl);
     DevBuf<strobe> rng;
     HostChains chains;   // (joined by its destructor on every path out of this function)
-    if (host_chain) {
+    if (ext) {
+        // nothing to hash and nothing to wait for: the transcripts are the caller's (past "m"), the draws go up and are reduced at once
+        job->h_raw_bytes = (size_t)(draws + 1) * B * 64;
+        job->h_raw = (uint64_t*)host_stage_alloc(job->h_raw_bytes);
+        memcpy(job->h_raw, ext_draws, job->h_raw_bytes);
+        dev_d2d(tr.p, d_init.p, (size_t)B * sizeof(strobe), sl);
+        if (shared) dev_stream_wait(sl, g->rng_free_ev);
+        dev_h2d_async(rng_raw.p, job->h_raw, job->h_raw_bytes, sl);
+        if (shared) dev_stream_wait(sl, g->w_free_ev);
+        launch((uint64_t)(draws + 1) * B, K_rng_reduce{rng_raw.p, blind.p, sL, sR, B, n, 1u}, sl);
+        dev_zero(rng_raw.p, rng_raw.bytes(), sl);
+        if (shared) dev_event_record(g->rng_free_ev, sl);
+        dev_event_record(job->ev_rng, sl);
+    } else if (host_chain) {
         // the chains need the V commitments (their compressed encodings are transcript messages): read them back now; the wires go
         // in and the A_I / A_O sums run on the device while the host hashes
         job->h_V = (uint8_t*)host_stage_alloc((size_t)B * m * 32);
@@ -659,7 +679,7 @@ static uint32_t auto_job_proofs(const bpr1cs_gens* g, const bpr1cs_circuit* c, b
 // front of job k+1 - TranscriptRng chain, witness synthesis - next to the multiscalar multiplications of job k).
 static int prove_batch_impl(const bpr1cs_gens* g, const bpr1cs_circuit* c, const strobe* init, size_t n_init, bpr1cs_transcript* const* tr_out,
                             const uint8_t* values, const uint8_t* v_blindings, const uint8_t* rng_seeds,
-                            const uint8_t* wires, size_t batch, uint8_t* proofs_out, uint8_t* commitments_out) {
+                            const uint8_t* wires, size_t batch, uint8_t* proofs_out, uint8_t* commitments_out, const uint8_t* ext_draws = nullptr) {
     if (!g || !c || !proofs_out || batch == 0) return BPR1CS_ERR_INVALID_ARGUMENT;
     if (batch > ((size_t)1 << 28)) return BPR1CS_ERR_INVALID_ARGUMENT;
     if (!have_device()) return BPR1CS_ERR_NO_DEVICE;
@@ -730,7 +750,8 @@ static int prove_batch_impl(const bpr1cs_gens* g, const bpr1cs_circuit* c, const
         if (inject_oom > 0) { inject_oom--; e = BPR1CS_ERR_OUT_OF_MEMORY; }   // (test knob, see above)
         else e = prove_job_begin(g, c, n_init == 1 ? init : init + done, n_init == 1 ? 1 : take, tr_out != nullptr,
                                  values ? values + done * m * 32 : nullptr, v_blindings ? v_blindings + done * m * 32 : nullptr,
-                                 rng_seeds ? rng_seeds + done * 32 : nullptr, wires ? wires + done * wn * 32 : nullptr, take, &job);
+                                 rng_seeds ? rng_seeds + done * 32 : nullptr, wires ? wires + done * wn * 32 : nullptr, take, &job,
+                                 ext_draws ? ext_draws + done * (2 * (size_t)c->n + 8) * 64 : nullptr);
         if (e == BPR1CS_ERR_OUT_OF_MEMORY && (take > 64 || !retried)) {
             // out of memory: let the jobs in flight finish and hand the scratch back (arenas sized for the smaller jobs of an
             // earlier call sit next to the blocks that replace them until their last user has drained) - then the same job once
@@ -802,6 +823,17 @@ int bpr1cs_prove_batch_transcripts(const bpr1cs_gens* g, const bpr1cs_circuit* c
         for (size_t i = 0; i < n_transcripts; i++) init[i] = transcripts[i]->s;
         return prove_batch_impl(g, c, init.data(), n_transcripts, n_transcripts == batch ? transcripts : nullptr, values, v_blindings, rng_seeds, wires,
                                 batch, proofs_out, commitments_out);
+    } catch (const std::bad_alloc&) { return BPR1CS_ERR_OUT_OF_MEMORY; }
+}
+int bpr1cs_prove_batch_draws(const bpr1cs_gens* g, const bpr1cs_circuit* c, bpr1cs_transcript* const* transcripts, const uint8_t* values,
+                             const uint8_t* v_blindings, const uint8_t* draws, const uint8_t* wires, size_t batch, uint8_t* proofs_out) {
+    if (!transcripts || !draws || batch == 0) return BPR1CS_ERR_INVALID_ARGUMENT;
+    for (size_t i = 0; i < batch; i++)
+        if (!transcripts[i]) return BPR1CS_ERR_INVALID_ARGUMENT;
+    try {
+        std::vector<strobe> init(batch);
+        for (size_t i = 0; i < batch; i++) init[i] = transcripts[i]->s;
+        return prove_batch_impl(g, c, init.data(), batch, transcripts, values, v_blindings, nullptr, wires, batch, proofs_out, nullptr, draws);
     } catch (const std::bad_alloc&) { return BPR1CS_ERR_OUT_OF_MEMORY; }
 }
 int bpr1cs_last_prove_stats(bpr1cs_prove_stats* out) {

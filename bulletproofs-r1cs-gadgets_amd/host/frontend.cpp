@@ -62,9 +62,23 @@ R1CSProof Prover::prove(const BulletproofGens& bp_gens) {
         for (auto& x : seed) x = (uint8_t)rd();
     }
     std::vector<uint8_t> bytes(bpr1cs_proof_len(c)), comm_bytes(32 * m + 1);
-    bpr1cs_transcript* ts[1] = {transcript.h};
-    rc = bpr1cs_prove_batch_transcripts(bp_gens.h, c, ts, 1, vals.data(), bls.data(), seed.data(), wires.data(), 1, bytes.data(), comm_bytes.data());
-    if (rc == 0 && ledger && !defer_commitments) ledger->fill(comm_bytes.data(), m);   // commitments nobody has read yet: the job computed them
+    // the chain that has been running since the gadget's first constraint-system call (ChainAhead) - if no commitment came after it
+    std::vector<uint8_t> draws;
+    if (chain && chain->m == m && chain->rng && pc_gens.gens == bp_gens.h) draws = chain->take(2 * n + 8);
+    if (!draws.empty()) {
+        bpr1cs_transcript* ts[1] = {chain->t};
+        rc = bpr1cs_prove_batch_draws(bp_gens.h, c, ts, vals.data(), bls.data(), draws.data(), wires.data(), 1, bytes.data());
+        { volatile uint8_t* v = draws.data(); for (size_t i = 0; i < draws.size(); i++) v[i] = 0; }
+        if (rc == 0) {   // the caller's transcript is where upstream's `&mut` transcript is after prove(): the clone that went through it
+            std::swap(transcript.h, chain->t);
+        }
+        chain.reset();
+    } else {
+        chain.reset();   // (none, or stale: a commitment was made after the synthesis had begun) - the library hashes the chain inside the call
+        bpr1cs_transcript* ts[1] = {transcript.h};
+        rc = bpr1cs_prove_batch_transcripts(bp_gens.h, c, ts, 1, vals.data(), bls.data(), seed.data(), wires.data(), 1, bytes.data(), comm_bytes.data());
+        if (rc == 0 && ledger && !defer_commitments) ledger->fill(comm_bytes.data(), m);   // commitments nobody has read yet: the job computed them
+    }
     transcript.fresh = false;
     bpr1cs_circuit_destroy(c);
     if (seconds) { seconds[0] += t1 - t0; seconds[1] += now_s() - t1; }
@@ -430,10 +444,10 @@ int bpr1cs_gadget_prove_single(const char* gadget, const uint32_t* iparams, size
                   },
                   [&](size_t k) { return std::optional<Scalar>(vals.at(k)); },
                   [&](size_t k) { return std::optional<uint64_t>(low64(vals.at(k))); }};
-        run_gadget(g, h);
         std::array<uint8_t, 32> seed;
         memcpy(seed.data(), rng_seed, 32);
-        prover.set_rng_seed(seed);
+        prover.set_rng_seed(seed);   // (before the gadget: the chain that starts at its first constraint-system call is keyed with these bytes)
+        run_gadget(g, h);
         R1CSProof proof = prover.prove(bp_gens);
         std::vector<uint8_t> bytes = proof.to_bytes();
         if (bytes.size() > proof_cap) return BPR1CS_ERR_INVALID_ARGUMENT;
@@ -497,6 +511,7 @@ int bpr1cs_gadget_prove_on_flags(const bpr1cs_gens* gens, const char* gadget, co
             Transcript t((const char*)label, label_len);
             Prover prover(pc_gens, t);
             prover.eager_commitments = (flags & BPR1CS_GADGET_EAGER_COMMITS) != 0;
+            prover.chain_ahead_enabled = (flags & BPR1CS_GADGET_NO_CHAIN_AHEAD) == 0;
             std::vector<Commitment> comms;
             std::array<uint8_t, 32> seed;
             memcpy(seed.data(), rng_seeds, 32);

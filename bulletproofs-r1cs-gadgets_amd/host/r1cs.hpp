@@ -22,6 +22,8 @@
 #include <optional>
 #include <random>
 #include <string>
+#include <thread>
+#include <atomic>
 #include <tuple>
 #include <unordered_map>
 #include <utility>
@@ -440,6 +442,64 @@ public:
     }
 };
 
+// The proof's TranscriptRng chain, run by the Prover on a thread of its own WHILE the gadget is synthesised.  Upstream builds the RNG
+// inside prove() - transcript after Prover::new's, every commit's and prove's ("m") messages, keyed with the commitments' blindings and
+// 32 bytes of thread_rng() - and draws 3 + 2n + 5 scalars from it: 2n + 8 strictly sequential Keccak-f[1600], 7 ms for a depth-32 tree
+// proof and 57 ms at depth 253 on a host core, a quarter of the whole call - and nothing of it depends on the synthesis.  The reference's
+// harnesses make all their commitments first (src/gadget_vsmt_4.rs:393-419) and synthesise afterwards (:421-432), so at the gadget's
+// first constraint-system call everything the chain needs is known but its LENGTH; it needs none: the thread draws until prove() tells it
+// how many draws the proof has.  A commit() after that first call (legal, never done by the reference) invalidates the chain: prove()
+// then ignores it and the library hashes the chain inside the call as it does for every caller that has none (csrc/host_chain.hpp).
+// Host hashing only; the object lives and dies with its Prover; nothing is shared, guessed about n, or kept between proofs.
+struct ChainAhead {
+    static constexpr size_t CHUNK = 4096;   // draws per block of the growing output (256 KB)
+    bpr1cs_transcript* t = nullptr;         // the caller's transcript, cloned, after "dom-sep", the V's and "m"
+    bpr1cs_transcript_rng* rng = nullptr;
+    size_t m = 0;                           // commitments it was started with
+    std::vector<std::unique_ptr<uint8_t[]>> blocks;
+    std::mutex mu;                          // guards `blocks`
+    std::atomic<size_t> produced{0}, target{SIZE_MAX};
+    std::atomic<bool> stop{false};
+    std::thread th;
+    static constexpr size_t LIMIT = (size_t)1 << 21;   // draws a chain nobody stops runs to (128 MB; the reference's largest circuit has 287 416)
+    void run() {
+        while (!stop.load(std::memory_order_relaxed)) {
+            const size_t have = produced.load(std::memory_order_relaxed), want = std::min(target.load(std::memory_order_acquire), LIMIT);
+            if (have >= want) {
+                if (target.load() != SIZE_MAX || have >= LIMIT) return;   // the proof's length is known and reached
+                continue;
+            }
+            if (have % CHUNK == 0) {
+                std::unique_ptr<uint8_t[]> b(new uint8_t[CHUNK * 64]);
+                std::lock_guard<std::mutex> lk(mu);
+                blocks.push_back(std::move(b));
+            }
+            uint8_t* blk;
+            { std::lock_guard<std::mutex> lk(mu); blk = blocks.back().get(); }
+            const size_t in_blk = have % CHUNK, n = std::min<size_t>({CHUNK - in_blk, want - have, (size_t)256});
+            bpr1cs_transcript_rng_fill_bytes(rng, blk + 64 * in_blk, 64, n);
+            produced.store(have + n, std::memory_order_release);
+        }
+    }
+    // -> the first `count` draws, contiguous (waits for the thread to get there)
+    std::vector<uint8_t> take(size_t count) {
+        target.store(count, std::memory_order_release);
+        if (th.joinable()) th.join();
+        std::vector<uint8_t> out(64 * count);
+        const size_t have = std::min(produced.load(), count);
+        for (size_t k = 0; k * CHUNK < have; k++) memcpy(&out[64 * k * CHUNK], blocks[k].get(), 64 * std::min(CHUNK, have - k * CHUNK));
+        if (have < count) out.clear();   // (stopped early: LIMIT)
+        return out;
+    }
+    ~ChainAhead() {
+        stop.store(true);
+        if (th.joinable()) th.join();
+        for (auto& b : blocks) { volatile uint8_t* v = b.get(); for (size_t i = 0; i < CHUNK * 64; i++) v[i] = 0; }   // blinding material
+        bpr1cs_transcript_rng_free(rng);
+        bpr1cs_transcript_free(t);
+    }
+};
+
 class Prover : public CSBase {
 public:
     Prover(const PedersenGens& pc, Transcript& t) : pc_gens(pc), transcript(t), ledger(std::make_shared<CommitLedger>()) { ledger->gens = pc.gens; }
@@ -470,6 +530,7 @@ public:
     }
     std::optional<Scalar> evaluate_lc(const LinearCombination& lc) const override { return eval(lc); }
     MulVars multiply(LinearCombination left, LinearCombination right) override {
+        if (!synthesis_begun) begin_synthesis();
         Scalar l = eval(left), r = eval(right);
         uint32_t i = (uint32_t)a_L.size();
         a_L.push_back(l); a_R.push_back(r); a_O.push_back(l * r);
@@ -483,6 +544,7 @@ public:
     }
     MulVars allocate_multiplier(const std::optional<std::pair<Scalar, Scalar>>& a, const WitnessHint&, const WitnessHint&) override {
         if (!a) throw R1CSError::MissingAssignment();
+        if (!synthesis_begun) begin_synthesis();
         uint32_t i = (uint32_t)a_L.size();
         a_L.push_back(a->first); a_R.push_back(a->second); a_O.push_back(a->first * a->second);
         num_vars = a_L.size();
@@ -490,6 +552,7 @@ public:
     }
     std::pair<Variable, std::optional<Variable>> allocate_single(const std::optional<Scalar>& a, const WitnessHint&) override {
         if (!a) throw R1CSError::MissingAssignment();
+        if (!synthesis_begun) begin_synthesis();
         if (!pending_multiplier) {
             uint32_t i = (uint32_t)a_L.size();
             pending_multiplier = i;
@@ -505,13 +568,54 @@ public:
     }
     // The 32 bytes upstream takes from thread_rng() in TranscriptRng::finalize; explicit here
     // (SURVEY §8c); defaults to OS randomness.
-    void set_rng_seed(const std::array<uint8_t, 32>& s) { rng_seed = s; }
+    void set_rng_seed(const std::array<uint8_t, 32>& s) {
+        if (chain && (!rng_seed || *rng_seed != s)) chain.reset();   // a chain already running was keyed with other bytes: prove() hashes its own
+        rng_seed = s;
+    }
     R1CSProof prove(const BulletproofGens& bp_gens);
     // what prove() hands to the device: committed values, blindings (m x 32 each) and the wires a_L | a_R | a_O (3 n x 32), appended
     void export_witness(std::vector<uint8_t>& vals, std::vector<uint8_t>& bls, std::vector<uint8_t>& wires) const;
     bool defer_commitments = false;
     bool eager_commitments = false;   // true: every commit() computes its point at once (what a caller bound to upstream's signature pays)
     std::shared_ptr<CommitLedger> ledger;
+    bool chain_ahead_enabled = true;  // false: prove() lets the library hash the chain inside the call (the other path, same bytes)
+    size_t chain_ahead_min_commitments = 16;
+    std::unique_ptr<ChainAhead> chain;
+    bool synthesis_begun = false;
+    // the gadget's first constraint-system call: every commitment of the reference's harnesses is made - start the proof's chain (ChainAhead)
+    void begin_synthesis() {
+        synthesis_begun = true;
+        // (a statement of a few commitments is a small circuit - the reference's range and preimage proofs: 3-10 commitments, chains of
+        // 0.05-0.3 ms - and gains nothing from a thread and an extra device call; its Merkle-path statements have 69-511)
+        if (!chain_ahead_enabled || defer_commitments || !pc_gens.gens || v_.size() < chain_ahead_min_commitments) return;
+        try {
+            ledger->resolve();   // the V's, in ONE device call (nothing to do for eager commitments)
+            if (!rng_seed) {
+                std::array<uint8_t, 32> sd;
+                std::random_device rd;  // stands in for rand::thread_rng(): the 32 bytes upstream draws inside prove()
+                for (auto& x : sd) x = (uint8_t)rd();
+                rng_seed = sd;
+            }
+            std::unique_ptr<ChainAhead> c(new ChainAhead());
+            c->m = v_.size();
+            c->t = bpr1cs_transcript_clone(transcript.h);
+            if (!c->t) return;
+            auto app = [&](const char* lbl, const uint8_t* msg, size_t len) { bpr1cs_transcript_append_message(c->t, (const uint8_t*)lbl, strlen(lbl), msg, len); };
+            app("dom-sep", (const uint8_t*)"r1cs v1", 7);
+            for (size_t i = 0; i < c->m; i++) app("V", ledger->points[i].data(), 32);
+            uint8_t mb[8];
+            for (int i = 0; i < 8; i++) mb[i] = (uint8_t)((uint64_t)c->m >> (8 * i));
+            app("m", mb, 8);
+            std::vector<uint8_t> bl(32 * c->m + 1);
+            for (size_t i = 0; i < c->m; i++) v_blinding_[i].write_bytes(&bl[32 * i]);
+            c->rng = bpr1cs_transcript_build_rng(c->t, (const uint8_t*)"v_blinding", 10, bl.data(), 32, c->m, rng_seed->data());
+            { volatile uint8_t* v = bl.data(); for (size_t i = 0; i < bl.size(); i++) v[i] = 0; }
+            if (!c->rng) return;
+            ChainAhead* raw = c.get();
+            c->th = std::thread([raw]() { raw->run(); });
+            chain = std::move(c);
+        } catch (...) { chain.reset(); }   // (no thread to be had, a device error resolving the commitments: prove() takes the other path)
+    }
     double* seconds = nullptr;   // optional [2]: seconds spent in (CSR export + bpr1cs_circuit_create, the prove call) of prove()
 
     const PedersenGens& pc_gens;

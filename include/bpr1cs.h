@@ -226,6 +226,20 @@ int bpr1cs_prove_batch_transcripts(const bpr1cs_gens* g, const bpr1cs_circuit* c
                                    const uint8_t* values, const uint8_t* v_blindings, const uint8_t* rng_seeds,
                                    const uint8_t* wires, size_t batch, uint8_t* proofs_out, uint8_t* commitments_out);
 
+/* The same for a caller that runs the front of Prover::prove ITSELF, on the host, before the call: it has appended Prover::new's
+ * ("dom-sep", "r1cs v1"), every commit's ("V", V_i) and prove's ("m", m as LE64) messages to transcripts[i] (bpr1cs_transcript_* below, or
+ * its own merlin), and has drawn the proof's 2n + 8 `Scalar::random(&mut rng)` values from the TranscriptRng upstream builds there
+ * (transcript.build_rng().rekey_with_witness_bytes("v_blinding", b_i) for every commitment, finalize(32 bytes of thread_rng())):
+ * i_bl, o_bl, s_bl, s_L[0..n), s_R[0..n), the five t blindings - `draws` = batch x (2n + 8) x 64 raw bytes in that order, not reduced.
+ * Why: that chain is 2n + 8 strictly sequential Keccak-f[1600] - 7 ms for a depth-32 tree proof, 57 ms at depth 253 on a host core - and
+ * depends on nothing the gadget's synthesis produces: a caller that starts it on a thread of its own when its last commitment is made
+ * (host/r1cs.hpp Prover does; a Rust shim would with merlin's own TranscriptRng) finds it finished when prove() is called.  The library
+ * only reduces the draws mod l and proves; transcripts[i] is left where upstream's `&mut` transcript is after prove().  No commitments
+ * are returned (the caller made them).  Same proof bytes as bpr1cs_prove_batch_transcripts with the same 32 bytes. */
+int bpr1cs_prove_batch_draws(const bpr1cs_gens* g, const bpr1cs_circuit* c, bpr1cs_transcript* const* transcripts /* batch */,
+                             const uint8_t* values, const uint8_t* v_blindings, const uint8_t* draws, const uint8_t* wires, size_t batch,
+                             uint8_t* proofs_out);
+
 /* Asynchronous form of bpr1cs_prove_batch: `begin` uploads the inputs and enqueues the whole prove on
  * one of two per-handle HIP stream pairs and returns without waiting; `end` waits for that job and
  * copies the results out.  Two jobs may be in flight per gens handle (a third `begin` before an `end` is refused with
@@ -315,6 +329,14 @@ bpr1cs_transcript* bpr1cs_transcript_new(const uint8_t* label, size_t label_len)
 void bpr1cs_transcript_free(bpr1cs_transcript* t);
 void bpr1cs_transcript_append_message(bpr1cs_transcript* t, const uint8_t* label, size_t label_len, const uint8_t* msg, size_t msg_len);
 void bpr1cs_transcript_challenge_bytes(bpr1cs_transcript* t, const uint8_t* label, size_t label_len, uint8_t* out, size_t out_len);
+bpr1cs_transcript* bpr1cs_transcript_clone(const bpr1cs_transcript* t);                                 /* Transcript: Clone          */
+/* merlin::TranscriptRng: t.build_rng().rekey_with_witness_bytes(witness_label, w_j) for j < count (witnesses: count x witness_len bytes)
+ * .finalize(seed); fill_bytes = `count` successive RngCore::fill_bytes(len) calls (a draw of 64 bytes is one Scalar::random) */
+typedef struct bpr1cs_transcript_rng bpr1cs_transcript_rng;
+bpr1cs_transcript_rng* bpr1cs_transcript_build_rng(const bpr1cs_transcript* t, const uint8_t* witness_label, size_t label_len,
+                                                   const uint8_t* witnesses, size_t witness_len, size_t count, const uint8_t seed[32]);
+void bpr1cs_transcript_rng_fill_bytes(bpr1cs_transcript_rng* r, uint8_t* out, size_t len, size_t count);
+void bpr1cs_transcript_rng_free(bpr1cs_transcript_rng* r);
 /* InnerProductProof::create(transcript, &Q, G_factors, H_factors, G, H, a, b) of the bulletproofs crate (the last step of
  * every Prover::prove, reference src/gadget_vsmt_4.rs:434) for ONE proof over the handle's generators G[0..n), H[0..n):
  * appends ("dom-sep","ipp v1"), ("n", n) to `t`, runs the lg n rounds on the device (appending L_k, R_k and drawing u_k),

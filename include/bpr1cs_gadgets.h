@@ -63,8 +63,12 @@ int bpr1cs_gadget_prove_on(const bpr1cs_gens* gens, const char* gadget, const ui
 /* The same with flags.  BPR1CS_GADGET_EAGER_COMMITS (batch = 1): every Prover::commit computes its point before it returns - one
  * bpr1cs_msm_fixed call per commitment, what a caller bound to upstream's signature `commit(v, blinding) -> (CompressedRistretto,
  * Variable)` pays (tools/rust_shim/prover.rs).  Without it (and in bpr1cs_gadget_prove_on) the C++ Prover hands out commitments that
- * are resolved when read - here after prove(), from the V's the prove call returns - host/r1cs.hpp class Commitment.  Same bytes. */
+ * are resolved when read - host/r1cs.hpp class Commitment.  Same bytes.
+ * BPR1CS_GADGET_NO_CHAIN_AHEAD (batch = 1): the C++ Prover does not start the proof's TranscriptRng chain on a thread of its own at the
+ * gadget's first constraint-system call (host/r1cs.hpp ChainAhead -> bpr1cs_prove_batch_draws); prove() then calls
+ * bpr1cs_prove_batch_transcripts and the library hashes the chain inside that call.  Same bytes. */
 #define BPR1CS_GADGET_EAGER_COMMITS 1u
+#define BPR1CS_GADGET_NO_CHAIN_AHEAD 2u
 int bpr1cs_gadget_prove_on_flags(const bpr1cs_gens* gens, const char* gadget, const uint32_t* iparams, size_t n_iparams, const uint8_t* sparams,
                                  size_t n_sparams, const uint8_t* poseidon_blob, size_t blob_len, const uint8_t* label, size_t label_len,
                                  const uint8_t* values, const uint8_t* v_blindings, size_t m, size_t batch, const uint8_t* rng_seeds,

@@ -1,6 +1,8 @@
 """C++ gadget front-end (host/) vs the oracle's restatement of the reference gadgets.
 Backend = the CPU simulator of the device code, so this runs without a GPU; the same
 checks run against the HIP backend in test_gpu_frontend.py."""
+import os
+
 import pytest
 
 from pyref import scenarios as S, gadgets as g
@@ -34,7 +36,7 @@ def test_prover_single(sim_lib, sim_glib):
     fc.check_prove_single(sim_glib, "set_membership")
 
 
-@pytest.mark.parametrize("case,batch", [("bound_check", 5), ("set_membership", 3), ("poseidon_hash_2_inverse_pr1", 3)])
+@pytest.mark.parametrize("case,batch", [("bound_check", 5), ("set_membership", 3), ("poseidon_hash_2_inverse_pr1", 3), ("vsmt_4_pr2_cube", 2)])
 def test_reference_call_shape_on_shared_generators(sim_lib, sim_glib, case, batch):
     """one proof per prove() on generators created once (bpr1cs_gadget_prove_on), and several witnesses per call"""
     fc.check_prove_on(sim_lib, sim_glib, case, batch)
@@ -121,3 +123,18 @@ def test_host_synthesis_with_a_zero_sbox_input_takes_the_one_by_one_path(sim_gli
         ob = common.oracle_batch(lambda j: fc.case(name, 0)[3], cap, 1, satisfiable=not name.endswith("_zero"), key=name + "_synth")
         wires, n, q = bp.gadget_synthesize(gname, ip, sp, ob["values"], ob["m"], glib=sim_glib)
         assert n == ob["n"] and wires == ob["wires"], name
+
+
+def test_prover_chain_ahead_and_a_commitment_after_the_synthesis_began(sim_lib, sim_glib):
+    """host/r1cs.hpp ChainAhead: the C++ Prover runs the proof's TranscriptRng chain on a thread of its own from the gadget's first
+    constraint-system call on and proves through bpr1cs_prove_batch_draws; a commit() after that call drops the chain and prove() takes
+    bpr1cs_prove_batch_transcripts.  tests/hostsim/late_commit_check.cpp drives a Prover by hand both ways (fresh and advanced
+    transcript): same proof bytes, same commitments, same transcript state afterwards as the Prover without the chain."""
+    import subprocess
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    bdir = os.path.join(ROOT, "tests", "hostsim", "_build")
+    exe = os.path.join(bdir, "late_commit_check")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-DBPR1CS_HOST_ONLY", os.path.join(ROOT, "tests", "hostsim", "late_commit_check.cpp"), "-o", exe,
+                           "-L" + bdir, "-lbpr1cs_gadgets_sim", "-lbpr1cs_sim", "-Wl,-rpath," + bdir, "-pthread"])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stdout + r.stderr

@@ -15,6 +15,7 @@ pub const BPR1CS_ERR_OUT_OF_MEMORY: i32 = -19;
 #[repr(C)] pub struct bpr1cs_transcript { _private: [u8; 0] }
 #[repr(C)] pub struct bpr1cs_job { _private: [u8; 0] }
 #[repr(C)] pub struct bpr1cs_comm { _private: [u8; 0] }
+#[repr(C)] pub struct bpr1cs_transcript_rng { _private: [u8; 0] }
 #[repr(C)] pub struct bpr1cs_wop {
     pub lkind: u32,
     pub larg: u32,
@@ -103,6 +104,7 @@ extern "C" {
     pub fn bpr1cs_proof_len(c: *const bpr1cs_circuit) -> usize;
     pub fn bpr1cs_prove_batch(g: *const bpr1cs_gens, c: *const bpr1cs_circuit, label: *const u8, label_len: usize, values: *const u8, v_blindings: *const u8, rng_seeds: *const u8, wires: *const u8, batch: usize, proofs_out: *mut u8, commitments_out: *mut u8) -> i32;
     pub fn bpr1cs_prove_batch_transcripts(g: *const bpr1cs_gens, c: *const bpr1cs_circuit, transcripts: *mut *mut bpr1cs_transcript, n_transcripts: usize, values: *const u8, v_blindings: *const u8, rng_seeds: *const u8, wires: *const u8, batch: usize, proofs_out: *mut u8, commitments_out: *mut u8) -> i32;
+    pub fn bpr1cs_prove_batch_draws(g: *const bpr1cs_gens, c: *const bpr1cs_circuit, transcripts: *mut *mut bpr1cs_transcript, values: *const u8, v_blindings: *const u8, draws: *const u8, wires: *const u8, batch: usize, proofs_out: *mut u8) -> i32;
     pub fn bpr1cs_prove_batch_begin(g: *const bpr1cs_gens, c: *const bpr1cs_circuit, label: *const u8, label_len: usize, values: *const u8, v_blindings: *const u8, rng_seeds: *const u8, wires: *const u8, batch: usize, job_out: *mut *mut bpr1cs_job) -> i32;
     pub fn bpr1cs_prove_batch_end(job: *mut bpr1cs_job, proofs_out: *mut u8, commitments_out: *mut u8) -> i32;
     pub fn bpr1cs_verify_batch(g: *const bpr1cs_gens, c: *const bpr1cs_circuit, label: *const u8, label_len: usize, proofs: *const u8, commitments: *const u8, verifier_rng_seeds: *const u8, batch: usize, ok_out: *mut i32) -> i32;
@@ -119,6 +121,10 @@ extern "C" {
     pub fn bpr1cs_transcript_free(t: *mut bpr1cs_transcript);
     pub fn bpr1cs_transcript_append_message(t: *mut bpr1cs_transcript, label: *const u8, label_len: usize, msg: *const u8, msg_len: usize);
     pub fn bpr1cs_transcript_challenge_bytes(t: *mut bpr1cs_transcript, label: *const u8, label_len: usize, out: *mut u8, out_len: usize);
+    pub fn bpr1cs_transcript_clone(t: *const bpr1cs_transcript) -> *mut bpr1cs_transcript;
+    pub fn bpr1cs_transcript_build_rng(t: *const bpr1cs_transcript, witness_label: *const u8, label_len: usize, witnesses: *const u8, witness_len: usize, count: usize, seed: *const u8) -> *mut bpr1cs_transcript_rng;
+    pub fn bpr1cs_transcript_rng_fill_bytes(r: *mut bpr1cs_transcript_rng, out: *mut u8, len: usize, count: usize);
+    pub fn bpr1cs_transcript_rng_free(r: *mut bpr1cs_transcript_rng);
     pub fn bpr1cs_ipa_create(g: *const bpr1cs_gens, t: *mut bpr1cs_transcript, Q: *const u8, G_factors: *const u8, H_factors: *const u8, a: *const u8, b: *const u8, n: usize, L_out: *mut u8, R_out: *mut u8, a_out: *mut u8, b_out: *mut u8) -> i32;
     pub fn bpr1cs_msm(scalars: *const u8, points: *const u8, n: usize, out: *mut u8) -> i32;
     pub fn bpr1cs_points_sum(points: *const u8, count: usize, out: *mut u8) -> i32;
