@@ -152,7 +152,9 @@ struct PoseidonParams {
         std::vector<std::vector<Scalar>> cst;     // [r] = c_r (width), r = 0..partial_rounds
     };
     const PartialTables& partial_tables() const {
-        std::call_once(pt_once, [this] {
+        Derived& dv = derived();
+        PartialTables& pt = dv.pt;
+        std::call_once(dv.pt_once, [this, &pt] {
             const size_t w = width, pr = partial_rounds;
             auto matvec = [&](const std::vector<Scalar>& mat, const std::vector<Scalar>& v) {
                 std::vector<Scalar> o(w);
@@ -187,9 +189,104 @@ struct PoseidonParams {
         });
         return pt;
     }
+    // ---- the S-box INPUT VALUES of the partial rounds with 2 w - 1 products per round instead of w^2 (the "equivalent sparse matrices"
+    // of the Poseidon paper, specialised to what the prover needs: the values, not the state).  Split the state into the w - 1 untouched
+    // elements R and the S-box element; M = [[M_RR, b], [m^T, d]].  In the basis R = M_RR^r R~ the untouched part of round r's linear
+    // layer is the identity: R~_(r+1) = R~_r + k~_r + y_r u_r with u_r the S-box output, y_r = M_RR^-(r+1) b, k~_r = M_RR^-r k_r (the keys of
+    // the untouched elements: they only accumulate, K_r = sum_{j<r} k~_j, so v_r = R~_r - K_r carries none), and the next S-box input is
+    // t_(r+1) = c_r^T v_r + d u_r + kappa_r with c_r^T = m^T M_RR^r, kappa_r = c_r^T K_(r+1) + (the S-box element's key of round r+1).
+    struct SparsePartial {
+        bool ok = false;                          // false: M_RR is singular (never for an MDS matrix): the dense path
+        std::vector<std::vector<Scalar>> y, c;    // [r][w-1]
+        std::vector<Scalar> kappa;                // [r]
+        Scalar d;
+    };
+    const SparsePartial& sparse_partial() const {
+        Derived& dv = derived();
+        SparsePartial& sp = dv.sp;
+        std::call_once(dv.sp_once, [this, &sp] {
+            const size_t w = width, q = w - 1, pr = partial_rounds, off0 = full_rounds_beginning * w;
+            typedef std::vector<Scalar> Mat;   // q x q row-major
+            auto mul = [&](const Mat& A, const Mat& B) { Mat C(q * q); for (size_t i = 0; i < q; i++) for (size_t k = 0; k < q; k++) for (size_t j = 0; j < q; j++) C[i * q + j] += A[i * q + k] * B[k * q + j]; return C; };
+            auto mv = [&](const Mat& A, const std::vector<Scalar>& v) { std::vector<Scalar> o(q); for (size_t i = 0; i < q; i++) for (size_t j = 0; j < q; j++) o[i] += A[i * q + j] * v[j]; return o; };
+            Mat MRR(q * q), G(q * q), aug(q * 2 * q);
+            for (size_t i = 0; i < q; i++) for (size_t j = 0; j < q; j++) MRR[i * q + j] = MDS_matrix[i][j];
+            // G = M_RR^-1 by Gauss-Jordan
+            for (size_t i = 0; i < q; i++) for (size_t j = 0; j < 2 * q; j++) aug[i * 2 * q + j] = j < q ? MRR[i * q + j] : (j - q == i ? Scalar::one() : Scalar());
+            for (size_t col = 0; col < q; col++) {
+                size_t piv = col;
+                while (piv < q && aug[piv * 2 * q + col].is_zero()) piv++;
+                if (piv == q) return;   // singular: sp.ok stays false
+                if (piv != col) for (size_t j = 0; j < 2 * q; j++) std::swap(aug[piv * 2 * q + j], aug[col * 2 * q + j]);
+                const Scalar inv = aug[col * 2 * q + col].invert();
+                for (size_t j = 0; j < 2 * q; j++) aug[col * 2 * q + j] = aug[col * 2 * q + j] * inv;
+                for (size_t i = 0; i < q; i++) {
+                    if (i == col) continue;
+                    const Scalar f = aug[i * 2 * q + col];
+                    if (f.is_zero()) continue;
+                    for (size_t j = 0; j < 2 * q; j++) aug[i * 2 * q + j] = aug[i * 2 * q + j] - f * aug[col * 2 * q + j];
+                }
+            }
+            for (size_t i = 0; i < q; i++) for (size_t j = 0; j < q; j++) G[i * q + j] = aug[i * 2 * q + q + j];
+            std::vector<Scalar> b(q), m(q);
+            for (size_t i = 0; i < q; i++) { b[i] = MDS_matrix[i][q]; m[i] = MDS_matrix[q][i]; }
+            sp.d = MDS_matrix[q][q];
+            sp.y.resize(pr); sp.c.resize(pr); sp.kappa.resize(pr);
+            Mat Gr(q * q), Pr(q * q);   // G^r, M_RR^r
+            for (size_t i = 0; i < q; i++) Gr[i * q + i] = Pr[i * q + i] = Scalar::one();
+            std::vector<Scalar> K(q);     // K_r
+            for (size_t r = 0; r < pr; r++) {
+                std::vector<Scalar> kr(q);
+                for (size_t i = 0; i < q; i++) kr[i] = round_keys[off0 + r * w + i];
+                const std::vector<Scalar> kt = mv(Gr, kr);               // k~_r = G^r k_r
+                for (size_t i = 0; i < q; i++) K[i] += kt[i];            // K_(r+1)
+                Gr = mul(Gr, G);                                         // G^(r+1)
+                sp.y[r] = mv(Gr, b);
+                sp.c[r].assign(q, Scalar());                             // c_r^T = m^T M_RR^r
+                for (size_t j = 0; j < q; j++) for (size_t i = 0; i < q; i++) sp.c[r][j] += m[i] * Pr[i * q + j];
+                Scalar kap;
+                for (size_t i = 0; i < q; i++) kap += sp.c[r][i] * K[i];
+                if (r + 1 < pr) kap += round_keys[off0 + (r + 1) * w + q];
+                sp.kappa[r] = kap;
+                Pr = mul(Pr, MRR);
+            }
+            sp.ok = true;
+        });
+        return sp;
+    }
 private:
-    mutable std::once_flag pt_once;
-    mutable PartialTables pt;
+    // The tables above depend on the parameter set alone, and the reference's harnesses build a PoseidonParams per proof
+    // (src/gadget_vsmt_4.rs:372-378): they are kept per process, keyed by the full contents of the set (a few entries, oldest out) -
+    // ~50 000 products per proof otherwise, a tenth of a depth-32 synthesis.
+    struct Derived {
+        size_t width, fb, pr;
+        std::vector<Scalar> keys, mds;
+        std::once_flag pt_once, sp_once;
+        PartialTables pt;
+        SparsePartial sp;
+    };
+    Derived& derived() const {
+        if (!der) {
+            static std::mutex mu;
+            static std::vector<std::shared_ptr<Derived>> cache;
+            std::vector<Scalar> flat;
+            for (auto& row : MDS_matrix) flat.insert(flat.end(), row.begin(), row.end());
+            auto same = [](const std::vector<Scalar>& a, const std::vector<Scalar>& b) {
+                return a.size() == b.size() && (a.empty() || memcmp(a.data(), b.data(), a.size() * sizeof(Scalar)) == 0);
+            };
+            std::lock_guard<std::mutex> lk(mu);
+            for (auto& d : cache)
+                if (d->width == width && d->fb == full_rounds_beginning && d->pr == partial_rounds && same(d->keys, round_keys) && same(d->mds, flat)) { der = d; break; }
+            if (!der) {
+                der = std::make_shared<Derived>();
+                der->width = width; der->fb = full_rounds_beginning; der->pr = partial_rounds; der->keys = round_keys; der->mds = flat;
+                if (cache.size() >= 8) cache.erase(cache.begin());
+                cache.push_back(der);
+            }
+        }
+        return *der;
+    }
+    mutable std::shared_ptr<Derived> der;
 };
 
 enum class SboxType { Cube, Inverse };  // gadget_poseidon.rs:114-117
@@ -402,25 +499,46 @@ inline std::vector<LinearCombination> Poseidon_permutation_constraints(Constrain
             // (an unsatisfiable witness: the convention 1/0 = 0 has no fraction) leaves `pre` empty: the round-by-round path below.
             std::vector<Scalar> pre_l, pre_r;
             if (have && pr > 0) {
-                std::vector<Scalar> N = st, T(width), seq;
-                Scalar D = Scalar::one();
+                std::vector<Scalar> seq;
                 seq.reserve(2 * pr);
                 bool ok = true;
-                size_t o2 = off;
-                for (size_t r = 0; r < pr && ok; r++) {
-                    if (r == 0) { for (size_t i = 0; i < width; i++) N[i] += params.round_keys[o2 + i]; }
-                    else { for (size_t i = 0; i < width; i++) N[i] += params.round_keys[o2 + i] * D; }
-                    const Scalar a = N[width - 1];
-                    if (a.is_zero()) { ok = false; break; }
-                    seq.push_back(a); seq.push_back(D);
-                    for (size_t i = 0; i + 1 < width; i++) N[i] = N[i] * a;
-                    N[width - 1] = D * D;
-                    D = D * a;
-                    for (size_t i = 0; i < width; i++) T[i] = Scalar();
-                    for (size_t j = 0; j < width; j++)
-                        for (size_t i = 0; i < width; i++) T[i] += N[j] * params.MDS_matrix[i][j];
-                    N = T;
-                    o2 += width;
+                const PoseidonParams::SparsePartial& SP = params.sparse_partial();
+                if (SP.ok && off == params.full_rounds_beginning * width) {
+                    // 20 products per round: v (the untouched elements in the basis where their linear layer is the identity, without their
+                    // keys) as numerators Nv over D, the S-box input as a / D (PoseidonParams::sparse_partial)
+                    const size_t q = width - 1;
+                    std::vector<Scalar> Nv(st.begin(), st.begin() + q);
+                    Scalar D = Scalar::one(), a = st[q] + params.round_keys[off + q];
+                    for (size_t r = 0; r < pr && ok; r++) {
+                        if (a.is_zero()) { ok = false; break; }
+                        seq.push_back(a); seq.push_back(D);
+                        const Scalar D2 = D * D, Da = D * a;
+                        Scalar sdot;
+                        for (size_t i = 0; i < q; i++) sdot += SP.c[r][i] * Nv[i];
+                        const Scalar a_next = sdot * a + SP.d * D2 + SP.kappa[r] * Da;
+                        for (size_t i = 0; i < q; i++) Nv[i] = Nv[i] * a + SP.y[r][i] * D2;
+                        a = a_next;
+                        D = Da;
+                    }
+                } else {
+                    std::vector<Scalar> N = st, T(width);
+                    Scalar D = Scalar::one();
+                    size_t o2 = off;
+                    for (size_t r = 0; r < pr && ok; r++) {
+                        if (r == 0) { for (size_t i = 0; i < width; i++) N[i] += params.round_keys[o2 + i]; }
+                        else { for (size_t i = 0; i < width; i++) N[i] += params.round_keys[o2 + i] * D; }
+                        const Scalar a = N[width - 1];
+                        if (a.is_zero()) { ok = false; break; }
+                        seq.push_back(a); seq.push_back(D);
+                        for (size_t i = 0; i + 1 < width; i++) N[i] = N[i] * a;
+                        N[width - 1] = D * D;
+                        D = D * a;
+                        for (size_t i = 0; i < width; i++) T[i] = Scalar();
+                        for (size_t j = 0; j < width; j++)
+                            for (size_t i = 0; i < width; i++) T[i] += N[j] * params.MDS_matrix[i][j];
+                        N = T;
+                        o2 += width;
+                    }
                 }
                 if (ok) {
                     std::vector<Scalar> prefix(seq.size());
