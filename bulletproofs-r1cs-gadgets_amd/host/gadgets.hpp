@@ -200,6 +200,8 @@ struct PoseidonParams {
         std::vector<std::vector<Scalar>> y, c;    // [r][w-1]
         std::vector<Scalar> kappa;                // [r]
         Scalar d;
+        std::vector<Scalar> P_end, K_end;         // M_RR^pr ((w-1)^2 row-major) and K_pr: the state after the last partial round is
+                                                  // (M_RR^pr (v_pr + K_pr), t_pr) - for the values of the first full round that follows
     };
     const SparsePartial& sparse_partial() const {
         Derived& dv = derived();
@@ -250,6 +252,8 @@ struct PoseidonParams {
                 sp.kappa[r] = kap;
                 Pr = mul(Pr, MRR);
             }
+            sp.P_end = Pr;
+            sp.K_end = K;
             sp.ok = true;
         });
         return sp;
@@ -433,13 +437,14 @@ inline std::vector<LinearCombination> Poseidon_permutation_constraints(Constrain
     size_t off = 0;
     // one full round: `width` S-boxes on independent inputs.  For a constraint system that knows the values (and records no hints) the
     // `width` inverses come from ONE inversion (Montgomery's trick); the calls on `cs` are those of synthesize_sbox, in its order.
+    std::vector<Scalar> known_state;   // the VALUES of input_vars when somebody has them already (the state after the partial rounds: 177-term combinations)
     auto full_round = [&]() {
         std::vector<LinearCombination> outs(width);
         if (sbox_type == SboxType::Inverse && !cs.uses_witness_hints()) {
             std::vector<Scalar> x(width), pre(width);
             bool ok = true;
             for (size_t i = 0; i < width && ok; i++) {
-                std::optional<Scalar> val = cs.evaluate_lc(input_vars[i]);
+                std::optional<Scalar> val = known_state.size() == width ? std::optional<Scalar>(known_state[i]) : cs.evaluate_lc(input_vars[i]);
                 if (!val) { ok = false; break; }
                 x[i] = *val + params.round_keys[off + i];
                 if (x[i].is_zero()) ok = false;   // (1/0 = 0 by convention: the one-by-one path below)
@@ -452,11 +457,13 @@ inline std::vector<LinearCombination> Poseidon_permutation_constraints(Constrain
                 for (size_t i = 0; i < width; i++) outs[i] = LinearCombination(synthesize_inverse_sbox_from_values(cs, x[i], pre[i]));
                 off += width;
                 input_vars = apply_linear_layer(outs);
+                known_state.clear();
                 return;
             }
         }
         for (size_t i = 0; i < width; i++) outs[i] = LinearCombination(synthesize_sbox(cs, sbox_type, input_vars[i], params.round_keys[off++]));
         input_vars = apply_linear_layer(outs);
+        known_state.clear();
     };
     if (sbox_type == SboxType::Inverse) {
         PoseidonShape sh;
@@ -480,6 +487,7 @@ inline std::vector<LinearCombination> Poseidon_permutation_constraints(Constrain
             lc.terms.push_back({Variable::One(), T.cst[r][e]});
             return lc;
         };
+        std::vector<Scalar> partial_end_state;
         if (sbox_type == SboxType::Inverse && !cs.uses_witness_hints()) {
             // Prover / Verifier: the S-box input of a partial round is needed as a VALUE only (see synthesize_inverse_sbox_from_value),
             // and the value is the native permutation's state (Poseidon_permutation above: add the keys, invert the last element,
@@ -497,7 +505,7 @@ inline std::vector<LinearCombination> Poseidon_permutation_constraints(Constrain
             // instead of 36 and an inversion worth ~48 (one safegcd per S-box was a third of the host's synthesis of a tree proof).  The
             // same values, hence the same wires (tests/test_frontend.py: full-size synthesis against the C oracle).  A zero S-box input
             // (an unsatisfiable witness: the convention 1/0 = 0 has no fraction) leaves `pre` empty: the round-by-round path below.
-            std::vector<Scalar> pre_l, pre_r;
+            std::vector<Scalar> pre_l, pre_r, end_state;
             if (have && pr > 0) {
                 std::vector<Scalar> seq;
                 seq.reserve(2 * pr);
@@ -519,6 +527,15 @@ inline std::vector<LinearCombination> Poseidon_permutation_constraints(Constrain
                         for (size_t i = 0; i < q; i++) Nv[i] = Nv[i] * a + SP.y[r][i] * D2;
                         a = a_next;
                         D = Da;
+                    }
+                    if (ok && !D.is_zero()) {   // the state after the last partial round, for the first full round of the end: (M_RR^pr (v + K_pr), a / D)
+                        const Scalar Dinv = D.invert();
+                        std::vector<Scalar> vv(q);
+                        for (size_t i = 0; i < q; i++) vv[i] = Nv[i] * Dinv + SP.K_end[i];
+                        end_state.assign(width, Scalar());
+                        for (size_t i = 0; i < q; i++)
+                            for (size_t j = 0; j < q; j++) end_state[i] += SP.P_end[i * q + j] * vv[j];
+                        end_state[q] = a * Dinv;
                     }
                 } else {
                     std::vector<Scalar> N = st, T(width);
@@ -550,6 +567,7 @@ inline std::vector<LinearCombination> Poseidon_permutation_constraints(Constrain
                     for (size_t r = 0; r < pr; r++) { pre_l[r] = seq[2 * r] * prefix[2 * r + 1]; pre_r[r] = seq[2 * r + 1] * prefix[2 * r]; }
                 }
             }
+            if (!pre_l.empty()) partial_end_state = end_state;
             for (size_t r = 0; r < pr; r++) {
                 std::optional<Scalar> val_l, val_r;
                 if (!pre_l.empty()) {
@@ -579,6 +597,7 @@ inline std::vector<LinearCombination> Poseidon_permutation_constraints(Constrain
             }
         }
         for (size_t e = 0; e < width; e++) input_vars[e] = element(pr, e).simplify();
+        if (!partial_end_state.empty()) known_state = partial_end_state;
     }
     for (size_t k = 0; k < params.full_rounds_end; k++) full_round();
     if (sbox_type == SboxType::Inverse) cs.poseidon_end();
