@@ -413,8 +413,8 @@ static int prove_job_begin(const bpr1cs_gens* g, const bpr1cs_circuit* c, const 
         MsmSeg none{nullptr, 0, 1, 1, 0, 0, 0};
         auto seg = [&](const sc* p, uint32_t base0) { return MsmSeg{p, n, n ? n : 1, n ? n : 1, 0, base0, 1}; };
         const uint32_t T3 = (uint32_t)c->h_trip.size();
-        DevBuf<ge> partial2, partialO1;
-        MsmPlan planO, planO1{0, 0};
+        DevBuf<ge> partial2, partialO1, partialS;
+        MsmPlan planO, planO1{0, 0}, planS;
         const ge* ones_pt = nullptr;
         K_msm_finish finI{g->tab.p, g->tc, nullptr, blind.p + 0 * (size_t)B, nullptr, AOS.p + 0 * (size_t)B * 32, B, 0, 1};
         if (!wires && T3) {
@@ -468,12 +468,18 @@ static int prove_job_begin(const bpr1cs_gens* g, const bpr1cs_circuit* c, const 
         finish_host_chains();
         dev_stream_wait(st, job->ev_rng);  // the chain's draws (blindings, s_L, s_R), the transcript after the V's
         pt.mark(st);
-        launch_finish(finI, B, st);
         K_msm_finish finO{g->tab.p, g->tc, partialO.p, blind.p + 1 * (size_t)B, nullptr, AOS.p + 1 * (size_t)B * 32, B, planO.nchunks, 1};
         if (ones_pt) { finO.shared_pt = ones_pt; finO.partial_b = partialO1.p; finO.nchunks_b = planO1.nchunks; }
-        launch_finish(finO, B, st);
-        run_msm(g, seg(sL, baseG), seg(sR, baseH), B, partial, plan, st, stats);
-        launch_finish(K_msm_finish{g->tab.p, g->tc, partial.p, blind.p + 2 * (size_t)B, nullptr, AOS.p + 2 * (size_t)B * 32, B, plan.nchunks, 1}, B, st);
+        if (B <= SMALL_JOB_PROOFS) {
+            // a job of a few proofs: S's sum has chunk sums of its own, and the three finishes share one launch
+            run_msm(g, seg(sL, baseG), seg(sR, baseH), B, partialS, planS, st, stats);
+            launch_finish_triple(finI, finO, K_msm_finish{g->tab.p, g->tc, partialS.p, blind.p + 2 * (size_t)B, nullptr, AOS.p + 2 * (size_t)B * 32, B, planS.nchunks, 1}, B, st);
+        } else {
+            launch_finish(finI, B, st);
+            launch_finish(finO, B, st);
+            run_msm(g, seg(sL, baseG), seg(sR, baseH), B, partial, plan, st, stats);
+            launch_finish(K_msm_finish{g->tab.p, g->tc, partial.p, blind.p + 2 * (size_t)B, nullptr, AOS.p + 2 * (size_t)B * 32, B, plan.nchunks, 1}, B, st);
+        }
     }
     pt.mark(st);
 

@@ -270,11 +270,11 @@ __device__ inline ge msm_finish_wave(const K_msm_finish& f, uint32_t b, uint32_t
     for (int sft = 32; sft > 0; sft >>= 1) acc = ge_add_ge(acc, ge_shfl_xor(acc, sft));
     return acc;
 }
-__global__ void __launch_bounds__(64) k_finish_wave(K_msm_finish fa, K_msm_finish fb, uint32_t B, uint32_t n_inst) {
+__global__ void __launch_bounds__(64) k_finish_wave(K_msm_finish fa, K_msm_finish fb, K_msm_finish fc, uint32_t B) {
     const uint32_t g = blockIdx.x, inst = g / B, b = g % B;
-    (void)n_inst;
-    const ge acc = inst ? msm_finish_wave(fb, b, threadIdx.x) : msm_finish_wave(fa, b, threadIdx.x);
-    if (threadIdx.x == 0) ge_compress(acc, (inst ? fb.out : fa.out) + 32 * (size_t)b);
+    const K_msm_finish& f = inst == 0 ? fa : inst == 1 ? fb : fc;
+    const ge acc = msm_finish_wave(f, b, threadIdx.x);
+    if (threadIdx.x == 0) ge_compress(acc, f.out + 32 * (size_t)b);
 }
 
 // The verifier's own points (A_I1 .. S1, V_j, T_i, L_k, R_k: 138 for a depth-32 tree proof) of a handful of proofs by Straus: a
