@@ -217,11 +217,12 @@ HD inline ge_niels ge_to_niels(const ge& p) {
 }
 
 // RFC 9496 §4.3.2 Encode  (== RistrettoPoint::compress)
-HD inline void ge_compress(const ge& p, uint8_t out[32]) {
+template <class POW>
+HD inline void ge_compress_t(const ge& p, uint8_t out[32], POW pow) {
     fe u1 = fe_mul(fe_add(p.Z, p.Y), fe_sub(p.Z, p.Y));
     fe u2 = fe_mul(p.X, p.Y);
     fe invsqrt;
-    fe_sqrt_ratio_m1(fe_one(), fe_mul(u1, fe_sq(u2)), invsqrt);
+    fe_sqrt_ratio_m1_t(fe_one(), fe_mul(u1, fe_sq(u2)), invsqrt, pow);
     fe den1 = fe_mul(invsqrt, u1), den2 = fe_mul(invsqrt, u2);
     fe z_inv = fe_mul(fe_mul(den1, den2), p.T);
     fe i = fe_const(FE_SQRT_M1_L);
@@ -235,6 +236,7 @@ HD inline void ge_compress(const ge& p, uint8_t out[32]) {
     fe s = fe_abs(fe_mul(den_inv, fe_sub(p.Z, y)));
     fe_tobytes(s, out);
 }
+HD inline void ge_compress(const ge& p, uint8_t out[32]) { ge_compress_t(p, out, fe_pow_lane{}); }
 
 // RFC 9496 §4.3.1 Decode (== CompressedRistretto::decompress); returns 0 on failure
 HD inline int ge_decompress(const uint8_t in[32], ge& out) {

@@ -335,7 +335,7 @@ struct K_transcript_A {
         tr[b] = s;
         chal[0 * (size_t)B + b] = y;
         chal[1 * (size_t)B + b] = z;
-        chal[2 * (size_t)B + b] = sc_invert(y);
+        chal[2 * (size_t)B + b] = sc_invert_var(y);   // (a challenge: public)
     }
 };
 #define CH_Y 0
@@ -1181,7 +1181,7 @@ struct K_transcript_LR {  // append L,R -> u_k, u_k^-1
         sc u = merlin_challenge_scalar(s, "u", 1);
         tr[b] = s;
         uk[b] = u;
-        uk[(size_t)B + b] = sc_invert(u);
+        uk[(size_t)B + b] = sc_invert_var(u);   // (a challenge: public - the variable-time division steps)
     }
 };
 struct K_ipa_fold_ab {  // gid = j*B + b, j<m
@@ -1580,7 +1580,7 @@ struct K_verify_transcript {  // gid = b
                 uk[((size_t)k * 2 + 1) * B + b] = acc;
                 acc = sc_mul(acc, uk[((size_t)k * 2 + 0) * B + b]);
             }
-            sc inv = sc_invert(acc);
+            sc inv = sc_invert_var(acc);   // (a product of challenges: public)
             for (uint32_t k = lgN; k-- > 0;) {
                 const sc before = uk[((size_t)k * 2 + 1) * B + b];
                 uk[((size_t)k * 2 + 1) * B + b] = sc_mul(inv, before);

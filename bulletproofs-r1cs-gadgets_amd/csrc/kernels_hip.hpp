@@ -4,6 +4,21 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "kernels.hpp"
+#include "fe_wide.hpp"
+
+// RistrettoPoint::compress of lane 0's point by the whole wavefront (one wavefront per workgroup): the chain of 252 squarings runs
+// with a limb per lane (fe_wide.hpp), the rest as ge_compress.  Every lane must call it; `out` is written by lane 0.
+struct fe_pow_wave {
+    __device__ fe operator()(const fe& z) const { return fe_pow22523_wave(z); }
+};
+__device__ inline void ge_compress_wave(const ge& p, uint8_t* out) {
+    uint8_t enc[32];
+    ge_compress_t(p, enc, fe_pow_wave{});   // (lanes other than 0 mix their own coordinates with lane 0's power: their bytes are not used)
+    if ((threadIdx.x & 63u) == 0) {
+#pragma unroll
+        for (int i = 0; i < 32; i++) out[i] = enc[i];
+    }
+}
 
 // ---------------------------------------------------------------- witness synthesis
 // T lanes of a wavefront cooperate on ONE proof: the terms of each linear combination are
@@ -150,7 +165,7 @@ __global__ void __launch_bounds__(64) k_commit_wave(const uint8_t* tab, TabCfg t
     acc = ge_from_table_class(acc);
 #pragma unroll 1
     for (int sft = 32; sft > 0; sft >>= 1) acc = ge_add_ge(acc, ge_shfl_xor(acc, sft));   // every lane ends with the sum of all 64
-    if (lane == 0) ge_compress(acc, out + ((size_t)b * m + j) * 32);
+    ge_compress_wave(acc, out + ((size_t)b * m + j) * 32);
 }
 
 // K_sum_partials for a job of a few proofs: a wavefront per output.  One thread adding up to 256 chunk sums one after the other is
@@ -194,7 +209,7 @@ __global__ void __launch_bounds__(64) k_commit_T_wave(K_commit_T f) {
     acc = ge_from_table_class(acc);
 #pragma unroll 1
     for (int sft = 32; sft > 0; sft >>= 1) acc = ge_add_ge(acc, ge_shfl_xor(acc, sft));
-    if (lane == 0) ge_compress(acc, f.out + 32 * (size_t)g);
+    ge_compress_wave(acc, f.out + 32 * (size_t)g);
 }
 
 // K_pow_tables for a job of a few proofs: a wavefront per (y | y^-1 | z, proof).  The functor's thread multiplies its way through
@@ -274,7 +289,7 @@ __global__ void __launch_bounds__(64) k_finish_wave(K_msm_finish fa, K_msm_finis
     const uint32_t g = blockIdx.x, inst = g / B, b = g % B;
     const K_msm_finish& f = inst == 0 ? fa : inst == 1 ? fb : fc;
     const ge acc = msm_finish_wave(f, b, threadIdx.x);
-    if (threadIdx.x == 0) ge_compress(acc, f.out + 32 * (size_t)b);
+    ge_compress_wave(acc, f.out + 32 * (size_t)b);
 }
 
 // The verifier's own points (A_I1 .. S1, V_j, T_i, L_k, R_k: 138 for a depth-32 tree proof) of a handful of proofs by Straus: a
@@ -329,11 +344,9 @@ __global__ void __launch_bounds__(64) k_verify_finish_wave(K_verify_finish f) {
     if (table_class) acc = ge_from_table_class(acc);
 #pragma unroll 1
     for (int sft = 32; sft > 0; sft >>= 1) acc = ge_add_ge(acc, ge_shfl_xor(acc, sft));
-    if (lane == 0) {
-        uint8_t enc[32];
-        ge_compress(acc, enc);
-        f.ok[b] = (!f.fail[b]) && bytes_are_zero32(enc);
-    }
+    uint8_t enc[32];
+    ge_compress_t(acc, enc, fe_pow_wave{});
+    if (lane == 0) f.ok[b] = (!f.fail[b]) && bytes_are_zero32(enc);
 }
 
 // K_msm_fixed_small with the first level of its reduction tree inside the wavefront: workgroup (request r, proof b, group w) sums the

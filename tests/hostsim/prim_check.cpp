@@ -72,6 +72,7 @@ void hs_merlin_script(const uint8_t* label, uint32_t ll, const uint8_t* msgs, ui
     sc_mont_tobytes(c, chal);
 }
 }
+extern "C" void hs_sc_inv_var(const uint8_t* a, uint8_t* o) { sc_mont_tobytes(sc_invert_var(sc_mont_from_bytes_mod_order(a)), o); }
 extern "C" void hs_sc_inv_fermat(const uint8_t* a, uint8_t* o) { sc_mont_tobytes(sc_invert_fermat(sc_mont_from_bytes_mod_order(a)), o); }
 extern "C" void hs_fe_sq(const uint8_t* a, uint8_t* o) { fe_tobytes(fe_sq(fe_frombytes(a)), o); }
 // limb-level entry points: the caller supplies raw (non-canonical, signed) 29-bit limbs so that the

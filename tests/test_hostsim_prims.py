@@ -34,6 +34,17 @@ def test_field_and_scalar_arithmetic(prim_lib):
         inv = pow(ia % L, L - 2, L)
         assert int.from_bytes(_call(prim_lib.hs_sc_inv, a)[0], "little") == inv          # safegcd divsteps
         assert int.from_bytes(_call(prim_lib.hs_sc_inv_fermat, a)[0], "little") == inv   # Fermat ladder
+        assert int.from_bytes(_call(prim_lib.hs_sc_inv_var, a)[0], "little") == inv      # variable-time divsteps (public values)
+
+
+def test_variable_time_inverse_on_many_values(prim_lib):
+    rnd = random.Random(77)
+    vals = [1 << k for k in range(0, 253, 7)] + [L - (1 << k) for k in range(0, 250, 11)] + [(1 << k) - 1 for k in range(1, 253, 9)]
+    vals += [rnd.getrandbits(rnd.choice((8, 31, 60, 61, 120, 200, 252))) for _ in range(1500)]
+    for x in vals:
+        x %= L
+        got = int.from_bytes(_call(prim_lib.hs_sc_inv_var, x.to_bytes(32, "little"))[0], "little")
+        assert got == (pow(x, L - 2, L) if x else 0), hex(x)
 
 
 def test_group_and_encoding(prim_lib):
