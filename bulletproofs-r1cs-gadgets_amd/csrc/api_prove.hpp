@@ -79,10 +79,7 @@ static double dbg_ms() {
 }
 #define DBG_JOB(...) do { if (dbg_jobs()) { fprintf(stderr, "bpr1cs[%9.2f ms] ", dbg_ms()); fprintf(stderr, __VA_ARGS__); fputc('\n', stderr); } } while (0)
 // secrets in host memory: a plain memset in front of a free is a dead store the compiler may drop
-static void host_wipe(void* p, size_t n) {
-    volatile uint8_t* v = (volatile uint8_t*)p;
-    for (size_t i = 0; i < n; i++) v[i] = 0;
-}
+static void host_wipe(void* p, size_t n) { explicit_bzero(p, n); }   // (a volatile byte loop here was 9 ms of a depth-253 proof: its 18 MB of draws)
 // wait for everything a job has enqueued and release what it holds (normal end and error paths)
 static void job_wait(bpr1cs_job* job) {
     if (!job) return;

@@ -337,8 +337,7 @@ struct CommitLedger {
     size_t asked = 0;
     ~CommitLedger() { wipe(); }
     void wipe() {
-        volatile uint8_t* v = scalars.data();
-        for (size_t i = 0; i < scalars.size(); i++) v[i] = 0;
+        explicit_bzero(scalars.data(), scalars.size());
     }
     size_t add(const Scalar& v, const Scalar& blinding) {
         scalars.resize(64 * (asked + 1));
@@ -452,16 +451,16 @@ public:
 // then ignores it and the library hashes the chain inside the call as it does for every caller that has none (csrc/host_chain.hpp).
 // Host hashing only; the object lives and dies with its Prover; nothing is shared, guessed about n, or kept between proofs.
 struct ChainAhead {
-    static constexpr size_t CHUNK = 4096;   // draws per block of the growing output (256 KB)
     bpr1cs_transcript* t = nullptr;         // the caller's transcript, cloned, after "dom-sep", the V's and "m"
     bpr1cs_transcript_rng* rng = nullptr;
     size_t m = 0;                           // commitments it was started with
-    std::vector<std::unique_ptr<uint8_t[]>> blocks;
-    std::mutex mu;                          // guards `blocks`
+    static constexpr size_t LIMIT = (size_t)1 << 21;   // draws a chain nobody stops runs to (the reference's largest circuit has 287 416)
+    // ONE region for the draws, as long as the longest chain (128 MB of address space: pages exist once they are written), so that
+    // prove() hands the library the chain's own memory - no copy of a depth-253 proof's 18 MB
+    std::unique_ptr<uint8_t[]> buf{new uint8_t[LIMIT * 64]};
     std::atomic<size_t> produced{0}, target{SIZE_MAX};
     std::atomic<bool> stop{false};
     std::thread th;
-    static constexpr size_t LIMIT = (size_t)1 << 21;   // draws a chain nobody stops runs to (128 MB; the reference's largest circuit has 287 416)
     void run() {
         while (!stop.load(std::memory_order_relaxed)) {
             const size_t have = produced.load(std::memory_order_relaxed), want = std::min(target.load(std::memory_order_acquire), LIMIT);
@@ -469,32 +468,21 @@ struct ChainAhead {
                 if (target.load() != SIZE_MAX || have >= LIMIT) return;   // the proof's length is known and reached
                 continue;
             }
-            if (have % CHUNK == 0) {
-                std::unique_ptr<uint8_t[]> b(new uint8_t[CHUNK * 64]);
-                std::lock_guard<std::mutex> lk(mu);
-                blocks.push_back(std::move(b));
-            }
-            uint8_t* blk;
-            { std::lock_guard<std::mutex> lk(mu); blk = blocks.back().get(); }
-            const size_t in_blk = have % CHUNK, n = std::min<size_t>({CHUNK - in_blk, want - have, (size_t)256});
-            bpr1cs_transcript_rng_fill_bytes(rng, blk + 64 * in_blk, 64, n);
+            const size_t n = std::min<size_t>(want - have, 256);
+            bpr1cs_transcript_rng_fill_bytes(rng, buf.get() + 64 * have, 64, n);
             produced.store(have + n, std::memory_order_release);
         }
     }
-    // -> the first `count` draws, contiguous (waits for the thread to get there)
-    std::vector<uint8_t> take(size_t count) {
+    // -> the first `count` draws, contiguous (waits for the thread to get there); null if the chain was stopped short of them
+    const uint8_t* take(size_t count) {
         target.store(count, std::memory_order_release);
         if (th.joinable()) th.join();
-        std::vector<uint8_t> out(64 * count);
-        const size_t have = std::min(produced.load(), count);
-        for (size_t k = 0; k * CHUNK < have; k++) memcpy(&out[64 * k * CHUNK], blocks[k].get(), 64 * std::min(CHUNK, have - k * CHUNK));
-        if (have < count) out.clear();   // (stopped early: LIMIT)
-        return out;
+        return produced.load() >= count ? buf.get() : nullptr;
     }
     ~ChainAhead() {
         stop.store(true);
         if (th.joinable()) th.join();
-        for (auto& b : blocks) { volatile uint8_t* v = b.get(); for (size_t i = 0; i < CHUNK * 64; i++) v[i] = 0; }   // blinding material
+        explicit_bzero(buf.get(), 64 * std::min(produced.load(), LIMIT));   // blinding material
         bpr1cs_transcript_rng_free(rng);
         bpr1cs_transcript_free(t);
     }
@@ -609,7 +597,7 @@ public:
             std::vector<uint8_t> bl(32 * c->m + 1);
             for (size_t i = 0; i < c->m; i++) v_blinding_[i].write_bytes(&bl[32 * i]);
             c->rng = bpr1cs_transcript_build_rng(c->t, (const uint8_t*)"v_blinding", 10, bl.data(), 32, c->m, rng_seed->data());
-            { volatile uint8_t* v = bl.data(); for (size_t i = 0; i < bl.size(); i++) v[i] = 0; }
+            explicit_bzero(bl.data(), bl.size());
             if (!c->rng) return;
             ChainAhead* raw = c.get();
             c->th = std::thread([raw]() { raw->run(); });

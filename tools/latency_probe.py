@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Latency of the reference's own call shape - ONE proof per prove() (src/gadget_vsmt_4.rs:421-435, gadget_bound_check.rs:49-87) -
-and of small host-wire batches, with the seconds per stage.  python tools/latency_probe.py [--cases c1,c4] [--batches 1,8,64]"""
+and of small host-wire batches, with the seconds per stage.  python tools/latency_probe.py [--cases c1,c4,d128,d253] [--batches 1,8,64]"""
 import argparse
 import importlib
 import json
@@ -27,8 +27,13 @@ def main():
     opts = {k: int(v) for k, v in (kv.split("=") for kv in args.opt)}
     out = {}
     for case in args.cases.split(","):
+        nb = max(int(x) for x in args.batches.split(","))
         if case == "c1":
             w, cap = wl.bound_check64(64), 128
+        elif case == "d128":   # the reference's literal tests (src/gadget_vsmt_4.rs:25, gadget_vsmt_2.rs:23)
+            w, cap = wl.vsmt4(bp, None, 128, nb, nb, 11), 131072
+        elif case == "d253":
+            w, cap = wl.vsmt2(bp, None, 253, nb, b"l253", (1 << 250) - 1, 2 * 10**6), 262144
         else:
             w, cap = wl.vsmt4(bp, None, 32, 64, 64, 0), 32768
         t0 = time.time()
