@@ -27,6 +27,8 @@
  *                      sbox: 1 or absent = SboxType::Inverse as the reference hard-wires it (gadget_vsmt_4.rs:301, gadget_vsmt_2.rs:203), 0 = Cube
  * The statics (0 / 101 / 0...) are committed with blinding 0 (reference gadget_poseidon.rs:554-578).
  * `poseidon_blob` = bulletproofs-r1cs-gadgets_amd/data/poseidon_params_ristretto.bin (may be NULL for non-Poseidon gadgets).
+ * Environment (diagnostics only): BPR1CS_DEBUG_FRONT - Prover::prove prints the milliseconds of its stages (circuit export, witness
+ * export, wait for the chain beside the synthesis, device call) to stderr.
  */
 #ifndef BPR1CS_GADGETS_H
 #define BPR1CS_GADGETS_H
