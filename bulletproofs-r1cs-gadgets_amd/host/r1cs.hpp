@@ -108,23 +108,79 @@ struct Variable {
     bool operator==(const Variable& o) const { return kind == o.kind && index == o.index; }
 };
 
+// The terms of a linear combination: a vector with room for two terms inside the object.  Most combinations a gadget builds have one
+// or two (a variable; x - y; a wire minus a constant): with std::vector every one of them was a heap block - 1.16 million allocations,
+// 180 MB, in the synthesis of one depth-253 Merkle-path proof, two fifths of its time.
+using Term = std::pair<Variable, Scalar>;
+class TermVec {
+    static constexpr uint32_t INL = 2;
+    Term* p_;
+    uint32_t n_ = 0, cap_ = INL;
+    alignas(Term) unsigned char inl_[INL * sizeof(Term)];
+    Term* inl() { return reinterpret_cast<Term*>(inl_); }
+    bool on_heap() const { return cap_ > INL; }
+    void grow(size_t want) {
+        size_t cap = cap_;
+        while (cap < want) cap *= 2;
+        Term* q = static_cast<Term*>(::operator new(cap * sizeof(Term)));
+        for (uint32_t i = 0; i < n_; i++) new (q + i) Term(p_[i]);
+        if (on_heap()) ::operator delete(p_);
+        p_ = q; cap_ = (uint32_t)cap;
+    }
+  public:
+    TermVec() : p_(inl()) {}
+    TermVec(const TermVec& o) : p_(inl()) { append(o.begin(), o.end()); }
+    TermVec(TermVec&& o) noexcept : p_(inl()) { steal(o); }
+    TermVec(const std::vector<Term>& v) : p_(inl()) { append(v.data(), v.data() + v.size()); }
+    ~TermVec() { if (on_heap()) ::operator delete(p_); }
+    TermVec& operator=(const TermVec& o) { if (this != &o) { n_ = 0; append(o.begin(), o.end()); } return *this; }
+    TermVec& operator=(TermVec&& o) noexcept {
+        if (this != &o) { if (on_heap()) ::operator delete(p_); p_ = inl(); n_ = 0; cap_ = INL; steal(o); }
+        return *this;
+    }
+    void steal(TermVec& o) {   // (*this is empty and inline)
+        if (o.on_heap()) { p_ = o.p_; n_ = o.n_; cap_ = o.cap_; o.p_ = o.inl(); o.n_ = 0; o.cap_ = INL; }
+        else { for (uint32_t i = 0; i < o.n_; i++) new (p_ + i) Term(o.p_[i]); n_ = o.n_; o.n_ = 0; }
+    }
+    size_t size() const { return n_; }
+    bool empty() const { return n_ == 0; }
+    Term* begin() { return p_; }
+    Term* end() { return p_ + n_; }
+    const Term* begin() const { return p_; }
+    const Term* end() const { return p_ + n_; }
+    Term& operator[](size_t i) { return p_[i]; }
+    const Term& operator[](size_t i) const { return p_[i]; }
+    Term& back() { return p_[n_ - 1]; }
+    void reserve(size_t want) { if (want > cap_) grow(want); }
+    void push_back(const Term& t) {
+        if (n_ == cap_) { const Term keep = t; grow((size_t)n_ + 1); new (p_ + n_++) Term(keep); return; }   // (t may live in this vector)
+        new (p_ + n_++) Term(t);
+    }
+    void append(const Term* first, const Term* last) {   // [first, last) outside this vector
+        reserve((size_t)n_ + (size_t)(last - first));
+        for (; first != last; ++first) new (p_ + n_++) Term(*first);
+    }
+    void clear() { n_ = 0; }
+};
+
 struct LinearCombination {
-    std::vector<std::pair<Variable, Scalar>> terms;
+    TermVec terms;
     LinearCombination() {}
     LinearCombination(const Variable& v) { terms.push_back({v, Scalar::one()}); }             // From<Variable>
     LinearCombination(const Scalar& s) { terms.push_back({Variable::One(), s}); }             // From<Scalar>
     LinearCombination(uint64_t s) { terms.push_back({Variable::One(), Scalar(s)}); }          // From<u64>
-    LinearCombination(std::vector<std::pair<Variable, Scalar>> t) : terms(std::move(t)) {}    // FromIterator
-    const std::vector<std::pair<Variable, Scalar>>& get_terms() const { return terms; }       // fork API
+    LinearCombination(const std::vector<Term>& t) : terms(t) {}                               // FromIterator
+    const TermVec& get_terms() const { return terms; }                                        // fork API (iterable, indexable)
     LinearCombination operator+(const LinearCombination& o) const& {
         LinearCombination r;
         r.terms.reserve(terms.size() + o.terms.size());
-        r.terms.insert(r.terms.end(), terms.begin(), terms.end());
-        r.terms.insert(r.terms.end(), o.terms.begin(), o.terms.end());
+        r.terms.append(terms.begin(), terms.end());
+        r.terms.append(o.terms.begin(), o.terms.end());
         return r;
     }
     LinearCombination operator+(const LinearCombination& o) && {   // (a temporary on the left keeps its storage)
-        terms.insert(terms.end(), o.terms.begin(), o.terms.end());
+        if (&o == this) { const LinearCombination c(o); terms.append(c.terms.begin(), c.terms.end()); }
+        else terms.append(o.terms.begin(), o.terms.end());
         return std::move(*this);
     }
     // *this = *this + o * s without the two temporaries (the inner statement of apply_linear_layer, gadget_poseidon.rs:296)
@@ -132,13 +188,22 @@ struct LinearCombination {
         terms.reserve(terms.size() + o.terms.size());
         for (auto& t : o.terms) terms.push_back({t.first, t.second * s});
     }
-    LinearCombination operator-(const LinearCombination& o) const {
-        LinearCombination r(terms);
+    LinearCombination operator-(const LinearCombination& o) const& {
+        LinearCombination r;
+        r.terms.reserve(terms.size() + o.terms.size());
+        r.terms.append(terms.begin(), terms.end());
         for (auto& t : o.terms) r.terms.push_back({t.first, -t.second});
         return r;
     }
+    LinearCombination operator-(const LinearCombination& o) && {
+        if (&o == this) return LinearCombination(static_cast<const LinearCombination&>(*this) - o);
+        terms.reserve(terms.size() + o.terms.size());
+        for (auto& t : o.terms) terms.push_back({t.first, -t.second});
+        return std::move(*this);
+    }
     LinearCombination operator-() const {
         LinearCombination r;
+        r.terms.reserve(terms.size());
         for (auto& t : terms) r.terms.push_back({t.first, -t.second});
         return r;
     }
@@ -412,10 +477,34 @@ struct R1CSProof {
     size_t ipp_rounds() const { return f.lg_n; }
 };
 
+// A list that grows by blocks and never moves what it holds (push_back, size, iteration - all a constraint list needs): the 335 000
+// constraints of a depth-253 Merkle-path proof were moved twice over by a growing std::vector, an eighth of the synthesis.
+template <class T, size_t BLOCK = 1024>
+class BlockList {
+    std::vector<std::unique_ptr<T[]>> blocks_;
+    size_t n_ = 0;
+  public:
+    void push_back(T&& v) {
+        if (n_ % BLOCK == 0) blocks_.emplace_back(new T[BLOCK]);
+        blocks_[n_ / BLOCK][n_ % BLOCK] = std::move(v);
+        n_++;
+    }
+    size_t size() const { return n_; }
+    const T& operator[](size_t i) const { return blocks_[i / BLOCK][i % BLOCK]; }
+    struct const_iterator {
+        const BlockList* l; size_t i;
+        const T& operator*() const { return (*l)[i]; }
+        const_iterator& operator++() { ++i; return *this; }
+        bool operator!=(const const_iterator& o) const { return i != o.i; }
+    };
+    const_iterator begin() const { return {this, 0}; }
+    const_iterator end() const { return {this, n_}; }
+};
+
 // shared bookkeeping of the three constraint systems
 class CSBase : public ConstraintSystem {
 public:
-    std::vector<LinearCombination> constraints;
+    BlockList<LinearCombination> constraints;
     size_t num_vars = 0;
     std::optional<size_t> pending_multiplier;
     void constrain(LinearCombination lc) override { constraints.push_back(std::move(lc)); }
