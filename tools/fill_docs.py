@@ -48,6 +48,9 @@ def row(prefix, r):
     V[prefix + "COM"] = f2(s["commit"]); V[prefix + "GAD"] = f1(s["gadget"]) if s["gadget"] >= 1 else f2(s["gadget"])
     V[prefix + "CIR"] = f2(s["circuit"]); V[prefix + "PRV"] = f1(s["prove"]) if s["prove"] >= 10 else f2(s["prove"])
     V[prefix + "FIRST"] = f1(b["first_call_ms"])
+    ph = b["device_phase_ms"]
+    V[prefix + "IPA"] = f1(ph["ipa"]) if ph["ipa"] >= 3 else f2(ph["ipa"]); V[prefix + "DEV"] = f1(ph["total"]) if ph["total"] >= 3 else f2(ph["total"])
+    V[prefix + "MID"] = f1(ph["commit_msm"] + ph["poly"]); V[prefix + "FRONT"] = f1(ph["inputs+commitV"] + ph["rng||witness"])
     v = r["verify_b1"]; vs = v["stage_ms"]
     return b, v, vs
 
@@ -57,6 +60,10 @@ V["C4B1"] = f1(b["ms_per_call"]); V["VC4"] = f1(v["ms_per_call"]); V["VC4G"] = f
 e = c4["b1_eager_commits"]
 V["C4B1E"] = f1(e["ms_per_call"]); V["C4ECOM"] = f1(e["stage_ms"]["commit"]); V["US_COMMIT"] = "%.0f" % e["us_per_commit"]
 V["C4CPU"] = "%.0f" % c4["cpu_port_ms_per_proof"]
+V["C1B1E"] = f2(c1["b1_eager_commits"]["ms_per_call"])
+ul = open(P("ubench_latency.txt")).read()
+m = re.search(r"ge_compress\s+([\d.]+) ns per op\s+([\d.]+) clock64", ul)
+V["COMPRESS_US"] = "%.0f" % (float(m.group(2)) / 2390.0) if m else "n/a"
 for B in (8, 64):
     r = c4["b%d" % B]; s = r["stage_ms"]
     V["C4B%d" % B] = f1(r["ms_per_call"]); V["C4B%dPP" % B] = f2(r["ms_per_proof"]); V["C4B%dGAD" % B] = f1(s["gadget"])
