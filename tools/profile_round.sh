@@ -44,3 +44,5 @@ timeout 900 python tools/c_caller_standalone.py 8192 20480 > $out/c_caller_stand
 g++ -O3 -std=c++17 -DBPR1CS_HOST_ONLY -Ibulletproofs-r1cs-gadgets_amd/csrc tools/host_chain_bench.cpp -o /tmp/hcb -pthread 2>/dev/null && /tmp/hcb > $out/host_chain_rate.txt 2>&1
 timeout 600 python tools/latency_probe.py --cases c1,c4 --batches 1,8,64 --reps 3 --no-device-program > $out/latency_probe.txt 2>&1
 if [ "$2" = tests ]; then timeout 1700 python -m pytest tests -m gpu -x -q > $out/gputests.txt 2>&1; tail -3 $out/gputests.txt; fi
+# the driver's smoke call
+( echo "# python -c 'import __graft_entry__ as g; g.smoke()' ($tag)"; timeout 600 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -3 ) > $out/smoke.txt
