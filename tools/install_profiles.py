@@ -25,6 +25,7 @@ hdr["ubench_latency.txt"] = "# tools/ubench_latency on MI355X (%s): ONE wavefron
 hdr["host_chain_rate.txt"] = "# tools/host_chain_bench.cpp on the GPU box's host CPU (%s): the TranscriptRng chain of a depth-32 proof (csrc/host_chain.hpp) on 1 .. 64 threads at once\n" % tag
 hdr["latency_probe.txt"] = "# python tools/latency_probe.py --cases c1,c4 --batches 1,8,64 --reps 3 --no-device-program (%s, commit %s): bpr1cs_gadget_prove_on / _verify_on, wall ms and stage ms per call\n" % (tag, commit)
 hdr["gputests.txt"] = "# python -m pytest tests -m gpu -x -q (%s, commit %s)\n" % (tag, commit)
+hdr["smoke.txt"] = ""   # (the file carries its own header)
 names = {"ubench.txt": "ubench_gfx950.txt"}
 for f, h in hdr.items():
     p = os.path.join(src, f)
