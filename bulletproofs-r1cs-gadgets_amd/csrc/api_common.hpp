@@ -77,10 +77,14 @@ static bool opt_apply(BpOpts& o, int option, int value, bool creating) {
 // proofs in flight it is pure latency (measured on MI355X, depth-32 tree circuit, ONE proof: 4.5 ms per variable-base round against
 // 0.3 ms per table round).  Small jobs therefore take EVERY round from the tables; large jobs switch after 4.
 static const uint32_t SMALL_JOB_PROOFS = 64;
+// (where "small" ends for THIS choice, measured on the depth-32 tree circuit, argument of one call in ms, all rounds from the tables /
+// 4 rounds: 8 proofs 12.2 / 19.3, 16: 20.8 / 22.1, 24: 26.7 / 23.9, 32: 32.9 / 26.5, 48: 45.9 / 31.2, 64: 60.9 / 36.1 - a table round
+// costs per proof, a variable-base round per wavefront of 64 proofs)
+static const uint32_t UNFOLD_ALL_MAX_PROOFS = 16;
 static uint32_t eff_unfold(const BpOpts& o, uint32_t B, uint32_t lgN) {
     const int u = o.unfold.load();
     if (u >= 0) return std::min<uint32_t>((uint32_t)u, lgN);
-    return B <= SMALL_JOB_PROOFS ? lgN : std::min<uint32_t>(4u, lgN);
+    return B <= UNFOLD_ALL_MAX_PROOFS ? lgN : std::min<uint32_t>(4u, lgN);
 }
 // statistics of the last prove call that RETURNED ON THIS THREAD (bpr1cs_last_prove_stats)
 inline bpr1cs_prove_stats& tl_last_stats() {
