@@ -514,7 +514,17 @@ static int prove_job_begin(const bpr1cs_gens* g, const bpr1cs_circuit* c, const 
     launch((uint64_t)TC * B, K_tcoef_partial{W.p, wvec.p, plo.p, phi.p, tpart.p, B, H, n, tchunk, TC}, st);
     launch_sum_partials((uint64_t)6 * B, K_sum_partials{tpart.p, tco.p, B, TC}, st);
     launch_commit_T(K_commit_T{g->tab.p, g->tc, tco.p, blind.p, Tc.p, B}, B, st);
-    launch_transcript(B, K_transcript_T{tr.p, Tc.p, tco.p, blind.p, wvec.p + (size_t)3 * n * B, vbl_m.p, chal.p, txs.p, B, m, (uint64_t)N}, st);
+    K_transcript_T ktt{tr.p, Tc.p, tco.p, blind.p, wvec.p + (size_t)3 * n * B, vbl_m.p, chal.p, txs.p, B, m, (uint64_t)N};
+    DevBuf<sc> t2b_pre;
+#if !defined(BPR1CS_HOSTSIM)
+    if (B <= FINISH_WAVE_MAX_PROOFS && m > 1) {
+        t2b_pre.alloc(B);
+        hipLaunchKernelGGL(k_dot_wave, dim3(B), dim3(64), 0, st, ktt.wV, ktt.vbl_m, t2b_pre.p, B, m);
+        HIPCHK(hipGetLastError());
+        ktt.t2b_pre = t2b_pre.p;
+    }
+#endif
+    launch_transcript(B, ktt, st);
     DevBuf<sc> a((size_t)N * B), bb((size_t)N * B);
     launch((uint64_t)N * B, K_lr_eval{W.p, wvec.p, plo.p, phi.p, chal.p, a.p, bb.p, cG.p, cH.p, B, H, n}, st);
     // the wires and blinding vectors are dead: wiped here (upstream: clear_on_drop), and the next job in flight may write its own

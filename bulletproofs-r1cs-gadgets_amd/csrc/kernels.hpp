@@ -953,6 +953,7 @@ struct K_transcript_T {
     sc* txs;             // [3][B] t_x, t_x_blinding, e_blinding (Montgomery)
     uint32_t B, m;
     uint64_t padded_n;
+    const sc* t2b_pre = nullptr;   // [B] <wV, v_blinding>, when a kernel of its own has summed it (k_dot_wave: jobs of a few proofs)
     HD void operator()(uint32_t b) const {
         strobe s = tr[b];
         merlin_append(s, "T_1", 3, Tc + ((size_t)0 * B + b) * 32, 32);
@@ -963,7 +964,8 @@ struct K_transcript_T {
         sc u = merlin_challenge_scalar(s, "u", 1);
         sc x = merlin_challenge_scalar(s, "x", 1);
         sc t2b = sc_zero();
-        for (uint32_t j = 0; j < m; j++) t2b = sc_add(t2b, sc_mul(wV[(size_t)j * B + b], vbl_m[(size_t)j * B + b]));
+        if (t2b_pre) t2b = t2b_pre[b];
+        else for (uint32_t j = 0; j < m; j++) t2b = sc_add(t2b, sc_mul(wV[(size_t)j * B + b], vbl_m[(size_t)j * B + b]));
         sc t[6], tb[6];
         for (int k = 0; k < 6; k++) t[k] = tco[(size_t)k * B + b];
         tb[0] = blind[(size_t)3 * B + b]; tb[1] = t2b;
