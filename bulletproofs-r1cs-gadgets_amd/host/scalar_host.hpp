@@ -30,7 +30,9 @@ inline sc mul(const sc& a, const sc& b) {
         c += t[4]; t[4] = (uint64_t)c; t[5] = (uint64_t)(c >> 64);
         const uint64_t m = t[0] * LINV;
         c = ((u128)m * L64[0] + t[0]) >> 64;
-        for (int j = 1; j < 4; j++) { c += (u128)m * L64[j] + t[j]; t[j - 1] = (uint64_t)c; c >>= 64; }
+        c += (u128)m * L64[1] + t[1]; t[0] = (uint64_t)c; c >>= 64;
+        c += t[2]; t[1] = (uint64_t)c; c >>= 64;                                   // (limb 2 of l is zero,
+        c += ((u128)m << 60) + t[3]; t[2] = (uint64_t)c; c >>= 64;                 //  limb 3 is 2^60: a shift)
         c += t[4]; t[3] = (uint64_t)c; t[4] = t[5] + (uint64_t)(c >> 64);
     }
     // t < 2l (a, b < l): one conditional subtraction
