@@ -77,14 +77,16 @@ static bool opt_apply(BpOpts& o, int option, int value, bool creating) {
 // proofs in flight it is pure latency (measured on MI355X, depth-32 tree circuit, ONE proof: 4.5 ms per variable-base round against
 // 0.3 ms per table round).  Small jobs therefore take EVERY round from the tables; large jobs switch after 4.
 static const uint32_t SMALL_JOB_PROOFS = 64;
-// (where "small" ends for THIS choice, measured on the depth-32 tree circuit, argument of one call in ms, all rounds from the tables /
-// 4 rounds: 8 proofs 12.2 / 19.3, 16: 20.8 / 22.1, 24: 26.7 / 23.9, 32: 32.9 / 26.5, 48: 45.9 / 31.2, 64: 60.9 / 36.1 - a table round
-// costs per proof, a variable-base round per wavefront of 64 proofs)
-static const uint32_t UNFOLD_ALL_MAX_PROOFS = 16;
+// (where "small" ends for THIS choice: a table round costs N x B, a variable-base round is latency until a wavefront's 64 lanes have
+// proofs.  Measured, argument of one call in ms, all rounds from the tables / 4 rounds - depth-32 tree (N = 2^15): 8 proofs 12.2 / 19.3,
+// 16: 20.8 / 22.1, 24: 26.7 / 23.9, 32: 32.9 / 26.5, 64: 60.9 / 36.1; depth 128 (2^17): 2: 16.8 / 27.0, 4: 27.0 / 29.6, 8: 48.1 / 36.6;
+// depth 253 (2^18): 2: 31.8 / 36.2, 4: 57.3 / 44.1, 8: 108.8 / 58.1; a 64-bit bound check (2^6), 64 proofs, whole call: 4.3 / 7.6 - the crossover
+// sits at N x B = 0.6-0.7 million in the three trees)
+static const uint64_t UNFOLD_ALL_MAX_TERMS = 20u << 15;
 static uint32_t eff_unfold(const BpOpts& o, uint32_t B, uint32_t lgN) {
     const int u = o.unfold.load();
     if (u >= 0) return std::min<uint32_t>((uint32_t)u, lgN);
-    return B <= UNFOLD_ALL_MAX_PROOFS ? lgN : std::min<uint32_t>(4u, lgN);
+    return (B <= SMALL_JOB_PROOFS && ((uint64_t)B << lgN) <= UNFOLD_ALL_MAX_TERMS) ? lgN : std::min<uint32_t>(4u, lgN);
 }
 // statistics of the last prove call that RETURNED ON THIS THREAD (bpr1cs_last_prove_stats)
 inline bpr1cs_prove_stats& tl_last_stats() {

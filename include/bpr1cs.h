@@ -143,8 +143,8 @@ int bpr1cs_gens_table_info(const bpr1cs_gens* g, uint32_t* window_bits, uint32_t
  * value < 0 = back to that default.  No process-wide knobs exist: two threads on two handles never see each other's settings.
  * Results (proof bytes, verdicts) never depend on an option. */
 #define BPR1CS_OPT_UNFOLD_ROUNDS 0    /* IPA rounds computed from the UN-folded generator tables before the folded generators are
-                                         materialised (default: 4 for jobs of more than 16 proofs - measured 2 / 3 / 4 / 5 = 2420 / 2748 / 2880 / 2678 proofs/s -,
-                                         every round for smaller ones, where a variable-base round is pure latency; clamped to lg N) */
+                                         materialised (default: 4 - measured 2 / 3 / 4 / 5 = 2420 / 2748 / 2880 / 2678 proofs/s -, every round for a job of
+                                         at most 64 proofs with N x proofs <= 655 360, where a variable-base round is pure latency; clamped to lg N) */
 #define BPR1CS_OPT_WITNESS_TEAM 2     /* lanes of a wavefront cooperating on one proof during witness synthesis: 4, 8 (default) or 16
                                          (measured 4 / 8 / 16 = 2941 / 2970 / 2939 proofs/s on one box) */
 #define BPR1CS_OPT_TAIL_ROUNDS 3      /* how many of the LAST inner-product rounds (latency bound) a job enqueues on its own tail stream
