@@ -2,6 +2,7 @@
 #pragma once
 #include "msm_run.hpp"
 // ---------------------------------------------------------------- verifier
+static const uint32_t VERIFY_HOST_TRANSCRIPT_MAX_PROOFS = 8;
 struct VerifyCtx {  // device state shared by the per-proof and the cross-proof verifier
     uint32_t B, n, m, N, lgN, H, P;
     size_t plen;
@@ -33,6 +34,26 @@ static void verify_front(VerifyCtx& v, const bpr1cs_gens* g, const bpr1cs_circui
     dev_zero(v.fail.p, sizeof(int) * B, st);
     K_verify_transcript kt{v.d_label.p, (uint32_t)label_len, v.d_pf.p, v.d_vc.p, v.d_seed.p, v.chal.p, v.uk.p, v.fail.p, B, m, lgN, (uint32_t)v.plen, (uint64_t)N};
     if (want_bind) { v.bind.alloc((size_t)B * 32); kt.bind = v.bind.p; }
+#if !defined(BPR1CS_HOSTSIM)
+    // A handful of proofs: the transcript replay - every byte it hashes is public and in the caller's memory - runs on the calling
+    // thread (the same functor, host STROBE: ~150 appends and 20 challenges of a depth-32 proof in ~50 us) and its challenges go up;
+    // on the device it is one lane per proof walking the appends a state word at a time: 1.2 of a depth-32 verification's 3.3 ms.
+    // (BPR1CS_OPT_HOST_CHAIN_PROOFS = 0 keeps every transcript on the device, as for the prover.)
+    if (B <= VERIFY_HOST_TRANSCRIPT_MAX_PROOFS && g->opts.host_chain.load() != 0) {
+        std::vector<sc> h_chal((size_t)VCH_COUNT * B), h_uk((size_t)(lgN ? lgN : 1) * 2 * B);
+        std::vector<int> h_fail(B, 0);
+        std::vector<uint8_t> h_bind(want_bind ? (size_t)B * 32 : 0), zero_seeds;
+        const uint8_t* seeds = verifier_rng_seeds;
+        if (!seeds) { zero_seeds.assign((size_t)B * 32, 0); seeds = zero_seeds.data(); }
+        K_verify_transcript kh{label, (uint32_t)label_len, proofs, commitments, seeds, h_chal.data(), h_uk.data(), h_fail.data(), B, m, lgN, (uint32_t)v.plen, (uint64_t)N};
+        if (want_bind) kh.bind = h_bind.data();
+        for (uint32_t b = 0; b < B; b++) kh(b);
+        dev_h2d(v.chal.p, h_chal.data(), h_chal.size() * sizeof(sc), st);
+        dev_h2d(v.uk.p, h_uk.data(), h_uk.size() * sizeof(sc), st);
+        dev_h2d(v.fail.p, h_fail.data(), sizeof(int) * B, st);
+        if (want_bind) dev_h2d(v.bind.p, h_bind.data(), h_bind.size(), st);
+    } else
+#endif
     launch_transcript(B, kt, st);
     uint32_t maxe = std::max<uint32_t>(N, c->q + 1);
     v.H = (maxe >> 8) + 1;

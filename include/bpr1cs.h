@@ -166,7 +166,10 @@ int bpr1cs_gens_table_info(const bpr1cs_gens* g, uint32_t* window_bits, uint32_t
                                          per thread, while the device takes the wires and computes A_I / A_O; the raw 64-byte draws are
                                          uploaded and reduced mod l on the device.  Default (-1): 4 proofs per CPU the process may use
                                          (affinity mask, cgroup quota); 0: never (the device chain, what a large batch hides behind the job
-                                         before it).  Hashing only - no group or field arithmetic ever runs on the host */
+                                         before it).  The verifier likewise replays the transcripts of up to 8 proofs on the calling
+                                         thread (public bytes only; 0 keeps them on the device).  Hashing, and for the verifier the
+                                         reduction and inversion of its public challenges, only - no group arithmetic, and no arithmetic
+                                         on a secret, ever runs on the host */
 #define BPR1CS_OPT_WINDOW_BITS 16     /* creation only: signed window width W (4..15) of the fixed-base tables.  A term costs
                                          ceil(253/W) mixed additions; table bytes = (2+2*cap) * ceil(253/W) * (2^(W-1)+1) * 128
                                          (W=8: 35 GB, W=11: 198 GB at capacity 32768).  Default 0 = the widest W <= 15 whose tables fit in
